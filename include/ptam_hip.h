@@ -1,0 +1,272 @@
+/*
+ * ptam_hip.h — C ABI of libptam_hip.so: PTAM's tracking + bundle-adjustment hot path on
+ * MI355X (gfx950), hand-written HIP kernels behind plain-C entry points.
+ *
+ * The reference (cggos/ptam_cg) has no FFI/plugin layer: its boundary for this path is the C++
+ * class surface of KeyFrame / PatchFinder / Tracker / Bundle.  Each entry point below names the
+ * reference interface it replaces (file:line, relative to the reference tree).  A header-only C++
+ * shim that re-creates those class signatures over this ABI lives in ptam_shim.hpp.
+ *
+ * Conventions
+ *   - every function returns an int status: PTAM_OK (0) or a negative PTAM_E_* code; algorithmic
+ *     outcomes (found flags, accepted-iteration counts, the 32001 "out of border" ZMSSD sentinel,
+ *     the -1 "bad template/level" sentinel) travel in out-parameters with the reference's values.
+ *   - the caller keeps ownership of every host buffer; the library owns device memory behind
+ *     opaque handles.  Bundle copies all inputs at add_* time like the reference
+ *     (src/Bundle.cc:46-93).
+ *   - a ptam_ctx is bound to ONE calling thread (own HIP stream + scratch).  The reference is
+ *     entered from two threads (tracker: src/Tracker.cc:86, mapmaker: src/MapMaker.cc:57); give
+ *     each its own ctx.  There is no global mutable state and no cached camera state
+ *     (the reference's ATANCamera caches its last projection, include/ATANCamera.h:12-16).
+ *   - poses are camera-from-world SE3 as 12 doubles: R row-major (9) then t (3).
+ *   - images are 8-bit grey, row-major, `stride` bytes per row.
+ *   - there is NO CPU fallback: if no gfx950 device / kernel image is available the create call
+ *     fails with PTAM_E_HIP.
+ */
+#ifndef PTAM_HIP_H
+#define PTAM_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTAM_LEVELS 4                /* include/KeyFrame.h:34 */
+#define PTAM_PATCH 8                 /* PatchFinder default nPatchSize, include/PatchFinder.h:55 */
+#define PTAM_MAX_SSD (8 * 8 * 500)   /* src/PatchFinder.cc:18-19  -> 32000 */
+
+enum {
+    PTAM_OK = 0,
+    PTAM_E_ARG = -1,      /* bad argument */
+    PTAM_E_HIP = -2,      /* HIP runtime error (see ptam_last_error) */
+    PTAM_E_STATE = -3,    /* call out of order */
+    PTAM_E_LIMIT = -4,    /* size above a documented limit */
+    PTAM_E_COMM = -5      /* collective failed */
+};
+
+/* libCVD halfSample rounding variant.  R = SSE2 pavgb/pavgw double rounding
+ * (what an x86-64 libCVD build does for 16-byte aligned byte images), T = (a+b+c+d)/4 truncating. */
+enum { PTAM_HALFSAMPLE_R = 0, PTAM_HALFSAMPLE_T = 1 };
+
+/* cg::Tukey / Cauchy / Huber, include/Tools.h:128-228 */
+enum { PTAM_EST_TUKEY = 0, PTAM_EST_CAUCHY = 1, PTAM_EST_HUBER = 2 };
+
+typedef struct ptam_ctx ptam_ctx;
+typedef struct ptam_kf ptam_kf;
+typedef struct ptam_ba ptam_ba;
+
+typedef struct { int32_t x, y; } ptam_int2;   /* CVD::ImageRef */
+
+/* ATANCamera parameters: the 5-vector of config/camera.cfg:7 (normalised fx fy cx cy, w) and the
+ * image size of ATANCamera::SetImageSize (src/ATANCamera.cc:21-25). */
+typedef struct {
+    double fx, fy, cx, cy, w;
+    int32_t width, height;
+} ptam_cam_params;
+
+const char* ptam_last_error(void);           /* thread-local message of the last failure */
+int ptam_device_count(int* n);
+
+/* ---- context ------------------------------------------------------------------------------- */
+/* replaces: ATANCamera(..) + RefreshParams (src/ATANCamera.cc:11-66); one per calling thread. */
+int ptam_ctx_create(const ptam_cam_params* cam, int device, ptam_ctx** out);
+int ptam_ctx_destroy(ptam_ctx* ctx);
+int ptam_ctx_set_halfsample(ptam_ctx* ctx, int variant);
+int ptam_ctx_sync(ptam_ctx* ctx);
+void* ptam_ctx_stream(ptam_ctx* ctx);        /* the hipStream_t all of ctx's work is queued on */
+/* derived camera constants (mdLargestRadius, mdMaxR, md2Tan, focal, centre: src/ATANCamera.cc:33-66) */
+int ptam_ctx_camera_constants(ptam_ctx* ctx, double out[8]);
+
+/* device memory helpers for callers that keep inputs resident (bench, shards) */
+int ptam_dev_alloc(ptam_ctx* ctx, size_t bytes, void** dptr);
+int ptam_dev_free(ptam_ctx* ctx, void* dptr);
+int ptam_dev_upload(ptam_ctx* ctx, void* dptr, const void* host, size_t bytes);
+int ptam_dev_download(ptam_ctx* ctx, void* host, const void* dptr, size_t bytes);
+
+/* ---- KeyFrame::MakeKeyFrame_Lite  (src/KeyFrame.cc:18-54) ------------------------------------ */
+int ptam_kf_create(ptam_ctx* ctx, int width, int height, ptam_kf** out);
+int ptam_kf_destroy(ptam_kf* kf);
+/* host image -> pyramid + FAST-10 (thresholds 10,15,15,10) + row LUTs, all on device. */
+int ptam_make_keyframe_lite(ptam_ctx* ctx, ptam_kf* kf, const uint8_t* im, int stride);
+/* same, image already resident on the device (stride == width) */
+int ptam_make_keyframe_lite_dev(ptam_ctx* ctx, ptam_kf* kf, const uint8_t* d_im);
+/* Level::operator= deep copy (include/KeyFrame.h:66-75) for the tracker->mapmaker hand-off
+ * (src/MapMaker.cc:480-488), device to device. */
+int ptam_kf_clone(ptam_ctx* ctx, const ptam_kf* src, ptam_kf** out);
+int ptam_kf_level_info(ptam_ctx* ctx, const ptam_kf* kf, int level, int* w, int* h, int* n_corners);
+/* host read-back of aLevels[level].im / vCorners / vCornerRowLUT; NULL pointers are skipped.
+ * px: w*h bytes; corners: n_corners entries (raster order); rowlut: h ints. */
+int ptam_kf_read_level(ptam_ctx* ctx, const ptam_kf* kf, int level,
+                       uint8_t* px, ptam_int2* corners, int32_t* rowlut);
+
+/* ---- PatchFinder::FindPatchCoarse / ZMSSDAtPoint  (src/PatchFinder.cc:160-211, 326-329;
+ *      src/ImageProcess.cc:130-163) ------------------------------------------------------------- */
+typedef struct {
+    int32_t x, y;        /* irPos: predicted position, LEVEL-0 pixels (ir(v2Image), src/Tracker.cc:881) */
+    int32_t level;       /* mnSearchLevel 0..3; < 0 = template bad, not searched */
+    uint32_t range;      /* nRange in level-0 pixels */
+} ptam_patch_query;
+
+typedef struct {
+    int32_t found;       /* mbFound */
+    int32_t best_ssd;    /* nBestSSD; PTAM_MAX_SSD+1 when nothing scored */
+    int32_t best_x, best_y;   /* irBest in search-level pixels (undefined when nothing scored: -1) */
+    int32_t n_scored;    /* candidates that reached ZMSSDAtPoint */
+    int32_t pad_;
+    double pos[2];       /* mv2CoarsePos = LevelZeroPos(irBest, level), valid iff found */
+} ptam_patch_result;
+
+/* n queries, templates = n * 64 bytes (8x8 row-major, mimTemplate).  Host buffers. */
+int ptam_find_patch_coarse_batch(ptam_ctx* ctx, const ptam_kf* kf, int n,
+                                 const ptam_patch_query* queries, const uint8_t* templates,
+                                 ptam_patch_result* results);
+/* device-resident variant (queries/templates/results are device pointers), asynchronous */
+int ptam_find_patch_coarse_batch_dev(ptam_ctx* ctx, const ptam_kf* kf, int n,
+                                     const ptam_patch_query* d_queries, const uint8_t* d_templates,
+                                     ptam_patch_result* d_results);
+/* ZMSSDAtPoint of ONE template at n explicit points of a level (parity / epipolar use). */
+int ptam_zmssd_at_points(ptam_ctx* ctx, const ptam_kf* kf, int level, int n,
+                         const ptam_int2* points, const uint8_t* tmpl64, int32_t* ssd_out);
+
+/* ---- TrackerData::Project / ProjectAndDerivs + ATANCamera (include/Tracker.h:70-94,
+ *      src/ATANCamera.cc:109-121, 179-209) ------------------------------------------------------- */
+typedef struct {
+    double cam[3];       /* v3Cam */
+    double image[2];     /* v2Image */
+    double derivs[4];    /* m2CamDerivs row-major */
+    int32_t in_image;    /* bInImage */
+    int32_t pad_;
+} ptam_projection;
+int ptam_project_points(ptam_ctx* ctx, int n, const double* world_xyz, const double pose[12],
+                        ptam_projection* out);
+
+/* ---- Tracker pose Gauss-Newton (src/Tracker.cc:613-643 driver, :928-1005 CalcPoseUpdate,
+ *      include/Tracker.h:125-142 CalcJacobian/LinearUpdate) ---------------------------------------- */
+typedef struct {
+    double world[3];         /* MapPoint::v3WorldPos */
+    double found[2];         /* v2Found (level-0 pixels) */
+    double sqrt_inv_noise;   /* dSqrtInvNoise = 1 / 2^level (src/Tracker.cc:889) */
+} ptam_pose_meas;
+
+typedef struct {
+    int32_t iterations;          /* 10 */
+    uint32_t nonlinear_mask;     /* bit i set = full re-projection + Jacobian on iteration i;
+                                    fine stage 0x211 (iter 0,4,9), coarse stage 0x3ff */
+    int32_t override_after;      /* override sigma^2 used for iter > override_after (5) */
+    double override_sigma_sq;    /* 16.0 fine, 1.0 coarse */
+    int32_t mark_outliers_iter;  /* iteration whose weight==0 set is reported (9; -1 = none) */
+    int32_t estimator;           /* PTAM_EST_* ("Tracker.MEstimator") */
+    double prior;                /* wls.add_prior(100.0) */
+} ptam_gn_opts;
+void ptam_gn_opts_default(ptam_gn_opts* o);   /* fine-stage schedule of src/Tracker.cc:613-643 */
+
+/* Runs the whole 10-iteration loop on the device in one launch.
+ * pose_inout: mse3CamFromWorld.  entry (nullable): per-measurement state at loop entry as left by
+ * the caller's last Project (used on iteration 0, which does not re-project, src/Tracker.cc:617);
+ * NULL = project every point with the entry pose.  outlier_flags (nullable, n ints): 1 where
+ * Weight()==0 on mark_outliers_iter.  updates_out (nullable): iterations*6 doubles, the v6Update
+ * of every iteration. */
+int ptam_pose_gn(ptam_ctx* ctx, int n, const ptam_pose_meas* meas, const ptam_projection* entry,
+                 double pose_inout[12], const ptam_gn_opts* opts,
+                 int32_t* outlier_flags, double* updates_out);
+
+/* One Tracker::CalcPoseUpdate (src/Tracker.cc:928-1005) on caller-provided Jacobians. */
+typedef struct {
+    double found[2];
+    double image[2];
+    double sqrt_inv_noise;
+    double jac[12];          /* m26Jacobian row-major 2x6 */
+} ptam_pose_update_meas;
+int ptam_calc_pose_update(ptam_ctx* ctx, int n, const ptam_pose_update_meas* meas,
+                          double override_sigma_sq, int estimator, double prior,
+                          double mu_out[6], int32_t* weight_zero_flags);
+
+/* ---- Bundle (include/Bundle.h:106-152, src/Bundle.cc) -------------------------------------------- */
+typedef struct {
+    int32_t max_iterations;          /* Bundle.MaxIterations = 20          src/Bundle.cc:40 */
+    double update_sq_conv_limit;     /* UpdateSquaredConvergenceLimit 1e-6  src/Bundle.cc:41 */
+    double min_sigma;                /* Bundle.MinTukeySigma = 0.4          src/Bundle.cc:234 */
+    int32_t estimator;               /* Bundle.MEstimator = Tukey           src/Bundle.cc:132 */
+    int32_t verbose;                 /* Bundle.Cout                         src/Bundle.cc:42 */
+} ptam_ba_opts;
+void ptam_ba_opts_default(ptam_ba_opts* o);
+
+/* one lambda trial (the unit mnCounter counts, src/Bundle.cc:518); mirrors the cout line :508 */
+typedef struct {
+    double lambda;          /* mdLambda used by this trial */
+    double sigma_sq;        /* mdSigmaSquared of the enclosing LM step */
+    double err_old;         /* dCurrentError */
+    double err_new;         /* dNewError */
+    double sum_sq_update;   /* |da|^2 + |db|^2 */
+    int32_t n_bad;          /* measurements flagged bBad in the enclosing step (so far) */
+    int32_t accepted;       /* 1 if this trial's step was committed */
+} ptam_ba_trial;
+
+int ptam_ba_create(ptam_ctx* ctx, const ptam_ba_opts* opts, ptam_ba** out);
+int ptam_ba_destroy(ptam_ba* ba);
+/* Bundle::AddCamera src/Bundle.cc:46-63: returns the camera id (>= 0) */
+int ptam_ba_add_camera(ptam_ba* ba, const double pose[12], int fixed);
+/* Bundle::AddPoint src/Bundle.cc:66-79 (NaN point -> zeros): returns the point id (>= 0) */
+int ptam_ba_add_point(ptam_ba* ba, const double pos[3]);
+/* Bundle::AddMeas src/Bundle.cc:82-93; sigma_sq = 4^level (src/MapMaker.cc:879-880) */
+int ptam_ba_add_meas(ptam_ba* ba, int cam, int point, const double found[2], double sigma_sq);
+/* bulk marshalling of the same three calls (ids are assigned in array order) */
+int ptam_ba_add_cameras(ptam_ba* ba, int n, const double* poses12, const uint8_t* fixed);
+int ptam_ba_add_points(ptam_ba* ba, int n, const double* pos3);
+int ptam_ba_add_measurements(ptam_ba* ba, int n, const int32_t* cam, const int32_t* point,
+                             const double* found2, const double* sigma_sq);
+/* Bundle::Compute src/Bundle.cc:116-158.  *abort_flag (nullable) is polled on the host between
+ * device trials (src/Bundle.cc:134,338).  *accepted_out = mnAccepted, or -1 on numerical failure. */
+int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* accepted_out);
+int ptam_ba_converged(const ptam_ba* ba);                    /* include/Bundle.h:115 */
+int ptam_ba_get_point(const ptam_ba* ba, int n, double pos[3]);      /* src/Bundle.cc:613 */
+int ptam_ba_get_camera(const ptam_ba* ba, int n, double pose[12]);   /* src/Bundle.cc:618 */
+int ptam_ba_get_all(const ptam_ba* ba, double* poses12, double* points3);
+/* GetOutlierMeasurements src/Bundle.cc:623: (point, camera) pairs in the reference's order
+ * (LM step, then measurement insertion order).  Returns the count; writes up to cap pairs. */
+int ptam_ba_get_outliers(const ptam_ba* ba, int32_t* point_cam_pairs, int cap);
+int ptam_ba_get_trials(const ptam_ba* ba, ptam_ba_trial* out, int cap);   /* returns count */
+int ptam_ba_counts(const ptam_ba* ba, int* n_cams, int* n_free_cams, int* n_points, int* n_meas);
+
+/* profiling hooks used by bench.py: HIP-event timing of individual kernels on the ctx stream. */
+enum {
+    PTAM_K_PROJECT = 0,     /* K5 pass-1 project + e^2 */
+    PTAM_K_SELECT = 1,      /* K6 order statistic */
+    PTAM_K_JACOBIAN = 2,    /* K7 fused Jacobian + normal-equation accumulate (roofline kernel) */
+    PTAM_K_VINV = 3,
+    PTAM_K_SCHUR = 4,       /* K8 */
+    PTAM_K_SOLVE = 5,       /* K9 */
+    PTAM_K_UPDATE = 6,      /* K10 back-substitution + apply + new error */
+    PTAM_K_COUNT = 7
+};
+int ptam_ba_set_profiling(ptam_ba* ba, int on);
+int ptam_ba_kernel_time(const ptam_ba* ba, int kernel, double* total_ms, int* launches);
+/* upload + build the device structures without running (Compute does this implicitly) */
+int ptam_ba_prepare(ptam_ba* ba);
+/* launch ONLY the K7 kernel `reps` times on the prepared problem (pass 1 + sigma must have run
+ * once: done internally), HIP-event timed; returns average ms per launch and the algorithmic
+ * byte count of one launch. */
+int ptam_ba_bench_jacobian(ptam_ba* ba, int reps, double* avg_ms, double* algorithmic_bytes);
+
+/* ---- sharded global BA: measurements sharded by point across ranks ----------- */
+/* A collective hook: all-reduce (sum) `count` doubles in place at device pointer `dptr`,
+ * ordered on `stream` (hipStream_t).  Return 0 on success. */
+typedef int (*ptam_allreduce_f64_fn)(void* user, double* dptr, size_t count, void* stream);
+/* Attach a communicator to a bundle: `rank`'s bundle holds ALL cameras but only its shard of the
+ * points (and every measurement of those points).  With a hook attached, Compute all-reduces the
+ * camera system (S lower blocks + E), the error scalars and the median histogram per trial. */
+int ptam_ba_set_comm(ptam_ba* ba, int rank, int world, ptam_allreduce_f64_fn fn, void* user);
+
+/* built-in RCCL implementation of the hook (librccl is dlopen'ed on first use) */
+typedef struct ptam_rccl ptam_rccl;
+int ptam_rccl_unique_id(uint8_t id_out[128]);
+int ptam_rccl_create(ptam_ctx* ctx, const uint8_t id[128], int rank, int world, ptam_rccl** out);
+int ptam_rccl_destroy(ptam_rccl* c);
+int ptam_rccl_allreduce_f64(void* comm /* ptam_rccl* */, double* dptr, size_t count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTAM_HIP_H */

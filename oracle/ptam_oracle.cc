@@ -1,0 +1,1378 @@
+// ptam_oracle.cc — CPU restatement of the reference's (cggos/ptam_cg) tracking + bundle hot path.
+//
+// TEST INFRASTRUCTURE ONLY.  Nothing under ptam_cg_amd/ or include/ may link, import or call this
+// file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker
+// and as the timed CPU baseline ("port"), never as the product path.
+//
+// PARITY UNPINNED: the reference tree holds no tests, golden vectors or fixtures for this path
+// (SURVEY.md §4), and it cannot be built here: every hot-path file includes TooN-2.2 / libcvd-20150407
+// / gvars-3.0 headers (src/KeyFrame.cc:4-5, src/Bundle.cc:4-8, ...) which are fetched by
+// install_deps.sh:36-60, are not vendored and are absent from this image (no network).  The oracle is
+// therefore anchored on (i) the cited reference lines it follows one for one, (ii) the published
+// semantics of the third-party calls restated below, (iii) an independent numpy restatement
+// (oracle/np_oracle.py) it is cross-checked against, (iv) hand-derivable known answers (tests/).
+//
+// Third-party semantics restated (cannot be re-verified in this container):
+//   libCVD halfSample: two upstream variants — T: (a+b+c+d)/4 truncating (generic template);
+//     R: SSE2 byte specialisation = vertical pavgb then horizontal pavgw:
+//     v1=(a+c+1)>>1, v2=(b+d+1)>>1, out=(v1+v2+1)>>1  (a,b top row; c,d bottom row).  Default R.
+//   libCVD fast_corner_detect_10: pixel p is a corner iff >= 10 contiguous pixels of the 16-pixel
+//     radius-3 ring are all > p+b or all < p-b (strict); y in [3,h-3), x in [3,w-3); raster order.
+//   TooN SE3::exp, SE3*SE3, generator_field, Cholesky (unpivoted LDL^T, lower triangle), WLS
+//     (normal equations; TooN's default decomposition for WLS is an SVD back-substitution, which for
+//     the SPD, prior-regularised 6x6 systems here equals the LDL^T solve used below to rounding).
+//
+// Each function cites the reference file:line it follows.  Loop and data-structure order mirror the
+// reference (std::list of measurements, dense camera x point LUT, off-diagonal scripts, std::sort
+// median) so that this file is also an honest single-thread CPU baseline.
+
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <list>
+#include <set>
+#include <utility>
+#include <vector>
+
+#include "../include/ptam_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// mini math (TooN stand-in; semantics of SURVEY.md §8c)
+// ------------------------------------------------------------------------------------------------
+struct SE3 {
+    double R[9];   // row-major
+    double t[3];
+};
+
+SE3 se3_from12(const double* p) {
+    SE3 s;
+    std::memcpy(s.R, p, 9 * sizeof(double));
+    std::memcpy(s.t, p + 9, 3 * sizeof(double));
+    return s;
+}
+void se3_to12(const SE3& s, double* p) {
+    std::memcpy(p, s.R, 9 * sizeof(double));
+    std::memcpy(p + 9, s.t, 3 * sizeof(double));
+}
+
+// TooN SE3<>::exp(mu), mu = (t, w)
+SE3 se3_exp(const double mu[6]) {
+    static const double one_6th = 1.0 / 6.0, one_20th = 1.0 / 20.0;
+    const double* tr = mu;
+    const double* w = mu + 3;
+    const double theta_sq = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double theta = std::sqrt(theta_sq);
+    double A, B;
+    const double cr[3] = {w[1] * tr[2] - w[2] * tr[1], w[2] * tr[0] - w[0] * tr[2],
+                          w[0] * tr[1] - w[1] * tr[0]};   // w x t
+    SE3 out;
+    if (theta_sq < 1e-8) {
+        A = 1.0 - one_6th * theta_sq;
+        B = 0.5;
+        for (int i = 0; i < 3; i++) out.t[i] = tr[i] + 0.5 * cr[i];
+    } else {
+        double C;
+        if (theta_sq < 1e-6) {
+            C = one_6th * (1.0 - one_20th * theta_sq);
+            A = 1.0 - theta_sq * C;
+            B = 0.5 - 0.25 * one_6th * theta_sq;
+        } else {
+            const double inv_theta = 1.0 / theta;
+            A = std::sin(theta) * inv_theta;
+            B = (1 - std::cos(theta)) * (inv_theta * inv_theta);
+            C = (1 - A) * (inv_theta * inv_theta);
+        }
+        const double wcr[3] = {w[1] * cr[2] - w[2] * cr[1], w[2] * cr[0] - w[0] * cr[2],
+                               w[0] * cr[1] - w[1] * cr[0]};   // w x (w x t)
+        for (int i = 0; i < 3; i++) out.t[i] = tr[i] + B * cr[i] + C * wcr[i];
+    }
+    // Rodrigues
+    {
+        const double wx2 = w[0] * w[0], wy2 = w[1] * w[1], wz2 = w[2] * w[2];
+        out.R[0] = 1.0 - B * (wy2 + wz2);
+        out.R[4] = 1.0 - B * (wx2 + wz2);
+        out.R[8] = 1.0 - B * (wx2 + wy2);
+        double a = A * w[2], b = B * (w[0] * w[1]);
+        out.R[1] = b - a;
+        out.R[3] = b + a;
+        a = A * w[1];
+        b = B * (w[0] * w[2]);
+        out.R[2] = b + a;
+        out.R[6] = b - a;
+        a = A * w[0];
+        b = B * (w[1] * w[2]);
+        out.R[5] = b - a;
+        out.R[7] = b + a;
+    }
+    return out;
+}
+
+// SE3 * SE3: R = R1 R2, t = t1 + R1 t2 (no re-orthonormalisation)
+SE3 se3_mul(const SE3& a, const SE3& b) {
+    SE3 o;
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += a.R[r * 3 + k] * b.R[k * 3 + c];
+            o.R[r * 3 + c] = s;
+        }
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += a.R[r * 3 + k] * b.t[k];
+        o.t[r] = a.t[r] + s;
+    }
+    return o;
+}
+
+void se3_apply(const SE3& s, const double x[3], double out[3]) {
+    for (int r = 0; r < 3; r++)
+        out[r] = s.t[r] + (s.R[r * 3 + 0] * x[0] + s.R[r * 3 + 1] * x[1] + s.R[r * 3 + 2] * x[2]);
+}
+
+// SE3<>::generator_field(m, (x,y,z,w))
+void generator_field(int m, const double p[4], double out[4]) {
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (m < 3) {
+        out[m] = p[3];
+        return;
+    }
+    switch (m) {
+        case 3: out[1] = -p[2]; out[2] = p[1]; break;
+        case 4: out[0] = p[2]; out[2] = -p[0]; break;
+        default: out[0] = -p[1]; out[1] = p[0]; break;
+    }
+}
+
+// TooN Cholesky<>: unpivoted LDL^T reading only the lower triangle; the strict upper triangle is
+// used as a cache of the undivided column.  backsub = L solve, D scale, L^T solve.
+struct LDLT {
+    int n;
+    std::vector<double> a;   // n*n row-major
+    LDLT(int n_, const double* m) : n(n_), a(m, m + (size_t)n_ * n_) { compute(); }
+    double& at(int r, int c) { return a[(size_t)r * n + c]; }
+    double at(int r, int c) const { return a[(size_t)r * n + c]; }
+    void compute() {
+        for (int col = 0; col < n; col++) {
+            double inv_diag = 1;
+            for (int row = col; row < n; row++) {
+                double val = at(row, col);
+                for (int c2 = 0; c2 < col; c2++) val -= at(c2, col) * at(row, c2);
+                if (row == col) {
+                    at(row, col) = val;
+                    if (val == 0) return;   // rank deficient: TooN stops; backsub then yields inf/nan
+                    inv_diag = 1 / val;
+                } else {
+                    at(col, row) = val;
+                    at(row, col) = val * inv_diag;
+                }
+            }
+        }
+    }
+    void backsub(const double* v, double* x) const {
+        std::vector<double> y(n);
+        for (int i = 0; i < n; i++) {
+            double val = v[i];
+            for (int j = 0; j < i; j++) val -= at(i, j) * y[j];
+            y[i] = val;
+        }
+        for (int i = 0; i < n; i++) y[i] /= at(i, i);
+        for (int i = n - 1; i >= 0; i--) {
+            double val = y[i];
+            for (int j = i + 1; j < n; j++) val -= at(j, i) * x[j];
+            x[i] = val;
+        }
+    }
+    void inverse(double* out) const {   // get_inverse(): backsub of identity columns
+        std::vector<double> e(n), x(n);
+        for (int c = 0; c < n; c++) {
+            std::fill(e.begin(), e.end(), 0.0);
+            e[c] = 1.0;
+            backsub(e.data(), x.data());
+            for (int r = 0; r < n; r++) out[(size_t)r * n + c] = x[r];
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// M-estimators: include/Tools.h:128-228
+// ------------------------------------------------------------------------------------------------
+double median_sigma(std::vector<double>& v, double k) {   // Tools.h:152-162 / 180-190 / 218-228
+    assert(!v.empty());
+    std::sort(v.begin(), v.end());
+    const double med = v[v.size() / 2];
+    // NB size_t arithmetic: (2n - 6) wraps for n < 3, is 0 for n == 3
+    double sigma = 1.4826 * (1 + 5.0 / (v.size() * 2 - 6)) * std::sqrt(med);
+    sigma = k * sigma;
+    return sigma * sigma;
+}
+struct Tukey {
+    static double FindSigmaSquared(std::vector<double>& v) { return median_sigma(v, 4.6851); }
+    static double SquareRootWeight(double e2, double s2) { return e2 > s2 ? 0.0 : 1.0 - (e2 / s2); }
+    static double Weight(double e2, double s2) {
+        const double r = SquareRootWeight(e2, s2);
+        return r * r;
+    }
+    static double ObjectiveScore(double e2, double s2) {
+        if (e2 > s2) return 1.0;
+        const double d = 1.0 - e2 / s2;
+        return 1.0 - d * d * d;
+    }
+};
+struct Cauchy {
+    static double FindSigmaSquared(std::vector<double>& v) { return median_sigma(v, 4.6851); }
+    static double Weight(double e2, double s2) { return 1.0 / (1.0 + e2 / s2); }
+    static double SquareRootWeight(double e2, double s2) { return std::sqrt(Weight(e2, s2)); }
+    static double ObjectiveScore(double e2, double s2) { return std::log(1.0 + e2 / s2); }
+};
+struct Huber {
+    static double FindSigmaSquared(std::vector<double>& v) { return median_sigma(v, 1.345); }
+    static double Weight(double e2, double s2) { return e2 < s2 ? 1.0 : std::sqrt(s2 / e2); }
+    static double SquareRootWeight(double e2, double s2) { return std::sqrt(Weight(e2, s2)); }
+    static double ObjectiveScore(double e2, double s2) {
+        if (e2 < s2) return 0.5 * e2;
+        const double s = std::sqrt(s2), e = std::sqrt(e2);
+        return s * (e - 0.5 * s);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// ATANCamera: src/ATANCamera.cc:27-66 (RefreshParams), :109-121 (Project), :179-209 (derivs),
+// include/ATANCamera.h:143-157 (rtrans_factor / invrtrans).  Stateful like the reference.
+// ------------------------------------------------------------------------------------------------
+struct ATANCamera {
+    double focal[2], centre[2], w, two_tan, one_over_two_tan, w_inv, dist_enabled;
+    double largest_radius, max_r;
+    double size[2];
+    // cache of the last projection
+    double last_cam[2], last_r, last_factor;
+    bool invalid;
+
+    explicit ATANCamera(const ptam_cam_params& p) {
+        size[0] = p.width;
+        size[1] = p.height;
+        focal[0] = size[0] * p.fx;
+        focal[1] = size[1] * p.fy;
+        centre[0] = size[0] * p.cx - 0.5;
+        centre[1] = size[1] * p.cy - 0.5;
+        w = p.w;
+        if (w != 0.0) {
+            two_tan = 2.0 * std::tan(w / 2.0);
+            one_over_two_tan = 1.0 / two_tan;
+            w_inv = 1.0 / w;
+            dist_enabled = 1.0;
+        } else {
+            w_inv = 0.0;
+            two_tan = 0.0;
+            one_over_two_tan = 0.0;
+            dist_enabled = 0.0;
+        }
+        double v[2];
+        v[0] = std::max(p.cx, 1.0 - p.cx) / p.fx;
+        v[1] = std::max(p.cy, 1.0 - p.cy) / p.fy;
+        largest_radius = invrtrans(std::sqrt(v[0] * v[0] + v[1] * v[1]));
+        max_r = 1.5 * largest_radius;
+        last_cam[0] = last_cam[1] = last_r = 0;
+        last_factor = 1;
+        invalid = false;
+    }
+    double rtrans_factor(double r) const {
+        if (r < 0.001 || w == 0.0) return 1.0;
+        return w_inv * std::atan(r * two_tan) / r;
+    }
+    double invrtrans(double r) const {
+        if (w == 0.0) return r;
+        return std::tan(r * w) * one_over_two_tan;
+    }
+    void Project(const double cam[2], double im[2]) {
+        last_cam[0] = cam[0];
+        last_cam[1] = cam[1];
+        last_r = std::sqrt(cam[0] * cam[0] + cam[1] * cam[1]);
+        invalid = last_r > max_r;
+        last_factor = rtrans_factor(last_r);
+        im[0] = centre[0] + focal[0] * (last_factor * last_cam[0]);
+        im[1] = centre[1] + focal[1] * (last_factor * last_cam[1]);
+    }
+    void GetProjectionDerivs(double d[4]) const {
+        const double k = two_tan, x = last_cam[0], y = last_cam[1];
+        const double r = last_r * dist_enabled;
+        double fx, fy;
+        if (r < 0.01) {
+            fx = fy = 0.0;
+        } else {
+            fx = w_inv * (k * x) / (r * r * (1 + k * k * r * r)) - x * last_factor / (r * r);
+            fy = w_inv * (k * y) / (r * r * (1 + k * k * r * r)) - y * last_factor / (r * r);
+        }
+        d[0] = focal[0] * (fx * x + last_factor);
+        d[2] = focal[1] * (fx * y);
+        d[1] = focal[0] * (fy * x);
+        d[3] = focal[1] * (fy * y + last_factor);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// KeyFrame / Level: include/KeyFrame.h:55-124, src/KeyFrame.cc:18-54
+// ------------------------------------------------------------------------------------------------
+struct Level {
+    int w = 0, h = 0;
+    std::vector<uint8_t> im;
+    std::vector<ptam_int2> corners;
+    std::vector<int> rowlut;
+};
+
+// CVD::halfSample; out size = in / 2 (src/KeyFrame.cc:26)
+void half_sample(const uint8_t* in, int w, int h, uint8_t* out, int variant) {
+    const int ow = w / 2, oh = h / 2;
+    for (int y = 0; y < oh; y++) {
+        const uint8_t* top = in + (size_t)(2 * y) * w;
+        const uint8_t* bot = top + w;
+        uint8_t* o = out + (size_t)y * ow;
+        for (int x = 0; x < ow; x++) {
+            const int a = top[2 * x], b = top[2 * x + 1], c = bot[2 * x], d = bot[2 * x + 1];
+            if (variant == PTAM_HALFSAMPLE_T) {
+                o[x] = (uint8_t)((a + b + c + d) / 4);
+            } else {
+                const int v1 = (a + c + 1) >> 1, v2 = (b + d + 1) >> 1;
+                o[x] = (uint8_t)((v1 + v2 + 1) >> 1);
+            }
+        }
+    }
+}
+
+// CVD::fast_corner_detect_10 (definition in the header comment)
+const int kRing[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},   {3, 0},  {3, -1}, {2, -2}, {1, -3},
+                          {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+
+inline bool has_run10(unsigned m16) {
+    const unsigned d = m16 | (m16 << 16);
+    unsigned a = d & (d >> 1);
+    unsigned b = a & (a >> 2);
+    unsigned c = b & (b >> 4);
+    return (c & (a >> 8) & 0xffffu) != 0;
+}
+
+void fast10(const uint8_t* im, int w, int h, int thr, std::vector<ptam_int2>& out) {
+    int off[16];
+    for (int i = 0; i < 16; i++) off[i] = kRing[i][1] * w + kRing[i][0];
+    for (int y = 3; y < h - 3; y++) {
+        const uint8_t* row = im + (size_t)y * w;
+        for (int x = 3; x < w - 3; x++) {
+            const uint8_t* p = row + x;
+            const int hi = *p + thr, lo = *p - thr;
+            // a 10-arc contains at least one pixel of every opposite pair: cheap rejects
+            const int p0 = p[off[0]], p8 = p[off[8]];
+            if (!(p0 > hi || p8 > hi || p0 < lo || p8 < lo)) continue;
+            const int p4 = p[off[4]], p12 = p[off[12]];
+            if (!(p4 > hi || p12 > hi || p4 < lo || p12 < lo)) continue;
+            unsigned brighter = 0, darker = 0;
+            for (int i = 0; i < 16; i++) {
+                const int v = p[off[i]];
+                brighter |= (unsigned)(v > hi) << i;
+                darker |= (unsigned)(v < lo) << i;
+            }
+            if (has_run10(brighter) || has_run10(darker)) out.push_back({x, y});
+        }
+    }
+}
+
+struct KeyFrame {
+    Level lev[PTAM_LEVELS];
+    // src/KeyFrame.cc:18-54
+    void MakeKeyFrame_Lite(const uint8_t* im, int w, int h, int stride, int variant) {
+        static const int thr[PTAM_LEVELS] = {10, 15, 15, 10};   // :35-42
+        lev[0].w = w;
+        lev[0].h = h;
+        lev[0].im.resize((size_t)w * h);
+        for (int y = 0; y < h; y++) std::memcpy(&lev[0].im[(size_t)y * w], im + (size_t)y * stride, w);
+        for (int i = 0; i < PTAM_LEVELS; i++) {
+            Level& L = lev[i];
+            if (i != 0) {
+                L.w = lev[i - 1].w / 2;
+                L.h = lev[i - 1].h / 2;
+                L.im.resize((size_t)L.w * L.h);
+                half_sample(lev[i - 1].im.data(), lev[i - 1].w, lev[i - 1].h, L.im.data(), variant);
+            }
+            L.corners.clear();
+            fast10(L.im.data(), L.w, L.h, thr[i], L.corners);
+            // row LUT :46-52
+            unsigned v = 0;
+            L.rowlut.clear();
+            for (int y = 0; y < L.h; y++) {
+                while (v < L.corners.size() && y > L.corners[v].y) v++;
+                L.rowlut.push_back((int)v);
+            }
+        }
+    }
+};
+
+// ImageProcess::ZMSSDAtPoint src/ImageProcess.cc:130-163 (8x8 template)
+int zmssd_at_point(const Level& L, int x, int y, const uint8_t* tmpl, int tsum, int tsumsq, int max_ssd) {
+    const int b = PTAM_PATCH / 2;
+    if (!(x >= b && y >= b && x < L.w - b && y < L.h - b)) return max_ssd + 1;
+    const int bx = x - b, by = y - b;
+    int isumsq = 0, isum = 0, cross = 0;
+    for (int r = 0; r < PTAM_PATCH; r++) {
+        const uint8_t* ip = &L.im[(size_t)(by + r) * L.w + bx];
+        const uint8_t* tp = tmpl + r * PTAM_PATCH;
+        for (int c = 0; c < PTAM_PATCH; c++) {
+            const int n = ip[c];
+            isum += n;
+            isumsq += n * n;
+            cross += n * tp[c];
+        }
+    }
+    const int SA = tsum, SB = isum, N = PTAM_PATCH * PTAM_PATCH;
+    return ((2 * SA * SB - SA * SA - SB * SB) / N + isumsq + tsumsq - 2 * cross);
+}
+
+void template_sums(const uint8_t* t, int& sum, int& sumsq) {   // PatchFinder::MakeTemplateSums
+    sum = sumsq = 0;
+    for (int i = 0; i < 64; i++) {
+        sum += t[i];
+        sumsq += t[i] * t[i];
+    }
+}
+
+// PatchFinder::FindPatchCoarse src/PatchFinder.cc:160-211
+void find_patch_coarse(const KeyFrame& kf, const ptam_patch_query& q, const uint8_t* tmpl,
+                       ptam_patch_result& res) {
+    res.found = 0;
+    res.best_ssd = PTAM_MAX_SSD + 1;
+    res.best_x = res.best_y = -1;
+    res.n_scored = 0;
+    res.pad_ = 0;
+    res.pos[0] = res.pos[1] = 0;
+    if (q.level < 0 || q.level >= PTAM_LEVELS) return;   // template bad: not searched (Tracker.cc:874)
+    int tsum, tsumsq;
+    template_sums(tmpl, tsum, tsumsq);
+    const int scale = 1 << q.level;
+    int px = q.x / scale, py = q.y / scale;                  // ImageRef / int: C division
+    unsigned nRange = (q.range + scale - 1) / scale;          // unsigned like the reference
+    int nTop = py - nRange;
+    int nBottomPlusOne = py + nRange + 1;
+    int nLeft = px - nRange;
+    int nRight = px + nRange;
+    const Level& L = kf.lev[q.level];
+    if (nTop < 0) nTop = 0;
+    if (nTop >= L.h) return;
+    if (nBottomPlusOne <= 0) return;
+    int bx = -1, by = -1;
+    int best = PTAM_MAX_SSD + 1;
+    size_t i = (size_t)L.rowlut[nTop];
+    size_t i_end = nBottomPlusOne >= L.h ? L.corners.size() : (size_t)L.rowlut[nBottomPlusOne];
+    for (; i < i_end; i++) {
+        const ptam_int2 c = L.corners[i];
+        if (c.x < nLeft || c.x > nRight) continue;
+        const int dx = px - c.x, dy = py - c.y;
+        if ((unsigned)(dx * dx + dy * dy) > nRange * nRange) continue;
+        const int ssd = zmssd_at_point(L, c.x, c.y, tmpl, tsum, tsumsq, PTAM_MAX_SSD);
+        res.n_scored++;
+        if (ssd < best) {
+            bx = c.x;
+            by = c.y;
+            best = ssd;
+        }
+    }
+    res.best_ssd = best;
+    res.best_x = bx;
+    res.best_y = by;
+    if (best < PTAM_MAX_SSD) {
+        res.found = 1;
+        res.pos[0] = (bx + 0.5) * scale - 0.5;   // Level::LevelZeroPos include/KeyFrame.h:91-94
+        res.pos[1] = (by + 0.5) * scale - 0.5;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TrackerData: include/Tracker.h:41-145
+// ------------------------------------------------------------------------------------------------
+struct TrackerData {
+    double world[3];
+    double v3Cam[3], v2ImPlane[2], v2Image[2], m2CamDerivs[4];
+    bool bInImage = false, bFound = false;
+    double v2Found[2], dSqrtInvNoise;
+    double v2Error_CovScaled[2];
+    double m26Jacobian[12];
+
+    // :70-85; returns true if the camera model was reached (for the stale-cache accounting)
+    bool Project(const SE3& T, ATANCamera& cam) {
+        bInImage = false;
+        se3_apply(T, world, v3Cam);
+        if (v3Cam[2] < 0.001) return false;
+        v2ImPlane[0] = v3Cam[0] / v3Cam[2];
+        v2ImPlane[1] = v3Cam[1] / v3Cam[2];
+        if (v2ImPlane[0] * v2ImPlane[0] + v2ImPlane[1] * v2ImPlane[1] >
+            cam.largest_radius * cam.largest_radius)
+            return false;
+        cam.Project(v2ImPlane, v2Image);
+        if (cam.invalid) return true;
+        if (v2Image[0] < 0 || v2Image[1] < 0 || v2Image[0] > cam.size[0] || v2Image[1] > cam.size[1])
+            return true;
+        bInImage = true;
+        return true;
+    }
+    void CalcJacobian() {   // :125-136
+        const double inv_z = 1.0 / v3Cam[2];
+        const double p4[4] = {v3Cam[0], v3Cam[1], v3Cam[2], 1.0};
+        for (int m = 0; m < 6; m++) {
+            double g[4];
+            generator_field(m, p4, g);
+            const double mx = (g[0] - v3Cam[0] * g[2] * inv_z) * inv_z;
+            const double my = (g[1] - v3Cam[1] * g[2] * inv_z) * inv_z;
+            m26Jacobian[m] = m2CamDerivs[0] * mx + m2CamDerivs[1] * my;
+            m26Jacobian[6 + m] = m2CamDerivs[2] * mx + m2CamDerivs[3] * my;
+        }
+    }
+    void LinearUpdate(const double v6[6]) {   // :139-142
+        for (int r = 0; r < 2; r++) {
+            double s = 0;
+            for (int m = 0; m < 6; m++) s += m26Jacobian[r * 6 + m] * v6[m];
+            v2Image[r] += s;
+        }
+    }
+};
+
+// Tracker::CalcPoseUpdate src/Tracker.cc:928-1005
+void calc_pose_update(std::vector<TrackerData>& vTD, double overrideSigma, int estimator, double prior,
+                      bool markOutliers, int32_t* outlier_flags, double mu[6]) {
+    std::vector<double> vdErrorSquared;
+    for (auto& TD : vTD) {
+        if (!TD.bFound) continue;
+        TD.v2Error_CovScaled[0] = TD.dSqrtInvNoise * (TD.v2Found[0] - TD.v2Image[0]);
+        TD.v2Error_CovScaled[1] = TD.dSqrtInvNoise * (TD.v2Found[1] - TD.v2Image[1]);
+        vdErrorSquared.push_back(TD.v2Error_CovScaled[0] * TD.v2Error_CovScaled[0] +
+                                 TD.v2Error_CovScaled[1] * TD.v2Error_CovScaled[1]);
+    }
+    for (int i = 0; i < 6; i++) mu[i] = 0;
+    if (vdErrorSquared.empty()) return;
+    double dSigmaSquared;
+    if (overrideSigma > 0)
+        dSigmaSquared = overrideSigma;
+    else if (estimator == PTAM_EST_TUKEY)
+        dSigmaSquared = Tukey::FindSigmaSquared(vdErrorSquared);
+    else if (estimator == PTAM_EST_CAUCHY)
+        dSigmaSquared = Cauchy::FindSigmaSquared(vdErrorSquared);
+    else
+        dSigmaSquared = Huber::FindSigmaSquared(vdErrorSquared);
+
+    // WLS<6>: add_prior, add_mJ, compute
+    double C[36] = {0}, b[6] = {0};
+    for (int i = 0; i < 6; i++) C[i * 6 + i] += prior;
+    size_t idx = 0;
+    for (auto& TD : vTD) {
+        const size_t me = idx++;
+        if (!TD.bFound) continue;
+        const double* v2 = TD.v2Error_CovScaled;
+        const double e2 = v2[0] * v2[0] + v2[1] * v2[1];
+        double wgt;
+        if (estimator == PTAM_EST_TUKEY)
+            wgt = Tukey::Weight(e2, dSigmaSquared);
+        else if (estimator == PTAM_EST_CAUCHY)
+            wgt = Cauchy::Weight(e2, dSigmaSquared);
+        else
+            wgt = Huber::Weight(e2, dSigmaSquared);
+        if (wgt == 0.0) {
+            if (markOutliers && outlier_flags) outlier_flags[me] = 1;
+            continue;
+        }
+        for (int r = 0; r < 2; r++) {
+            double J[6], Jw[6];
+            for (int m = 0; m < 6; m++) {
+                J[m] = TD.dSqrtInvNoise * TD.m26Jacobian[r * 6 + m];
+                Jw[m] = J[m] * wgt;
+            }
+            for (int i = 0; i < 6; i++) {
+                for (int j = 0; j < 6; j++) C[i * 6 + j] += Jw[i] * J[j];
+                b[i] += v2[r] * Jw[i];
+            }
+        }
+    }
+    LDLT chol(6, C);
+    chol.backsub(b, mu);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bundle: include/Bundle.h:38-152, src/Bundle.cc (whole file)
+// ------------------------------------------------------------------------------------------------
+struct BCamera {
+    bool bFixed;
+    SE3 se3CfW, se3CfWNew;
+    double m6U[36];
+    double v6EpsilonA[6];
+    int nStartRow;
+};
+struct OffDiagScriptEntry {
+    int j, k;
+};
+struct BPoint {
+    double v3Pos[3], v3PosNew[3];
+    double m3V[9], v3EpsilonB[3], m3VStarInv[9];
+    int nMeasurements = 0, nOutliers = 0;
+    std::set<int> sCameras;
+    std::vector<OffDiagScriptEntry> vOffDiagonalScript;
+};
+struct Meas {
+    int p, c;
+    bool bBad = false;
+    double v2Found[2], v2Epsilon[2];
+    double m26A[12], m23B[6], m63W[18];
+    double dSqrtInvNoise;
+    double v3Cam[3], dErrorSquared, m2CamDerivs[4];
+};
+
+typedef int (*allreduce_fn)(void* user, double* ptr, size_t count, void* stream);
+
+struct Bundle {
+    ATANCamera mCamera;
+    ptam_ba_opts opts;
+    std::vector<BPoint> mvPoints;
+    std::vector<BCamera> mvCameras;
+    std::list<Meas> mMeasList;
+    std::vector<std::pair<int, int>> mvOutlierMeasurementIdx;
+    std::vector<std::vector<Meas*>> mvMeasLUTs;
+    int mnCamsToUpdate = 0, mnStartRow = 0;
+    double mdSigmaSquared = 0, mdLambda = 0, mdLambdaFactor = 0;
+    bool mbConverged = false, mbHitMaxIterations = false;
+    int mnCounter = 0, mnAccepted = 0;
+    std::vector<ptam_ba_trial> trials;
+    // sharded mode (test infrastructure for the N>1 protocol)
+    int rank = 0, world = 1;
+    allreduce_fn comm = nullptr;
+    void* comm_user = nullptr;
+
+    Bundle(const ptam_cam_params& cam, const ptam_ba_opts& o) : mCamera(cam), opts(o) {}
+
+    int AddCamera(const SE3& pose, bool bFixed) {   // src/Bundle.cc:46-63
+        const int n = (int)mvCameras.size();
+        BCamera c;
+        c.bFixed = bFixed;
+        c.se3CfW = pose;
+        c.se3CfWNew = pose;
+        if (!bFixed) {
+            c.nStartRow = mnStartRow;
+            mnStartRow += 6;
+            mnCamsToUpdate++;
+        } else
+            c.nStartRow = -999999999;
+        mvCameras.push_back(c);
+        return n;
+    }
+    int AddPoint(const double* pos) {   // :66-79
+        const int n = (int)mvPoints.size();
+        BPoint p;
+        double v[3] = {pos[0], pos[1], pos[2]};
+        if (std::isnan(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])) v[0] = v[1] = v[2] = 0;
+        std::memcpy(p.v3Pos, v, sizeof v);
+        std::memcpy(p.v3PosNew, v, sizeof v);
+        mvPoints.push_back(p);
+        return n;
+    }
+    void AddMeas(int nCam, int nPoint, const double* v2Pos, double dSigmaSquared) {   // :82-93
+        mvPoints[nPoint].nMeasurements++;
+        mvPoints[nPoint].sCameras.insert(nCam);
+        Meas m;
+        m.p = nPoint;
+        m.c = nCam;
+        m.v2Found[0] = v2Pos[0];
+        m.v2Found[1] = v2Pos[1];
+        m.dSqrtInvNoise = std::sqrt(1.0 / dSigmaSquared);
+        mMeasList.push_back(m);
+    }
+    void ClearAccumulators() {   // :96-108
+        for (auto& p : mvPoints) {
+            std::fill(p.m3V, p.m3V + 9, 0.0);
+            std::fill(p.v3EpsilonB, p.v3EpsilonB + 3, 0.0);
+        }
+        for (auto& c : mvCameras) {
+            std::fill(c.m6U, c.m6U + 36, 0.0);
+            std::fill(c.v6EpsilonA, c.v6EpsilonA + 6, 0.0);
+        }
+    }
+    void GenerateMeasLUTs() {   // :558-567
+        mvMeasLUTs.clear();
+        for (size_t c = 0; c < mvCameras.size(); c++)
+            mvMeasLUTs.push_back(std::vector<Meas*>(mvPoints.size(), nullptr));
+        for (auto& m : mMeasList) mvMeasLUTs[m.c][m.p] = &m;
+    }
+    void GenerateOffDiagScripts() {   // :572-599
+        for (size_t i = 0; i < mvPoints.size(); i++) {
+            BPoint& p = mvPoints[i];
+            p.vOffDiagonalScript.clear();
+            for (auto it_j = p.sCameras.begin(); it_j != p.sCameras.end(); ++it_j) {
+                const int j = *it_j;
+                if (mvCameras[j].bFixed) continue;
+                for (auto it_k = p.sCameras.begin(); it_k != it_j; ++it_k) {
+                    const int k = *it_k;
+                    if (mvCameras[k].bFixed) continue;
+                    p.vOffDiagonalScript.push_back({j, k});
+                }
+            }
+        }
+    }
+    void ProjectAndFindSquaredError(Meas& meas) {   // :164-180
+        BCamera& cam = mvCameras[meas.c];
+        BPoint& point = mvPoints[meas.p];
+        se3_apply(cam.se3CfW, point.v3Pos, meas.v3Cam);
+        if (meas.v3Cam[2] <= 0) {
+            meas.bBad = true;
+            return;
+        }
+        meas.bBad = false;
+        const double ip[2] = {meas.v3Cam[0] / meas.v3Cam[2], meas.v3Cam[1] / meas.v3Cam[2]};
+        double im[2];
+        mCamera.Project(ip, im);
+        mCamera.GetProjectionDerivs(meas.m2CamDerivs);
+        meas.v2Epsilon[0] = meas.dSqrtInvNoise * (meas.v2Found[0] - im[0]);
+        meas.v2Epsilon[1] = meas.dSqrtInvNoise * (meas.v2Found[1] - im[1]);
+        meas.dErrorSquared = meas.v2Epsilon[0] * meas.v2Epsilon[0] + meas.v2Epsilon[1] * meas.v2Epsilon[1];
+    }
+    template <class ME>
+    double FindNewError() {   // :188-207
+        double dNewError = 0;
+        for (auto& meas : mMeasList) {
+            double v3Cam[3];
+            se3_apply(mvCameras[meas.c].se3CfWNew, mvPoints[meas.p].v3PosNew, v3Cam);
+            if (v3Cam[2] <= 0) {
+                dNewError += 1.0;
+                continue;
+            }
+            const double ip[2] = {v3Cam[0] / v3Cam[2], v3Cam[1] / v3Cam[2]};
+            double im[2];
+            mCamera.Project(ip, im);
+            const double ex = meas.dSqrtInvNoise * (meas.v2Found[0] - im[0]);
+            const double ey = meas.dSqrtInvNoise * (meas.v2Found[1] - im[1]);
+            dNewError += ME::ObjectiveScore(ex * ex + ey * ey, mdSigmaSquared);
+        }
+        return dNewError;
+    }
+
+    // sharded helpers: sum a scalar / a buffer over ranks (identity when no comm is attached)
+    void allreduce(double* p, size_t n) {
+        if (comm && world > 1) {
+            const int rc = comm(comm_user, p, n, nullptr);
+            if (rc != 0) std::fprintf(stderr, "oracle: allreduce hook failed (%d)\n", rc);
+        }
+    }
+    // gather every rank's squared errors (all-gather built from two all-reduces)
+    void gather_errors(std::vector<double>& v) {
+        if (!(comm && world > 1)) return;
+        std::vector<double> counts(world, 0.0);
+        counts[rank] = (double)v.size();
+        allreduce(counts.data(), counts.size());
+        size_t total = 0, off = 0;
+        for (int r = 0; r < world; r++) {
+            if (r == rank) off = total;
+            total += (size_t)counts[r];
+        }
+        std::vector<double> all(total, 0.0);
+        std::copy(v.begin(), v.end(), all.begin() + off);
+        allreduce(all.data(), all.size());
+        v.swap(all);
+    }
+
+    template <class ME>
+    bool Do_LM_Step(const volatile unsigned char* pbAbort) {   // :209-551
+        ClearAccumulators();
+        std::vector<double> vdErrorSquared;
+        for (auto& meas : mMeasList) {   // pass 1 :219-225
+            ProjectAndFindSquaredError(meas);
+            if (!meas.bBad) vdErrorSquared.push_back(meas.dErrorSquared);
+        }
+        gather_errors(vdErrorSquared);
+        mdSigmaSquared = ME::FindSigmaSquared(vdErrorSquared);   // :230
+        const double dMinSigmaSquared = opts.min_sigma * opts.min_sigma;
+        if (mdSigmaSquared < dMinSigmaSquared) mdSigmaSquared = dMinSigmaSquared;
+
+        double dCurrentError = 0.0;
+        for (auto& meas : mMeasList) {   // pass 2 :250-332
+            BCamera& cam = mvCameras[meas.c];
+            BPoint& point = mvPoints[meas.p];
+            if (meas.bBad) {
+                dCurrentError += 1.0;
+                continue;
+            }
+            const double dWeight = ME::SquareRootWeight(meas.dErrorSquared, mdSigmaSquared);
+            meas.v2Epsilon[0] = dWeight * meas.v2Epsilon[0];
+            meas.v2Epsilon[1] = dWeight * meas.v2Epsilon[1];
+            if (dWeight == 0) {
+                meas.bBad = true;
+                dCurrentError += 1.0;
+                continue;
+            }
+            dCurrentError += ME::ObjectiveScore(meas.dErrorSquared, mdSigmaSquared);
+            double D[4];
+            for (int i = 0; i < 4; i++) D[i] = dWeight * meas.m2CamDerivs[i];
+            const double inv_z = 1.0 / meas.v3Cam[2];
+            const double v4Cam[4] = {meas.v3Cam[0], meas.v3Cam[1], meas.v3Cam[2], 1.0};
+            if (cam.bFixed)
+                std::fill(meas.m26A, meas.m26A + 12, 0.0);
+            else
+                for (int m = 0; m < 6; m++) {
+                    double g[4];
+                    generator_field(m, v4Cam, g);
+                    const double mx = (g[0] - v4Cam[0] * g[2] * inv_z) * inv_z;
+                    const double my = (g[1] - v4Cam[1] * g[2] * inv_z) * inv_z;
+                    meas.m26A[m] = meas.dSqrtInvNoise * (D[0] * mx + D[1] * my);
+                    meas.m26A[6 + m] = meas.dSqrtInvNoise * (D[2] * mx + D[3] * my);
+                }
+            for (int m = 0; m < 3; m++) {
+                // m-th column of R_cw
+                const double g[3] = {cam.se3CfW.R[0 * 3 + m], cam.se3CfW.R[1 * 3 + m], cam.se3CfW.R[2 * 3 + m]};
+                const double mx = (g[0] - v4Cam[0] * g[2] * inv_z) * inv_z;
+                const double my = (g[1] - v4Cam[1] * g[2] * inv_z) * inv_z;
+                meas.m23B[m] = meas.dSqrtInvNoise * (D[0] * mx + D[1] * my);
+                meas.m23B[3 + m] = meas.dSqrtInvNoise * (D[2] * mx + D[3] * my);
+            }
+            if (!cam.bFixed) {
+                for (int r = 0; r < 6; r++)   // BundleTriangle_UpdateM6U_LL :21-26
+                    for (int c = 0; c <= r; c++)
+                        cam.m6U[r * 6 + c] += meas.m26A[r] * meas.m26A[c] + meas.m26A[6 + r] * meas.m26A[6 + c];
+                for (int r = 0; r < 6; r++)
+                    cam.v6EpsilonA[r] += meas.m26A[r] * meas.v2Epsilon[0] + meas.m26A[6 + r] * meas.v2Epsilon[1];
+            }
+            for (int r = 0; r < 3; r++)   // BundleTriangle_UpdateM3V_LL :27-32
+                for (int c = 0; c <= r; c++)
+                    point.m3V[r * 3 + c] += meas.m23B[r] * meas.m23B[c] + meas.m23B[3 + r] * meas.m23B[3 + c];
+            for (int r = 0; r < 3; r++)
+                point.v3EpsilonB[r] += meas.m23B[r] * meas.v2Epsilon[0] + meas.m23B[3 + r] * meas.v2Epsilon[1];
+            if (cam.bFixed)
+                std::fill(meas.m63W, meas.m63W + 18, 0.0);
+            else
+                for (int r = 0; r < 6; r++)
+                    for (int c = 0; c < 3; c++)
+                        meas.m63W[r * 3 + c] = meas.m26A[r] * meas.m23B[c] + meas.m26A[6 + r] * meas.m23B[3 + c];
+        }
+        // sharded mode: U / epsA stay per-rank partial sums; (1+lambda)*diag(U) is linear, so the
+        // partials fold into the single S/E all-reduce below
+        allreduce(&dCurrentError, 1);
+
+        const int n = mnCamsToUpdate * 6;
+        double dNewError = dCurrentError + 9999;
+        int nBadSoFar = 0;
+        for (auto& m : mMeasList) nBadSoFar += m.bBad;
+        while (dNewError > dCurrentError && !mbConverged && !mbHitMaxIterations && !(pbAbort && *pbAbort)) {
+            for (auto& point : mvPoints) {   // V*^-1 :341-359
+                double V[9];
+                std::memcpy(V, point.m3V, sizeof V);
+                if (V[0] * V[4] * V[8] == 0)
+                    std::fill(point.m3VStarInv, point.m3VStarInv + 9, 0.0);
+                else {
+                    V[1] = V[3];
+                    V[2] = V[6];
+                    V[5] = V[7];
+                    for (int i = 0; i < 3; i++) V[i * 3 + i] *= (1.0 + mdLambda);
+                    LDLT chol(3, V);
+                    chol.inverse(point.m3VStarInv);
+                }
+            }
+            std::vector<double> mS((size_t)n * n, 0.0), vE(n, 0.0);
+            double m6[36], v6[6];
+            for (size_t j = 0; j < mvCameras.size(); j++) {   // diagonal blocks :374-406
+                BCamera& cam_j = mvCameras[j];
+                if (cam_j.bFixed) continue;
+                const int row = cam_j.nStartRow;
+                for (int r = 0; r < 6; r++) {
+                    for (int c = 0; c < r; c++) m6[r * 6 + c] = m6[c * 6 + r] = cam_j.m6U[r * 6 + c];
+                    m6[r * 6 + r] = cam_j.m6U[r * 6 + r];
+                }
+                for (int nn = 0; nn < 6; nn++) m6[nn * 6 + nn] *= (1.0 + mdLambda);
+                std::memcpy(v6, cam_j.v6EpsilonA, sizeof v6);
+                std::vector<Meas*>& lut = mvMeasLUTs[j];
+                for (size_t i = 0; i < mvPoints.size(); i++) {
+                    Meas* pm = lut[i];
+                    if (pm == nullptr || pm->bBad) continue;
+                    const double* Vi = mvPoints[i].m3VStarInv;
+                    double WV[18];
+                    for (int r = 0; r < 6; r++)
+                        for (int c = 0; c < 3; c++)
+                            WV[r * 3 + c] = pm->m63W[r * 3 + 0] * Vi[0 * 3 + c] + pm->m63W[r * 3 + 1] * Vi[1 * 3 + c] +
+                                            pm->m63W[r * 3 + 2] * Vi[2 * 3 + c];
+                    for (int r = 0; r < 6; r++)
+                        for (int c = 0; c < 6; c++)
+                            m6[r * 6 + c] -= WV[r * 3 + 0] * pm->m63W[c * 3 + 0] + WV[r * 3 + 1] * pm->m63W[c * 3 + 1] +
+                                             WV[r * 3 + 2] * pm->m63W[c * 3 + 2];
+                    double ve[3];
+                    for (int r = 0; r < 3; r++)
+                        ve[r] = Vi[r * 3 + 0] * mvPoints[i].v3EpsilonB[0] + Vi[r * 3 + 1] * mvPoints[i].v3EpsilonB[1] +
+                                Vi[r * 3 + 2] * mvPoints[i].v3EpsilonB[2];
+                    for (int r = 0; r < 6; r++)
+                        v6[r] -= pm->m63W[r * 3 + 0] * ve[0] + pm->m63W[r * 3 + 1] * ve[1] + pm->m63W[r * 3 + 2] * ve[2];
+                }
+                for (int r = 0; r < 6; r++) {
+                    for (int c = 0; c < 6; c++) mS[(size_t)(row + r) * n + row + c] = m6[r * 6 + c];
+                    vE[row + r] = v6[r];
+                }
+            }
+            for (size_t i = 0; i < mvPoints.size(); i++) {   // off-diagonal blocks :410-446
+                BPoint& p = mvPoints[i];
+                int nCurrentJ = -1, nJRow = -1;
+                double WV[18];
+                for (auto& e : p.vOffDiagonalScript) {
+                    Meas* pMeas_ik = mvMeasLUTs[e.k][i];
+                    if (pMeas_ik == nullptr || pMeas_ik->bBad) continue;
+                    if (e.j != nCurrentJ) {
+                        Meas* pMeas_ij = mvMeasLUTs[e.j][i];
+                        if (pMeas_ij == nullptr || pMeas_ij->bBad) continue;
+                        nCurrentJ = e.j;
+                        nJRow = mvCameras[e.j].nStartRow;
+                        for (int r = 0; r < 6; r++)
+                            for (int c = 0; c < 3; c++)
+                                WV[r * 3 + c] = pMeas_ij->m63W[r * 3 + 0] * p.m3VStarInv[0 * 3 + c] +
+                                                pMeas_ij->m63W[r * 3 + 1] * p.m3VStarInv[1 * 3 + c] +
+                                                pMeas_ij->m63W[r * 3 + 2] * p.m3VStarInv[2 * 3 + c];
+                    }
+                    const int nKRow = mvCameras[pMeas_ik->c].nStartRow;
+                    for (int r = 0; r < 6; r++)
+                        for (int c = 0; c < 6; c++)
+                            mS[(size_t)(nJRow + r) * n + nKRow + c] -=
+                                WV[r * 3 + 0] * pMeas_ik->m63W[c * 3 + 0] + WV[r * 3 + 1] * pMeas_ik->m63W[c * 3 + 1] +
+                                WV[r * 3 + 2] * pMeas_ik->m63W[c * 3 + 2];
+                    assert(nKRow < nJRow);
+                }
+            }
+            if (comm && world > 1) {   // the one exchange step of the path
+                allreduce(mS.data(), mS.size());
+                allreduce(vE.data(), vE.size());
+            }
+            for (int i = 0; i < n; i++)   // mirror :451-453
+                for (int j = 0; j < i; j++) mS[(size_t)j * n + i] = mS[(size_t)i * n + j];
+
+            std::vector<double> vCamerasUpdate(n, 0.0);   // :457-458
+            if (n > 0) {
+                LDLT chol(n, mS.data());
+                chol.backsub(vE.data(), vCamerasUpdate.data());
+            }
+            std::vector<double> vMapUpdates(mvPoints.size() * 3);   // :461-483
+            for (size_t i = 0; i < mvPoints.size(); i++) {
+                double v3Sum[3] = {0, 0, 0};
+                for (size_t j = 0; j < mvCameras.size(); j++) {
+                    BCamera& cam = mvCameras[j];
+                    if (cam.bFixed) continue;
+                    Meas* pm = mvMeasLUTs[j][i];
+                    if (pm == nullptr || pm->bBad) continue;
+                    const double* da = &vCamerasUpdate[cam.nStartRow];
+                    for (int c = 0; c < 3; c++) {
+                        double s = 0;
+                        for (int r = 0; r < 6; r++) s += pm->m63W[r * 3 + c] * da[r];
+                        v3Sum[c] += s;
+                    }
+                }
+                double v3[3];
+                for (int c = 0; c < 3; c++) v3[c] = mvPoints[i].v3EpsilonB[c] - v3Sum[c];
+                const double* Vi = mvPoints[i].m3VStarInv;
+                for (int r = 0; r < 3; r++)
+                    vMapUpdates[i * 3 + r] = Vi[r * 3 + 0] * v3[0] + Vi[r * 3 + 1] * v3[1] + Vi[r * 3 + 2] * v3[2];
+            }
+            double dMapSq = 0;
+            for (double v : vMapUpdates) dMapSq += v * v;
+            allreduce(&dMapSq, 1);
+            double dSumSquaredUpdate = dMapSq;   // :488-490
+            for (double v : vCamerasUpdate) dSumSquaredUpdate += v * v;
+            if (dSumSquaredUpdate < opts.update_sq_conv_limit) mbConverged = true;
+
+            for (auto& cam : mvCameras) {   // :496-504
+                if (cam.bFixed)
+                    cam.se3CfWNew = cam.se3CfW;
+                else
+                    cam.se3CfWNew = se3_mul(se3_exp(&vCamerasUpdate[cam.nStartRow]), cam.se3CfW);
+            }
+            for (size_t i = 0; i < mvPoints.size(); i++)
+                for (int c = 0; c < 3; c++) mvPoints[i].v3PosNew[c] = mvPoints[i].v3Pos[c] + vMapUpdates[i * 3 + c];
+            dNewError = FindNewError<ME>();   // :506
+            allreduce(&dNewError, 1);
+
+            ptam_ba_trial t;
+            t.lambda = mdLambda;
+            t.sigma_sq = mdSigmaSquared;
+            t.err_old = dCurrentError;
+            t.err_new = dNewError;
+            t.sum_sq_update = dSumSquaredUpdate;
+            t.n_bad = nBadSoFar;
+            t.accepted = 0;
+            if (opts.verbose)
+                std::printf("L%.1e\tOld %.6f  New %.6f  Diff %.6f\n", mdLambda, dCurrentError, dNewError,
+                            dCurrentError - dNewError);
+            if (dNewError > dCurrentError) {   // ModifyLambda_BadStep :607-611
+                mdLambda = mdLambda * mdLambdaFactor;
+                mdLambdaFactor = mdLambdaFactor * 2;
+            }
+            mnCounter++;
+            if (mnCounter >= opts.max_iterations) mbHitMaxIterations = true;
+            trials.push_back(t);
+        }
+        if (dNewError < dCurrentError) {   // :523-533, ModifyLambda_GoodStep :601-605
+            mdLambdaFactor = 2.0;
+            mdLambda *= 0.3;
+            for (auto& c : mvCameras) c.se3CfW = c.se3CfWNew;
+            for (auto& p : mvPoints) std::memcpy(p.v3Pos, p.v3PosNew, sizeof p.v3Pos);
+            mnAccepted++;
+            if (!trials.empty()) trials.back().accepted = 1;
+        }
+        // ditch the outliers :536-547
+        for (auto it = mMeasList.begin(); it != mMeasList.end();) {
+            if (it->bBad) {
+                mvOutlierMeasurementIdx.push_back(std::make_pair(it->p, it->c));
+                mvPoints[it->p].nOutliers++;
+                mvMeasLUTs[it->c][it->p] = nullptr;
+                it = mMeasList.erase(it);
+            } else
+                ++it;
+        }
+        return true;
+    }
+
+    int Compute(const volatile unsigned char* pbAbort) {   // :116-158
+        GenerateMeasLUTs();
+        GenerateOffDiagScripts();
+        mdLambda = 0.0001;
+        mdLambdaFactor = 2.0;
+        mbConverged = false;
+        mbHitMaxIterations = false;
+        mnCounter = 0;
+        mnAccepted = 0;
+        trials.clear();
+        while (!mbConverged && !mbHitMaxIterations && !(pbAbort && *pbAbort)) {
+            bool ok;
+            if (opts.estimator == PTAM_EST_CAUCHY)
+                ok = Do_LM_Step<Cauchy>(pbAbort);
+            else if (opts.estimator == PTAM_EST_HUBER)
+                ok = Do_LM_Step<Huber>(pbAbort);
+            else
+                ok = Do_LM_Step<Tukey>(pbAbort);
+            if (!ok) return -1;
+        }
+        return mnAccepted;
+    }
+};
+
+struct OCtx {
+    ptam_cam_params cam;
+    int variant = PTAM_HALFSAMPLE_R;
+    long cache_hazards = 0;   // ProjectAndDerivs calls that read another point's cached derivs
+};
+
+}   // namespace
+
+// ================================================================================================
+// C entry points (ptamo_*): same structs and argument meaning as include/ptam_hip.h
+// ================================================================================================
+extern "C" {
+
+struct ptamo_ctx {
+    OCtx c;
+};
+struct ptamo_kf {
+    KeyFrame kf;
+    int w = 0, h = 0;
+};
+struct ptamo_ba {
+    Bundle b;
+    ptamo_ba(const ptam_cam_params& cam, const ptam_ba_opts& o) : b(cam, o) {}
+};
+
+const char* ptamo_last_error(void) { return ""; }
+int ptamo_ctx_create(const ptam_cam_params* cam, int /*device*/, ptamo_ctx** out) {
+    if (!cam || !out) return PTAM_E_ARG;
+    *out = new ptamo_ctx();
+    (*out)->c.cam = *cam;
+    return PTAM_OK;
+}
+int ptamo_ctx_destroy(ptamo_ctx* c) {
+    delete c;
+    return PTAM_OK;
+}
+int ptamo_ctx_set_halfsample(ptamo_ctx* c, int v) {
+    c->c.variant = v;
+    return PTAM_OK;
+}
+long ptamo_ctx_cache_hazards(ptamo_ctx* c) { return c->c.cache_hazards; }
+int ptamo_ctx_camera_constants(ptamo_ctx* c, double out[8]) {
+    ATANCamera cam(c->c.cam);
+    out[0] = cam.focal[0];
+    out[1] = cam.focal[1];
+    out[2] = cam.centre[0];
+    out[3] = cam.centre[1];
+    out[4] = cam.two_tan;
+    out[5] = cam.w_inv;
+    out[6] = cam.largest_radius;
+    out[7] = cam.max_r;
+    return PTAM_OK;
+}
+
+int ptamo_half_sample(const uint8_t* in, int w, int h, uint8_t* out, int variant) {
+    half_sample(in, w, h, out, variant);
+    return PTAM_OK;
+}
+int ptamo_fast10(const uint8_t* im, int w, int h, int thr, ptam_int2* out, int cap) {
+    std::vector<ptam_int2> v;
+    fast10(im, w, h, thr, v);
+    const int n = (int)v.size();
+    for (int i = 0; i < n && i < cap; i++) out[i] = v[i];
+    return n;
+}
+
+int ptamo_ctx_sync(ptamo_ctx*) { return PTAM_OK; }
+int ptamo_kf_create(ptamo_ctx*, int w, int h, ptamo_kf** out) {
+    *out = new ptamo_kf();
+    (*out)->w = w;
+    (*out)->h = h;
+    return PTAM_OK;
+}
+int ptamo_kf_destroy(ptamo_kf* k) {
+    delete k;
+    return PTAM_OK;
+}
+int ptamo_make_keyframe_lite(ptamo_ctx* c, ptamo_kf* k, const uint8_t* im, int stride) {
+    k->kf.MakeKeyFrame_Lite(im, k->w, k->h, stride, c->c.variant);
+    return PTAM_OK;
+}
+int ptamo_kf_level_info(ptamo_ctx*, const ptamo_kf* k, int l, int* w, int* h, int* n) {
+    if (l < 0 || l >= PTAM_LEVELS) return PTAM_E_ARG;
+    if (w) *w = k->kf.lev[l].w;
+    if (h) *h = k->kf.lev[l].h;
+    if (n) *n = (int)k->kf.lev[l].corners.size();
+    return PTAM_OK;
+}
+int ptamo_kf_read_level(ptamo_ctx*, const ptamo_kf* k, int l, uint8_t* px, ptam_int2* corners, int32_t* lut) {
+    if (l < 0 || l >= PTAM_LEVELS) return PTAM_E_ARG;
+    const Level& L = k->kf.lev[l];
+    if (px) std::memcpy(px, L.im.data(), L.im.size());
+    if (corners) std::memcpy(corners, L.corners.data(), L.corners.size() * sizeof(ptam_int2));
+    if (lut) std::memcpy(lut, L.rowlut.data(), L.rowlut.size() * sizeof(int));
+    return PTAM_OK;
+}
+
+int ptamo_find_patch_coarse_batch(ptamo_ctx*, const ptamo_kf* k, int n, const ptam_patch_query* q,
+                                  const uint8_t* tmpl, ptam_patch_result* res) {
+    for (int i = 0; i < n; i++) find_patch_coarse(k->kf, q[i], tmpl + (size_t)i * 64, res[i]);
+    return PTAM_OK;
+}
+int ptamo_zmssd_at_points(ptamo_ctx*, const ptamo_kf* k, int level, int n, const ptam_int2* pts,
+                          const uint8_t* tmpl, int32_t* out) {
+    int s, ss;
+    template_sums(tmpl, s, ss);
+    for (int i = 0; i < n; i++) out[i] = zmssd_at_point(k->kf.lev[level], pts[i].x, pts[i].y, tmpl, s, ss, PTAM_MAX_SSD);
+    return PTAM_OK;
+}
+
+int ptamo_project_points(ptamo_ctx* c, int n, const double* world, const double pose[12], ptam_projection* out) {
+    ATANCamera cam(c->c.cam);
+    const SE3 T = se3_from12(pose);
+    for (int i = 0; i < n; i++) {
+        TrackerData td;
+        std::memcpy(td.world, world + 3 * i, sizeof td.world);
+        td.v2Image[0] = td.v2Image[1] = 0;
+        const bool reached = td.Project(T, cam);
+        std::memset(&out[i], 0, sizeof out[i]);
+        std::memcpy(out[i].cam, td.v3Cam, sizeof td.v3Cam);
+        if (reached) {
+            std::memcpy(out[i].image, td.v2Image, sizeof td.v2Image);
+            cam.GetProjectionDerivs(out[i].derivs);
+        }
+        out[i].in_image = td.bInImage;
+    }
+    return PTAM_OK;
+}
+
+void ptamo_gn_opts_default(ptam_gn_opts* o) {
+    o->iterations = 10;
+    o->nonlinear_mask = 0x211;
+    o->override_after = 5;
+    o->override_sigma_sq = 16.0;
+    o->mark_outliers_iter = 9;
+    o->estimator = PTAM_EST_TUKEY;
+    o->prior = 100.0;
+}
+
+// src/Tracker.cc:613-643 (fine stage) / :552-568 (coarse stage) driven by opts
+int ptamo_pose_gn(ptamo_ctx* c, int n, const ptam_pose_meas* meas, const ptam_projection* entry,
+                  double pose[12], const ptam_gn_opts* opts, int32_t* outlier_flags, double* updates_out) {
+    ATANCamera cam(c->c.cam);
+    SE3 T = se3_from12(pose);
+    std::vector<TrackerData> vTD(n);
+    for (int i = 0; i < n; i++) {
+        TrackerData& td = vTD[i];
+        std::memcpy(td.world, meas[i].world, sizeof td.world);
+        std::memcpy(td.v2Found, meas[i].found, sizeof td.v2Found);
+        td.dSqrtInvNoise = meas[i].sqrt_inv_noise;
+        td.bFound = true;
+        if (entry) {
+            std::memcpy(td.v3Cam, entry[i].cam, sizeof td.v3Cam);
+            std::memcpy(td.v2Image, entry[i].image, sizeof td.v2Image);
+            std::memcpy(td.m2CamDerivs, entry[i].derivs, sizeof td.m2CamDerivs);
+        } else {
+            // TrackMap's PVS projection (src/Tracker.cc:454-462): points not in the image never
+            // enter the set
+            td.Project(T, cam);
+            if (!td.bInImage)
+                td.bFound = false;
+            else
+                cam.GetProjectionDerivs(td.m2CamDerivs);
+        }
+        if (outlier_flags) outlier_flags[i] = 0;
+    }
+    double last[6] = {0, 0, 0, 0, 0, 0};
+    for (int iter = 0; iter < opts->iterations; iter++) {
+        const bool nonlinear = (opts->nonlinear_mask >> iter) & 1u;
+        if (iter != 0) {
+            if (nonlinear) {
+                for (auto& td : vTD)
+                    if (td.bFound) {   // ProjectAndDerivs include/Tracker.h:89-94
+                        const bool reached = td.Project(T, cam);
+                        if (reached)
+                            cam.GetProjectionDerivs(td.m2CamDerivs);
+                        else
+                            c->c.cache_hazards++;   // reference would read another point's cache;
+                                                    // oracle and product both keep the old derivs
+                    }
+            } else {
+                for (auto& td : vTD)
+                    if (td.bFound) td.LinearUpdate(last);
+            }
+        }
+        if (nonlinear)
+            for (auto& td : vTD)
+                if (td.bFound) td.CalcJacobian();
+        const double ov = iter > opts->override_after ? opts->override_sigma_sq : 0.0;
+        double mu[6];
+        calc_pose_update(vTD, ov, opts->estimator, opts->prior, iter == opts->mark_outliers_iter, outlier_flags, mu);
+        T = se3_mul(se3_exp(mu), T);
+        std::memcpy(last, mu, sizeof last);
+        if (updates_out) std::memcpy(updates_out + 6 * iter, mu, sizeof mu);
+    }
+    se3_to12(T, pose);
+    return PTAM_OK;
+}
+
+int ptamo_calc_pose_update(ptamo_ctx*, int n, const ptam_pose_update_meas* meas, double override_sigma_sq,
+                           int estimator, double prior, double mu_out[6], int32_t* flags) {
+    std::vector<TrackerData> vTD(n);
+    for (int i = 0; i < n; i++) {
+        vTD[i].bFound = true;
+        std::memcpy(vTD[i].v2Found, meas[i].found, 16);
+        std::memcpy(vTD[i].v2Image, meas[i].image, 16);
+        vTD[i].dSqrtInvNoise = meas[i].sqrt_inv_noise;
+        std::memcpy(vTD[i].m26Jacobian, meas[i].jac, sizeof meas[i].jac);
+        if (flags) flags[i] = 0;
+    }
+    calc_pose_update(vTD, override_sigma_sq, estimator, prior, flags != nullptr, flags, mu_out);
+    return PTAM_OK;
+}
+
+int ptamo_se3_exp(const double mu[6], double out12[12]) {
+    se3_to12(se3_exp(mu), out12);
+    return PTAM_OK;
+}
+int ptamo_se3_mul(const double a[12], const double b[12], double out[12]) {
+    se3_to12(se3_mul(se3_from12(a), se3_from12(b)), out);
+    return PTAM_OK;
+}
+double ptamo_tukey_sigma_sq(const double* e2, int n) {
+    std::vector<double> v(e2, e2 + n);
+    return Tukey::FindSigmaSquared(v);
+}
+int ptamo_ldlt_solve(int n, const double* A, const double* b, double* x) {
+    LDLT c(n, A);
+    c.backsub(b, x);
+    return PTAM_OK;
+}
+
+void ptamo_ba_opts_default(ptam_ba_opts* o) {
+    o->max_iterations = 20;
+    o->update_sq_conv_limit = 1e-6;
+    o->min_sigma = 0.4;
+    o->estimator = PTAM_EST_TUKEY;
+    o->verbose = 0;
+}
+int ptamo_ba_create(ptamo_ctx* c, const ptam_ba_opts* opts, ptamo_ba** out) {
+    ptam_ba_opts o;
+    if (opts)
+        o = *opts;
+    else
+        ptamo_ba_opts_default(&o);
+    *out = new ptamo_ba(c->c.cam, o);
+    return PTAM_OK;
+}
+int ptamo_ba_destroy(ptamo_ba* b) {
+    delete b;
+    return PTAM_OK;
+}
+int ptamo_ba_add_camera(ptamo_ba* b, const double pose[12], int fixed) {
+    return b->b.AddCamera(se3_from12(pose), fixed != 0);
+}
+int ptamo_ba_add_point(ptamo_ba* b, const double pos[3]) { return b->b.AddPoint(pos); }
+int ptamo_ba_add_meas(ptamo_ba* b, int cam, int point, const double found[2], double sigma_sq) {
+    if (cam < 0 || cam >= (int)b->b.mvCameras.size() || point < 0 || point >= (int)b->b.mvPoints.size())
+        return PTAM_E_ARG;
+    b->b.AddMeas(cam, point, found, sigma_sq);
+    return PTAM_OK;
+}
+int ptamo_ba_add_cameras(ptamo_ba* b, int n, const double* poses, const uint8_t* fixed) {
+    for (int i = 0; i < n; i++) b->b.AddCamera(se3_from12(poses + 12 * i), fixed[i] != 0);
+    return PTAM_OK;
+}
+int ptamo_ba_add_points(ptamo_ba* b, int n, const double* pos) {
+    for (int i = 0; i < n; i++) b->b.AddPoint(pos + 3 * i);
+    return PTAM_OK;
+}
+int ptamo_ba_add_measurements(ptamo_ba* b, int n, const int32_t* cam, const int32_t* point, const double* found,
+                              const double* sigma_sq) {
+    for (int i = 0; i < n; i++) {
+        const int rc = ptamo_ba_add_meas(b, cam[i], point[i], found + 2 * i, sigma_sq[i]);
+        if (rc) return rc;
+    }
+    return PTAM_OK;
+}
+int ptamo_ba_compute(ptamo_ba* b, const volatile unsigned char* abort_flag, int* accepted) {
+    const int a = b->b.Compute(abort_flag);
+    if (accepted) *accepted = a;
+    return PTAM_OK;
+}
+int ptamo_ba_converged(const ptamo_ba* b) { return b->b.mbConverged; }
+int ptamo_ba_counts(const ptamo_ba* b, int* nc, int* nf, int* np, int* nm) {
+    if (nc) *nc = (int)b->b.mvCameras.size();
+    if (nf) *nf = b->b.mnCamsToUpdate;
+    if (np) *np = (int)b->b.mvPoints.size();
+    if (nm) *nm = (int)b->b.mMeasList.size();
+    return PTAM_OK;
+}
+int ptamo_ba_get_point(const ptamo_ba* b, int n, double pos[3]) {
+    if (n < 0 || n >= (int)b->b.mvPoints.size()) return PTAM_E_ARG;
+    std::memcpy(pos, b->b.mvPoints[n].v3Pos, 24);
+    return PTAM_OK;
+}
+int ptamo_ba_get_camera(const ptamo_ba* b, int n, double pose[12]) {
+    if (n < 0 || n >= (int)b->b.mvCameras.size()) return PTAM_E_ARG;
+    se3_to12(b->b.mvCameras[n].se3CfW, pose);
+    return PTAM_OK;
+}
+int ptamo_ba_get_all(const ptamo_ba* b, double* poses, double* points) {
+    for (size_t i = 0; i < b->b.mvCameras.size(); i++) se3_to12(b->b.mvCameras[i].se3CfW, poses + 12 * i);
+    for (size_t i = 0; i < b->b.mvPoints.size(); i++) std::memcpy(points + 3 * i, b->b.mvPoints[i].v3Pos, 24);
+    return PTAM_OK;
+}
+int ptamo_ba_get_outliers(const ptamo_ba* b, int32_t* pairs, int cap) {
+    const int n = (int)b->b.mvOutlierMeasurementIdx.size();
+    for (int i = 0; i < n && i < cap; i++) {
+        pairs[2 * i] = b->b.mvOutlierMeasurementIdx[i].first;
+        pairs[2 * i + 1] = b->b.mvOutlierMeasurementIdx[i].second;
+    }
+    return n;
+}
+int ptamo_ba_get_trials(const ptamo_ba* b, ptam_ba_trial* out, int cap) {
+    const int n = (int)b->b.trials.size();
+    for (int i = 0; i < n && i < cap; i++) out[i] = b->b.trials[i];
+    return n;
+}
+int ptamo_ba_set_comm(ptamo_ba* b, int rank, int world, ptam_allreduce_f64_fn fn, void* user) {
+    b->b.rank = rank;
+    b->b.world = world;
+    b->b.comm = fn;
+    b->b.comm_user = user;
+    return PTAM_OK;
+}
+
+}   // extern "C"

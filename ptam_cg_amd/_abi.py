@@ -1,0 +1,154 @@
+"""ctypes view of include/ptam_hip.h: struct layouts and prototypes.
+
+`bind(lib, prefix)` attaches argtypes/restypes for every entry point that the given shared library
+exports under `prefix` ("ptam_" for libptam_hip.so).  The binding is prefix-generic so that the
+test-suite can drive its CPU checker through the very same host classes; the package itself only
+ever loads libptam_hip.so (see _lib.py).
+"""
+import ctypes as C
+
+LEVELS = 4
+MAX_SSD = 8 * 8 * 500
+HALFSAMPLE_R, HALFSAMPLE_T = 0, 1
+EST_TUKEY, EST_CAUCHY, EST_HUBER = 0, 1, 2
+K_PROJECT, K_SELECT, K_JACOBIAN, K_VINV, K_SCHUR, K_SOLVE, K_UPDATE, K_COUNT = range(8)
+KERNEL_NAMES = ["project", "select", "jacobian", "vinv", "schur", "solve", "update"]
+
+
+class Int2(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32)]
+
+
+class CamParams(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("w", C.c_double), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class PatchQuery(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("level", C.c_int32), ("range", C.c_uint32)]
+
+
+class PatchResult(C.Structure):
+    _fields_ = [("found", C.c_int32), ("best_ssd", C.c_int32), ("best_x", C.c_int32),
+                ("best_y", C.c_int32), ("n_scored", C.c_int32), ("pad_", C.c_int32),
+                ("pos", C.c_double * 2)]
+
+
+class Projection(C.Structure):
+    _fields_ = [("cam", C.c_double * 3), ("image", C.c_double * 2), ("derivs", C.c_double * 4),
+                ("in_image", C.c_int32), ("pad_", C.c_int32)]
+
+
+class PoseMeas(C.Structure):
+    _fields_ = [("world", C.c_double * 3), ("found", C.c_double * 2), ("sqrt_inv_noise", C.c_double)]
+
+
+class GnOpts(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("nonlinear_mask", C.c_uint32),
+                ("override_after", C.c_int32), ("override_sigma_sq", C.c_double),
+                ("mark_outliers_iter", C.c_int32), ("estimator", C.c_int32), ("prior", C.c_double)]
+
+
+class PoseUpdateMeas(C.Structure):
+    _fields_ = [("found", C.c_double * 2), ("image", C.c_double * 2), ("sqrt_inv_noise", C.c_double),
+                ("jac", C.c_double * 12)]
+
+
+class BaOpts(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("update_sq_conv_limit", C.c_double),
+                ("min_sigma", C.c_double), ("estimator", C.c_int32), ("verbose", C.c_int32)]
+
+
+class BaTrial(C.Structure):
+    _fields_ = [("lambda_", C.c_double), ("sigma_sq", C.c_double), ("err_old", C.c_double),
+                ("err_new", C.c_double), ("sum_sq_update", C.c_double), ("n_bad", C.c_int32),
+                ("accepted", C.c_int32)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.c_void_p)
+
+_vp, _i, _d = C.c_void_p, C.c_int, C.c_double
+_pd, _pi, _pu8 = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+_ppv = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes).  Names are given WITHOUT the prefix.
+PROTOTYPES = {
+    "last_error": (C.c_char_p, []),
+    "device_count": (_i, [C.POINTER(_i)]),
+    "ctx_create": (_i, [C.POINTER(CamParams), _i, _ppv]),
+    "ctx_destroy": (_i, [_vp]),
+    "ctx_set_halfsample": (_i, [_vp, _i]),
+    "ctx_sync": (_i, [_vp]),
+    "ctx_stream": (_vp, [_vp]),
+    "ctx_camera_constants": (_i, [_vp, _pd]),
+    "dev_alloc": (_i, [_vp, C.c_size_t, _ppv]),
+    "dev_free": (_i, [_vp, _vp]),
+    "dev_upload": (_i, [_vp, _vp, _vp, C.c_size_t]),
+    "dev_download": (_i, [_vp, _vp, _vp, C.c_size_t]),
+    "kf_create": (_i, [_vp, _i, _i, _ppv]),
+    "kf_destroy": (_i, [_vp]),
+    "make_keyframe_lite": (_i, [_vp, _vp, _vp, _i]),
+    "make_keyframe_lite_dev": (_i, [_vp, _vp, _vp]),
+    "kf_clone": (_i, [_vp, _vp, _ppv]),
+    "kf_level_info": (_i, [_vp, _vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "kf_read_level": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "find_patch_coarse_batch": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "find_patch_coarse_batch_dev": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "zmssd_at_points": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "project_points": (_i, [_vp, _i, _vp, _pd, _vp]),
+    "gn_opts_default": (None, [C.POINTER(GnOpts)]),
+    "pose_gn": (_i, [_vp, _i, _vp, _vp, _pd, C.POINTER(GnOpts), _vp, _vp]),
+    "calc_pose_update": (_i, [_vp, _i, _vp, _d, _i, _d, _pd, _vp]),
+    "ba_opts_default": (None, [C.POINTER(BaOpts)]),
+    "ba_create": (_i, [_vp, C.POINTER(BaOpts), _ppv]),
+    "ba_destroy": (_i, [_vp]),
+    "ba_add_camera": (_i, [_vp, _pd, _i]),
+    "ba_add_point": (_i, [_vp, _pd]),
+    "ba_add_meas": (_i, [_vp, _i, _i, _pd, _d]),
+    "ba_add_cameras": (_i, [_vp, _i, _vp, _vp]),
+    "ba_add_points": (_i, [_vp, _i, _vp]),
+    "ba_add_measurements": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "ba_compute": (_i, [_vp, _vp, C.POINTER(_i)]),
+    "ba_converged": (_i, [_vp]),
+    "ba_get_point": (_i, [_vp, _i, _pd]),
+    "ba_get_camera": (_i, [_vp, _i, _pd]),
+    "ba_get_all": (_i, [_vp, _vp, _vp]),
+    "ba_get_outliers": (_i, [_vp, _vp, _i]),
+    "ba_get_trials": (_i, [_vp, _vp, _i]),
+    "ba_counts": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "ba_set_profiling": (_i, [_vp, _i]),
+    "ba_kernel_time": (_i, [_vp, _i, _pd, C.POINTER(_i)]),
+    "ba_prepare": (_i, [_vp]),
+    "ba_bench_jacobian": (_i, [_vp, _i, _pd, _pd]),
+    "ba_set_comm": (_i, [_vp, _i, _i, ALLREDUCE_FN, _vp]),
+    "rccl_unique_id": (_i, [_vp]),
+    "rccl_create": (_i, [_vp, _vp, _i, _i, _ppv]),
+    "rccl_destroy": (_i, [_vp]),
+    "rccl_allreduce_f64": (_i, [_vp, _pd, C.c_size_t, _vp]),
+}
+
+# every symbol include/ptam_hip.h declares (checked by the CPU test-suite against the built .so)
+DECLARED = sorted(PROTOTYPES)
+
+
+class Bound:
+    """Attribute access to `<prefix><name>` functions of one shared library."""
+
+    def __init__(self, lib, prefix):
+        self.lib, self.prefix = lib, prefix
+        self.missing = []
+        for name, (res, args) in PROTOTYPES.items():
+            try:
+                fn = getattr(lib, prefix + name)
+            except AttributeError:
+                self.missing.append(name)
+                continue
+            fn.restype, fn.argtypes = res, args
+            setattr(self, name, fn)
+
+    def has(self, name):
+        return hasattr(self, name)
+
+
+def bind(lib, prefix):
+    return Bound(lib, prefix)

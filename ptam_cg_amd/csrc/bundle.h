@@ -1,0 +1,109 @@
+// bundle.h — device data layout of the bundle adjuster (Bundle, include/Bundle.h:106-152).
+//
+// HBM layout (all fp64 unless noted; M = measurements, P = points, C = cameras, F = free cameras):
+//   measurements are sorted POINT-MAJOR (point id, then camera id) at Compute() time — the CSR
+//   `rowptr[P+1]` replaces the reference's dense C x P pointer LUT (src/Bundle.cc:558-567) and its
+//   per-point off-diagonal scripts (:572-599).  Planar (SoA) arrays so that a wave's 64 lanes touch
+//   64 consecutive elements:
+//     m_cam[M] i32 | m_pt[M] i32 | m_found[M] double2 | m_s[M] f64 | m_state[M] u8 | m_orig[M] i32
+//     m_e2[M]                       squared error of pass 1
+//     W[9][M] double2               W_ij = A^T B (6x3 row-major, 18 doubles) as 9 planes of double2
+//   points:  pt[2][P][3] (current / trial), V[P][6] (lower 00,10,11,20,21,22), epsB[P][3],
+//            Vinv[P][9]
+//   cameras: pose[2][C][12] (current / trial), U[F][21] lower-triangle row-major, epsA[F][6]
+//   camera system: SE = [ S (npad x npad, lower triangle valid) | E (npad) ] contiguous so that the
+//            sharded path all-reduces ONE buffer; L (npad x npad) + Dg (npad) hold the LDL^T factor.
+#pragma once
+#include "common.h"
+
+enum { MS_ALIVE = 0, MS_BAD = 1, MS_DEAD = 2 };
+
+#define BA_CHUNK 256          // threads per measurement block; a block owns whole points
+#define SCHUR_TC 8            // cameras per Schur tile (48 rows)
+#define SOLVE_NB 32           // LDL^T block size
+#define HIST_BINS 4096        // first-level histogram of the order-statistic select (bits 62..51)
+
+struct BaChunk {
+    int pt_begin, pt_end, m_begin, m_end;
+};
+
+// one (camera-tile pair, point) work item of the Schur build
+struct SchurEntry {
+    int pt;         // point id
+    int ma;         // first measurement of the point inside tile a
+    int mb;         // first measurement of the point inside tile b
+    int na_nb;      // na | nb << 16   (measurement counts, fixed cameras included)
+};
+struct SchurWG {
+    int pair;       // tile pair index a*(a+1)/2 + b
+    int e_begin, e_end;
+};
+
+// device scalars shared between kernels and read back once per trial
+struct BaScalars {
+    double sigma_sq;        // mdSigmaSquared
+    double cur_err;         // dCurrentError
+    double new_err;         // dNewError
+    double sumsq_cam;       // |delta a|^2
+    double sumsq_pt;        // |delta b|^2
+    double median;          // selected order statistic
+    long long n_valid;      // non-bad measurements in pass 1
+    int n_bad;              // measurements flagged bad so far in this LM step
+    int n_outliers;         // total entries in the outlier list
+    int sel_bin;            // first-level bin of the order statistic
+    int sel_k;              // residual rank inside that bin
+    int n_cand;             // compacted candidates
+    int pad_;
+};
+
+struct BaDev {
+    int C, F, P, M;
+    int n, npad;            // camera system order 6F and its padding to SOLVE_NB
+    int n_chunks, grid_acc; // measurement chunks; persistent grid of the accumulate kernel
+    int n_tiles, n_pairs, n_schur_wg, n_schur_entries;
+    // cameras
+    double* pose[2];
+    int* cam_free;          // [C] free index or -1
+    // points
+    double* pt[2];
+    double* V;
+    double* epsB;
+    double* Vinv;
+    int* rowptr;
+    // measurements
+    int* m_cam;
+    int* m_pt;
+    double2* m_found;
+    double* m_s;
+    int* m_orig;
+    uint8_t* m_state;
+    double* m_e2;
+    double2* W;
+    // accumulators
+    double* U;              // [F][21]
+    double* epsA;           // [F][6]
+    double* Upart;          // [grid_acc][F*27]
+    double* err_part;       // [max(n_chunks, grid_acc)][2]
+    int* bad_part;          // [grid_acc]
+    BaChunk* chunks;
+    // select
+    unsigned* hist;         // [HIST_BINS]
+    double* cand;           // [M]
+    // Schur
+    SchurEntry* s_entries;
+    SchurWG* s_wgs;
+    int* s_pair_wg_begin;   // [n_pairs+1] first WG of each pair
+    double* s_part;         // [n_schur_wg][48*48 + 48]
+    // camera system
+    double* SE;             // S then E
+    double* L;
+    double* Dg;
+    double* y;              // forward-substituted rhs
+    double* da;             // [npad] camera update
+    // outliers
+    int* outliers;          // [M] original indices, in purge order
+    BaScalars* sc;
+};
+
+// solve.hip
+int ba_solve(ptam_ctx* ctx, BaDev& d);

@@ -1,0 +1,1672 @@
+// bundle.hip — Bundle::Compute (src/Bundle.cc:116-158) and Do_LM_Step (:209-551) on gfx950.
+//
+// Kernels (DESIGN.md has the byte counts):
+//   K5  project_e2_kernel     pass 1 (:219-225, :164-180) + first-level histogram of e^2
+//   K6  select_*_kernel       exact order statistic sorted[n/2] (include/Tools.h:152-162) by radix
+//                             select on the fp64 bit pattern -> sigma^2 (floor MinTukeySigma^2 :234-237)
+//   K7  jac_accum_kernel      pass 2 (:250-332) FUSED: weight, A(2x6), B(2x3), U += A^T A, epsA,
+//                             V += B^T B, epsB, W = A^T B.  Roofline kernel (HBM-bound, ~185 B/meas).
+//       reduce_partials_kernel  fixed-order sum of the per-workgroup camera partials
+//   K8a vinv_kernel           V*^-1 (:341-359)
+//   K8  schur_tile_kernel     S = U* - sum_i (W V*^-1) W^T, E = epsA - sum_i W V*^-1 epsB (:374-446),
+//                             output-stationary over 8x8-camera tiles; schur_reduce_kernel sums the
+//                             tile partials in fixed order (deterministic) and writes S lower / E
+//   K9  solve.hip             blocked LDL^T + substitutions (:457-458)
+//   K10 pose_update_kernel, point_update_kernel, finalize_new_kernel
+//                             delta b (:461-483), update norm (:488-490), trial poses/points
+//                             (:496-504), new robust error (:188-207, :506)
+//       purge_kernel          erase bad measurements, record outliers (:536-547)
+// The lambda-trial control flow, convergence test and abort polling stay on the host, one readback of
+// a 64-byte scalar block per trial.
+#include <algorithm>
+#include <numeric>
+#include <utility>
+
+#include "bundle.h"
+
+// =================================================================================================
+// device helpers
+// =================================================================================================
+__device__ __forceinline__ int e2_bin(double e2) {
+    return (int)(((unsigned long long)__double_as_longlong(e2) >> 51) & (HIST_BINS - 1));
+}
+
+// project one measurement: returns false (bad) if z <= 0  (ProjectAndFindSquaredError :164-180)
+__device__ __forceinline__ bool ba_project(const DevCam& cam, const double* __restrict__ T, const double* __restrict__ X,
+                                           double& cx, double& cy, double& cz, double& x, double& y, double& u,
+                                           double& v, double& r, double& f) {
+    se3_apply(T, X[0], X[1], X[2], cx, cy, cz);
+    if (cz <= 0) return false;
+    x = cx / cz;
+    y = cy / cz;
+    cam_project(cam, x, y, u, v, r, f);
+    return true;
+}
+
+// =================================================================================================
+// K5: pass 1
+// =================================================================================================
+__global__ void __launch_bounds__(BA_CHUNK) project_e2_kernel(DevCam cam, BaDev d, int cur, int build_hist) {
+    __shared__ unsigned hist[HIST_BINS];
+    const int tid = threadIdx.x;
+    if (build_hist)
+        for (int b = tid; b < HIST_BINS; b += BA_CHUNK) hist[b] = 0;
+    __syncthreads();
+    const double* __restrict__ pose = d.pose[cur];
+    const double* __restrict__ pt = d.pt[cur];
+    for (int ci = blockIdx.x; ci < d.n_chunks; ci += gridDim.x) {
+        const BaChunk ch = d.chunks[ci];
+        const int m = ch.m_begin + tid;
+        if (m < ch.m_end) {
+            const int st = d.m_state[m];
+            if (st != MS_DEAD) {
+                const int c = d.m_cam[m], p = d.m_pt[m];
+                double cx, cy, cz, x, y, u, v, r, f;
+                if (!ba_project(cam, pose + 12 * c, pt + 3 * p, cx, cy, cz, x, y, u, v, r, f)) {
+                    d.m_state[m] = MS_BAD;
+                } else {
+                    const double2 fo = d.m_found[m];
+                    const double s = d.m_s[m];
+                    const double ex = s * (fo.x - u), ey = s * (fo.y - v);
+                    const double e2 = ex * ex + ey * ey;
+                    d.m_e2[m] = e2;
+                    if (st != MS_ALIVE) d.m_state[m] = MS_ALIVE;
+                    if (build_hist) atomicAdd(&hist[e2_bin(e2)], 1u);
+                }
+            }
+        }
+    }
+    if (build_hist) {
+        __syncthreads();
+        for (int b = tid; b < HIST_BINS; b += BA_CHUNK) {
+            const unsigned c = hist[b];
+            if (c) atomicAdd(&d.hist[b], c);
+        }
+    }
+}
+
+// =================================================================================================
+// K6: exact order statistic
+// =================================================================================================
+// histogram of an explicit key array (sharded mode: the gathered e^2 of all ranks)
+__global__ void __launch_bounds__(256) hist_keys_kernel(const double* __restrict__ keys, long long n, unsigned* __restrict__ ghist) {
+    __shared__ unsigned hist[HIST_BINS];
+    for (int b = threadIdx.x; b < HIST_BINS; b += 256) hist[b] = 0;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        atomicAdd(&hist[e2_bin(keys[i])], 1u);
+    __syncthreads();
+    for (int b = threadIdx.x; b < HIST_BINS; b += 256) {
+        const unsigned c = hist[b];
+        if (c) atomicAdd(&ghist[b], c);
+    }
+}
+
+// one block: find the first-level bin holding rank n_valid/2
+__global__ void __launch_bounds__(1024) select_find_bin_kernel(BaDev d) {
+    __shared__ long long wsum[16];
+    __shared__ long long total_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    unsigned c[4];
+    long long s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        c[j] = d.hist[4 * tid + j];
+        s += c[j];
+    }
+    long long incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        long long run = 0;
+        for (int i = 0; i < 16; i++) {
+            const long long v = wsum[i];
+            wsum[i] = run;
+            run += v;
+        }
+        total_s = run;
+    }
+    __syncthreads();
+    const long long total = total_s;
+    const long long k = total / 2;   // vdErrorSquared[size()/2]
+    const long long excl = wsum[wid] + incl - s;
+    if (tid == 0) {
+        d.sc->n_valid = total;
+        d.sc->n_cand = 0;
+        if (total == 0) {
+            d.sc->sel_bin = -1;
+            d.sc->sel_k = 0;
+        }
+    }
+    if (total > 0 && excl <= k && k < excl + s) {
+        long long kk = k - excl;
+        int b = 4 * tid;
+        for (int j = 0; j < 3; j++)
+            if (kk >= c[j]) {
+                kk -= c[j];
+                b++;
+            } else
+                break;
+        d.sc->sel_bin = b;
+        d.sc->sel_k = (int)kk;
+    }
+}
+
+// gather the keys of the selected bin (keys = m_e2 masked by state, or an explicit array)
+__global__ void __launch_bounds__(256) select_compact_kernel(BaDev d, const double* __restrict__ keys, long long n,
+                                                             const uint8_t* __restrict__ state) {
+    const int bin = d.sc->sel_bin;
+    if (bin < 0) return;
+    const int lane = threadIdx.x & 63;
+    for (long long base = (long long)blockIdx.x * 256; base < n; base += (long long)gridDim.x * 256) {
+        const long long i = base + threadIdx.x;
+        bool take = false;
+        double key = 0;
+        if (i < n && (!state || state[i] == MS_ALIVE)) {
+            key = keys[i];
+            take = e2_bin(key) == bin;
+        }
+        const unsigned long long m = __ballot(take);
+        if (m) {
+            int pos = 0;
+            if (lane == 0) pos = atomicAdd(&d.sc->n_cand, __popcll(m));
+            pos = __shfl(pos, 0, 64);
+            if (take) d.cand[pos + __popcll(m & ((1ull << lane) - 1ull))] = key;
+        }
+    }
+}
+
+// one block: radix select of rank sel_k among the candidates; sigma^2; reset the histogram
+__global__ void __launch_bounds__(1024) select_final_kernel(BaDev d, int est, double min_sigma_sq) {
+    __shared__ unsigned hist[256];
+    __shared__ int s_digit, s_k;
+    const int tid = threadIdx.x;
+    const int n = d.sc->n_cand;
+    int k = d.sc->sel_k;
+    unsigned long long prefix = 0;
+    if (n > 0) {
+        prefix = (unsigned long long)__double_as_longlong(d.cand[0]) & ~((1ull << 56) - 1ull);
+        for (int pass = 0; pass < 7; pass++) {
+            const int shift = 48 - 8 * pass;
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += 1024) {
+                const unsigned long long key = (unsigned long long)__double_as_longlong(d.cand[i]);
+                if ((key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 255], 1u);
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const unsigned c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+                const int s = (int)(c0 + c1 + c2 + c3);
+                int incl = s;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(incl, o, 64);
+                    if (tid >= o) incl += v;
+                }
+                const int excl = incl - s;
+                if (excl <= k && k < incl) {
+                    int kk = k - excl, dg = 4 * tid;
+                    if (kk >= (int)c0) {
+                        kk -= c0;
+                        dg++;
+                        if (kk >= (int)c1) {
+                            kk -= c1;
+                            dg++;
+                            if (kk >= (int)c2) {
+                                kk -= c2;
+                                dg++;
+                            }
+                        }
+                    }
+                    s_digit = dg;
+                    s_k = kk;
+                }
+            }
+            __syncthreads();
+            prefix |= (unsigned long long)s_digit << shift;
+            k = s_k;
+            __syncthreads();
+        }
+    }
+    for (int b = tid; b < HIST_BINS; b += 1024) d.hist[b] = 0;
+    if (tid == 0) {
+        const double med = n > 0 ? __longlong_as_double((long long)prefix) : 0.0;
+        d.sc->median = med;
+        double s2 = est_sigma_sq_from_median(est, med, (unsigned long long)d.sc->n_valid);
+        if (s2 < min_sigma_sq) s2 = min_sigma_sq;   // :234-237
+        d.sc->sigma_sq = s2;
+        d.sc->n_bad = 0;
+    }
+}
+
+// compact this rank's valid e^2 (sharded mode)
+__global__ void __launch_bounds__(256) compact_valid_kernel(BaDev d, double* __restrict__ out, int* __restrict__ counter) {
+    const int lane = threadIdx.x & 63;
+    for (int base = blockIdx.x * 256; base < d.M; base += gridDim.x * 256) {
+        const int i = base + threadIdx.x;
+        const bool take = i < d.M && d.m_state[i] == MS_ALIVE;
+        const unsigned long long m = __ballot(take);
+        if (m) {
+            int pos = 0;
+            if (lane == 0) pos = atomicAdd(counter, __popcll(m));
+            pos = __shfl(pos, 0, 64);
+            if (take) out[pos + __popcll(m & ((1ull << lane) - 1ull))] = d.m_e2[i];
+        }
+    }
+}
+
+// =================================================================================================
+// K7: fused Jacobian + normal-equation accumulation (pass 2, :250-332)
+// =================================================================================================
+// dynamic LDS: Ul[F*27] camera partials | Bs[BA_CHUNK][8] per-measurement B (2x3) and weighted eps
+__global__ void __launch_bounds__(BA_CHUNK) jac_accum_kernel(DevCam cam, BaDev d, int cur, int est) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* Ul = smem;
+    double* Bs = smem + (((size_t)d.F * 27 + 1) & ~(size_t)1);
+    const int tid = threadIdx.x;
+    for (int k = tid; k < d.F * 27; k += BA_CHUNK) Ul[k] = 0;
+    __syncthreads();
+    const double* __restrict__ pose = d.pose[cur];
+    const double* __restrict__ pt = d.pt[cur];
+    const double sigma_sq = d.sc->sigma_sq;
+    double err = 0;
+    int nbad = 0;
+    for (int ci = blockIdx.x; ci < d.n_chunks; ci += gridDim.x) {
+        const BaChunk ch = d.chunks[ci];
+        const int m = ch.m_begin + tid;
+        double B0[3] = {0, 0, 0}, B1[3] = {0, 0, 0}, ex = 0, ey = 0;
+        if (m < ch.m_end) {
+            double Wv[18];
+#pragma unroll
+            for (int k = 0; k < 18; k++) Wv[k] = 0;
+            const int st = d.m_state[m];
+            if (st == MS_BAD) {   // z <= 0 in pass 1  (:259-263)
+                err += 1.0;
+                nbad++;
+            } else if (st == MS_ALIVE) {
+                const int c = d.m_cam[m], p = d.m_pt[m];
+                const double* __restrict__ T = pose + 12 * c;
+                double X, Y, Z, x, y, u, v, r, f;
+                ba_project(cam, T, pt + 3 * p, X, Y, Z, x, y, u, v, r, f);
+                const double2 fo = d.m_found[m];
+                const double s = d.m_s[m];
+                ex = s * (fo.x - u);
+                ey = s * (fo.y - v);
+                const double e2 = ex * ex + ey * ey;
+                const double w = est_sqrt_weight(est, e2, sigma_sq);
+                ex *= w;   // meas.v2Epsilon = dWeight * meas.v2Epsilon  (:272)
+                ey *= w;
+                if (w == 0) {   // :274-279
+                    d.m_state[m] = MS_BAD;
+                    err += 1.0;
+                    nbad++;
+                    ex = ey = 0;
+                } else {
+                    err += est_objective(est, e2, sigma_sq);
+                    double D[4];
+                    cam_derivs(cam, x, y, r, f, D);
+                    // fold sqrt-weight and dSqrtInvNoise into the camera derivatives (:285, :302)
+                    const double D0 = s * w * D[0], D1 = s * w * D[1], D2 = s * w * D[2], D3 = s * w * D[3];
+                    const double iz = 1.0 / Z;
+                    // B: point Jacobian, motion = m-th column of R_cw (:306-313)
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const double g0 = T[k], g1 = T[3 + k], g2 = T[6 + k];
+                        const double mx = (g0 - X * g2 * iz) * iz, my = (g1 - Y * g2 * iz) * iz;
+                        B0[k] = D0 * mx + D1 * my;
+                        B1[k] = D2 * mx + D3 * my;
+                    }
+                    const int fidx = d.cam_free[c];
+                    if (fidx >= 0) {
+                        // A: camera Jacobian, SE3 generator fields (:291-303)
+                        const double gx[6] = {1, 0, 0, 0, Z, -Y};
+                        const double gy[6] = {0, 1, 0, -Z, 0, X};
+                        const double gz[6] = {0, 0, 1, Y, -X, 0};
+                        double A0[6], A1[6];
+#pragma unroll
+                        for (int k = 0; k < 6; k++) {
+                            const double mx = (gx[k] - X * gz[k] * iz) * iz, my = (gy[k] - Y * gz[k] * iz) * iz;
+                            A0[k] = D0 * mx + D1 * my;
+                            A1[k] = D2 * mx + D3 * my;
+                        }
+                        double* Uc = Ul + fidx * 27;
+                        int k = 0;
+#pragma unroll
+                        for (int a = 0; a < 6; a++)
+#pragma unroll
+                            for (int b = 0; b <= a; b++) atomicAdd(&Uc[k++], A0[a] * A0[b] + A1[a] * A1[b]);   // U_LL :21-26
+#pragma unroll
+                        for (int a = 0; a < 6; a++) atomicAdd(&Uc[21 + a], A0[a] * ex + A1[a] * ey);       // epsA :321
+#pragma unroll
+                        for (int a = 0; a < 6; a++)
+#pragma unroll
+                            for (int b = 0; b < 3; b++) Wv[a * 3 + b] = A0[a] * B0[b] + A1[a] * B1[b];   // W = A^T B :331
+                    }
+                }
+            }
+            // W planes: 9 x double2, coalesced across the wave
+#pragma unroll
+            for (int k = 0; k < 9; k++) d.W[(size_t)k * d.M + m] = make_double2(Wv[2 * k], Wv[2 * k + 1]);
+        }
+        double* bs = Bs + tid * 8;
+        bs[0] = B0[0];
+        bs[1] = B0[1];
+        bs[2] = B0[2];
+        bs[3] = B1[0];
+        bs[4] = B1[1];
+        bs[5] = B1[2];
+        bs[6] = ex;
+        bs[7] = ey;
+        __syncthreads();
+        // V_LL += B^T B, epsB += B^T eps : this block owns every measurement of its points, so the
+        // sums are complete and written once, in measurement order (deterministic)  (:325-326)
+        const int npts = ch.pt_end - ch.pt_begin;
+        for (int task = tid; task < npts * 9; task += BA_CHUNK) {
+            const int pi = task / 9, o = task - pi * 9;
+            const int p = ch.pt_begin + pi;
+            const int r0 = d.rowptr[p] - ch.m_begin, r1 = d.rowptr[p + 1] - ch.m_begin;
+            double acc = 0;
+            if (o < 6) {
+                const int a = o < 1 ? 0 : (o < 3 ? 1 : 2);
+                const int b = o - (a * (a + 1)) / 2;
+                for (int rr = r0; rr < r1; rr++) {
+                    const double* q = Bs + rr * 8;
+                    acc += q[a] * q[b] + q[3 + a] * q[3 + b];
+                }
+                d.V[(size_t)p * 6 + o] = acc;
+            } else {
+                const int a = o - 6;
+                for (int rr = r0; rr < r1; rr++) {
+                    const double* q = Bs + rr * 8;
+                    acc += q[a] * q[6] + q[3 + a] * q[7];
+                }
+                d.epsB[(size_t)p * 3 + a] = acc;
+            }
+        }
+        __syncthreads();
+    }
+    // flush this workgroup's camera partials + error partial
+    double* up = d.Upart + (size_t)blockIdx.x * d.F * 27;
+    for (int k = tid; k < d.F * 27; k += BA_CHUNK) up[k] = Ul[k];
+    __shared__ double werr[BA_CHUNK / 64];
+    __shared__ int wbad[BA_CHUNK / 64];
+    err = wave_sum_f64(err);
+    nbad = wave_sum_i32(nbad);
+    if ((tid & 63) == 0) {
+        werr[tid >> 6] = err;
+        wbad[tid >> 6] = nbad;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double e = 0;
+        int b = 0;
+        for (int i = 0; i < BA_CHUNK / 64; i++) {
+            e += werr[i];
+            b += wbad[i];
+        }
+        d.err_part[2 * blockIdx.x] = e;
+        d.bad_part[blockIdx.x] = b;
+    }
+}
+
+// fixed-order sum over the accumulate grid: U, epsA, cur_err, n_bad
+__global__ void __launch_bounds__(256) reduce_partials_kernel(BaDev d, int grid_acc) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int total = d.F * 27;
+    if (k < total) {
+        double s = 0;
+        for (int b = 0; b < grid_acc; b++) s += d.Upart[(size_t)b * total + k];
+        const int f = k / 27, o = k - f * 27;
+        if (o < 21)
+            d.U[f * 21 + o] = s;
+        else
+            d.epsA[f * 6 + o - 21] = s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double e = 0;
+        int nb = 0;
+        for (int b = 0; b < grid_acc; b++) {
+            e += d.err_part[2 * b];
+            nb += d.bad_part[b];
+        }
+        d.sc->cur_err = e;
+        d.sc->n_bad = nb;
+    }
+}
+
+// =================================================================================================
+// K8a: V*^-1  (:341-359)   TooN Cholesky<3>::get_inverse
+// =================================================================================================
+__global__ void __launch_bounds__(256) vinv_kernel(BaDev d, double lambda) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= d.P) return;
+    const double* v = d.V + (size_t)p * 6;
+    double A[9] = {v[0], v[1], v[3], v[1], v[2], v[4], v[3], v[4], v[5]};
+    double* out = d.Vinv + (size_t)p * 9;
+    if (A[0] * A[4] * A[8] == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) out[i] = 0;
+        return;
+    }
+    A[0] *= (1.0 + lambda);
+    A[4] *= (1.0 + lambda);
+    A[8] *= (1.0 + lambda);
+    // LDL^T, lower triangle; strict upper caches the undivided column
+    for (int col = 0; col < 3; col++) {
+        double inv_diag = 1;
+        for (int row = col; row < 3; row++) {
+            double val = A[row * 3 + col];
+            for (int c2 = 0; c2 < col; c2++) val -= A[c2 * 3 + col] * A[row * 3 + c2];
+            if (row == col) {
+                A[row * 3 + col] = val;
+                inv_diag = 1 / val;
+            } else {
+                A[col * 3 + row] = val;
+                A[row * 3 + col] = val * inv_diag;
+            }
+        }
+    }
+    for (int c = 0; c < 3; c++) {
+        double y[3], x[3];
+        for (int i = 0; i < 3; i++) {
+            double val = (i == c) ? 1.0 : 0.0;
+            for (int j = 0; j < i; j++) val -= A[i * 3 + j] * y[j];
+            y[i] = val;
+        }
+        for (int i = 0; i < 3; i++) y[i] /= A[i * 3 + i];
+        for (int i = 2; i >= 0; i--) {
+            double val = y[i];
+            for (int j = i + 1; j < 3; j++) val -= A[j * 3 + i] * x[j];
+            x[i] = val;
+        }
+        for (int r = 0; r < 3; r++) out[r * 3 + c] = x[r];
+    }
+}
+
+// =================================================================================================
+// K8: Schur complement, output-stationary camera-tile pairs
+// =================================================================================================
+#define SCHUR_TILE_ELEMS (SCHUR_TC * SCHUR_TC * 36 + SCHUR_TC * 6)   // 2304 + 48
+
+// per-wave LDS panel: Y[8][18] | W[8][18]
+struct SchurPanel {
+    double Y[SCHUR_TC][18];
+    double W[SCHUR_TC][18];
+};
+
+__global__ void __launch_bounds__(256) schur_tile_kernel(BaDev d) {
+    __shared__ SchurPanel panels[4];
+    __shared__ double red[2][64][42];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const SchurWG wg = d.s_wgs[blockIdx.x];
+    // pair -> (a, b), a >= b
+    int a = (int)((sqrt(8.0 * wg.pair + 1.0) - 1.0) * 0.5);
+    while ((a + 1) * (a + 2) / 2 <= wg.pair) a++;
+    while (a * (a + 1) / 2 > wg.pair) a--;
+    const int b = wg.pair - a * (a + 1) / 2;
+    const bool diag = a == b;
+    const int j = lane >> 3, k = lane & 7;
+    SchurPanel& P = panels[wid];
+    double acc[36], accE[6];
+#pragma unroll
+    for (int i = 0; i < 36; i++) acc[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) accE[i] = 0;
+    const int n_ent = wg.e_end - wg.e_begin;
+    const int iters = (n_ent + 3) / 4;
+    for (int it = 0; it < iters; it++) {
+        const int e = wg.e_begin + it * 4 + wid;
+        const bool have = e < wg.e_end;
+        unsigned pa = 0, pb = 0;
+        double eB[3] = {0, 0, 0};
+        if (have) {
+            const SchurEntry ent = d.s_entries[e];
+            const int na = ent.na_nb & 0xffff, nb = (ent.na_nb >> 16) & 0xffff;
+            const double* __restrict__ Vi = d.Vinv + (size_t)ent.pt * 9;
+            // zero the panel (288 doubles)
+            double* pz = &P.Y[0][0];
+            for (int i = lane; i < 2 * SCHUR_TC * 18; i += 64) pz[i] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // tile a: Y = W V*^-1 (and W too when a == b)
+            for (int l = lane; l < na; l += 64) {
+                const int m = ent.ma + l;
+                const int f = d.cam_free[d.m_cam[m]];
+                if (f >= 0 && d.m_state[m] == MS_ALIVE) {
+                    const int slot = f - a * SCHUR_TC;
+                    double w[18];
+#pragma unroll
+                    for (int q = 0; q < 9; q++) {
+                        const double2 t = d.W[(size_t)q * d.M + m];
+                        w[2 * q] = t.x;
+                        w[2 * q + 1] = t.y;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 6; r++)
+#pragma unroll
+                        for (int c = 0; c < 3; c++)
+                            P.Y[slot][r * 3 + c] = w[r * 3] * Vi[c] + w[r * 3 + 1] * Vi[3 + c] + w[r * 3 + 2] * Vi[6 + c];
+                    if (diag) {
+#pragma unroll
+                        for (int q = 0; q < 18; q++) P.W[slot][q] = w[q];
+                    }
+                    pa |= 1u << slot;
+                }
+            }
+            if (!diag) {
+                for (int l = lane; l < nb; l += 64) {
+                    const int m = ent.mb + l;
+                    const int f = d.cam_free[d.m_cam[m]];
+                    if (f >= 0 && d.m_state[m] == MS_ALIVE) {
+                        const int slot = f - b * SCHUR_TC;
+#pragma unroll
+                        for (int q = 0; q < 9; q++) {
+                            const double2 t = d.W[(size_t)q * d.M + m];
+                            P.W[slot][2 * q] = t.x;
+                            P.W[slot][2 * q + 1] = t.y;
+                        }
+                        pb |= 1u << slot;
+                    }
+                }
+            }
+            // wave-wide presence masks
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                pa |= __shfl_xor(pa, o, 64);
+                pb |= __shfl_xor(pb, o, 64);
+            }
+            if (diag) pb = pa;
+            eB[0] = d.epsB[(size_t)ent.pt * 3];
+            eB[1] = d.epsB[(size_t)ent.pt * 3 + 1];
+            eB[2] = d.epsB[(size_t)ent.pt * 3 + 2];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (((pa >> j) & 1u) && ((pb >> k) & 1u)) {
+                double Yj[18], Wk[18];
+#pragma unroll
+                for (int q = 0; q < 18; q++) {
+                    Yj[q] = P.Y[j][q];
+                    Wk[q] = P.W[k][q];
+                }
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int c = 0; c < 6; c++)
+                        acc[r * 6 + c] += Yj[r * 3] * Wk[c * 3] + Yj[r * 3 + 1] * Wk[c * 3 + 1] + Yj[r * 3 + 2] * Wk[c * 3 + 2];
+                if (diag && k == j) {
+#pragma unroll
+                    for (int r = 0; r < 6; r++) accE[r] += Yj[r * 3] * eB[0] + Yj[r * 3 + 1] * eB[1] + Yj[r * 3 + 2] * eB[2];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // cross-wave reduction in fixed order: (w2 -> w0, w3 -> w1), then (w1 -> w0)
+    if (wid >= 2) {
+#pragma unroll
+        for (int i = 0; i < 36; i++) red[wid - 2][lane][i] = acc[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) red[wid - 2][lane][36 + i] = accE[i];
+    }
+    __syncthreads();
+    if (wid < 2) {
+#pragma unroll
+        for (int i = 0; i < 36; i++) acc[i] += red[wid][lane][i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) accE[i] += red[wid][lane][36 + i];
+    }
+    __syncthreads();
+    if (wid == 1) {
+#pragma unroll
+        for (int i = 0; i < 36; i++) red[0][lane][i] = acc[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) red[0][lane][36 + i] = accE[i];
+    }
+    __syncthreads();
+    if (wid == 0) {
+        double* out = d.s_part + (size_t)blockIdx.x * SCHUR_TILE_ELEMS;
+#pragma unroll
+        for (int i = 0; i < 36; i++) out[(size_t)lane * 36 + i] = acc[i] + red[0][lane][i];
+        if (k == j) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) out[SCHUR_TC * SCHUR_TC * 36 + j * 6 + i] = accE[i] + red[0][lane][36 + i];
+        }
+    }
+}
+
+// one block per tile pair: fixed-order sum of the partial tiles, add U* / epsA, write S (lower) and E.
+// contributes_u: this rank adds U*, epsA and the padding identity (always true on one GPU; in sharded
+// mode every rank adds its OWN partial U, the padding identity only on rank 0).
+__global__ void __launch_bounds__(256) schur_reduce_kernel(BaDev d, double lambda, int pad_identity) {
+    const int pair = blockIdx.x;
+    int a = (int)((sqrt(8.0 * pair + 1.0) - 1.0) * 0.5);
+    while ((a + 1) * (a + 2) / 2 <= pair) a++;
+    while (a * (a + 1) / 2 > pair) a--;
+    const int b = pair - a * (a + 1) / 2;
+    const int wg0 = d.s_pair_wg_begin[pair], wg1 = d.s_pair_wg_begin[pair + 1];
+    double* S = d.SE;
+    double* E = d.SE + (size_t)d.npad * d.npad;
+    const int npad = d.npad;
+    for (int idx = threadIdx.x; idx < SCHUR_TC * SCHUR_TC * 36; idx += 256) {
+        const int jk = idx / 36, rc = idx - jk * 36;
+        const int j = jk >> 3, k = jk & 7, r = rc / 6, c = rc - r * 6;
+        const int fa = a * SCHUR_TC + j, fb = b * SCHUR_TC + k;
+        if (fa >= d.F || fb >= d.F) continue;
+        if (a == b && j < k) continue;   // strict upper blocks are never read
+        double s = 0;
+        for (int w = wg0; w < wg1; w++) s += d.s_part[(size_t)w * SCHUR_TILE_ELEMS + idx];
+        double val = -s;
+        if (a == b && j == k) {
+            // U* : symmetrised U with diag * (1 + lambda)  (:383-390)
+            const int rr = r >= c ? r : c, cc = r >= c ? c : r;
+            double u = d.U[fa * 21 + rr * (rr + 1) / 2 + cc];
+            if (r == c) u *= (1.0 + lambda);
+            val += u;
+        }
+        S[(size_t)(6 * fa + r) * npad + 6 * fb + c] = val;
+    }
+    if (a == b) {
+        for (int idx = threadIdx.x; idx < SCHUR_TC * 6; idx += 256) {
+            const int j = idx / 6, r = idx - j * 6;
+            const int fa = a * SCHUR_TC + j;
+            if (fa >= d.F) continue;
+            double s = 0;
+            for (int w = wg0; w < wg1; w++) s += d.s_part[(size_t)w * SCHUR_TILE_ELEMS + SCHUR_TC * SCHUR_TC * 36 + idx];
+            E[6 * fa + r] = d.epsA[fa * 6 + r] - s;
+        }
+    }
+    if (pair == 0) {
+        // padding rows n..npad-1: identity so that the blocked factorisation is well defined
+        const int np = d.npad - d.n;
+        for (int idx = threadIdx.x; idx < np * d.npad; idx += 256) {
+            const int r = d.n + idx / d.npad, c = idx % d.npad;
+            if (c <= r) S[(size_t)r * npad + c] = (r == c && pad_identity) ? 1.0 : 0.0;
+        }
+        for (int idx = threadIdx.x; idx < np; idx += 256) E[d.n + idx] = 0.0;
+    }
+}
+
+// =================================================================================================
+// K10
+// =================================================================================================
+__global__ void __launch_bounds__(64) pose_update_kernel(BaDev d, int cur) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c < d.C) {
+        const double* T = d.pose[cur] + 12 * c;
+        double* Tn = d.pose[cur ^ 1] + 12 * c;
+        const int f = d.cam_free[c];
+        if (f < 0) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) Tn[i] = T[i];
+        } else {
+            double mu[6], Tl[12], o[12];
+#pragma unroll
+            for (int i = 0; i < 6; i++) mu[i] = d.da[6 * f + i];
+#pragma unroll
+            for (int i = 0; i < 12; i++) Tl[i] = T[i];
+            se3_exp_mul(mu, Tl, o);   // exp(da_j) * se3CfW  (:501)
+#pragma unroll
+            for (int i = 0; i < 12; i++) Tn[i] = o[i];
+        }
+    }
+    if (blockIdx.x == 0) {
+        double s = 0;
+        for (int i = threadIdx.x; i < d.n; i += 64) s += d.da[i] * d.da[i];
+        s = wave_sum_f64(s);
+        if (threadIdx.x == 0) d.sc->sumsq_cam = s;
+    }
+}
+
+// delta b, trial points, new robust error; block owns whole points
+__global__ void __launch_bounds__(BA_CHUNK) point_update_kernel(DevCam cam, BaDev d, int cur, int est) {
+    __shared__ double Ts[BA_CHUNK][3];
+    __shared__ double Np[BA_CHUNK][3];
+    __shared__ double wred[BA_CHUNK / 64][2];
+    const int tid = threadIdx.x;
+    const BaChunk ch = d.chunks[blockIdx.x];
+    const int m = ch.m_begin + tid;
+    const bool active = m < ch.m_end;
+    int st = MS_DEAD, c = 0, p = 0;
+    double t0 = 0, t1 = 0, t2 = 0;
+    if (active) {
+        st = d.m_state[m];
+        c = d.m_cam[m];
+        p = d.m_pt[m];
+        const int f = d.cam_free[c];
+        if (st == MS_ALIVE && f >= 0) {   // non-fixed, non-bad  (:469-474)
+            double w[18];
+#pragma unroll
+            for (int q = 0; q < 9; q++) {
+                const double2 t = d.W[(size_t)q * d.M + m];
+                w[2 * q] = t.x;
+                w[2 * q + 1] = t.y;
+            }
+            const double* da = d.da + 6 * f;
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                const double a = da[r];
+                t0 += w[r * 3] * a;
+                t1 += w[r * 3 + 1] * a;
+                t2 += w[r * 3 + 2] * a;
+            }
+        }
+    }
+    Ts[tid][0] = t0;
+    Ts[tid][1] = t1;
+    Ts[tid][2] = t2;
+    __syncthreads();
+    const int npts = ch.pt_end - ch.pt_begin;
+    double sq = 0;
+    for (int pi = tid; pi < npts; pi += BA_CHUNK) {
+        const int pp = ch.pt_begin + pi;
+        const int r0 = d.rowptr[pp] - ch.m_begin, r1 = d.rowptr[pp + 1] - ch.m_begin;
+        double s0 = 0, s1 = 0, s2 = 0;
+        for (int rr = r0; rr < r1; rr++) {
+            s0 += Ts[rr][0];
+            s1 += Ts[rr][1];
+            s2 += Ts[rr][2];
+        }
+        const double* eb = d.epsB + (size_t)pp * 3;
+        const double v0 = eb[0] - s0, v1 = eb[1] - s1, v2 = eb[2] - s2;
+        const double* Vi = d.Vinv + (size_t)pp * 9;
+        const double d0 = Vi[0] * v0 + Vi[1] * v1 + Vi[2] * v2;
+        const double d1 = Vi[3] * v0 + Vi[4] * v1 + Vi[5] * v2;
+        const double d2 = Vi[6] * v0 + Vi[7] * v1 + Vi[8] * v2;
+        sq += d0 * d0 + d1 * d1 + d2 * d2;
+        const double* X = d.pt[cur] + (size_t)pp * 3;
+        const double n0 = X[0] + d0, n1 = X[1] + d1, n2 = X[2] + d2;   // :503-504
+        double* Xn = d.pt[cur ^ 1] + (size_t)pp * 3;
+        Xn[0] = n0;
+        Xn[1] = n1;
+        Xn[2] = n2;
+        Np[pi][0] = n0;
+        Np[pi][1] = n1;
+        Np[pi][2] = n2;
+    }
+    __syncthreads();
+    double err = 0;
+    if (active && st != MS_DEAD) {   // FindNewError over every listed measurement (:188-207)
+        const double* T = d.pose[cur ^ 1] + 12 * c;
+        const double* X = Np[p - ch.pt_begin];
+        double cx, cy, cz, x, y, u, v, r, f;
+        if (!ba_project(cam, T, X, cx, cy, cz, x, y, u, v, r, f))
+            err = 1.0;
+        else {
+            const double2 fo = d.m_found[m];
+            const double s = d.m_s[m];
+            const double ex = s * (fo.x - u), ey = s * (fo.y - v);
+            err = est_objective(est, ex * ex + ey * ey, d.sc->sigma_sq);
+        }
+    }
+    err = wave_sum_f64(err);
+    sq = wave_sum_f64(sq);
+    if ((tid & 63) == 0) {
+        wred[tid >> 6][0] = err;
+        wred[tid >> 6][1] = sq;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double e = 0, s = 0;
+        for (int i = 0; i < BA_CHUNK / 64; i++) {
+            e += wred[i][0];
+            s += wred[i][1];
+        }
+        d.err_part[2 * blockIdx.x] = e;
+        d.err_part[2 * blockIdx.x + 1] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256) finalize_new_kernel(BaDev d) {
+    __shared__ double w[4][2];
+    double e = 0, s = 0;
+    // fixed assignment + fixed combine order: deterministic
+    for (int i = threadIdx.x; i < d.n_chunks; i += 256) {
+        e += d.err_part[2 * i];
+        s += d.err_part[2 * i + 1];
+    }
+    e = wave_sum_f64(e);
+    s = wave_sum_f64(s);
+    if ((threadIdx.x & 63) == 0) {
+        w[threadIdx.x >> 6][0] = e;
+        w[threadIdx.x >> 6][1] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        d.sc->new_err = w[0][0] + w[1][0] + w[2][0] + w[3][0];
+        d.sc->sumsq_pt = w[0][1] + w[1][1] + w[2][1] + w[3][1];
+    }
+}
+
+// erase bad measurements, append to the outlier list (:536-547)
+__global__ void __launch_bounds__(256) purge_kernel(BaDev d) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= d.M) return;
+    if (d.m_state[m] == MS_BAD) {
+        const int pos = atomicAdd(&d.sc->n_outliers, 1);
+        d.outliers[pos] = d.m_orig[m];
+        d.m_state[m] = MS_DEAD;
+    }
+}
+
+__global__ void set_scalars_kernel(BaDev d, double cur_err, int n_bad) {
+    d.sc->cur_err = cur_err;
+    d.sc->n_bad = n_bad;
+}
+__global__ void set_new_kernel(BaDev d, double new_err, double sumsq_pt) {
+    d.sc->new_err = new_err;
+    d.sc->sumsq_pt = sumsq_pt;
+}
+__global__ void pack2_kernel(const BaScalars* sc, double* out, int which) {
+    if (which == 0) {
+        out[0] = sc->cur_err;
+        out[1] = (double)sc->n_bad;
+    } else {
+        out[0] = sc->new_err;
+        out[1] = sc->sumsq_pt;
+    }
+}
+__global__ void unpack2_kernel(BaScalars* sc, const double* in, int which) {
+    if (which == 0) {
+        sc->cur_err = in[0];
+        sc->n_bad = (int)(in[1] + 0.5);
+    } else {
+        sc->new_err = in[0];
+        sc->sumsq_pt = in[1];
+    }
+}
+__global__ void place_keys_kernel(const double* __restrict__ src, int n, double* __restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// =================================================================================================
+// host
+// =================================================================================================
+struct ptam_ba {
+    ptam_ctx* ctx;
+    ptam_ba_opts opts;
+    // inputs (insertion order), copied at add_* time like the reference
+    std::vector<double> cam_pose;
+    std::vector<uint8_t> cam_fixed;
+    std::vector<double> pts;
+    std::vector<int> m_cam, m_pt;
+    std::vector<double> m_found, m_s;
+    std::vector<uint8_t> m_dead;
+    // results
+    bool converged = false;
+    int accepted = 0;
+    std::vector<ptam_ba_trial> trials;
+    std::vector<std::pair<int, int>> outliers;   // (point, camera)
+    // device
+    bool prepared = false;
+    BaDev d;
+    void* block = nullptr;
+    size_t block_bytes = 0;
+    int cur = 0;
+    size_t smem_acc = 0;
+    std::vector<int> sorted_orig;   // sorted position -> insertion index
+    // gather buffers (sharded mode)
+    double* d_gather = nullptr;
+    size_t gather_cap = 0;
+    double* d_xchg = nullptr;   // small exchange buffer (counts, scalars)
+    // profiling
+    bool prof = false;
+    hipEvent_t ev[PTAM_K_COUNT][2];
+    bool ev_ok = false;
+    bool ev_used[PTAM_K_COUNT];
+    double k_ms[PTAM_K_COUNT];
+    int k_n[PTAM_K_COUNT];
+    // communicator
+    int rank = 0, world = 1;
+    ptam_allreduce_f64_fn comm = nullptr;
+    void* comm_user = nullptr;
+};
+
+static void ba_free_device(ptam_ba* ba) {
+    if (ba->block) hipFree(ba->block);
+    if (ba->d_gather) hipFree(ba->d_gather);
+    if (ba->d_xchg) hipFree(ba->d_xchg);
+    ba->block = nullptr;
+    ba->d_gather = nullptr;
+    ba->d_xchg = nullptr;
+    ba->gather_cap = 0;
+    ba->prepared = false;
+}
+
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    }
+};
+
+static int ba_prepare_impl(ptam_ba* ba) {
+    ptam_ctx* ctx = ba->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ba_free_device(ba);
+    BaDev& d = ba->d;
+    std::memset(&d, 0, sizeof d);
+    const int C = (int)ba->cam_fixed.size(), P = (int)(ba->pts.size() / 3);
+    const int Mall = (int)ba->m_cam.size();
+    // free-camera indices in insertion order  (nStartRow, src/Bundle.cc:52-57)
+    std::vector<int> cam_free(C, -1);
+    int F = 0;
+    for (int c = 0; c < C; c++)
+        if (!ba->cam_fixed[c]) cam_free[c] = F++;
+    // live measurements sorted point-major (point, camera); ties keep insertion order
+    std::vector<int> order;
+    order.reserve(Mall);
+    for (int i = 0; i < Mall; i++)
+        if (!ba->m_dead[i]) order.push_back(i);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+        if (ba->m_pt[x] != ba->m_pt[y]) return ba->m_pt[x] < ba->m_pt[y];
+        return ba->m_cam[x] < ba->m_cam[y];
+    });
+    const int M = (int)order.size();
+    for (int i = 1; i < M; i++)
+        if (ba->m_pt[order[i]] == ba->m_pt[order[i - 1]] && ba->m_cam[order[i]] == ba->m_cam[order[i - 1]]) {
+            ptam_set_error("duplicate measurement of point %d by camera %d", ba->m_pt[order[i]], ba->m_cam[order[i]]);
+            return PTAM_E_ARG;
+        }
+    ba->sorted_orig = order;
+    std::vector<int> rowptr(P + 1, 0);
+    for (int i = 0; i < M; i++) rowptr[ba->m_pt[order[i]] + 1]++;
+    for (int p = 0; p < P; p++) {
+        if (rowptr[p + 1] > BA_CHUNK) {
+            ptam_set_error("point %d has %d measurements; the limit is %d cameras per point", p, rowptr[p + 1], BA_CHUNK);
+            return PTAM_E_LIMIT;
+        }
+        rowptr[p + 1] += rowptr[p];
+    }
+    // chunks: consecutive whole points, at most BA_CHUNK measurements
+    std::vector<BaChunk> chunks;
+    {
+        int p = 0;
+        while (p < P) {
+            BaChunk ch;
+            ch.pt_begin = p;
+            ch.m_begin = rowptr[p];
+            int cnt = 0, np = 0;
+            while (p < P && cnt + (rowptr[p + 1] - rowptr[p]) <= BA_CHUNK && np < BA_CHUNK) {
+                cnt += rowptr[p + 1] - rowptr[p];
+                p++;
+                np++;
+            }
+            ch.pt_end = p;
+            ch.m_end = rowptr[p];
+            chunks.push_back(ch);
+        }
+    }
+    // Schur work lists
+    const int n_tiles = (F + SCHUR_TC - 1) / SCHUR_TC;
+    const int n_pairs = n_tiles * (n_tiles + 1) / 2;
+    std::vector<std::vector<SchurEntry>> per_pair(n_pairs);
+    {
+        std::vector<int> t_first(n_tiles), t_cnt(n_tiles), touched;
+        for (int p = 0; p < P; p++) {
+            touched.clear();
+            // measurement sub-range of each tile inside the point's row (camera ids ascending ->
+            // free indices ascending; fixed cameras may sit in between and are skipped in-kernel)
+            int last_tile = -1;
+            for (int i = rowptr[p]; i < rowptr[p + 1]; i++) {
+                const int f = cam_free[ba->m_cam[order[i]]];
+                if (f < 0) continue;
+                const int t = f / SCHUR_TC;
+                if (t != last_tile) {
+                    touched.push_back(t);
+                    t_first[t] = i;
+                    last_tile = t;
+                }
+                t_cnt[t] = i - t_first[t] + 1;
+            }
+            for (size_t ia = 0; ia < touched.size(); ia++)
+                for (size_t ib = 0; ib <= ia; ib++) {
+                    const int a = touched[ia], b = touched[ib];
+                    SchurEntry e;
+                    e.pt = p;
+                    e.ma = t_first[a];
+                    e.mb = t_first[b];
+                    e.na_nb = t_cnt[a] | (t_cnt[b] << 16);
+                    per_pair[a * (a + 1) / 2 + b].push_back(e);
+                }
+        }
+    }
+    std::vector<SchurEntry> s_entries;
+    std::vector<SchurWG> s_wgs;
+    std::vector<int> pair_wg_begin(n_pairs + 1, 0);
+    {
+        size_t total = 0;
+        for (auto& v : per_pair) total += v.size();
+        int per_wg = (int)std::min<size_t>(1024, std::max<size_t>(64, total / 1024 + 1));
+        per_wg = (per_wg + 3) & ~3;
+        for (int pr = 0; pr < n_pairs; pr++) {
+            pair_wg_begin[pr] = (int)s_wgs.size();
+            const int base = (int)s_entries.size();
+            s_entries.insert(s_entries.end(), per_pair[pr].begin(), per_pair[pr].end());
+            const int cnt = (int)per_pair[pr].size();
+            for (int o = 0; o < cnt; o += per_wg) s_wgs.push_back(SchurWG{pr, base + o, base + std::min(cnt, o + per_wg)});
+        }
+        pair_wg_begin[n_pairs] = (int)s_wgs.size();
+    }
+
+    d.C = C;
+    d.F = F;
+    d.P = P;
+    d.M = M;
+    d.n = 6 * F;
+    d.npad = ((d.n + SOLVE_NB - 1) / SOLVE_NB) * SOLVE_NB;
+    d.n_chunks = (int)chunks.size();
+    d.n_tiles = n_tiles;
+    d.n_pairs = n_pairs;
+    d.n_schur_wg = (int)s_wgs.size();
+    d.n_schur_entries = (int)s_entries.size();
+    // persistent grid of the accumulate kernel: bounded by LDS residency, 2 x 256 CUs by default
+    ba->smem_acc = ((((size_t)F * 27 + 1) & ~(size_t)1) + (size_t)BA_CHUNK * 8) * sizeof(double);
+    if (ba->smem_acc > 160 * 1024) {
+        ptam_set_error("%d free cameras exceed the LDS budget of the accumulate kernel", F);
+        return PTAM_E_LIMIT;
+    }
+    int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / ba->smem_acc));
+    d.grid_acc = std::max(1, std::min(d.n_chunks, 256 * per_cu));
+
+    // ---- carve one device allocation ------------------------------------------------------------
+    Carver cv;
+    const size_t Mz = std::max(M, 1), Pz = std::max(P, 1), Cz = std::max(C, 1), Fz = std::max(F, 1);
+    const size_t o_pose0 = cv.take(Cz * 96), o_pose1 = cv.take(Cz * 96), o_camfree = cv.take(Cz * 4);
+    const size_t o_pt0 = cv.take(Pz * 24), o_pt1 = cv.take(Pz * 24), o_V = cv.take(Pz * 48), o_epsB = cv.take(Pz * 24),
+                 o_Vinv = cv.take(Pz * 72), o_rowptr = cv.take((Pz + 1) * 4);
+    const size_t o_mcam = cv.take(Mz * 4), o_mpt = cv.take(Mz * 4), o_mfound = cv.take(Mz * 16), o_ms = cv.take(Mz * 8),
+                 o_morig = cv.take(Mz * 4), o_mstate = cv.take(Mz), o_me2 = cv.take(Mz * 8), o_W = cv.take(Mz * 144);
+    const size_t o_U = cv.take(Fz * 21 * 8), o_epsA = cv.take(Fz * 6 * 8), o_Upart = cv.take((size_t)d.grid_acc * Fz * 27 * 8);
+    const size_t n_part = std::max(d.n_chunks, d.grid_acc);
+    const size_t o_errp = cv.take(n_part * 16 + 16), o_badp = cv.take((size_t)d.grid_acc * 4 + 16);
+    const size_t o_chunks = cv.take(std::max<size_t>(1, chunks.size()) * sizeof(BaChunk));
+    const size_t o_hist = cv.take(HIST_BINS * 4), o_cand = cv.take(Mz * 8);
+    const size_t o_sent = cv.take(std::max<size_t>(1, s_entries.size()) * sizeof(SchurEntry)),
+                 o_swg = cv.take(std::max<size_t>(1, s_wgs.size()) * sizeof(SchurWG)),
+                 o_spw = cv.take((size_t)(n_pairs + 1) * 4),
+                 o_spart = cv.take(std::max<size_t>(1, s_wgs.size()) * SCHUR_TILE_ELEMS * 8);
+    const size_t npad = std::max(d.npad, SOLVE_NB);
+    const size_t o_SE = cv.take((npad * npad + npad) * 8), o_L = cv.take(npad * npad * 8), o_Dg = cv.take(npad * 8),
+                 o_y = cv.take(npad * 8), o_da = cv.take(npad * 8);
+    const size_t o_out = cv.take(Mz * 4), o_sc = cv.take(sizeof(BaScalars));
+    ba->block_bytes = cv.off;
+    HIP_TRY(hipMalloc(&ba->block, ba->block_bytes));
+    HIP_TRY(hipMemsetAsync(ba->block, 0, ba->block_bytes, ctx->stream));
+    char* base = (char*)ba->block;
+    d.pose[0] = (double*)(base + o_pose0);
+    d.pose[1] = (double*)(base + o_pose1);
+    d.cam_free = (int*)(base + o_camfree);
+    d.pt[0] = (double*)(base + o_pt0);
+    d.pt[1] = (double*)(base + o_pt1);
+    d.V = (double*)(base + o_V);
+    d.epsB = (double*)(base + o_epsB);
+    d.Vinv = (double*)(base + o_Vinv);
+    d.rowptr = (int*)(base + o_rowptr);
+    d.m_cam = (int*)(base + o_mcam);
+    d.m_pt = (int*)(base + o_mpt);
+    d.m_found = (double2*)(base + o_mfound);
+    d.m_s = (double*)(base + o_ms);
+    d.m_orig = (int*)(base + o_morig);
+    d.m_state = (uint8_t*)(base + o_mstate);
+    d.m_e2 = (double*)(base + o_me2);
+    d.W = (double2*)(base + o_W);
+    d.U = (double*)(base + o_U);
+    d.epsA = (double*)(base + o_epsA);
+    d.Upart = (double*)(base + o_Upart);
+    d.err_part = (double*)(base + o_errp);
+    d.bad_part = (int*)(base + o_badp);
+    d.chunks = (BaChunk*)(base + o_chunks);
+    d.hist = (unsigned*)(base + o_hist);
+    d.cand = (double*)(base + o_cand);
+    d.s_entries = (SchurEntry*)(base + o_sent);
+    d.s_wgs = (SchurWG*)(base + o_swg);
+    d.s_pair_wg_begin = (int*)(base + o_spw);
+    d.s_part = (double*)(base + o_spart);
+    d.SE = (double*)(base + o_SE);
+    d.L = (double*)(base + o_L);
+    d.Dg = (double*)(base + o_Dg);
+    d.y = (double*)(base + o_y);
+    d.da = (double*)(base + o_da);
+    d.outliers = (int*)(base + o_out);
+    d.sc = (BaScalars*)(base + o_sc);
+
+    // ---- upload -------------------------------------------------------------------------------------
+    std::vector<int> h_cam(Mz), h_pt(Mz), h_orig(Mz);
+    std::vector<double> h_found(2 * Mz), h_s(Mz);
+    for (int i = 0; i < M; i++) {
+        const int o = order[i];
+        h_cam[i] = ba->m_cam[o];
+        h_pt[i] = ba->m_pt[o];
+        h_orig[i] = o;
+        h_found[2 * i] = ba->m_found[2 * o];
+        h_found[2 * i + 1] = ba->m_found[2 * o + 1];
+        h_s[i] = ba->m_s[o];
+    }
+#define UP(dst, src, bytes)                                                                        \
+    if ((bytes) > 0) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream))
+    UP(d.pose[0], ba->cam_pose.data(), (size_t)C * 96);
+    UP(d.cam_free, cam_free.data(), (size_t)C * 4);
+    UP(d.pt[0], ba->pts.data(), (size_t)P * 24);
+    UP(d.rowptr, rowptr.data(), (size_t)(P + 1) * 4);
+    UP(d.m_cam, h_cam.data(), (size_t)M * 4);
+    UP(d.m_pt, h_pt.data(), (size_t)M * 4);
+    UP(d.m_found, h_found.data(), (size_t)M * 16);
+    UP(d.m_s, h_s.data(), (size_t)M * 8);
+    UP(d.m_orig, h_orig.data(), (size_t)M * 4);
+    UP(d.chunks, chunks.data(), chunks.size() * sizeof(BaChunk));
+    UP(d.s_entries, s_entries.data(), s_entries.size() * sizeof(SchurEntry));
+    UP(d.s_wgs, s_wgs.data(), s_wgs.size() * sizeof(SchurWG));
+    UP(d.s_pair_wg_begin, pair_wg_begin.data(), pair_wg_begin.size() * 4);
+#undef UP
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // host staging vectors die here
+    if (ba->smem_acc > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)jac_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)ba->smem_acc));
+    HIP_TRY(hipMalloc((void**)&ba->d_xchg, 4096));
+    ba->cur = 0;
+    ba->prepared = true;
+    return PTAM_OK;
+}
+
+// ---- profiling --------------------------------------------------------------------------------
+static void prof_begin(ptam_ba* ba, int k) {
+    if (!ba->prof) return;
+    hipEventRecord(ba->ev[k][0], ba->ctx->stream);
+}
+static void prof_end(ptam_ba* ba, int k) {
+    if (!ba->prof) return;
+    hipEventRecord(ba->ev[k][1], ba->ctx->stream);
+    ba->ev_used[k] = true;
+}
+static void prof_collect(ptam_ba* ba) {   // call after a stream sync
+    if (!ba->prof) return;
+    for (int k = 0; k < PTAM_K_COUNT; k++)
+        if (ba->ev_used[k]) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ba->ev[k][0], ba->ev[k][1]) == hipSuccess) {
+                ba->k_ms[k] += ms;
+                ba->k_n[k]++;
+            }
+            ba->ev_used[k] = false;
+        }
+}
+
+static int ba_allreduce(ptam_ba* ba, double* dptr, size_t count) {
+    if (!(ba->comm && ba->world > 1)) return PTAM_OK;
+    const int rc = ba->comm(ba->comm_user, dptr, count, (void*)ba->ctx->stream);
+    if (rc != 0) {
+        ptam_set_error("all-reduce hook failed (%d)", rc);
+        return PTAM_E_COMM;
+    }
+    return PTAM_OK;
+}
+
+// pass 1 + sigma^2
+static int ba_pass1_sigma(ptam_ba* ba) {
+    ptam_ctx* ctx = ba->ctx;
+    BaDev& d = ba->d;
+    const bool sharded = ba->comm && ba->world > 1;
+    const double min_s2 = ba->opts.min_sigma * ba->opts.min_sigma;
+    prof_begin(ba, PTAM_K_PROJECT);
+    if (d.n_chunks > 0)
+        hipLaunchKernelGGL(project_e2_kernel, dim3(std::min(d.n_chunks, 1024)), dim3(BA_CHUNK), 0, ctx->stream, ctx->cam, d,
+                           ba->cur, sharded ? 0 : 1);
+    prof_end(ba, PTAM_K_PROJECT);
+    prof_begin(ba, PTAM_K_SELECT);
+    if (!sharded) {
+        hipLaunchKernelGGL(select_find_bin_kernel, dim3(1), dim3(1024), 0, ctx->stream, d);
+        hipLaunchKernelGGL(select_compact_kernel, dim3(std::max(1, std::min((d.M + 255) / 256, 1024))), dim3(256), 0,
+                           ctx->stream, d, (const double*)d.m_e2, (long long)d.M, (const uint8_t*)d.m_state);
+    } else {
+        // all-gather of the valid e^2 built from two all-reduces (counts, then a zero-padded vector)
+        int* d_cnt = (int*)(ba->d_xchg + 256);
+        HIP_TRY(hipMemsetAsync(d_cnt, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(compact_valid_kernel, dim3(std::max(1, std::min((d.M + 255) / 256, 1024))), dim3(256), 0,
+                           ctx->stream, d, d.cand, d_cnt);
+        int n_local = 0;
+        HIP_TRY(hipMemcpyAsync(&n_local, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        std::vector<double> counts(ba->world, 0.0);
+        counts[ba->rank] = n_local;
+        HIP_TRY(hipMemcpyAsync(ba->d_xchg, counts.data(), ba->world * 8, hipMemcpyHostToDevice, ctx->stream));
+        int rc = ba_allreduce(ba, ba->d_xchg, ba->world);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(counts.data(), ba->d_xchg, ba->world * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        long long total = 0, off = 0;
+        for (int r = 0; r < ba->world; r++) {
+            if (r == ba->rank) off = total;
+            total += (long long)(counts[r] + 0.5);
+        }
+        if ((size_t)total > ba->gather_cap) {
+            if (ba->d_gather) HIP_TRY(hipFree(ba->d_gather));
+            ba->gather_cap = (size_t)total + (size_t)total / 8 + 1024;
+            HIP_TRY(hipMalloc((void**)&ba->d_gather, ba->gather_cap * 16));   // keys + candidate area
+        }
+        HIP_TRY(hipMemsetAsync(ba->d_gather, 0, (size_t)total * 8, ctx->stream));
+        if (n_local > 0)
+            hipLaunchKernelGGL(place_keys_kernel, dim3((n_local + 255) / 256), dim3(256), 0, ctx->stream,
+                               (const double*)d.cand, n_local, ba->d_gather + off);
+        rc = ba_allreduce(ba, ba->d_gather, (size_t)total);
+        if (rc) return rc;
+        BaDev dg = d;
+        dg.cand = ba->d_gather + ba->gather_cap;   // candidates go behind the gathered keys
+        if (total > 0)
+            hipLaunchKernelGGL(hist_keys_kernel, dim3((int)std::max<long long>(1, std::min<long long>((total + 255) / 256, 1024))),
+                               dim3(256), 0, ctx->stream, (const double*)ba->d_gather, total, d.hist);
+        hipLaunchKernelGGL(select_find_bin_kernel, dim3(1), dim3(1024), 0, ctx->stream, dg);
+        hipLaunchKernelGGL(select_compact_kernel, dim3((int)std::max<long long>(1, std::min<long long>((total + 255) / 256, 1024))),
+                           dim3(256), 0, ctx->stream, dg, (const double*)ba->d_gather, total, (const uint8_t*)nullptr);
+        hipLaunchKernelGGL(select_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, dg, ba->opts.estimator, min_s2);
+        prof_end(ba, PTAM_K_SELECT);
+        HIP_TRY(hipGetLastError());
+        return PTAM_OK;
+    }
+    hipLaunchKernelGGL(select_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, d, ba->opts.estimator, min_s2);
+    prof_end(ba, PTAM_K_SELECT);
+    HIP_TRY(hipGetLastError());
+    return PTAM_OK;
+}
+
+static int ba_pass2(ptam_ba* ba) {
+    ptam_ctx* ctx = ba->ctx;
+    BaDev& d = ba->d;
+    prof_begin(ba, PTAM_K_JACOBIAN);
+    hipLaunchKernelGGL(jac_accum_kernel, dim3(d.grid_acc), dim3(BA_CHUNK), ba->smem_acc, ctx->stream, ctx->cam, d, ba->cur,
+                       ba->opts.estimator);
+    prof_end(ba, PTAM_K_JACOBIAN);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(std::max(1, (d.F * 27 + 255) / 256)), dim3(256), 0, ctx->stream, d,
+                       d.grid_acc);
+    HIP_TRY(hipGetLastError());
+    if (ba->comm && ba->world > 1) {
+        hipLaunchKernelGGL(pack2_kernel, dim3(1), dim3(1), 0, ctx->stream, (const BaScalars*)d.sc, ba->d_xchg, 0);
+        int rc = ba_allreduce(ba, ba->d_xchg, 2);
+        if (rc) return rc;
+        hipLaunchKernelGGL(unpack2_kernel, dim3(1), dim3(1), 0, ctx->stream, d.sc, (const double*)ba->d_xchg, 0);
+    }
+    return PTAM_OK;
+}
+
+static int ba_trial(ptam_ba* ba, double lambda) {
+    ptam_ctx* ctx = ba->ctx;
+    BaDev& d = ba->d;
+    prof_begin(ba, PTAM_K_VINV);
+    if (d.P > 0) hipLaunchKernelGGL(vinv_kernel, dim3((d.P + 255) / 256), dim3(256), 0, ctx->stream, d, lambda);
+    prof_end(ba, PTAM_K_VINV);
+    if (d.F > 0) {
+        prof_begin(ba, PTAM_K_SCHUR);
+        if (d.n_schur_wg > 0) hipLaunchKernelGGL(schur_tile_kernel, dim3(d.n_schur_wg), dim3(256), 0, ctx->stream, d);
+        hipLaunchKernelGGL(schur_reduce_kernel, dim3(d.n_pairs), dim3(256), 0, ctx->stream, d, lambda,
+                           (ba->world > 1 && ba->rank != 0) ? 0 : 1);
+        prof_end(ba, PTAM_K_SCHUR);
+        HIP_TRY(hipGetLastError());
+        int rc = ba_allreduce(ba, d.SE, (size_t)d.npad * d.npad + d.npad);   // the path's one exchange step
+        if (rc) return rc;
+        prof_begin(ba, PTAM_K_SOLVE);
+        rc = ba_solve(ctx, d);
+        prof_end(ba, PTAM_K_SOLVE);
+        if (rc) return rc;
+    }
+    prof_begin(ba, PTAM_K_UPDATE);
+    hipLaunchKernelGGL(pose_update_kernel, dim3(std::max(1, (d.C + 63) / 64)), dim3(64), 0, ctx->stream, d, ba->cur);
+    if (d.n_chunks > 0)
+        hipLaunchKernelGGL(point_update_kernel, dim3(d.n_chunks), dim3(BA_CHUNK), 0, ctx->stream, ctx->cam, d, ba->cur,
+                           ba->opts.estimator);
+    hipLaunchKernelGGL(finalize_new_kernel, dim3(1), dim3(256), 0, ctx->stream, d);
+    prof_end(ba, PTAM_K_UPDATE);
+    HIP_TRY(hipGetLastError());
+    if (ba->comm && ba->world > 1) {
+        hipLaunchKernelGGL(pack2_kernel, dim3(1), dim3(1), 0, ctx->stream, (const BaScalars*)d.sc, ba->d_xchg, 1);
+        int rc = ba_allreduce(ba, ba->d_xchg, 2);
+        if (rc) return rc;
+        hipLaunchKernelGGL(unpack2_kernel, dim3(1), dim3(1), 0, ctx->stream, d.sc, (const double*)ba->d_xchg, 1);
+    }
+    return PTAM_OK;
+}
+
+static int ba_read_scalars(ptam_ba* ba, BaScalars* out) {
+    void* pin;
+    int rc = ctx_pinned(ba->ctx, sizeof(BaScalars), &pin);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(pin, ba->d.sc, sizeof(BaScalars), hipMemcpyDeviceToHost, ba->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ba->ctx->stream));
+    std::memcpy(out, pin, sizeof(BaScalars));
+    prof_collect(ba);
+    return PTAM_OK;
+}
+
+extern "C" {
+
+void ptam_ba_opts_default(ptam_ba_opts* o) {
+    if (!o) return;
+    o->max_iterations = 20;
+    o->update_sq_conv_limit = 1e-6;
+    o->min_sigma = 0.4;
+    o->estimator = PTAM_EST_TUKEY;
+    o->verbose = 0;
+}
+
+int ptam_ba_create(ptam_ctx* ctx, const ptam_ba_opts* opts, ptam_ba** out) {
+    ARG_TRY(ctx && out);
+    ptam_ba* ba = new ptam_ba();
+    ba->ctx = ctx;
+    if (opts)
+        ba->opts = *opts;
+    else
+        ptam_ba_opts_default(&ba->opts);
+    std::memset(&ba->d, 0, sizeof ba->d);
+    std::memset(ba->k_ms, 0, sizeof ba->k_ms);
+    std::memset(ba->k_n, 0, sizeof ba->k_n);
+    std::memset(ba->ev_used, 0, sizeof ba->ev_used);
+    *out = ba;
+    return PTAM_OK;
+}
+
+int ptam_ba_destroy(ptam_ba* ba) {
+    if (!ba) return PTAM_OK;
+    hipSetDevice(ba->ctx->device);
+    hipStreamSynchronize(ba->ctx->stream);
+    ba_free_device(ba);
+    if (ba->ev_ok)
+        for (int k = 0; k < PTAM_K_COUNT; k++) {
+            hipEventDestroy(ba->ev[k][0]);
+            hipEventDestroy(ba->ev[k][1]);
+        }
+    delete ba;
+    return PTAM_OK;
+}
+
+int ptam_ba_add_camera(ptam_ba* ba, const double pose[12], int fixed) {
+    ARG_TRY(ba && pose);
+    const int n = (int)ba->cam_fixed.size();
+    ba->cam_pose.insert(ba->cam_pose.end(), pose, pose + 12);
+    ba->cam_fixed.push_back(fixed ? 1 : 0);
+    ba->prepared = false;
+    return n;
+}
+
+int ptam_ba_add_point(ptam_ba* ba, const double pos[3]) {
+    ARG_TRY(ba && pos);
+    const int n = (int)(ba->pts.size() / 3);
+    double v[3] = {pos[0], pos[1], pos[2]};
+    if (std::isnan(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])) v[0] = v[1] = v[2] = 0;   // src/Bundle.cc:70-74
+    ba->pts.insert(ba->pts.end(), v, v + 3);
+    ba->prepared = false;
+    return n;
+}
+
+int ptam_ba_add_meas(ptam_ba* ba, int cam, int point, const double found[2], double sigma_sq) {
+    ARG_TRY(ba && found);
+    ARG_TRY(cam >= 0 && cam < (int)ba->cam_fixed.size());
+    ARG_TRY(point >= 0 && point < (int)(ba->pts.size() / 3));
+    ba->m_cam.push_back(cam);
+    ba->m_pt.push_back(point);
+    ba->m_found.push_back(found[0]);
+    ba->m_found.push_back(found[1]);
+    ba->m_s.push_back(std::sqrt(1.0 / sigma_sq));   // dSqrtInvNoise src/Bundle.cc:91
+    ba->m_dead.push_back(0);
+    ba->prepared = false;
+    return PTAM_OK;
+}
+
+int ptam_ba_add_cameras(ptam_ba* ba, int n, const double* poses12, const uint8_t* fixed) {
+    ARG_TRY(ba && n >= 0 && (n == 0 || (poses12 && fixed)));
+    for (int i = 0; i < n; i++) ptam_ba_add_camera(ba, poses12 + 12 * i, fixed[i]);
+    return PTAM_OK;
+}
+int ptam_ba_add_points(ptam_ba* ba, int n, const double* pos3) {
+    ARG_TRY(ba && n >= 0 && (n == 0 || pos3));
+    for (int i = 0; i < n; i++) ptam_ba_add_point(ba, pos3 + 3 * i);
+    return PTAM_OK;
+}
+int ptam_ba_add_measurements(ptam_ba* ba, int n, const int32_t* cam, const int32_t* point, const double* found2,
+                             const double* sigma_sq) {
+    ARG_TRY(ba && n >= 0 && (n == 0 || (cam && point && found2 && sigma_sq)));
+    for (int i = 0; i < n; i++) {
+        const int rc = ptam_ba_add_meas(ba, cam[i], point[i], found2 + 2 * i, sigma_sq[i]);
+        if (rc < 0) return rc;
+    }
+    return PTAM_OK;
+}
+
+int ptam_ba_prepare(ptam_ba* ba) {
+    ARG_TRY(ba);
+    if (ba->prepared) return PTAM_OK;
+    return ba_prepare_impl(ba);
+}
+
+int ptam_ba_set_profiling(ptam_ba* ba, int on) {
+    ARG_TRY(ba);
+    HIP_TRY(hipSetDevice(ba->ctx->device));
+    if (on && !ba->ev_ok) {
+        for (int k = 0; k < PTAM_K_COUNT; k++) {
+            HIP_TRY(hipEventCreate(&ba->ev[k][0]));
+            HIP_TRY(hipEventCreate(&ba->ev[k][1]));
+        }
+        ba->ev_ok = true;
+    }
+    ba->prof = on != 0;
+    return PTAM_OK;
+}
+
+int ptam_ba_kernel_time(const ptam_ba* ba, int kernel, double* total_ms, int* launches) {
+    ARG_TRY(ba && kernel >= 0 && kernel < PTAM_K_COUNT);
+    if (total_ms) *total_ms = ba->k_ms[kernel];
+    if (launches) *launches = ba->k_n[kernel];
+    return PTAM_OK;
+}
+
+int ptam_ba_set_comm(ptam_ba* ba, int rank, int world, ptam_allreduce_f64_fn fn, void* user) {
+    ARG_TRY(ba && world >= 1 && rank >= 0 && rank < world);
+    ARG_TRY(world == 1 || fn);
+    ARG_TRY(world <= 32);
+    ba->rank = rank;
+    ba->world = world;
+    ba->comm = fn;
+    ba->comm_user = user;
+    return PTAM_OK;
+}
+
+// Bundle::Compute src/Bundle.cc:116-158
+int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* accepted_out) {
+    ARG_TRY(ba);
+    ptam_ctx* ctx = ba->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ptam_ba_prepare(ba);
+    if (rc) return rc;
+    BaDev& d = ba->d;
+    double lambda = 0.0001, lambda_factor = 2.0;   // :125-126
+    ba->converged = false;
+    bool hit_max = false;
+    int counter = 0;
+    ba->accepted = 0;
+    ba->trials.clear();
+    std::vector<int> step_outlier_end;   // outlier-list length after every LM step
+    auto aborted = [&]() { return abort_flag && *abort_flag; };
+    BaScalars sc;
+    std::memset(&sc, 0, sizeof sc);
+    const bool empty = d.M == 0;
+    while (!empty && !ba->converged && !hit_max && !aborted()) {
+        // ---- Do_LM_Step :209-551 ----
+        rc = ba_pass1_sigma(ba);
+        if (rc) return rc;
+        rc = ba_pass2(ba);
+        if (rc) return rc;
+        bool have_cur = false;
+        double cur_err = 0, new_err = 0;
+        bool ran_any = false;
+        // while(dNewError > dCurrentError && !converged && !hitmax && !abort)  :338
+        for (;;) {
+            if (have_cur && !(new_err > cur_err)) break;
+            if (ba->converged || hit_max || aborted()) break;
+            rc = ba_trial(ba, lambda);
+            if (rc) return rc;
+            rc = ba_read_scalars(ba, &sc);
+            if (rc) return rc;
+            if (!have_cur) {
+                have_cur = true;
+                cur_err = sc.cur_err;
+                new_err = cur_err + 9999;   // :337
+                if (!(new_err > cur_err)) break;   // NaN/inf current error: the reference never enters the loop
+            }
+            ran_any = true;
+            new_err = sc.new_err;
+            const double sumsq = sc.sumsq_cam + sc.sumsq_pt;
+            if (sumsq < ba->opts.update_sq_conv_limit) ba->converged = true;   // :488-490
+            ptam_ba_trial t;
+            t.lambda = lambda;
+            t.sigma_sq = sc.sigma_sq;
+            t.err_old = cur_err;
+            t.err_new = new_err;
+            t.sum_sq_update = sumsq;
+            t.n_bad = sc.n_bad;
+            t.accepted = 0;
+            if (ba->opts.verbose)
+                std::printf("L%.1e\tOld %.6f  New %.6f  Diff %.6f\n", lambda, cur_err, new_err, cur_err - new_err);
+            if (new_err > cur_err) {   // ModifyLambda_BadStep :607-611
+                lambda = lambda * lambda_factor;
+                lambda_factor = lambda_factor * 2;
+            }
+            counter++;
+            if (counter >= ba->opts.max_iterations) hit_max = true;   // :518-520
+            ba->trials.push_back(t);
+        }
+        if (ran_any && new_err < cur_err) {   // :523-533
+            lambda_factor = 2.0;
+            lambda *= 0.3;
+            ba->cur ^= 1;   // commit: trial poses / points become current
+            ba->accepted++;
+            ba->trials.back().accepted = 1;
+        }
+        if (d.M > 0) hipLaunchKernelGGL(purge_kernel, dim3((d.M + 255) / 256), dim3(256), 0, ctx->stream, d);   // :536-547
+        HIP_TRY(hipGetLastError());
+        rc = ba_read_scalars(ba, &sc);
+        if (rc) return rc;
+        step_outlier_end.push_back(sc.n_outliers);
+    }
+    // ---- read back results ----
+    HIP_TRY(hipMemcpyAsync(ba->cam_pose.data(), d.pose[ba->cur], (size_t)d.C * 96, hipMemcpyDeviceToHost, ctx->stream));
+    if (d.P > 0) HIP_TRY(hipMemcpyAsync(ba->pts.data(), d.pt[ba->cur], (size_t)d.P * 24, hipMemcpyDeviceToHost, ctx->stream));
+    const int n_out = step_outlier_end.empty() ? 0 : step_outlier_end.back();
+    std::vector<int> out_idx(std::max(n_out, 1));
+    if (n_out > 0) HIP_TRY(hipMemcpyAsync(out_idx.data(), d.outliers, (size_t)n_out * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // outlier list in the reference's order: LM step, then list (insertion) order
+    int begin = 0;
+    for (int end : step_outlier_end) {
+        std::sort(out_idx.begin() + begin, out_idx.begin() + end);
+        for (int i = begin; i < end; i++) {
+            const int o = out_idx[i];
+            ba->outliers.push_back(std::make_pair(ba->m_pt[o], ba->m_cam[o]));
+            ba->m_dead[o] = 1;
+        }
+        begin = end;
+    }
+    // the device copy stays valid for another Compute(): poses/points are current in pose[cur]; the
+    // outlier counter restarts
+    if (n_out > 0) {
+        ba->prepared = false;   // rebuild without the erased measurements on the next Compute
+    }
+    if (accepted_out) *accepted_out = ba->accepted;
+    return PTAM_OK;
+}
+
+int ptam_ba_converged(const ptam_ba* ba) { return ba && ba->converged ? 1 : 0; }
+
+int ptam_ba_get_point(const ptam_ba* ba, int n, double pos[3]) {
+    ARG_TRY(ba && pos && n >= 0 && n < (int)(ba->pts.size() / 3));   // vector::at() would throw
+    std::memcpy(pos, &ba->pts[3 * (size_t)n], 24);
+    return PTAM_OK;
+}
+int ptam_ba_get_camera(const ptam_ba* ba, int n, double pose[12]) {
+    ARG_TRY(ba && pose && n >= 0 && n < (int)ba->cam_fixed.size());
+    std::memcpy(pose, &ba->cam_pose[12 * (size_t)n], 96);
+    return PTAM_OK;
+}
+int ptam_ba_get_all(const ptam_ba* ba, double* poses12, double* points3) {
+    ARG_TRY(ba);
+    if (poses12) std::memcpy(poses12, ba->cam_pose.data(), ba->cam_pose.size() * 8);
+    if (points3) std::memcpy(points3, ba->pts.data(), ba->pts.size() * 8);
+    return PTAM_OK;
+}
+int ptam_ba_get_outliers(const ptam_ba* ba, int32_t* pairs, int cap) {
+    if (!ba) return PTAM_E_ARG;
+    const int n = (int)ba->outliers.size();
+    for (int i = 0; i < n && i < cap && pairs; i++) {
+        pairs[2 * i] = ba->outliers[i].first;
+        pairs[2 * i + 1] = ba->outliers[i].second;
+    }
+    return n;
+}
+int ptam_ba_get_trials(const ptam_ba* ba, ptam_ba_trial* out, int cap) {
+    if (!ba) return PTAM_E_ARG;
+    const int n = (int)ba->trials.size();
+    for (int i = 0; i < n && i < cap && out; i++) out[i] = ba->trials[i];
+    return n;
+}
+int ptam_ba_counts(const ptam_ba* ba, int* n_cams, int* n_free, int* n_points, int* n_meas) {
+    ARG_TRY(ba);
+    int f = 0;
+    for (uint8_t x : ba->cam_fixed) f += x ? 0 : 1;
+    int live = 0;
+    for (uint8_t x : ba->m_dead) live += x ? 0 : 1;
+    if (n_cams) *n_cams = (int)ba->cam_fixed.size();
+    if (n_free) *n_free = f;
+    if (n_points) *n_points = (int)(ba->pts.size() / 3);
+    if (n_meas) *n_meas = live;
+    return PTAM_OK;
+}
+
+// K7 alone, HIP-event timed per launch (bench.py roofline leg)
+int ptam_ba_bench_jacobian(ptam_ba* ba, int reps, double* avg_ms, double* algorithmic_bytes) {
+    ARG_TRY(ba && reps > 0);
+    ptam_ctx* ctx = ba->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ptam_ba_prepare(ba);
+    if (rc) return rc;
+    BaDev& d = ba->d;
+    ARG_TRY(d.M > 0);
+    const bool prof = ba->prof;
+    ba->prof = false;
+    rc = ba_pass1_sigma(ba);
+    if (rc) return rc;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    for (int i = 0; i < 3; i++)
+        hipLaunchKernelGGL(jac_accum_kernel, dim3(d.grid_acc), dim3(BA_CHUNK), ba->smem_acc, ctx->stream, ctx->cam, d, ba->cur,
+                           ba->opts.estimator);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    double total = 0;
+    for (int i = 0; i < reps; i++) {
+        HIP_TRY(hipEventRecord(e0, ctx->stream));
+        hipLaunchKernelGGL(jac_accum_kernel, dim3(d.grid_acc), dim3(BA_CHUNK), ba->smem_acc, ctx->stream, ctx->cam, d, ba->cur,
+                           ba->opts.estimator);
+        HIP_TRY(hipEventRecord(e1, ctx->stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        total += ms;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    ba->prof = prof;
+    if (avg_ms) *avg_ms = total / reps;
+    if (algorithmic_bytes)   // 8 idx + 24 found/s + 1 state + 144 W per measurement,
+                             // 96 B/camera pose read, 24 read + 72 write per point, 216 B/free camera
+        *algorithmic_bytes = (double)d.M * (8 + 24 + 1 + 144) + (double)d.C * 96 + (double)d.P * (24 + 72) + (double)d.F * 216;
+    return PTAM_OK;
+}
+
+}   // extern "C"

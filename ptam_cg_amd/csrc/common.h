@@ -1,0 +1,199 @@
+// common.h — shared host/device definitions of libptam_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ptam_hip.h"
+
+// ---- error plumbing -------------------------------------------------------------------------
+void ptam_set_error(const char* fmt, ...);
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess) {                                                             \
+            ptam_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, \
+                           __LINE__);                                                        \
+            return PTAM_E_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+#define ARG_TRY(cond)                                                        \
+    do {                                                                     \
+        if (!(cond)) {                                                       \
+            ptam_set_error("bad argument: %s (%s:%d)", #cond, __FILE__, __LINE__); \
+            return PTAM_E_ARG;                                               \
+        }                                                                    \
+    } while (0)
+
+// ---- camera model on the device (pure function of these constants; no cached state) ----------
+// RefreshParams src/ATANCamera.cc:27-66
+struct DevCam {
+    double fx, fy, cx, cy;        // mvFocal, mvCenter (pixels)
+    double w, two_tan, w_inv, dist_enabled;
+    double largest_radius, max_r;
+    double width, height;
+};
+
+struct ptam_ctx {
+    int device;
+    hipStream_t stream;
+    ptam_cam_params params;
+    DevCam cam;
+    int halfsample;
+    // grow-on-demand device scratch + pinned host staging (owned by this ctx / thread)
+    void* d_scratch;
+    size_t d_scratch_cap;
+    void* h_pinned;
+    size_t h_pinned_cap;
+};
+
+int ctx_scratch(ptam_ctx* ctx, size_t bytes, void** out);     // device scratch >= bytes
+int ctx_pinned(ptam_ctx* ctx, size_t bytes, void** out);      // pinned host staging >= bytes
+
+// ---- small device math ---------------------------------------------------------------------
+#define PTAM_HD __host__ __device__ __forceinline__
+
+// rtrans_factor include/ATANCamera.h:143-149 + Project src/ATANCamera.cc:109-121
+PTAM_HD void cam_project(const DevCam& c, double x, double y, double& u, double& v, double& r, double& f) {
+    r = sqrt(x * x + y * y);
+    f = (r < 0.001 || c.w == 0.0) ? 1.0 : (c.w_inv * atan(r * c.two_tan) / r);
+    u = c.cx + c.fx * (f * x);
+    v = c.cy + c.fy * (f * y);
+}
+// GetProjectionDerivs src/ATANCamera.cc:179-209 for the projection (x, y, r, f)
+PTAM_HD void cam_derivs(const DevCam& c, double x, double y, double r_in, double f, double D[4]) {
+    const double k = c.two_tan;
+    const double r = r_in * c.dist_enabled;
+    double dx, dy;
+    if (r < 0.01) {
+        dx = 0.0;
+        dy = 0.0;
+    } else {
+        const double den = r * r * (1 + k * k * r * r);
+        dx = c.w_inv * (k * x) / den - x * f / (r * r);
+        dy = c.w_inv * (k * y) / den - y * f / (r * r);
+    }
+    D[0] = c.fx * (dx * x + f);
+    D[2] = c.fy * (dx * y);
+    D[1] = c.fx * (dy * x);
+    D[3] = c.fy * (dy * y + f);
+}
+
+// pose = R row-major (9) + t (3)
+PTAM_HD void se3_apply(const double* T, double x, double y, double z, double& ox, double& oy, double& oz) {
+    ox = T[9] + (T[0] * x + T[1] * y + T[2] * z);
+    oy = T[10] + (T[3] * x + T[4] * y + T[5] * z);
+    oz = T[11] + (T[6] * x + T[7] * y + T[8] * z);
+}
+
+// TooN SE3<>::exp followed by left-multiplication: out = exp(mu) * T
+PTAM_HD void se3_exp_mul(const double* mu, const double* T, double* out) {
+    const double one_6th = 1.0 / 6.0, one_20th = 1.0 / 20.0;
+    const double tx = mu[0], ty = mu[1], tz = mu[2], wx = mu[3], wy = mu[4], wz = mu[5];
+    const double theta_sq = wx * wx + wy * wy + wz * wz;
+    const double theta = sqrt(theta_sq);
+    const double cx = wy * tz - wz * ty, cy = wz * tx - wx * tz, cz = wx * ty - wy * tx;
+    double A, B, et[3];
+    if (theta_sq < 1e-8) {
+        A = 1.0 - one_6th * theta_sq;
+        B = 0.5;
+        et[0] = tx + 0.5 * cx;
+        et[1] = ty + 0.5 * cy;
+        et[2] = tz + 0.5 * cz;
+    } else {
+        double Cc;
+        if (theta_sq < 1e-6) {
+            Cc = one_6th * (1.0 - one_20th * theta_sq);
+            A = 1.0 - theta_sq * Cc;
+            B = 0.5 - 0.25 * one_6th * theta_sq;
+        } else {
+            const double inv_theta = 1.0 / theta;
+            A = sin(theta) * inv_theta;
+            B = (1 - cos(theta)) * (inv_theta * inv_theta);
+            Cc = (1 - A) * (inv_theta * inv_theta);
+        }
+        const double dx = wy * cz - wz * cy, dy = wz * cx - wx * cz, dz = wx * cy - wy * cx;
+        et[0] = tx + B * cx + Cc * dx;
+        et[1] = ty + B * cy + Cc * dy;
+        et[2] = tz + B * cz + Cc * dz;
+    }
+    double R[9];
+    {
+        const double wx2 = wx * wx, wy2 = wy * wy, wz2 = wz * wz;
+        R[0] = 1.0 - B * (wy2 + wz2);
+        R[4] = 1.0 - B * (wx2 + wz2);
+        R[8] = 1.0 - B * (wx2 + wy2);
+        double a = A * wz, b = B * (wx * wy);
+        R[1] = b - a;
+        R[3] = b + a;
+        a = A * wy;
+        b = B * (wx * wz);
+        R[2] = b + a;
+        R[6] = b - a;
+        a = A * wx;
+        b = B * (wy * wz);
+        R[5] = b - a;
+        R[7] = b + a;
+    }
+    double o[12];
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++)
+            o[r * 3 + c] = R[r * 3 + 0] * T[0 * 3 + c] + R[r * 3 + 1] * T[1 * 3 + c] + R[r * 3 + 2] * T[2 * 3 + c];
+        o[9 + r] = et[r] + (R[r * 3 + 0] * T[9] + R[r * 3 + 1] * T[10] + R[r * 3 + 2] * T[11]);
+    }
+    for (int i = 0; i < 12; i++) out[i] = o[i];
+}
+
+// M-estimators include/Tools.h:128-228
+PTAM_HD double est_sqrt_weight(int est, double e2, double s2) {
+    if (est == PTAM_EST_TUKEY) return e2 > s2 ? 0.0 : 1.0 - (e2 / s2);
+    if (est == PTAM_EST_CAUCHY) return sqrt(1.0 / (1.0 + e2 / s2));
+    return sqrt(e2 < s2 ? 1.0 : sqrt(s2 / e2));
+}
+PTAM_HD double est_weight(int est, double e2, double s2) {
+    if (est == PTAM_EST_TUKEY) {
+        const double r = e2 > s2 ? 0.0 : 1.0 - (e2 / s2);
+        return r * r;
+    }
+    if (est == PTAM_EST_CAUCHY) return 1.0 / (1.0 + e2 / s2);
+    return e2 < s2 ? 1.0 : sqrt(s2 / e2);
+}
+PTAM_HD double est_objective(int est, double e2, double s2) {
+    if (est == PTAM_EST_TUKEY) {
+        if (e2 > s2) return 1.0;
+        const double d = 1.0 - e2 / s2;
+        return 1.0 - d * d * d;
+    }
+    if (est == PTAM_EST_CAUCHY) return log(1.0 + e2 / s2);
+    if (e2 < s2) return 0.5 * e2;
+    const double s = sqrt(s2), e = sqrt(e2);
+    return s * (e - 0.5 * s);
+}
+// FindSigmaSquared from the median (sorted[n/2]) of n squared errors; size_t arithmetic in (2n-6)
+PTAM_HD double est_sigma_sq_from_median(int est, double median_sq, unsigned long long n) {
+    const unsigned long long den = n * 2ull - 6ull;   // wraps for n < 3 like the reference
+    double sigma = 1.4826 * (1 + 5.0 / (double)den) * sqrt(median_sq);
+    sigma = (est == PTAM_EST_HUBER ? 1.345 : 4.6851) * sigma;
+    return sigma * sigma;
+}
+
+// ---- wave64 / block helpers (device only) -----------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+#endif

@@ -1,0 +1,369 @@
+// keyframe.hip — KeyFrame::MakeKeyFrame_Lite (src/KeyFrame.cc:18-54) on gfx950:
+//   K1  pyramid_kernel       3x halfSample in one launch (register cascade over an 8x8 L0 block)
+//   K2a fast_detect_kernel   FAST-10 on all 4 levels in one launch; LDS-staged tiles with halo;
+//                            one wave = one 64-pixel row segment, corner bit-mask by wave ballot
+//   K2b fast_compact_kernel  raster-ordered compaction: popcount prefix over the (row, tile) masks
+//                            -> corner list + row LUT (the LUT IS the exclusive row prefix)
+#include "common.h"
+#include "keyframe.h"
+
+// ------------------------------------------------------------------------------------------------
+// K1: halfSample cascade.  Thread = one 8x8 block of L0 -> 4x4 of L1, 2x2 of L2, 1 of L3.
+// Variant R (default) = libCVD SSE2 byte path: vertical pavgb then horizontal pavgw;
+// variant T = (a+b+c+d)/4 truncating.  
+// ------------------------------------------------------------------------------------------------
+template <int VARIANT>
+__device__ __forceinline__ int half4(int a, int b, int c, int d) {
+    if (VARIANT == PTAM_HALFSAMPLE_T) return (a + b + c + d) >> 2;   // operands >= 0: shift == C division
+    const int v1 = (a + c + 1) >> 1, v2 = (b + d + 1) >> 1;
+    return (v1 + v2 + 1) >> 1;
+}
+
+struct PyrArgs {
+    const uint8_t* src;   // source image (device), stride == w0
+    uint8_t* lv[4];       // level images; lv[0] is written iff src != lv[0]
+    int w[4], h[4];
+};
+
+template <int VARIANT>
+__global__ void __launch_bounds__(256) pyramid_kernel(PyrArgs a) {
+    const int bx = blockIdx.x * blockDim.x + threadIdx.x;   // 8x8 block column
+    const int by = blockIdx.y * blockDim.y + threadIdx.y;
+    const int x0 = bx * 8, y0 = by * 8;
+    if (x0 >= a.w[0] || y0 >= a.h[0]) return;
+    const bool full = (x0 + 8 <= a.w[0]) && (y0 + 8 <= a.h[0]) && ((a.w[0] & 7) == 0);
+    uint8_t p[8][8];
+    if (full) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint2 v = *reinterpret_cast<const uint2*>(a.src + (size_t)(y0 + r) * a.w[0] + x0);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                p[r][c] = (v.x >> (8 * c)) & 0xff;
+                p[r][4 + c] = (v.y >> (8 * c)) & 0xff;
+            }
+        }
+        if (a.src != a.lv[0]) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                uint2 v;
+                v.x = p[r][0] | (p[r][1] << 8) | (p[r][2] << 16) | ((unsigned)p[r][3] << 24);
+                v.y = p[r][4] | (p[r][5] << 8) | (p[r][6] << 16) | ((unsigned)p[r][7] << 24);
+                *reinterpret_cast<uint2*>(a.lv[0] + (size_t)(y0 + r) * a.w[0] + x0) = v;
+            }
+        }
+    } else {
+        for (int r = 0; r < 8; r++)
+            for (int c = 0; c < 8; c++) {
+                const int x = x0 + c, y = y0 + r;
+                const bool in = x < a.w[0] && y < a.h[0];
+                p[r][c] = in ? a.src[(size_t)y * a.w[0] + x] : 0;
+                if (in && a.src != a.lv[0]) a.lv[0][(size_t)y * a.w[0] + x] = p[r][c];
+            }
+    }
+    // L1: 4x4
+    uint8_t q[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            q[r][c] = (uint8_t)half4<VARIANT>(p[2 * r][2 * c], p[2 * r][2 * c + 1], p[2 * r + 1][2 * c], p[2 * r + 1][2 * c + 1]);
+    const int x1 = bx * 4, y1 = by * 4;
+    if (full) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            *reinterpret_cast<uint32_t*>(a.lv[1] + (size_t)(y1 + r) * a.w[1] + x1) =
+                q[r][0] | (q[r][1] << 8) | (q[r][2] << 16) | ((unsigned)q[r][3] << 24);
+    } else {
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++)
+                if (x1 + c < a.w[1] && y1 + r < a.h[1]) a.lv[1][(size_t)(y1 + r) * a.w[1] + x1 + c] = q[r][c];
+    }
+    // L2: 2x2
+    uint8_t s[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+            s[r][c] = (uint8_t)half4<VARIANT>(q[2 * r][2 * c], q[2 * r][2 * c + 1], q[2 * r + 1][2 * c], q[2 * r + 1][2 * c + 1]);
+    const int x2 = bx * 2, y2 = by * 2;
+    for (int r = 0; r < 2; r++)
+        for (int c = 0; c < 2; c++)
+            if (x2 + c < a.w[2] && y2 + r < a.h[2]) a.lv[2][(size_t)(y2 + r) * a.w[2] + x2 + c] = s[r][c];
+    // L3
+    if (bx < a.w[3] && by < a.h[3])
+        a.lv[3][(size_t)by * a.w[3] + bx] = (uint8_t)half4<VARIANT>(s[0][0], s[0][1], s[1][0], s[1][1]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2a: FAST-10 segment test (libCVD fast_corner_detect_10 semantics).
+// Block = 256 threads = 4 waves = a 64 x 4 pixel tile; LDS tile carries a 3-pixel halo.
+// ------------------------------------------------------------------------------------------------
+#define FAST_TW 64
+#define FAST_TH 4
+#define FAST_LW (FAST_TW + 6 + 2)   // padded row pitch (72 bytes)
+
+__device__ __forceinline__ bool has_run10(unsigned m16) {
+    const unsigned d = m16 | (m16 << 16);
+    const unsigned a = d & (d >> 1);
+    const unsigned b = a & (a >> 2);
+    const unsigned c = b & (b >> 4);
+    return (c & (a >> 8) & 0xffffu) != 0;
+}
+
+__global__ void __launch_bounds__(256) fast_detect_kernel(KfLevels L) {
+    __shared__ uint8_t tile[(FAST_TH + 6) * FAST_LW];
+    // which level does this block belong to?
+    int lev = 0;
+#pragma unroll
+    for (int l = 1; l < PTAM_LEVELS; l++)
+        if ((int)blockIdx.x >= L.block_begin[l]) lev = l;
+    const int b = blockIdx.x - L.block_begin[lev];
+    const int w = L.w[lev], h = L.h[lev], ntx = L.ntx[lev];
+    const int tx = b % ntx, ty = b / ntx;
+    const int x0 = tx * FAST_TW, y0 = ty * FAST_TH;
+    const uint8_t* __restrict__ im = L.im[lev];
+    // stage (TH+6) x (TW+6) pixels, origin (x0-3, y0-3); out-of-image pixels read as 0 (never used
+    // by an in-range centre)
+    for (int i = threadIdx.x; i < (FAST_TH + 6) * (FAST_TW + 6); i += 256) {
+        const int r = i / (FAST_TW + 6), c = i - r * (FAST_TW + 6);
+        const int x = x0 - 3 + c, y = y0 - 3 + r;
+        uint8_t v = 0;
+        if (x >= 0 && x < w && y >= 0 && y < h) v = im[(size_t)y * w + x];
+        tile[r * FAST_LW + c] = v;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int x = x0 + lx, y = y0 + ly;
+    bool corner = false;
+    if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) {
+        const uint8_t* c = &tile[(ly + 3) * FAST_LW + lx + 3];
+        const int v = *c, hi = v + L.thr[lev], lo = v - L.thr[lev];
+        // ring order (dx,dy): (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
+        const int ring[16] = {c[3 * FAST_LW],      c[3 * FAST_LW + 1],  c[2 * FAST_LW + 2],  c[FAST_LW + 3],
+                              c[3],                c[-FAST_LW + 3],     c[-2 * FAST_LW + 2], c[-3 * FAST_LW + 1],
+                              c[-3 * FAST_LW],     c[-3 * FAST_LW - 1], c[-2 * FAST_LW - 2], c[-FAST_LW - 3],
+                              c[-3],               c[FAST_LW - 3],      c[2 * FAST_LW - 2],  c[3 * FAST_LW - 1]};
+        unsigned br = 0, dk = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            br |= (unsigned)(ring[i] > hi) << i;
+            dk |= (unsigned)(ring[i] < lo) << i;
+        }
+        corner = has_run10(br) || has_run10(dk);
+    }
+    const unsigned long long m = __ballot(corner);
+    if (lx == 0 && y < h) L.mask[lev][(size_t)y * ntx + tx] = m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2b: one block per level.  Entries e = y*ntx + tx in raster order; thread t owns a contiguous
+// chunk of entries, so an exclusive scan of per-thread popcounts gives raster-ordered offsets.
+// rowlut[y] = offset of entry (y, 0) = index of the first corner with row >= y (src/KeyFrame.cc:46-52).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) fast_compact_kernel(KfLevels L) {
+    __shared__ int wsum[16];
+    __shared__ int total_s;
+    const int lev = blockIdx.x;
+    const int h = L.h[lev], ntx = L.ntx[lev];
+    const int E = h * ntx;
+    const int per = (E + 1023) / 1024;
+    const int e0 = threadIdx.x * per, e1 = min(E, e0 + per);
+    const unsigned long long* __restrict__ mask = L.mask[lev];
+    int cnt = 0;
+    for (int e = e0; e < e1; e++) cnt += __popcll(mask[e]);
+    // block exclusive scan
+    int incl = cnt;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < 16; i++) {
+            const int v = wsum[i];
+            wsum[i] = run;
+            run += v;
+        }
+        total_s = run;
+    }
+    __syncthreads();
+    int off = wsum[wid] + incl - cnt;
+    ptam_int2* __restrict__ out = L.corners[lev];
+    int* __restrict__ lut = L.rowlut[lev];
+    for (int e = e0; e < e1; e++) {
+        const int y = e / ntx, tx = e - y * ntx;
+        if (tx == 0) lut[y] = off;
+        unsigned long long m = mask[e];
+        while (m) {
+            const int bit = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            out[off++] = ptam_int2{tx * FAST_TW + bit, y};
+        }
+    }
+    if (threadIdx.x == 0) L.ncorners[lev] = total_s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int kf_alloc(ptam_ctx* ctx, int w, int h, ptam_kf** out) {
+    ptam_kf* kf = new ptam_kf();
+    std::memset(kf, 0, sizeof *kf);
+    kf->device = ctx->device;
+    size_t px = 0, ent = 0, rows = 0;
+    int blocks = 0;
+    static const int thr[PTAM_LEVELS] = {10, 15, 15, 10};   // src/KeyFrame.cc:35-42
+    for (int l = 0; l < PTAM_LEVELS; l++) {
+        kf->L.w[l] = l ? kf->L.w[l - 1] / 2 : w;
+        kf->L.h[l] = l ? kf->L.h[l - 1] / 2 : h;
+        kf->L.thr[l] = thr[l];
+        kf->L.ntx[l] = (kf->L.w[l] + FAST_TW - 1) / FAST_TW;
+        kf->L.block_begin[l] = blocks;
+        blocks += kf->L.ntx[l] * ((kf->L.h[l] + FAST_TH - 1) / FAST_TH);
+        px += ((size_t)kf->L.w[l] * kf->L.h[l] + 255) & ~(size_t)255;
+        ent += (size_t)kf->L.ntx[l] * kf->L.h[l];
+        rows += kf->L.h[l];
+    }
+    kf->n_blocks = blocks;
+    kf->bytes_px = px;
+    // one allocation: pixels | masks | corners (worst case = every pixel) | rowluts | counts
+    const size_t b_mask = ent * 8, b_corn = px * sizeof(ptam_int2), b_lut = rows * 4 + 64;
+    kf->bytes_total = px + b_mask + b_corn + b_lut + 64;
+    hipError_t e = hipMalloc(&kf->base, kf->bytes_total);
+    if (e != hipSuccess) {
+        ptam_set_error("hipMalloc(%zu) failed: %s", kf->bytes_total, hipGetErrorString(e));
+        delete kf;
+        return PTAM_E_HIP;
+    }
+    char* p = (char*)kf->base;
+    for (int l = 0; l < PTAM_LEVELS; l++) {
+        kf->L.im[l] = (uint8_t*)p;
+        p += ((size_t)kf->L.w[l] * kf->L.h[l] + 255) & ~(size_t)255;
+    }
+    for (int l = 0; l < PTAM_LEVELS; l++) {
+        kf->L.mask[l] = (unsigned long long*)p;
+        p += (size_t)kf->L.ntx[l] * kf->L.h[l] * 8;
+    }
+    for (int l = 0; l < PTAM_LEVELS; l++) {
+        kf->L.corners[l] = (ptam_int2*)p;
+        p += (((size_t)kf->L.w[l] * kf->L.h[l] + 255) & ~(size_t)255) * sizeof(ptam_int2);
+    }
+    for (int l = 0; l < PTAM_LEVELS; l++) {
+        kf->L.rowlut[l] = (int*)p;
+        p += (size_t)kf->L.h[l] * 4;
+    }
+    p = (char*)(((uintptr_t)p + 63) & ~(uintptr_t)63);
+    kf->L.ncorners = (int*)p;
+    *out = kf;
+    return PTAM_OK;
+}
+
+static int kf_run(ptam_ctx* ctx, ptam_kf* kf, const uint8_t* d_src) {
+    PyrArgs a;
+    a.src = d_src;
+    for (int l = 0; l < PTAM_LEVELS; l++) {
+        a.lv[l] = kf->L.im[l];
+        a.w[l] = kf->L.w[l];
+        a.h[l] = kf->L.h[l];
+    }
+    const int nbx = (a.w[0] + 7) / 8, nby = (a.h[0] + 7) / 8;
+    dim3 blk(64, 4), grd((nbx + 63) / 64, (nby + 3) / 4);
+    if (ctx->halfsample == PTAM_HALFSAMPLE_T)
+        hipLaunchKernelGGL(pyramid_kernel<PTAM_HALFSAMPLE_T>, grd, blk, 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(pyramid_kernel<PTAM_HALFSAMPLE_R>, grd, blk, 0, ctx->stream, a);
+    hipLaunchKernelGGL(fast_detect_kernel, dim3(kf->n_blocks), dim3(256), 0, ctx->stream, kf->L);
+    hipLaunchKernelGGL(fast_compact_kernel, dim3(PTAM_LEVELS), dim3(1024), 0, ctx->stream, kf->L);
+    HIP_TRY(hipGetLastError());
+    kf->counts_valid = 0;
+    return PTAM_OK;
+}
+
+int kf_fetch_counts(ptam_ctx* ctx, const ptam_kf* kf_c) {
+    ptam_kf* kf = const_cast<ptam_kf*>(kf_c);
+    if (kf->counts_valid) return PTAM_OK;
+    HIP_TRY(hipMemcpyAsync(kf->n_corners, kf->L.ncorners, sizeof kf->n_corners, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    kf->counts_valid = 1;
+    return PTAM_OK;
+}
+
+extern "C" {
+
+int ptam_kf_create(ptam_ctx* ctx, int width, int height, ptam_kf** out) {
+    ARG_TRY(ctx && out && width >= 8 && height >= 8);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return kf_alloc(ctx, width, height, out);
+}
+
+int ptam_kf_destroy(ptam_kf* kf) {
+    if (!kf) return PTAM_OK;
+    hipSetDevice(kf->device);
+    hipDeviceSynchronize();
+    hipFree(kf->base);
+    delete kf;
+    return PTAM_OK;
+}
+
+int ptam_make_keyframe_lite(ptam_ctx* ctx, ptam_kf* kf, const uint8_t* im, int stride) {
+    ARG_TRY(ctx && kf && im && stride >= kf->L.w[0]);
+    HIP_TRY(hipSetDevice(ctx->device));
+    // copy(im, aLevels[0].im)  src/KeyFrame.cc:20-21 — straight into the keyframe's level 0
+    HIP_TRY(hipMemcpy2DAsync(kf->L.im[0], kf->L.w[0], im, stride, kf->L.w[0], kf->L.h[0], hipMemcpyHostToDevice,
+                             ctx->stream));
+    return kf_run(ctx, kf, kf->L.im[0]);
+}
+
+int ptam_make_keyframe_lite_dev(ptam_ctx* ctx, ptam_kf* kf, const uint8_t* d_im) {
+    ARG_TRY(ctx && kf && d_im);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return kf_run(ctx, kf, d_im);   // the pyramid kernel also copies src -> level 0
+}
+
+int ptam_kf_clone(ptam_ctx* ctx, const ptam_kf* src, ptam_kf** out) {
+    ARG_TRY(ctx && src && out);
+    HIP_TRY(hipSetDevice(ctx->device));
+    ptam_kf* kf = nullptr;
+    int rc = kf_alloc(ctx, src->L.w[0], src->L.h[0], &kf);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(kf->base, src->base, src->bytes_total, hipMemcpyDeviceToDevice, ctx->stream));
+    kf->counts_valid = 0;
+    *out = kf;
+    return PTAM_OK;
+}
+
+int ptam_kf_level_info(ptam_ctx* ctx, const ptam_kf* kf, int level, int* w, int* h, int* n_corners) {
+    ARG_TRY(ctx && kf && level >= 0 && level < PTAM_LEVELS);
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (w) *w = kf->L.w[level];
+    if (h) *h = kf->L.h[level];
+    if (n_corners) {
+        int rc = kf_fetch_counts(ctx, kf);
+        if (rc) return rc;
+        *n_corners = kf->n_corners[level];
+    }
+    return PTAM_OK;
+}
+
+int ptam_kf_read_level(ptam_ctx* ctx, const ptam_kf* kf, int level, uint8_t* px, ptam_int2* corners,
+                       int32_t* rowlut) {
+    ARG_TRY(ctx && kf && level >= 0 && level < PTAM_LEVELS);
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = kf_fetch_counts(ctx, kf);
+    if (rc) return rc;
+    const int w = kf->L.w[level], h = kf->L.h[level], n = kf->n_corners[level];
+    if (px) HIP_TRY(hipMemcpyAsync(px, kf->L.im[level], (size_t)w * h, hipMemcpyDeviceToHost, ctx->stream));
+    if (corners && n > 0)
+        HIP_TRY(hipMemcpyAsync(corners, kf->L.corners[level], (size_t)n * sizeof(ptam_int2), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    if (rowlut) HIP_TRY(hipMemcpyAsync(rowlut, kf->L.rowlut[level], (size_t)h * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PTAM_OK;
+}
+
+}   // extern "C"

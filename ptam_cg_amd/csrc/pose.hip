@@ -1,0 +1,458 @@
+// pose.hip — Tracker pose Gauss-Newton on gfx950 (K4).
+//   driver      src/Tracker.cc:613-643 (fine stage; :552-568 coarse stage via opts)
+//   per point   include/Tracker.h:70-142 (Project / ProjectAndDerivs / CalcJacobian / LinearUpdate)
+//   update      src/Tracker.cc:928-1005 (CalcPoseUpdate: Tukey sigma from the exact order statistic
+//               sorted[n/2], weighted 6x6 normal equations with prior 100, LDL^T solve)
+// The whole 10-iteration loop runs in ONE launch of ONE persistent workgroup (1024 threads): the
+// pose lives in LDS, per-measurement state in an L2-resident scratch array, the median is an exact
+// 8x8-bit MSB radix select over LDS histograms, the 27 normal-equation sums are reduced by wavefront
+// shuffles + a fixed-order cross-wave pass (deterministic), thread 0 solves and applies exp().
+#include "common.h"
+
+struct PoseState {
+    double cam[3];
+    double img[2];
+    double D[4];
+    double J[12];
+    double e[2];
+    double e2;
+    int found;
+    int pad_;
+};
+
+#define GN_THREADS 1024
+#define GN_WAVES (GN_THREADS / 64)
+
+struct GnShared {
+    double pose[12];
+    double mu[6];
+    double red[GN_WAVES][27];
+    double sigma_sq;
+    unsigned hist[256];
+    int sel_digit;
+    int sel_k;
+    int count;
+    int wcount[GN_WAVES];
+};
+
+// exact k-th smallest (0-based) of the e2 of found measurements: MSB-first radix select on the IEEE
+// bit pattern (all keys >= 0, so unsigned bit order == value order)
+__device__ double block_select_kth(GnShared& sh, const PoseState* __restrict__ st, int n, int k) {
+    unsigned long long prefix = 0;
+    const int tid = threadIdx.x;
+    for (int pass = 0; pass < 8; pass++) {
+        const int shift = 56 - 8 * pass;
+        if (tid < 256) sh.hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += GN_THREADS) {
+            if (!st[i].found) continue;
+            const unsigned long long key = (unsigned long long)__double_as_longlong(st[i].e2);
+            if (pass == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8)))
+                atomicAdd(&sh.hist[(key >> shift) & 255], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const unsigned c0 = sh.hist[4 * tid], c1 = sh.hist[4 * tid + 1], c2 = sh.hist[4 * tid + 2],
+                           c3 = sh.hist[4 * tid + 3];
+            const int s = (int)(c0 + c1 + c2 + c3);
+            int incl = s;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o, 64);
+                if (tid >= o) incl += v;
+            }
+            const int excl = incl - s;
+            if (excl <= k && k < incl) {
+                int kk = k - excl, d = 4 * tid;
+                if (kk >= (int)c0) {
+                    kk -= c0;
+                    d++;
+                    if (kk >= (int)c1) {
+                        kk -= c1;
+                        d++;
+                        if (kk >= (int)c2) {
+                            kk -= c2;
+                            d++;
+                        }
+                    }
+                }
+                sh.sel_digit = d;
+                sh.sel_k = kk;
+            }
+        }
+        __syncthreads();
+        prefix |= (unsigned long long)sh.sel_digit << shift;
+        k = sh.sel_k;
+        __syncthreads();
+    }
+    return __longlong_as_double((long long)prefix);
+}
+
+// TooN Cholesky<6> (unpivoted LDL^T, lower triangle) + backsub, run by one thread
+__device__ void ldlt6_solve(double A[36], const double b[6], double x[6]) {
+    for (int col = 0; col < 6; col++) {
+        double inv_diag = 1;
+        for (int row = col; row < 6; row++) {
+            double val = A[row * 6 + col];
+            for (int c2 = 0; c2 < col; c2++) val -= A[c2 * 6 + col] * A[row * 6 + c2];
+            if (row == col) {
+                A[row * 6 + col] = val;
+                inv_diag = 1 / val;
+            } else {
+                A[col * 6 + row] = val;
+                A[row * 6 + col] = val * inv_diag;
+            }
+        }
+    }
+    double y[6];
+    for (int i = 0; i < 6; i++) {
+        double val = b[i];
+        for (int j = 0; j < i; j++) val -= A[i * 6 + j] * y[j];
+        y[i] = val;
+    }
+    for (int i = 0; i < 6; i++) y[i] /= A[i * 6 + i];
+    for (int i = 5; i >= 0; i--) {
+        double val = y[i];
+        for (int j = i + 1; j < 6; j++) val -= A[j * 6 + i] * x[j];
+        x[i] = val;
+    }
+}
+
+// Tracker::CalcPoseUpdate (src/Tracker.cc:928-1005) for the whole block; result in sh.mu
+__device__ void block_calc_pose_update(GnShared& sh, PoseState* __restrict__ st, int n,
+                                       const double* __restrict__ found, const double* __restrict__ snoise,
+                                       int found_stride, double override_sigma, int est, double prior, bool mark,
+                                       int* __restrict__ flags) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // errors :946-954
+    int cnt = 0;
+    for (int i = tid; i < n; i += GN_THREADS) {
+        if (!st[i].found) continue;
+        const double s = snoise[(size_t)i * found_stride];
+        const double ex = s * (found[(size_t)i * found_stride] - st[i].img[0]);
+        const double ey = s * (found[(size_t)i * found_stride + 1] - st[i].img[1]);
+        st[i].e[0] = ex;
+        st[i].e[1] = ey;
+        st[i].e2 = ex * ex + ey * ey;
+        cnt++;
+    }
+    cnt = wave_sum_i32(cnt);
+    if (lane == 0) sh.wcount[wid] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        int t = 0;
+        for (int i = 0; i < GN_WAVES; i++) t += sh.wcount[i];
+        sh.count = t;
+    }
+    __syncthreads();
+    const int nf = sh.count;
+    if (nf == 0) {   // :955-956
+        if (tid < 6) sh.mu[tid] = 0;
+        __syncthreads();
+        return;
+    }
+    double sigma_sq;
+    if (override_sigma > 0)
+        sigma_sq = override_sigma;
+    else {
+        const double med = block_select_kth(sh, st, n, nf / 2);
+        sigma_sq = est_sigma_sq_from_median(est, med, (unsigned long long)nf);
+    }
+    // WLS<6> accumulate :973-1002 : 21 lower-triangle sums of C + 6 of b
+    double acc[27];
+#pragma unroll
+    for (int k = 0; k < 27; k++) acc[k] = 0;
+    for (int i = tid; i < n; i += GN_THREADS) {
+        if (!st[i].found) continue;
+        const double wgt = est_weight(est, st[i].e2, sigma_sq);
+        if (wgt == 0.0) {
+            if (mark && flags) flags[i] = 1;
+            continue;
+        }
+        const double s = snoise[(size_t)i * found_stride];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            double J[6], Jw[6];
+#pragma unroll
+            for (int m = 0; m < 6; m++) {
+                J[m] = s * st[i].J[r * 6 + m];
+                Jw[m] = J[m] * wgt;
+            }
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int b = 0; b <= a; b++) acc[k++] += Jw[a] * J[b];
+#pragma unroll
+            for (int a = 0; a < 6; a++) acc[21 + a] += st[i].e[r] * Jw[a];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 27; k++) {
+        const double v = wave_sum_f64(acc[k]);
+        if (lane == 0) sh.red[wid][k] = v;
+    }
+    __syncthreads();
+    if (tid < 27) {
+        double t = 0;
+        for (int i = 0; i < GN_WAVES; i++) t += sh.red[i][tid];
+        sh.red[0][tid] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double C[36], b[6], x[6];
+        int k = 0;
+        for (int a = 0; a < 6; a++)
+            for (int c = 0; c <= a; c++) {
+                C[a * 6 + c] = C[c * 6 + a] = sh.red[0][k++];
+            }
+        for (int a = 0; a < 6; a++) {
+            C[a * 6 + a] += prior;   // add_prior :974
+            b[a] = sh.red[0][21 + a];
+        }
+        ldlt6_solve(C, b, x);
+        for (int a = 0; a < 6; a++) sh.mu[a] = x[a];
+    }
+    __syncthreads();
+}
+
+// TrackerData::Project (include/Tracker.h:70-85); returns "camera model reached"
+__device__ __forceinline__ bool td_project(const DevCam& cam, const double* T, const double* X, PoseState& st,
+                                           bool& in_image) {
+    in_image = false;
+    se3_apply(T, X[0], X[1], X[2], st.cam[0], st.cam[1], st.cam[2]);
+    if (st.cam[2] < 0.001) return false;
+    const double x = st.cam[0] / st.cam[2], y = st.cam[1] / st.cam[2];
+    if (x * x + y * y > cam.largest_radius * cam.largest_radius) return false;
+    double u, v, r, f;
+    cam_project(cam, x, y, u, v, r, f);
+    st.img[0] = u;
+    st.img[1] = v;
+    cam_derivs(cam, x, y, r, f, st.D);   // GetProjectionDerivs of THIS projection (no shared cache)
+    if (r > cam.max_r) return true;
+    if (u < 0 || v < 0 || u > cam.width || v > cam.height) return true;
+    in_image = true;
+    return true;
+}
+
+// CalcJacobian include/Tracker.h:125-136
+__device__ __forceinline__ void td_jacobian(PoseState& st) {
+    const double X = st.cam[0], Y = st.cam[1], Z = st.cam[2];
+    const double iz = 1.0 / Z;
+    // generator_field(m, (X,Y,Z,1)): m<3 -> e_m ; 3 -> (0,-Z,Y) ; 4 -> (Z,0,-X) ; 5 -> (-Y,X,0)
+    const double gx[6] = {1, 0, 0, 0, Z, -Y};
+    const double gy[6] = {0, 1, 0, -Z, 0, X};
+    const double gz[6] = {0, 0, 1, Y, -X, 0};
+#pragma unroll
+    for (int m = 0; m < 6; m++) {
+        const double mx = (gx[m] - X * gz[m] * iz) * iz;
+        const double my = (gy[m] - Y * gz[m] * iz) * iz;
+        st.J[m] = st.D[0] * mx + st.D[1] * my;
+        st.J[6 + m] = st.D[2] * mx + st.D[3] * my;
+    }
+}
+
+__global__ void __launch_bounds__(GN_THREADS) pose_gn_kernel(DevCam cam, int n, const ptam_pose_meas* __restrict__ meas,
+                                                             const ptam_projection* __restrict__ entry,
+                                                             double* __restrict__ pose_io, ptam_gn_opts opts,
+                                                             PoseState* __restrict__ st, int* __restrict__ flags,
+                                                             double* __restrict__ updates) {
+    __shared__ GnShared sh;
+    const int tid = threadIdx.x;
+    if (tid < 12) sh.pose[tid] = pose_io[tid];
+    __syncthreads();
+    for (int i = tid; i < n; i += GN_THREADS) {
+        PoseState s;
+        s.found = 1;
+        s.pad_ = 0;
+        s.e[0] = s.e[1] = s.e2 = 0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) s.J[k] = 0;
+        if (entry) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) s.cam[k] = entry[i].cam[k];
+            s.img[0] = entry[i].image[0];
+            s.img[1] = entry[i].image[1];
+#pragma unroll
+            for (int k = 0; k < 4; k++) s.D[k] = entry[i].derivs[k];
+        } else {
+            s.img[0] = s.img[1] = 0;
+            s.D[0] = s.D[1] = s.D[2] = s.D[3] = 0;
+            bool in_image;
+            td_project(cam, sh.pose, meas[i].world, s, in_image);
+            if (!in_image) s.found = 0;   // not in the potentially-visible set (src/Tracker.cc:456-458)
+        }
+        st[i] = s;
+        if (flags) flags[i] = 0;
+    }
+    __syncthreads();
+    const double* found = meas[0].found;
+    const double* snoise = &meas[0].sqrt_inv_noise;
+    const int stride = sizeof(ptam_pose_meas) / sizeof(double);
+    for (int iter = 0; iter < opts.iterations; iter++) {
+        const bool nonlinear = (opts.nonlinear_mask >> iter) & 1u;
+        if (iter != 0) {
+            if (nonlinear) {
+                for (int i = tid; i < n; i += GN_THREADS)
+                    if (st[i].found) {
+                        PoseState s = st[i];
+                        bool in_image;
+                        td_project(cam, sh.pose, meas[i].world, s, in_image);   // keeps img/D when not reached
+                        st[i] = s;
+                    }
+            } else {
+                for (int i = tid; i < n; i += GN_THREADS)
+                    if (st[i].found) {   // LinearUpdate include/Tracker.h:139-142
+                        double a = 0, b = 0;
+#pragma unroll
+                        for (int m = 0; m < 6; m++) {
+                            a += st[i].J[m] * sh.mu[m];
+                            b += st[i].J[6 + m] * sh.mu[m];
+                        }
+                        st[i].img[0] += a;
+                        st[i].img[1] += b;
+                    }
+            }
+        }
+        if (nonlinear)
+            for (int i = tid; i < n; i += GN_THREADS)
+                if (st[i].found) {
+                    PoseState s = st[i];
+                    td_jacobian(s);
+                    st[i] = s;
+                }
+        __syncthreads();   // sh.mu (last update) fully consumed before it is overwritten
+        const double ov = iter > opts.override_after ? opts.override_sigma_sq : 0.0;
+        block_calc_pose_update(sh, st, n, found, snoise, stride, ov, opts.estimator, opts.prior,
+                               iter == opts.mark_outliers_iter, flags);
+        if (tid == 0) {
+            double np[12];
+            se3_exp_mul(sh.mu, sh.pose, np);   // mse3CamFromWorld = SE3<>::exp(v6Update) * mse3CamFromWorld
+            for (int k = 0; k < 12; k++) sh.pose[k] = np[k];
+            if (updates)
+                for (int k = 0; k < 6; k++) updates[6 * iter + k] = sh.mu[k];
+        }
+        __syncthreads();
+    }
+    if (tid < 12) pose_io[tid] = sh.pose[tid];
+}
+
+__global__ void __launch_bounds__(GN_THREADS) calc_pose_update_kernel(int n, const ptam_pose_update_meas* __restrict__ meas,
+                                                                      double override_sigma, int est, double prior,
+                                                                      PoseState* __restrict__ st, int* __restrict__ flags,
+                                                                      double* __restrict__ mu_out) {
+    __shared__ GnShared sh;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += GN_THREADS) {
+        PoseState s;
+        s.found = 1;
+        s.pad_ = 0;
+        s.cam[0] = s.cam[1] = s.cam[2] = 0;
+        s.D[0] = s.D[1] = s.D[2] = s.D[3] = 0;
+        s.img[0] = meas[i].image[0];
+        s.img[1] = meas[i].image[1];
+#pragma unroll
+        for (int k = 0; k < 12; k++) s.J[k] = meas[i].jac[k];
+        s.e[0] = s.e[1] = s.e2 = 0;
+        st[i] = s;
+        if (flags) flags[i] = 0;
+    }
+    __syncthreads();
+    const int stride = sizeof(ptam_pose_update_meas) / sizeof(double);
+    block_calc_pose_update(sh, st, n, meas[0].found, &meas[0].sqrt_inv_noise, stride, override_sigma, est, prior,
+                           flags != nullptr, flags);
+    if (tid < 6) mu_out[tid] = sh.mu[tid];
+}
+
+extern "C" {
+
+void ptam_gn_opts_default(ptam_gn_opts* o) {
+    if (!o) return;
+    o->iterations = 10;
+    o->nonlinear_mask = 0x211;   // iter 0, 4, 9  src/Tracker.cc:618
+    o->override_after = 5;       // :637
+    o->override_sigma_sq = 16.0;
+    o->mark_outliers_iter = 9;   // :640
+    o->estimator = PTAM_EST_TUKEY;
+    o->prior = 100.0;            // :974
+}
+
+int ptam_pose_gn(ptam_ctx* ctx, int n, const ptam_pose_meas* meas, const ptam_projection* entry,
+                 double pose_inout[12], const ptam_gn_opts* opts, int32_t* outlier_flags, double* updates_out) {
+    ARG_TRY(ctx && n >= 0 && pose_inout);
+    ptam_gn_opts o;
+    if (opts)
+        o = *opts;
+    else
+        ptam_gn_opts_default(&o);
+    ARG_TRY(o.iterations >= 0 && o.iterations <= 32);
+    if (n == 0) {
+        // CalcPoseUpdate returns a zero update for an empty set (:955-956): pose unchanged
+        if (updates_out) std::memset(updates_out, 0, sizeof(double) * 6 * o.iterations);
+        return PTAM_OK;
+    }
+    ARG_TRY(meas);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t bm = (size_t)n * sizeof(ptam_pose_meas), be = entry ? (size_t)n * sizeof(ptam_projection) : 0,
+                 bs = (size_t)n * sizeof(PoseState), bf = (size_t)n * 4, bu = (size_t)6 * 32 * 8;
+    void* s;
+    int rc = ctx_scratch(ctx, bm + be + bs + bf + bu + 96 + 64, &s);
+    if (rc) return rc;
+    char* p = (char*)s;
+    ptam_pose_meas* d_m = (ptam_pose_meas*)p;
+    p += bm;
+    ptam_projection* d_e = entry ? (ptam_projection*)p : nullptr;
+    p += be;
+    PoseState* d_s = (PoseState*)p;
+    p += bs;
+    double* d_pose = (double*)p;
+    p += 96;
+    double* d_u = (double*)p;
+    p += bu;
+    int* d_f = (int*)p;
+    HIP_TRY(hipMemcpyAsync(d_m, meas, bm, hipMemcpyHostToDevice, ctx->stream));
+    if (entry) HIP_TRY(hipMemcpyAsync(d_e, entry, be, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_pose, pose_inout, 96, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(pose_gn_kernel, dim3(1), dim3(GN_THREADS), 0, ctx->stream, ctx->cam, n, d_m, d_e, d_pose, o, d_s,
+                       d_f, d_u);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(pose_inout, d_pose, 96, hipMemcpyDeviceToHost, ctx->stream));
+    if (outlier_flags) HIP_TRY(hipMemcpyAsync(outlier_flags, d_f, bf, hipMemcpyDeviceToHost, ctx->stream));
+    if (updates_out)
+        HIP_TRY(hipMemcpyAsync(updates_out, d_u, sizeof(double) * 6 * o.iterations, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PTAM_OK;
+}
+
+int ptam_calc_pose_update(ptam_ctx* ctx, int n, const ptam_pose_update_meas* meas, double override_sigma_sq,
+                          int estimator, double prior, double mu_out[6], int32_t* weight_zero_flags) {
+    ARG_TRY(ctx && n >= 0 && mu_out);
+    if (n == 0) {
+        for (int i = 0; i < 6; i++) mu_out[i] = 0;
+        return PTAM_OK;
+    }
+    ARG_TRY(meas);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t bm = (size_t)n * sizeof(ptam_pose_update_meas), bs = (size_t)n * sizeof(PoseState), bf = (size_t)n * 4;
+    void* s;
+    int rc = ctx_scratch(ctx, bm + bs + bf + 64, &s);
+    if (rc) return rc;
+    char* p = (char*)s;
+    ptam_pose_update_meas* d_m = (ptam_pose_update_meas*)p;
+    p += bm;
+    PoseState* d_s = (PoseState*)p;
+    p += bs;
+    double* d_mu = (double*)p;
+    p += 64;
+    int* d_f = (int*)p;
+    HIP_TRY(hipMemcpyAsync(d_m, meas, bm, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(calc_pose_update_kernel, dim3(1), dim3(GN_THREADS), 0, ctx->stream, n, d_m, override_sigma_sq,
+                       estimator, prior, d_s, weight_zero_flags ? d_f : nullptr, d_mu);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(mu_out, d_mu, 48, hipMemcpyDeviceToHost, ctx->stream));
+    if (weight_zero_flags) HIP_TRY(hipMemcpyAsync(weight_zero_flags, d_f, bf, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PTAM_OK;
+}
+
+}   // extern "C"

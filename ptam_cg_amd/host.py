@@ -1,0 +1,308 @@
+"""Host-side mirror of the reference's class surface for the hot path, over the C ABI.
+
+Class / method names follow the reference (KeyFrame::MakeKeyFrame_Lite src/KeyFrame.cc:18,
+PatchFinder::FindPatchCoarse src/PatchFinder.cc:160, Tracker::CalcPoseUpdate src/Tracker.cc:928,
+Bundle include/Bundle.h:106-152) so that tests read like tests of the reference.  Every class takes
+the bound library (`_abi.Bound`) it drives; `ptam_cg_amd.Context()` defaults to libptam_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import (BaOpts, BaTrial, CamParams, GnOpts, Int2, PatchQuery, PatchResult, PoseMeas,
+                   PoseUpdateMeas, Projection)
+
+# config/camera.cfg:7
+DEFAULT_CAMERA = (1.0803, 1.43987, 0.519983, 0.548655, 0.244943)
+
+PATCH_QUERY_DT = np.dtype([("x", "<i4"), ("y", "<i4"), ("level", "<i4"), ("range", "<u4")])
+PATCH_RESULT_DT = np.dtype([("found", "<i4"), ("best_ssd", "<i4"), ("best_x", "<i4"), ("best_y", "<i4"),
+                            ("n_scored", "<i4"), ("pad_", "<i4"), ("pos", "<f8", (2,))])
+PROJECTION_DT = np.dtype([("cam", "<f8", (3,)), ("image", "<f8", (2,)), ("derivs", "<f8", (4,)),
+                          ("in_image", "<i4"), ("pad_", "<i4")])
+POSE_MEAS_DT = np.dtype([("world", "<f8", (3,)), ("found", "<f8", (2,)), ("sqrt_inv_noise", "<f8")])
+POSE_UPDATE_MEAS_DT = np.dtype([("found", "<f8", (2,)), ("image", "<f8", (2,)), ("sqrt_inv_noise", "<f8"),
+                                ("jac", "<f8", (12,))])
+BA_TRIAL_DT = np.dtype([("lambda", "<f8"), ("sigma_sq", "<f8"), ("err_old", "<f8"), ("err_new", "<f8"),
+                        ("sum_sq_update", "<f8"), ("n_bad", "<i4"), ("accepted", "<i4")])
+assert PATCH_RESULT_DT.itemsize == C.sizeof(PatchResult)
+assert PROJECTION_DT.itemsize == C.sizeof(Projection)
+assert POSE_MEAS_DT.itemsize == C.sizeof(PoseMeas)
+assert POSE_UPDATE_MEAS_DT.itemsize == C.sizeof(PoseUpdateMeas)
+assert BA_TRIAL_DT.itemsize == C.sizeof(BaTrial)
+
+
+class PtamError(RuntimeError):
+    pass
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _pd(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Context:
+    """One per calling thread: camera model (ATANCamera, src/ATANCamera.cc) + stream + scratch."""
+
+    def __init__(self, lib=None, camera=DEFAULT_CAMERA, size=(640, 480), device=0,
+                 halfsample=_abi.HALFSAMPLE_R):
+        if lib is None:
+            from ._lib import load
+            lib = load()
+        self.lib = lib
+        self.size = tuple(size)
+        self.cam = CamParams(*camera, size[0], size[1])
+        h = C.c_void_p()
+        self._check(lib.ctx_create(C.byref(self.cam), device, C.byref(h)), "ctx_create")
+        self.h = h
+        self._check(lib.ctx_set_halfsample(self.h, halfsample), "ctx_set_halfsample")
+
+    def _check(self, rc, what):
+        if rc < 0:
+            msg = self.lib.last_error() if self.lib.has("last_error") else b""
+            raise PtamError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+        return rc
+
+    def sync(self):
+        self._check(self.lib.ctx_sync(self.h), "ctx_sync")
+
+    def camera_constants(self):
+        out = np.zeros(8)
+        self._check(self.lib.ctx_camera_constants(self.h, _pd(out)), "camera_constants")
+        return dict(zip(["focal_x", "focal_y", "centre_x", "centre_y", "two_tan", "w_inv",
+                         "largest_radius", "max_r"], out))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ctx_destroy(self.h)
+            self.h = None
+
+    # -- TrackerData::Project batch (include/Tracker.h:70-94) --
+    def project_points(self, world, pose):
+        world = np.ascontiguousarray(world, dtype=np.float64).reshape(-1, 3)
+        pose = np.ascontiguousarray(pose, dtype=np.float64).reshape(12)
+        out = np.zeros(len(world), dtype=PROJECTION_DT)
+        self._check(self.lib.project_points(self.h, len(world), _ptr(world), _pd(pose), _ptr(out)),
+                    "project_points")
+        return out
+
+    # -- Tracker pose Gauss-Newton (src/Tracker.cc:613-643) --
+    def gn_opts(self, **kw):
+        o = GnOpts()
+        self.lib.gn_opts_default(C.byref(o))
+        for k, v in kw.items():
+            setattr(o, k, v)
+        return o
+
+    def pose_gn(self, world, found, sqrt_inv_noise, pose, opts=None, entry=None):
+        n = len(world)
+        meas = np.zeros(n, dtype=POSE_MEAS_DT)
+        meas["world"] = world
+        meas["found"] = found
+        meas["sqrt_inv_noise"] = sqrt_inv_noise
+        pose = np.array(pose, dtype=np.float64).reshape(12).copy()
+        opts = opts or self.gn_opts()
+        flags = np.zeros(n, dtype=np.int32)
+        updates = np.zeros((opts.iterations, 6))
+        if entry is not None:
+            entry = np.ascontiguousarray(entry, dtype=PROJECTION_DT)
+        self._check(self.lib.pose_gn(self.h, n, _ptr(meas), _ptr(entry), _pd(pose), C.byref(opts),
+                                     _ptr(flags), _ptr(updates)), "pose_gn")
+        return pose, flags, updates
+
+    # -- Tracker::CalcPoseUpdate (src/Tracker.cc:928-1005) --
+    def calc_pose_update(self, found, image, sqrt_inv_noise, jac, override_sigma_sq=0.0,
+                         estimator=_abi.EST_TUKEY, prior=100.0):
+        n = len(found)
+        meas = np.zeros(n, dtype=POSE_UPDATE_MEAS_DT)
+        meas["found"], meas["image"] = found, image
+        meas["sqrt_inv_noise"] = sqrt_inv_noise
+        meas["jac"] = np.asarray(jac).reshape(n, 12)
+        mu = np.zeros(6)
+        flags = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.calc_pose_update(self.h, n, _ptr(meas), override_sigma_sq, estimator, prior,
+                                              _pd(mu), _ptr(flags)), "calc_pose_update")
+        return mu, flags
+
+
+class KeyFrame:
+    """KeyFrame (include/KeyFrame.h:130-149): 4 pyramid levels with FAST corners + row LUTs."""
+
+    def __init__(self, ctx, handle=None):
+        self.ctx, self.lib = ctx, ctx.lib
+        w, h = ctx.size
+        if handle is None:
+            handle = C.c_void_p()
+            ctx._check(self.lib.kf_create(ctx.h, w, h, C.byref(handle)), "kf_create")
+        self.h = handle
+
+    def MakeKeyFrame_Lite(self, im):
+        im = np.ascontiguousarray(im, dtype=np.uint8)
+        assert im.shape == (self.ctx.size[1], self.ctx.size[0]), im.shape
+        self.ctx._check(self.lib.make_keyframe_lite(self.ctx.h, self.h, _ptr(im), im.strides[0]),
+                        "make_keyframe_lite")
+        return self
+
+    def clone(self):
+        out = C.c_void_p()
+        self.ctx._check(self.lib.kf_clone(self.ctx.h, self.h, C.byref(out)), "kf_clone")
+        return KeyFrame(self.ctx, out)
+
+    def level(self, l):
+        """-> dict(im, corners (n,2) int32 [x,y] raster order, rowlut)"""
+        w, h, n = C.c_int(), C.c_int(), C.c_int()
+        self.ctx._check(self.lib.kf_level_info(self.ctx.h, self.h, l, C.byref(w), C.byref(h), C.byref(n)),
+                        "kf_level_info")
+        im = np.zeros((h.value, w.value), dtype=np.uint8)
+        corners = np.zeros((n.value, 2), dtype=np.int32)
+        lut = np.zeros(h.value, dtype=np.int32)
+        self.ctx._check(self.lib.kf_read_level(self.ctx.h, self.h, l, _ptr(im), _ptr(corners), _ptr(lut)),
+                        "kf_read_level")
+        return {"im": im, "corners": corners, "rowlut": lut}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.kf_destroy(self.h)
+            self.h = None
+
+
+class PatchFinder:
+    """Batched PatchFinder::FindPatchCoarse (src/PatchFinder.cc:160-211) over one KeyFrame."""
+
+    def __init__(self, ctx):
+        self.ctx, self.lib = ctx, ctx.lib
+
+    def FindPatchCoarse(self, kf, queries, templates):
+        queries = np.ascontiguousarray(queries, dtype=PATCH_QUERY_DT)
+        templates = np.ascontiguousarray(templates, dtype=np.uint8).reshape(len(queries), 64)
+        res = np.zeros(len(queries), dtype=PATCH_RESULT_DT)
+        self.ctx._check(self.lib.find_patch_coarse_batch(self.ctx.h, kf.h, len(queries), _ptr(queries),
+                                                         _ptr(templates), _ptr(res)), "find_patch_coarse")
+        return res
+
+    def ZMSSDAtPoint(self, kf, level, points, template):
+        points = np.ascontiguousarray(points, dtype=np.int32).reshape(-1, 2)
+        template = np.ascontiguousarray(template, dtype=np.uint8).reshape(64)
+        out = np.zeros(len(points), dtype=np.int32)
+        self.ctx._check(self.lib.zmssd_at_points(self.ctx.h, kf.h, level, len(points), _ptr(points),
+                                                 _ptr(template), _ptr(out)), "zmssd_at_points")
+        return out
+
+
+class Bundle:
+    """Bundle (include/Bundle.h:106-152)."""
+
+    def __init__(self, ctx, **opts):
+        self.ctx, self.lib = ctx, ctx.lib
+        o = BaOpts()
+        self.lib.ba_opts_default(C.byref(o))
+        for k, v in opts.items():
+            setattr(o, k, v)
+        self.opts = o
+        h = C.c_void_p()
+        ctx._check(self.lib.ba_create(ctx.h, C.byref(o), C.byref(h)), "ba_create")
+        self.h = h
+        self._keep = []
+
+    def AddCamera(self, pose, fixed):
+        pose = np.ascontiguousarray(pose, dtype=np.float64).reshape(12)
+        return self.ctx._check(self.lib.ba_add_camera(self.h, _pd(pose), int(fixed)), "ba_add_camera")
+
+    def AddPoint(self, pos):
+        pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(3)
+        return self.ctx._check(self.lib.ba_add_point(self.h, _pd(pos)), "ba_add_point")
+
+    def AddMeas(self, cam, point, found, sigma_sq):
+        found = np.ascontiguousarray(found, dtype=np.float64).reshape(2)
+        self.ctx._check(self.lib.ba_add_meas(self.h, int(cam), int(point), _pd(found), float(sigma_sq)),
+                        "ba_add_meas")
+
+    def add_problem(self, poses, fixed, points, cam_idx, pt_idx, found, sigma_sq):
+        """bulk marshalling: same ids as calling AddCamera/AddPoint/AddMeas in array order"""
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 12)
+        fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
+        points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        cam_idx = np.ascontiguousarray(cam_idx, dtype=np.int32)
+        pt_idx = np.ascontiguousarray(pt_idx, dtype=np.int32)
+        found = np.ascontiguousarray(found, dtype=np.float64).reshape(-1, 2)
+        sigma_sq = np.ascontiguousarray(sigma_sq, dtype=np.float64)
+        c = self.ctx._check
+        c(self.lib.ba_add_cameras(self.h, len(poses), _ptr(poses), _ptr(fixed)), "ba_add_cameras")
+        c(self.lib.ba_add_points(self.h, len(points), _ptr(points)), "ba_add_points")
+        c(self.lib.ba_add_measurements(self.h, len(cam_idx), _ptr(cam_idx), _ptr(pt_idx), _ptr(found),
+                                       _ptr(sigma_sq)), "ba_add_measurements")
+
+    def Compute(self, abort=None):
+        """-> mnAccepted (or -1).  abort: optional np.uint8 array of length 1 polled by the library."""
+        acc = C.c_int()
+        self.ctx._check(self.lib.ba_compute(self.h, _ptr(abort), C.byref(acc)), "ba_compute")
+        return acc.value
+
+    def Converged(self):
+        return bool(self.lib.ba_converged(self.h))
+
+    def counts(self):
+        v = [C.c_int() for _ in range(4)]
+        self.ctx._check(self.lib.ba_counts(self.h, *[C.byref(x) for x in v]), "ba_counts")
+        return tuple(x.value for x in v)   # cams, free cams, points, meas
+
+    def GetPoint(self, n):
+        out = np.zeros(3)
+        self.ctx._check(self.lib.ba_get_point(self.h, n, _pd(out)), "ba_get_point")
+        return out
+
+    def GetCamera(self, n):
+        out = np.zeros(12)
+        self.ctx._check(self.lib.ba_get_camera(self.h, n, _pd(out)), "ba_get_camera")
+        return out
+
+    def get_all(self):
+        nc, _, npt, _ = self.counts()
+        poses, pts = np.zeros((nc, 12)), np.zeros((npt, 3))
+        self.ctx._check(self.lib.ba_get_all(self.h, _ptr(poses), _ptr(pts)), "ba_get_all")
+        return poses, pts
+
+    def GetOutlierMeasurements(self):
+        n = self.lib.ba_get_outliers(self.h, None, 0)
+        out = np.zeros((max(n, 1), 2), dtype=np.int32)
+        self.lib.ba_get_outliers(self.h, _ptr(out), n)
+        return out[:n]   # (point, camera) pairs
+
+    def trials(self):
+        n = self.lib.ba_get_trials(self.h, None, 0)
+        out = np.zeros(max(n, 1), dtype=BA_TRIAL_DT)
+        self.lib.ba_get_trials(self.h, _ptr(out), n)
+        return out[:n]
+
+    def set_comm(self, rank, world, fn, user=None):
+        self._keep.append(fn)
+        self.ctx._check(self.lib.ba_set_comm(self.h, rank, world, fn, user), "ba_set_comm")
+
+    # profiling hooks (HIP library only)
+    def set_profiling(self, on=True):
+        self.ctx._check(self.lib.ba_set_profiling(self.h, int(on)), "ba_set_profiling")
+
+    def kernel_times(self):
+        out = {}
+        for k, name in enumerate(_abi.KERNEL_NAMES):
+            ms, n = C.c_double(), C.c_int()
+            self.ctx._check(self.lib.ba_kernel_time(self.h, k, C.byref(ms), C.byref(n)), "ba_kernel_time")
+            out[name] = (ms.value, n.value)
+        return out
+
+    def prepare(self):
+        self.ctx._check(self.lib.ba_prepare(self.h), "ba_prepare")
+
+    def bench_jacobian(self, reps):
+        ms, by = C.c_double(), C.c_double()
+        self.ctx._check(self.lib.ba_bench_jacobian(self.h, reps, C.byref(ms), C.byref(by)), "ba_bench_jacobian")
+        return ms.value, by.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ba_destroy(self.h)
+            self.h = None

@@ -1,0 +1,229 @@
+"""Seeded synthetic inputs for the hot path: frames, patch queries, pose-GN cases and
+bundle problems.  Pure numpy; used by tests/ and bench.py.  Nothing here depends on the oracle."""
+import numpy as np
+
+SEED_FRAME = 0x5EED0001
+SEED_QUERIES = 0x5EED0002
+SEED_POSE = 0x5EED0003
+SEED_BA_LOCAL = 0x5EED0004
+SEED_BA_HEADLINE = 0x5EED0005
+SEED_BA_GLOBAL = 0x5EED0006
+
+DEFAULT_CAMERA = (1.0803, 1.43987, 0.519983, 0.548655, 0.244943)   # config/camera.cfg:7
+LEVEL_MIX = (0.50, 0.25, 0.15, 0.10)
+
+
+# ---------------------------------------------------------------------------------------------
+# frames
+# ---------------------------------------------------------------------------------------------
+def make_frame(seed=SEED_FRAME, w=640, h=480, n_rect=400, shift=(0, 0), noise_seed=None):
+    """Rectangles + integer noise frame.  `shift` translates the rectangle layout (dx, dy); the
+    noise is drawn from `noise_seed` (default: seed) so a shifted frame can carry fresh noise."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    im = np.full((h, w), 128, dtype=np.int32)
+    rw = rng.integers(32, 129, n_rect)
+    rh = rng.integers(32, 129, n_rect)
+    x0 = rng.integers(-64, w, n_rect)
+    y0 = rng.integers(-64, h, n_rect)
+    val = rng.integers(30, 226, n_rect)
+    for i in range(n_rect):
+        xa, ya = x0[i] + shift[0], y0[i] + shift[1]
+        xb, yb = xa + rw[i], ya + rh[i]
+        xa, ya, xb, yb = max(xa, 0), max(ya, 0), min(xb, w), min(yb, h)
+        if xb > xa and yb > ya:
+            im[ya:yb, xa:xb] = val[i]
+    nrng = np.random.Generator(np.random.PCG64(seed if noise_seed is None else noise_seed))
+    im += nrng.integers(-3, 4, (h, w))
+    return np.clip(im, 0, 255).astype(np.uint8)
+
+
+def make_frame_pair(seed=SEED_FRAME, shift=(3, -2)):
+    a = make_frame(seed)
+    b = make_frame(seed, shift=shift, noise_seed=seed + 1)
+    return a, b
+
+
+def make_patch_queries(levels_a, n=1000, seed=SEED_QUERIES, shift=(3, -2), search_range=10, jitter=4):
+    """Queries for FindPatchCoarse in frame B built from corners of frame A.
+    levels_a: list of 4 dicts {im, corners} (KeyFrame.level(l) of frame A).
+    Returns (queries structured array fields x,y,level,range ; templates (n,64) uint8)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    q = np.zeros(n, dtype=[("x", "<i4"), ("y", "<i4"), ("level", "<i4"), ("range", "<u4")])
+    tm = np.zeros((n, 64), dtype=np.uint8)
+    lv = rng.choice(4, size=n, p=LEVEL_MIX)
+    for i in range(n):
+        l = int(lv[i])
+        im, corners = levels_a[l]["im"], levels_a[l]["corners"]
+        hh, ww = im.shape
+        # MakeTemplateCoarseNoWarp needs in_image_with_border(pos, 5)  (src/PatchFinder.cc:141)
+        ok = corners[(corners[:, 0] >= 5) & (corners[:, 1] >= 5) & (corners[:, 0] < ww - 5) & (corners[:, 1] < hh - 5)]
+        if len(ok) == 0:
+            q[i] = (0, 0, -1, search_range)
+            continue
+        cx, cy = ok[rng.integers(len(ok))]
+        tm[i] = im[cy - 4:cy + 4, cx - 4:cx + 4].reshape(64)
+        s = 1 << l
+        px = (cx + 0.5) * s - 0.5 + shift[0] + rng.uniform(-jitter, jitter)
+        py = (cy + 0.5) * s - 0.5 + shift[1] + rng.uniform(-jitter, jitter)
+        q[i] = (int(px), int(py), l, search_range)   # ir(): truncation toward zero
+    return q, tm
+
+
+# ---------------------------------------------------------------------------------------------
+# camera + SE3 helpers (numpy, for data generation only)
+# ---------------------------------------------------------------------------------------------
+class AtanCam:
+    def __init__(self, params=DEFAULT_CAMERA, size=(640, 480)):
+        fx, fy, cx, cy, w = params
+        self.size = size
+        self.focal = np.array([size[0] * fx, size[1] * fy])
+        self.centre = np.array([size[0] * cx - 0.5, size[1] * cy - 0.5])
+        self.w = w
+        self.two_tan = 2.0 * np.tan(w / 2.0) if w != 0 else 0.0
+        v = np.array([max(cx, 1 - cx) / fx, max(cy, 1 - cy) / fy])
+        r = np.hypot(*v)
+        self.largest_radius = np.tan(r * w) / self.two_tan if w != 0 else r
+        self.max_r = 1.5 * self.largest_radius
+
+    def project(self, xy):
+        xy = np.asarray(xy, dtype=np.float64)
+        r = np.hypot(xy[..., 0], xy[..., 1])
+        with np.errstate(divide="ignore", invalid="ignore"):
+            f = np.where((r < 0.001) | (self.w == 0), 1.0, np.arctan(r * self.two_tan) / (self.w * np.where(r == 0, 1, r)))
+        return self.centre + self.focal * (f[..., None] * xy), r
+
+    def visible(self, pose, X):
+        """TrackerData::Project visibility (include/Tracker.h:70-85) -> (mask, image coords)"""
+        R, t = pose[:9].reshape(3, 3), pose[9:]
+        Xc = X @ R.T + t
+        z = Xc[:, 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            xy = Xc[:, :2] / z[:, None]
+        im, r = self.project(np.nan_to_num(xy))
+        ok = (z >= 0.001) & (r * r <= self.largest_radius ** 2) & (r <= self.max_r)
+        ok &= (im[:, 0] >= 0) & (im[:, 1] >= 0) & (im[:, 0] <= self.size[0]) & (im[:, 1] <= self.size[1])
+        return ok, im
+
+
+def so3_exp(w):
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-9:
+        return np.eye(3) + K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * (K @ K)
+
+
+def se3_exp(mu):
+    """4x4 matrix exponential of the twist (t, w) — closed form."""
+    t, w = np.asarray(mu[:3], float), np.asarray(mu[3:], float)
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    R = so3_exp(w)
+    if th < 1e-9:
+        V = np.eye(3) + 0.5 * K
+    else:
+        V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * K + (th - np.sin(th)) / th ** 3 * (K @ K)
+    return np.concatenate([R.reshape(9), V @ t])
+
+
+def se3_mul(a, b):
+    Ra, ta = a[:9].reshape(3, 3), a[9:]
+    Rb, tb = b[:9].reshape(3, 3), b[9:]
+    return np.concatenate([(Ra @ Rb).reshape(9), ta + Ra @ tb])
+
+
+def look_at(cam_pos, target, up=(0.0, 0.0, 1.0)):
+    """camera-from-world pose (12,) with +z looking from cam_pos to target, image y pointing 'down'."""
+    cam_pos, target = np.asarray(cam_pos, float), np.asarray(target, float)
+    z = target - cam_pos
+    z /= np.linalg.norm(z)
+    x = np.cross(z, np.asarray(up, float))
+    if np.linalg.norm(x) < 1e-9:
+        x = np.array([1.0, 0, 0])
+    x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    R = np.stack([x, y, z])
+    return np.concatenate([R.reshape(9), -R @ cam_pos])
+
+
+# ---------------------------------------------------------------------------------------------
+# pose Gauss-Newton case
+# ---------------------------------------------------------------------------------------------
+def make_pose_case(n=1000, seed=SEED_POSE, camera=DEFAULT_CAMERA, size=(640, 480), outlier_frac=0.05):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    cam = AtanCam(camera, size)
+    # 1.5 m above the plane, looking down with a 0.1 rad tilt about x
+    base = np.concatenate([np.diag([1.0, -1.0, -1.0]).reshape(9), [0, 0, 1.5]])
+    tilt = np.concatenate([so3_exp(np.array([0.1, 0, 0])).reshape(9), [0, 0, 0]])
+    true_pose = se3_mul(tilt, base)
+    pts = np.zeros((0, 3))
+    while len(pts) < n:
+        cand = np.column_stack([rng.uniform(-0.45, 0.45, 2 * n), rng.uniform(-0.45, 0.45, 2 * n),
+                                rng.uniform(-0.1, 0.1, 2 * n)])
+        ok, _ = cam.visible(true_pose, cand)
+        pts = np.vstack([pts, cand[ok]])
+    pts = pts[:n]
+    _, im = cam.visible(true_pose, pts)
+    lv = rng.choice(4, size=n, p=LEVEL_MIX)
+    found = im + rng.normal(0, 1, (n, 2)) * (0.5 * 2.0 ** lv)[:, None]
+    out = rng.random(n) < outlier_frac
+    sign = rng.choice([-1.0, 1.0], (n, 2))
+    found[out] += sign[out] * rng.uniform(10, 30, (n, 2))[out]
+    xi = np.concatenate([rng.normal(0, 0.01, 3), rng.normal(0, 0.01, 3)])
+    init_pose = se3_mul(se3_exp(xi), true_pose)
+    # keep only points visible from the initial pose too (TrackMap's PVS test)
+    ok, _ = cam.visible(init_pose, pts)
+    keep = np.flatnonzero(ok)
+    return {"world": pts[keep], "found": found[keep], "sqrt_inv_noise": 1.0 / 2.0 ** lv[keep],
+            "init_pose": init_pose, "true_pose": true_pose, "is_outlier": out[keep]}
+
+
+# ---------------------------------------------------------------------------------------------
+# bundle problems
+# ---------------------------------------------------------------------------------------------
+def make_ba_problem(n_cams, n_pts, seed, window=None, camera=DEFAULT_CAMERA, size=(640, 480),
+                    outlier_frac=0.02, n_fixed=1, pt_noise=0.01, pose_noise=0.005):
+    """Cameras on a 120 degree arc (radius 2 m, height 1 m) looking at the origin; points in
+    [-0.5,0.5]^2 x [-0.1,0.1].  window=k limits each point to k consecutive cameras (banded
+    covisibility).  Measurements are emitted in the reference's marshalling order: keyframe
+    order, then point order (src/MapMaker.cc:871-882)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    cam = AtanCam(camera, size)
+    ang = np.linspace(-np.pi / 3, np.pi / 3, n_cams)
+    poses_true = np.stack([look_at([2 * np.sin(a), -2 * np.cos(a), 1.0], [0, 0, 0]) for a in ang])
+    pts_true = np.column_stack([rng.uniform(-0.5, 0.5, n_pts), rng.uniform(-0.5, 0.5, n_pts),
+                                rng.uniform(-0.1, 0.1, n_pts)])
+    if window is not None and window < n_cams:
+        start = rng.integers(0, n_cams - window + 1, n_pts)
+    cam_idx, pt_idx, found, sig = [], [], [], []
+    for c in range(n_cams):
+        ok, im = cam.visible(poses_true[c], pts_true)
+        if window is not None and window < n_cams:
+            ok &= (start <= c) & (c < start + window)
+        ids = np.flatnonzero(ok)
+        lv = rng.choice(4, size=len(ids), p=LEVEL_MIX)
+        f = im[ids] + rng.normal(0, 1, (len(ids), 2)) * (0.5 * 2.0 ** lv)[:, None]
+        out = rng.random(len(ids)) < outlier_frac
+        sign = rng.choice([-1.0, 1.0], (len(ids), 2))
+        f[out] += (sign * rng.uniform(10, 30, (len(ids), 2)))[out]
+        cam_idx.append(np.full(len(ids), c, np.int32))
+        pt_idx.append(ids.astype(np.int32))
+        found.append(f)
+        sig.append(4.0 ** lv)
+    poses = poses_true.copy()
+    for c in range(n_fixed, n_cams):
+        poses[c] = se3_mul(se3_exp(rng.normal(0, pose_noise, 6)), poses_true[c])
+    fixed = np.zeros(n_cams, np.uint8)
+    fixed[:n_fixed] = 1
+    return {"poses": poses, "fixed": fixed, "points": pts_true + rng.normal(0, pt_noise, (n_pts, 3)),
+            "cam_idx": np.concatenate(cam_idx), "pt_idx": np.concatenate(pt_idx),
+            "found": np.concatenate(found), "sigma_sq": np.concatenate(sig),
+            "poses_true": poses_true, "points_true": pts_true}
+
+
+def load_into(bundle, prob):
+    """Marshal a problem dict into a host.Bundle exactly as MapMaker::BundleAdjust does
+    (non-fixed cameras first is NOT required by Bundle; ids follow array order)."""
+    bundle.add_problem(prob["poses"], prob["fixed"], prob["points"], prob["cam_idx"], prob["pt_idx"],
+                       prob["found"], prob["sigma_sq"])
+    return bundle

@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from tests.oracle_lib import load_oracle
+    return load_oracle()
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The product library.  No fallback: a missing .so or GPU is a hard failure of -m gpu tests."""
+    from ptam_cg_amd._lib import load
+    return load()

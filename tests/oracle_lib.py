@@ -1,0 +1,33 @@
+"""Test-side loader of the CPU oracle (oracle/libptam_oracle.so).  tests/, smoke() and bench.py's
+cpu_baseline leg are the only users (see oracle/ptam_oracle.cc header)."""
+import ctypes
+import os
+import subprocess
+
+from ptam_cg_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libptam_oracle.so")
+_bound = None
+
+
+def load_oracle(build=True):
+    global _bound
+    if _bound is None:
+        if build and (not os.path.exists(ORACLE_SO) or
+                      os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(ORACLE_DIR, "ptam_oracle.cc"))):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+        lib = ctypes.CDLL(ORACLE_SO)
+        _bound = _abi.bind(lib, "ptamo_")
+        # oracle-only helpers
+        lib.ptamo_half_sample.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        lib.ptamo_fast10.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        lib.ptamo_se3_exp.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.ptamo_se3_mul.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.ptamo_tukey_sigma_sq.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.ptamo_tukey_sigma_sq.restype = ctypes.c_double
+        lib.ptamo_ldlt_solve.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.ptamo_ctx_cache_hazards.argtypes = [ctypes.c_void_p]
+        lib.ptamo_ctx_cache_hazards.restype = ctypes.c_long
+    return _bound

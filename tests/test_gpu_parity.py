@@ -1,0 +1,204 @@
+"""-m gpu: parity of the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+Integers (pyramid pixels, corner lists, LUTs, ZMSSD, best index) bit-exact; fp64 pose / bundle
+results within the tolerances written in each test (north_star: 1e-6 relative on the post-LM error)."""
+import numpy as np
+import pytest
+
+from ptam_cg_amd import _abi, host, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("variant", [_abi.HALFSAMPLE_R, _abi.HALFSAMPLE_T])
+@pytest.mark.parametrize("case", ["synthetic", "shifted", "noise", "odd", "flat", "tiny"])
+def test_keyframe_lite_bit_exact(hip, oracle, variant, case):
+    rng = np.random.default_rng(7)
+    if case == "synthetic":
+        im = synth.make_frame()
+    elif case == "shifted":
+        im = synth.make_frame_pair()[1]
+    elif case == "noise":
+        im = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    elif case == "odd":
+        im = rng.integers(0, 256, (77, 101), dtype=np.uint8)   # ragged: halves drop the last row/col
+        im[20:60, 30:80] = 200
+    elif case == "flat":
+        im = np.full((480, 640), 77, np.uint8)                  # no corners at all: empty lists, zero LUTs
+    else:
+        im = rng.integers(0, 256, (8, 8), dtype=np.uint8)       # minimum size: level 3 is 1x1
+    a = util.keyframe_levels(hip, im, variant)
+    b = util.keyframe_levels(oracle, im, variant)
+    util.assert_levels_equal(a, b)
+    if case == "synthetic":
+        assert sum(len(x["corners"]) for x in a) > 1000
+
+
+def test_keyframe_clone_and_reuse(hip, oracle):
+    a, b = synth.make_frame_pair()
+    ctx = host.Context(lib=hip)
+    kf = host.KeyFrame(ctx).MakeKeyFrame_Lite(a)
+    cl = kf.clone()                    # Level::operator= deep copy
+    kf.MakeKeyFrame_Lite(b)            # re-use the handle for the next frame
+    util.assert_levels_equal([cl.level(l) for l in range(4)], util.keyframe_levels(oracle, a))
+    util.assert_levels_equal([kf.level(l) for l in range(4)], util.keyframe_levels(oracle, b))
+
+
+def _patch_case(lib, search_range, n=1000):
+    a, b = synth.make_frame_pair()
+    ctx = host.Context(lib=lib)
+    kfa = host.KeyFrame(ctx).MakeKeyFrame_Lite(a)
+    kfb = host.KeyFrame(ctx).MakeKeyFrame_Lite(b)
+    q, t = synth.make_patch_queries([kfa.level(l) for l in range(4)], n=n, search_range=search_range)
+    return ctx, kfb, q, t
+
+
+@pytest.mark.parametrize("search_range", [10, 30, 120])
+def test_find_patch_coarse_bit_exact(hip, oracle, search_range):
+    ctx_h, kf_h, q, t = _patch_case(hip, search_range)
+    ctx_o, kf_o, q2, t2 = _patch_case(oracle, search_range)
+    assert np.array_equal(q, q2) and np.array_equal(t, t2)
+    # edge cases: bad template, off-image predictions, zero range, border positions
+    q = q.copy()
+    q[0]["level"] = -1
+    q[1]["x"], q[1]["y"] = -50, -50
+    q[2]["x"], q[2]["y"] = 5000, 100
+    q[3]["range"] = 0
+    q[4]["x"], q[4]["y"] = 0, 0
+    q[5]["x"], q[5]["y"] = 639, 479
+    rh = host.PatchFinder(ctx_h).FindPatchCoarse(kf_h, q, t)
+    ro = host.PatchFinder(ctx_o).FindPatchCoarse(kf_o, q, t)
+    for f in ("found", "best_ssd", "best_x", "best_y", "n_scored"):
+        assert np.array_equal(rh[f], ro[f]), f
+    assert np.array_equal(rh["pos"], ro["pos"])
+    assert rh["found"].sum() > 0.8 * len(q) or search_range == 120
+
+
+def test_zmssd_at_points_bit_exact(hip, oracle):
+    im = synth.make_frame()
+    rng = np.random.default_rng(3)
+    pts = np.column_stack([rng.integers(-2, 84, 500), rng.integers(-2, 64, 500)]).astype(np.int32)
+    for level in range(4):
+        ctx_h, ctx_o = host.Context(lib=hip), host.Context(lib=oracle)
+        kh = host.KeyFrame(ctx_h).MakeKeyFrame_Lite(im)
+        ko = host.KeyFrame(ctx_o).MakeKeyFrame_Lite(im)
+        tmpl = rng.integers(0, 256, 64, dtype=np.uint8)
+        sh = host.PatchFinder(ctx_h).ZMSSDAtPoint(kh, level, pts, tmpl)
+        so = host.PatchFinder(ctx_o).ZMSSDAtPoint(ko, level, pts, tmpl)
+        assert np.array_equal(sh, so)
+        if level == 3:
+            assert (so == _abi.MAX_SSD + 1).any() and (so < _abi.MAX_SSD + 1).any()
+
+
+def test_project_points(hip, oracle):
+    pc = synth.make_pose_case()
+    rng = np.random.default_rng(5)
+    world = np.vstack([pc["world"], rng.uniform(-3, 3, (500, 3))])   # many invisible / behind-camera points
+    ph = host.Context(lib=hip).project_points(world, pc["init_pose"])
+    po = host.Context(lib=oracle).project_points(world, pc["init_pose"])
+    assert np.array_equal(ph["in_image"], po["in_image"])
+    for f in ("cam", "image", "derivs"):
+        assert np.allclose(ph[f], po[f], rtol=1e-12, atol=1e-9), f
+    assert 0 < ph["in_image"].sum() < len(world)
+
+
+@pytest.mark.parametrize("stage", ["fine", "coarse"])
+def test_pose_gn(hip, oracle, stage):
+    pc = synth.make_pose_case()
+    ch, co = host.Context(lib=hip), host.Context(lib=oracle)
+    kw = {} if stage == "fine" else dict(nonlinear_mask=0x3FF, override_sigma_sq=1.0, mark_outliers_iter=-1)
+    ph, fh, uh = ch.pose_gn(pc["world"], pc["found"], pc["sqrt_inv_noise"], pc["init_pose"], ch.gn_opts(**kw))
+    po, fo, uo = co.pose_gn(pc["world"], pc["found"], pc["sqrt_inv_noise"], pc["init_pose"], co.gn_opts(**kw))
+    assert np.allclose(ph, po, rtol=0, atol=1e-10)          # final pose
+    assert np.allclose(uh, uo, rtol=1e-6, atol=1e-12)       # every iteration's 6-vector update
+    assert np.array_equal(fh, fo)                           # M-estimator outlier marks
+    if stage == "fine":
+        assert fh.sum() >= 0.8 * pc["is_outlier"].sum()
+    assert np.abs(ph - pc["true_pose"]).max() < 5e-3
+
+
+def test_pose_gn_entry_state_and_empty(hip, oracle):
+    pc = synth.make_pose_case(n=300)
+    ch, co = host.Context(lib=hip), host.Context(lib=oracle)
+    # entry state = projections at a slightly different pose (what TrackMap leaves after a coarse stage)
+    other = synth.se3_mul(synth.se3_exp(np.array([1e-3, -2e-3, 5e-4, 1e-3, 0, -1e-3])), pc["init_pose"])
+    entry = co.project_points(pc["world"], other)
+    ph, fh, uh = ch.pose_gn(pc["world"], pc["found"], pc["sqrt_inv_noise"], pc["init_pose"], entry=entry)
+    po, fo, uo = co.pose_gn(pc["world"], pc["found"], pc["sqrt_inv_noise"], pc["init_pose"], entry=entry)
+    assert np.allclose(ph, po, rtol=0, atol=1e-10) and np.array_equal(fh, fo)
+    # empty set: zero update, pose unchanged (src/Tracker.cc:955-956)
+    p0, _, u0 = ch.pose_gn(np.zeros((0, 3)), np.zeros((0, 2)), np.zeros(0), pc["init_pose"])
+    assert np.array_equal(p0, pc["init_pose"]) and not u0.any()
+
+
+@pytest.mark.parametrize("est", [_abi.EST_TUKEY, _abi.EST_CAUCHY, _abi.EST_HUBER])
+@pytest.mark.parametrize("override", [0.0, 16.0])
+def test_calc_pose_update(hip, oracle, est, override):
+    rng = np.random.default_rng(11)
+    n = 777
+    found = rng.uniform(0, 640, (n, 2))
+    image = found + rng.normal(0, 1.5, (n, 2))
+    image[::20] += 40
+    s = 1.0 / 2.0 ** rng.integers(0, 4, n)
+    jac = rng.normal(0, 300, (n, 12))
+    mh, fh = host.Context(lib=hip).calc_pose_update(found, image, s, jac, override, est)
+    mo, fo = host.Context(lib=oracle).calc_pose_update(found, image, s, jac, override, est)
+    assert np.allclose(mh, mo, rtol=1e-9, atol=1e-15)
+    assert np.array_equal(fh, fo)
+
+
+BA_CASES = {
+    "toy_8x50": dict(n_cams=8, n_pts=50, seed=1),
+    "local_20x300": dict(n_cams=20, n_pts=300, seed=synth.SEED_BA_LOCAL),
+    "banded_40x400": dict(n_cams=40, n_pts=400, seed=3, window=10),
+    "two_fixed": dict(n_cams=12, n_pts=120, seed=4, n_fixed=2),
+    "config4_20x3000": dict(n_cams=20, n_pts=3000, seed=synth.SEED_BA_LOCAL),
+}
+
+
+@pytest.mark.parametrize("case", list(BA_CASES))
+def test_bundle_trial_by_trial(hip, oracle, case):
+    prob = synth.make_ba_problem(**BA_CASES[case])
+    rh = util.run_ba(hip, prob)
+    ro = util.run_ba(oracle, prob)
+    util.assert_ba_equal(rh, ro, rel=1e-6)
+    assert rh["accepted"] > 0
+    # the adjuster actually improved the map
+    assert np.abs(rh["points"] - prob["points_true"]).mean() < np.abs(prob["points"] - prob["points_true"]).mean()
+
+
+@pytest.mark.parametrize("est", [_abi.EST_CAUCHY, _abi.EST_HUBER])
+def test_bundle_other_estimators(hip, oracle, est):
+    prob = synth.make_ba_problem(10, 150, 9)
+    util.assert_ba_equal(util.run_ba(hip, prob, estimator=est), util.run_ba(oracle, prob, estimator=est), rel=1e-6)
+
+
+def test_bundle_noise_free_is_fixed_point(hip):
+    prob = synth.make_ba_problem(6, 80, 2, outlier_frac=0.0)
+    cam = synth.AtanCam()
+    # exact measurements from the true geometry, start at the truth
+    prob["poses"], prob["points"] = prob["poses_true"].copy(), prob["points_true"].copy()
+    f = np.zeros_like(prob["found"])
+    for i, (c, p) in enumerate(zip(prob["cam_idx"], prob["pt_idx"])):
+        _, im = cam.visible(prob["poses_true"][c], prob["points_true"][p:p + 1])
+        f[i] = im[0]
+    prob["found"] = f
+    r = util.run_ba(hip, prob)
+    assert r["trials"]["err_old"].max() < 1e-9
+    assert np.allclose(r["poses"], prob["poses_true"], atol=1e-9)
+    assert np.allclose(r["points"], prob["points_true"], atol=1e-9)
+    assert len(r["outliers"]) == 0
+
+
+def test_bundle_abort_and_limits(hip):
+    prob = synth.make_ba_problem(6, 60, 5)
+    ctx = host.Context(lib=hip)
+    ba = synth.load_into(host.Bundle(ctx), prob)
+    flag = np.ones(1, dtype=np.uint8)                       # abort already requested: nothing accepted
+    assert ba.Compute(abort=flag) == 0 and len(ba.trials()) == 0 and not ba.Converged()
+    assert ba.Compute() > 0                                 # and the same object still works afterwards
+    ba2 = synth.load_into(host.Bundle(ctx, max_iterations=3), prob)
+    ba2.Compute()
+    assert len(ba2.trials()) == 3                           # Bundle.MaxIterations counts lambda trials
+    with pytest.raises(host.PtamError):
+        ba2.AddMeas(99, 0, [1.0, 2.0], 1.0)                 # unknown camera id

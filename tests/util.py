@@ -1,0 +1,50 @@
+"""Shared helpers for parity tests: run the same scenario through two bound libraries."""
+import numpy as np
+
+from ptam_cg_amd import host, synth
+
+
+def keyframe_levels(lib, im, variant=0):
+    ctx = host.Context(lib=lib, size=(im.shape[1], im.shape[0]), halfsample=variant)
+    kf = host.KeyFrame(ctx).MakeKeyFrame_Lite(im)
+    out = [kf.level(l) for l in range(4)]
+    kf.close()
+    ctx.close()
+    return out
+
+
+def assert_levels_equal(a, b):
+    for l in range(4):
+        assert a[l]["im"].shape == b[l]["im"].shape
+        assert np.array_equal(a[l]["im"], b[l]["im"]), f"level {l} pixels differ"
+        assert np.array_equal(a[l]["corners"], b[l]["corners"]), f"level {l} corners differ"
+        assert np.array_equal(a[l]["rowlut"], b[l]["rowlut"]), f"level {l} row LUT differs"
+
+
+def run_ba(lib, prob, **opts):
+    ctx = host.Context(lib=lib)
+    ba = synth.load_into(host.Bundle(ctx, **opts), prob)
+    acc = ba.Compute()
+    poses, pts = ba.get_all()
+    res = {"accepted": acc, "converged": ba.Converged(), "trials": ba.trials(), "poses": poses,
+           "points": pts, "outliers": ba.GetOutlierMeasurements()}
+    ba.close()
+    ctx.close()
+    return res
+
+
+def assert_ba_equal(a, b, rel=1e-6, abs_state=1e-7):
+    """trial-by-trial comparison (compare lambda, sigma^2, cur, new, n_bad per trial)"""
+    ta, tb = a["trials"], b["trials"]
+    assert len(ta) == len(tb), (len(ta), len(tb))
+    for i, (x, y) in enumerate(zip(ta, tb)):
+        assert x["lambda"] == y["lambda"], (i, x["lambda"], y["lambda"])
+        assert x["accepted"] == y["accepted"], i
+        assert x["n_bad"] == y["n_bad"], (i, x["n_bad"], y["n_bad"])
+        for k in ("sigma_sq", "err_old", "err_new"):
+            assert abs(x[k] - y[k]) <= rel * max(abs(x[k]), abs(y[k]), 1e-300), (i, k, x[k], y[k])
+    assert a["accepted"] == b["accepted"]
+    assert a["converged"] == b["converged"]
+    assert np.array_equal(a["outliers"], b["outliers"])
+    assert np.allclose(a["poses"], b["poses"], rtol=0, atol=abs_state)
+    assert np.allclose(a["points"], b["points"], rtol=0, atol=abs_state)
