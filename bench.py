@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""bench.py — headline metric of BASELINE.json on MI355X.
+
+  metric  : bundle-adjustment LM iterations/s (one iteration = one lambda trial, the unit mnCounter
+            counts, src/Bundle.cc:518) on the synthetic 50-keyframe x 5000-point problem
+            (seed 0x5EED0005, M = 250 000 measurements), plus — as extra keys of the
+            same JSON line — tracked frames/s at 640x480 (pyramid + FAST-10 + 1000-patch ZMSSD search
+            + 10-iteration pose Gauss-Newton per frame).
+  step    : one lambda trial.  W warm-up trials run in a separate Compute(); the timed region is ONE
+            Compute() with max_iterations = K and the convergence limit disabled, so exactly K trials
+            execute.  Inputs are resident in HBM (ptam_ba_prepare) before the clock starts.
+  N > 1   : weak scaling of sharded global BA: 50 shared keyframes, 5000 points PER RANK, points
+            (and all their measurements) sharded by point id modulo N; per trial one RCCL
+            all-reduce of the camera system S|E (+ two scalar pairs, + the e^2 gather for the
+            exact global median).  value = N * trials/s (50x5000-shard iterations per second).
+  roofline: K7 (fused Jacobian + normal-equation kernel), algorithmic bytes / HIP-event time.
+  cpu_baseline: the CPU oracle (oracle/ptam_oracle.cc, a single-thread restatement of the
+            reference's loops — kind "port") on the same problem, rank 0, N = 1 only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cams", type=int, default=50)
+    ap.add_argument("--points", type=int, default=5000)
+    ap.add_argument("--window", type=int, default=0, help="covisibility window (0 = dense)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tracking", action="store_true")
+    ap.add_argument("--jac-reps", type=int, default=50)
+    return ap.parse_args()
+
+
+def shard_problem(prob, rank, world):
+    """points p with p % world == rank (and every measurement of those points); all cameras."""
+    if world == 1:
+        return prob
+    keep_pt = np.flatnonzero(np.arange(len(prob["points"])) % world == rank)
+    remap = -np.ones(len(prob["points"]), dtype=np.int64)
+    remap[keep_pt] = np.arange(len(keep_pt))
+    km = remap[prob["pt_idx"]] >= 0
+    out = dict(prob)
+    out["points"] = prob["points"][keep_pt]
+    out["points_true"] = prob["points_true"][keep_pt]
+    out["cam_idx"] = prob["cam_idx"][km]
+    out["pt_idx"] = remap[prob["pt_idx"][km]].astype(np.int32)
+    out["found"] = prob["found"][km]
+    out["sigma_sq"] = prob["sigma_sq"][km]
+    return out
+
+
+def tracking_bench(hip, host, synth, frames=200):
+    """tracked frames/s: K1+K2 (keyframe) + K3 (1000 patches) + K4 (pose GN, 10 iterations)."""
+    C = ctypes
+    ctx = host.Context(lib=hip)
+    a, b = synth.make_frame_pair()
+    kfa = host.KeyFrame(ctx).MakeKeyFrame_Lite(a)
+    q, t = synth.make_patch_queries([kfa.level(l) for l in range(4)], n=1000)
+    kfb = host.KeyFrame(ctx)
+    pc = synth.make_pose_case()
+    # resident inputs
+    d_im, d_q, d_t, d_r = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    chk = ctx._check
+    chk(hip.dev_alloc(ctx.h, b.size, C.byref(d_im)), "alloc")
+    chk(hip.dev_alloc(ctx.h, q.nbytes, C.byref(d_q)), "alloc")
+    chk(hip.dev_alloc(ctx.h, t.nbytes, C.byref(d_t)), "alloc")
+    chk(hip.dev_alloc(ctx.h, len(q) * 32, C.byref(d_r)), "alloc")
+    chk(hip.dev_upload(ctx.h, d_im, b.ctypes.data, b.size), "up")
+    chk(hip.dev_upload(ctx.h, d_q, q.ctypes.data, q.nbytes), "up")
+    chk(hip.dev_upload(ctx.h, d_t, t.ctypes.data, t.nbytes), "up")
+    n = len(pc["world"])
+    meas = np.zeros(n, dtype=host.POSE_MEAS_DT)
+    meas["world"], meas["found"], meas["sqrt_inv_noise"] = pc["world"], pc["found"], pc["sqrt_inv_noise"]
+    opts = ctx.gn_opts()
+    pose = pc["init_pose"].copy()
+    stage = {}
+
+    def one(parts):
+        if "kf" in parts:
+            chk(hip.make_keyframe_lite_dev(ctx.h, kfb.h, d_im), "kf")
+        if "patch" in parts:
+            chk(hip.find_patch_coarse_batch_dev(ctx.h, kfb.h, len(q), d_q, d_t, d_r), "patch")
+        if "pose" in parts:
+            p = pose.copy()
+            chk(hip.pose_gn(ctx.h, n, meas.ctypes.data, None, p.ctypes.data_as(C.POINTER(C.c_double)),
+                            C.byref(opts), None, None), "pose")
+
+    for name, parts in (("frame", ("kf", "patch", "pose")), ("keyframe", ("kf",)), ("patch", ("kf", "patch")),
+                        ("pose", ("pose",))):
+        for _ in range(10):
+            one(parts)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            one(parts)
+        ctx.sync()
+        stage[name] = (time.perf_counter() - t0) / frames
+    for p in (d_im, d_q, d_t, d_r):
+        hip.dev_free(ctx.h, p)
+    return {"tracked_fps": 1.0 / stage["frame"], "frame_us": stage["frame"] * 1e6,
+            "keyframe_us": stage["keyframe"] * 1e6, "keyframe_plus_patch_us": stage["patch"] * 1e6,
+            "pose_gn_us": stage["pose"] * 1e6, "patches_per_frame": int(len(q)), "pose_meas": int(n)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch   # before libptam_hip.so: one shared HIP runtime (see ptam_cg_amd/_lib.py)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from ptam_cg_amd import _abi, host, synth
+    from ptam_cg_amd._lib import load
+    hip = load()
+    device = local_rank if world > 1 else 0
+    ctx = host.Context(lib=hip, device=device)
+
+    n_pts_total = args.points * world
+    prob_full = synth.make_ba_problem(args.cams, n_pts_total, synth.SEED_BA_HEADLINE,
+                                      window=args.window if args.window > 0 else None)
+    prob = shard_problem(prob_full, rank, world)
+
+    comm = None
+    if world > 1:
+        ident = (ctypes.c_uint8 * 128)()
+        if rank == 0:
+            ctx._check(hip.rccl_unique_id(ident), "rccl_unique_id")
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=0)
+        ident = (ctypes.c_uint8 * 128).from_buffer_copy(box[0])
+        comm = ctypes.c_void_p()
+        ctx._check(hip.rccl_create(ctx.h, ident, rank, world, ctypes.byref(comm)), "rccl_create")
+        hook = ctypes.cast(hip.lib.ptam_rccl_allreduce_f64, _abi.ALLREDUCE_FN)
+
+    def new_bundle(max_it):
+        ba = synth.load_into(host.Bundle(ctx, max_iterations=max_it, update_sq_conv_limit=0.0), prob)
+        if comm is not None:
+            ba.set_comm(rank, world, hook, comm)
+        ba.prepare()     # sort + upload: inputs resident in HBM before any timed region
+        return ba
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize() if torch.cuda.is_available() else None
+        ctx.sync()
+
+    # warm-up: W untimed trials
+    if args.warmup > 0:
+        wb = new_bundle(args.warmup)
+        wb.Compute()
+        wb.close()
+    ba = new_bundle(args.steps)
+    barrier()
+    t0 = time.perf_counter()
+    ba.Compute()
+    ctx.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    trials = ba.trials()
+    assert len(trials) == args.steps, (len(trials), args.steps)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    n_cams, n_free, n_points, n_meas = ba.counts()
+    ba.close()
+
+    out = None
+    if rank == 0:
+        value = world * args.steps / dt
+        out = {
+            "metric": "BA LM iterations/s (50 KF x 5k pts per GPU) [+ tracked frames/s @640x480 in 'tracking']",
+            "value": value, "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"bundle_{args.cams}kf_x_{args.points}pts_per_gpu"
+                                   + (f"_window{args.window}" if args.window else "_dense"),
+                       "keyframes": args.cams, "points_total": n_pts_total,
+                       "measurements_rank0": int(len(prob["cam_idx"])), "estimator": "Tukey",
+                       "parallelism": f"points sharded x{world}, RCCL all-reduce of S|E" if world > 1 else "1 GPU",
+                       "halfsample": "R"},
+            "accepted_trials": int(trials["accepted"].sum()),
+            "err_first_last": [float(trials["err_old"][0]), float(trials["err_new"][-1])],
+        }
+    if world == 1:
+        # ---- roofline leg: K7 alone, HIP events on the library's stream -------------------------
+        pb = new_bundle(args.steps)
+        avg_ms, alg_bytes = pb.bench_jacobian(args.jac_reps)
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "jac_accum_kernel", "achieved": achieved,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                           "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                           "avg_launch_us": avg_ms * 1e3, "launches_timed": args.jac_reps}
+        pb.close()
+        # ---- per-kernel breakdown of one profiled Compute (HIP events; not the timed run) -------
+        kb = new_bundle(args.steps)
+        kb.set_profiling(True)
+        kb.Compute()
+        out["kernel_ms_per_trial"] = {k: (ms / max(n, 1)) for k, (ms, n) in kb.kernel_times().items()}
+        kb.close()
+        if not args.no_tracking:
+            out["tracking"] = tracking_bench(hip, host, synth)
+        if not args.no_cpu_baseline:
+            from tests.oracle_lib import load_oracle
+            oracle = load_oracle()
+            octx = host.Context(lib=oracle)
+            ob = synth.load_into(host.Bundle(octx, max_iterations=args.steps, update_sq_conv_limit=0.0), prob)
+            t0 = time.perf_counter()
+            ob.Compute()
+            cdt = time.perf_counter() - t0
+            otr = ob.trials()
+            cpu = {"value": len(otr) / cdt, "unit": "LM iterations/s", "cores": 1, "kind": "port",
+                   "sample": f"same {args.cams}x{args.points} problem, {len(otr)} lambda trials, oracle/ptam_oracle.cc "
+                             f"(single-thread restatement of src/Bundle.cc; the upstream binary cannot be built here)",
+                   "host_cores_available": os.cpu_count()}
+            if not args.no_tracking:
+                a, b = synth.make_frame_pair()
+                kfa = host.KeyFrame(octx).MakeKeyFrame_Lite(a)
+                q, t = synth.make_patch_queries([kfa.level(l) for l in range(4)], n=1000)
+                kfb = host.KeyFrame(octx)
+                pc = synth.make_pose_case()
+                pf = host.PatchFinder(octx)
+                t0 = time.perf_counter()
+                nf = 100
+                for _ in range(nf):
+                    kfb.MakeKeyFrame_Lite(b)
+                    pf.FindPatchCoarse(kfb, q, t)
+                    octx.pose_gn(pc["world"], pc["found"], pc["sqrt_inv_noise"], pc["init_pose"])
+                cpu["tracked_fps"] = nf / (time.perf_counter() - t0)
+            out["cpu_baseline"] = cpu
+            # parity of the timed workload itself (oracle as checker, cheap: it already ran)
+            rel = abs(otr["err_new"][-1] - trials["err_new"][-1]) / abs(otr["err_new"][-1])
+            out["parity_rel_err_final_trial"] = float(rel)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        if comm is not None:
+            hip.rccl_destroy(comm)
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
