@@ -10,7 +10,7 @@
 //     W[9][M] double2               W_ij = A^T B (6x3 row-major, 18 doubles) as 9 planes of double2
 //   points:  pt[2][P][3] (current / trial), V[P][6] (lower 00,10,11,20,21,22), epsB[P][3],
 //            Vinv[P][9]
-//   cameras: pose[2][C][12] (current / trial), U[F][21] lower-triangle row-major, epsA[F][6]
+//   cameras: pose[2][C][12] (current / trial), Usplit[16][F][27] (U lower triangle 21 + epsA 6)
 //   camera system: SE = [ S (npad x npad, lower triangle valid) | E (npad) ] contiguous so that the
 //            sharded path all-reduces ONE buffer; L (npad x npad) + Dg (npad) hold the LDL^T factor.
 #pragma once
@@ -80,8 +80,8 @@ struct BaDev {
     double* m_e2;
     double2* W;
     // accumulators
-    double* U;              // [F][21]
-    double* epsA;           // [F][6]
+    double* Usplit;         // [16][F*27] : per camera 21 lower-triangle U sums + 6 epsA sums, in 16
+                            // fixed-order row splits of the accumulate grid (consumers add the 16)
     double* Upart;          // [grid_acc][F*27]
     double* err_part;       // [max(n_chunks, grid_acc)][2]
     int* bad_part;          // [grid_acc]

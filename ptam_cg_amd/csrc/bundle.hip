@@ -102,16 +102,18 @@ __global__ void __launch_bounds__(256) hist_keys_kernel(const double* __restrict
     }
 }
 
-// one block: find the first-level bin holding rank n_valid/2
-__global__ void __launch_bounds__(1024) select_find_bin_kernel(BaDev d) {
-    __shared__ long long wsum[16];
-    __shared__ long long total_s;
+// block-wide: locate the first-level bin that holds rank total/2 (every block computes the same
+// answer from the global histogram; saves a launch + hand-off).  256 threads, 16 bins each.
+__device__ void block_find_bin(const unsigned* __restrict__ hist, long long& total_out, int& bin_out, int& k_out) {
+    __shared__ long long wsum[4];
+    __shared__ long long s_total;
+    __shared__ int s_bin, s_k;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    unsigned c[4];
+    unsigned c[16];
     long long s = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        c[j] = d.hist[4 * tid + j];
+    for (int j = 0; j < 16; j++) {
+        c[j] = hist[16 * tid + j];
         s += c[j];
     }
     long long incl = s;
@@ -121,127 +123,223 @@ __global__ void __launch_bounds__(1024) select_find_bin_kernel(BaDev d) {
         if (lane >= o) incl += v;
     }
     if (lane == 63) wsum[wid] = incl;
+    if (tid == 0) {
+        s_bin = -1;
+        s_k = 0;
+    }
     __syncthreads();
     if (tid == 0) {
         long long run = 0;
-        for (int i = 0; i < 16; i++) {
+        for (int i = 0; i < 4; i++) {
             const long long v = wsum[i];
             wsum[i] = run;
             run += v;
         }
-        total_s = run;
+        s_total = run;
     }
     __syncthreads();
-    const long long total = total_s;
+    const long long total = s_total;
     const long long k = total / 2;   // vdErrorSquared[size()/2]
     const long long excl = wsum[wid] + incl - s;
-    if (tid == 0) {
-        d.sc->n_valid = total;
-        d.sc->n_cand = 0;
-        if (total == 0) {
-            d.sc->sel_bin = -1;
-            d.sc->sel_k = 0;
-        }
-    }
     if (total > 0 && excl <= k && k < excl + s) {
         long long kk = k - excl;
-        int b = 4 * tid;
-        for (int j = 0; j < 3; j++)
+        int bb = 16 * tid;
+        for (int j = 0; j < 15; j++)
             if (kk >= c[j]) {
                 kk -= c[j];
-                b++;
+                bb++;
             } else
                 break;
-        d.sc->sel_bin = b;
-        d.sc->sel_k = (int)kk;
+        s_bin = bb;
+        s_k = (int)kk;
     }
+    __syncthreads();
+    total_out = total;
+    bin_out = s_bin;
+    k_out = s_k;
 }
 
-// gather the keys of the selected bin (keys = m_e2 masked by state, or an explicit array)
+#define CAND_BUF 2048
+// gather the keys of the selected first-level bin (keys = m_e2 masked by state, or an explicit
+// array) and histogram their next 12 bits (50..39).  Candidates are staged in LDS and appended with
+// one global atomic per flush.
 __global__ void __launch_bounds__(256) select_compact_kernel(BaDev d, const double* __restrict__ keys, long long n,
                                                              const uint8_t* __restrict__ state) {
-    const int bin = d.sc->sel_bin;
+    __shared__ double buf[CAND_BUF];
+    __shared__ unsigned h2[HIST_BINS];
+    __shared__ int cnt, gpos;
+    long long total;
+    int bin, k1;
+    block_find_bin(d.hist, total, bin, k1);
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0) {
+        d.sc->n_valid = total;
+        d.sc->sel_bin = bin;
+        d.sc->sel_k = k1;
+    }
     if (bin < 0) return;
-    const int lane = threadIdx.x & 63;
-    for (long long base = (long long)blockIdx.x * 256; base < n; base += (long long)gridDim.x * 256) {
-        const long long i = base + threadIdx.x;
-        bool take = false;
-        double key = 0;
-        if (i < n && (!state || state[i] == MS_ALIVE)) {
-            key = keys[i];
-            take = e2_bin(key) == bin;
+    for (int b = tid; b < HIST_BINS; b += 256) h2[b] = 0;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    const long long per = (n + gridDim.x - 1) / gridDim.x;
+    const long long i0 = (long long)blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+    for (long long base = i0; base < i1; base += 256) {
+        const long long i = base + tid;
+        if (i < i1 && (!state || state[i] == MS_ALIVE)) {
+            const double key = keys[i];
+            if (e2_bin(key) == bin) {
+                const int pos = atomicAdd(&cnt, 1);
+                buf[pos] = key;
+                atomicAdd(&h2[((unsigned long long)__double_as_longlong(key) >> 39) & (HIST_BINS - 1)], 1u);
+            }
         }
-        const unsigned long long m = __ballot(take);
-        if (m) {
-            int pos = 0;
-            if (lane == 0) pos = atomicAdd(&d.sc->n_cand, __popcll(m));
-            pos = __shfl(pos, 0, 64);
-            if (take) d.cand[pos + __popcll(m & ((1ull << lane) - 1ull))] = key;
+        __syncthreads();
+        if (cnt > CAND_BUF - 256 || base + 256 >= i1) {
+            const int c = cnt;
+            if (tid == 0 && c > 0) gpos = atomicAdd(&d.sc->n_cand, c);
+            __syncthreads();
+            for (int j = tid; j < c; j += 256) d.cand[gpos + j] = buf[j];
+            __syncthreads();
+            if (tid == 0) cnt = 0;
+            __syncthreads();
         }
+    }
+    unsigned* hist2 = d.hist + HIST_BINS;
+    for (int b = tid; b < HIST_BINS; b += 256) {
+        const unsigned c = h2[b];
+        if (c) atomicAdd(&hist2[b], c);
     }
 }
 
-// one block: radix select of rank sel_k among the candidates; sigma^2; reset the histogram
-__global__ void __launch_bounds__(1024) select_final_kernel(BaDev d, int est, double min_sigma_sq) {
-    __shared__ unsigned hist[256];
-    __shared__ int s_digit, s_k;
+// MSB-first 8-bit radix select of rank k among src[0..n) restricted to keys whose bits above
+// (first_shift + 8) equal those of `prefix`.  1024 threads.
+__device__ unsigned long long block_radix_select(const double* src, int n, int k, unsigned long long prefix,
+                                                 int first_shift, unsigned* hist, int* s_digit, int* s_k) {
     const int tid = threadIdx.x;
-    const int n = d.sc->n_cand;
-    int k = d.sc->sel_k;
-    unsigned long long prefix = 0;
-    if (n > 0) {
-        prefix = (unsigned long long)__double_as_longlong(d.cand[0]) & ~((1ull << 56) - 1ull);
-        for (int pass = 0; pass < 7; pass++) {
-            const int shift = 48 - 8 * pass;
-            if (tid < 256) hist[tid] = 0;
-            __syncthreads();
-            for (int i = tid; i < n; i += 1024) {
-                const unsigned long long key = (unsigned long long)__double_as_longlong(d.cand[i]);
-                if ((key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 255], 1u);
-            }
-            __syncthreads();
-            if (tid < 64) {
-                const unsigned c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
-                const int s = (int)(c0 + c1 + c2 + c3);
-                int incl = s;
+    for (int shift = first_shift; shift >= 0; shift -= 8) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += 1024) {
+            const unsigned long long key = (unsigned long long)__double_as_longlong(src[i]);
+            if ((key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 255], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const unsigned c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+            const int s = (int)(c0 + c1 + c2 + c3);
+            int incl = s;
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int v = __shfl_up(incl, o, 64);
-                    if (tid >= o) incl += v;
-                }
-                const int excl = incl - s;
-                if (excl <= k && k < incl) {
-                    int kk = k - excl, dg = 4 * tid;
-                    if (kk >= (int)c0) {
-                        kk -= c0;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o, 64);
+                if (tid >= o) incl += v;
+            }
+            const int excl = incl - s;
+            if (excl <= k && k < incl) {
+                int kk = k - excl, dg = 4 * tid;
+                if (kk >= (int)c0) {
+                    kk -= c0;
+                    dg++;
+                    if (kk >= (int)c1) {
+                        kk -= c1;
                         dg++;
-                        if (kk >= (int)c1) {
-                            kk -= c1;
+                        if (kk >= (int)c2) {
+                            kk -= c2;
                             dg++;
-                            if (kk >= (int)c2) {
-                                kk -= c2;
-                                dg++;
-                            }
                         }
                     }
-                    s_digit = dg;
-                    s_k = kk;
                 }
+                *s_digit = dg;
+                *s_k = kk;
             }
-            __syncthreads();
-            prefix |= (unsigned long long)s_digit << shift;
-            k = s_k;
-            __syncthreads();
         }
+        __syncthreads();
+        prefix |= (unsigned long long)(*s_digit) << shift;
+        k = *s_k;
+        __syncthreads();
     }
-    for (int b = tid; b < HIST_BINS; b += 1024) d.hist[b] = 0;
+    return prefix;
+}
+
+#define SMALL_CAP 4096
+// one block: second-level bin from hist2, collect its (few) members in LDS, finish the select there;
+// sigma^2; reset both histograms
+__global__ void __launch_bounds__(1024) select_final_kernel(BaDev d, int est, double min_sigma_sq) {
+    __shared__ double sm[SMALL_CAP];
+    __shared__ unsigned hist[256];
+    __shared__ long long wsum[16];
+    __shared__ int s_digit, s_k, s_bin2, s_k2, s_cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int n = d.sc->n_cand;
+    unsigned* hist2 = d.hist + HIST_BINS;
+    unsigned long long result = 0;
+    if (n > 0) {
+        // second-level bin
+        unsigned c[4];
+        long long s = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            c[j] = hist2[4 * tid + j];
+            s += c[j];
+        }
+        long long incl = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wsum[wid] = incl;
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        if (tid == 0) {
+            long long run = 0;
+            for (int i = 0; i < 16; i++) {
+                const long long v = wsum[i];
+                wsum[i] = run;
+                run += v;
+            }
+        }
+        __syncthreads();
+        const long long k1 = d.sc->sel_k;
+        const long long excl = wsum[wid] + incl - s;
+        if (excl <= k1 && k1 < excl + s) {
+            long long kk = k1 - excl;
+            int bb = 4 * tid;
+            for (int j = 0; j < 3; j++)
+                if (kk >= c[j]) {
+                    kk -= c[j];
+                    bb++;
+                } else
+                    break;
+            s_bin2 = bb;
+            s_k2 = (int)kk;
+        }
+        __syncthreads();
+        const int bin2 = s_bin2, k2 = s_k2;
+        for (int i = tid; i < n; i += 1024) {
+            const double key = d.cand[i];
+            if ((int)(((unsigned long long)__double_as_longlong(key) >> 39) & (HIST_BINS - 1)) == bin2) {
+                const int pos = atomicAdd(&s_cnt, 1);
+                if (pos < SMALL_CAP) sm[pos] = key;
+            }
+        }
+        __syncthreads();
+        const int m = s_cnt;
+        // bits 63..39 are fixed by (bin, bin2): take them from any member
+        const unsigned long long top = ((unsigned long long)d.sc->sel_bin << 51) | ((unsigned long long)bin2 << 39);
+        if (m <= SMALL_CAP)
+            result = block_radix_select(sm, m, k2, top, 32, hist, &s_digit, &s_k);
+        else   // pathological (thousands of near-identical keys): same passes straight from global
+            result = block_radix_select(d.cand, n, k2, top, 32, hist, &s_digit, &s_k);
+    }
+    for (int b = tid; b < 2 * HIST_BINS; b += 1024) d.hist[b] = 0;
     if (tid == 0) {
-        const double med = n > 0 ? __longlong_as_double((long long)prefix) : 0.0;
+        const double med = n > 0 ? __longlong_as_double((long long)result) : 0.0;
         d.sc->median = med;
         double s2 = est_sigma_sq_from_median(est, med, (unsigned long long)d.sc->n_valid);
         if (s2 < min_sigma_sq) s2 = min_sigma_sq;   // :234-237
         d.sc->sigma_sq = s2;
         d.sc->n_bad = 0;
+        d.sc->n_cand = 0;
     }
 }
 
@@ -415,28 +513,46 @@ __global__ void __launch_bounds__(BA_CHUNK) jac_accum_kernel(DevCam cam, BaDev d
     }
 }
 
-// fixed-order sum over the accumulate grid: U, epsA, cur_err, n_bad
+// fixed-order sum over the accumulate grid.  Stage A (this kernel): grid (column groups of 64,
+// RSPLIT row splits); wave w of a block sums rows w, w+4, ... of its split with coalesced 512-byte
+// loads, the four waves combine in fixed order -> Usplit[split][F*27].  Stage B is folded into the
+// consumers (schur_reduce_kernel sums the RSPLIT values of the 27 numbers it needs per camera).
+// Block (0,0) also reduces the error / bad-count partials.
+#define RSPLIT 16
 __global__ void __launch_bounds__(256) reduce_partials_kernel(BaDev d, int grid_acc) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    __shared__ double comb[4][64];
+    __shared__ double werr[4];
+    __shared__ int wbad[4];
     const int total = d.F * 27;
-    if (k < total) {
-        double s = 0;
-        for (int b = 0; b < grid_acc; b++) s += d.Upart[(size_t)b * total + k];
-        const int f = k / 27, o = k - f * 27;
-        if (o < 21)
-            d.U[f * 21 + o] = s;
-        else
-            d.epsA[f * 6 + o - 21] = s;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    const int split = blockIdx.y;
+    const int rows_per = (grid_acc + RSPLIT - 1) / RSPLIT;
+    const int r0 = split * rows_per, r1 = min(grid_acc, r0 + rows_per);
+    double s = 0;
+    if (col < total)
+        for (int b = r0 + wid; b < r1; b += 4) s += d.Upart[(size_t)b * total + col];
+    comb[wid][lane] = s;
+    __syncthreads();
+    if (wid == 0 && col < total) d.Usplit[(size_t)split * total + col] = ((comb[0][lane] + comb[1][lane]) + comb[2][lane]) + comb[3][lane];
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
         double e = 0;
         int nb = 0;
-        for (int b = 0; b < grid_acc; b++) {
+        for (int b = threadIdx.x; b < grid_acc; b += 256) {
             e += d.err_part[2 * b];
             nb += d.bad_part[b];
         }
-        d.sc->cur_err = e;
-        d.sc->n_bad = nb;
+        e = wave_sum_f64(e);
+        nb = wave_sum_i32(nb);
+        if (lane == 0) {
+            werr[wid] = e;
+            wbad[wid] = nb;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            d.sc->cur_err = ((werr[0] + werr[1]) + werr[2]) + werr[3];
+            d.sc->n_bad = wbad[0] + wbad[1] + wbad[2] + wbad[3];
+        }
     }
 }
 
@@ -493,74 +609,84 @@ __global__ void __launch_bounds__(256) vinv_kernel(BaDev d, double lambda) {
 // K8: Schur complement, output-stationary camera-tile pairs
 // =================================================================================================
 #define SCHUR_TILE_ELEMS (SCHUR_TC * SCHUR_TC * 36 + SCHUR_TC * 6)   // 2304 + 48
+#define SCHUR_BATCH 16                                                 // entries staged per LDS round
 
-// per-wave LDS panel: Y[8][18] | W[8][18]
-struct SchurPanel {
-    double Y[SCHUR_TC][18];
-    double W[SCHUR_TC][18];
-};
-
+// Workgroup = (tile pair (a,b), a slice of the points touching both tiles).  Per round it stages
+// SCHUR_BATCH entries: 16 loader lanes per entry fetch the W blocks of the point's measurements in
+// tile a / tile b (9 x double2 each, all 256 threads loading at once -> deep memory-level parallelism),
+// form Y = W V*^-1 on the fly and drop Y / W into LDS panels indexed by camera slot.  Then each wave
+// takes 4 entries; lane (j,k) accumulates the 6x6 block  Y_j W_k^T  in 36 registers (and E_j on the
+// diagonal pair).  Absent cameras are skipped through per-entry presence masks (no panel zeroing).
 __global__ void __launch_bounds__(256) schur_tile_kernel(BaDev d) {
-    __shared__ SchurPanel panels[4];
-    __shared__ double red[2][64][42];
+    __shared__ __attribute__((aligned(16))) double lds[2 * 64 * 42];   // panels (4608) alias the reduce buffer (5376)
+    __shared__ unsigned pmA[2][SCHUR_BATCH], pmB[2][SCHUR_BATCH];   // presence masks, double-buffered by round parity
+    __shared__ double eBs[SCHUR_BATCH][3];
+    double(*PY)[SCHUR_TC][18] = reinterpret_cast<double(*)[SCHUR_TC][18]>(lds);
+    double(*PW)[SCHUR_TC][18] = reinterpret_cast<double(*)[SCHUR_TC][18]>(lds + SCHUR_BATCH * SCHUR_TC * 18);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const SchurWG wg = d.s_wgs[blockIdx.x];
-    // pair -> (a, b), a >= b
     int a = (int)((sqrt(8.0 * wg.pair + 1.0) - 1.0) * 0.5);
     while ((a + 1) * (a + 2) / 2 <= wg.pair) a++;
     while (a * (a + 1) / 2 > wg.pair) a--;
     const int b = wg.pair - a * (a + 1) / 2;
     const bool diag = a == b;
     const int j = lane >> 3, k = lane & 7;
-    SchurPanel& P = panels[wid];
+    const int le = tid >> 4, ls = tid & 15;   // loader role: local entry, lane within the entry
     double acc[36], accE[6];
 #pragma unroll
     for (int i = 0; i < 36; i++) acc[i] = 0;
 #pragma unroll
     for (int i = 0; i < 6; i++) accE[i] = 0;
-    const int n_ent = wg.e_end - wg.e_begin;
-    const int iters = (n_ent + 3) / 4;
-    for (int it = 0; it < iters; it++) {
-        const int e = wg.e_begin + it * 4 + wid;
-        const bool have = e < wg.e_end;
-        unsigned pa = 0, pb = 0;
-        double eB[3] = {0, 0, 0};
-        if (have) {
-            const SchurEntry ent = d.s_entries[e];
-            const int na = ent.na_nb & 0xffff, nb = (ent.na_nb >> 16) & 0xffff;
+    if (tid < 2 * SCHUR_BATCH) {
+        (&pmA[0][0])[tid] = 0;
+        (&pmB[0][0])[tid] = 0;
+    }
+    int par = 0;
+    for (int e0 = wg.e_begin; e0 < wg.e_end; e0 += SCHUR_BATCH, par ^= 1) {
+        const int nb_ent = min(SCHUR_BATCH, wg.e_end - e0);
+        __syncthreads();   // previous round's compute done (its masks / panels are dead)
+        if (tid < SCHUR_BATCH) {   // clear the OTHER parity for the next round
+            pmA[par ^ 1][tid] = 0;
+            pmB[par ^ 1][tid] = 0;
+        }
+        if (le < nb_ent) {
+            const SchurEntry ent = d.s_entries[e0 + le];
+            const int na = ent.na_nb & 0xffff, nbm = (ent.na_nb >> 16) & 0xffff;
             const double* __restrict__ Vi = d.Vinv + (size_t)ent.pt * 9;
-            // zero the panel (288 doubles)
-            double* pz = &P.Y[0][0];
-            for (int i = lane; i < 2 * SCHUR_TC * 18; i += 64) pz[i] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // tile a: Y = W V*^-1 (and W too when a == b)
-            for (int l = lane; l < na; l += 64) {
-                const int m = ent.ma + l;
-                const int f = d.cam_free[d.m_cam[m]];
-                if (f >= 0 && d.m_state[m] == MS_ALIVE) {
-                    const int slot = f - a * SCHUR_TC;
-                    double w[18];
+            if (ls < 3) eBs[le][ls] = d.epsB[(size_t)ent.pt * 3 + ls];
+            // tile a (lanes 0..7 of the entry when off-diagonal, all 16 when diagonal)
+            const int stepA = diag ? 16 : 8;
+            if (diag || ls < 8) {
+                for (int l = ls; l < na; l += stepA) {
+                    const int m = ent.ma + l;
+                    const int f = d.cam_free[d.m_cam[m]];
+                    if (f >= 0 && d.m_state[m] == MS_ALIVE) {
+                        const int slot = f - a * SCHUR_TC;
+                        double w[18];
 #pragma unroll
-                    for (int q = 0; q < 9; q++) {
-                        const double2 t = d.W[(size_t)q * d.M + m];
-                        w[2 * q] = t.x;
-                        w[2 * q + 1] = t.y;
+                        for (int q = 0; q < 9; q++) {
+                            const double2 t = d.W[(size_t)q * d.M + m];
+                            w[2 * q] = t.x;
+                            w[2 * q + 1] = t.y;
+                        }
+                        double v[9];
+#pragma unroll
+                        for (int q = 0; q < 9; q++) v[q] = Vi[q];
+#pragma unroll
+                        for (int r = 0; r < 6; r++)
+#pragma unroll
+                            for (int c = 0; c < 3; c++)
+                                PY[le][slot][r * 3 + c] = w[r * 3] * v[c] + w[r * 3 + 1] * v[3 + c] + w[r * 3 + 2] * v[6 + c];
+                        if (diag) {
+#pragma unroll
+                            for (int q = 0; q < 18; q++) PW[le][slot][q] = w[q];
+                        }
+                        atomicOr(&pmA[par][le], 1u << slot);
                     }
-#pragma unroll
-                    for (int r = 0; r < 6; r++)
-#pragma unroll
-                        for (int c = 0; c < 3; c++)
-                            P.Y[slot][r * 3 + c] = w[r * 3] * Vi[c] + w[r * 3 + 1] * Vi[3 + c] + w[r * 3 + 2] * Vi[6 + c];
-                    if (diag) {
-#pragma unroll
-                        for (int q = 0; q < 18; q++) P.W[slot][q] = w[q];
-                    }
-                    pa |= 1u << slot;
                 }
             }
-            if (!diag) {
-                for (int l = lane; l < nb; l += 64) {
+            if (!diag && ls >= 8) {
+                for (int l = ls - 8; l < nbm; l += 8) {
                     const int m = ent.mb + l;
                     const int f = d.cam_free[d.m_cam[m]];
                     if (f >= 0 && d.m_state[m] == MS_ALIVE) {
@@ -568,32 +694,23 @@ __global__ void __launch_bounds__(256) schur_tile_kernel(BaDev d) {
 #pragma unroll
                         for (int q = 0; q < 9; q++) {
                             const double2 t = d.W[(size_t)q * d.M + m];
-                            P.W[slot][2 * q] = t.x;
-                            P.W[slot][2 * q + 1] = t.y;
+                            PW[le][slot][2 * q] = t.x;
+                            PW[le][slot][2 * q + 1] = t.y;
                         }
-                        pb |= 1u << slot;
+                        atomicOr(&pmB[par][le], 1u << slot);
                     }
                 }
             }
-            // wave-wide presence masks
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                pa |= __shfl_xor(pa, o, 64);
-                pb |= __shfl_xor(pb, o, 64);
-            }
-            if (diag) pb = pa;
-            eB[0] = d.epsB[(size_t)ent.pt * 3];
-            eB[1] = d.epsB[(size_t)ent.pt * 3 + 1];
-            eB[2] = d.epsB[(size_t)ent.pt * 3 + 2];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        __syncthreads();
+        for (int e = wid; e < nb_ent; e += 4) {
+            const unsigned pa = pmA[par][e], pb = diag ? pa : pmB[par][e];
             if (((pa >> j) & 1u) && ((pb >> k) & 1u)) {
                 double Yj[18], Wk[18];
 #pragma unroll
                 for (int q = 0; q < 18; q++) {
-                    Yj[q] = P.Y[j][q];
-                    Wk[q] = P.W[k][q];
+                    Yj[q] = PY[e][j][q];
+                    Wk[q] = PW[e][k][q];
                 }
 #pragma unroll
                 for (int r = 0; r < 6; r++)
@@ -601,13 +718,15 @@ __global__ void __launch_bounds__(256) schur_tile_kernel(BaDev d) {
                     for (int c = 0; c < 6; c++)
                         acc[r * 6 + c] += Yj[r * 3] * Wk[c * 3] + Yj[r * 3 + 1] * Wk[c * 3 + 1] + Yj[r * 3 + 2] * Wk[c * 3 + 2];
                 if (diag && k == j) {
+                    const double b0 = eBs[e][0], b1 = eBs[e][1], b2 = eBs[e][2];
 #pragma unroll
-                    for (int r = 0; r < 6; r++) accE[r] += Yj[r * 3] * eB[0] + Yj[r * 3 + 1] * eB[1] + Yj[r * 3 + 2] * eB[2];
+                    for (int r = 0; r < 6; r++) accE[r] += Yj[r * 3] * b0 + Yj[r * 3 + 1] * b1 + Yj[r * 3 + 2] * b2;
                 }
             }
-            __builtin_amdgcn_wave_barrier();
         }
     }
+    __syncthreads();   // panels dead: the buffer becomes the cross-wave reduction scratch
+    double(*red)[64][42] = reinterpret_cast<double(*)[64][42]>(lds);
     // cross-wave reduction in fixed order: (w2 -> w0, w3 -> w1), then (w1 -> w0)
     if (wid >= 2) {
 #pragma unroll
@@ -666,7 +785,8 @@ __global__ void __launch_bounds__(256) schur_reduce_kernel(BaDev d, double lambd
         if (a == b && j == k) {
             // U* : symmetrised U with diag * (1 + lambda)  (:383-390)
             const int rr = r >= c ? r : c, cc = r >= c ? c : r;
-            double u = d.U[fa * 21 + rr * (rr + 1) / 2 + cc];
+            double u = 0;
+            for (int sp = 0; sp < RSPLIT; sp++) u += d.Usplit[(size_t)sp * d.F * 27 + fa * 27 + rr * (rr + 1) / 2 + cc];
             if (r == c) u *= (1.0 + lambda);
             val += u;
         }
@@ -679,7 +799,9 @@ __global__ void __launch_bounds__(256) schur_reduce_kernel(BaDev d, double lambd
             if (fa >= d.F) continue;
             double s = 0;
             for (int w = wg0; w < wg1; w++) s += d.s_part[(size_t)w * SCHUR_TILE_ELEMS + SCHUR_TC * SCHUR_TC * 36 + idx];
-            E[6 * fa + r] = d.epsA[fa * 6 + r] - s;
+            double ea = 0;
+            for (int sp = 0; sp < RSPLIT; sp++) ea += d.Usplit[(size_t)sp * d.F * 27 + fa * 27 + 21 + r];
+            E[6 * fa + r] = ea - s;
         }
     }
     if (pair == 0) {
@@ -1047,8 +1169,9 @@ static int ba_prepare_impl(ptam_ba* ba) {
     {
         size_t total = 0;
         for (auto& v : per_pair) total += v.size();
-        int per_wg = (int)std::min<size_t>(1024, std::max<size_t>(64, total / 1024 + 1));
-        per_wg = (per_wg + 3) & ~3;
+        // ~3 resident workgroups per CU x 256 CUs in one round; whole LDS batches per workgroup
+        int per_wg = (int)std::min<size_t>(2048, std::max<size_t>(64, total / 760 + 1));
+        per_wg = (per_wg + SCHUR_BATCH - 1) / SCHUR_BATCH * SCHUR_BATCH;
         for (int pr = 0; pr < n_pairs; pr++) {
             pair_wg_begin[pr] = (int)s_wgs.size();
             const int base = (int)s_entries.size();
@@ -1076,8 +1199,18 @@ static int ba_prepare_impl(ptam_ba* ba) {
         ptam_set_error("%d free cameras exceed the LDS budget of the accumulate kernel", F);
         return PTAM_E_LIMIT;
     }
-    int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / ba->smem_acc));
-    d.grid_acc = std::max(1, std::min(d.n_chunks, 256 * per_cu));
+    if (ba->smem_acc > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)jac_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)ba->smem_acc));
+    int per_cu = 0, n_cu = 256;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)jac_accum_kernel, BA_CHUNK, ba->smem_acc));
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+        n_cu = prop.multiProcessorCount;
+    }
+    per_cu = std::max(1, std::min(per_cu, 8));
+    d.grid_acc = std::max(1, std::min(d.n_chunks, n_cu * per_cu));
 
     // ---- carve one device allocation ------------------------------------------------------------
     Carver cv;
@@ -1087,11 +1220,11 @@ static int ba_prepare_impl(ptam_ba* ba) {
                  o_Vinv = cv.take(Pz * 72), o_rowptr = cv.take((Pz + 1) * 4);
     const size_t o_mcam = cv.take(Mz * 4), o_mpt = cv.take(Mz * 4), o_mfound = cv.take(Mz * 16), o_ms = cv.take(Mz * 8),
                  o_morig = cv.take(Mz * 4), o_mstate = cv.take(Mz), o_me2 = cv.take(Mz * 8), o_W = cv.take(Mz * 144);
-    const size_t o_U = cv.take(Fz * 21 * 8), o_epsA = cv.take(Fz * 6 * 8), o_Upart = cv.take((size_t)d.grid_acc * Fz * 27 * 8);
+    const size_t o_U = cv.take(Fz * 27 * 8 * 16), o_Upart = cv.take((size_t)d.grid_acc * Fz * 27 * 8);
     const size_t n_part = std::max(d.n_chunks, d.grid_acc);
     const size_t o_errp = cv.take(n_part * 16 + 16), o_badp = cv.take((size_t)d.grid_acc * 4 + 16);
     const size_t o_chunks = cv.take(std::max<size_t>(1, chunks.size()) * sizeof(BaChunk));
-    const size_t o_hist = cv.take(HIST_BINS * 4), o_cand = cv.take(Mz * 8);
+    const size_t o_hist = cv.take(2 * HIST_BINS * 4), o_cand = cv.take(Mz * 8);
     const size_t o_sent = cv.take(std::max<size_t>(1, s_entries.size()) * sizeof(SchurEntry)),
                  o_swg = cv.take(std::max<size_t>(1, s_wgs.size()) * sizeof(SchurWG)),
                  o_spw = cv.take((size_t)(n_pairs + 1) * 4),
@@ -1121,8 +1254,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.m_state = (uint8_t*)(base + o_mstate);
     d.m_e2 = (double*)(base + o_me2);
     d.W = (double2*)(base + o_W);
-    d.U = (double*)(base + o_U);
-    d.epsA = (double*)(base + o_epsA);
+    d.Usplit = (double*)(base + o_U);
     d.Upart = (double*)(base + o_Upart);
     d.err_part = (double*)(base + o_errp);
     d.bad_part = (int*)(base + o_badp);
@@ -1170,9 +1302,6 @@ static int ba_prepare_impl(ptam_ba* ba) {
     UP(d.s_pair_wg_begin, pair_wg_begin.data(), pair_wg_begin.size() * 4);
 #undef UP
     HIP_TRY(hipStreamSynchronize(ctx->stream));   // host staging vectors die here
-    if (ba->smem_acc > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void*)jac_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)ba->smem_acc));
     HIP_TRY(hipMalloc((void**)&ba->d_xchg, 4096));
     ba->cur = 0;
     ba->prepared = true;
@@ -1225,8 +1354,7 @@ static int ba_pass1_sigma(ptam_ba* ba) {
     prof_end(ba, PTAM_K_PROJECT);
     prof_begin(ba, PTAM_K_SELECT);
     if (!sharded) {
-        hipLaunchKernelGGL(select_find_bin_kernel, dim3(1), dim3(1024), 0, ctx->stream, d);
-        hipLaunchKernelGGL(select_compact_kernel, dim3(std::max(1, std::min((d.M + 255) / 256, 1024))), dim3(256), 0,
+        hipLaunchKernelGGL(select_compact_kernel, dim3(std::max(1, std::min((d.M + 1023) / 1024, 256))), dim3(256), 0,
                            ctx->stream, d, (const double*)d.m_e2, (long long)d.M, (const uint8_t*)d.m_state);
     } else {
         // all-gather of the valid e^2 built from two all-reduces (counts, then a zero-padded vector)
@@ -1265,8 +1393,7 @@ static int ba_pass1_sigma(ptam_ba* ba) {
         if (total > 0)
             hipLaunchKernelGGL(hist_keys_kernel, dim3((int)std::max<long long>(1, std::min<long long>((total + 255) / 256, 1024))),
                                dim3(256), 0, ctx->stream, (const double*)ba->d_gather, total, d.hist);
-        hipLaunchKernelGGL(select_find_bin_kernel, dim3(1), dim3(1024), 0, ctx->stream, dg);
-        hipLaunchKernelGGL(select_compact_kernel, dim3((int)std::max<long long>(1, std::min<long long>((total + 255) / 256, 1024))),
+        hipLaunchKernelGGL(select_compact_kernel, dim3((int)std::max<long long>(1, std::min<long long>((total + 1023) / 1024, 256))),
                            dim3(256), 0, ctx->stream, dg, (const double*)ba->d_gather, total, (const uint8_t*)nullptr);
         hipLaunchKernelGGL(select_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, dg, ba->opts.estimator, min_s2);
         prof_end(ba, PTAM_K_SELECT);
@@ -1286,8 +1413,8 @@ static int ba_pass2(ptam_ba* ba) {
     hipLaunchKernelGGL(jac_accum_kernel, dim3(d.grid_acc), dim3(BA_CHUNK), ba->smem_acc, ctx->stream, ctx->cam, d, ba->cur,
                        ba->opts.estimator);
     prof_end(ba, PTAM_K_JACOBIAN);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(std::max(1, (d.F * 27 + 255) / 256)), dim3(256), 0, ctx->stream, d,
-                       d.grid_acc);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(std::max(1, (d.F * 27 + 63) / 64), RSPLIT), dim3(256), 0, ctx->stream,
+                       d, d.grid_acc);
     HIP_TRY(hipGetLastError());
     if (ba->comm && ba->world > 1) {
         hipLaunchKernelGGL(pack2_kernel, dim3(1), dim3(1), 0, ctx->stream, (const BaScalars*)d.sc, ba->d_xchg, 0);
