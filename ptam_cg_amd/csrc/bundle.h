@@ -76,6 +76,7 @@ struct BaDev {
     double2* m_found;
     double* m_s;
     int* m_orig;
+    int* m_fidx;            // free-camera index of the measurement's camera (-1 = fixed)
     uint8_t* m_state;
     double* m_e2;
     double2* W;

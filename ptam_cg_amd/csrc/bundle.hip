@@ -659,8 +659,9 @@ __global__ void __launch_bounds__(256) schur_tile_kernel(BaDev d) {
             if (diag || ls < 8) {
                 for (int l = ls; l < na; l += stepA) {
                     const int m = ent.ma + l;
-                    const int f = d.cam_free[d.m_cam[m]];
-                    if (f >= 0 && d.m_state[m] == MS_ALIVE) {
+                    const int f = d.m_fidx[m];   // free-camera index, -1 for fixed cameras (W of bad /
+                                                 // erased measurements is zero, so they need no test)
+                    if (f >= 0) {
                         const int slot = f - a * SCHUR_TC;
                         double w[18];
 #pragma unroll
@@ -688,8 +689,8 @@ __global__ void __launch_bounds__(256) schur_tile_kernel(BaDev d) {
             if (!diag && ls >= 8) {
                 for (int l = ls - 8; l < nbm; l += 8) {
                     const int m = ent.mb + l;
-                    const int f = d.cam_free[d.m_cam[m]];
-                    if (f >= 0 && d.m_state[m] == MS_ALIVE) {
+                    const int f = d.m_fidx[m];
+                    if (f >= 0) {
                         const int slot = f - b * SCHUR_TC;
 #pragma unroll
                         for (int q = 0; q < 9; q++) {
@@ -760,11 +761,12 @@ __global__ void __launch_bounds__(256) schur_tile_kernel(BaDev d) {
     }
 }
 
-// one block per tile pair: fixed-order sum of the partial tiles, add U* / epsA, write S (lower) and E.
-// contributes_u: this rank adds U*, epsA and the padding identity (always true on one GPU; in sharded
-// mode every rank adds its OWN partial U, the padding identity only on rank 0).
+// grid (tile pair, slice): fixed-order sum of the partial tiles, add U* / epsA, write S (lower) and E.
+// Every rank adds its OWN partial U* and epsA ((1+lambda) diag(U) is linear, so the sharded partials
+// fold into the one all-reduce); the padding identity is added on rank 0 only.
+#define SRED_SLICES 10   // 9 x 256 tile elements + 1 slice for E and the padding rows
 __global__ void __launch_bounds__(256) schur_reduce_kernel(BaDev d, double lambda, int pad_identity) {
-    const int pair = blockIdx.x;
+    const int pair = blockIdx.x, slice = blockIdx.y;
     int a = (int)((sqrt(8.0 * pair + 1.0) - 1.0) * 0.5);
     while ((a + 1) * (a + 2) / 2 <= pair) a++;
     while (a * (a + 1) / 2 > pair) a--;
@@ -773,34 +775,47 @@ __global__ void __launch_bounds__(256) schur_reduce_kernel(BaDev d, double lambd
     double* S = d.SE;
     double* E = d.SE + (size_t)d.npad * d.npad;
     const int npad = d.npad;
-    for (int idx = threadIdx.x; idx < SCHUR_TC * SCHUR_TC * 36; idx += 256) {
+    const size_t FS = (size_t)d.F * 27;
+    if (slice < 9) {
+        const int idx = slice * 256 + threadIdx.x;
         const int jk = idx / 36, rc = idx - jk * 36;
         const int j = jk >> 3, k = jk & 7, r = rc / 6, c = rc - r * 6;
         const int fa = a * SCHUR_TC + j, fb = b * SCHUR_TC + k;
-        if (fa >= d.F || fb >= d.F) continue;
-        if (a == b && j < k) continue;   // strict upper blocks are never read
-        double s = 0;
-        for (int w = wg0; w < wg1; w++) s += d.s_part[(size_t)w * SCHUR_TILE_ELEMS + idx];
-        double val = -s;
+        if (fa >= d.F || fb >= d.F) return;
+        if (a == b && j < k) return;   // strict upper blocks are never read
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        const double* p = d.s_part + (size_t)wg0 * SCHUR_TILE_ELEMS + idx;
+        int w = wg0;
+        for (; w + 4 <= wg1; w += 4, p += 4 * (size_t)SCHUR_TILE_ELEMS) {
+            s0 += p[0];
+            s1 += p[SCHUR_TILE_ELEMS];
+            s2 += p[2 * (size_t)SCHUR_TILE_ELEMS];
+            s3 += p[3 * (size_t)SCHUR_TILE_ELEMS];
+        }
+        for (; w < wg1; w++, p += SCHUR_TILE_ELEMS) s0 += p[0];
+        double val = -((s0 + s1) + (s2 + s3));
         if (a == b && j == k) {
             // U* : symmetrised U with diag * (1 + lambda)  (:383-390)
             const int rr = r >= c ? r : c, cc = r >= c ? c : r;
             double u = 0;
-            for (int sp = 0; sp < RSPLIT; sp++) u += d.Usplit[(size_t)sp * d.F * 27 + fa * 27 + rr * (rr + 1) / 2 + cc];
+#pragma unroll
+            for (int sp = 0; sp < RSPLIT; sp++) u += d.Usplit[sp * FS + fa * 27 + rr * (rr + 1) / 2 + cc];
             if (r == c) u *= (1.0 + lambda);
             val += u;
         }
         S[(size_t)(6 * fa + r) * npad + 6 * fb + c] = val;
+        return;
     }
-    if (a == b) {
-        for (int idx = threadIdx.x; idx < SCHUR_TC * 6; idx += 256) {
-            const int j = idx / 6, r = idx - j * 6;
-            const int fa = a * SCHUR_TC + j;
-            if (fa >= d.F) continue;
+    if (a == b && threadIdx.x < SCHUR_TC * 6) {
+        const int idx = threadIdx.x;
+        const int j = idx / 6, r = idx - j * 6;
+        const int fa = a * SCHUR_TC + j;
+        if (fa < d.F) {
             double s = 0;
             for (int w = wg0; w < wg1; w++) s += d.s_part[(size_t)w * SCHUR_TILE_ELEMS + SCHUR_TC * SCHUR_TC * 36 + idx];
             double ea = 0;
-            for (int sp = 0; sp < RSPLIT; sp++) ea += d.Usplit[(size_t)sp * d.F * 27 + fa * 27 + 21 + r];
+#pragma unroll
+            for (int sp = 0; sp < RSPLIT; sp++) ea += d.Usplit[sp * FS + fa * 27 + 21 + r];
             E[6 * fa + r] = ea - s;
         }
     }
@@ -1169,8 +1184,8 @@ static int ba_prepare_impl(ptam_ba* ba) {
     {
         size_t total = 0;
         for (auto& v : per_pair) total += v.size();
-        // ~3 resident workgroups per CU x 256 CUs in one round; whole LDS batches per workgroup
-        int per_wg = (int)std::min<size_t>(2048, std::max<size_t>(64, total / 760 + 1));
+        // ~2 resident workgroups per CU x 256 CUs in ONE round; whole LDS batches per workgroup
+        int per_wg = (int)std::min<size_t>(2048, std::max<size_t>(64, total / 500 + 1));
         per_wg = (per_wg + SCHUR_BATCH - 1) / SCHUR_BATCH * SCHUR_BATCH;
         for (int pr = 0; pr < n_pairs; pr++) {
             pair_wg_begin[pr] = (int)s_wgs.size();
@@ -1219,7 +1234,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     const size_t o_pt0 = cv.take(Pz * 24), o_pt1 = cv.take(Pz * 24), o_V = cv.take(Pz * 48), o_epsB = cv.take(Pz * 24),
                  o_Vinv = cv.take(Pz * 72), o_rowptr = cv.take((Pz + 1) * 4);
     const size_t o_mcam = cv.take(Mz * 4), o_mpt = cv.take(Mz * 4), o_mfound = cv.take(Mz * 16), o_ms = cv.take(Mz * 8),
-                 o_morig = cv.take(Mz * 4), o_mstate = cv.take(Mz), o_me2 = cv.take(Mz * 8), o_W = cv.take(Mz * 144);
+                 o_morig = cv.take(Mz * 4), o_mfidx = cv.take(Mz * 4), o_mstate = cv.take(Mz), o_me2 = cv.take(Mz * 8), o_W = cv.take(Mz * 144);
     const size_t o_U = cv.take(Fz * 27 * 8 * 16), o_Upart = cv.take((size_t)d.grid_acc * Fz * 27 * 8);
     const size_t n_part = std::max(d.n_chunks, d.grid_acc);
     const size_t o_errp = cv.take(n_part * 16 + 16), o_badp = cv.take((size_t)d.grid_acc * 4 + 16);
@@ -1251,6 +1266,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.m_found = (double2*)(base + o_mfound);
     d.m_s = (double*)(base + o_ms);
     d.m_orig = (int*)(base + o_morig);
+    d.m_fidx = (int*)(base + o_mfidx);
     d.m_state = (uint8_t*)(base + o_mstate);
     d.m_e2 = (double*)(base + o_me2);
     d.W = (double2*)(base + o_W);
@@ -1274,13 +1290,14 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.sc = (BaScalars*)(base + o_sc);
 
     // ---- upload -------------------------------------------------------------------------------------
-    std::vector<int> h_cam(Mz), h_pt(Mz), h_orig(Mz);
+    std::vector<int> h_cam(Mz), h_pt(Mz), h_orig(Mz), h_fidx(Mz);
     std::vector<double> h_found(2 * Mz), h_s(Mz);
     for (int i = 0; i < M; i++) {
         const int o = order[i];
         h_cam[i] = ba->m_cam[o];
         h_pt[i] = ba->m_pt[o];
         h_orig[i] = o;
+        h_fidx[i] = cam_free[ba->m_cam[o]];
         h_found[2 * i] = ba->m_found[2 * o];
         h_found[2 * i + 1] = ba->m_found[2 * o + 1];
         h_s[i] = ba->m_s[o];
@@ -1296,6 +1313,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     UP(d.m_found, h_found.data(), (size_t)M * 16);
     UP(d.m_s, h_s.data(), (size_t)M * 8);
     UP(d.m_orig, h_orig.data(), (size_t)M * 4);
+    UP(d.m_fidx, h_fidx.data(), (size_t)M * 4);
     UP(d.chunks, chunks.data(), chunks.size() * sizeof(BaChunk));
     UP(d.s_entries, s_entries.data(), s_entries.size() * sizeof(SchurEntry));
     UP(d.s_wgs, s_wgs.data(), s_wgs.size() * sizeof(SchurWG));
@@ -1434,7 +1452,7 @@ static int ba_trial(ptam_ba* ba, double lambda) {
     if (d.F > 0) {
         prof_begin(ba, PTAM_K_SCHUR);
         if (d.n_schur_wg > 0) hipLaunchKernelGGL(schur_tile_kernel, dim3(d.n_schur_wg), dim3(256), 0, ctx->stream, d);
-        hipLaunchKernelGGL(schur_reduce_kernel, dim3(d.n_pairs), dim3(256), 0, ctx->stream, d, lambda,
+        hipLaunchKernelGGL(schur_reduce_kernel, dim3(d.n_pairs, SRED_SLICES), dim3(256), 0, ctx->stream, d, lambda,
                            (ba->world > 1 && ba->rank != 0) ? 0 : 1);
         prof_end(ba, PTAM_K_SCHUR);
         HIP_TRY(hipGetLastError());
