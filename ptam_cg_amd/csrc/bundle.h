@@ -60,6 +60,7 @@ struct BaDev {
     int C, F, P, M;
     int n, npad;            // camera system order 6F and its padding to SOLVE_NB
     int n_chunks, grid_acc; // measurement chunks; persistent grid of the accumulate kernel
+    int n_wchunks;          // wave chunks (<= 64 measurements, whole points); 0 = block variant only
     int n_tiles, n_pairs, n_schur_wg, n_schur_entries;
     // cameras
     double* pose[2];
@@ -87,6 +88,7 @@ struct BaDev {
     double* err_part;       // [max(n_chunks, grid_acc)][2]
     int* bad_part;          // [grid_acc]
     BaChunk* chunks;
+    BaChunk* wchunks;
     // select
     unsigned* hist;         // [HIST_BINS]
     double* cand;           // [M]

@@ -362,6 +362,175 @@ __global__ void __launch_bounds__(256) compact_valid_kernel(BaDev d, double* __r
 // =================================================================================================
 // K7: fused Jacobian + normal-equation accumulation (pass 2, :250-332)
 // =================================================================================================
+// One measurement of pass 2: weight, Jacobians, camera accumulation (LDS atomics into Ul), W store.
+// Returns B (2x3) and the weighted error for the caller's per-point reduction.
+__device__ __forceinline__ void jac_measure(const DevCam& cam, const BaDev& d, const double* __restrict__ pose,
+                                            const double* __restrict__ pt, double sigma_sq, int est, int m, double* Ul,
+                                            double& err, int& nbad, double B0[3], double B1[3], double& ex, double& ey) {
+    double Wv[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) Wv[k] = 0;
+    const int st = d.m_state[m];
+    if (st == MS_BAD) {   // z <= 0 in pass 1  (:259-263)
+        err += 1.0;
+        nbad++;
+    } else if (st == MS_ALIVE) {
+        const int c = d.m_cam[m], p = d.m_pt[m];
+        const double* __restrict__ T = pose + 12 * c;
+        double X, Y, Z, x, y, u, v, r, f;
+        ba_project(cam, T, pt + 3 * p, X, Y, Z, x, y, u, v, r, f);
+        const double2 fo = d.m_found[m];
+        const double s = d.m_s[m];
+        ex = s * (fo.x - u);
+        ey = s * (fo.y - v);
+        const double e2 = ex * ex + ey * ey;
+        const double w = est_sqrt_weight(est, e2, sigma_sq);
+        ex *= w;   // meas.v2Epsilon = dWeight * meas.v2Epsilon  (:272)
+        ey *= w;
+        if (w == 0) {   // :274-279
+            d.m_state[m] = MS_BAD;
+            err += 1.0;
+            nbad++;
+            ex = ey = 0;
+        } else {
+            err += est_objective(est, e2, sigma_sq);
+            double D[4];
+            cam_derivs(cam, x, y, r, f, D);
+            // fold sqrt-weight and dSqrtInvNoise into the camera derivatives (:285, :302)
+            const double D0 = s * w * D[0], D1 = s * w * D[1], D2 = s * w * D[2], D3 = s * w * D[3];
+            const double iz = 1.0 / Z;
+            // B: point Jacobian, motion = m-th column of R_cw (:306-313)
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const double g0 = T[k], g1 = T[3 + k], g2 = T[6 + k];
+                const double mx = (g0 - X * g2 * iz) * iz, my = (g1 - Y * g2 * iz) * iz;
+                B0[k] = D0 * mx + D1 * my;
+                B1[k] = D2 * mx + D3 * my;
+            }
+            const int fidx = d.m_fidx[m];
+            if (fidx >= 0) {
+                // A: camera Jacobian, SE3 generator fields (:291-303)
+                const double gx[6] = {1, 0, 0, 0, Z, -Y};
+                const double gy[6] = {0, 1, 0, -Z, 0, X};
+                const double gz[6] = {0, 0, 1, Y, -X, 0};
+                double A0[6], A1[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    const double mx = (gx[k] - X * gz[k] * iz) * iz, my = (gy[k] - Y * gz[k] * iz) * iz;
+                    A0[k] = D0 * mx + D1 * my;
+                    A1[k] = D2 * mx + D3 * my;
+                }
+                double* Uc = Ul + fidx * 27;
+                int k = 0;
+#pragma unroll
+                for (int a = 0; a < 6; a++)
+#pragma unroll
+                    for (int b = 0; b <= a; b++) atomicAdd(&Uc[k++], A0[a] * A0[b] + A1[a] * A1[b]);   // U_LL :21-26
+#pragma unroll
+                for (int a = 0; a < 6; a++) atomicAdd(&Uc[21 + a], A0[a] * ex + A1[a] * ey);       // epsA :321
+#pragma unroll
+                for (int a = 0; a < 6; a++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++) Wv[a * 3 + b] = A0[a] * B0[b] + A1[a] * B1[b];   // W = A^T B :331
+            }
+        }
+    }
+    // W planes: 9 x double2, coalesced across the wave
+#pragma unroll
+    for (int k = 0; k < 9; k++) d.W[(size_t)k * d.M + m] = make_double2(Wv[2 * k], Wv[2 * k + 1]);
+}
+
+// flush a workgroup's camera partials + error partial (end of both accumulate kernels)
+__device__ __forceinline__ void jac_flush(const BaDev& d, const double* Ul, double err, int nbad) {
+    __shared__ double werr[BA_CHUNK / 64];
+    __shared__ int wbad[BA_CHUNK / 64];
+    const int tid = threadIdx.x;
+    double* up = d.Upart + (size_t)blockIdx.x * d.F * 27;
+    for (int k = tid; k < d.F * 27; k += BA_CHUNK) up[k] = Ul[k];
+    err = wave_sum_f64(err);
+    nbad = wave_sum_i32(nbad);
+    if ((tid & 63) == 0) {
+        werr[tid >> 6] = err;
+        wbad[tid >> 6] = nbad;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double e = 0;
+        int b = 0;
+        for (int i = 0; i < BA_CHUNK / 64; i++) {
+            e += werr[i];
+            b += wbad[i];
+        }
+        d.err_part[2 * blockIdx.x] = e;
+        d.bad_part[blockIdx.x] = b;
+    }
+}
+
+// K7, wave variant (every point has <= 64 measurements): ONE WAVE owns whole points, lane = measurement.
+// No workgroup barrier inside the loop, so the 8..16 resident waves of a CU overlap each other's
+// gather latency.  V / epsB: the 9 per-measurement products are combined by a segmented inclusive
+// scan over the wave (shuffles, fixed tree => deterministic); the last lane of each point stores.
+// dynamic LDS: Ul[F*27] camera partials, shared by the 4 waves (ds_add_f64).
+__global__ void __launch_bounds__(BA_CHUNK) jac_accum_wave_kernel(DevCam cam, BaDev d, int cur, int est) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* Ul = smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int k = tid; k < d.F * 27; k += BA_CHUNK) Ul[k] = 0;
+    __syncthreads();
+    const double* __restrict__ pose = d.pose[cur];
+    const double* __restrict__ pt = d.pt[cur];
+    const double sigma_sq = d.sc->sigma_sq;
+    double err = 0;
+    int nbad = 0;
+    const int nw = gridDim.x * (BA_CHUNK / 64);
+    for (int ci = blockIdx.x * (BA_CHUNK / 64) + (tid >> 6); ci < d.n_wchunks; ci += nw) {
+        const BaChunk ch = d.wchunks[ci];
+        const int m = ch.m_begin + lane;
+        const bool active = m < ch.m_end;
+        double v[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) v[i] = 0;
+        int pid = -1 - lane;   // inactive lanes: unique ids, never merged
+        if (active) {
+            double B0[3] = {0, 0, 0}, B1[3] = {0, 0, 0}, ex = 0, ey = 0;
+            jac_measure(cam, d, pose, pt, sigma_sq, est, m, Ul, err, nbad, B0, B1, ex, ey);
+            pid = d.m_pt[m];
+            v[0] = B0[0] * B0[0] + B1[0] * B1[0];   // V_LL 00,10,11,20,21,22  (:325)
+            v[1] = B0[1] * B0[0] + B1[1] * B1[0];
+            v[2] = B0[1] * B0[1] + B1[1] * B1[1];
+            v[3] = B0[2] * B0[0] + B1[2] * B1[0];
+            v[4] = B0[2] * B0[1] + B1[2] * B1[1];
+            v[5] = B0[2] * B0[2] + B1[2] * B1[2];
+            v[6] = B0[0] * ex + B1[0] * ey;         // epsB (:326)
+            v[7] = B0[1] * ex + B1[1] * ey;
+            v[8] = B0[2] * ex + B1[2] * ey;
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int po = __shfl_up(pid, o, 64);
+            const bool take = lane >= o && po == pid;
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const double t = __shfl_up(v[i], o, 64);
+                if (take) v[i] += t;
+            }
+        }
+        const int pn = __shfl_down(pid, 1, 64);
+        if (active && (lane == 63 || pn != pid)) {
+            double* Vp = d.V + (size_t)pid * 6;
+#pragma unroll
+            for (int i = 0; i < 6; i++) Vp[i] = v[i];
+            double* Ep = d.epsB + (size_t)pid * 3;
+            Ep[0] = v[6];
+            Ep[1] = v[7];
+            Ep[2] = v[8];
+        }
+    }
+    __syncthreads();
+    jac_flush(d, Ul, err, nbad);
+}
+
+// K7, block variant (points with up to BA_CHUNK measurements): a workgroup owns whole points.
 // dynamic LDS: Ul[F*27] camera partials | Bs[BA_CHUNK][8] per-measurement B (2x3) and weighted eps
 __global__ void __launch_bounds__(BA_CHUNK) jac_accum_kernel(DevCam cam, BaDev d, int cur, int est) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -379,79 +548,7 @@ __global__ void __launch_bounds__(BA_CHUNK) jac_accum_kernel(DevCam cam, BaDev d
         const BaChunk ch = d.chunks[ci];
         const int m = ch.m_begin + tid;
         double B0[3] = {0, 0, 0}, B1[3] = {0, 0, 0}, ex = 0, ey = 0;
-        if (m < ch.m_end) {
-            double Wv[18];
-#pragma unroll
-            for (int k = 0; k < 18; k++) Wv[k] = 0;
-            const int st = d.m_state[m];
-            if (st == MS_BAD) {   // z <= 0 in pass 1  (:259-263)
-                err += 1.0;
-                nbad++;
-            } else if (st == MS_ALIVE) {
-                const int c = d.m_cam[m], p = d.m_pt[m];
-                const double* __restrict__ T = pose + 12 * c;
-                double X, Y, Z, x, y, u, v, r, f;
-                ba_project(cam, T, pt + 3 * p, X, Y, Z, x, y, u, v, r, f);
-                const double2 fo = d.m_found[m];
-                const double s = d.m_s[m];
-                ex = s * (fo.x - u);
-                ey = s * (fo.y - v);
-                const double e2 = ex * ex + ey * ey;
-                const double w = est_sqrt_weight(est, e2, sigma_sq);
-                ex *= w;   // meas.v2Epsilon = dWeight * meas.v2Epsilon  (:272)
-                ey *= w;
-                if (w == 0) {   // :274-279
-                    d.m_state[m] = MS_BAD;
-                    err += 1.0;
-                    nbad++;
-                    ex = ey = 0;
-                } else {
-                    err += est_objective(est, e2, sigma_sq);
-                    double D[4];
-                    cam_derivs(cam, x, y, r, f, D);
-                    // fold sqrt-weight and dSqrtInvNoise into the camera derivatives (:285, :302)
-                    const double D0 = s * w * D[0], D1 = s * w * D[1], D2 = s * w * D[2], D3 = s * w * D[3];
-                    const double iz = 1.0 / Z;
-                    // B: point Jacobian, motion = m-th column of R_cw (:306-313)
-#pragma unroll
-                    for (int k = 0; k < 3; k++) {
-                        const double g0 = T[k], g1 = T[3 + k], g2 = T[6 + k];
-                        const double mx = (g0 - X * g2 * iz) * iz, my = (g1 - Y * g2 * iz) * iz;
-                        B0[k] = D0 * mx + D1 * my;
-                        B1[k] = D2 * mx + D3 * my;
-                    }
-                    const int fidx = d.cam_free[c];
-                    if (fidx >= 0) {
-                        // A: camera Jacobian, SE3 generator fields (:291-303)
-                        const double gx[6] = {1, 0, 0, 0, Z, -Y};
-                        const double gy[6] = {0, 1, 0, -Z, 0, X};
-                        const double gz[6] = {0, 0, 1, Y, -X, 0};
-                        double A0[6], A1[6];
-#pragma unroll
-                        for (int k = 0; k < 6; k++) {
-                            const double mx = (gx[k] - X * gz[k] * iz) * iz, my = (gy[k] - Y * gz[k] * iz) * iz;
-                            A0[k] = D0 * mx + D1 * my;
-                            A1[k] = D2 * mx + D3 * my;
-                        }
-                        double* Uc = Ul + fidx * 27;
-                        int k = 0;
-#pragma unroll
-                        for (int a = 0; a < 6; a++)
-#pragma unroll
-                            for (int b = 0; b <= a; b++) atomicAdd(&Uc[k++], A0[a] * A0[b] + A1[a] * A1[b]);   // U_LL :21-26
-#pragma unroll
-                        for (int a = 0; a < 6; a++) atomicAdd(&Uc[21 + a], A0[a] * ex + A1[a] * ey);       // epsA :321
-#pragma unroll
-                        for (int a = 0; a < 6; a++)
-#pragma unroll
-                            for (int b = 0; b < 3; b++) Wv[a * 3 + b] = A0[a] * B0[b] + A1[a] * B1[b];   // W = A^T B :331
-                    }
-                }
-            }
-            // W planes: 9 x double2, coalesced across the wave
-#pragma unroll
-            for (int k = 0; k < 9; k++) d.W[(size_t)k * d.M + m] = make_double2(Wv[2 * k], Wv[2 * k + 1]);
-        }
+        if (m < ch.m_end) jac_measure(cam, d, pose, pt, sigma_sq, est, m, Ul, err, nbad, B0, B1, ex, ey);
         double* bs = Bs + tid * 8;
         bs[0] = B0[0];
         bs[1] = B0[1];
@@ -489,28 +586,8 @@ __global__ void __launch_bounds__(BA_CHUNK) jac_accum_kernel(DevCam cam, BaDev d
         }
         __syncthreads();
     }
-    // flush this workgroup's camera partials + error partial
-    double* up = d.Upart + (size_t)blockIdx.x * d.F * 27;
-    for (int k = tid; k < d.F * 27; k += BA_CHUNK) up[k] = Ul[k];
-    __shared__ double werr[BA_CHUNK / 64];
-    __shared__ int wbad[BA_CHUNK / 64];
-    err = wave_sum_f64(err);
-    nbad = wave_sum_i32(nbad);
-    if ((tid & 63) == 0) {
-        werr[tid >> 6] = err;
-        wbad[tid >> 6] = nbad;
-    }
     __syncthreads();
-    if (tid == 0) {
-        double e = 0;
-        int b = 0;
-        for (int i = 0; i < BA_CHUNK / 64; i++) {
-            e += werr[i];
-            b += wbad[i];
-        }
-        d.err_part[2 * blockIdx.x] = e;
-        d.bad_part[blockIdx.x] = b;
-    }
+    jac_flush(d, Ul, err, nbad);
 }
 
 // fixed-order sum over the accumulate grid.  Stage A (this kernel): grid (column groups of 64,
@@ -1048,6 +1125,7 @@ struct ptam_ba {
     size_t block_bytes = 0;
     int cur = 0;
     size_t smem_acc = 0;
+    bool use_wave = false;
     std::vector<int> sorted_orig;   // sorted position -> insertion index
     // gather buffers (sharded mode)
     double* d_gather = nullptr;
@@ -1144,6 +1222,26 @@ static int ba_prepare_impl(ptam_ba* ba) {
             chunks.push_back(ch);
         }
     }
+    // wave chunks (K7 wave variant): consecutive whole points, at most 64 measurements
+    std::vector<BaChunk> wchunks;
+    int max_row = 0;
+    for (int p = 0; p < P; p++) max_row = std::max(max_row, rowptr[p + 1] - rowptr[p]);
+    if (max_row <= 64) {
+        int p = 0;
+        while (p < P) {
+            BaChunk ch;
+            ch.pt_begin = p;
+            ch.m_begin = rowptr[p];
+            int cnt = 0;
+            while (p < P && cnt + (rowptr[p + 1] - rowptr[p]) <= 64) {
+                cnt += rowptr[p + 1] - rowptr[p];
+                p++;
+            }
+            ch.pt_end = p;
+            ch.m_end = rowptr[p];
+            wchunks.push_back(ch);
+        }
+    }
     // Schur work lists
     const int n_tiles = (F + SCHUR_TC - 1) / SCHUR_TC;
     const int n_pairs = n_tiles * (n_tiles + 1) / 2;
@@ -1204,28 +1302,30 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.n = 6 * F;
     d.npad = ((d.n + SOLVE_NB - 1) / SOLVE_NB) * SOLVE_NB;
     d.n_chunks = (int)chunks.size();
+    d.n_wchunks = (int)wchunks.size();
+    ba->use_wave = !wchunks.empty();
     d.n_tiles = n_tiles;
     d.n_pairs = n_pairs;
     d.n_schur_wg = (int)s_wgs.size();
     d.n_schur_entries = (int)s_entries.size();
     // persistent grid of the accumulate kernel: bounded by LDS residency, 2 x 256 CUs by default
-    ba->smem_acc = ((((size_t)F * 27 + 1) & ~(size_t)1) + (size_t)BA_CHUNK * 8) * sizeof(double);
+    ba->smem_acc = ((((size_t)F * 27 + 1) & ~(size_t)1) + (ba->use_wave ? 0 : (size_t)BA_CHUNK * 8)) * sizeof(double);
+    const void* k7 = ba->use_wave ? (const void*)jac_accum_wave_kernel : (const void*)jac_accum_kernel;
     if (ba->smem_acc > 160 * 1024) {
         ptam_set_error("%d free cameras exceed the LDS budget of the accumulate kernel", F);
         return PTAM_E_LIMIT;
     }
     if (ba->smem_acc > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void*)jac_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)ba->smem_acc));
+        HIP_TRY(hipFuncSetAttribute(k7, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba->smem_acc));
     int per_cu = 0, n_cu = 256;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)jac_accum_kernel, BA_CHUNK, ba->smem_acc));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k7, BA_CHUNK, ba->smem_acc));
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
         n_cu = prop.multiProcessorCount;
     }
     per_cu = std::max(1, std::min(per_cu, 8));
-    d.grid_acc = std::max(1, std::min(d.n_chunks, n_cu * per_cu));
+    d.grid_acc = std::max(1, std::min(ba->use_wave ? (d.n_wchunks + 3) / 4 : d.n_chunks, n_cu * per_cu));
 
     // ---- carve one device allocation ------------------------------------------------------------
     Carver cv;
@@ -1239,6 +1339,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     const size_t n_part = std::max(d.n_chunks, d.grid_acc);
     const size_t o_errp = cv.take(n_part * 16 + 16), o_badp = cv.take((size_t)d.grid_acc * 4 + 16);
     const size_t o_chunks = cv.take(std::max<size_t>(1, chunks.size()) * sizeof(BaChunk));
+    const size_t o_wchunks = cv.take(std::max<size_t>(1, wchunks.size()) * sizeof(BaChunk));
     const size_t o_hist = cv.take(2 * HIST_BINS * 4), o_cand = cv.take(Mz * 8);
     const size_t o_sent = cv.take(std::max<size_t>(1, s_entries.size()) * sizeof(SchurEntry)),
                  o_swg = cv.take(std::max<size_t>(1, s_wgs.size()) * sizeof(SchurWG)),
@@ -1275,6 +1376,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.err_part = (double*)(base + o_errp);
     d.bad_part = (int*)(base + o_badp);
     d.chunks = (BaChunk*)(base + o_chunks);
+    d.wchunks = (BaChunk*)(base + o_wchunks);
     d.hist = (unsigned*)(base + o_hist);
     d.cand = (double*)(base + o_cand);
     d.s_entries = (SchurEntry*)(base + o_sent);
@@ -1315,6 +1417,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     UP(d.m_orig, h_orig.data(), (size_t)M * 4);
     UP(d.m_fidx, h_fidx.data(), (size_t)M * 4);
     UP(d.chunks, chunks.data(), chunks.size() * sizeof(BaChunk));
+    UP(d.wchunks, wchunks.data(), wchunks.size() * sizeof(BaChunk));
     UP(d.s_entries, s_entries.data(), s_entries.size() * sizeof(SchurEntry));
     UP(d.s_wgs, s_wgs.data(), s_wgs.size() * sizeof(SchurWG));
     UP(d.s_pair_wg_begin, pair_wg_begin.data(), pair_wg_begin.size() * 4);
@@ -1424,12 +1527,21 @@ static int ba_pass1_sigma(ptam_ba* ba) {
     return PTAM_OK;
 }
 
+static void launch_k7(ptam_ba* ba) {
+    ptam_ctx* ctx = ba->ctx;
+    if (ba->use_wave)
+        hipLaunchKernelGGL(jac_accum_wave_kernel, dim3(ba->d.grid_acc), dim3(BA_CHUNK), ba->smem_acc, ctx->stream, ctx->cam,
+                           ba->d, ba->cur, ba->opts.estimator);
+    else
+        hipLaunchKernelGGL(jac_accum_kernel, dim3(ba->d.grid_acc), dim3(BA_CHUNK), ba->smem_acc, ctx->stream, ctx->cam, ba->d,
+                           ba->cur, ba->opts.estimator);
+}
+
 static int ba_pass2(ptam_ba* ba) {
     ptam_ctx* ctx = ba->ctx;
     BaDev& d = ba->d;
     prof_begin(ba, PTAM_K_JACOBIAN);
-    hipLaunchKernelGGL(jac_accum_kernel, dim3(d.grid_acc), dim3(BA_CHUNK), ba->smem_acc, ctx->stream, ctx->cam, d, ba->cur,
-                       ba->opts.estimator);
+    launch_k7(ba);
     prof_end(ba, PTAM_K_JACOBIAN);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(std::max(1, (d.F * 27 + 63) / 64), RSPLIT), dim3(256), 0, ctx->stream,
                        d, d.grid_acc);
@@ -1790,14 +1902,12 @@ int ptam_ba_bench_jacobian(ptam_ba* ba, int reps, double* avg_ms, double* algori
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     for (int i = 0; i < 3; i++)
-        hipLaunchKernelGGL(jac_accum_kernel, dim3(d.grid_acc), dim3(BA_CHUNK), ba->smem_acc, ctx->stream, ctx->cam, d, ba->cur,
-                           ba->opts.estimator);
+        launch_k7(ba);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     double total = 0;
     for (int i = 0; i < reps; i++) {
         HIP_TRY(hipEventRecord(e0, ctx->stream));
-        hipLaunchKernelGGL(jac_accum_kernel, dim3(d.grid_acc), dim3(BA_CHUNK), ba->smem_acc, ctx->stream, ctx->cam, d, ba->cur,
-                           ba->opts.estimator);
+        launch_k7(ba);
         HIP_TRY(hipEventRecord(e1, ctx->stream));
         HIP_TRY(hipEventSynchronize(e1));
         float ms = 0;

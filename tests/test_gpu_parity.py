@@ -153,6 +153,7 @@ BA_CASES = {
     "banded_40x400": dict(n_cams=40, n_pts=400, seed=3, window=10),
     "two_fixed": dict(n_cams=12, n_pts=120, seed=4, n_fixed=2),
     "config4_20x3000": dict(n_cams=20, n_pts=3000, seed=synth.SEED_BA_LOCAL),
+    "wide_80x60": dict(n_cams=80, n_pts=60, seed=6),          # > 64 measurements per point: block variant of K7
 }
 
 
