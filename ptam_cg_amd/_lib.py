@@ -7,7 +7,7 @@ import sys
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libptam_hip.so")
+LIB_PATH = os.environ.get("PTAM_HIP_LIB", os.path.join(_HERE, "csrc", "libptam_hip.so"))   # override: instrumented builds
 _bound = None
 
 

@@ -106,6 +106,7 @@ struct BaDev {
     // outliers
     int* outliers;          // [M] original indices, in purge order
     BaScalars* sc;
+    long long* dbg;         // 16 cycle stamps (only written by -DK7_TIMING builds)
 };
 
 // solve.hip

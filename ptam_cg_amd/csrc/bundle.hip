@@ -31,16 +31,64 @@ __device__ __forceinline__ int e2_bin(double e2) {
     return (int)(((unsigned long long)__double_as_longlong(e2) >> 51) & (HIST_BINS - 1));
 }
 
-// project one measurement: returns false (bad) if z <= 0  (ProjectAndFindSquaredError :164-180)
+// project one measurement: returns false (bad) if z <= 0  (ProjectAndFindSquaredError :164-180).
+// Same arithmetic as cam_project / cam_derivs (common.h) with the divisions replaced by three
+// Newton-refined reciprocals (1/z, 1/r, 1/(1+k^2 r^2)); pass 1, pass 2 and the new-error pass all
+// go through this one function, so they see bit-identical projections.
+struct BaProj {
+    double X, Y, Z;      // v3Cam
+    double x, y;         // z = 1 plane
+    double u, v;         // image
+    double r, ir, f;     // radius, 1/r, rtrans_factor
+};
 __device__ __forceinline__ bool ba_project(const DevCam& cam, const double* __restrict__ T, const double* __restrict__ X,
-                                           double& cx, double& cy, double& cz, double& x, double& y, double& u,
-                                           double& v, double& r, double& f) {
-    se3_apply(T, X[0], X[1], X[2], cx, cy, cz);
-    if (cz <= 0) return false;
-    x = cx / cz;
-    y = cy / cz;
-    cam_project(cam, x, y, u, v, r, f);
+                                           BaProj& p) {
+    se3_apply(T, X[0], X[1], X[2], p.X, p.Y, p.Z);
+    if (p.Z <= 0) return false;
+    const double iz = rcp_nr(p.Z);
+    p.x = p.X * iz;
+    p.y = p.Y * iz;
+    const double r2 = p.x * p.x + p.y * p.y;
+    p.r = sqrt(r2);
+    if (p.r < 0.001 || cam.w == 0.0) {
+        p.ir = 0;
+        p.f = 1.0;
+    } else {
+        p.ir = rcp_nr(p.r);
+        p.f = cam.w_inv * atan(p.r * cam.two_tan) * p.ir;
+    }
+    p.u = cam.cx + cam.fx * (p.f * p.x);
+    p.v = cam.cy + cam.fy * (p.f * p.y);
     return true;
+}
+// GetProjectionDerivs (src/ATANCamera.cc:179-209): dFdx = x*g, dFdy = y*g with the common factor
+// g = [ (k/w)/(1+k^2 r^2) - f ] / r^2
+__device__ __forceinline__ void ba_derivs(const DevCam& cam, const BaProj& p, double D[4]) {
+    const double r = p.r * cam.dist_enabled;
+    double g = 0.0;
+    if (!(r < 0.01)) {
+        const double k = cam.two_tan;
+        const double iden = rcp_nr(1 + k * k * r * r);
+        g = (cam.w_inv * k * iden - p.f) * (p.ir * p.ir);
+    }
+    const double dx = p.x * g, dy = p.y * g;
+    D[0] = cam.fx * (dx * p.x + p.f);
+    D[2] = cam.fy * (dx * p.y);
+    D[1] = cam.fx * (dy * p.x);
+    D[3] = cam.fy * (dy * p.y + p.f);
+}
+// Tukey with a precomputed 1/sigma^2 (other estimators keep their general form)
+__device__ __forceinline__ double ba_sqrt_weight(int est, double e2, double s2, double is2) {
+    if (est == PTAM_EST_TUKEY) return e2 > s2 ? 0.0 : 1.0 - e2 * is2;
+    return est_sqrt_weight(est, e2, s2);
+}
+__device__ __forceinline__ double ba_objective(int est, double e2, double s2, double is2) {
+    if (est == PTAM_EST_TUKEY) {
+        if (e2 > s2) return 1.0;
+        const double dd = 1.0 - e2 * is2;
+        return 1.0 - dd * dd * dd;
+    }
+    return est_objective(est, e2, s2);
 }
 
 // =================================================================================================
@@ -59,15 +107,26 @@ __global__ void __launch_bounds__(BA_CHUNK) project_e2_kernel(DevCam cam, BaDev 
         const int m = ch.m_begin + tid;
         if (m < ch.m_end) {
             const int st = d.m_state[m];
+            if ((m & 63) == 0 && m > 0) {
+                // a point cut by a 64-measurement boundary is completed by atomics in K7's wave
+                // variant: clear its accumulators here, one pass ahead
+                const int pc = d.m_pt[m];
+                if (d.rowptr[pc] < m) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) d.V[(size_t)pc * 6 + i] = 0;
+#pragma unroll
+                    for (int i = 0; i < 3; i++) d.epsB[(size_t)pc * 3 + i] = 0;
+                }
+            }
             if (st != MS_DEAD) {
                 const int c = d.m_cam[m], p = d.m_pt[m];
-                double cx, cy, cz, x, y, u, v, r, f;
-                if (!ba_project(cam, pose + 12 * c, pt + 3 * p, cx, cy, cz, x, y, u, v, r, f)) {
+                BaProj pr;
+                if (!ba_project(cam, pose + 12 * c, pt + 3 * p, pr)) {
                     d.m_state[m] = MS_BAD;
                 } else {
                     const double2 fo = d.m_found[m];
                     const double s = d.m_s[m];
-                    const double ex = s * (fo.x - u), ey = s * (fo.y - v);
+                    const double ex = s * (fo.x - pr.u), ey = s * (fo.y - pr.v);
                     const double e2 = ex * ex + ey * ey;
                     d.m_e2[m] = e2;
                     if (st != MS_ALIVE) d.m_state[m] = MS_ALIVE;
@@ -365,7 +424,8 @@ __global__ void __launch_bounds__(256) compact_valid_kernel(BaDev d, double* __r
 // One measurement of pass 2: weight, Jacobians, camera accumulation (LDS atomics into Ul), W store.
 // Returns B (2x3) and the weighted error for the caller's per-point reduction.
 __device__ __forceinline__ void jac_measure(const DevCam& cam, const BaDev& d, const double* __restrict__ pose,
-                                            const double* __restrict__ pt, double sigma_sq, int est, int m, double* Ul,
+                                            const double* __restrict__ pt, double sigma_sq, double inv_sigma_sq, int est,
+                                            int m, double* Ul,
                                             double& err, int& nbad, double B0[3], double B1[3], double& ex, double& ey) {
     double Wv[18];
 #pragma unroll
@@ -377,14 +437,15 @@ __device__ __forceinline__ void jac_measure(const DevCam& cam, const BaDev& d, c
     } else if (st == MS_ALIVE) {
         const int c = d.m_cam[m], p = d.m_pt[m];
         const double* __restrict__ T = pose + 12 * c;
-        double X, Y, Z, x, y, u, v, r, f;
-        ba_project(cam, T, pt + 3 * p, X, Y, Z, x, y, u, v, r, f);
+        BaProj pr;
+        ba_project(cam, T, pt + 3 * p, pr);
+        const double X = pr.X, Y = pr.Y, Z = pr.Z;
         const double2 fo = d.m_found[m];
         const double s = d.m_s[m];
-        ex = s * (fo.x - u);
-        ey = s * (fo.y - v);
+        ex = s * (fo.x - pr.u);
+        ey = s * (fo.y - pr.v);
         const double e2 = ex * ex + ey * ey;
-        const double w = est_sqrt_weight(est, e2, sigma_sq);
+        const double w = ba_sqrt_weight(est, e2, sigma_sq, inv_sigma_sq);
         ex *= w;   // meas.v2Epsilon = dWeight * meas.v2Epsilon  (:272)
         ey *= w;
         if (w == 0) {   // :274-279
@@ -393,12 +454,12 @@ __device__ __forceinline__ void jac_measure(const DevCam& cam, const BaDev& d, c
             nbad++;
             ex = ey = 0;
         } else {
-            err += est_objective(est, e2, sigma_sq);
+            err += ba_objective(est, e2, sigma_sq, inv_sigma_sq);
             double D[4];
-            cam_derivs(cam, x, y, r, f, D);
+            ba_derivs(cam, pr, D);
             // fold sqrt-weight and dSqrtInvNoise into the camera derivatives (:285, :302)
             const double D0 = s * w * D[0], D1 = s * w * D[1], D2 = s * w * D[2], D3 = s * w * D[3];
-            const double iz = 1.0 / Z;
+            const double iz = rcp_nr(Z);
             // B: point Jacobian, motion = m-th column of R_cw (:306-313)
 #pragma unroll
             for (int k = 0; k < 3; k++) {
@@ -466,35 +527,178 @@ __device__ __forceinline__ void jac_flush(const BaDev& d, const double* Ul, doub
     }
 }
 
-// K7, wave variant (every point has <= 64 measurements): ONE WAVE owns whole points, lane = measurement.
-// No workgroup barrier inside the loop, so the 8..16 resident waves of a CU overlap each other's
-// gather latency.  V / epsB: the 9 per-measurement products are combined by a segmented inclusive
-// scan over the wave (shuffles, fixed tree => deterministic); the last lane of each point stores.
-// dynamic LDS: Ul[F*27] camera partials, shared by the 4 waves (ds_add_f64).
-__global__ void __launch_bounds__(BA_CHUNK) jac_accum_wave_kernel(DevCam cam, BaDev d, int cur, int est) {
+// K7, wave variant (every point has <= 64 measurements): lane = measurement, a wave takes runs of
+// 64 consecutive measurements of the point-major order.  No workgroup barrier inside the loop.
+//  - balance: every wave gets the same number `per_wave` of consecutive 64-measurement chunks, and
+//    the next chunk's inputs are prefetched while the current one is computed;
+//  - poses are staged once per workgroup in LDS (C*96 B); the chunk's points are fetched one per
+//    lane and handed to their measurements by ds_bpermute: ONE global round trip per chunk;
+//  - U / epsA: ds_add_f64 into the workgroup's LDS partials;
+//  - V / epsB: segmented inclusive scan over the wave (DPP row shifts + row broadcasts, fixed tree).
+//    A point lying inside the chunk is stored by its last lane; a point cut by a chunk boundary
+//    (at most two pieces since n_i <= 64) is completed with fp64 atomics on the zeroed V / epsB —
+//    0 + a + b is order independent, so the result stays deterministic;
+//  - W: 9 coalesced double2 planes.
+// dynamic LDS: Ul[F*27] | poses[C*12]
+struct K7In {
+    int st, c, p, fidx;
+    double2 fo;
+    double sn;
+    double px, py, pz;   // point (pt0 + lane), fetched one per lane
+    int pt0;
+    int p_prev, p_next;  // point of the measurement just before / after this chunk (-1 at the ends)
+};
+__device__ __forceinline__ void k7_load(const BaDev& d, const double* __restrict__ pt, int m0, int lane, K7In& in) {
+    const int m = m0 + lane;
+    in.st = MS_DEAD;
+    in.c = 0;
+    in.p = 0;
+    in.fidx = -1;
+    in.fo = make_double2(0, 0);
+    in.sn = 0;
+    in.px = in.py = in.pz = 0;
+    const int mlast = min(m0 + 63, d.M - 1);
+    in.pt0 = d.m_pt[m0];
+    const int pt1 = d.m_pt[mlast];
+    in.p_prev = m0 > 0 ? d.m_pt[m0 - 1] : -1;
+    in.p_next = m0 + 64 < d.M ? d.m_pt[m0 + 64] : -1;
+    if (m < d.M) {
+        in.st = d.m_state[m];
+        in.c = d.m_cam[m];
+        in.p = d.m_pt[m];
+        in.fidx = d.m_fidx[m];
+        in.fo = d.m_found[m];
+        in.sn = d.m_s[m];
+    }
+    if (in.pt0 + lane <= pt1) {
+        const double* q = pt + 3 * (size_t)(in.pt0 + lane);
+        in.px = q[0];
+        in.py = q[1];
+        in.pz = q[2];
+    }
+}
+
+#ifdef K7_TIMING
+#define K7_STAMP(i) if (blockIdx.x == 7 && tid == 0) d.dbg[i] = (long long)__builtin_readcyclecounter();
+#else
+#define K7_STAMP(i)
+#endif
+template <int MINW, bool PREFETCH>
+__global__ void __launch_bounds__(BA_CHUNK, MINW) jac_accum_wave_kernel(DevCam cam, BaDev d, int cur, int est, int per_wave) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Ul = smem;
+    double* Ps = smem + (((size_t)d.F * 27 + 1) & ~(size_t)1);
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int k = tid; k < d.F * 27; k += BA_CHUNK) Ul[k] = 0;
-    __syncthreads();
-    const double* __restrict__ pose = d.pose[cur];
     const double* __restrict__ pt = d.pt[cur];
+    const int n_chunks64 = (d.M + 63) >> 6;
+    const int c_begin = (blockIdx.x * (BA_CHUNK / 64) + (tid >> 6)) * per_wave;
+    const int c_end = min(n_chunks64, c_begin + per_wave);
+    // first chunk's loads and sigma^2 go out before the LDS prologue, so both latencies overlap it
+    K7In in;
+    if (PREFETCH && c_begin < c_end) k7_load(d, pt, c_begin << 6, lane, in);
     const double sigma_sq = d.sc->sigma_sq;
+    for (int k = tid; k < d.F * 27; k += BA_CHUNK) Ul[k] = 0;
+    {
+        const double* __restrict__ pose = d.pose[cur];
+        for (int k = tid; k < d.C * 12; k += BA_CHUNK) Ps[k] = pose[k];
+    }
+    __syncthreads();
+    K7_STAMP(0)
+    const double inv_sigma_sq = 1.0 / sigma_sq;
     double err = 0;
     int nbad = 0;
-    const int nw = gridDim.x * (BA_CHUNK / 64);
-    for (int ci = blockIdx.x * (BA_CHUNK / 64) + (tid >> 6); ci < d.n_wchunks; ci += nw) {
-        const BaChunk ch = d.wchunks[ci];
-        const int m = ch.m_begin + lane;
-        const bool active = m < ch.m_end;
+    K7_STAMP(1)
+    for (int ci = c_begin; ci < c_end; ci++) {
+        const int m0 = ci << 6;
+        const int m = m0 + lane;
+        const bool active = m < d.M;
+        if (!PREFETCH) k7_load(d, pt, m0, lane, in);
+        const K7In cu = in;
+        K7_STAMP(2)
+        if (PREFETCH && ci + 1 < c_end) k7_load(d, pt, (ci + 1) << 6, lane, in);   // prefetch the next chunk
+        const int st = cu.st, c = cu.c, p = cu.p, fidx = cu.fidx;
+        const int src = p - cu.pt0;   // lane that fetched my point
+        const double Xw = __shfl(cu.px, src, 64), Yw = __shfl(cu.py, src, 64), Zw = __shfl(cu.pz, src, 64);
+        int pid = active ? p : (-1 - lane);   // inactive lanes: unique ids, never merged
         double v[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) v[i] = 0;
-        int pid = -1 - lane;   // inactive lanes: unique ids, never merged
-        if (active) {
-            double B0[3] = {0, 0, 0}, B1[3] = {0, 0, 0}, ex = 0, ey = 0;
-            jac_measure(cam, d, pose, pt, sigma_sq, est, m, Ul, err, nbad, B0, B1, ex, ey);
-            pid = d.m_pt[m];
+        bool full = false;
+        BaProj pr;
+        double ex = 0, ey = 0, w = 0;
+        const double* T = Ps + 12 * c;
+        if (st == MS_BAD) {   // z <= 0 in pass 1  (:259-263)
+            err += 1.0;
+            nbad++;
+        } else if (st == MS_ALIVE) {
+            const double Xp[3] = {Xw, Yw, Zw};
+            ba_project(cam, T, Xp, pr);
+            ex = cu.sn * (cu.fo.x - pr.u);
+            ey = cu.sn * (cu.fo.y - pr.v);
+            const double e2 = ex * ex + ey * ey;
+            w = ba_sqrt_weight(est, e2, sigma_sq, inv_sigma_sq);
+            if (w == 0) {   // :274-279
+                d.m_state[m] = MS_BAD;
+                err += 1.0;
+                nbad++;
+            } else {
+                err += ba_objective(est, e2, sigma_sq, inv_sigma_sq);
+                full = true;
+            }
+        }
+        K7_STAMP(3)
+        if (full) {
+            ex *= w;   // meas.v2Epsilon = dWeight * meas.v2Epsilon  (:272)
+            ey *= w;
+            double D[4];
+            ba_derivs(cam, pr, D);
+            const double sw = cu.sn * w;   // fold sqrt-weight and dSqrtInvNoise into the derivatives (:285, :302)
+            const double D0 = sw * D[0], D1 = sw * D[1], D2 = sw * D[2], D3 = sw * D[3];
+            const double X = pr.X, Y = pr.Y, Z = pr.Z;
+            const double iz = rcp_nr(Z);
+            __builtin_amdgcn_sched_barrier(0);   // phase fences keep live ranges short (128-VGPR budget)
+            double B0[3], B1[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {   // B: motion = k-th column of R_cw (:306-313)
+                const double g0 = T[k], g1 = T[3 + k], g2 = T[6 + k];
+                const double mx = (g0 - X * g2 * iz) * iz, my = (g1 - Y * g2 * iz) * iz;
+                B0[k] = D0 * mx + D1 * my;
+                B1[k] = D2 * mx + D3 * my;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (fidx >= 0) {
+                // A: SE3 generator fields (:291-303): e_k for k<3 ; (0,-Z,Y) (Z,0,-X) (-Y,X,0)
+                const double zx = -X * iz * iz, zy = -Y * iz * iz;   // d(x)/dZ, d(y)/dZ
+                double A0[6], A1[6];
+                {
+                    const double mxs[6] = {iz, 0, zx, zx * Y, iz * Z - zx * X, -iz * Y};
+                    const double mys[6] = {0, iz, zy, -iz * Z + zy * Y, -zy * X, iz * X};
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        A0[k] = D0 * mxs[k] + D1 * mys[k];
+                        A1[k] = D2 * mxs[k] + D3 * mys[k];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                K7_STAMP(4)
+                double* Uc = Ul + fidx * 27;
+                int k = 0;
+#pragma unroll
+                for (int a = 0; a < 6; a++)
+#pragma unroll
+                    for (int b = 0; b <= a; b++) atomicAdd(&Uc[k++], A0[a] * A0[b] + A1[a] * A1[b]);   // U_LL :21-26
+#pragma unroll
+                for (int a = 0; a < 6; a++) atomicAdd(&Uc[21 + a], A0[a] * ex + A1[a] * ey);       // epsA :321
+                __builtin_amdgcn_sched_barrier(0);
+                K7_STAMP(5)
+#pragma unroll
+                for (int q = 0; q < 9; q++) {   // W = A^T B (:331), 9 coalesced double2 planes
+                    const int i0 = 2 * q, i1 = 2 * q + 1;
+                    d.W[(size_t)q * d.M + m] = make_double2(A0[i0 / 3] * B0[i0 % 3] + A1[i0 / 3] * B1[i0 % 3],
+                                                            A0[i1 / 3] * B0[i1 % 3] + A1[i1 / 3] * B1[i1 % 3]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             v[0] = B0[0] * B0[0] + B1[0] * B1[0];   // V_LL 00,10,11,20,21,22  (:325)
             v[1] = B0[1] * B0[0] + B1[1] * B1[0];
             v[2] = B0[1] * B0[1] + B1[1] * B1[1];
@@ -505,29 +709,71 @@ __global__ void __launch_bounds__(BA_CHUNK) jac_accum_wave_kernel(DevCam cam, Ba
             v[7] = B0[1] * ex + B1[1] * ey;
             v[8] = B0[2] * ex + B1[2] * ey;
         }
+        if (active && !(full && fidx >= 0)) {
+            const double2 z2 = make_double2(0, 0);
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int po = __shfl_up(pid, o, 64);
-            const bool take = lane >= o && po == pid;
-#pragma unroll
-            for (int i = 0; i < 9; i++) {
-                const double t = __shfl_up(v[i], o, 64);
-                if (take) v[i] += t;
-            }
+            for (int q = 0; q < 9; q++) d.W[(size_t)q * d.M + m] = z2;
         }
+        // segmented inclusive scan keyed by the point id: 4 in-row steps (DPP row_shr 1,2,4,8), then
+        // the row carries (row_bcast15 into rows 1,3; row_bcast31 into rows 2,3).  Segments are
+        // contiguous, so "the source lane has my point id" implies every lane in between has it too.
+        K7_STAMP(6)
+        const int SENT = (int)0x80000000;
+#define SEG_STEP(GETP, GETV)                                             \
+    {                                                                    \
+        const int po = GETP;                                             \
+        double t[9];                                                     \
+        _Pragma("unroll") for (int i = 0; i < 9; i++) t[i] = GETV;       \
+        if (po == pid) {                                                 \
+            _Pragma("unroll") for (int i = 0; i < 9; i++) v[i] += t[i];  \
+        }                                                                \
+    }
+        SEG_STEP(dpp_row_shr_i32<1>(SENT, pid), dpp_row_shr_f64<1>(v[i]))
+        SEG_STEP(dpp_row_shr_i32<2>(SENT, pid), dpp_row_shr_f64<2>(v[i]))
+        SEG_STEP(dpp_row_shr_i32<4>(SENT, pid), dpp_row_shr_f64<4>(v[i]))
+        SEG_STEP(dpp_row_shr_i32<8>(SENT, pid), dpp_row_shr_f64<8>(v[i]))
+        SEG_STEP((dpp_bcast_i32<0x142, 0xa>(SENT, pid)), (dpp_bcast_f64<0x142, 0xa>(v[i])))
+        SEG_STEP((dpp_bcast_i32<0x143, 0xc>(SENT, pid)), (dpp_bcast_f64<0x143, 0xc>(v[i])))
+#undef SEG_STEP
+        K7_STAMP(7)
         const int pn = __shfl_down(pid, 1, 64);
         if (active && (lane == 63 || pn != pid)) {
             double* Vp = d.V + (size_t)pid * 6;
-#pragma unroll
-            for (int i = 0; i < 6; i++) Vp[i] = v[i];
             double* Ep = d.epsB + (size_t)pid * 3;
-            Ep[0] = v[6];
-            Ep[1] = v[7];
-            Ep[2] = v[8];
+            const bool whole = pid != cu.p_prev && pid != cu.p_next;
+            if (whole) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) Vp[i] = v[i];
+                Ep[0] = v[6];
+                Ep[1] = v[7];
+                Ep[2] = v[8];
+            } else {   // the point is cut by a chunk boundary: two pieces meet in the zeroed slot
+#pragma unroll
+                for (int i = 0; i < 6; i++) atomicAdd(&Vp[i], v[i]);
+                atomicAdd(&Ep[0], v[6]);
+                atomicAdd(&Ep[1], v[7]);
+                atomicAdd(&Ep[2], v[8]);
+            }
         }
     }
+    K7_STAMP(8)
     __syncthreads();
     jac_flush(d, Ul, err, nbad);
+    K7_STAMP(9)
+}
+
+// zero V / epsB of the points that are cut by a 64-measurement chunk boundary (targets of the atomics)
+__global__ void __launch_bounds__(256) zero_cut_points_kernel(BaDev d) {
+    const int ci = blockIdx.x * 256 + threadIdx.x + 1;   // boundary before chunk ci
+    const int m0 = ci << 6;
+    if (m0 >= d.M) return;
+    const int p = d.m_pt[m0];
+    if (d.rowptr[p] < m0) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) d.V[(size_t)p * 6 + i] = 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) d.epsB[(size_t)p * 3 + i] = 0;
+    }
 }
 
 // K7, block variant (points with up to BA_CHUNK measurements): a workgroup owns whole points.
@@ -542,13 +788,14 @@ __global__ void __launch_bounds__(BA_CHUNK) jac_accum_kernel(DevCam cam, BaDev d
     const double* __restrict__ pose = d.pose[cur];
     const double* __restrict__ pt = d.pt[cur];
     const double sigma_sq = d.sc->sigma_sq;
+    const double inv_sigma_sq = 1.0 / sigma_sq;
     double err = 0;
     int nbad = 0;
     for (int ci = blockIdx.x; ci < d.n_chunks; ci += gridDim.x) {
         const BaChunk ch = d.chunks[ci];
         const int m = ch.m_begin + tid;
         double B0[3] = {0, 0, 0}, B1[3] = {0, 0, 0}, ex = 0, ey = 0;
-        if (m < ch.m_end) jac_measure(cam, d, pose, pt, sigma_sq, est, m, Ul, err, nbad, B0, B1, ex, ey);
+        if (m < ch.m_end) jac_measure(cam, d, pose, pt, sigma_sq, inv_sigma_sq, est, m, Ul, err, nbad, B0, B1, ex, ey);
         double* bs = Bs + tid * 8;
         bs[0] = B0[0];
         bs[1] = B0[1];
@@ -1009,14 +1256,15 @@ __global__ void __launch_bounds__(BA_CHUNK) point_update_kernel(DevCam cam, BaDe
     if (active && st != MS_DEAD) {   // FindNewError over every listed measurement (:188-207)
         const double* T = d.pose[cur ^ 1] + 12 * c;
         const double* X = Np[p - ch.pt_begin];
-        double cx, cy, cz, x, y, u, v, r, f;
-        if (!ba_project(cam, T, X, cx, cy, cz, x, y, u, v, r, f))
+        BaProj pr;
+        if (!ba_project(cam, T, X, pr))
             err = 1.0;
         else {
             const double2 fo = d.m_found[m];
             const double s = d.m_s[m];
-            const double ex = s * (fo.x - u), ey = s * (fo.y - v);
-            err = est_objective(est, ex * ex + ey * ey, d.sc->sigma_sq);
+            const double ex = s * (fo.x - pr.u), ey = s * (fo.y - pr.v);
+            const double s2 = d.sc->sigma_sq;
+            err = ba_objective(est, ex * ex + ey * ey, s2, 1.0 / s2);
         }
     }
     err = wave_sum_f64(err);
@@ -1126,6 +1374,7 @@ struct ptam_ba {
     int cur = 0;
     size_t smem_acc = 0;
     bool use_wave = false;
+    int per_wave = 1;
     std::vector<int> sorted_orig;   // sorted position -> insertion index
     // gather buffers (sharded mode)
     double* d_gather = nullptr;
@@ -1309,8 +1558,8 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.n_schur_wg = (int)s_wgs.size();
     d.n_schur_entries = (int)s_entries.size();
     // persistent grid of the accumulate kernel: bounded by LDS residency, 2 x 256 CUs by default
-    ba->smem_acc = ((((size_t)F * 27 + 1) & ~(size_t)1) + (ba->use_wave ? 0 : (size_t)BA_CHUNK * 8)) * sizeof(double);
-    const void* k7 = ba->use_wave ? (const void*)jac_accum_wave_kernel : (const void*)jac_accum_kernel;
+    ba->smem_acc = ((((size_t)F * 27 + 1) & ~(size_t)1) + (ba->use_wave ? (size_t)C * 12 : (size_t)BA_CHUNK * 8)) * sizeof(double);
+    const void* k7 = ba->use_wave ? (const void*)jac_accum_wave_kernel<1, true> : (const void*)jac_accum_kernel;
     if (ba->smem_acc > 160 * 1024) {
         ptam_set_error("%d free cameras exceed the LDS budget of the accumulate kernel", F);
         return PTAM_E_LIMIT;
@@ -1325,7 +1574,13 @@ static int ba_prepare_impl(ptam_ba* ba) {
         n_cu = prop.multiProcessorCount;
     }
     per_cu = std::max(1, std::min(per_cu, 8));
-    d.grid_acc = std::max(1, std::min(ba->use_wave ? (d.n_wchunks + 3) / 4 : d.n_chunks, n_cu * per_cu));
+    if (ba->use_wave) {
+        // every wave gets the same number of consecutive 64-measurement chunks
+        const int n64 = (M + 63) / 64, slots = n_cu * per_cu * (BA_CHUNK / 64);
+        ba->per_wave = std::max(1, (n64 + slots - 1) / slots);
+        d.grid_acc = std::max(1, (n64 + ba->per_wave * (BA_CHUNK / 64) - 1) / (ba->per_wave * (BA_CHUNK / 64)));
+    } else
+        d.grid_acc = std::max(1, std::min(d.n_chunks, n_cu * per_cu));
 
     // ---- carve one device allocation ------------------------------------------------------------
     Carver cv;
@@ -1348,7 +1603,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     const size_t npad = std::max(d.npad, SOLVE_NB);
     const size_t o_SE = cv.take((npad * npad + npad) * 8), o_L = cv.take(npad * npad * 8), o_Dg = cv.take(npad * 8),
                  o_y = cv.take(npad * 8), o_da = cv.take(npad * 8);
-    const size_t o_out = cv.take(Mz * 4), o_sc = cv.take(sizeof(BaScalars));
+    const size_t o_out = cv.take(Mz * 4), o_sc = cv.take(sizeof(BaScalars)), o_dbg = cv.take(256);
     ba->block_bytes = cv.off;
     HIP_TRY(hipMalloc(&ba->block, ba->block_bytes));
     HIP_TRY(hipMemsetAsync(ba->block, 0, ba->block_bytes, ctx->stream));
@@ -1390,6 +1645,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.da = (double*)(base + o_da);
     d.outliers = (int*)(base + o_out);
     d.sc = (BaScalars*)(base + o_sc);
+    d.dbg = (long long*)(base + o_dbg);
 
     // ---- upload -------------------------------------------------------------------------------------
     std::vector<int> h_cam(Mz), h_pt(Mz), h_orig(Mz), h_fidx(Mz);
@@ -1529,9 +1785,10 @@ static int ba_pass1_sigma(ptam_ba* ba) {
 
 static void launch_k7(ptam_ba* ba) {
     ptam_ctx* ctx = ba->ctx;
-    if (ba->use_wave)
-        hipLaunchKernelGGL(jac_accum_wave_kernel, dim3(ba->d.grid_acc), dim3(BA_CHUNK), ba->smem_acc, ctx->stream, ctx->cam,
-                           ba->d, ba->cur, ba->opts.estimator);
+    if (ba->use_wave) {
+        hipLaunchKernelGGL((jac_accum_wave_kernel<1, true>), dim3(ba->d.grid_acc), dim3(BA_CHUNK), ba->smem_acc, ctx->stream,
+                           ctx->cam, ba->d, ba->cur, ba->opts.estimator, ba->per_wave);
+    }
     else
         hipLaunchKernelGGL(jac_accum_kernel, dim3(ba->d.grid_acc), dim3(BA_CHUNK), ba->smem_acc, ctx->stream, ctx->cam, ba->d,
                            ba->cur, ba->opts.estimator);
@@ -1902,7 +2159,8 @@ int ptam_ba_bench_jacobian(ptam_ba* ba, int reps, double* avg_ms, double* algori
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     for (int i = 0; i < 3; i++)
-        launch_k7(ba);
+        launch_k7(ba);   // (the V / epsB of boundary-cut points keep accumulating across these benchmark
+                         //  repetitions; their values are not used: Compute() re-runs pass 1, which clears them)
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     double total = 0;
     for (int i = 0; i < reps; i++) {
@@ -1917,6 +2175,15 @@ int ptam_ba_bench_jacobian(ptam_ba* ba, int reps, double* avg_ms, double* algori
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     ba->prof = prof;
+#ifdef K7_TIMING
+    {
+        long long h[16];
+        HIP_TRY(hipMemcpy(h, d.dbg, sizeof h, hipMemcpyDeviceToHost));
+        std::printf("K7 stamps (cycles since kernel-body start):");
+        for (int i = 1; i < 10; i++) std::printf(" [%d] %lld", i, h[i] - h[0]);
+        std::printf("\n");
+    }
+#endif
     if (avg_ms) *avg_ms = total / reps;
     if (algorithmic_bytes)   // 8 idx + 24 found/s + 1 state + 144 W per measurement,
                              // 96 B/camera pose read, 24 read + 72 write per point, 216 B/free camera

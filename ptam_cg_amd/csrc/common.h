@@ -186,6 +186,38 @@ PTAM_HD double est_sigma_sq_from_median(int est, double median_sq, unsigned long
 
 // ---- wave64 / block helpers (device only) -----------------------------------------------------
 #ifdef __HIPCC__
+// reciprocal: v_rcp_f64 + two Newton steps (<= 1 ulp), ~5 instructions instead of an IEEE division
+__device__ __forceinline__ double rcp_nr(double d) {
+    double x = __builtin_amdgcn_rcp(d);
+    x = fma(fma(-d, x, 1.0), x, x);
+    x = fma(fma(-d, x, 1.0), x, x);
+    return x;
+}
+// DPP row shift right by SHR lanes inside each 16-lane row; lanes without a source keep `old`
+template <int SHR>
+__device__ __forceinline__ int dpp_row_shr_i32(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, 0x110 + SHR, 0xf, 0xf, false);
+}
+template <int SHR>
+__device__ __forceinline__ double dpp_row_shr_f64(double src) {
+    const long long b = __double_as_longlong(src);
+    const int lo = dpp_row_shr_i32<SHR>(0, (int)(b & 0xffffffffll));
+    const int hi = dpp_row_shr_i32<SHR>(0, (int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// DPP row_bcast15 (ctrl 0x142): lane 15 of row r -> every lane of row r+1 ; row_bcast31 (0x143):
+// lane 31 -> every lane of rows 2,3.  row_mask selects the destination rows; others keep `old`.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_bcast_i32(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROWMASK, 0xf, false);
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_bcast_f64(double src) {
+    const long long b = __double_as_longlong(src);
+    const int lo = dpp_bcast_i32<CTRL, ROWMASK>(0, (int)(b & 0xffffffffll));
+    const int hi = dpp_bcast_i32<CTRL, ROWMASK>(0, (int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ int wave_sum_i32(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
