@@ -337,6 +337,296 @@ __global__ void __launch_bounds__(GN_THREADS) pose_gn_kernel(DevCam cam, int n, 
     if (tid < 12) pose_io[tid] = sh.pose[tid];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast path, n <= 1024: ONE measurement per thread, all per-measurement state in registers, the e^2
+// keys of the order statistic in LDS, wave sums by DPP (no LDS round trips), same arithmetic and
+// the same fixed reduction order as the general kernel above.
+// ------------------------------------------------------------------------------------------------
+#define GS_THREADS 256
+#define GS_WAVES (GS_THREADS / 64)
+#define GS_MPT 4   // measurements per thread: n <= 1024
+
+struct GnSmallShared {
+    double pose[12];
+    double mu[6];
+    double red[GS_WAVES][27];
+    double keys[GS_THREADS * GS_MPT];
+    unsigned hist[256];
+    int sel_digit, sel_k;
+    int wcount[GS_WAVES];
+};
+
+// wave sum by DPP: row shifts 1,2,4,8 then row broadcasts; the total lands in lane 63
+__device__ __forceinline__ double wave_sum_f64_dpp(double v) {
+    v += dpp_row_shr_f64<1>(v);
+    v += dpp_row_shr_f64<2>(v);
+    v += dpp_row_shr_f64<4>(v);
+    v += dpp_row_shr_f64<8>(v);
+    v += dpp_bcast_f64<0x142, 0xa>(v);
+    v += dpp_bcast_f64<0x143, 0xc>(v);
+    return v;
+}
+
+// exact k-th smallest of sh.keys[0..n) (non-found entries hold +inf): MSB radix select, 8-bit digits
+__device__ double small_select_kth(GnSmallShared& sh, int n, int k) {
+    unsigned long long prefix = 0;
+    const int tid = threadIdx.x;
+    unsigned long long key[GS_MPT];
+#pragma unroll
+    for (int q = 0; q < GS_MPT; q++) {
+        const int i = tid + q * GS_THREADS;
+        key[q] = i < n ? (unsigned long long)__double_as_longlong(sh.keys[i]) : ~0ull;
+    }
+    for (int pass = 0; pass < 8; pass++) {
+        const int shift = 56 - 8 * pass;
+        sh.hist[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < GS_MPT; q++)
+            if (tid + q * GS_THREADS < n && (pass == 0 || (key[q] >> (shift + 8)) == (prefix >> (shift + 8))))
+                atomicAdd(&sh.hist[(key[q] >> shift) & 255], 1u);
+        __syncthreads();
+        if (tid < 64) {
+            const unsigned c0 = sh.hist[4 * tid], c1 = sh.hist[4 * tid + 1], c2 = sh.hist[4 * tid + 2],
+                           c3 = sh.hist[4 * tid + 3];
+            const int s = (int)(c0 + c1 + c2 + c3);
+            int incl = s;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o, 64);
+                if (tid >= o) incl += v;
+            }
+            const int excl = incl - s;
+            if (excl <= k && k < incl) {
+                int kk = k - excl, dg = 4 * tid;
+                if (kk >= (int)c0) {
+                    kk -= c0;
+                    dg++;
+                    if (kk >= (int)c1) {
+                        kk -= c1;
+                        dg++;
+                        if (kk >= (int)c2) {
+                            kk -= c2;
+                            dg++;
+                        }
+                    }
+                }
+                sh.sel_digit = dg;
+                sh.sel_k = kk;
+            }
+        }
+        __syncthreads();
+        prefix |= (unsigned long long)sh.sel_digit << shift;
+        k = sh.sel_k;
+    }
+    return __longlong_as_double((long long)prefix);
+}
+
+// CalcJacobian (include/Tracker.h:125-136) from the cached camera-frame point and derivatives.  The
+// fast path does not store J: v3Cam / m2CamDerivs only change on non-linear iterations, so
+// re-deriving J from them in the linear iterations gives the very values the reference keeps.
+__device__ __forceinline__ void small_jacobian(const double cam3[3], const double D[4], double J[12]) {
+    const double X = cam3[0], Y = cam3[1], Z = cam3[2];
+    const double iz = 1.0 / Z;
+    const double gx[6] = {1, 0, 0, 0, Z, -Y};
+    const double gy[6] = {0, 1, 0, -Z, 0, X};
+    const double gz[6] = {0, 0, 1, Y, -X, 0};
+#pragma unroll
+    for (int m = 0; m < 6; m++) {
+        const double mx = (gx[m] - X * gz[m] * iz) * iz;
+        const double my = (gy[m] - Y * gz[m] * iz) * iz;
+        J[m] = D[0] * mx + D[1] * my;
+        J[6 + m] = D[2] * mx + D[3] * my;
+    }
+}
+
+struct SmallMeas {
+    double world[3], fnd[2], sn;
+    double cam3[3], img[2], D[4];
+    int found;
+};
+
+// TrackerData::Project with the pose in LDS; updates the cached state exactly like td_project
+__device__ __forceinline__ void small_project(const DevCam& cam, const double* pose, SmallMeas& t, bool& in_image) {
+    in_image = false;
+    se3_apply(pose, t.world[0], t.world[1], t.world[2], t.cam3[0], t.cam3[1], t.cam3[2]);
+    if (t.cam3[2] < 0.001) return;
+    const double x = t.cam3[0] / t.cam3[2], y = t.cam3[1] / t.cam3[2];
+    if (x * x + y * y > cam.largest_radius * cam.largest_radius) return;
+    double u, v, r, f;
+    cam_project(cam, x, y, u, v, r, f);
+    t.img[0] = u;
+    t.img[1] = v;
+    cam_derivs(cam, x, y, r, f, t.D);
+    if (r > cam.max_r) return;
+    if (u < 0 || v < 0 || u > cam.width || v > cam.height) return;
+    in_image = true;
+}
+
+// Fast path, n <= 1024: 256 threads x 4 measurements held in registers (one wave per SIMD, the four
+// independent measurements of a thread give the fp64 pipeline its ILP), e^2 keys of the order
+// statistic in LDS, wave sums by DPP, same arithmetic and reduction order as the general kernel.
+__global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, int n, const ptam_pose_meas* __restrict__ meas,
+                                                                   const ptam_projection* __restrict__ entry,
+                                                                   double* __restrict__ pose_io, ptam_gn_opts opts,
+                                                                   int* __restrict__ flags, double* __restrict__ updates) {
+    __shared__ GnSmallShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid < 12) sh.pose[tid] = pose_io[tid];
+    if (tid < 6) sh.mu[tid] = 0;
+    SmallMeas t[GS_MPT];
+#pragma unroll
+    for (int q = 0; q < GS_MPT; q++) {
+        const int i = tid + q * GS_THREADS;
+        t[q].found = 0;
+        t[q].cam3[0] = t[q].cam3[1] = 0;
+        t[q].cam3[2] = 1;
+        t[q].img[0] = t[q].img[1] = 0;
+        t[q].D[0] = t[q].D[1] = t[q].D[2] = t[q].D[3] = 0;
+        t[q].world[0] = t[q].world[1] = t[q].world[2] = t[q].fnd[0] = t[q].fnd[1] = t[q].sn = 0;
+        if (i < n) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) t[q].world[k] = meas[i].world[k];
+            t[q].fnd[0] = meas[i].found[0];
+            t[q].fnd[1] = meas[i].found[1];
+            t[q].sn = meas[i].sqrt_inv_noise;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < GS_MPT; q++) {
+        const int i = tid + q * GS_THREADS;
+        if (i < n) {
+            t[q].found = 1;
+            if (entry) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) t[q].cam3[k] = entry[i].cam[k];
+                t[q].img[0] = entry[i].image[0];
+                t[q].img[1] = entry[i].image[1];
+#pragma unroll
+                for (int k = 0; k < 4; k++) t[q].D[k] = entry[i].derivs[k];
+            } else {
+                bool in_image;
+                small_project(cam, sh.pose, t[q], in_image);
+                if (!in_image) t[q].found = 0;   // not in the potentially-visible set (src/Tracker.cc:456-458)
+            }
+            if (flags) flags[i] = 0;
+        }
+    }
+    for (int iter = 0; iter < opts.iterations; iter++) {
+        const bool nonlinear = (opts.nonlinear_mask >> iter) & 1u;
+        const double ov = iter > opts.override_after ? opts.override_sigma_sq : 0.0;
+        double ex[GS_MPT], ey[GS_MPT], e2[GS_MPT];
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < GS_MPT; q++) {
+            ex[q] = ey[q] = e2[q] = 0;
+            if (t[q].found) {
+                if (iter != 0 && nonlinear) {
+                    bool in_image;
+                    small_project(cam, sh.pose, t[q], in_image);
+                } else if (iter != 0) {   // LinearUpdate include/Tracker.h:139-142
+                    double J[12];
+                    small_jacobian(t[q].cam3, t[q].D, J);
+                    double a = 0, b = 0;
+#pragma unroll
+                    for (int m = 0; m < 6; m++) {
+                        a += J[m] * sh.mu[m];
+                        b += J[6 + m] * sh.mu[m];
+                    }
+                    t[q].img[0] += a;
+                    t[q].img[1] += b;
+                }
+                // CalcPoseUpdate :946-954
+                ex[q] = t[q].sn * (t[q].fnd[0] - t[q].img[0]);
+                ey[q] = t[q].sn * (t[q].fnd[1] - t[q].img[1]);
+                e2[q] = ex[q] * ex[q] + ey[q] * ey[q];
+                cnt++;
+            }
+            if (!(ov > 0)) sh.keys[tid + q * GS_THREADS] = t[q].found ? e2[q] : __longlong_as_double(0x7ff0000000000000ll);
+        }
+        cnt = wave_sum_i32(cnt);
+        if (lane == 0) sh.wcount[wid] = cnt;
+        __syncthreads();   // also: every thread is done reading sh.mu (linear update) and sh.pose
+        int nf = 0;
+#pragma unroll
+        for (int i = 0; i < GS_WAVES; i++) nf += sh.wcount[i];
+        if (nf > 0) {
+            double sigma_sq;
+            if (ov > 0)
+                sigma_sq = ov;
+            else {
+                const double med = small_select_kth(sh, n, nf / 2);
+                sigma_sq = est_sigma_sq_from_median(opts.estimator, med, (unsigned long long)nf);
+            }
+            // WLS<6> :973-1002: C += (w J_r)(J_r)^T, b += e_r (w J_r), J_r scaled by dSqrtInvNoise
+            double acc[27];
+#pragma unroll
+            for (int k = 0; k < 27; k++) acc[k] = 0;
+#pragma unroll
+            for (int q = 0; q < GS_MPT; q++) {
+                if (!t[q].found) continue;
+                const double wgt = est_weight(opts.estimator, e2[q], sigma_sq);
+                if (wgt == 0.0) {
+                    if (iter == opts.mark_outliers_iter && flags) flags[tid + q * GS_THREADS] = 1;
+                    continue;
+                }
+                double Jm[12];
+                small_jacobian(t[q].cam3, t[q].D, Jm);
+                const double er[2] = {ex[q], ey[q]};
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    double J[6], Jw[6];
+#pragma unroll
+                    for (int m = 0; m < 6; m++) {
+                        J[m] = t[q].sn * Jm[r * 6 + m];
+                        Jw[m] = J[m] * wgt;
+                    }
+                    int k = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; a++)
+#pragma unroll
+                        for (int b = 0; b <= a; b++) acc[k++] += Jw[a] * J[b];
+#pragma unroll
+                    for (int a = 0; a < 6; a++) acc[21 + a] += er[r] * Jw[a];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 27; k++) {
+                const double v = wave_sum_f64_dpp(acc[k]);
+                if (lane == 63) sh.red[wid][k] = v;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double x[6] = {0, 0, 0, 0, 0, 0};
+            if (nf > 0) {
+                double C[36], b[6];
+                int k = 0;
+                for (int a = 0; a < 6; a++)
+                    for (int c = 0; c <= a; c++) {
+                        const double s4 = ((sh.red[0][k] + sh.red[1][k]) + sh.red[2][k]) + sh.red[3][k];
+                        C[a * 6 + c] = C[c * 6 + a] = s4;
+                        k++;
+                    }
+                for (int a = 0; a < 6; a++) {
+                    C[a * 6 + a] += opts.prior;   // add_prior :974
+                    b[a] = ((sh.red[0][21 + a] + sh.red[1][21 + a]) + sh.red[2][21 + a]) + sh.red[3][21 + a];
+                }
+                ldlt6_solve(C, b, x);
+            }
+            double np[12];
+            se3_exp_mul(x, sh.pose, np);   // mse3CamFromWorld = SE3<>::exp(v6Update) * mse3CamFromWorld
+            for (int k = 0; k < 12; k++) sh.pose[k] = np[k];
+            for (int k = 0; k < 6; k++) sh.mu[k] = x[k];
+            if (updates)
+                for (int k = 0; k < 6; k++) updates[6 * iter + k] = x[k];
+        }
+        __syncthreads();
+    }
+    if (tid < 12) pose_io[tid] = sh.pose[tid];
+}
+
 __global__ void __launch_bounds__(GN_THREADS) calc_pose_update_kernel(int n, const ptam_pose_update_meas* __restrict__ meas,
                                                                       double override_sigma, int est, double prior,
                                                                       PoseState* __restrict__ st, int* __restrict__ flags,
@@ -413,8 +703,12 @@ int ptam_pose_gn(ptam_ctx* ctx, int n, const ptam_pose_meas* meas, const ptam_pr
     HIP_TRY(hipMemcpyAsync(d_m, meas, bm, hipMemcpyHostToDevice, ctx->stream));
     if (entry) HIP_TRY(hipMemcpyAsync(d_e, entry, be, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(d_pose, pose_inout, 96, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(pose_gn_kernel, dim3(1), dim3(GN_THREADS), 0, ctx->stream, ctx->cam, n, d_m, d_e, d_pose, o, d_s,
-                       d_f, d_u);
+    if (n <= GS_THREADS * GS_MPT)
+        hipLaunchKernelGGL(pose_gn_small_kernel, dim3(1), dim3(GS_THREADS), 0, ctx->stream, ctx->cam, n, d_m, d_e, d_pose,
+                           o, d_f, d_u);
+    else
+        hipLaunchKernelGGL(pose_gn_kernel, dim3(1), dim3(GN_THREADS), 0, ctx->stream, ctx->cam, n, d_m, d_e, d_pose, o,
+                           d_s, d_f, d_u);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(pose_inout, d_pose, 96, hipMemcpyDeviceToHost, ctx->stream));
     if (outlier_flags) HIP_TRY(hipMemcpyAsync(outlier_flags, d_f, bf, hipMemcpyDeviceToHost, ctx->stream));
