@@ -46,24 +46,6 @@ def parse():
     return ap.parse_args()
 
 
-def shard_problem(prob, rank, world):
-    """points p with p % world == rank (and every measurement of those points); all cameras."""
-    if world == 1:
-        return prob
-    keep_pt = np.flatnonzero(np.arange(len(prob["points"])) % world == rank)
-    remap = -np.ones(len(prob["points"]), dtype=np.int64)
-    remap[keep_pt] = np.arange(len(keep_pt))
-    km = remap[prob["pt_idx"]] >= 0
-    out = dict(prob)
-    out["points"] = prob["points"][keep_pt]
-    out["points_true"] = prob["points_true"][keep_pt]
-    out["cam_idx"] = prob["cam_idx"][km]
-    out["pt_idx"] = remap[prob["pt_idx"][km]].astype(np.int32)
-    out["found"] = prob["found"][km]
-    out["sigma_sq"] = prob["sigma_sq"][km]
-    return out
-
-
 def tracking_bench(hip, host, synth, frames=200):
     """tracked frames/s: K1+K2 (keyframe) + K3 (1000 patches) + K4 (pose GN, 10 iterations)."""
     C = ctypes
@@ -129,6 +111,7 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     from ptam_cg_amd import _abi, host, synth
+    from ptam_cg_amd.sharding import shard_problem
     from ptam_cg_amd._lib import load
     hip = load()
     device = local_rank if world > 1 else 0

@@ -1,0 +1,428 @@
+"""np_oracle.py — second, independent restatement of the hot path in numpy (vectorised, dense linear
+algebra), used ONLY in this container to (a) cross-check oracle/ptam_oracle.cc and (b) generate the
+golden fixtures under tests/golden/ (tests/golden/make_golden.py).  TEST INFRASTRUCTURE; PARITY
+UNPINNED against the reference binary for the reasons given in ptam_oracle.cc's header.
+
+It deliberately shares no code or structure with the C++ oracle: FAST is evaluated as whole-image
+boolean algebra, ZMSSD from its definition with exact integer arithmetic, the bundle adjuster builds
+the normal equations from dense per-measurement Jacobian arrays and solves with numpy.linalg, the
+order statistic comes from np.sort.  Reference lines each piece follows are cited per function."""
+import numpy as np
+
+LEVELS = 4
+MAX_SSD = 8 * 8 * 500
+FAST_THRESH = (10, 15, 15, 10)                    # src/KeyFrame.cc:35-42
+RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1),
+        (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+# ---- KeyFrame::MakeKeyFrame_Lite (src/KeyFrame.cc:18-54) ---------------------------------------
+def half_sample(im, variant="R"):
+    """CVD::halfSample: T = (a+b+c+d)/4 ; R = SSE2 pavgb (vertical) then pavgw (horizontal)."""
+    h, w = im.shape[0] // 2, im.shape[1] // 2
+    a = im[0:2 * h:2, 0:2 * w:2].astype(np.int32)
+    b = im[0:2 * h:2, 1:2 * w:2].astype(np.int32)
+    c = im[1:2 * h:2, 0:2 * w:2].astype(np.int32)
+    d = im[1:2 * h:2, 1:2 * w:2].astype(np.int32)
+    if variant == "T":
+        return ((a + b + c + d) // 4).astype(np.uint8)
+    v1, v2 = (a + c + 1) >> 1, (b + d + 1) >> 1
+    return ((v1 + v2 + 1) >> 1).astype(np.uint8)
+
+
+def fast10(im, thr):
+    """fast_corner_detect_10: >= 10 contiguous ring pixels all > p+b or all < p-b; raster order."""
+    h, w = im.shape
+    if h < 7 or w < 7:
+        return np.zeros((0, 2), np.int32)
+    p = im[3:h - 3, 3:w - 3].astype(np.int32)
+    ring = np.stack([im[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx].astype(np.int32) for dx, dy in RING])
+    out = np.zeros(p.shape, bool)
+    for flags in (ring > p + thr, ring < p - thr):
+        ext = np.concatenate([flags, flags[:9]])          # circular runs
+        run = np.ones((16,) + p.shape, bool)
+        for k in range(10):
+            run &= ext[k:k + 16]
+        out |= run.any(axis=0)
+    ys, xs = np.nonzero(out)                               # row-major == raster order
+    return np.column_stack([xs + 3, ys + 3]).astype(np.int32)
+
+
+def row_lut(corners, h):
+    """LUT[y] = index of the first corner with row >= y (src/KeyFrame.cc:46-52)."""
+    return np.searchsorted(corners[:, 1], np.arange(h), side="left").astype(np.int32)
+
+
+def make_keyframe_lite(im, variant="R"):
+    levels = []
+    cur = np.ascontiguousarray(im, np.uint8)
+    for l in range(LEVELS):
+        if l:
+            cur = half_sample(cur, variant)
+        c = fast10(cur, FAST_THRESH[l])
+        levels.append({"im": cur, "corners": c, "rowlut": row_lut(c, cur.shape[0])})
+    return levels
+
+
+# ---- ZMSSD + FindPatchCoarse (src/ImageProcess.cc:130-163, src/PatchFinder.cc:160-211) -----------
+def trunc_div(a, b):
+    """C integer division (toward zero)."""
+    q = abs(a) // abs(b)
+    return q if (a >= 0) == (b > 0) else -q
+
+
+def zmssd(im, x, y, tmpl):
+    h, w = im.shape
+    if not (4 <= x < w - 4 and 4 <= y < h - 4):
+        return MAX_SSD + 1
+    I = im[y - 4:y + 4, x - 4:x + 4].astype(np.int64).ravel()
+    T = np.asarray(tmpl, np.int64).ravel()
+    SA, SB = int(T.sum()), int(I.sum())
+    return trunc_div(2 * SA * SB - SA * SA - SB * SB, 64) + int((I * I).sum()) + int((T * T).sum()) - 2 * int((I * T).sum())
+
+
+def find_patch_coarse(levels, q, tmpl):
+    x, y, level, rng = int(q["x"]), int(q["y"]), int(q["level"]), int(q["range"])
+    res = dict(found=0, best_ssd=MAX_SSD + 1, best_x=-1, best_y=-1, n_scored=0, pos=(0.0, 0.0))
+    if level < 0 or level >= LEVELS:
+        return res
+    L = levels[level]
+    h, w = L["im"].shape
+    s = 1 << level
+    px, py = trunc_div(x, s), trunc_div(y, s)
+    r = (rng + s - 1) // s
+    top, bot1 = max(py - r, 0), py + r + 1
+    if top >= h or bot1 <= 0:
+        return res
+    i0 = L["rowlut"][top]
+    i1 = len(L["corners"]) if bot1 >= h else L["rowlut"][bot1]
+    for cx, cy in L["corners"][i0:i1]:
+        if cx < px - r or cx > px + r or (px - cx) ** 2 + (py - cy) ** 2 > r * r:
+            continue
+        ssd = zmssd(L["im"], int(cx), int(cy), tmpl)
+        res["n_scored"] += 1
+        if ssd < res["best_ssd"]:
+            res.update(best_ssd=ssd, best_x=int(cx), best_y=int(cy))
+    if res["best_ssd"] < MAX_SSD:
+        res["found"] = 1
+        res["pos"] = ((res["best_x"] + 0.5) * s - 0.5, (res["best_y"] + 0.5) * s - 0.5)
+    return res
+
+
+# ---- ATANCamera (src/ATANCamera.cc:27-66, 109-121, 179-209) -------------------------------------
+class Camera:
+    def __init__(self, params, size):
+        fx, fy, cx, cy, w = params
+        self.size = np.array(size, float)
+        self.focal = self.size * [fx, fy]
+        self.centre = self.size * [cx, cy] - 0.5
+        self.w = w
+        self.k = 2 * np.tan(w / 2) if w else 0.0
+        rr = np.hypot(max(cx, 1 - cx) / fx, max(cy, 1 - cy) / fy)
+        self.largest_radius = np.tan(rr * w) / self.k if w else rr
+        self.max_r = 1.5 * self.largest_radius
+
+    def project(self, xy):
+        """-> image (N,2), r, factor"""
+        xy = np.atleast_2d(xy)
+        r = np.hypot(xy[:, 0], xy[:, 1])
+        small = (r < 0.001) | (self.w == 0)
+        f = np.ones_like(r)
+        rs = np.where(small, 1.0, r)
+        f = np.where(small, 1.0, np.arctan(rs * self.k) / (self.w * rs) if self.w else 1.0)
+        return self.centre + self.focal * (f[:, None] * xy), r, f
+
+    def derivs(self, xy, r, f):
+        """2x2 d(image)/d(z=1 plane), shape (N,2,2)"""
+        x, y = xy[:, 0], xy[:, 1]
+        k, w = self.k, self.w
+        re = r * (1.0 if w else 0.0)
+        ok = re >= 0.01
+        rs = np.where(ok, re, 1.0)
+        common = np.where(ok, ((k / w if w else 0.0) / (1 + k * k * rs * rs) - f) / (rs * rs), 0.0)
+        dfx, dfy = x * common, y * common
+        D = np.zeros((len(x), 2, 2))
+        D[:, 0, 0] = self.focal[0] * (dfx * x + f)
+        D[:, 1, 0] = self.focal[1] * (dfx * y)
+        D[:, 0, 1] = self.focal[0] * (dfy * x)
+        D[:, 1, 1] = self.focal[1] * (dfy * y + f)
+        return D
+
+
+# ---- SE3 (TooN semantics) -------------------------------------------------------------
+def hat(w):
+    return np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+
+
+def se3_exp(mu):
+    """closed-form exponential of the twist (t, w) -> pose (12,): R row-major + translation"""
+    t, w = np.asarray(mu[:3], float), np.asarray(mu[3:], float)
+    th2 = w @ w
+    th = np.sqrt(th2)
+    K = hat(w)
+    if th2 < 1e-8:
+        A, B, C = 1 - th2 / 6, 0.5, 0.0
+        trans = t + 0.5 * np.cross(w, t)
+    else:
+        if th2 < 1e-6:
+            C = (1 - th2 / 20) / 6
+            A = 1 - th2 * C
+            B = 0.5 - th2 / 24
+        else:
+            A, B = np.sin(th) / th, (1 - np.cos(th)) / th2
+            C = (1 - A) / th2
+        trans = t + B * np.cross(w, t) + C * np.cross(w, np.cross(w, t))
+    R = np.eye(3) + A * K + B * (K @ K)
+    return np.concatenate([R.ravel(), trans])
+
+
+def se3_mul(a, b):
+    Ra, Rb = a[:9].reshape(3, 3), b[:9].reshape(3, 3)
+    return np.concatenate([(Ra @ Rb).ravel(), a[9:] + Ra @ b[9:]])
+
+
+def se3_apply(T, X):
+    return X @ T[:9].reshape(3, 3).T + T[9:]
+
+
+def generators(Xc):
+    """generator_field(m, (X,Y,Z,1)) for m = 0..5 -> (N,6,3)"""
+    N = len(Xc)
+    G = np.zeros((N, 6, 3))
+    G[:, 0, 0] = G[:, 1, 1] = G[:, 2, 2] = 1
+    X, Y, Z = Xc[:, 0], Xc[:, 1], Xc[:, 2]
+    G[:, 3, 1], G[:, 3, 2] = -Z, Y
+    G[:, 4, 0], G[:, 4, 2] = Z, -X
+    G[:, 5, 0], G[:, 5, 1] = -Y, X
+    return G
+
+
+def motion_to_plane(Xc, G):
+    """d(x/z, y/z) for camera-frame motions G (N,K,3) -> (N,K,2)   (include/Tracker.h:132-133)"""
+    iz = 1.0 / Xc[:, 2]
+    mx = (G[:, :, 0] - Xc[:, None, 0] * G[:, :, 2] * iz[:, None]) * iz[:, None]
+    my = (G[:, :, 1] - Xc[:, None, 1] * G[:, :, 2] * iz[:, None]) * iz[:, None]
+    return np.stack([mx, my], axis=2)
+
+
+# ---- M-estimators (include/Tools.h:128-228) -------------------------------------------------------
+def sigma_squared(e2, est="Tukey"):
+    v = np.sort(np.asarray(e2, float))
+    n = len(v)
+    den = (2 * n - 6) % (1 << 64)                  # size_t arithmetic
+    with np.errstate(divide="ignore"):
+        s = 1.4826 * (1 + np.float64(5.0) / np.float64(den)) * np.sqrt(v[n // 2])
+    s *= 1.345 if est == "Huber" else 4.6851
+    return s * s
+
+
+def weight(e2, s2, est="Tukey"):
+    e2 = np.asarray(e2, float)
+    if est == "Tukey":
+        return np.where(e2 > s2, 0.0, (1 - e2 / s2) ** 2)
+    if est == "Cauchy":
+        return 1 / (1 + e2 / s2)
+    with np.errstate(divide="ignore"):
+        return np.where(e2 < s2, 1.0, np.sqrt(s2 / np.where(e2 == 0, 1, e2)))
+
+
+def sqrt_weight(e2, s2, est="Tukey"):
+    if est == "Tukey":
+        return np.where(e2 > s2, 0.0, 1 - e2 / s2)
+    return np.sqrt(weight(e2, s2, est))
+
+
+def objective(e2, s2, est="Tukey"):
+    e2 = np.asarray(e2, float)
+    if est == "Tukey":
+        return np.where(e2 > s2, 1.0, 1 - (1 - e2 / s2) ** 3)
+    if est == "Cauchy":
+        return np.log(1 + e2 / s2)
+    return np.where(e2 < s2, 0.5 * e2, np.sqrt(s2) * (np.sqrt(e2) - 0.5 * np.sqrt(s2)))
+
+
+# ---- Tracker pose Gauss-Newton (src/Tracker.cc:613-643, 928-1005; include/Tracker.h:70-142) ------
+def project_points(cam, pose, world):
+    """TrackerData::Project -> dict(cam, image, derivs, in_image, reached)"""
+    Xc = se3_apply(pose, world)
+    n = len(world)
+    out = dict(cam=Xc, image=np.zeros((n, 2)), derivs=np.zeros((n, 2, 2)), in_image=np.zeros(n, bool),
+               reached=np.zeros(n, bool))
+    ok = ~(Xc[:, 2] < 0.001)
+    xy = np.zeros((n, 2))
+    xy[ok] = Xc[ok, :2] / Xc[ok, 2:3]
+    ok &= ~((xy ** 2).sum(1) > cam.largest_radius ** 2)
+    im, r, f = cam.project(xy)
+    out["reached"] = ok
+    out["image"][ok] = im[ok]
+    out["derivs"][ok] = cam.derivs(xy, r, f)[ok]
+    inim = ok & ~(r > cam.max_r)
+    inim &= ~((im[:, 0] < 0) | (im[:, 1] < 0) | (im[:, 0] > cam.size[0]) | (im[:, 1] > cam.size[1]))
+    out["in_image"] = inim
+    return out
+
+
+def calc_pose_update(found, image, s, J, override=0.0, est="Tukey", prior=100.0):
+    """-> (mu, weight_zero_mask)   J: (N,2,6)"""
+    if len(found) == 0:
+        return np.zeros(6), np.zeros(0, bool)
+    e = s[:, None] * (found - image)
+    e2 = (e ** 2).sum(1)
+    s2 = override if override > 0 else sigma_squared(e2, est)
+    wgt = weight(e2, s2, est)
+    Js = s[:, None, None] * J
+    C = np.eye(6) * prior + np.einsum("n,nri,nrj->ij", wgt, Js, Js)
+    b = np.einsum("n,nr,nri->i", wgt, e, Js)
+    return np.linalg.solve(C, b), wgt == 0
+
+
+def pose_gn(cam, world, found, s, pose, iterations=10, nonlinear_mask=0x211, override_after=5, override_sigma_sq=16.0,
+            mark_outliers_iter=9, est="Tukey", prior=100.0):
+    pose = np.array(pose, float)
+    pr = project_points(cam, pose, world)
+    use = pr["in_image"].copy()
+    Xc, image, D = pr["cam"].copy(), pr["image"].copy(), pr["derivs"].copy()
+    J = np.zeros((len(world), 2, 6))
+    flags = np.zeros(len(world), np.int32)
+    updates, last = [], np.zeros(6)
+    for it in range(iterations):
+        nonlinear = (nonlinear_mask >> it) & 1
+        if it:
+            if nonlinear:
+                pr = project_points(cam, pose, world)
+                Xc = pr["cam"]
+                upd = pr["reached"]
+                image[upd], D[upd] = pr["image"][upd], pr["derivs"][upd]
+            else:
+                image = image + J @ last
+        if nonlinear:
+            with np.errstate(divide="ignore", invalid="ignore"):
+                J = np.einsum("nab,nkb->nak", D, motion_to_plane(Xc, generators(Xc)))
+        ov = override_sigma_sq if it > override_after else 0.0
+        mu, wz = calc_pose_update(found[use], image[use], s[use], J[use], ov, est, prior)
+        if it == mark_outliers_iter:
+            flags[np.flatnonzero(use)[wz]] = 1
+        pose = se3_mul(se3_exp(mu), pose)
+        last = mu
+        updates.append(mu)
+    return pose, flags, np.array(updates)
+
+
+# ---- Bundle (src/Bundle.cc) with dense linear algebra ---------------------------------------------
+def bundle_adjust(cam, prob, max_iterations=20, conv_limit=1e-6, min_sigma=0.4, est="Tukey"):
+    poses, pts = prob["poses"].copy(), prob["points"].copy()
+    fixed = prob["fixed"].astype(bool)
+    ci, pi = prob["cam_idx"].astype(int), prob["pt_idx"].astype(int)
+    found, sn = prob["found"].copy(), np.sqrt(1.0 / prob["sigma_sq"])
+    alive = np.ones(len(ci), bool)
+    free_of = -np.ones(len(poses), int)
+    free_of[~fixed] = np.arange((~fixed).sum())
+    nF, nP = int((~fixed).sum()), len(pts)
+    n = 6 * nF
+
+    def residuals(P, X):
+        Xc = np.einsum("nij,nj->ni", P[ci, :9].reshape(-1, 3, 3), X[pi]) + P[ci, 9:]
+        bad = Xc[:, 2] <= 0
+        z = np.where(bad, 1.0, Xc[:, 2])
+        xy = Xc[:, :2] / z[:, None]
+        im, r, f = cam.project(xy)
+        eps = sn[:, None] * (found - im)
+        return Xc, xy, r, f, eps, bad
+
+    lam, lam_f = 1e-4, 2.0
+    converged = hit_max = False
+    counter = accepted = 0
+    trials, outliers = [], []
+    while not converged and not hit_max:
+        Xc, xy, r, f, eps, bad1 = residuals(poses, pts)
+        bad = alive & bad1
+        ok = alive & ~bad1
+        e2 = (eps ** 2).sum(1)
+        s2 = max(sigma_squared(e2[ok], est), min_sigma ** 2)
+        w = np.where(ok, sqrt_weight(e2, s2, est), 0.0)
+        bad |= ok & (w == 0)
+        use = ok & (w != 0)
+        cur_err = bad.sum() + objective(e2[use], s2, est).sum()
+        D = cam.derivs(xy, r, f) * (w * sn)[:, None, None]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            A = np.einsum("nab,nkb->nak", D, motion_to_plane(Xc, generators(Xc)))          # (N,2,6)
+            Rcols = np.transpose(poses[ci, :9].reshape(-1, 3, 3), (0, 2, 1))                # k-th column of R
+            B = np.einsum("nab,nkb->nak", D, motion_to_plane(Xc, Rcols))                     # (N,2,3)
+        A[~use] = 0
+        B[~use] = 0
+        A[fixed[ci]] = 0
+        epsw = eps * w[:, None]
+        epsw[~use] = 0
+        U = np.zeros((nF, 6, 6))
+        eA = np.zeros((nF, 6))
+        fi = free_of[ci]
+        sel = use & (fi >= 0)
+        np.add.at(U, fi[sel], np.einsum("nri,nrj->nij", A[sel], A[sel]))
+        np.add.at(eA, fi[sel], np.einsum("nri,nr->ni", A[sel], epsw[sel]))
+        V = np.zeros((nP, 3, 3))
+        eB = np.zeros((nP, 3))
+        np.add.at(V, pi[use], np.einsum("nri,nrj->nij", B[use], B[use]))
+        np.add.at(eB, pi[use], np.einsum("nri,nr->ni", B[use], epsw[use]))
+        W = np.einsum("nri,nrj->nij", A, B)                                                  # (N,6,3)
+        new_err = cur_err + 9999
+        ran = False
+        while new_err > cur_err and not converged and not hit_max:
+            ran = True
+            Vs = V.copy()
+            Vs[:, [0, 1, 2], [0, 1, 2]] *= (1 + lam)
+            deg = (V[:, 0, 0] * V[:, 1, 1] * V[:, 2, 2]) == 0
+            Vs[deg] = np.eye(3)
+            Vinv = np.linalg.inv(Vs)
+            Vinv[deg] = 0
+            S = np.zeros((n, n))
+            E = np.zeros(n)
+            for j in range(nF):
+                Uj = U[j].copy()
+                Uj[range(6), range(6)] *= (1 + lam)
+                S[6 * j:6 * j + 6, 6 * j:6 * j + 6] = Uj
+                E[6 * j:6 * j + 6] = eA[j]
+            Y = np.einsum("nij,njk->nik", W, Vinv[pi])                                        # (N,6,3)
+            msel = np.flatnonzero(sel)
+            order = msel[np.argsort(pi[msel], kind="stable")]
+            ptr = np.searchsorted(pi[order], np.arange(nP + 1))
+            for p in range(nP):
+                ms = order[ptr[p]:ptr[p + 1]]
+                if len(ms) == 0:
+                    continue
+                Yp = Y[ms].reshape(-1, 3)                                                     # (6k,3)
+                Wp = W[ms].reshape(-1, 3)
+                rows = (6 * fi[ms][:, None] + np.arange(6)).ravel()
+                S[np.ix_(rows, rows)] -= Yp @ Wp.T
+                E[rows] -= Yp @ eB[p]
+            da = np.linalg.solve(S, E) if n else np.zeros(0)
+            t = np.zeros((nP, 3))
+            np.add.at(t, pi[sel], np.einsum("nij,ni->nj", W[sel], da.reshape(-1, 6)[fi[sel]]))
+            db = np.einsum("pij,pj->pi", Vinv, eB - t)
+            sumsq = float(da @ da + (db ** 2).sum())
+            if sumsq < conv_limit:
+                converged = True
+            new_poses = poses.copy()
+            for c in np.flatnonzero(~fixed):
+                new_poses[c] = se3_mul(se3_exp(da[6 * free_of[c]:6 * free_of[c] + 6]), poses[c])
+            new_pts = pts + db
+            _, _, _, _, eps_n, bad_n = residuals(new_poses, new_pts)
+            e2n = (eps_n ** 2).sum(1)
+            new_err = float((alive & bad_n).sum() + objective(e2n[alive & ~bad_n], s2, est).sum())
+            trials.append(dict(lam=lam, sigma_sq=s2, err_old=float(cur_err), err_new=new_err, sumsq=sumsq,
+                               n_bad=int(bad.sum()), accepted=0))
+            if new_err > cur_err:
+                lam *= lam_f
+                lam_f *= 2
+            counter += 1
+            if counter >= max_iterations:
+                hit_max = True
+        if ran and new_err < cur_err:
+            lam_f = 2.0
+            lam *= 0.3
+            poses, pts = new_poses, new_pts
+            accepted += 1
+            trials[-1]["accepted"] = 1
+        for m in np.flatnonzero(bad):
+            outliers.append((int(pi[m]), int(ci[m])))
+        alive &= ~bad
+    return dict(poses=poses, points=pts, trials=trials, outliers=outliers, accepted=accepted, converged=converged)

@@ -853,6 +853,11 @@ struct Bundle {
         double dNewError = dCurrentError + 9999;
         int nBadSoFar = 0;
         for (auto& m : mMeasList) nBadSoFar += m.bBad;
+        {
+            double nb = nBadSoFar;   // trial log only: global count in sharded mode
+            allreduce(&nb, 1);
+            nBadSoFar = (int)(nb + 0.5);
+        }
         while (dNewError > dCurrentError && !mbConverged && !mbHitMaxIterations && !(pbAbort && *pbAbort)) {
             for (auto& point : mvPoints) {   // V*^-1 :341-359
                 double V[9];

@@ -1,0 +1,53 @@
+"""Worker of the world_size-2 sharded bundle test.  Backend library: 'oracle' (CPU, gloo — runs in
+the build container) or 'hip' (two processes sharing one GPU, gloo with host staging — GPU box)."""
+import os
+import pickle
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    which, out_path = sys.argv[1], sys.argv[2]
+    import numpy as np
+    import torch  # noqa: F401
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo", init_method=f"tcp://127.0.0.1:{os.environ['MASTER_PORT']}",
+                            rank=rank, world_size=world)
+    from ptam_cg_amd import host, synth
+    from ptam_cg_amd.sharding import gather_points, merge_outliers, shard_problem, torch_allreduce_hook
+    if which == "oracle":
+        from tests.oracle_lib import load_oracle
+        lib = load_oracle()
+    else:
+        from ptam_cg_amd._lib import load
+        lib = load()
+    kw = eval(os.environ.get("PTAM_DIST_CASE", "dict(n_cams=10, n_pts=160, seed=5)"))
+    prob = synth.make_ba_problem(**kw)
+    mine = shard_problem(prob, rank, world)
+    ctx = host.Context(lib=lib)
+    ba = synth.load_into(host.Bundle(ctx), mine)
+    ba.set_comm(rank, world, torch_allreduce_hook(ctx, device_ptr=(which == "hip")))
+    acc = ba.Compute()
+    poses, pts = ba.get_all()
+
+    def all_gather(obj):
+        out = [None] * world
+        dist.all_gather_object(out, obj)
+        return out
+
+    full_pts = gather_points(pts, mine["global_point_ids"], len(prob["points"]), all_gather)
+    outl = merge_outliers(ba.GetOutlierMeasurements(), mine["global_point_ids"], all_gather)
+    all_poses = all_gather(poses)
+    if rank == 0:
+        with open(out_path, "wb") as f:
+            pickle.dump(dict(accepted=acc, converged=ba.Converged(), trials=ba.trials(), poses=poses, points=full_pts,
+                             outliers=outl, poses_all=all_poses), f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

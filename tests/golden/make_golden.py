@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Generates the golden input/output vectors under tests/golden/ with the independent numpy
+restatement (oracle/np_oracle.py).  Run in the build container:  python tests/golden/make_golden.py
+The reference itself cannot produce vectors (no tests, not buildable here — see the oracle header),
+so these pin the C++ oracle and the HIP path to a second, structurally different restatement."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import np_oracle as npo  # noqa: E402
+from ptam_cg_amd import synth  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+CAM = synth.DEFAULT_CAMERA
+
+
+def small_pair():
+    """a 160x128 crop of the synthetic frame pair (keeps the fixture small)"""
+    a, b = synth.make_frame_pair()
+    return np.ascontiguousarray(a[100:228, 200:360]), np.ascontiguousarray(b[100:228, 200:360])
+
+
+def main():
+    a, b = small_pair()
+    # --- keyframe: both halfSample variants ---
+    for v in ("R", "T"):
+        lv = npo.make_keyframe_lite(a, v)
+        d = {"im": a}
+        for l in range(4):
+            d[f"im{l}"], d[f"corners{l}"], d[f"rowlut{l}"] = lv[l]["im"], lv[l]["corners"], lv[l]["rowlut"]
+        np.savez_compressed(os.path.join(OUT, f"keyframe_160x128_{v}.npz"), **d)
+        print(v, [len(x["corners"]) for x in lv])
+    # --- patch search on the pair (variant R) ---
+    la, lb = npo.make_keyframe_lite(a), npo.make_keyframe_lite(b)
+    q, t = synth.make_patch_queries(la, n=400, seed=synth.SEED_QUERIES)
+    q[0]["level"] = -1
+    q[1]["x"], q[1]["y"] = -40, 7
+    q[2]["range"] = 0
+    q[3]["range"] = 45
+    res = [npo.find_patch_coarse(lb, q[i], t[i]) for i in range(len(q))]
+    np.savez_compressed(os.path.join(OUT, "patch_160x128.npz"), im=b, queries=q, templates=t,
+                        found=np.array([r["found"] for r in res], np.int32),
+                        best_ssd=np.array([r["best_ssd"] for r in res], np.int32),
+                        best_xy=np.array([(r["best_x"], r["best_y"]) for r in res], np.int32),
+                        n_scored=np.array([r["n_scored"] for r in res], np.int32),
+                        pos=np.array([r["pos"] for r in res], np.float64))
+    print("patch found", sum(r["found"] for r in res), "of", len(res))
+    # --- pose Gauss-Newton (fine and coarse schedules) ---
+    cam = npo.Camera(CAM, (640, 480))
+    pc = synth.make_pose_case(n=250)
+    pf, ff, uf = npo.pose_gn(cam, pc["world"], pc["found"], pc["sqrt_inv_noise"], pc["init_pose"])
+    pcs, fc, uc = npo.pose_gn(cam, pc["world"], pc["found"], pc["sqrt_inv_noise"], pc["init_pose"],
+                              nonlinear_mask=0x3FF, override_sigma_sq=1.0, mark_outliers_iter=-1)
+    np.savez_compressed(os.path.join(OUT, "pose_gn_250.npz"), world=pc["world"], found=pc["found"],
+                        sqrt_inv_noise=pc["sqrt_inv_noise"], init_pose=pc["init_pose"], fine_pose=pf, fine_flags=ff,
+                        fine_updates=uf, coarse_pose=pcs, coarse_updates=uc)
+    # --- bundle adjustment ---
+    for name, kw in (("ba_8x50", dict(n_cams=8, n_pts=50, seed=1)),
+                     ("ba_20x300", dict(n_cams=20, n_pts=300, seed=synth.SEED_BA_LOCAL)),
+                     ("ba_banded_30x200", dict(n_cams=30, n_pts=200, seed=11, window=8))):
+        prob = synth.make_ba_problem(**kw)
+        r = npo.bundle_adjust(cam, prob)
+        tr = r["trials"]
+        np.savez_compressed(os.path.join(OUT, name + ".npz"),
+                            poses=prob["poses"], fixed=prob["fixed"], points=prob["points"], cam_idx=prob["cam_idx"],
+                            pt_idx=prob["pt_idx"], found=prob["found"], sigma_sq=prob["sigma_sq"],
+                            out_poses=r["poses"], out_points=r["points"],
+                            out_outliers=np.array(r["outliers"], np.int32).reshape(-1, 2),
+                            accepted=r["accepted"], converged=r["converged"],
+                            t_lambda=np.array([x["lam"] for x in tr]), t_sigma_sq=np.array([x["sigma_sq"] for x in tr]),
+                            t_err_old=np.array([x["err_old"] for x in tr]), t_err_new=np.array([x["err_new"] for x in tr]),
+                            t_n_bad=np.array([x["n_bad"] for x in tr], np.int32),
+                            t_accepted=np.array([x["accepted"] for x in tr], np.int32))
+        print(name, len(tr), "trials, accepted", r["accepted"], "outliers", len(r["outliers"]))
+
+
+if __name__ == "__main__":
+    main()

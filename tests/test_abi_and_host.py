@@ -1,0 +1,101 @@
+"""CPU: the C-ABI library loads and exports every symbol include/ptam_hip.h declares (no compute
+calls — there is no GPU here), struct layouts match the header, host-side logic is sound."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from ptam_cg_amd import _abi, host, synth
+from ptam_cg_amd.sharding import shard_problem
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "ptam_cg_amd", "csrc", "libptam_hip.so")
+HEADER = os.path.join(ROOT, "include", "ptam_hip.h")
+
+
+@pytest.fixture(scope="module")
+def built():
+    if not os.path.exists(LIB):
+        import __graft_entry__
+        __graft_entry__.build()
+    return ctypes.CDLL(LIB)
+
+
+def header_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ptam_[a-z0-9_]+)\s*\(", src)) - {"ptam_allreduce_f64_fn"})
+
+
+def test_library_exports_every_declared_symbol(built):
+    names = header_functions()
+    assert len(names) >= 50
+    missing = [n for n in names if not hasattr(built, n)]
+    assert not missing, missing
+
+
+def test_python_prototypes_cover_the_header():
+    assert sorted("ptam_" + n for n in _abi.DECLARED) == header_functions()
+
+
+def test_no_gpu_means_loud_failure(built):
+    """the product has no CPU fallback: creating a context without a device must fail with PTAM_E_HIP"""
+    n = ctypes.c_int(-1)
+    rc = built.ptam_device_count(ctypes.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    cam = _abi.CamParams(*host.DEFAULT_CAMERA, 640, 480)
+    h = ctypes.c_void_p()
+    assert built.ptam_ctx_create(ctypes.byref(cam), 0, ctypes.byref(h)) == -2
+    built.ptam_last_error.restype = ctypes.c_char_p
+    assert built.ptam_last_error()
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(_abi.PatchQuery) == 16 and ctypes.sizeof(_abi.PatchResult) == 40
+    assert ctypes.sizeof(_abi.Projection) == 80 and ctypes.sizeof(_abi.PoseMeas) == 48
+    assert ctypes.sizeof(_abi.PoseUpdateMeas) == 136 and ctypes.sizeof(_abi.BaTrial) == 48
+    assert ctypes.sizeof(_abi.CamParams) == 48 and ctypes.sizeof(_abi.GnOpts) == 40 and ctypes.sizeof(_abi.BaOpts) == 32
+
+
+def test_product_never_touches_the_oracle():
+    """only tests/, smoke() and bench.py's cpu_baseline leg may reference oracle/"""
+    bad = []
+    for d, _, files in os.walk(os.path.join(ROOT, "ptam_cg_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cc", "Makefile")):
+                txt = open(os.path.join(d, f), errors="ignore").read()
+                if re.search(r"oracle/|ptamo_|np_oracle|oracle_lib", txt):
+                    bad.append(os.path.join(d, f))
+    assert not bad, bad
+    assert "oracle" not in open(os.path.join(ROOT, "include", "ptam_hip.h")).read().lower()
+
+
+def test_synthetic_inputs_are_deterministic_and_sane():
+    a1, b1 = synth.make_frame_pair()
+    a2, _ = synth.make_frame_pair()
+    assert np.array_equal(a1, a2) and a1.shape == (480, 640) and a1.dtype == np.uint8
+    assert not np.array_equal(a1, b1)
+    pc = synth.make_pose_case()
+    assert 900 <= len(pc["world"]) <= 1000 and 0.02 < pc["is_outlier"].mean() < 0.09
+    p = synth.make_ba_problem(20, 3000, synth.SEED_BA_LOCAL)
+    assert len(p["cam_idx"]) == 60000 and p["fixed"].sum() == 1              # every point visible
+    g = synth.make_ba_problem(40, 500, 3, window=16)
+    per_pt = np.bincount(g["pt_idx"], minlength=500)
+    assert per_pt.max() <= 16
+
+
+def test_shard_problem_is_a_partition():
+    prob = synth.make_ba_problem(6, 101, 8)
+    shards = [shard_problem(prob, r, 3) for r in range(3)]
+    ids = np.concatenate([s["global_point_ids"] for s in shards])
+    assert sorted(ids) == list(range(101))
+    assert sum(len(s["cam_idx"]) for s in shards) == len(prob["cam_idx"])
+    mids = np.concatenate([s["global_meas_ids"] for s in shards])
+    assert sorted(mids) == list(range(len(prob["cam_idx"])))
+    for s in shards:
+        assert np.array_equal(s["points"], prob["points"][s["global_point_ids"]])
+        assert np.array_equal(s["global_point_ids"][s["pt_idx"]], prob["pt_idx"][s["global_meas_ids"]])
+        assert s["pt_idx"].max() < len(s["points"]) and len(s["poses"]) == 6

@@ -1,0 +1,23 @@
+"""CPU: the C++ oracle against the committed golden vectors (independent numpy restatement)."""
+import pytest
+
+from ptam_cg_amd import _abi
+from tests import golden_util as G
+
+
+@pytest.mark.parametrize("variant", [_abi.HALFSAMPLE_R, _abi.HALFSAMPLE_T])
+def test_keyframe(oracle, variant):
+    G.check_keyframe(oracle, variant)
+
+
+def test_patch(oracle):
+    G.check_patch(oracle)
+
+
+def test_pose(oracle):
+    G.check_pose(oracle)
+
+
+@pytest.mark.parametrize("name", ["ba_8x50", "ba_20x300", "ba_banded_30x200"])
+def test_bundle(oracle, name):
+    G.check_ba(oracle, name)
