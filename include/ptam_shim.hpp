@@ -1,0 +1,274 @@
+// ptam_shim.hpp — header-only C++ shim that re-creates the reference's class surface for the hot
+// path on top of the C ABI of ptam_hip.h, so the two-thread SLAM loop of cggos/ptam_cg can switch
+// KeyFrame::MakeKeyFrame_Lite / PatchFinder::FindPatchCoarse / Tracker::CalcPoseUpdate + pose loop /
+// Bundle to the MI355X path by changing includes (INTEGRATION.md shows the edits).
+//
+// TooN / libCVD are not available to this repo, so the shim uses POD stand-ins with the same
+// meaning: ptam::SE3 (R row-major + t) for TooN::SE3<>, ptam::ImageRef for CVD::ImageRef,
+// ptam::Vec<N> for TooN::Vector<N>.  A maintainer with TooN at hand converts with two memcpy's
+// (see INTEGRATION.md §3).  Each method cites the reference declaration it mirrors.
+#ifndef PTAM_SHIM_HPP
+#define PTAM_SHIM_HPP
+
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "ptam_hip.h"
+
+namespace ptam {
+
+static_assert(sizeof(bool) == 1, "abort flag is passed as one byte");
+
+struct ImageRef {   // CVD::ImageRef
+    int x, y;
+};
+template <int N>
+using Vec = std::array<double, N>;   // TooN::Vector<N>
+
+struct SE3 {   // TooN::SE3<> : camera-from-world
+    double R[9];   // row-major
+    double t[3];
+    static SE3 Identity() {
+        SE3 s{};
+        s.R[0] = s.R[4] = s.R[8] = 1.0;
+        return s;
+    }
+    void to12(double* p) const {
+        std::memcpy(p, R, sizeof R);
+        std::memcpy(p + 9, t, sizeof t);
+    }
+    static SE3 from12(const double* p) {
+        SE3 s;
+        std::memcpy(s.R, p, sizeof s.R);
+        std::memcpy(s.t, p + 9, sizeof s.t);
+        return s;
+    }
+};
+
+inline void check(int rc, const char* what) {
+    if (rc < 0) throw std::runtime_error(std::string(what) + ": " + ptam_last_error());
+}
+
+// One per calling thread (tracker thread / mapmaker thread): replaces the per-owner ATANCamera copies
+// of the reference (include/MapMaker.h:61, include/Tracker.h) and owns the HIP stream.
+class Context {
+public:
+    // vParams = Camera.Parameters (config/camera.cfg:7), irSize = ATANCamera::SetImageSize
+    Context(const Vec<5>& vParams, ImageRef irSize, int device = 0) {
+        ptam_cam_params p{vParams[0], vParams[1], vParams[2], vParams[3], vParams[4], irSize.x, irSize.y};
+        check(ptam_ctx_create(&p, device, &h_), "ptam_ctx_create");
+        size_ = irSize;
+    }
+    ~Context() { ptam_ctx_destroy(h_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    ptam_ctx* handle() const { return h_; }
+    ImageRef size() const { return size_; }
+    void SetHalfSampleVariant(int v) { check(ptam_ctx_set_halfsample(h_, v), "set_halfsample"); }
+
+private:
+    ptam_ctx* h_ = nullptr;
+    ImageRef size_{0, 0};
+};
+
+// struct Level (include/KeyFrame.h:55-124): host views are fetched lazily from the device
+struct Level {
+    int w = 0, h = 0;
+    std::vector<uint8_t> im;                 // CVD::Image<CVD::byte>
+    std::vector<ImageRef> vCorners;          // FAST corners, raster order
+    std::vector<int> vCornerRowLUT;
+    static int LevelScale(int nLevel) { return 1 << nLevel; }                                   // :85-88
+    static double LevelZeroPos(double dLevelPos, int nLevel) { return (dLevelPos + 0.5) * LevelScale(nLevel) - 0.5; }
+    static double LevelNPos(double dRootPos, int nLevel) { return (dRootPos + 0.5) / LevelScale(nLevel) - 0.5; }
+};
+
+// struct KeyFrame (include/KeyFrame.h:130-149)
+class KeyFrame {
+public:
+    explicit KeyFrame(Context& c) : ctx_(&c) { check(ptam_kf_create(c.handle(), c.size().x, c.size().y, &h_), "ptam_kf_create"); }
+    ~KeyFrame() { ptam_kf_destroy(h_); }
+    KeyFrame(const KeyFrame& o) : ctx_(o.ctx_) {   // Level::operator= deep copy (:66-75), device side
+        check(ptam_kf_clone(ctx_->handle(), o.h_, &h_), "ptam_kf_clone");
+    }
+    KeyFrame& operator=(const KeyFrame& o) {
+        if (this != &o) {
+            ptam_kf* n = nullptr;
+            check(ptam_kf_clone(o.ctx_->handle(), o.h_, &n), "ptam_kf_clone");
+            ptam_kf_destroy(h_);
+            h_ = n;
+            ctx_ = o.ctx_;
+            fetched_ = 0;
+        }
+        return *this;
+    }
+    // void MakeKeyFrame_Lite(CVD::BasicImage<CVD::byte>& im)   include/KeyFrame.h:141, src/KeyFrame.cc:18
+    void MakeKeyFrame_Lite(const uint8_t* im, int stride) {
+        check(ptam_make_keyframe_lite(ctx_->handle(), h_, im, stride), "ptam_make_keyframe_lite");
+        fetched_ = 0;
+    }
+    // aLevels[l] host view (pixels, vCorners, vCornerRowLUT)
+    const Level& aLevels(int l) {
+        if (!(fetched_ & (1u << l))) {
+            Level& L = lev_[l];
+            int n = 0;
+            check(ptam_kf_level_info(ctx_->handle(), h_, l, &L.w, &L.h, &n), "ptam_kf_level_info");
+            L.im.resize((size_t)L.w * L.h);
+            L.vCorners.resize(n);
+            L.vCornerRowLUT.resize(L.h);
+            static_assert(sizeof(ImageRef) == sizeof(ptam_int2), "layout");
+            check(ptam_kf_read_level(ctx_->handle(), h_, l, L.im.data(), reinterpret_cast<ptam_int2*>(L.vCorners.data()),
+                                     L.vCornerRowLUT.data()),
+                  "ptam_kf_read_level");
+            fetched_ |= 1u << l;
+        }
+        return lev_[l];
+    }
+    ptam_kf* handle() const { return h_; }
+    SE3 se3CfromW = SE3::Identity();
+    bool bFixed = false;
+
+private:
+    Context* ctx_;
+    ptam_kf* h_ = nullptr;
+    Level lev_[PTAM_LEVELS];
+    unsigned fetched_ = 0;
+};
+
+// class PatchFinder (include/PatchFinder.h:51-137): coarse search stage
+class PatchFinder {
+public:
+    explicit PatchFinder(Context& c) : ctx_(&c) {}
+    // template + level as left by MakeTemplateCoarseCont / NoWarp (src/PatchFinder.cc:98-148)
+    void SetTemplate(const uint8_t tmpl64[64], int nSearchLevel, bool bBad = false) {
+        std::memcpy(tmpl_, tmpl64, 64);
+        mnSearchLevel = nSearchLevel;
+        mbTemplateBad = bBad;
+    }
+    // bool FindPatchCoarse(CVD::ImageRef ir, KeyFrame& kf, unsigned int nRange)  include/PatchFinder.h:78
+    bool FindPatchCoarse(ImageRef irPos, KeyFrame& kf, unsigned int nRange) {
+        ptam_patch_query q{irPos.x, irPos.y, mbTemplateBad ? -1 : mnSearchLevel, nRange};
+        ptam_patch_result r;
+        check(ptam_find_patch_coarse_batch(ctx_->handle(), kf.handle(), 1, &q, tmpl_, &r), "ptam_find_patch_coarse_batch");
+        mbFound = r.found != 0;
+        if (mbFound) mv2CoarsePos = {r.pos[0], r.pos[1]};
+        return mbFound;
+    }
+    // the batched form SearchForPoints (src/Tracker.cc:867-912) should use: one launch for all patches
+    static void FindPatchCoarseBatch(Context& c, KeyFrame& kf, const std::vector<ptam_patch_query>& q,
+                                     const std::vector<uint8_t>& templates64, std::vector<ptam_patch_result>& out) {
+        out.resize(q.size());
+        check(ptam_find_patch_coarse_batch(c.handle(), kf.handle(), (int)q.size(), q.data(), templates64.data(), out.data()),
+              "ptam_find_patch_coarse_batch");
+    }
+    // int ZMSSDAtPoint(CVD::BasicImage<CVD::byte>&, const CVD::ImageRef&)   include/PatchFinder.h:79
+    int ZMSSDAtPoint(KeyFrame& kf, int nLevel, ImageRef ir) {
+        ptam_int2 p{ir.x, ir.y};
+        int32_t v = 0;
+        check(ptam_zmssd_at_points(ctx_->handle(), kf.handle(), nLevel, 1, &p, tmpl_, &v), "ptam_zmssd_at_points");
+        return v;
+    }
+    Vec<2> GetCoarsePosAsVector() const { return mv2CoarsePos; }
+    int GetLevel() const { return mnSearchLevel; }
+    bool TemplateBad() const { return mbTemplateBad; }
+
+private:
+    Context* ctx_;
+    uint8_t tmpl_[64] = {0};
+    int mnSearchLevel = 0;
+    bool mbTemplateBad = false, mbFound = false;
+    Vec<2> mv2CoarsePos{0, 0};
+};
+
+// The part of TrackerData (include/Tracker.h:41-145) the pose loop reads
+struct TrackerDataLite {
+    Vec<3> v3WorldPos;       // Point.v3WorldPos
+    Vec<2> v2Found;          // v2Found (L0 pixels)
+    double dSqrtInvNoise;    // 1 / 2^level
+    bool bOutlier = false;   // set where Tracker::CalcPoseUpdate would ++nMEstimatorOutlierCount
+};
+
+// Tracker::TrackMap's ten Gauss-Newton pose iterations (src/Tracker.cc:613-643; :552-568 when bCoarse),
+// including every CalcPoseUpdate (:928-1005), in one device launch.
+inline SE3 TrackMapPoseIterations(Context& c, std::vector<TrackerDataLite>& vTD, const SE3& se3CamFromWorld,
+                                  bool bCoarse = false, int nEstimator = PTAM_EST_TUKEY) {
+    std::vector<ptam_pose_meas> m(vTD.size());
+    for (size_t i = 0; i < vTD.size(); i++) {
+        std::memcpy(m[i].world, vTD[i].v3WorldPos.data(), 24);
+        std::memcpy(m[i].found, vTD[i].v2Found.data(), 16);
+        m[i].sqrt_inv_noise = vTD[i].dSqrtInvNoise;
+    }
+    ptam_gn_opts o;
+    ptam_gn_opts_default(&o);
+    o.estimator = nEstimator;
+    if (bCoarse) {
+        o.nonlinear_mask = 0x3ff;
+        o.override_sigma_sq = 1.0;
+        o.mark_outliers_iter = -1;
+    }
+    double pose[12];
+    se3CamFromWorld.to12(pose);
+    std::vector<int32_t> flags(vTD.size());
+    check(ptam_pose_gn(c.handle(), (int)m.size(), m.data(), nullptr, pose, &o, flags.data(), nullptr), "ptam_pose_gn");
+    for (size_t i = 0; i < vTD.size(); i++) vTD[i].bOutlier = flags[i] != 0;
+    return SE3::from12(pose);
+}
+
+// class Bundle (include/Bundle.h:106-152)
+class Bundle {
+public:
+    explicit Bundle(Context& c, const ptam_ba_opts* opts = nullptr) { check(ptam_ba_create(c.handle(), opts, &h_), "ptam_ba_create"); }
+    ~Bundle() { ptam_ba_destroy(h_); }
+    Bundle(const Bundle&) = delete;
+    Bundle& operator=(const Bundle&) = delete;
+    int AddCamera(const SE3& se3CamFromWorld, bool bFixed) {   // :111
+        double p[12];
+        se3CamFromWorld.to12(p);
+        int id = ptam_ba_add_camera(h_, p, bFixed);
+        check(id, "ptam_ba_add_camera");
+        return id;
+    }
+    int AddPoint(const Vec<3>& v3Pos) {   // :112
+        int id = ptam_ba_add_point(h_, v3Pos.data());
+        check(id, "ptam_ba_add_point");
+        return id;
+    }
+    void AddMeas(int nCam, int nPoint, const Vec<2>& v2Pos, double dSigmaSquared) {   // :113
+        check(ptam_ba_add_meas(h_, nCam, nPoint, v2Pos.data(), dSigmaSquared), "ptam_ba_add_meas");
+    }
+    int Compute(bool* pbAbortSignal) {   // :114 ; returns mnAccepted or -1
+        int acc = 0;
+        check(ptam_ba_compute(h_, reinterpret_cast<const volatile unsigned char*>(pbAbortSignal), &acc), "ptam_ba_compute");
+        return acc;
+    }
+    bool Converged() const { return ptam_ba_converged(h_) != 0; }   // :115
+    Vec<3> GetPoint(int n) const {                                   // :116
+        Vec<3> v{};
+        check(ptam_ba_get_point(h_, n, v.data()), "ptam_ba_get_point");
+        return v;
+    }
+    SE3 GetCamera(int n) const {   // :117
+        double p[12];
+        check(ptam_ba_get_camera(h_, n, p), "ptam_ba_get_camera");
+        return SE3::from12(p);
+    }
+    std::vector<std::pair<int, int>> GetOutlierMeasurements() const {   // :118 ; (point, camera)
+        const int n = ptam_ba_get_outliers(h_, nullptr, 0);
+        std::vector<int32_t> raw((size_t)2 * (n > 0 ? n : 0));
+        if (n > 0) ptam_ba_get_outliers(h_, raw.data(), n);
+        std::vector<std::pair<int, int>> out;
+        for (int i = 0; i < n; i++) out.emplace_back(raw[2 * i], raw[2 * i + 1]);
+        return out;
+    }
+    ptam_ba* handle() const { return h_; }
+
+private:
+    ptam_ba* h_ = nullptr;
+};
+
+}   // namespace ptam
+#endif
