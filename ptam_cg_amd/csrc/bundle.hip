@@ -935,18 +935,120 @@ __global__ void __launch_bounds__(256) vinv_kernel(BaDev d, double lambda) {
 #define SCHUR_TILE_ELEMS (SCHUR_TC * SCHUR_TC * 36 + SCHUR_TC * 6)   // 2304 + 48
 #define SCHUR_BATCH 16                                                 // entries staged per LDS round
 
-// Workgroup = (tile pair (a,b), a slice of the points touching both tiles).  Per round it stages
-// SCHUR_BATCH entries: 16 loader lanes per entry fetch the W blocks of the point's measurements in
-// tile a / tile b (9 x double2 each, all 256 threads loading at once -> deep memory-level parallelism),
-// form Y = W V*^-1 on the fly and drop Y / W into LDS panels indexed by camera slot.  Then each wave
-// takes 4 entries; lane (j,k) accumulates the 6x6 block  Y_j W_k^T  in 36 registers (and E_j on the
-// diagonal pair).  Absent cameras are skipped through per-entry presence masks (no panel zeroing).
+// Workgroup = (tile pair (a,b), a slice of the points touching both tiles), SOFTWARE PIPELINED:
+// while the four waves compute round i out of one LDS stage (lane (j,k) accumulates the 6x6 block
+// Y_j W_k^T of every entry in 36 registers, E_j on the diagonal pair), the global loads of round i+1
+// (16 entries x 16 loader lanes: the W blocks of the point's measurements in tile a / tile b, V*^-1,
+// epsB) are in flight, and the work-list entries of round i+2 are being fetched.  After the compute the
+// loaders form Y = W V*^-1 and drop Y / W into the OTHER LDS stage; one barrier per round.  Absent
+// cameras are skipped through per-entry presence masks built with DPP ORs (no zeroing, no atomics).
+struct SchurStage {
+    double PY[SCHUR_BATCH][SCHUR_TC][18];
+    double PW[SCHUR_BATCH][SCHUR_TC][18];
+    double eB[SCHUR_BATCH][4];
+    unsigned pmA[SCHUR_BATCH], pmB[SCHUR_BATCH];
+};
+struct SchurPre {      // one loader lane's prefetched share of a round
+    SchurEntry ent;
+    int have;          // this lane's entry exists
+    int m;             // measurement index (first iteration), -1 if none
+    int f;             // its free-camera index
+    double w[18];
+    double vq;         // lane q < 9 of the entry carries Vinv[q]
+    double eb;         // lane q < 3 carries epsB[q]
+};
+
+__device__ __forceinline__ void schur_fetch(const BaDev& d, const SchurEntry& ent, bool have, bool diag, int ls, SchurPre& p) {
+    p.ent = ent;
+    p.have = have;
+    p.m = -1;
+    p.f = -1;
+    p.vq = 0;
+    p.eb = 0;
+    if (!have) return;
+    const int na = ent.na_nb & 0xffff, nbm = (ent.na_nb >> 16) & 0xffff;
+    const bool roleA = diag || ls < 8;
+    const int l = roleA ? ls : ls - 8;
+    const int n = roleA ? na : nbm;
+    if (l < n) {
+        p.m = (roleA ? ent.ma : ent.mb) + l;
+        p.f = d.m_fidx[p.m];
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+            const double2 t = d.W[(size_t)q * d.M + p.m];
+            p.w[2 * q] = t.x;
+            p.w[2 * q + 1] = t.y;
+        }
+    }
+    if (ls < 9) p.vq = d.Vinv[(size_t)ent.pt * 9 + ls];
+    if (ls < 3) p.eb = d.epsB[(size_t)ent.pt * 3 + ls];
+}
+
+// write one measurement's blocks into the stage; returns its presence bit
+__device__ __forceinline__ unsigned schur_put(SchurStage& st, int le, bool roleA, bool diag, int slot, const double w[18],
+                                              const double v[9]) {
+    if (roleA) {
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                st.PY[le][slot][r * 3 + c] = w[r * 3] * v[c] + w[r * 3 + 1] * v[3 + c] + w[r * 3 + 2] * v[6 + c];
+        if (diag) {
+#pragma unroll
+            for (int q = 0; q < 18; q++) st.PW[le][slot][q] = w[q];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 18; q++) st.PW[le][slot][q] = w[q];
+    }
+    return 1u << slot;
+}
+
+__device__ __forceinline__ void schur_store(const BaDev& d, SchurStage& st, const SchurPre& p, bool diag, int a, int b,
+                                            int le, int ls, int lane) {
+    // V*^-1 of the entry: element q lives in lane q of the entry's 16-lane group
+    double v[9];
+#pragma unroll
+    for (int q = 0; q < 9; q++) v[q] = __shfl(p.vq, (lane & 48) | q, 64);
+    const bool roleA = diag || ls < 8;
+    unsigned bit = 0;
+    if (p.have) {
+        if (ls < 3) st.eB[le][ls] = p.eb;
+        if (p.m >= 0 && p.f >= 0) bit = schur_put(st, le, roleA, diag, p.f - (roleA ? a : b) * SCHUR_TC, p.w, v);
+        // rare: more measurements in the tile range than loader lanes (fixed cameras interleaved)
+        const int na = p.ent.na_nb & 0xffff, nbm = (p.ent.na_nb >> 16) & 0xffff;
+        const int step = diag ? 16 : 8, n = roleA ? na : nbm;
+        for (int l = (roleA ? ls : ls - 8) + step; l < n; l += step) {
+            const int m = (roleA ? p.ent.ma : p.ent.mb) + l;
+            const int f = d.m_fidx[m];
+            if (f >= 0) {
+                double w[18];
+#pragma unroll
+                for (int q = 0; q < 9; q++) {
+                    const double2 t = d.W[(size_t)q * d.M + m];
+                    w[2 * q] = t.x;
+                    w[2 * q + 1] = t.y;
+                }
+                bit |= schur_put(st, le, roleA, diag, f - (roleA ? a : b) * SCHUR_TC, w, v);
+            }
+        }
+    }
+    // presence masks: OR over the entry's loader lanes (a-role and b-role halves separately)
+    unsigned ba = roleA ? bit : 0u, bb = roleA ? 0u : bit;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        ba |= __shfl_xor(ba, o, 64);
+        bb |= __shfl_xor(bb, o, 64);
+    }
+    if (ls == 0) {
+        st.pmA[le] = ba;
+        st.pmB[le] = diag ? ba : bb;
+    }
+}
+
 __global__ void __launch_bounds__(256) schur_tile_kernel(BaDev d) {
-    __shared__ __attribute__((aligned(16))) double lds[2 * 64 * 42];   // panels (4608) alias the reduce buffer (5376)
-    __shared__ unsigned pmA[2][SCHUR_BATCH], pmB[2][SCHUR_BATCH];   // presence masks, double-buffered by round parity
-    __shared__ double eBs[SCHUR_BATCH][3];
-    double(*PY)[SCHUR_TC][18] = reinterpret_cast<double(*)[SCHUR_TC][18]>(lds);
-    double(*PW)[SCHUR_TC][18] = reinterpret_cast<double(*)[SCHUR_TC][18]>(lds + SCHUR_BATCH * SCHUR_TC * 18);
+    extern __shared__ __attribute__((aligned(16))) double schur_lds[];
+    SchurStage* stage = reinterpret_cast<SchurStage*>(schur_lds);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const SchurWG wg = d.s_wgs[blockIdx.x];
     int a = (int)((sqrt(8.0 * wg.pair + 1.0) - 1.0) * 0.5);
@@ -961,97 +1063,83 @@ __global__ void __launch_bounds__(256) schur_tile_kernel(BaDev d) {
     for (int i = 0; i < 36; i++) acc[i] = 0;
 #pragma unroll
     for (int i = 0; i < 6; i++) accE[i] = 0;
-    if (tid < 2 * SCHUR_BATCH) {
-        (&pmA[0][0])[tid] = 0;
-        (&pmB[0][0])[tid] = 0;
-    }
-    int par = 0;
-    for (int e0 = wg.e_begin; e0 < wg.e_end; e0 += SCHUR_BATCH, par ^= 1) {
-        const int nb_ent = min(SCHUR_BATCH, wg.e_end - e0);
-        __syncthreads();   // previous round's compute done (its masks / panels are dead)
-        if (tid < SCHUR_BATCH) {   // clear the OTHER parity for the next round
-            pmA[par ^ 1][tid] = 0;
-            pmB[par ^ 1][tid] = 0;
-        }
-        if (le < nb_ent) {
-            const SchurEntry ent = d.s_entries[e0 + le];
-            const int na = ent.na_nb & 0xffff, nbm = (ent.na_nb >> 16) & 0xffff;
-            const double* __restrict__ Vi = d.Vinv + (size_t)ent.pt * 9;
-            if (ls < 3) eBs[le][ls] = d.epsB[(size_t)ent.pt * 3 + ls];
-            // tile a (lanes 0..7 of the entry when off-diagonal, all 16 when diagonal)
-            const int stepA = diag ? 16 : 8;
-            if (diag || ls < 8) {
-                for (int l = ls; l < na; l += stepA) {
-                    const int m = ent.ma + l;
-                    const int f = d.m_fidx[m];   // free-camera index, -1 for fixed cameras (W of bad /
-                                                 // erased measurements is zero, so they need no test)
-                    if (f >= 0) {
-                        const int slot = f - a * SCHUR_TC;
-                        double w[18];
-#pragma unroll
-                        for (int q = 0; q < 9; q++) {
-                            const double2 t = d.W[(size_t)q * d.M + m];
-                            w[2 * q] = t.x;
-                            w[2 * q + 1] = t.y;
-                        }
-                        double v[9];
-#pragma unroll
-                        for (int q = 0; q < 9; q++) v[q] = Vi[q];
-#pragma unroll
-                        for (int r = 0; r < 6; r++)
-#pragma unroll
-                            for (int c = 0; c < 3; c++)
-                                PY[le][slot][r * 3 + c] = w[r * 3] * v[c] + w[r * 3 + 1] * v[3 + c] + w[r * 3 + 2] * v[6 + c];
-                        if (diag) {
-#pragma unroll
-                            for (int q = 0; q < 18; q++) PW[le][slot][q] = w[q];
-                        }
-                        atomicOr(&pmA[par][le], 1u << slot);
-                    }
-                }
-            }
-            if (!diag && ls >= 8) {
-                for (int l = ls - 8; l < nbm; l += 8) {
-                    const int m = ent.mb + l;
-                    const int f = d.m_fidx[m];
-                    if (f >= 0) {
-                        const int slot = f - b * SCHUR_TC;
-#pragma unroll
-                        for (int q = 0; q < 9; q++) {
-                            const double2 t = d.W[(size_t)q * d.M + m];
-                            PW[le][slot][2 * q] = t.x;
-                            PW[le][slot][2 * q + 1] = t.y;
-                        }
-                        atomicOr(&pmB[par][le], 1u << slot);
-                    }
-                }
-            }
-        }
-        __syncthreads();
+    const int n_ent = wg.e_end - wg.e_begin;
+    const int n_rounds = (n_ent + SCHUR_BATCH - 1) / SCHUR_BATCH;
+    const SchurEntry none = {0, 0, 0, 0};
+    auto entry_at = [&](int round, bool& have) {
+        const int e = wg.e_begin + round * SCHUR_BATCH + le;
+        have = round < n_rounds && e < wg.e_end;
+        return have ? d.s_entries[e] : none;
+    };
+#ifdef K7_TIMING
+    long long t_comp = 0, t_store = 0, t_fetch = 0, t_bar = 0;
+    const long long t_start = (long long)__builtin_readcyclecounter();
+#define SCH_T(acc, stmt) { const long long t0_ = (long long)__builtin_readcyclecounter(); stmt; acc += (long long)__builtin_readcyclecounter() - t0_; }
+#else
+#define SCH_T(acc, stmt) { stmt; }
+#endif
+    // prologue: round 0 into stage 0, entries of round 1 in registers
+    SchurPre pre;
+    bool have0, have_next;
+    const SchurEntry e0 = entry_at(0, have0);
+    schur_fetch(d, e0, have0, diag, ls, pre);
+    SchurEntry ent_next = entry_at(1, have_next);
+    schur_store(d, stage[0], pre, diag, a, b, le, ls, lane);
+    __syncthreads();
+    for (int i = 0; i < n_rounds; i++) {
+        const bool more = i + 1 < n_rounds;
+        SCH_T(t_fetch, if (more) schur_fetch(d, ent_next, have_next, diag, ls, pre));   // round i+1's data: loads in flight
+        bool have2;
+        const SchurEntry ent2 = entry_at(i + 2, have2);                  // round i+2's work-list entries
+        // ---- compute round i ----
+        const SchurStage& st = stage[i & 1];
+        const int nb_ent = min(SCHUR_BATCH, n_ent - i * SCHUR_BATCH);
+#ifdef K7_TIMING
+        const long long tc0 = (long long)__builtin_readcyclecounter();
+#endif
         for (int e = wid; e < nb_ent; e += 4) {
-            const unsigned pa = pmA[par][e], pb = diag ? pa : pmB[par][e];
+            const unsigned pa = st.pmA[e], pb = st.pmB[e];
             if (((pa >> j) & 1u) && ((pb >> k) & 1u)) {
                 double Yj[18], Wk[18];
 #pragma unroll
                 for (int q = 0; q < 18; q++) {
-                    Yj[q] = PY[e][j][q];
-                    Wk[q] = PW[e][k][q];
+                    Yj[q] = st.PY[e][j][q];
+                    Wk[q] = st.PW[e][k][q];
                 }
 #pragma unroll
                 for (int r = 0; r < 6; r++)
 #pragma unroll
-                    for (int c = 0; c < 6; c++)
-                        acc[r * 6 + c] += Yj[r * 3] * Wk[c * 3] + Yj[r * 3 + 1] * Wk[c * 3 + 1] + Yj[r * 3 + 2] * Wk[c * 3 + 2];
+                    for (int c = 0; c < 6; c++)   // three chained FMAs straight into the accumulator
+                        acc[r * 6 + c] = fma(Yj[r * 3 + 2], Wk[c * 3 + 2],
+                                             fma(Yj[r * 3 + 1], Wk[c * 3 + 1], fma(Yj[r * 3], Wk[c * 3], acc[r * 6 + c])));
                 if (diag && k == j) {
-                    const double b0 = eBs[e][0], b1 = eBs[e][1], b2 = eBs[e][2];
+                    const double b0 = st.eB[e][0], b1 = st.eB[e][1], b2 = st.eB[e][2];
 #pragma unroll
-                    for (int r = 0; r < 6; r++) accE[r] += Yj[r * 3] * b0 + Yj[r * 3 + 1] * b1 + Yj[r * 3 + 2] * b2;
+                    for (int r = 0; r < 6; r++) accE[r] = fma(Yj[r * 3 + 2], b2, fma(Yj[r * 3 + 1], b1, fma(Yj[r * 3], b0, accE[r])));
                 }
             }
         }
+#ifdef K7_TIMING
+        t_comp += (long long)__builtin_readcyclecounter() - tc0;
+#endif
+        // ---- stage round i+1 ----
+        SCH_T(t_store, if (more) schur_store(d, stage[(i + 1) & 1], pre, diag, a, b, le, ls, lane));
+        ent_next = ent2;
+        have_next = have2;
+        SCH_T(t_bar, __syncthreads());
     }
-    __syncthreads();   // panels dead: the buffer becomes the cross-wave reduction scratch
-    double(*red)[64][42] = reinterpret_cast<double(*)[64][42]>(lds);
+#ifdef K7_TIMING
+    if (blockIdx.x == 100 && tid == 0) {
+        d.dbg[10] = (long long)__builtin_readcyclecounter() - t_start;
+        d.dbg[11] = t_fetch;
+        d.dbg[12] = t_comp;
+        d.dbg[13] = t_store;
+        d.dbg[14] = t_bar;
+        d.dbg[15] = n_rounds;
+    }
+#endif
+    // stages dead: the buffer becomes the cross-wave reduction scratch
+    double(*red)[64][42] = reinterpret_cast<double(*)[64][42]>(schur_lds);
     // cross-wave reduction in fixed order: (w2 -> w0, w3 -> w1), then (w1 -> w0)
     if (wid >= 2) {
 #pragma unroll
@@ -1679,6 +1767,8 @@ static int ba_prepare_impl(ptam_ba* ba) {
     UP(d.s_pair_wg_begin, pair_wg_begin.data(), pair_wg_begin.size() * 4);
 #undef UP
     HIP_TRY(hipStreamSynchronize(ctx->stream));   // host staging vectors die here
+    HIP_TRY(hipFuncSetAttribute((const void*)schur_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(2 * sizeof(SchurStage))));
     HIP_TRY(hipMalloc((void**)&ba->d_xchg, 4096));
     ba->cur = 0;
     ba->prepared = true;
@@ -1820,7 +1910,8 @@ static int ba_trial(ptam_ba* ba, double lambda) {
     prof_end(ba, PTAM_K_VINV);
     if (d.F > 0) {
         prof_begin(ba, PTAM_K_SCHUR);
-        if (d.n_schur_wg > 0) hipLaunchKernelGGL(schur_tile_kernel, dim3(d.n_schur_wg), dim3(256), 0, ctx->stream, d);
+        if (d.n_schur_wg > 0)
+            hipLaunchKernelGGL(schur_tile_kernel, dim3(d.n_schur_wg), dim3(256), 2 * sizeof(SchurStage), ctx->stream, d);
         hipLaunchKernelGGL(schur_reduce_kernel, dim3(d.n_pairs, SRED_SLICES), dim3(256), 0, ctx->stream, d, lambda,
                            (ba->world > 1 && ba->rank != 0) ? 0 : 1);
         prof_end(ba, PTAM_K_SCHUR);
@@ -2069,6 +2160,14 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
         if (rc) return rc;
         step_outlier_end.push_back(sc.n_outliers);
     }
+#ifdef K7_TIMING
+    {
+        long long h[16];
+        HIP_TRY(hipMemcpy(h, d.dbg, sizeof h, hipMemcpyDeviceToHost));
+        std::printf("SCHUR wg100 cycles: total %lld fetch %lld compute %lld store %lld barrier %lld rounds %lld\n", h[10], h[11],
+                    h[12], h[13], h[14], h[15]);
+    }
+#endif
     // ---- read back results ----
     HIP_TRY(hipMemcpyAsync(ba->cam_pose.data(), d.pose[ba->cur], (size_t)d.C * 96, hipMemcpyDeviceToHost, ctx->stream));
     if (d.P > 0) HIP_TRY(hipMemcpyAsync(ba->pts.data(), d.pt[ba->cur], (size_t)d.P * 24, hipMemcpyDeviceToHost, ctx->stream));
