@@ -1397,10 +1397,15 @@ __global__ void __launch_bounds__(256) finalize_new_kernel(BaDev d) {
 // erase bad measurements, append to the outlier list (:536-547)
 __global__ void __launch_bounds__(256) purge_kernel(BaDev d) {
     const int m = blockIdx.x * 256 + threadIdx.x;
-    if (m >= d.M) return;
-    if (d.m_state[m] == MS_BAD) {
-        const int pos = atomicAdd(&d.sc->n_outliers, 1);
-        d.outliers[pos] = d.m_orig[m];
+    const int lane = threadIdx.x & 63;
+    const bool bad = m < d.M && d.m_state[m] == MS_BAD;
+    const unsigned long long mask = __ballot(bad);
+    if (mask == 0) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&d.sc->n_outliers, __popcll(mask));   // one atomic per wave
+    base = __shfl(base, 0, 64);
+    if (bad) {
+        d.outliers[base + __popcll(mask & ((1ull << lane) - 1ull))] = d.m_orig[m];
         d.m_state[m] = MS_DEAD;
     }
 }
@@ -1816,7 +1821,7 @@ static int ba_pass1_sigma(ptam_ba* ba) {
     const double min_s2 = ba->opts.min_sigma * ba->opts.min_sigma;
     prof_begin(ba, PTAM_K_PROJECT);
     if (d.n_chunks > 0)
-        hipLaunchKernelGGL(project_e2_kernel, dim3(std::min(d.n_chunks, 1024)), dim3(BA_CHUNK), 0, ctx->stream, ctx->cam, d,
+        hipLaunchKernelGGL(project_e2_kernel, dim3(std::min(d.n_chunks, 512)), dim3(BA_CHUNK), 0, ctx->stream, ctx->cam, d,
                            ba->cur, sharded ? 0 : 1);
     prof_end(ba, PTAM_K_PROJECT);
     prof_begin(ba, PTAM_K_SELECT);
