@@ -1772,6 +1772,10 @@ static int ba_prepare_impl(ptam_ba* ba) {
     UP(d.s_pair_wg_begin, pair_wg_begin.data(), pair_wg_begin.size() * 4);
 #undef UP
     HIP_TRY(hipStreamSynchronize(ctx->stream));   // host staging vectors die here
+    {
+        const int rc_s = ba_solve_init();
+        if (rc_s) return rc_s;
+    }
     HIP_TRY(hipFuncSetAttribute((const void*)schur_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(2 * sizeof(SchurStage))));
     HIP_TRY(hipMalloc((void**)&ba->d_xchg, 4096));
@@ -2169,6 +2173,8 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     {
         long long h[16];
         HIP_TRY(hipMemcpy(h, d.dbg, sizeof h, hipMemcpyDeviceToHost));
+        std::printf("LDLT step2 wg0: loop %lld tail %lld | last wg (role %lld): loop %lld tail %lld\n", h[1] - h[0], h[2] - h[1], h[7],
+                    h[5] - h[4], h[6] - h[5]);
         std::printf("SCHUR wg100 cycles: total %lld fetch %lld compute %lld store %lld barrier %lld rounds %lld\n", h[10], h[11],
                     h[12], h[13], h[14], h[15]);
     }

@@ -17,7 +17,9 @@
 #include "bundle.h"
 
 #define NB SOLVE_NB
-#define LDP (NB + 1)   // LDS pitch in doubles (odd -> conflict-free column access)
+#define LDP (NB + 1)        // LDS pitch in doubles (odd -> conflict-free column access)
+#define TPB (NB * NB / 4)   // threads per workgroup: 4 columns of one row per thread (256 @ NB=32, 1024 @ NB=64)
+#define GROUPS (NB / 4)     // column groups: thread (r, g) owns columns g, g+GROUPS, g+2*GROUPS, g+3*GROUPS
 
 __device__ __forceinline__ double fast_rcp(double d) {
     double x = __builtin_amdgcn_rcp(d);
@@ -61,17 +63,18 @@ __device__ __forceinline__ void micro_subst(const Micro& f, const double a[4], d
     x[3] = a[3] - x[0] * f.l30 - x[1] * f.l31 - x[2] * f.l32;
 }
 
-__global__ void __launch_bounds__(256) ldlt_step_kernel(BaDev d, int k) {
-    __shared__ double Akk[NB * LDP];
-    __shared__ double Ai[NB * LDP];
-    __shared__ double Aj[NB * LDP];
-    __shared__ double iD[NB];
-    __shared__ double bz[NB];
+__global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
+    extern __shared__ __attribute__((aligned(16))) double step_lds[];
+    double* Akk = step_lds;
+    double* Ai = Akk + NB * LDP;
+    double* Aj = Ai + NB * LDP;
+    double* iD = Aj + NB * LDP;
+    double* bz = iD + NB;
     const int npad = d.npad, nblk = npad / NB, rem = nblk - k - 1;
     double* __restrict__ S = d.SE;
     double* __restrict__ E = d.SE + (size_t)npad * npad;
     const int tid = threadIdx.x;
-    const int r = tid >> 3, g = tid & 7;   // row, column group (columns g, g+8, g+16, g+24)
+    const int r = tid / GROUPS, g = tid % GROUPS;   // row, column group
     int role, bi = 0, bj = 0;
     const int wg = blockIdx.x;
     if (wg == 0)
@@ -93,13 +96,16 @@ __global__ void __launch_bounds__(256) ldlt_step_kernel(BaDev d, int k) {
     // load: A_kk mirrored from its lower triangle, panels, rhs
 #pragma unroll
     for (int jj = 0; jj < 4; jj++) {
-        const int q = g + 8 * jj;
+        const int q = g + GROUPS * jj;
         const int rr = r >= q ? r : q, cc = r >= q ? q : r;
         Akk[r * LDP + q] = S[(size_t)(k * NB + rr) * npad + k * NB + cc];
         if (pan) Ai[r * LDP + q] = S[(size_t)(bi * NB + r) * npad + k * NB + q];
         if (two) Aj[r * LDP + q] = S[(size_t)(bj * NB + r) * npad + k * NB + q];
     }
     if (tid < NB) bz[tid] = E[k * NB + tid];
+#ifdef K7_TIMING
+    const long long ts0 = (long long)__builtin_readcyclecounter();
+#endif
 
     for (int c0 = 0; c0 < NB; c0 += 4) {
         __syncthreads();   // (A) previous panel's writes visible
@@ -112,7 +118,7 @@ __global__ void __launch_bounds__(256) ldlt_step_kernel(BaDev d, int k) {
         double lq[4][4];
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
-            const int q = g + 8 * jj;
+            const int q = g + GROUPS * jj;
             if (q > c0 + 3) {
                 const double a[4] = {Akk[q * LDP + c0], Akk[q * LDP + c0 + 1], Akk[q * LDP + c0 + 2], Akk[q * LDP + c0 + 3]};
                 double x[4];
@@ -149,7 +155,7 @@ __global__ void __launch_bounds__(256) ldlt_step_kernel(BaDev d, int k) {
         // ---- writes ----
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
-            const int q = g + 8 * jj;
+            const int q = g + GROUPS * jj;
             if (q > c0 + 3) {
                 const double* l = lq[jj];
                 if (q <= r) Akk[r * LDP + q] -= xk[0] * l[0] + xk[1] * l[1] + xk[2] * l[2] + xk[3] * l[3];
@@ -187,12 +193,15 @@ __global__ void __launch_bounds__(256) ldlt_step_kernel(BaDev d, int k) {
         }
     }
     __syncthreads();
+#ifdef K7_TIMING
+    const long long ts1 = (long long)__builtin_readcyclecounter();
+#endif
     if (tid < NB) iD[tid] = fast_rcp(Akk[tid * LDP + tid]);
     __syncthreads();
     if (role == 0) {
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
-            const int q = g + 8 * jj;
+            const int q = g + GROUPS * jj;
             double v = 0.0;
             if (q < r)
                 v = Akk[r * LDP + q] * iD[q];
@@ -207,7 +216,7 @@ __global__ void __launch_bounds__(256) ldlt_step_kernel(BaDev d, int k) {
     } else if (role == 1) {
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
-            const int q = g + 8 * jj;
+            const int q = g + GROUPS * jj;
             d.L[(size_t)(bi * NB + r) * npad + k * NB + q] = Ai[r * LDP + q] * iD[q];
         }
         if (tid < NB) {
@@ -220,7 +229,7 @@ __global__ void __launch_bounds__(256) ldlt_step_kernel(BaDev d, int k) {
         double* XjD = Aj;
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
-            const int q = g + 8 * jj;
+            const int q = g + GROUPS * jj;
             XjD[r * LDP + q] = (two ? Aj[r * LDP + q] : Ai[r * LDP + q]) * iD[q];
         }
         __syncthreads();
@@ -229,11 +238,20 @@ __global__ void __launch_bounds__(256) ldlt_step_kernel(BaDev d, int k) {
         for (int c = 0; c < NB; c++) {
             const double a = Ai[r * LDP + c];
 #pragma unroll
-            for (int jj = 0; jj < 4; jj++) acc[jj] += a * XjD[(g + 8 * jj) * LDP + c];
+            for (int jj = 0; jj < 4; jj++) acc[jj] += a * XjD[(g + GROUPS * jj) * LDP + c];
         }
 #pragma unroll
-        for (int jj = 0; jj < 4; jj++) S[(size_t)(bi * NB + r) * npad + bj * NB + g + 8 * jj] -= acc[jj];
+        for (int jj = 0; jj < 4; jj++) S[(size_t)(bi * NB + r) * npad + bj * NB + g + GROUPS * jj] -= acc[jj];
     }
+#ifdef K7_TIMING
+    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && k == 2) {
+        long long* o = d.dbg + (blockIdx.x == 0 ? 0 : 4);
+        o[0] = ts0;
+        o[1] = ts1;
+        o[2] = (long long)__builtin_readcyclecounter();
+        o[3] = role;
+    }
+#endif
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
@@ -243,28 +261,30 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// w = D^-1 z ; L^T x = w, blocked backwards.  One workgroup.
+// w = D^-1 z ; L^T x = w, blocked backwards.  One workgroup of 1024 threads.
+#define BW_PART (1024 / NB)   // row partitions of the GEMV part
 __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d) {
-    extern __shared__ __attribute__((aligned(16))) double xs[];   // npad doubles
-    __shared__ double part[32][NB + 1];
-    __shared__ double Lk[NB * LDP];
+    extern __shared__ __attribute__((aligned(16))) double bw_lds[];
     const int npad = d.npad, nblk = npad / NB;
+    double* xs = bw_lds;                       // npad
+    double* part = xs + npad;                  // BW_PART x (NB + 1)
+    double* Lk = part + BW_PART * (NB + 1);    // NB x LDP
     const int tid = threadIdx.x;
-    const int c = tid & 31, pr = tid >> 5;   // column within block, row partition (32 partitions)
+    const int c = tid % NB, pr = tid / NB;     // column within block, row partition
     for (int k = nblk - 1; k >= 0; k--) {
         // stage the diagonal block of L (independent of the running solution)
-        Lk[pr * LDP + c] = d.L[(size_t)(k * NB + pr) * npad + k * NB + c];
+        for (int rr = pr; rr < NB; rr += BW_PART) Lk[rr * LDP + c] = d.L[(size_t)(k * NB + rr) * npad + k * NB + c];
         // s[c] = sum_{r > block k} L[r][k*NB + c] * x[r]
         double s = 0;
-        for (int rr = (k + 1) * NB + pr; rr < npad; rr += 32) s += d.L[(size_t)rr * npad + k * NB + c] * xs[rr];
-        part[pr][c] = s;
+        for (int rr = (k + 1) * NB + pr; rr < npad; rr += BW_PART) s += d.L[(size_t)rr * npad + k * NB + c] * xs[rr];
+        part[pr * (NB + 1) + c] = s;
         __syncthreads();
         if (tid < 64) {
-            // unit upper-triangular solve Lkk^T x = v in registers of one wave (lanes 0..31)
+            // unit upper-triangular solve Lkk^T x = v in registers of one wave (lanes 0..NB-1)
             double vt = 0;
             if (tid < NB) {
                 double t = 0;
-                for (int p = 0; p < 32; p++) t += part[p][tid];
+                for (int p = 0; p < BW_PART; p++) t += part[p * (NB + 1) + tid];
                 vt = d.y[k * NB + tid] / d.Dg[k * NB + tid] - t;
             }
             for (int cc = NB - 1; cc > 0; cc--) {
@@ -278,14 +298,22 @@ __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d) {
     for (int i = tid; i < npad; i += 1024) d.da[i] = xs[i];
 }
 
+#define STEP_LDS_BYTES ((3 * NB * LDP + 2 * NB) * sizeof(double))
+int ba_solve_init() {
+    HIP_TRY(hipFuncSetAttribute((const void*)ldlt_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)STEP_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void*)ldlt_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return PTAM_OK;
+}
+
 int ba_solve(ptam_ctx* ctx, BaDev& d) {
     const int nblk = d.npad / NB;
     for (int k = 0; k < nblk; k++) {
         const int rem = nblk - k - 1;
         const int nwg = 1 + rem + rem * (rem + 1) / 2;
-        hipLaunchKernelGGL(ldlt_step_kernel, dim3(nwg), dim3(256), 0, ctx->stream, d, k);
+        hipLaunchKernelGGL(ldlt_step_kernel, dim3(nwg), dim3(TPB), STEP_LDS_BYTES, ctx->stream, d, k);
     }
-    hipLaunchKernelGGL(ldlt_backward_kernel, dim3(1), dim3(1024), (size_t)d.npad * sizeof(double), ctx->stream, d);
+    const size_t bw_bytes = ((size_t)d.npad + BW_PART * (NB + 1) + NB * LDP) * sizeof(double);
+    hipLaunchKernelGGL(ldlt_backward_kernel, dim3(1), dim3(1024), bw_bytes, ctx->stream, d);
     HIP_TRY(hipGetLastError());
     return PTAM_OK;
 }
