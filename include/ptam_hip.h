@@ -130,6 +130,22 @@ int ptam_find_patch_coarse_batch_dev(ptam_ctx* ctx, const ptam_kf* kf, int n,
 int ptam_zmssd_at_points(ptam_ctx* ctx, const ptam_kf* kf, int level, int n,
                          const ptam_int2* points, const uint8_t* tmpl64, int32_t* ssd_out);
 
+/* ---- PatchFinder::MakeSubPixTemplate + IterateSubPixToConvergence (src/PatchFinder.cc:219-318):
+ *      inverse-compositional sub-pixel refinement of a coarse match (second half) */
+typedef struct {
+    double coarse_pos[2];   /* mv2CoarsePos, level-0 pixels (result of FindPatchCoarse) */
+    int32_t level;          /* mnSearchLevel; < 0 = skip */
+    int32_t max_its;        /* nMaxIts (8 in the tracker, src/Tracker.cc:583) */
+} ptam_subpix_query;
+typedef struct {
+    int32_t converged;      /* return value of IterateSubPixToConvergence */
+    int32_t iterations;     /* IterateSubPix calls made */
+    double pos[2];          /* mv2SubPixPos */
+    double mean_diff;       /* mdMeanDiff */
+} ptam_subpix_result;
+int ptam_subpix_batch(ptam_ctx* ctx, const ptam_kf* kf, int n, const ptam_subpix_query* queries,
+                      const uint8_t* templates, ptam_subpix_result* results);
+
 /* ---- TrackerData::Project / ProjectAndDerivs + ATANCamera (include/Tracker.h:70-94,
  *      src/ATANCamera.cc:109-121, 179-209) ------------------------------------------------------- */
 typedef struct {
@@ -141,6 +157,23 @@ typedef struct {
 } ptam_projection;
 int ptam_project_points(ptam_ctx* ctx, int n, const double* world_xyz, const double pose[12],
                         ptam_projection* out);
+
+/* ---- Tracker::TrackMap potentially-visible-set loop (src/Tracker.cc:453-478) with
+ *      PatchFinder::CalcSearchLevelAndWarpMatrix (src/PatchFinder.cc:52-84)   */
+typedef struct {
+    double world[3];          /* MapPoint::v3WorldPos */
+    double pixel_right_w[3];  /* MapPoint::v3PixelRight_W */
+    double pixel_down_w[3];   /* MapPoint::v3PixelDown_W */
+} ptam_pvs_point;
+typedef struct {
+    ptam_projection proj;     /* TData.v3Cam / v2Image / m2CamDerivs / bInImage */
+    double warp_inverse[4];   /* mm2WarpInverse row-major (valid iff proj.in_image) */
+    int32_t level;            /* nSearchLevel 0..3, or -1 (not in image, or inappropriate warp) */
+    int32_t pad_;
+} ptam_pvs_result;
+/* counts (nullable): number of points per search level = sizes of avPVS[0..3] */
+int ptam_track_pvs(ptam_ctx* ctx, int n, const ptam_pvs_point* points, const double pose[12],
+                   ptam_pvs_result* results, int32_t counts[4]);
 
 /* ---- Tracker pose Gauss-Newton (src/Tracker.cc:613-643 driver, :928-1005 CalcPoseUpdate,
  *      include/Tracker.h:125-142 CalcJacobian/LinearUpdate) ---------------------------------------- */

@@ -172,6 +172,16 @@ public:
         check(ptam_zmssd_at_points(ctx_->handle(), kf.handle(), nLevel, 1, &p, tmpl_, &v), "ptam_zmssd_at_points");
         return v;
     }
+    // void MakeSubPixTemplate(); bool IterateSubPixToConvergence(KeyFrame&, int nMaxIts)
+    //   include/PatchFinder.h:83-87, src/PatchFinder.cc:219-318 — starts at the coarse position
+    bool IterateSubPixToConvergence(KeyFrame& kf, int nMaxIts) {
+        ptam_subpix_query q{{mv2CoarsePos[0], mv2CoarsePos[1]}, mnSearchLevel, nMaxIts};
+        ptam_subpix_result r;
+        check(ptam_subpix_batch(ctx_->handle(), kf.handle(), 1, &q, tmpl_, &r), "ptam_subpix_batch");
+        mv2SubPixPos = {r.pos[0], r.pos[1]};
+        return r.converged != 0;
+    }
+    Vec<2> GetSubPixPos() const { return mv2SubPixPos; }
     Vec<2> GetCoarsePosAsVector() const { return mv2CoarsePos; }
     int GetLevel() const { return mnSearchLevel; }
     bool TemplateBad() const { return mbTemplateBad; }
@@ -181,8 +191,21 @@ private:
     uint8_t tmpl_[64] = {0};
     int mnSearchLevel = 0;
     bool mbTemplateBad = false, mbFound = false;
-    Vec<2> mv2CoarsePos{0, 0};
+    Vec<2> mv2CoarsePos{0, 0}, mv2SubPixPos{0, 0};
 };
+
+// TrackMap's potentially-visible-set loop (src/Tracker.cc:453-478): TData.Project + GetProjectionDerivs
+// + Finder.CalcSearchLevelAndWarpMatrix for every map point, one launch.
+inline void TrackMapPVS(Context& c, const std::vector<ptam_pvs_point>& vMapPoints, const SE3& se3CamFromWorld,
+                        std::vector<ptam_pvs_result>& out, int anPVSSize[PTAM_LEVELS] = nullptr) {
+    double pose[12];
+    se3CamFromWorld.to12(pose);
+    out.resize(vMapPoints.size());
+    int32_t counts[4];
+    check(ptam_track_pvs(c.handle(), (int)vMapPoints.size(), vMapPoints.data(), pose, out.data(), counts), "ptam_track_pvs");
+    if (anPVSSize)
+        for (int l = 0; l < PTAM_LEVELS; l++) anPVSSize[l] = counts[l];
+}
 
 // The part of TrackerData (include/Tracker.h:41-145) the pose loop reads
 struct TrackerDataLite {

@@ -109,6 +109,47 @@ def find_patch_coarse(levels, q, tmpl):
     return res
 
 
+# ---- sub-pixel refinement (src/PatchFinder.cc:219-318) -----------------------------------------------
+def subpix(levels, coarse_pos, level, tmpl, max_its=8):
+    """-> dict(converged, iterations, pos, mean_diff).  Gradient image + 3x3 normal matrix from the
+    template, then inverse-compositional iterations with a float32 bilinear mix."""
+    res = dict(converged=0, iterations=0, pos=np.array(coarse_pos, float), mean_diff=0.0)
+    if level < 0 or level >= LEVELS:
+        return res
+    im = levels[level]["im"]
+    h, w = im.shape
+    T = np.asarray(tmpl, np.float64).reshape(8, 8)
+    gx = 0.5 * (T[1:7, 2:8] - T[1:7, 0:6])            # [y-1][x-1]
+    gy = 0.5 * (T[2:8, 1:7] - T[0:6, 1:7])
+    G = np.stack([gx.ravel(), gy.ravel(), np.ones(36)], axis=1)
+    Hinv = np.linalg.inv(G.T @ G)
+    jx, jy = gx.astype(np.float32).astype(np.float64), gy.astype(np.float32).astype(np.float64)
+    pos, mean_diff, s = np.array(coarse_pos, float), 0.0, 1 << level
+    for it in range(max_its):
+        res["iterations"] = it + 1
+        c = (pos + 0.5) / s - 0.5
+        r = np.where(c > 0, c + 0.5, c - 0.5).astype(int)      # ir_rounded
+        if not (5 <= r[0] < w - 5 and 5 <= r[1] < h - 5):
+            break
+        base = c - 4
+        d = base - np.floor(base)
+        f32 = np.float32
+        mix = [f32((1 - d[0]) * (1 - d[1])), f32(d[0] * (1 - d[1])), f32((1 - d[0]) * d[1]), f32(d[0] * d[1])]
+        ib = base.astype(int)                                     # ir(): truncation
+        win = im[ib[1] + 1:ib[1] + 8, ib[0] + 1:ib[0] + 8].astype(np.float32)
+        pix = ((mix[0] * win[0:6, 0:6] + mix[1] * win[0:6, 1:7]) + mix[2] * win[1:7, 0:6]) + mix[3] * win[1:7, 1:7]
+        diff = pix.astype(np.float64) - T[1:7, 1:7] + mean_diff
+        acc = np.array([(diff * jx).sum(), (diff * jy).sum(), diff.sum()])
+        upd = Hinv @ acc
+        pos = pos - upd[:2] * s
+        mean_diff -= upd[2]
+        if upd[0] ** 2 + upd[1] ** 2 < 0.03 ** 2:
+            res["converged"] = 1
+            break
+    res["pos"], res["mean_diff"] = pos, mean_diff
+    return res
+
+
 # ---- ATANCamera (src/ATANCamera.cc:27-66, 109-121, 179-209) -------------------------------------
 class Camera:
     def __init__(self, params, size):
@@ -260,6 +301,29 @@ def project_points(cam, pose, world):
     inim &= ~((im[:, 0] < 0) | (im[:, 1] < 0) | (im[:, 0] > cam.size[0]) | (im[:, 1] > cam.size[1]))
     out["in_image"] = inim
     return out
+
+
+def track_pvs(cam, pose, world, pixel_right_w, pixel_down_w):
+    """TrackMap's PVS loop + CalcSearchLevelAndWarpMatrix (src/Tracker.cc:453-478, src/PatchFinder.cc:52-84)
+    -> dict(in_image, image, derivs, warp_inverse (N,2,2), level, counts)"""
+    pr = project_points(cam, pose, world)
+    R = pose[:9].reshape(3, 3)
+    Xc = pr["cam"]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        M = np.stack([pixel_right_w @ R.T, pixel_down_w @ R.T], axis=1)                  # (N,2,3)
+        W = np.einsum("nab,nkb->nak", pr["derivs"], motion_to_plane(Xc, M))              # columns = right, down
+        det = W[:, 0, 0] * W[:, 1, 1] - W[:, 0, 1] * W[:, 1, 0]
+    level = np.zeros(len(world), int)
+    for _ in range(LEVELS - 1):
+        up = (det > 3) & (level < LEVELS - 1)
+        level[up] += 1
+        det = np.where(up, det * 0.25, det)
+    bad = (det > 3) | (det < 0.25) | ~pr["in_image"] | ~np.isfinite(det)
+    level[bad] = -1
+    W[~pr["in_image"]] = 0
+    counts = np.array([(level == l).sum() for l in range(LEVELS)], np.int32)
+    return dict(in_image=pr["in_image"], image=pr["image"], derivs=pr["derivs"], cam=Xc, warp_inverse=W, level=level,
+                counts=counts)
 
 
 def calc_pose_update(found, image, s, J, override=0.0, est="Tukey", prior=100.0):

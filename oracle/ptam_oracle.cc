@@ -486,6 +486,80 @@ void find_patch_coarse(const KeyFrame& kf, const ptam_patch_query& q, const uint
     }
 }
 
+// PatchFinder::MakeSubPixTemplate + IterateSubPix(ToConvergence)  src/PatchFinder.cc:219-318.
+// libCVD's ir_rounded (round half away from zero) and ir (truncation) are restated; the bilinear
+// mix is written out in float exactly as the reference does (the oracle is built with
+// -ffp-contract=off so that no FMA is formed, like upstream's -march=nocona build).
+void subpix_refine(const KeyFrame& kf, const ptam_subpix_query& q, const uint8_t* tmpl, ptam_subpix_result& res) {
+    res.converged = 0;
+    res.iterations = 0;
+    res.pos[0] = q.coarse_pos[0];
+    res.pos[1] = q.coarse_pos[1];
+    res.mean_diff = 0.0;
+    if (q.level < 0 || q.level >= PTAM_LEVELS) return;
+    const Level& L = kf.lev[q.level];
+    const int P = PTAM_PATCH;
+    // MakeSubPixTemplate :219-240  (ir.x outer, ir.y inner)
+    float jx[6][6], jy[6][6];   // mimJacs[ir - (1,1)] indexed [y-1][x-1]
+    double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int x = 1; x < P - 1; x++)
+        for (int y = 1; y < P - 1; y++) {
+            const double gx = 0.5 * (tmpl[y * P + x + 1] - tmpl[y * P + x - 1]);
+            const double gy = 0.5 * (tmpl[(y + 1) * P + x] - tmpl[(y - 1) * P + x]);
+            jx[y - 1][x - 1] = static_cast<float>(gx);
+            jy[y - 1][x - 1] = static_cast<float>(gy);
+            const double g3[3] = {gx, gy, 1.0};
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) H[a * 3 + b] += g3[a] * g3[b];
+        }
+    double Hinv[9];
+    {
+        LDLT chol(3, H);
+        chol.inverse(Hinv);
+    }
+    double pos[2] = {q.coarse_pos[0], q.coarse_pos[1]}, mean_diff = 0.0;
+    const int scale = 1 << q.level;
+    const double dConvLimit = 0.03;
+    for (int it = 0; it < q.max_its; it++) {
+        res.iterations = it + 1;
+        // IterateSubPix :271-318
+        const double cx = (pos[0] + 0.5) / scale - 0.5, cy = (pos[1] + 0.5) / scale - 0.5;   // LevelNPos
+        const int rx = static_cast<int>(cx > 0.0 ? cx + 0.5 : cx - 0.5), ry = static_cast<int>(cy > 0.0 ? cy + 0.5 : cy - 0.5);
+        const int bord = P / 2 + 1;
+        if (!(rx >= bord && ry >= bord && rx < L.w - bord && ry < L.h - bord)) break;   // returns -1 -> false
+        const double bx = cx - 4, by = cy - 4;
+        const double dX = bx - std::floor(bx), dY = by - std::floor(by);
+        const float fTL = static_cast<float>((1.0 - dX) * (1.0 - dY)), fTR = static_cast<float>(dX * (1.0 - dY));
+        const float fBL = static_cast<float>((1.0 - dX) * dY), fBR = static_cast<float>(dX * dY);
+        const int ibx = static_cast<int>(bx), iby = static_cast<int>(by);   // ::ir() truncation
+        double acc[3] = {0, 0, 0};
+        for (int y = 1; y < P - 1; y++) {
+            const uint8_t* p = &L.im[(size_t)(iby + y) * L.w + ibx + 1];
+            for (int x = 1; x < P - 1; x++) {
+                const float fPixel = fTL * p[0] + fTR * p[1] + fBL * p[L.w] + fBR * p[L.w + 1];
+                p++;
+                const double dDiff = fPixel - tmpl[y * P + x] + mean_diff;
+                acc[0] += dDiff * jx[y - 1][x - 1];
+                acc[1] += dDiff * jy[y - 1][x - 1];
+                acc[2] += dDiff;
+            }
+        }
+        double upd[3];
+        for (int a = 0; a < 3; a++) upd[a] = Hinv[a * 3] * acc[0] + Hinv[a * 3 + 1] * acc[1] + Hinv[a * 3 + 2] * acc[2];
+        pos[0] -= upd[0] * scale;
+        pos[1] -= upd[1] * scale;
+        mean_diff -= upd[2];
+        const double d2 = upd[0] * upd[0] + upd[1] * upd[1];
+        if (d2 < dConvLimit * dConvLimit) {
+            res.converged = 1;
+            break;
+        }
+    }
+    res.pos[0] = pos[0];
+    res.pos[1] = pos[1];
+    res.mean_diff = mean_diff;
+}
+
 // ------------------------------------------------------------------------------------------------
 // TrackerData: include/Tracker.h:41-145
 // ------------------------------------------------------------------------------------------------
@@ -1178,6 +1252,70 @@ int ptamo_project_points(ptamo_ctx* c, int n, const double* world, const double 
             cam.GetProjectionDerivs(out[i].derivs);
         }
         out[i].in_image = td.bInImage;
+    }
+    return PTAM_OK;
+}
+
+int ptamo_subpix_batch(ptamo_ctx*, const ptamo_kf* k, int n, const ptam_subpix_query* q, const uint8_t* tmpl,
+                       ptam_subpix_result* res) {
+    for (int i = 0; i < n; i++) subpix_refine(k->kf, q[i], tmpl + (size_t)i * 64, res[i]);
+    return PTAM_OK;
+}
+
+// Tracker::TrackMap PVS loop src/Tracker.cc:453-478 + PatchFinder::CalcSearchLevelAndWarpMatrix
+// src/PatchFinder.cc:52-84
+int ptamo_track_pvs(ptamo_ctx* c, int n, const ptam_pvs_point* pts, const double pose[12], ptam_pvs_result* out,
+                    int32_t counts[4]) {
+    ATANCamera cam(c->c.cam);
+    const SE3 T = se3_from12(pose);
+    if (counts) counts[0] = counts[1] = counts[2] = counts[3] = 0;
+    for (int i = 0; i < n; i++) {
+        std::memset(&out[i], 0, sizeof out[i]);
+        out[i].level = -1;
+        TrackerData td;
+        std::memcpy(td.world, pts[i].world, sizeof td.world);
+        td.v2Image[0] = td.v2Image[1] = 0;
+        const bool reached = td.Project(T, cam);
+        std::memcpy(out[i].proj.cam, td.v3Cam, sizeof td.v3Cam);
+        if (reached) {
+            std::memcpy(out[i].proj.image, td.v2Image, sizeof td.v2Image);
+            cam.GetProjectionDerivs(out[i].proj.derivs);
+        }
+        out[i].proj.in_image = td.bInImage;
+        if (!td.bInImage) continue;
+        const double* D = out[i].proj.derivs;
+        double v3Cam[3];
+        se3_apply(T, pts[i].world, v3Cam);
+        const double dOneOverCameraZ = 1.0 / v3Cam[2];
+        double mr[3], md[3];
+        for (int r = 0; r < 3; r++) {
+            mr[r] = T.R[r * 3] * pts[i].pixel_right_w[0] + T.R[r * 3 + 1] * pts[i].pixel_right_w[1] + T.R[r * 3 + 2] * pts[i].pixel_right_w[2];
+            md[r] = T.R[r * 3] * pts[i].pixel_down_w[0] + T.R[r * 3 + 1] * pts[i].pixel_down_w[1] + T.R[r * 3 + 2] * pts[i].pixel_down_w[2];
+        }
+        double W[4];   // mm2WarpInverse row-major; .T()[0] = column 0
+        {
+            const double ax = (mr[0] - v3Cam[0] * mr[2] * dOneOverCameraZ) * dOneOverCameraZ;
+            const double ay = (mr[1] - v3Cam[1] * mr[2] * dOneOverCameraZ) * dOneOverCameraZ;
+            W[0] = D[0] * ax + D[1] * ay;
+            W[2] = D[2] * ax + D[3] * ay;
+            const double bx = (md[0] - v3Cam[0] * md[2] * dOneOverCameraZ) * dOneOverCameraZ;
+            const double by = (md[1] - v3Cam[1] * md[2] * dOneOverCameraZ) * dOneOverCameraZ;
+            W[1] = D[0] * bx + D[1] * by;
+            W[3] = D[2] * bx + D[3] * by;
+        }
+        std::memcpy(out[i].warp_inverse, W, sizeof W);
+        double dDet = W[0] * W[3] - W[1] * W[2];
+        int level = 0;
+        while (dDet > 3 && level < PTAM_LEVELS - 1) {
+            level++;
+            dDet *= 0.25;
+        }
+        if (dDet > 3 || dDet < 0.25)
+            out[i].level = -1;
+        else {
+            out[i].level = level;
+            if (counts) counts[level]++;
+        }
     }
     return PTAM_OK;
 }

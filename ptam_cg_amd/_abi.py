@@ -39,6 +39,18 @@ class Projection(C.Structure):
                 ("in_image", C.c_int32), ("pad_", C.c_int32)]
 
 
+class SubpixQuery(C.Structure):
+    _fields_ = [("coarse_pos", C.c_double * 2), ("level", C.c_int32), ("max_its", C.c_int32)]
+
+
+class SubpixResult(C.Structure):
+    _fields_ = [("converged", C.c_int32), ("iterations", C.c_int32), ("pos", C.c_double * 2), ("mean_diff", C.c_double)]
+
+
+class PvsPoint(C.Structure):
+    _fields_ = [("world", C.c_double * 3), ("pixel_right_w", C.c_double * 3), ("pixel_down_w", C.c_double * 3)]
+
+
 class PoseMeas(C.Structure):
     _fields_ = [("world", C.c_double * 3), ("found", C.c_double * 2), ("sqrt_inv_noise", C.c_double)]
 
@@ -96,6 +108,8 @@ PROTOTYPES = {
     "find_patch_coarse_batch_dev": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "zmssd_at_points": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "project_points": (_i, [_vp, _i, _vp, _pd, _vp]),
+    "subpix_batch": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "track_pvs": (_i, [_vp, _i, _vp, _pd, _vp, _vp]),
     "gn_opts_default": (None, [C.POINTER(GnOpts)]),
     "pose_gn": (_i, [_vp, _i, _vp, _vp, _pd, C.POINTER(GnOpts), _vp, _vp]),
     "calc_pose_update": (_i, [_vp, _i, _vp, _d, _i, _d, _pd, _vp]),

@@ -121,7 +121,146 @@ __global__ void __launch_bounds__(256) zmssd_points_kernel(KfLevels L, int lev, 
     if (lane == 0) out[i] = ssd;
 }
 
+// ------------------------------------------------------------------------------------------------
+// PatchFinder::MakeSubPixTemplate + IterateSubPixToConvergence (src/PatchFinder.cc:219-318).
+// One wave per patch, lane = template pixel (y = lane>>3, x = lane&7); the 36 interior lanes carry the
+// inverse-compositional work.  Template gradients come from neighbouring lanes by shuffle; J^T J is a
+// sum of multiples of 0.25 (exact in fp64, so order-free); the bilinear mix is done in fp32 with
+// explicit round-to-nearest multiplies/adds in the reference's order (no FMA), so the interpolated
+// pixel is bit-identical to the CPU's; the three J^T d sums are wave reductions.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ldlt3_inverse(double A[9], double out[9]) {   // TooN Cholesky<3>::get_inverse
+    for (int col = 0; col < 3; col++) {
+        double inv_diag = 1;
+        for (int row = col; row < 3; row++) {
+            double val = A[row * 3 + col];
+            for (int c2 = 0; c2 < col; c2++) val -= A[c2 * 3 + col] * A[row * 3 + c2];
+            if (row == col) {
+                A[row * 3 + col] = val;
+                inv_diag = 1 / val;
+            } else {
+                A[col * 3 + row] = val;
+                A[row * 3 + col] = val * inv_diag;
+            }
+        }
+    }
+    for (int c = 0; c < 3; c++) {
+        double y[3], x[3];
+        for (int i = 0; i < 3; i++) {
+            double val = (i == c) ? 1.0 : 0.0;
+            for (int j = 0; j < i; j++) val -= A[i * 3 + j] * y[j];
+            y[i] = val;
+        }
+        for (int i = 0; i < 3; i++) y[i] /= A[i * 3 + i];
+        for (int i = 2; i >= 0; i--) {
+            double val = y[i];
+            for (int j = i + 1; j < 3; j++) val -= A[j * 3 + i] * x[j];
+            x[i] = val;
+        }
+        for (int r = 0; r < 3; r++) out[r * 3 + c] = x[r];
+    }
+}
+
+__global__ void __launch_bounds__(256) subpix_kernel(KfLevels L, int n, const ptam_subpix_query* __restrict__ queries,
+                                                     const uint8_t* __restrict__ templates,
+                                                     ptam_subpix_result* __restrict__ results) {
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= n) return;
+    const ptam_subpix_query q = queries[qi];
+    ptam_subpix_result res;
+    res.converged = 0;
+    res.iterations = 0;
+    res.pos[0] = q.coarse_pos[0];
+    res.pos[1] = q.coarse_pos[1];
+    res.mean_diff = 0.0;
+    if (q.level >= 0 && q.level < PTAM_LEVELS) {
+        const int w = L.w[q.level], h = L.h[q.level];
+        const uint8_t* __restrict__ im = L.im[q.level];
+        const int px = lane & 7, py = lane >> 3;
+        const bool inner = px >= 1 && px <= 6 && py >= 1 && py <= 6;
+        const int T = templates[(size_t)qi * 64 + lane];
+        // MakeSubPixTemplate :219-240
+        const int Txp = __shfl(T, (lane + 1) & 63, 64), Txm = __shfl(T, (lane - 1) & 63, 64);
+        const int Typ = __shfl(T, (lane + 8) & 63, 64), Tym = __shfl(T, (lane - 8) & 63, 64);
+        const double gx = inner ? 0.5 * (Txp - Txm) : 0.0, gy = inner ? 0.5 * (Typ - Tym) : 0.0;
+        const double one = inner ? 1.0 : 0.0;
+        double H[9];
+        H[0] = wave_sum_f64(gx * gx);
+        H[1] = H[3] = wave_sum_f64(gx * gy);
+        H[2] = H[6] = wave_sum_f64(gx * one);
+        H[4] = wave_sum_f64(gy * gy);
+        H[5] = H[7] = wave_sum_f64(gy * one);
+        H[8] = wave_sum_f64(one);
+        double Hinv[9];
+        ldlt3_inverse(H, Hinv);
+        const double jx = (double)(float)gx, jy = (double)(float)gy;   // mimJacs holds floats
+        double pos0 = q.coarse_pos[0], pos1 = q.coarse_pos[1], mean_diff = 0.0;
+        const int scale = 1 << q.level;
+        for (int it = 0; it < q.max_its; it++) {
+            res.iterations = it + 1;
+            // IterateSubPix :271-318
+            const double cx = (pos0 + 0.5) / scale - 0.5, cy = (pos1 + 0.5) / scale - 0.5;   // LevelNPos
+            const int rx = (int)(cx > 0.0 ? cx + 0.5 : cx - 0.5), ry = (int)(cy > 0.0 ? cy + 0.5 : cy - 0.5);   // ir_rounded
+            if (!(rx >= 5 && ry >= 5 && rx < w - 5 && ry < h - 5)) break;
+            const double bx = cx - 4, by = cy - 4;
+            const double dX = bx - floor(bx), dY = by - floor(by);
+            const float fTL = (float)((1.0 - dX) * (1.0 - dY)), fTR = (float)(dX * (1.0 - dY));
+            const float fBL = (float)((1.0 - dX) * dY), fBR = (float)(dX * dY);
+            const int ibx = (int)bx, iby = (int)by;   // ::ir() truncation
+            double d0 = 0, d1 = 0, d2 = 0;
+            if (inner) {
+                const uint8_t* p = im + (size_t)(iby + py) * w + ibx + px;
+                const float fPixel = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(fTL, (float)p[0]), __fmul_rn(fTR, (float)p[1])),
+                                                         __fmul_rn(fBL, (float)p[w])),
+                                               __fmul_rn(fBR, (float)p[w + 1]));
+                const double dDiff = (double)fPixel - (double)T + mean_diff;
+                d0 = dDiff * jx;
+                d1 = dDiff * jy;
+                d2 = dDiff;
+            }
+            const double a0 = wave_sum_f64(d0), a1 = wave_sum_f64(d1), a2 = wave_sum_f64(d2);
+            const double u0 = Hinv[0] * a0 + Hinv[1] * a1 + Hinv[2] * a2;
+            const double u1 = Hinv[3] * a0 + Hinv[4] * a1 + Hinv[5] * a2;
+            const double u2 = Hinv[6] * a0 + Hinv[7] * a1 + Hinv[8] * a2;
+            pos0 -= u0 * scale;
+            pos1 -= u1 * scale;
+            mean_diff -= u2;
+            if (u0 * u0 + u1 * u1 < 0.03 * 0.03) {
+                res.converged = 1;
+                break;
+            }
+        }
+        res.pos[0] = pos0;
+        res.pos[1] = pos1;
+        res.mean_diff = mean_diff;
+    }
+    if (lane == 0) results[qi] = res;
+}
+
 extern "C" {
+
+int ptam_subpix_batch(ptam_ctx* ctx, const ptam_kf* kf, int n, const ptam_subpix_query* queries, const uint8_t* templates,
+                      ptam_subpix_result* results) {
+    ARG_TRY(ctx && kf && n >= 0);
+    if (n == 0) return PTAM_OK;
+    ARG_TRY(queries && templates && results);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t bq = (size_t)n * sizeof(ptam_subpix_query), bt = (size_t)n * 64, br = (size_t)n * sizeof(ptam_subpix_result);
+    void* s;
+    int rc = ctx_scratch(ctx, bq + bt + br, &s);
+    if (rc) return rc;
+    ptam_subpix_query* d_q = (ptam_subpix_query*)s;
+    ptam_subpix_result* d_r = (ptam_subpix_result*)((char*)s + bq);
+    uint8_t* d_t = (uint8_t*)s + bq + br;
+    HIP_TRY(hipMemcpyAsync(d_q, queries, bq, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_t, templates, bt, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(subpix_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, kf->L, n, d_q, d_t, d_r);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(results, d_r, br, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PTAM_OK;
+}
 
 int ptam_find_patch_coarse_batch_dev(ptam_ctx* ctx, const ptam_kf* kf, int n, const ptam_patch_query* d_q,
                                      const uint8_t* d_t, ptam_patch_result* d_r) {

@@ -24,6 +24,10 @@ PROJECTION_DT = np.dtype([("cam", "<f8", (3,)), ("image", "<f8", (2,)), ("derivs
 POSE_MEAS_DT = np.dtype([("world", "<f8", (3,)), ("found", "<f8", (2,)), ("sqrt_inv_noise", "<f8")])
 POSE_UPDATE_MEAS_DT = np.dtype([("found", "<f8", (2,)), ("image", "<f8", (2,)), ("sqrt_inv_noise", "<f8"),
                                 ("jac", "<f8", (12,))])
+SUBPIX_QUERY_DT = np.dtype([("coarse_pos", "<f8", (2,)), ("level", "<i4"), ("max_its", "<i4")])
+SUBPIX_RESULT_DT = np.dtype([("converged", "<i4"), ("iterations", "<i4"), ("pos", "<f8", (2,)), ("mean_diff", "<f8")])
+PVS_POINT_DT = np.dtype([("world", "<f8", (3,)), ("pixel_right_w", "<f8", (3,)), ("pixel_down_w", "<f8", (3,))])
+PVS_RESULT_DT = np.dtype([("proj", PROJECTION_DT), ("warp_inverse", "<f8", (4,)), ("level", "<i4"), ("pad_", "<i4")])
 BA_TRIAL_DT = np.dtype([("lambda", "<f8"), ("sigma_sq", "<f8"), ("err_old", "<f8"), ("err_new", "<f8"),
                         ("sum_sq_update", "<f8"), ("n_bad", "<i4"), ("accepted", "<i4")])
 assert PATCH_RESULT_DT.itemsize == C.sizeof(PatchResult)
@@ -89,6 +93,17 @@ class Context:
         self._check(self.lib.project_points(self.h, len(world), _ptr(world), _pd(pose), _ptr(out)),
                     "project_points")
         return out
+
+    # -- TrackMap PVS loop + CalcSearchLevelAndWarpMatrix (src/Tracker.cc:453-478, src/PatchFinder.cc:52-84) --
+    def track_pvs(self, world, pixel_right_w, pixel_down_w, pose):
+        n = len(world)
+        pts = np.zeros(n, dtype=PVS_POINT_DT)
+        pts["world"], pts["pixel_right_w"], pts["pixel_down_w"] = world, pixel_right_w, pixel_down_w
+        pose = np.ascontiguousarray(pose, dtype=np.float64).reshape(12)
+        out = np.zeros(n, dtype=PVS_RESULT_DT)
+        counts = np.zeros(4, dtype=np.int32)
+        self._check(self.lib.track_pvs(self.h, n, _ptr(pts), _pd(pose), _ptr(out), _ptr(counts)), "track_pvs")
+        return out, counts
 
     # -- Tracker pose Gauss-Newton (src/Tracker.cc:613-643) --
     def gn_opts(self, **kw):
@@ -182,6 +197,16 @@ class PatchFinder:
         res = np.zeros(len(queries), dtype=PATCH_RESULT_DT)
         self.ctx._check(self.lib.find_patch_coarse_batch(self.ctx.h, kf.h, len(queries), _ptr(queries),
                                                          _ptr(templates), _ptr(res)), "find_patch_coarse")
+        return res
+
+    def SubPix(self, kf, coarse_pos, levels, templates, max_its=8):
+        """MakeSubPixTemplate + IterateSubPixToConvergence for a batch (src/PatchFinder.cc:219-318)"""
+        n = len(coarse_pos)
+        q = np.zeros(n, dtype=SUBPIX_QUERY_DT)
+        q["coarse_pos"], q["level"], q["max_its"] = coarse_pos, levels, max_its
+        templates = np.ascontiguousarray(templates, dtype=np.uint8).reshape(n, 64)
+        res = np.zeros(n, dtype=SUBPIX_RESULT_DT)
+        self.ctx._check(self.lib.subpix_batch(self.ctx.h, kf.h, n, _ptr(q), _ptr(templates), _ptr(res)), "subpix_batch")
         return res
 
     def ZMSSDAtPoint(self, kf, level, points, template):

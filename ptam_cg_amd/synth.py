@@ -178,6 +178,24 @@ def make_pose_case(n=1000, seed=SEED_POSE, camera=DEFAULT_CAMERA, size=(640, 480
             "init_pose": init_pose, "true_pose": true_pose, "is_outlier": out[keep]}
 
 
+def make_pvs_case(n=4000, seed=0x5EED0007, camera=DEFAULT_CAMERA, size=(640, 480)):
+    """Map points for TrackMap's PVS loop: positions (many outside the view), and the world-frame
+    one-pixel-right / one-pixel-down vectors MapPoint::RefreshPixelVectors (src/Map.cc:40-65) would give
+    for a fronto-parallel patch seen from a source keyframe at pyramid level l."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    cam = AtanCam(camera, size)
+    pc = make_pose_case(n=16, seed=seed + 1, camera=camera, size=size)
+    src_pose, cur_pose = pc["true_pose"], pc["init_pose"]
+    world = np.column_stack([rng.uniform(-0.9, 0.9, n), rng.uniform(-0.9, 0.9, n), rng.uniform(-0.3, 1.6, n)])
+    R = src_pose[:9].reshape(3, 3)
+    depth = (world @ R.T + src_pose[9:])[:, 2]
+    lv = rng.choice(4, size=n, p=LEVEL_MIX)
+    scale = rng.uniform(0.3, 3.0, n) * (2.0 ** lv) * np.abs(depth) / cam.focal[0]
+    right = scale[:, None] * R[0] + rng.normal(0, 0.02, (n, 3)) * scale[:, None]
+    down = scale[:, None] * (cam.focal[0] / cam.focal[1]) * R[1] + rng.normal(0, 0.02, (n, 3)) * scale[:, None]
+    return {"world": world, "pixel_right_w": right, "pixel_down_w": down, "pose": cur_pose}
+
+
 # ---------------------------------------------------------------------------------------------
 # bundle problems
 # ---------------------------------------------------------------------------------------------

@@ -48,8 +48,24 @@ def main():
                         n_scored=np.array([r["n_scored"] for r in res], np.int32),
                         pos=np.array([r["pos"] for r in res], np.float64))
     print("patch found", sum(r["found"] for r in res), "of", len(res))
+    # --- sub-pixel refinement of the found patches ---
+    ok = np.flatnonzero([r["found"] for r in res])
+    sp = [npo.subpix(lb, res[i]["pos"], int(q[i]["level"]), t[i], 8) for i in ok]
+    np.savez_compressed(os.path.join(OUT, "subpix_160x128.npz"), im=b, coarse_pos=np.array([res[i]["pos"] for i in ok]),
+                        level=q["level"][ok], templates=t[ok], converged=np.array([r["converged"] for r in sp], np.int32),
+                        iterations=np.array([r["iterations"] for r in sp], np.int32), pos=np.array([r["pos"] for r in sp]),
+                        mean_diff=np.array([r["mean_diff"] for r in sp]))
+    print("subpix converged", sum(r["converged"] for r in sp), "of", len(sp))
     # --- pose Gauss-Newton (fine and coarse schedules) ---
     cam = npo.Camera(CAM, (640, 480))
+    # --- PVS loop ---
+    pv = synth.make_pvs_case(n=1500)
+    r = npo.track_pvs(cam, pv["pose"], pv["world"], pv["pixel_right_w"], pv["pixel_down_w"])
+    np.savez_compressed(os.path.join(OUT, "pvs_1500.npz"), world=pv["world"], pixel_right_w=pv["pixel_right_w"],
+                        pixel_down_w=pv["pixel_down_w"], pose=pv["pose"], in_image=r["in_image"], image=r["image"],
+                        derivs=r["derivs"].reshape(-1, 4), warp_inverse=r["warp_inverse"].reshape(-1, 4), level=r["level"],
+                        counts=r["counts"])
+    print("pvs counts", r["counts"], "in image", int(r["in_image"].sum()))
     pc = synth.make_pose_case(n=250)
     pf, ff, uf = npo.pose_gn(cam, pc["world"], pc["found"], pc["sqrt_inv_noise"], pc["init_pose"])
     pcs, fc, uc = npo.pose_gn(cam, pc["world"], pc["found"], pc["sqrt_inv_noise"], pc["init_pose"],

@@ -23,3 +23,11 @@ def test_pose(hip):
 @pytest.mark.parametrize("name", ["ba_8x50", "ba_20x300", "ba_banded_30x200"])
 def test_bundle(hip, name):
     G.check_ba(hip, name)
+
+
+def test_subpix(hip):
+    G.check_subpix(hip)
+
+
+def test_pvs(hip):
+    G.check_pvs(hip)

@@ -203,3 +203,31 @@ def test_bundle_abort_and_limits(hip):
     assert len(ba2.trials()) == 3                           # Bundle.MaxIterations counts lambda trials
     with pytest.raises(host.PtamError):
         ba2.AddMeas(99, 0, [1.0, 2.0], 1.0)                 # unknown camera id
+
+
+def test_subpix_matches_oracle(hip, oracle):
+    ctx_h, kf_h, q, t = _patch_case(hip, 10, n=600)
+    ctx_o, kf_o, _, _ = _patch_case(oracle, 10, n=600)
+    r = host.PatchFinder(ctx_o).FindPatchCoarse(kf_o, q, t)
+    ok = np.flatnonzero(r["found"])
+    pos, lv = r["pos"][ok], q["level"][ok].copy()
+    lv[0] = -1                                                   # skipped query
+    pos[1] = (2.0, 2.0)                                          # border: fails on the first iteration
+    sh = host.PatchFinder(ctx_h).SubPix(kf_h, pos, lv, t[ok], 8)
+    so = host.PatchFinder(ctx_o).SubPix(kf_o, pos, lv, t[ok], 8)
+    assert np.array_equal(sh["converged"], so["converged"]) and np.array_equal(sh["iterations"], so["iterations"])
+    assert np.allclose(sh["pos"], so["pos"], rtol=0, atol=1e-9)
+    assert np.allclose(sh["mean_diff"], so["mean_diff"], rtol=0, atol=1e-9)
+    assert so["converged"].mean() > 0.8
+
+
+def test_track_pvs_matches_oracle(hip, oracle):
+    pv = synth.make_pvs_case()
+    rh, ch = host.Context(lib=hip).track_pvs(pv["world"], pv["pixel_right_w"], pv["pixel_down_w"], pv["pose"])
+    ro, co = host.Context(lib=oracle).track_pvs(pv["world"], pv["pixel_right_w"], pv["pixel_down_w"], pv["pose"])
+    assert np.array_equal(rh["level"], ro["level"]) and np.array_equal(ch, co)
+    assert np.array_equal(rh["proj"]["in_image"], ro["proj"]["in_image"])
+    for f in ("cam", "image", "derivs"):
+        assert np.allclose(rh["proj"][f], ro["proj"][f], rtol=1e-12, atol=1e-9), f
+    assert np.allclose(rh["warp_inverse"], ro["warp_inverse"], rtol=1e-11, atol=1e-12)
+    assert (co > 0).all() and (ro["level"] == -1).sum() > 0

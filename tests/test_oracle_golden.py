@@ -21,3 +21,11 @@ def test_pose(oracle):
 @pytest.mark.parametrize("name", ["ba_8x50", "ba_20x300", "ba_banded_30x200"])
 def test_bundle(oracle, name):
     G.check_ba(oracle, name)
+
+
+def test_subpix(oracle):
+    G.check_subpix(oracle)
+
+
+def test_pvs(oracle):
+    G.check_pvs(oracle)

@@ -253,3 +253,47 @@ def test_pose_update_empty_and_prior(oracle):
     mu, flags = ctx.calc_pose_update(found, image, np.array([1.0]), J, override_sigma_sq=16.0)
     w = (1 - 4.0 / 16.0) ** 2
     assert mu[0] == pytest.approx(w * 2.0 / (100 + w), rel=1e-12) and abs(mu[1]) < 1e-15 and flags[0] == 0
+
+
+def test_subpix_recovers_a_known_shift(oracle):
+    """a smooth blob shifted by a known sub-pixel offset: the inverse-compositional refinement must
+    land on the true position (error << 0.1 px) and report convergence"""
+    yy, xx = np.mgrid[0:64, 0:64].astype(float)
+
+    def blob(cx, cy):
+        return np.clip(40 + 180 * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / 30.0), 0, 255).round().astype(np.uint8)
+
+    src = blob(30.0, 28.0)
+    tmpl = src[24:32, 26:34]                                    # window centred on (30, 28)
+    for dx, dy in ((0.3, -0.4), (-0.45, 0.2), (0.0, 0.0)):
+        im = blob(30.0 + dx, 28.0 + dy)
+        ctx, kf = _kf(oracle, im)
+        r = host.PatchFinder(ctx).SubPix(kf, [[30.0, 28.0]], [0], tmpl.reshape(1, 64), 10)
+        assert r["converged"][0] == 1
+        assert abs(r["pos"][0][0] - (30.0 + dx)) < 0.06 and abs(r["pos"][0][1] - (28.0 + dy)) < 0.06
+    # too close to the border: IterateSubPix returns -1 on the first call -> not converged, one iteration
+    r = host.PatchFinder(ctx).SubPix(kf, [[3.0, 28.0]], [0], tmpl.reshape(1, 64), 10)
+    assert r["converged"][0] == 0 and r["iterations"][0] == 1 and tuple(r["pos"][0]) == (3.0, 28.0)
+
+
+def test_pvs_levels_follow_the_warp_determinant(oracle):
+    """fronto-parallel point on the optical axis at depth Z, pixel vectors s*(1,0,0) and s*(0,1,0):
+    WarpInverse = diag(fx*s/Z, fy*s/Z); the level is the number of x0.25 steps that bring det <= 3"""
+    ctx = host.Context(lib=oracle)
+    k = ctx.camera_constants()
+    pose = np.concatenate([np.eye(3).ravel(), [0, 0, 0]])
+    Z = 2.0
+    cases = []
+    for want, det in ((0, 1.0), (0, 2.9), (1, 3.5), (1, 11.9), (2, 13.0), (3, 60.0), (3, 191.0), (-1, 200.0), (-1, 0.2)):
+        s = np.sqrt(det * Z * Z / (k["focal_x"] * k["focal_y"]))
+        cases.append((want, s))
+    world = np.tile([0.0, 0.0, Z], (len(cases), 1))
+    right = np.array([[s, 0, 0] for _, s in cases])
+    down = np.array([[0, s, 0] for _, s in cases])
+    r, counts = ctx.track_pvs(world, right, down, pose)
+    assert list(r["level"]) == [w for w, _ in cases]
+    assert list(counts) == [2, 2, 1, 2]
+    assert np.allclose(r["warp_inverse"][:, 0], k["focal_x"] * right[:, 0] / Z) and not r["warp_inverse"][:, 1].any()
+    # behind the camera / outside the image: not in the PVS, level -1
+    r2, c2 = ctx.track_pvs([[0, 0, -1.0], [5.0, 0, 1.0]], right[:2], down[:2], pose)
+    assert list(r2["level"]) == [-1, -1] and not r2["proj"]["in_image"].any() and not c2.any()
