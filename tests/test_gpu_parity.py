@@ -231,3 +231,41 @@ def test_track_pvs_matches_oracle(hip, oracle):
         assert np.allclose(rh["proj"][f], ro["proj"][f], rtol=1e-12, atol=1e-9), f
     assert np.allclose(rh["warp_inverse"], ro["warp_inverse"], rtol=1e-11, atol=1e-12)
     assert (co > 0).all() and (ro["level"] == -1).sum() > 0
+
+
+def test_two_host_threads_two_contexts(hip, oracle):
+    """The reference enters this path from two OS threads (tracker: keyframes / search / pose,
+    mapmaker: bundle adjustment, src/MapMaker.cc:57).  One context per thread, run concurrently;
+    both must reproduce the single-threaded results."""
+    import threading
+    a, b = synth.make_frame_pair()
+    prob = synth.make_ba_problem(12, 400, 17)
+    want_kf = util.keyframe_levels(oracle, b)
+    want_ba = util.run_ba(oracle, prob)
+    pc = synth.make_pose_case(n=500)
+    want_pose = host.Context(lib=oracle).pose_gn(pc["world"], pc["found"], pc["sqrt_inv_noise"], pc["init_pose"])[0]
+    errors = []
+
+    def tracker():
+        try:
+            ctx = host.Context(lib=hip)
+            kf = host.KeyFrame(ctx)
+            for _ in range(30):
+                kf.MakeKeyFrame_Lite(b)
+                util.assert_levels_equal([kf.level(l) for l in range(4)], want_kf)
+                p = ctx.pose_gn(pc["world"], pc["found"], pc["sqrt_inv_noise"], pc["init_pose"])[0]
+                assert np.allclose(p, want_pose, atol=1e-10)
+        except Exception as e:  # noqa: BLE001
+            errors.append(("tracker", e))
+
+    def mapmaker():
+        try:
+            for _ in range(6):
+                util.assert_ba_equal(util.run_ba(hip, prob), want_ba)
+        except Exception as e:  # noqa: BLE001
+            errors.append(("mapmaker", e))
+
+    ts = [threading.Thread(target=tracker), threading.Thread(target=mapmaker)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
