@@ -502,12 +502,13 @@ __device__ __forceinline__ void jac_measure(const DevCam& cam, const BaDev& d, c
 }
 
 // flush a workgroup's camera partials + error partial (end of both accumulate kernels)
+template <int THREADS>
 __device__ __forceinline__ void jac_flush(const BaDev& d, const double* Ul, double err, int nbad) {
-    __shared__ double werr[BA_CHUNK / 64];
-    __shared__ int wbad[BA_CHUNK / 64];
+    __shared__ double werr[THREADS / 64];
+    __shared__ int wbad[THREADS / 64];
     const int tid = threadIdx.x;
     double* up = d.Upart + (size_t)blockIdx.x * d.F * 27;
-    for (int k = tid; k < d.F * 27; k += BA_CHUNK) up[k] = Ul[k];
+    for (int k = tid; k < d.F * 27; k += THREADS) up[k] = Ul[k];
     err = wave_sum_f64(err);
     nbad = wave_sum_i32(nbad);
     if ((tid & 63) == 0) {
@@ -518,7 +519,7 @@ __device__ __forceinline__ void jac_flush(const BaDev& d, const double* Ul, doub
     if (tid == 0) {
         double e = 0;
         int b = 0;
-        for (int i = 0; i < BA_CHUNK / 64; i++) {
+        for (int i = 0; i < THREADS / 64; i++) {
             e += werr[i];
             b += wbad[i];
         }
@@ -583,24 +584,24 @@ __device__ __forceinline__ void k7_load(const BaDev& d, const double* __restrict
 #else
 #define K7_STAMP(i)
 #endif
-template <int MINW, bool PREFETCH>
-__global__ void __launch_bounds__(BA_CHUNK, MINW) jac_accum_wave_kernel(DevCam cam, BaDev d, int cur, int est, int per_wave) {
+template <int THREADS, bool PREFETCH, bool LOOP>
+__global__ void __launch_bounds__(THREADS) jac_accum_wave_kernel(DevCam cam, BaDev d, int cur, int est, int per_wave) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Ul = smem;
     double* Ps = smem + (((size_t)d.F * 27 + 1) & ~(size_t)1);
     const int tid = threadIdx.x, lane = tid & 63;
     const double* __restrict__ pt = d.pt[cur];
     const int n_chunks64 = (d.M + 63) >> 6;
-    const int c_begin = (blockIdx.x * (BA_CHUNK / 64) + (tid >> 6)) * per_wave;
+    const int c_begin = (blockIdx.x * (THREADS / 64) + (tid >> 6)) * per_wave;
     const int c_end = min(n_chunks64, c_begin + per_wave);
     // first chunk's loads and sigma^2 go out before the LDS prologue, so both latencies overlap it
     K7In in;
     if (PREFETCH && c_begin < c_end) k7_load(d, pt, c_begin << 6, lane, in);
     const double sigma_sq = d.sc->sigma_sq;
-    for (int k = tid; k < d.F * 27; k += BA_CHUNK) Ul[k] = 0;
+    for (int k = tid; k < d.F * 27; k += THREADS) Ul[k] = 0;
     {
         const double* __restrict__ pose = d.pose[cur];
-        for (int k = tid; k < d.C * 12; k += BA_CHUNK) Ps[k] = pose[k];
+        for (int k = tid; k < d.C * 12; k += THREADS) Ps[k] = pose[k];
     }
     __syncthreads();
     K7_STAMP(0)
@@ -608,7 +609,7 @@ __global__ void __launch_bounds__(BA_CHUNK, MINW) jac_accum_wave_kernel(DevCam c
     double err = 0;
     int nbad = 0;
     K7_STAMP(1)
-    for (int ci = c_begin; ci < c_end; ci++) {
+    for (int ci = c_begin; ci < c_end; ci++) {   // (LOOP == false: exactly one chunk per wave, see the break below)
         const int m0 = ci << 6;
         const int m = m0 + lane;
         const bool active = m < d.M;
@@ -718,22 +719,24 @@ __global__ void __launch_bounds__(BA_CHUNK, MINW) jac_accum_wave_kernel(DevCam c
         // the row carries (row_bcast15 into rows 1,3; row_bcast31 into rows 2,3).  Segments are
         // contiguous, so "the source lane has my point id" implies every lane in between has it too.
         K7_STAMP(6)
-        const int SENT = (int)0x80000000;
+        // ids are compared as pid + 1 so that the 0 a row-shift returns for "no source lane" never
+        // matches a real point (inactive lanes carry zeros, a spurious match there adds 0)
+        const int pid1 = pid + 1;
 #define SEG_STEP(GETP, GETV)                                             \
     {                                                                    \
         const int po = GETP;                                             \
         double t[9];                                                     \
         _Pragma("unroll") for (int i = 0; i < 9; i++) t[i] = GETV;       \
-        if (po == pid) {                                                 \
+        if (po == pid1) {                                                \
             _Pragma("unroll") for (int i = 0; i < 9; i++) v[i] += t[i];  \
         }                                                                \
     }
-        SEG_STEP(dpp_row_shr_i32<1>(SENT, pid), dpp_row_shr_f64<1>(v[i]))
-        SEG_STEP(dpp_row_shr_i32<2>(SENT, pid), dpp_row_shr_f64<2>(v[i]))
-        SEG_STEP(dpp_row_shr_i32<4>(SENT, pid), dpp_row_shr_f64<4>(v[i]))
-        SEG_STEP(dpp_row_shr_i32<8>(SENT, pid), dpp_row_shr_f64<8>(v[i]))
-        SEG_STEP((dpp_bcast_i32<0x142, 0xa>(SENT, pid)), (dpp_bcast_f64<0x142, 0xa>(v[i])))
-        SEG_STEP((dpp_bcast_i32<0x143, 0xc>(SENT, pid)), (dpp_bcast_f64<0x143, 0xc>(v[i])))
+        SEG_STEP(dpp_row_shr0_i32<1>(pid1), dpp_row_shr_f64<1>(v[i]))
+        SEG_STEP(dpp_row_shr0_i32<2>(pid1), dpp_row_shr_f64<2>(v[i]))
+        SEG_STEP(dpp_row_shr0_i32<4>(pid1), dpp_row_shr_f64<4>(v[i]))
+        SEG_STEP(dpp_row_shr0_i32<8>(pid1), dpp_row_shr_f64<8>(v[i]))
+        SEG_STEP((dpp_bcast_i32<0x142, 0xa>(0, pid1)), (dpp_bcast_f64<0x142, 0xa>(v[i])))
+        SEG_STEP((dpp_bcast_i32<0x143, 0xc>(0, pid1)), (dpp_bcast_f64<0x143, 0xc>(v[i])))
 #undef SEG_STEP
         K7_STAMP(7)
         const int pn = __shfl_down(pid, 1, 64);
@@ -755,10 +758,11 @@ __global__ void __launch_bounds__(BA_CHUNK, MINW) jac_accum_wave_kernel(DevCam c
                 atomicAdd(&Ep[2], v[8]);
             }
         }
+        if (!LOOP) break;
     }
     K7_STAMP(8)
     __syncthreads();
-    jac_flush(d, Ul, err, nbad);
+    jac_flush<THREADS>(d, Ul, err, nbad);
     K7_STAMP(9)
 }
 
@@ -834,7 +838,7 @@ __global__ void __launch_bounds__(BA_CHUNK) jac_accum_kernel(DevCam cam, BaDev d
         __syncthreads();
     }
     __syncthreads();
-    jac_flush(d, Ul, err, nbad);
+    jac_flush<BA_CHUNK>(d, Ul, err, nbad);
 }
 
 // fixed-order sum over the accumulate grid.  Stage A (this kernel): grid (column groups of 64,
@@ -1468,6 +1472,8 @@ struct ptam_ba {
     size_t smem_acc = 0;
     bool use_wave = false;
     int per_wave = 1;
+    int k7_threads = BA_CHUNK;
+    bool k7_loop = false;
     std::vector<int> sorted_orig;   // sorted position -> insertion index
     // gather buffers (sharded mode)
     double* d_gather = nullptr;
@@ -1652,15 +1658,21 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.n_schur_entries = (int)s_entries.size();
     // persistent grid of the accumulate kernel: bounded by LDS residency, 2 x 256 CUs by default
     ba->smem_acc = ((((size_t)F * 27 + 1) & ~(size_t)1) + (ba->use_wave ? (size_t)C * 12 : (size_t)BA_CHUNK * 8)) * sizeof(double);
-    const void* k7 = ba->use_wave ? (const void*)jac_accum_wave_kernel<1, true> : (const void*)jac_accum_kernel;
-    if (ba->smem_acc > 160 * 1024) {
-        ptam_set_error("%d free cameras exceed the LDS budget of the accumulate kernel", F);
-        return PTAM_E_LIMIT;
-    }
+    // wave variant, two shapes:
+    //  - few chunks (every 64-measurement chunk can be resident at once: <= 24 waves per CU):
+    //    straight-line kernel, ONE chunk per wave, 512-thread workgroups (64 VGPRs);
+    //  - many chunks: persistent 256-thread workgroups looping over `per_wave` consecutive chunks,
+    //    which amortises the LDS prologue and the camera-partial flush.
+    const int n64_all = (M + 63) / 64;
+    ba->k7_loop = ba->use_wave && n64_all > 256 * 24;
+    ba->k7_threads = !ba->use_wave ? BA_CHUNK : (ba->k7_loop ? 256 : 512);
+    const void* k7 = !ba->use_wave ? (const void*)jac_accum_kernel
+                     : ba->k7_loop ? (const void*)jac_accum_wave_kernel<256, false, true>
+                                   : (const void*)jac_accum_wave_kernel<512, false, false>;
     if (ba->smem_acc > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(k7, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba->smem_acc));
     int per_cu = 0, n_cu = 256;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k7, BA_CHUNK, ba->smem_acc));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k7, ba->k7_threads, ba->smem_acc));
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
@@ -1669,9 +1681,11 @@ static int ba_prepare_impl(ptam_ba* ba) {
     per_cu = std::max(1, std::min(per_cu, 8));
     if (ba->use_wave) {
         // every wave gets the same number of consecutive 64-measurement chunks
-        const int n64 = (M + 63) / 64, slots = n_cu * per_cu * (BA_CHUNK / 64);
-        ba->per_wave = std::max(1, (n64 + slots - 1) / slots);
-        d.grid_acc = std::max(1, (n64 + ba->per_wave * (BA_CHUNK / 64) - 1) / (ba->per_wave * (BA_CHUNK / 64)));
+        // one 64-measurement chunk per wave (straight-line kernel body: 68 VGPRs instead of ~160 for the
+        // looping form, i.e. every chunk of a 250 k-measurement problem is resident at once)
+        const int n64 = (M + 63) / 64, slots = n_cu * per_cu * (ba->k7_threads / 64);
+        ba->per_wave = ba->k7_loop ? std::max(1, (n64 + slots - 1) / slots) : 1;
+        d.grid_acc = std::max(1, (n64 + ba->per_wave * (ba->k7_threads / 64) - 1) / (ba->per_wave * (ba->k7_threads / 64)));
     } else
         d.grid_acc = std::max(1, std::min(d.n_chunks, n_cu * per_cu));
 
@@ -1885,8 +1899,12 @@ static int ba_pass1_sigma(ptam_ba* ba) {
 static void launch_k7(ptam_ba* ba) {
     ptam_ctx* ctx = ba->ctx;
     if (ba->use_wave) {
-        hipLaunchKernelGGL((jac_accum_wave_kernel<1, true>), dim3(ba->d.grid_acc), dim3(BA_CHUNK), ba->smem_acc, ctx->stream,
-                           ctx->cam, ba->d, ba->cur, ba->opts.estimator, ba->per_wave);
+        if (ba->k7_loop)
+            hipLaunchKernelGGL((jac_accum_wave_kernel<256, false, true>), dim3(ba->d.grid_acc), dim3(256), ba->smem_acc,
+                               ctx->stream, ctx->cam, ba->d, ba->cur, ba->opts.estimator, ba->per_wave);
+        else
+            hipLaunchKernelGGL((jac_accum_wave_kernel<512, false, false>), dim3(ba->d.grid_acc), dim3(512), ba->smem_acc,
+                               ctx->stream, ctx->cam, ba->d, ba->cur, ba->opts.estimator, ba->per_wave);
     }
     else
         hipLaunchKernelGGL(jac_accum_kernel, dim3(ba->d.grid_acc), dim3(BA_CHUNK), ba->smem_acc, ctx->stream, ctx->cam, ba->d,

@@ -198,11 +198,16 @@ template <int SHR>
 __device__ __forceinline__ int dpp_row_shr_i32(int old, int src) {
     return __builtin_amdgcn_update_dpp(old, src, 0x110 + SHR, 0xf, 0xf, false);
 }
+// bound_ctrl form: lanes without a source read 0 (no `old` operand to materialise)
+template <int SHR>
+__device__ __forceinline__ int dpp_row_shr0_i32(int src) {
+    return __builtin_amdgcn_update_dpp(src, src, 0x110 + SHR, 0xf, 0xf, true);
+}
 template <int SHR>
 __device__ __forceinline__ double dpp_row_shr_f64(double src) {
     const long long b = __double_as_longlong(src);
-    const int lo = dpp_row_shr_i32<SHR>(0, (int)(b & 0xffffffffll));
-    const int hi = dpp_row_shr_i32<SHR>(0, (int)(b >> 32));
+    const int lo = dpp_row_shr0_i32<SHR>((int)(b & 0xffffffffll));
+    const int hi = dpp_row_shr0_i32<SHR>((int)(b >> 32));
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 // DPP row_bcast15 (ctrl 0x142): lane 15 of row r -> every lane of row r+1 ; row_bcast31 (0x143):
