@@ -101,6 +101,17 @@ int ptam_kf_level_info(ptam_ctx* ctx, const ptam_kf* kf, int level, int* w, int*
 int ptam_kf_read_level(ptam_ctx* ctx, const ptam_kf* kf, int level,
                        uint8_t* px, ptam_int2* corners, int32_t* rowlut);
 
+/* ---- KeyFrame::MakeKeyFrame_Rest (src/KeyFrame.cc:61-82) minus the SmallBlurryImage: libCVD fast_nonmax
+ *      (score = largest threshold >= 10 at which the corner survives; kept iff no 8-neighbour corner
+ *      scores strictly higher) and ImageProcess::ShiTomasiScoreAtPoint (src/ImageProcess.cc:20-47) on
+ *      the maximal corners that lie >= 10 pixels inside the level.   */
+int ptam_make_keyframe_rest(ptam_ctx* ctx, ptam_kf* kf);
+int ptam_kf_rest_info(ptam_ctx* ctx, const ptam_kf* kf, int level, int* n_max_corners);
+/* vMaxCorners (raster order) and, per maximal corner, its Shi-Tomasi score (-1.0 where the corner
+ * is closer than 10 pixels to the border and the reference skips it).  Level::vCandidates is the
+ * subset with score > MapMaker.CandidateMinShiTomasiScore (70; 400 in config/settings.cfg:27). */
+int ptam_kf_read_rest(ptam_ctx* ctx, const ptam_kf* kf, int level, ptam_int2* max_corners, double* st_scores);
+
 /* ---- PatchFinder::FindPatchCoarse / ZMSSDAtPoint  (src/PatchFinder.cc:160-211, 326-329;
  *      src/ImageProcess.cc:130-163) ------------------------------------------------------------- */
 typedef struct {

@@ -64,6 +64,48 @@ def make_keyframe_lite(im, variant="R"):
     return levels
 
 
+# ---- KeyFrame::MakeKeyFrame_Rest (src/KeyFrame.cc:61-82): fast_nonmax + Shi-Tomasi ------------------
+def fast_scores(im, corners):
+    """largest threshold at which each corner is still a FAST-10 corner: over the 16 arcs of 10 ring
+    pixels, max of min(ring - p) (brighter) or min(p - ring) (darker), minus 1"""
+    if len(corners) == 0:
+        return np.zeros(0, int)
+    x, y = corners[:, 0], corners[:, 1]
+    p = im[y, x].astype(int)
+    ring = np.stack([im[y + dy, x + dx].astype(int) for dx, dy in RING])       # (16, n)
+    ext = np.concatenate([ring, ring[:9]])
+    best = np.full(len(corners), -1000)
+    for sign in (1, -1):
+        d = sign * (ext - p)
+        arcs = np.stack([d[k:k + 10].min(axis=0) for k in range(16)])
+        best = np.maximum(best, arcs.max(axis=0) - 1)
+    return best
+
+
+def make_keyframe_rest(levels):
+    out = []
+    for L in levels:
+        im, c = L["im"], L["corners"]
+        h, w = im.shape
+        sc = fast_scores(im, c)
+        smap = np.zeros((h + 2, w + 2), int)                                      # padded score map, 0 = no corner
+        smap[c[:, 1] + 1, c[:, 0] + 1] = sc
+        nb = np.stack([smap[c[:, 1] + 1 + dy, c[:, 0] + 1 + dx] for dy in (-1, 0, 1) for dx in (-1, 0, 1) if dx or dy])
+        keep = (nb <= sc).all(axis=0) if len(c) else np.zeros(0, bool)
+        mc = c[keep]
+        st = np.full(len(mc), -1.0)
+        I = im.astype(np.float64)
+        for i, (x, y) in enumerate(mc):
+            if not (10 <= x < w - 10 and 10 <= y < h - 10):
+                continue
+            dx = I[y - 3:y + 4, x - 2:x + 5] - I[y - 3:y + 4, x - 4:x + 3]
+            dy = I[y - 2:y + 5, x - 3:x + 4] - I[y - 4:y + 3, x - 3:x + 4]
+            xx, yy, xy = (dx * dx).sum() / 98.0, (dy * dy).sum() / 98.0, (dx * dy).sum() / 98.0
+            st[i] = 0.5 * (xx + yy - np.sqrt((xx + yy) ** 2 - 4 * (xx * yy - xy * xy)))
+        out.append({"max_corners": mc, "st_scores": st})
+    return out
+
+
 # ---- ZMSSD + FindPatchCoarse (src/ImageProcess.cc:130-163, src/PatchFinder.cc:160-211) -----------
 def trunc_div(a, b):
     """C integer division (toward zero)."""

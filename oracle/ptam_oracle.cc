@@ -378,8 +378,85 @@ void fast10(const uint8_t* im, int w, int h, int thr, std::vector<ptam_int2>& ou
     }
 }
 
+// libCVD fast_corner_score_10 (restated): binary search for the largest threshold at which the
+// pixel is still a FAST-10 corner, starting from the detection barrier.
+bool is_corner10(const uint8_t* im, int w, int x, int y, int thr) {
+    const uint8_t* p = im + (size_t)y * w + x;
+    const int hi = *p + thr, lo = *p - thr;
+    unsigned brighter = 0, darker = 0;
+    for (int i = 0; i < 16; i++) {
+        const int v = p[kRing[i][1] * w + kRing[i][0]];
+        brighter |= (unsigned)(v > hi) << i;
+        darker |= (unsigned)(v < lo) << i;
+    }
+    return has_run10(brighter) || has_run10(darker);
+}
+int fast_corner_score10(const uint8_t* im, int w, int x, int y, int barrier) {
+    int bmin = barrier, bmax = 255, b = (bmax + bmin) / 2;
+    for (;;) {
+        if (is_corner10(im, w, x, y, b))
+            bmin = b;
+        else
+            bmax = b;
+        if (bmin == bmax - 1 || bmin == bmax) return bmin;
+        b = (bmin + bmax) / 2;
+    }
+}
+// ImageProcess::ShiTomasiScoreAtPoint src/ImageProcess.cc:20-47
+double shi_tomasi(const Level& L, int nHalfBoxSize, int cx, int cy) {
+    double dXX = 0, dYY = 0, dXY = 0;
+    for (int y = cy - nHalfBoxSize; y <= cy + nHalfBoxSize; y++)
+        for (int x = cx - nHalfBoxSize; x <= cx + nHalfBoxSize; x++) {
+            const double dx = L.im[(size_t)y * L.w + x + 1] - L.im[(size_t)y * L.w + x - 1];
+            const double dy = L.im[(size_t)(y + 1) * L.w + x] - L.im[(size_t)(y - 1) * L.w + x];
+            dXX += dx * dx;
+            dYY += dy * dy;
+            dXY += dx * dy;
+        }
+    const int nPixels = (2 * nHalfBoxSize + 1) * (2 * nHalfBoxSize + 1);
+    dXX = dXX / (2.0 * nPixels);
+    dYY = dYY / (2.0 * nPixels);
+    dXY = dXY / (2.0 * nPixels);
+    return 0.5 * (dXX + dYY - std::sqrt((dXX + dYY) * (dXX + dYY) - 4 * (dXX * dYY - dXY * dXY)));
+}
+
 struct KeyFrame {
     Level lev[PTAM_LEVELS];
+    std::vector<ptam_int2> max_corners[PTAM_LEVELS];
+    std::vector<double> st_scores[PTAM_LEVELS];
+    // KeyFrame::MakeKeyFrame_Rest src/KeyFrame.cc:61-82 (without the SmallBlurryImage)
+    void MakeKeyFrame_Rest() {
+        for (int l = 0; l < PTAM_LEVELS; l++) {
+            Level& L = lev[l];
+            // fast_nonmax(lev.im, lev.vCorners, 10, lev.vMaxCorners): scores, then non-strict 3x3
+            // suppression among corners (kept unless an 8-neighbour corner scores strictly higher)
+            std::vector<int> score(L.corners.size());
+            std::vector<int> at((size_t)L.w * L.h, -1);
+            for (size_t i = 0; i < L.corners.size(); i++) {
+                score[i] = fast_corner_score10(L.im.data(), L.w, L.corners[i].x, L.corners[i].y, 10);
+                at[(size_t)L.corners[i].y * L.w + L.corners[i].x] = (int)i;
+            }
+            max_corners[l].clear();
+            st_scores[l].clear();
+            for (size_t i = 0; i < L.corners.size(); i++) {
+                const int x = L.corners[i].x, y = L.corners[i].y;
+                bool keep = true;
+                for (int dy = -1; dy <= 1 && keep; dy++)
+                    for (int dx = -1; dx <= 1; dx++) {
+                        if (!dx && !dy) continue;
+                        const int j = at[(size_t)(y + dy) * L.w + x + dx];   // corners lie >= 3 px inside
+                        if (j >= 0 && score[j] > score[i]) {
+                            keep = false;
+                            break;
+                        }
+                    }
+                if (!keep) continue;
+                max_corners[l].push_back(L.corners[i]);
+                const bool inside = x >= 10 && y >= 10 && x < L.w - 10 && y < L.h - 10;   // :68
+                st_scores[l].push_back(inside ? shi_tomasi(L, 3, x, y) : -1.0);
+            }
+        }
+    }
     // src/KeyFrame.cc:18-54
     void MakeKeyFrame_Lite(const uint8_t* im, int w, int h, int stride, int variant) {
         static const int thr[PTAM_LEVELS] = {10, 15, 15, 10};   // :35-42
@@ -1221,6 +1298,22 @@ int ptamo_kf_read_level(ptamo_ctx*, const ptamo_kf* k, int l, uint8_t* px, ptam_
     if (px) std::memcpy(px, L.im.data(), L.im.size());
     if (corners) std::memcpy(corners, L.corners.data(), L.corners.size() * sizeof(ptam_int2));
     if (lut) std::memcpy(lut, L.rowlut.data(), L.rowlut.size() * sizeof(int));
+    return PTAM_OK;
+}
+
+int ptamo_make_keyframe_rest(ptamo_ctx*, ptamo_kf* k) {
+    k->kf.MakeKeyFrame_Rest();
+    return PTAM_OK;
+}
+int ptamo_kf_rest_info(ptamo_ctx*, const ptamo_kf* k, int l, int* n) {
+    if (l < 0 || l >= PTAM_LEVELS) return PTAM_E_ARG;
+    *n = (int)k->kf.max_corners[l].size();
+    return PTAM_OK;
+}
+int ptamo_kf_read_rest(ptamo_ctx*, const ptamo_kf* k, int l, ptam_int2* mc, double* st) {
+    if (l < 0 || l >= PTAM_LEVELS) return PTAM_E_ARG;
+    if (mc) std::memcpy(mc, k->kf.max_corners[l].data(), k->kf.max_corners[l].size() * sizeof(ptam_int2));
+    if (st) std::memcpy(st, k->kf.st_scores[l].data(), k->kf.st_scores[l].size() * sizeof(double));
     return PTAM_OK;
 }
 

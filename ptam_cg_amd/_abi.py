@@ -104,6 +104,9 @@ PROTOTYPES = {
     "kf_clone": (_i, [_vp, _vp, _ppv]),
     "kf_level_info": (_i, [_vp, _vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "kf_read_level": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "make_keyframe_rest": (_i, [_vp, _vp]),
+    "kf_rest_info": (_i, [_vp, _vp, _i, C.POINTER(_i)]),
+    "kf_read_rest": (_i, [_vp, _vp, _i, _vp, _vp]),
     "find_patch_coarse_batch": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "find_patch_coarse_batch_dev": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "zmssd_at_points": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),

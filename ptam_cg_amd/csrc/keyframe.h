@@ -12,6 +12,12 @@ struct KfLevels {
     ptam_int2* corners[PTAM_LEVELS];          // Level::vCorners (raster order)
     int* rowlut[PTAM_LEVELS];                 // Level::vCornerRowLUT
     int* ncorners;                            // [4] device counters
+    // MakeKeyFrame_Rest (src/KeyFrame.cc:61-82)
+    uint8_t* score[PTAM_LEVELS];              // FAST score per pixel (0 = not a corner)
+    unsigned long long* mmask[PTAM_LEVELS];   // [h][ntx] bit masks of the maximal corners
+    ptam_int2* mcorners[PTAM_LEVELS];         // Level::vMaxCorners (raster order)
+    double* st[PTAM_LEVELS];                  // Shi-Tomasi score per maximal corner (-1: within 10 px of the border)
+    int* nmax;                                // [4] device counters
 };
 
 struct ptam_kf {
@@ -22,6 +28,9 @@ struct ptam_kf {
     int n_blocks;
     int n_corners[PTAM_LEVELS];   // host copy, valid iff counts_valid
     int counts_valid;
+    int n_max[PTAM_LEVELS];       // host copy, valid iff rest_valid
+    int rest_valid;
+    size_t off_rest_clear, bytes_rest_clear;   // score maps + maximal-corner masks: zeroed per call
 };
 
 int kf_fetch_counts(ptam_ctx* ctx, const ptam_kf* kf);

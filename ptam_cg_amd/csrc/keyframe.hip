@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256) fast_detect_kernel(KfLevels L) {
 // chunk of entries, so an exclusive scan of per-thread popcounts gives raster-ordered offsets.
 // rowlut[y] = offset of entry (y, 0) = index of the first corner with row >= y (src/KeyFrame.cc:46-52).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) fast_compact_kernel(KfLevels L) {
+__global__ void __launch_bounds__(1024) fast_compact_kernel(KfLevels L, int rest) {
     __shared__ int wsum[16];
     __shared__ int total_s;
     const int lev = blockIdx.x;
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(1024) fast_compact_kernel(KfLevels L) {
     const int E = h * ntx;
     const int per = (E + 1023) / 1024;
     const int e0 = threadIdx.x * per, e1 = min(E, e0 + per);
-    const unsigned long long* __restrict__ mask = L.mask[lev];
+    const unsigned long long* __restrict__ mask = rest ? L.mmask[lev] : L.mask[lev];
     int cnt = 0;
     for (int e = e0; e < e1; e++) cnt += __popcll(mask[e]);
     // block exclusive scan
@@ -193,11 +193,11 @@ __global__ void __launch_bounds__(1024) fast_compact_kernel(KfLevels L) {
     }
     __syncthreads();
     int off = wsum[wid] + incl - cnt;
-    ptam_int2* __restrict__ out = L.corners[lev];
-    int* __restrict__ lut = L.rowlut[lev];
+    ptam_int2* __restrict__ out = rest ? L.mcorners[lev] : L.corners[lev];
+    int* __restrict__ lut = rest ? nullptr : L.rowlut[lev];
     for (int e = e0; e < e1; e++) {
         const int y = e / ntx, tx = e - y * ntx;
-        if (tx == 0) lut[y] = off;
+        if (tx == 0 && lut) lut[y] = off;
         unsigned long long m = mask[e];
         while (m) {
             const int bit = __ffsll((long long)m) - 1;
@@ -205,7 +205,84 @@ __global__ void __launch_bounds__(1024) fast_compact_kernel(KfLevels L) {
             out[off++] = ptam_int2{tx * FAST_TW + bit, y};
         }
     }
-    if (threadIdx.x == 0) L.ncorners[lev] = total_s;
+    if (threadIdx.x == 0) (rest ? L.nmax : L.ncorners)[lev] = total_s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MakeKeyFrame_Rest (src/KeyFrame.cc:61-82) without the SmallBlurryImage.
+//   fast_score_kernel   libCVD fast_corner_score_10: largest threshold at which the corner survives
+//                       = max over the 16 ten-pixel arcs of min(ring - p) resp. min(p - ring), minus 1
+//                       (closed form of the library's binary search); written into a score map
+//   fast_nonmax_kernel  non-strict 3x3 suppression on the score map (non-corners score 0): a corner
+//                       is kept unless an 8-neighbour scores strictly higher; kept bits -> masks
+//   fast_compact_kernel (shared with K2b) orders them; shi_tomasi_kernel scores the survivors
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int arc10_max_of_min(const int d[16]) {
+    int m2[16], m4[16], m8[16], best = -100000;
+#pragma unroll
+    for (int k = 0; k < 16; k++) m2[k] = min(d[k], d[(k + 1) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) m4[k] = min(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) m8[k] = min(m4[k], m4[(k + 4) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) best = max(best, min(m8[k], m2[(k + 8) & 15]));
+    return best;
+}
+
+__global__ void __launch_bounds__(256) fast_score_kernel(KfLevels L, int lev) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= L.ncorners[lev]) return;
+    const int w = L.w[lev];
+    const ptam_int2 c = L.corners[lev][i];
+    const uint8_t* p = L.im[lev] + (size_t)c.y * w + c.x;
+    const int v = *p;
+    const int ring[16] = {p[3 * w],      p[3 * w + 1],  p[2 * w + 2],  p[w + 3],  p[3],  p[-w + 3], p[-2 * w + 2], p[-3 * w + 1],
+                          p[-3 * w],     p[-3 * w - 1], p[-2 * w - 2], p[-w - 3], p[-3], p[w - 3],  p[2 * w - 2],  p[3 * w - 1]};
+    int up[16], dn[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        up[k] = ring[k] - v;
+        dn[k] = v - ring[k];
+    }
+    const int s = max(arc10_max_of_min(up), arc10_max_of_min(dn)) - 1;
+    L.score[lev][(size_t)c.y * w + c.x] = (uint8_t)s;   // 10 <= s <= 254 for a detected corner
+}
+
+__global__ void __launch_bounds__(256) fast_nonmax_kernel(KfLevels L, int lev) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= L.ncorners[lev]) return;
+    const int w = L.w[lev];
+    const ptam_int2 c = L.corners[lev][i];
+    const uint8_t* s = L.score[lev] + (size_t)c.y * w + c.x;   // corners lie >= 3 px inside: neighbours exist
+    const int me = *s;
+    const bool keep = s[-w - 1] <= me && s[-w] <= me && s[-w + 1] <= me && s[-1] <= me && s[1] <= me && s[w - 1] <= me &&
+                      s[w] <= me && s[w + 1] <= me;
+    if (keep) atomicOr(&L.mmask[lev][(size_t)c.y * L.ntx[lev] + (c.x >> 6)], 1ull << (c.x & 63));
+}
+
+// ImageProcess::ShiTomasiScoreAtPoint(im, 3, pos) src/ImageProcess.cc:20-47 for every maximal corner
+__global__ void __launch_bounds__(256) shi_tomasi_kernel(KfLevels L, int lev) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= L.nmax[lev]) return;
+    const int w = L.w[lev], h = L.h[lev];
+    const ptam_int2 c = L.mcorners[lev][i];
+    double out = -1.0;
+    if (c.x >= 10 && c.y >= 10 && c.x < w - 10 && c.y < h - 10) {   // in_image_with_border(*i, 10)  :68
+        const uint8_t* im = L.im[lev];
+        int xx = 0, yy = 0, xy = 0;   // sums of products of byte differences: exact in int (49 * 255^2 < 2^31)
+        for (int y = c.y - 3; y <= c.y + 3; y++)
+            for (int x = c.x - 3; x <= c.x + 3; x++) {
+                const int dx = (int)im[(size_t)y * w + x + 1] - (int)im[(size_t)y * w + x - 1];
+                const int dy = (int)im[(size_t)(y + 1) * w + x] - (int)im[(size_t)(y - 1) * w + x];
+                xx += dx * dx;
+                yy += dy * dy;
+                xy += dx * dy;
+            }
+        const double dXX = (double)xx / (2.0 * 49), dYY = (double)yy / (2.0 * 49), dXY = (double)xy / (2.0 * 49);
+        out = 0.5 * (dXX + dYY - sqrt((dXX + dYY) * (dXX + dYY) - 4 * (dXX * dYY - dXY * dXY)));
+    }
+    L.st[lev][i] = out;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -231,9 +308,11 @@ static int kf_alloc(ptam_ctx* ctx, int w, int h, ptam_kf** out) {
     }
     kf->n_blocks = blocks;
     kf->bytes_px = px;
-    // one allocation: pixels | masks | corners (worst case = every pixel) | rowluts | counts
+    // one allocation: pixels | masks | corners (worst case = every pixel) | rowluts | counts |
+    //                 score maps | max masks | max corners | Shi-Tomasi scores   (MakeKeyFrame_Rest)
     const size_t b_mask = ent * 8, b_corn = px * sizeof(ptam_int2), b_lut = rows * 4 + 64;
-    kf->bytes_total = px + b_mask + b_corn + b_lut + 64;
+    const size_t off_rest = (px + b_mask + b_corn + b_lut + 64 + 255) & ~(size_t)255;
+    kf->bytes_total = off_rest + px + b_mask + b_corn + px * 8 + 64;
     hipError_t e = hipMalloc(&kf->base, kf->bytes_total);
     if (e != hipSuccess) {
         ptam_set_error("hipMalloc(%zu) failed: %s", kf->bytes_total, hipGetErrorString(e));
@@ -259,6 +338,26 @@ static int kf_alloc(ptam_ctx* ctx, int w, int h, ptam_kf** out) {
     }
     p = (char*)(((uintptr_t)p + 63) & ~(uintptr_t)63);
     kf->L.ncorners = (int*)p;
+    kf->L.nmax = kf->L.ncorners + PTAM_LEVELS;
+    p = (char*)kf->base + off_rest;
+    kf->off_rest_clear = off_rest;
+    for (int l = 0; l < PTAM_LEVELS; l++) {
+        kf->L.score[l] = (uint8_t*)p;
+        p += ((size_t)kf->L.w[l] * kf->L.h[l] + 255) & ~(size_t)255;
+    }
+    for (int l = 0; l < PTAM_LEVELS; l++) {
+        kf->L.mmask[l] = (unsigned long long*)p;
+        p += (size_t)kf->L.ntx[l] * kf->L.h[l] * 8;
+    }
+    kf->bytes_rest_clear = (size_t)(p - ((char*)kf->base + off_rest));
+    for (int l = 0; l < PTAM_LEVELS; l++) {
+        kf->L.mcorners[l] = (ptam_int2*)p;
+        p += (((size_t)kf->L.w[l] * kf->L.h[l] + 255) & ~(size_t)255) * sizeof(ptam_int2);
+    }
+    for (int l = 0; l < PTAM_LEVELS; l++) {
+        kf->L.st[l] = (double*)p;
+        p += (((size_t)kf->L.w[l] * kf->L.h[l] + 255) & ~(size_t)255) * sizeof(double);
+    }
     *out = kf;
     return PTAM_OK;
 }
@@ -278,9 +377,10 @@ static int kf_run(ptam_ctx* ctx, ptam_kf* kf, const uint8_t* d_src) {
     else
         hipLaunchKernelGGL(pyramid_kernel<PTAM_HALFSAMPLE_R>, grd, blk, 0, ctx->stream, a);
     hipLaunchKernelGGL(fast_detect_kernel, dim3(kf->n_blocks), dim3(256), 0, ctx->stream, kf->L);
-    hipLaunchKernelGGL(fast_compact_kernel, dim3(PTAM_LEVELS), dim3(1024), 0, ctx->stream, kf->L);
+    hipLaunchKernelGGL(fast_compact_kernel, dim3(PTAM_LEVELS), dim3(1024), 0, ctx->stream, kf->L, 0);
     HIP_TRY(hipGetLastError());
     kf->counts_valid = 0;
+    kf->rest_valid = 0;
     return PTAM_OK;
 }
 
@@ -325,6 +425,63 @@ int ptam_make_keyframe_lite_dev(ptam_ctx* ctx, ptam_kf* kf, const uint8_t* d_im)
     return kf_run(ctx, kf, d_im);   // the pyramid kernel also copies src -> level 0
 }
 
+int ptam_make_keyframe_rest(ptam_ctx* ctx, ptam_kf* kf) {
+    ARG_TRY(ctx && kf);
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = kf_fetch_counts(ctx, kf);   // launch sizes (the mapmaker thread calls this, not the frame loop)
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync((char*)kf->base + kf->off_rest_clear, 0, kf->bytes_rest_clear, ctx->stream));
+    for (int l = 0; l < PTAM_LEVELS; l++) {
+        const int n = kf->n_corners[l];
+        if (n > 0) hipLaunchKernelGGL(fast_score_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, kf->L, l);
+    }
+    for (int l = 0; l < PTAM_LEVELS; l++) {
+        const int n = kf->n_corners[l];
+        if (n > 0) hipLaunchKernelGGL(fast_nonmax_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, kf->L, l);
+    }
+    hipLaunchKernelGGL(fast_compact_kernel, dim3(PTAM_LEVELS), dim3(1024), 0, ctx->stream, kf->L, 1);
+    for (int l = 0; l < PTAM_LEVELS; l++) {
+        const int n = kf->n_corners[l];   // upper bound of the maximal corners; the kernel checks nmax
+        if (n > 0) hipLaunchKernelGGL(shi_tomasi_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, kf->L, l);
+    }
+    HIP_TRY(hipGetLastError());
+    kf->rest_valid = 0;
+    return PTAM_OK;
+}
+
+static int kf_fetch_rest(ptam_ctx* ctx, const ptam_kf* kf_c) {
+    ptam_kf* kf = const_cast<ptam_kf*>(kf_c);
+    if (kf->rest_valid) return PTAM_OK;
+    HIP_TRY(hipMemcpyAsync(kf->n_max, kf->L.nmax, sizeof kf->n_max, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    kf->rest_valid = 1;
+    return PTAM_OK;
+}
+
+int ptam_kf_rest_info(ptam_ctx* ctx, const ptam_kf* kf, int level, int* n_max_corners) {
+    ARG_TRY(ctx && kf && level >= 0 && level < PTAM_LEVELS && n_max_corners);
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = kf_fetch_rest(ctx, kf);
+    if (rc) return rc;
+    *n_max_corners = kf->n_max[level];
+    return PTAM_OK;
+}
+
+int ptam_kf_read_rest(ptam_ctx* ctx, const ptam_kf* kf, int level, ptam_int2* max_corners, double* st_scores) {
+    ARG_TRY(ctx && kf && level >= 0 && level < PTAM_LEVELS);
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = kf_fetch_rest(ctx, kf);
+    if (rc) return rc;
+    const int n = kf->n_max[level];
+    if (n > 0 && max_corners)
+        HIP_TRY(hipMemcpyAsync(max_corners, kf->L.mcorners[level], (size_t)n * sizeof(ptam_int2), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    if (n > 0 && st_scores)
+        HIP_TRY(hipMemcpyAsync(st_scores, kf->L.st[level], (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PTAM_OK;
+}
+
 int ptam_kf_clone(ptam_ctx* ctx, const ptam_kf* src, ptam_kf** out) {
     ARG_TRY(ctx && src && out);
     HIP_TRY(hipSetDevice(ctx->device));
@@ -333,6 +490,7 @@ int ptam_kf_clone(ptam_ctx* ctx, const ptam_kf* src, ptam_kf** out) {
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(kf->base, src->base, src->bytes_total, hipMemcpyDeviceToDevice, ctx->stream));
     kf->counts_valid = 0;
+    kf->rest_valid = 0;
     *out = kf;
     return PTAM_OK;
 }

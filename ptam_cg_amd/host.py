@@ -162,6 +162,21 @@ class KeyFrame:
                         "make_keyframe_lite")
         return self
 
+    def MakeKeyFrame_Rest(self, min_shi_tomasi=70.0):
+        """fast_nonmax + Shi-Tomasi candidates (src/KeyFrame.cc:61-82); -> list of 4 dicts
+        {max_corners (n,2), st_scores (n,), candidates (m,2), candidate_scores (m,)}"""
+        self.ctx._check(self.lib.make_keyframe_rest(self.ctx.h, self.h), "make_keyframe_rest")
+        out = []
+        for l in range(_abi.LEVELS):
+            n = C.c_int()
+            self.ctx._check(self.lib.kf_rest_info(self.ctx.h, self.h, l, C.byref(n)), "kf_rest_info")
+            mc = np.zeros((n.value, 2), dtype=np.int32)
+            st = np.zeros(n.value, dtype=np.float64)
+            self.ctx._check(self.lib.kf_read_rest(self.ctx.h, self.h, l, _ptr(mc), _ptr(st)), "kf_read_rest")
+            sel = st > min_shi_tomasi
+            out.append({"max_corners": mc, "st_scores": st, "candidates": mc[sel], "candidate_scores": st[sel]})
+        return out
+
     def clone(self):
         out = C.c_void_p()
         self.ctx._check(self.lib.kf_clone(self.ctx.h, self.h, C.byref(out)), "kf_clone")

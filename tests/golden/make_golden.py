@@ -33,6 +33,13 @@ def main():
             d[f"im{l}"], d[f"corners{l}"], d[f"rowlut{l}"] = lv[l]["im"], lv[l]["corners"], lv[l]["rowlut"]
         np.savez_compressed(os.path.join(OUT, f"keyframe_160x128_{v}.npz"), **d)
         print(v, [len(x["corners"]) for x in lv])
+    # --- MakeKeyFrame_Rest: fast_nonmax + Shi-Tomasi ---
+    rest = npo.make_keyframe_rest(npo.make_keyframe_lite(a))
+    d = {"im": a}
+    for l in range(4):
+        d[f"max_corners{l}"], d[f"st_scores{l}"] = rest[l]["max_corners"], rest[l]["st_scores"]
+    np.savez_compressed(os.path.join(OUT, "keyframe_rest_160x128.npz"), **d)
+    print("rest", [len(x["max_corners"]) for x in rest])
     # --- patch search on the pair (variant R) ---
     la, lb = npo.make_keyframe_lite(a), npo.make_keyframe_lite(b)
     q, t = synth.make_patch_queries(la, n=400, seed=synth.SEED_QUERIES)

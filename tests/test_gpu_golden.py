@@ -31,3 +31,7 @@ def test_subpix(hip):
 
 def test_pvs(hip):
     G.check_pvs(hip)
+
+
+def test_keyframe_rest(hip):
+    G.check_keyframe_rest(hip)

@@ -269,3 +269,25 @@ def test_two_host_threads_two_contexts(hip, oracle):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errors, errors
+
+
+@pytest.mark.parametrize("case", ["synthetic", "noise", "odd"])
+def test_keyframe_rest_matches_oracle(hip, oracle, case):
+    rng = np.random.default_rng(13)
+    im = {"synthetic": synth.make_frame(), "noise": rng.integers(0, 256, (480, 640), dtype=np.uint8),
+          "odd": rng.integers(0, 256, (77, 101), dtype=np.uint8)}[case]
+    out = []
+    for lib in (hip, oracle):
+        ctx = host.Context(lib=lib, size=(im.shape[1], im.shape[0]))
+        kf = host.KeyFrame(ctx).MakeKeyFrame_Lite(im)
+        out.append(kf.MakeKeyFrame_Rest(min_shi_tomasi=70.0))
+        if lib is hip:                                   # second call on the same handle: state is reset
+            kf.MakeKeyFrame_Lite(im)
+            again = kf.MakeKeyFrame_Rest()
+            for l in range(4):
+                assert np.array_equal(again[l]["max_corners"], out[0][l]["max_corners"])
+    for l in range(4):
+        assert np.array_equal(out[0][l]["max_corners"], out[1][l]["max_corners"]), l       # bit-exact, raster order
+        assert np.allclose(out[0][l]["st_scores"], out[1][l]["st_scores"], rtol=1e-12, atol=1e-12)
+        assert np.array_equal(out[0][l]["candidates"], out[1][l]["candidates"])
+    assert len(out[0][0]["candidates"]) > 0

@@ -29,3 +29,7 @@ def test_subpix(oracle):
 
 def test_pvs(oracle):
     G.check_pvs(oracle)
+
+
+def test_keyframe_rest(oracle):
+    G.check_keyframe_rest(oracle)

@@ -297,3 +297,26 @@ def test_pvs_levels_follow_the_warp_determinant(oracle):
     # behind the camera / outside the image: not in the PVS, level -1
     r2, c2 = ctx.track_pvs([[0, 0, -1.0], [5.0, 0, 1.0]], right[:2], down[:2], pose)
     assert list(r2["level"]) == [-1, -1] and not r2["proj"]["in_image"].any() and not c2.any()
+
+
+def test_fast_score_and_nonmax_semantics(oracle):
+    """score = largest threshold at which the corner survives; 3x3 suppression is non-strict (ties kept)"""
+    im = np.full((32, 32), 100, np.uint8)
+    for (dx, dy), v in zip(RING, arc(0, 10, 150, 100)):           # arc of +50: survives up to threshold 49
+        im[12 + dy, 12 + dx] = v
+    ctx, kf = _kf(oracle, im)
+    lv = kf.level(0)
+    assert (12, 12) in {tuple(x) for x in lv["corners"]}
+    rest = kf.MakeKeyFrame_Rest()
+    mc = {tuple(x) for x in rest[0]["max_corners"]}
+    assert (12, 12) in mc
+    # every detected corner is either maximal or has an 8-neighbour corner (strictly better by definition)
+    corners = {tuple(x) for x in lv["corners"]}
+    for c in corners - mc:
+        assert any((c[0] + dx, c[1] + dy) in corners for dx in (-1, 0, 1) for dy in (-1, 0, 1) if dx or dy)
+    # Shi-Tomasi on a constant patch is 0; on a vertical step edge the smaller eigenvalue stays 0
+    flat = np.full((40, 40), 50, np.uint8)
+    flat[:, 20:] = 200
+    ctx2, kf2 = _kf(oracle, flat)
+    r2 = kf2.MakeKeyFrame_Rest()
+    assert all((s <= 1e-9).all() for s in [x["st_scores"][x["st_scores"] >= 0] for x in r2])
