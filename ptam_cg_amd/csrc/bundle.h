@@ -110,5 +110,5 @@ struct BaDev {
 };
 
 // solve.hip
-int ba_solve(ptam_ctx* ctx, BaDev& d);
+int ba_solve(ptam_ctx* ctx, BaDev& d, int cur);   // also writes the trial poses pose[cur^1] and |da|^2
 int ba_solve_init();   // raises the dynamic-LDS limits of the solve kernels (once per process/device)

@@ -27,8 +27,17 @@
 // =================================================================================================
 // device helpers
 // =================================================================================================
+// First-level bin of the order-statistic select: the top 16 bits of the fp64 pattern (exponent + 4
+// mantissa bits = 16 sub-bins per binade) relative to 2^-24, clamped to [0, 4095] — monotone in the
+// value, 256 binades wide (6e-8 .. 7e69).  A rank that lands in a clamped end bin takes the generic
+// full-width radix path of select_final_kernel.
+#define E2_BIN_BASE ((1023 - 24) << 4)
 __device__ __forceinline__ int e2_bin(double e2) {
-    return (int)(((unsigned long long)__double_as_longlong(e2) >> 51) & (HIST_BINS - 1));
+    const int t = (int)((unsigned long long)__double_as_longlong(e2) >> 48) - E2_BIN_BASE;
+    return t < 0 ? 0 : (t > HIST_BINS - 1 ? HIST_BINS - 1 : t);
+}
+__device__ __forceinline__ int e2_bin2(double e2) {   // next 12 bits
+    return (int)(((unsigned long long)__double_as_longlong(e2) >> 36) & (HIST_BINS - 1));
 }
 
 // project one measurement: returns false (bad) if z <= 0  (ProjectAndFindSquaredError :164-180).
@@ -220,7 +229,7 @@ __device__ void block_find_bin(const unsigned* __restrict__ hist, long long& tot
 
 #define CAND_BUF 2048
 // gather the keys of the selected first-level bin (keys = m_e2 masked by state, or an explicit
-// array) and histogram their next 12 bits (50..39).  Candidates are staged in LDS and appended with
+// array) and histogram their next 12 bits (47..36).  Candidates are staged in LDS and appended with
 // one global atomic per flush.
 __global__ void __launch_bounds__(256) select_compact_kernel(BaDev d, const double* __restrict__ keys, long long n,
                                                              const uint8_t* __restrict__ state) {
@@ -249,7 +258,7 @@ __global__ void __launch_bounds__(256) select_compact_kernel(BaDev d, const doub
             if (e2_bin(key) == bin) {
                 const int pos = atomicAdd(&cnt, 1);
                 buf[pos] = key;
-                atomicAdd(&h2[((unsigned long long)__double_as_longlong(key) >> 39) & (HIST_BINS - 1)], 1u);
+                atomicAdd(&h2[e2_bin2(key)], 1u);
             }
         }
         __syncthreads();
@@ -331,7 +340,13 @@ __global__ void __launch_bounds__(1024) select_final_kernel(BaDev d, int est, do
     const int n = d.sc->n_cand;
     unsigned* hist2 = d.hist + HIST_BINS;
     unsigned long long result = 0;
-    if (n > 0) {
+    const int bin1 = d.sc->sel_bin;
+    if (n > 0 && (bin1 == 0 || bin1 == HIST_BINS - 1)) {
+        // clamped end bin: its members do not share their top bits; plain 8-pass select over them
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        result = block_radix_select(d.cand, n, d.sc->sel_k, 0ull, 56, hist, &s_digit, &s_k);
+    } else if (n > 0) {
         // second-level bin
         unsigned c[4];
         long long s = 0;
@@ -376,15 +391,15 @@ __global__ void __launch_bounds__(1024) select_final_kernel(BaDev d, int est, do
         const int bin2 = s_bin2, k2 = s_k2;
         for (int i = tid; i < n; i += 1024) {
             const double key = d.cand[i];
-            if ((int)(((unsigned long long)__double_as_longlong(key) >> 39) & (HIST_BINS - 1)) == bin2) {
+            if (e2_bin2(key) == bin2) {
                 const int pos = atomicAdd(&s_cnt, 1);
                 if (pos < SMALL_CAP) sm[pos] = key;
             }
         }
         __syncthreads();
         const int m = s_cnt;
-        // bits 63..39 are fixed by (bin, bin2): take them from any member
-        const unsigned long long top = ((unsigned long long)d.sc->sel_bin << 51) | ((unsigned long long)bin2 << 39);
+        // bits 63..36 are fixed by (bin, bin2)
+        const unsigned long long top = ((unsigned long long)(bin1 + E2_BIN_BASE) << 48) | ((unsigned long long)bin2 << 36);
         if (m <= SMALL_CAP)
             result = block_radix_select(sm, m, k2, top, 32, hist, &s_digit, &s_k);
         else   // pathological (thousands of near-identical keys): same passes straight from global
@@ -1946,12 +1961,13 @@ static int ba_trial(ptam_ba* ba, double lambda) {
         int rc = ba_allreduce(ba, d.SE, (size_t)d.npad * d.npad + d.npad);   // the path's one exchange step
         if (rc) return rc;
         prof_begin(ba, PTAM_K_SOLVE);
-        rc = ba_solve(ctx, d);
+        rc = ba_solve(ctx, d, ba->cur);
         prof_end(ba, PTAM_K_SOLVE);
         if (rc) return rc;
     }
     prof_begin(ba, PTAM_K_UPDATE);
-    hipLaunchKernelGGL(pose_update_kernel, dim3(std::max(1, (d.C + 63) / 64)), dim3(64), 0, ctx->stream, d, ba->cur);
+    if (d.F == 0)   // no free camera: nothing was solved, the trial poses are copies
+        hipLaunchKernelGGL(pose_update_kernel, dim3(std::max(1, (d.C + 63) / 64)), dim3(64), 0, ctx->stream, d, ba->cur);
     if (d.n_chunks > 0)
         hipLaunchKernelGGL(point_update_kernel, dim3(d.n_chunks), dim3(BA_CHUNK), 0, ctx->stream, ctx->cam, d, ba->cur,
                            ba->opts.estimator);

@@ -263,7 +263,7 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 
 // w = D^-1 z ; L^T x = w, blocked backwards.  One workgroup of 1024 threads.
 #define BW_PART (1024 / NB)   // row partitions of the GEMV part
-__global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d) {
+__global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur) {
     extern __shared__ __attribute__((aligned(16))) double bw_lds[];
     const int npad = d.npad, nblk = npad / NB;
     double* xs = bw_lds;                       // npad
@@ -296,6 +296,33 @@ __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d) {
         __syncthreads();
     }
     for (int i = tid; i < npad; i += 1024) d.da[i] = xs[i];
+    // trial poses  exp(da_j) * se3CfW  (src/Bundle.cc:496-501) and |da|^2, straight from LDS: saves the
+    // separate pose-update launch
+    for (int c2 = tid; c2 < d.C; c2 += 1024) {
+        const double* T = d.pose[cur] + 12 * c2;
+        double* Tn = d.pose[cur ^ 1] + 12 * c2;
+        const int f = d.cam_free[c2];
+        double Tl[12], o[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) Tl[i] = T[i];
+        if (f < 0) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) Tn[i] = Tl[i];
+        } else {
+            double mu[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) mu[i] = xs[6 * f + i];
+            se3_exp_mul(mu, Tl, o);
+#pragma unroll
+            for (int i = 0; i < 12; i++) Tn[i] = o[i];
+        }
+    }
+    if (tid < 64) {
+        double sq = 0;
+        for (int i = tid; i < d.n; i += 64) sq += xs[i] * xs[i];
+        sq = wave_sum_f64(sq);
+        if (tid == 0) d.sc->sumsq_cam = sq;
+    }
 }
 
 #define STEP_LDS_BYTES ((3 * NB * LDP + 2 * NB) * sizeof(double))
@@ -305,7 +332,7 @@ int ba_solve_init() {
     return PTAM_OK;
 }
 
-int ba_solve(ptam_ctx* ctx, BaDev& d) {
+int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
     const int nblk = d.npad / NB;
     for (int k = 0; k < nblk; k++) {
         const int rem = nblk - k - 1;
@@ -313,7 +340,7 @@ int ba_solve(ptam_ctx* ctx, BaDev& d) {
         hipLaunchKernelGGL(ldlt_step_kernel, dim3(nwg), dim3(TPB), STEP_LDS_BYTES, ctx->stream, d, k);
     }
     const size_t bw_bytes = ((size_t)d.npad + BW_PART * (NB + 1) + NB * LDP) * sizeof(double);
-    hipLaunchKernelGGL(ldlt_backward_kernel, dim3(1), dim3(1024), bw_bytes, ctx->stream, d);
+    hipLaunchKernelGGL(ldlt_backward_kernel, dim3(1), dim3(1024), bw_bytes, ctx->stream, d, cur);
     HIP_TRY(hipGetLastError());
     return PTAM_OK;
 }
