@@ -80,6 +80,8 @@ struct BaDev {
     int* m_fidx;            // free-camera index of the measurement's camera (-1 = fixed)
     uint8_t* m_state;
     double* m_e2;
+    double* m_e2t;          // squared errors of the last trial state (adopted as pass 1 when the trial is accepted)
+    uint8_t* m_zbad_t;      // its z <= 0 flags
     double2* W;
     // accumulators
     double* Usplit;         // [16][F*27] : per camera 21 lower-triangle U sums + 6 epsA sums, in 16

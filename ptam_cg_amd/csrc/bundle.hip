@@ -153,6 +153,46 @@ __global__ void __launch_bounds__(BA_CHUNK) project_e2_kernel(DevCam cam, BaDev 
     }
 }
 
+// Pass 1 of the step that follows an ACCEPTED trial: the trial's new-error pass (point_update_kernel)
+// already projected every measurement with what are now the current poses / points, so this kernel only
+// adopts its squared errors and z <= 0 flags, clears the accumulators of boundary-cut points and builds
+// the histogram — no projection (K5 proper is project_e2_kernel above).
+__global__ void __launch_bounds__(256) pass1_from_trial_kernel(BaDev d, int build_hist) {
+    __shared__ unsigned hist[HIST_BINS];
+    const int tid = threadIdx.x;
+    if (build_hist)
+        for (int b = tid; b < HIST_BINS; b += 256) hist[b] = 0;
+    __syncthreads();
+    for (int m = blockIdx.x * 256 + tid; m < d.M; m += gridDim.x * 256) {
+        if ((m & 63) == 0 && m > 0) {
+            const int pc = d.m_pt[m];
+            if (d.rowptr[pc] < m) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) d.V[(size_t)pc * 6 + i] = 0;
+#pragma unroll
+                for (int i = 0; i < 3; i++) d.epsB[(size_t)pc * 3 + i] = 0;
+            }
+        }
+        const int st = d.m_state[m];
+        if (st == MS_DEAD) continue;
+        if (d.m_zbad_t[m]) {
+            d.m_state[m] = MS_BAD;
+        } else {
+            const double e2 = d.m_e2t[m];
+            d.m_e2[m] = e2;
+            if (st != MS_ALIVE) d.m_state[m] = MS_ALIVE;
+            if (build_hist) atomicAdd(&hist[e2_bin(e2)], 1u);
+        }
+    }
+    if (build_hist) {
+        __syncthreads();
+        for (int b = tid; b < HIST_BINS; b += 256) {
+            const unsigned c = hist[b];
+            if (c) atomicAdd(&d.hist[b], c);
+        }
+    }
+}
+
 // =================================================================================================
 // K6: exact order statistic
 // =================================================================================================
@@ -1364,14 +1404,20 @@ __global__ void __launch_bounds__(BA_CHUNK) point_update_kernel(DevCam cam, BaDe
         const double* T = d.pose[cur ^ 1] + 12 * c;
         const double* X = Np[p - ch.pt_begin];
         BaProj pr;
-        if (!ba_project(cam, T, X, pr))
+        if (!ba_project(cam, T, X, pr)) {
             err = 1.0;
-        else {
+            d.m_zbad_t[m] = 1;
+        } else {
             const double2 fo = d.m_found[m];
             const double s = d.m_s[m];
             const double ex = s * (fo.x - pr.u), ey = s * (fo.y - pr.v);
             const double s2 = d.sc->sigma_sq;
-            err = ba_objective(est, ex * ex + ey * ey, s2, 1.0 / s2);
+            const double e2n = ex * ex + ey * ey;
+            err = ba_objective(est, e2n, s2, 1.0 / s2);
+            // if this trial is accepted, these ARE pass 1's results of the next LM step (same poses,
+            // points and projection code): keep them so that the next step can skip its projection pass
+            d.m_e2t[m] = e2n;
+            d.m_zbad_t[m] = 0;
         }
     }
     err = wave_sum_f64(err);
@@ -1487,6 +1533,7 @@ struct ptam_ba {
     size_t smem_acc = 0;
     bool use_wave = false;
     int per_wave = 1;
+    bool trial_is_current = false;   // the last trial was accepted: its new-error pass == pass 1 of the next step
     int k7_threads = BA_CHUNK;
     bool k7_loop = false;
     std::vector<int> sorted_orig;   // sorted position -> insertion index
@@ -1711,7 +1758,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     const size_t o_pt0 = cv.take(Pz * 24), o_pt1 = cv.take(Pz * 24), o_V = cv.take(Pz * 48), o_epsB = cv.take(Pz * 24),
                  o_Vinv = cv.take(Pz * 72), o_rowptr = cv.take((Pz + 1) * 4);
     const size_t o_mcam = cv.take(Mz * 4), o_mpt = cv.take(Mz * 4), o_mfound = cv.take(Mz * 16), o_ms = cv.take(Mz * 8),
-                 o_morig = cv.take(Mz * 4), o_mfidx = cv.take(Mz * 4), o_mstate = cv.take(Mz), o_me2 = cv.take(Mz * 8), o_W = cv.take(Mz * 144);
+                 o_morig = cv.take(Mz * 4), o_mfidx = cv.take(Mz * 4), o_mstate = cv.take(Mz), o_me2 = cv.take(Mz * 8), o_me2t = cv.take(Mz * 8), o_zbad = cv.take(Mz), o_W = cv.take(Mz * 144);
     const size_t o_U = cv.take(Fz * 27 * 8 * 16), o_Upart = cv.take((size_t)d.grid_acc * Fz * 27 * 8);
     const size_t n_part = std::max(d.n_chunks, d.grid_acc);
     const size_t o_errp = cv.take(n_part * 16 + 16), o_badp = cv.take((size_t)d.grid_acc * 4 + 16);
@@ -1747,6 +1794,8 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.m_fidx = (int*)(base + o_mfidx);
     d.m_state = (uint8_t*)(base + o_mstate);
     d.m_e2 = (double*)(base + o_me2);
+    d.m_e2t = (double*)(base + o_me2t);
+    d.m_zbad_t = (uint8_t*)(base + o_zbad);
     d.W = (double2*)(base + o_W);
     d.Usplit = (double*)(base + o_U);
     d.Upart = (double*)(base + o_Upart);
@@ -1853,7 +1902,10 @@ static int ba_pass1_sigma(ptam_ba* ba) {
     const bool sharded = ba->comm && ba->world > 1;
     const double min_s2 = ba->opts.min_sigma * ba->opts.min_sigma;
     prof_begin(ba, PTAM_K_PROJECT);
-    if (d.n_chunks > 0)
+    if (ba->trial_is_current && d.M > 0)
+        hipLaunchKernelGGL(pass1_from_trial_kernel, dim3(std::min((d.M + 255) / 256, 512)), dim3(256), 0, ctx->stream, d,
+                           sharded ? 0 : 1);
+    else if (d.n_chunks > 0)
         hipLaunchKernelGGL(project_e2_kernel, dim3(std::min(d.n_chunks, 512)), dim3(BA_CHUNK), 0, ctx->stream, ctx->cam, d,
                            ba->cur, sharded ? 0 : 1);
     prof_end(ba, PTAM_K_PROJECT);
@@ -2136,6 +2188,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     BaDev& d = ba->d;
     double lambda = 0.0001, lambda_factor = 2.0;   // :125-126
     ba->converged = false;
+    ba->trial_is_current = false;
     bool hit_max = false;
     int counter = 0;
     ba->accepted = 0;
@@ -2190,12 +2243,14 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
             if (counter >= ba->opts.max_iterations) hit_max = true;   // :518-520
             ba->trials.push_back(t);
         }
+        ba->trial_is_current = false;
         if (ran_any && new_err < cur_err) {   // :523-533
             lambda_factor = 2.0;
             lambda *= 0.3;
             ba->cur ^= 1;   // commit: trial poses / points become current
             ba->accepted++;
             ba->trials.back().accepted = 1;
+            ba->trial_is_current = true;
         }
         if (d.M > 0) hipLaunchKernelGGL(purge_kernel, dim3((d.M + 255) / 256), dim3(256), 0, ctx->stream, d);   // :536-547
         HIP_TRY(hipGetLastError());
