@@ -50,6 +50,43 @@ struct BaProj {
     double u, v;         // image
     double r, ir, f;     // radius, 1/r, rtrans_factor
 };
+// atan for x >= 0 in ~45 VALU instructions (the library call is ~80 and sits in K7's critical VALU
+// budget): argument reduction atan(x) = atan(c) + atan((x - c) / (1 + c x)) with c in {0, 1/2, 1, 3/2}
+// (x >= 39/16: pi/2 - atan(1/x)) and the classic 11-term odd minimax polynomial on |t| < 7/16
+// (Sun fdlibm's published coefficients); the quotient uses rcp + 2 Newton steps.  Measured against
+// libm over [1e-8, 1e3]: <= 2 ulp (constants: tests/test_oracle_kat.py::test_atan_reduction_constants;
+// the device code itself is covered by the BA parity tests).
+__device__ __forceinline__ double ba_atan_pos(double x) {
+    double c = 0.0, hi = 0.0;
+    if (x >= 0.4375) c = 0.5, hi = 4.63647609000806093515e-01;
+    if (x >= 0.6875) c = 1.0, hi = 7.85398163397448278999e-01;
+    if (x >= 1.1875) c = 1.5, hi = 9.82793723247329054082e-01;
+    double num = x - c, den = fma(c, x, 1.0);
+    if (x >= 2.4375) {
+        num = -1.0;
+        den = x;
+        hi = 1.57079632679489655800e+00;
+    }
+    const double t = num * rcp_nr(den);
+    const double z = t * t, w = z * z;
+    const double s1 =
+        z * fma(w, fma(w, fma(w, fma(w, fma(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02), 6.66107313738753120669e-02),
+                               9.09088713343650656196e-02),
+                       1.42857142725034663711e-01),
+                3.33333333333329318027e-01);
+    const double s2 = w * fma(w, fma(w, fma(w, fma(w, -3.65315727442169155270e-02, -5.83357013379057348645e-02), -7.69187620504482999495e-02),
+                                     -1.11111104054623557880e-01),
+                              -1.99999999998764832476e-01);
+    return hi - (t * (s1 + s2) - t);
+}
+// 1/sqrt(a), a > 0: v_rsq_f64 + 2 Newton steps (<= 1 ulp)
+__device__ __forceinline__ double rsq_nr(double a) {
+    double y = __builtin_amdgcn_rsq(a);
+    const double h = 0.5 * a;
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    return y;
+}
 __device__ __forceinline__ bool ba_project(const DevCam& cam, const double* __restrict__ T, const double* __restrict__ X,
                                            BaProj& p) {
     se3_apply(T, X[0], X[1], X[2], p.X, p.Y, p.Z);
@@ -58,13 +95,15 @@ __device__ __forceinline__ bool ba_project(const DevCam& cam, const double* __re
     p.x = p.X * iz;
     p.y = p.Y * iz;
     const double r2 = p.x * p.x + p.y * p.y;
-    p.r = sqrt(r2);
-    if (p.r < 0.001 || cam.w == 0.0) {
+    if (r2 < 1e-6 || cam.w == 0.0) {   // r < 0.001  (src/ATANCamera.h:105-111)
+        p.r = r2 > 0 ? r2 * rsq_nr(r2) : 0.0;
         p.ir = 0;
         p.f = 1.0;
     } else {
-        p.ir = rcp_nr(p.r);
-        p.f = cam.w_inv * atan(p.r * cam.two_tan) * p.ir;
+        p.ir = rsq_nr(r2);
+        p.r = r2 * p.ir;
+        const double t = p.r * cam.two_tan;   // (negative only for a negative FOV parameter)
+        p.f = cam.w_inv * copysign(ba_atan_pos(fabs(t)), t) * p.ir;
     }
     p.u = cam.cx + cam.fx * (p.f * p.x);
     p.v = cam.cy + cam.fy * (p.f * p.y);
@@ -635,8 +674,10 @@ __device__ __forceinline__ void k7_load(const BaDev& d, const double* __restrict
 }
 
 #ifdef K7_TIMING
-#define K7_STAMP(i) if (blockIdx.x == 7 && tid == 0) d.dbg[i] = (long long)__builtin_readcyclecounter();
+#define K7_STAMP(i) if (blockIdx.x == 7 && tid == 0) d.dbg[i] = (long long)__builtin_amdgcn_s_memrealtime();
+#define K7_WALL(i) if (tid == 0 && blockIdx.x < 2000) d.dbg[16 + 2 * blockIdx.x + i] = (long long)__builtin_amdgcn_s_memrealtime();
 #else
+#define K7_WALL(i)
 #define K7_STAMP(i)
 #endif
 template <int THREADS, bool PREFETCH, bool LOOP>
@@ -645,6 +686,7 @@ __global__ void __launch_bounds__(THREADS) jac_accum_wave_kernel(DevCam cam, BaD
     double* Ul = smem;
     double* Ps = smem + (((size_t)d.F * 27 + 1) & ~(size_t)1);
     const int tid = threadIdx.x, lane = tid & 63;
+    K7_WALL(0)
     const double* __restrict__ pt = d.pt[cur];
     const int n_chunks64 = (d.M + 63) >> 6;
     const int c_begin = (blockIdx.x * (THREADS / 64) + (tid >> 6)) * per_wave;
@@ -671,7 +713,7 @@ __global__ void __launch_bounds__(THREADS) jac_accum_wave_kernel(DevCam cam, BaD
         if (!PREFETCH) k7_load(d, pt, m0, lane, in);
         const K7In cu = in;
         K7_STAMP(2)
-        if (PREFETCH && ci + 1 < c_end) k7_load(d, pt, (ci + 1) << 6, lane, in);   // prefetch the next chunk
+        if (PREFETCH && LOOP && ci + 1 < c_end) k7_load(d, pt, (ci + 1) << 6, lane, in);   // prefetch the next chunk
         const int st = cu.st, c = cu.c, p = cu.p, fidx = cu.fidx;
         const int src = p - cu.pt0;   // lane that fetched my point
         const double Xw = __shfl(cu.px, src, 64), Yw = __shfl(cu.py, src, 64), Zw = __shfl(cu.pz, src, 64);
@@ -790,8 +832,9 @@ __global__ void __launch_bounds__(THREADS) jac_accum_wave_kernel(DevCam cam, BaD
         SEG_STEP(dpp_row_shr0_i32<2>(pid1), dpp_row_shr_f64<2>(v[i]))
         SEG_STEP(dpp_row_shr0_i32<4>(pid1), dpp_row_shr_f64<4>(v[i]))
         SEG_STEP(dpp_row_shr0_i32<8>(pid1), dpp_row_shr_f64<8>(v[i]))
-        SEG_STEP((dpp_bcast_i32<0x142, 0xa>(0, pid1)), (dpp_bcast_f64<0x142, 0xa>(v[i])))
-        SEG_STEP((dpp_bcast_i32<0x143, 0xc>(0, pid1)), (dpp_bcast_f64<0x143, 0xc>(v[i])))
+        // row carries: only rows 1,3 (then 2,3) take part; 0 never matches a point id
+        SEG_STEP((dpp_bcastx_i32<0x142>(pid1) & -((lane >> 4) & 1)), dpp_bcastx_f64<0x142>(v[i]))
+        SEG_STEP((dpp_bcastx_i32<0x143>(pid1) & -((lane >> 5) & 1)), dpp_bcastx_f64<0x143>(v[i]))
 #undef SEG_STEP
         K7_STAMP(7)
         const int pn = __shfl_down(pid, 1, 64);
@@ -819,6 +862,7 @@ __global__ void __launch_bounds__(THREADS) jac_accum_wave_kernel(DevCam cam, BaD
     __syncthreads();
     jac_flush<THREADS>(d, Ul, err, nbad);
     K7_STAMP(9)
+    K7_WALL(1)
 }
 
 // zero V / epsB of the points that are cut by a 64-measurement chunk boundary (targets of the atomics)
@@ -1730,7 +1774,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     ba->k7_threads = !ba->use_wave ? BA_CHUNK : (ba->k7_loop ? 256 : 512);
     const void* k7 = !ba->use_wave ? (const void*)jac_accum_kernel
                      : ba->k7_loop ? (const void*)jac_accum_wave_kernel<256, false, true>
-                                   : (const void*)jac_accum_wave_kernel<512, false, false>;
+                                   : (const void*)jac_accum_wave_kernel<512, true, false>;
     if (ba->smem_acc > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(k7, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba->smem_acc));
     int per_cu = 0, n_cu = 256;
@@ -1772,7 +1816,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     const size_t npad = std::max(d.npad, SOLVE_NB);
     const size_t o_SE = cv.take((npad * npad + npad) * 8), o_L = cv.take(npad * npad * 8), o_Dg = cv.take(npad * 8),
                  o_y = cv.take(npad * 8), o_da = cv.take(npad * 8);
-    const size_t o_out = cv.take(Mz * 4), o_sc = cv.take(sizeof(BaScalars)), o_dbg = cv.take(256);
+    const size_t o_out = cv.take(Mz * 4), o_sc = cv.take(sizeof(BaScalars)), o_dbg = cv.take(32768);
     ba->block_bytes = cv.off;
     HIP_TRY(hipMalloc(&ba->block, ba->block_bytes));
     HIP_TRY(hipMemsetAsync(ba->block, 0, ba->block_bytes, ctx->stream));
@@ -1970,7 +2014,7 @@ static void launch_k7(ptam_ba* ba) {
             hipLaunchKernelGGL((jac_accum_wave_kernel<256, false, true>), dim3(ba->d.grid_acc), dim3(256), ba->smem_acc,
                                ctx->stream, ctx->cam, ba->d, ba->cur, ba->opts.estimator, ba->per_wave);
         else
-            hipLaunchKernelGGL((jac_accum_wave_kernel<512, false, false>), dim3(ba->d.grid_acc), dim3(512), ba->smem_acc,
+            hipLaunchKernelGGL((jac_accum_wave_kernel<512, true, false>), dim3(ba->d.grid_acc), dim3(512), ba->smem_acc,
                                ctx->stream, ctx->cam, ba->d, ba->cur, ba->opts.estimator, ba->per_wave);
     }
     else
@@ -2378,9 +2422,23 @@ int ptam_ba_bench_jacobian(ptam_ba* ba, int reps, double* avg_ms, double* algori
     {
         long long h[16];
         HIP_TRY(hipMemcpy(h, d.dbg, sizeof h, hipMemcpyDeviceToHost));
-        std::printf("K7 stamps (cycles since kernel-body start):");
+        std::printf("K7 stamps (10 ns ticks since kernel-body start):");
         for (int i = 1; i < 10; i++) std::printf(" [%d] %lld", i, h[i] - h[0]);
         std::printf("\n");
+        std::printf("K7 block 7: body start is %lld ticks after the block's first instruction\n", h[0] - h[16 + 14]);
+        const int nb = std::min(ba->d.grid_acc, 2000);
+        std::vector<long long> w(2 * nb);
+        HIP_TRY(hipMemcpy(w.data(), d.dbg + 16, w.size() * 8, hipMemcpyDeviceToHost));
+        long long t0 = w[0];
+        for (int b = 0; b < nb; b++) t0 = std::min(t0, w[2 * b]);
+        std::vector<long long> st(nb), en(nb), du(nb);
+        for (int b = 0; b < nb; b++) st[b] = w[2 * b] - t0, en[b] = w[2 * b + 1] - t0, du[b] = en[b] - st[b];
+        std::sort(st.begin(), st.end());
+        std::sort(en.begin(), en.end());
+        std::sort(du.begin(), du.end());
+        std::printf("K7 wall (10 ns ticks, %d blocks): start p0/p50/p90/p100 %lld %lld %lld %lld | end %lld %lld %lld %lld | dur %lld %lld %lld %lld\n",
+                    nb, st[0], st[nb / 2], st[nb * 9 / 10], st[nb - 1], en[0], en[nb / 2], en[nb * 9 / 10], en[nb - 1], du[0], du[nb / 2],
+                    du[nb * 9 / 10], du[nb - 1]);
     }
 #endif
     if (avg_ms) *avg_ms = total / reps;

@@ -223,6 +223,19 @@ __device__ __forceinline__ double dpp_bcast_f64(double src) {
     const int hi = dpp_bcast_i32<CTRL, ROWMASK>(0, (int)(b >> 32));
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+// full-row-mask form (no `old` to materialise): rows without a valid source hold garbage, the caller
+// must discard them (row_bcast15: row 0 ; row_bcast31: rows 0,1)
+template <int CTRL>
+__device__ __forceinline__ int dpp_bcastx_i32(int src) {
+    return __builtin_amdgcn_update_dpp(src, src, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_bcastx_f64(double src) {
+    const long long b = __double_as_longlong(src);
+    const int lo = dpp_bcastx_i32<CTRL>((int)(b & 0xffffffffll));
+    const int hi = dpp_bcastx_i32<CTRL>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ int wave_sum_i32(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -320,3 +320,33 @@ def test_fast_score_and_nonmax_semantics(oracle):
     ctx2, kf2 = _kf(oracle, flat)
     r2 = kf2.MakeKeyFrame_Rest()
     assert all((s <= 1e-9).all() for s in [x["st_scores"][x["st_scores"] >= 0] for x in r2])
+
+
+def test_atan_reduction_constants():
+    """The BA kernels evaluate atan with the classic 4-interval reduction + 11-term polynomial
+    (ptam_cg_amd/csrc/bundle.hip ba_atan_pos).  The same scheme in float64 numpy must agree with libm to
+    a couple of ulp — a wrong digit in any coefficient shows up as >= 1e-13."""
+    aT = [3.33333333333329318027e-01, -1.99999999998764832476e-01, 1.42857142725034663711e-01,
+          -1.11111104054623557880e-01, 9.09088713343650656196e-02, -7.69187620504482999495e-02,
+          6.66107313738753120669e-02, -5.83357013379057348645e-02, 4.97687799461593236017e-02,
+          -3.65315727442169155270e-02, 1.62858201153657823623e-02]
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(0, 4, 200000), 10.0 ** rng.uniform(-8, 3, 50000),
+                        np.array([0.4375, 0.6875, 1.1875, 2.4375])])
+    c = np.zeros_like(x)
+    hi = np.zeros_like(x)
+    for lim, cc, hh in ((0.4375, 0.5, 4.63647609000806093515e-01), (0.6875, 1.0, 7.85398163397448278999e-01),
+                        (1.1875, 1.5, 9.82793723247329054082e-01)):
+        sel = x >= lim
+        c[sel], hi[sel] = cc, hh
+    num, den = x - c, 1.0 + c * x
+    big = x >= 2.4375
+    num[big], den[big], hi[big] = -1.0, x[big], 1.57079632679489655800e+00
+    t = num / den
+    z = t * t
+    w = z * z
+    s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))))
+    s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))))
+    got = hi - (t * (s1 + s2) - t)
+    ref = np.arctan(x)
+    assert np.max(np.abs(got - ref) / ref) < 4 * 2.0 ** -52
