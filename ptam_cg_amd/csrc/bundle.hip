@@ -56,27 +56,42 @@ struct BaProj {
 // (Sun fdlibm's published coefficients); the quotient uses rcp + 2 Newton steps.  Measured against
 // libm over [1e-8, 1e3]: <= 2 ulp (constants: tests/test_oracle_kat.py::test_atan_reduction_constants;
 // the device code itself is covered by the BA parity tests).
+// The constants come from a __constant__ table: uniform loads put them in SGPRs, which a VOP3 fp64
+// instruction reads directly — as literals each use would cost two v_mov_b32 and a VGPR pair.
+__constant__ double BA_ATAN_K[20] = {
+    3.33333333333329318027e-01,  -1.99999999998764832476e-01, 1.42857142725034663711e-01,  -1.11111104054623557880e-01,
+    9.09088713343650656196e-02,  -7.69187620504482999495e-02, 6.66107313738753120669e-02,  -5.83357013379057348645e-02,
+    4.97687799461593236017e-02,  -3.65315727442169155270e-02, 1.62858201153657823623e-02,
+    4.63647609000806093515e-01,  7.85398163397448278999e-01,  9.82793723247329054082e-01,  1.57079632679489655800e+00,
+    0.4375, 0.6875, 1.1875, 2.4375, 1.5};
 __device__ __forceinline__ double ba_atan_pos(double x) {
+    const double* __restrict__ K = BA_ATAN_K;
     double c = 0.0, hi = 0.0;
-    if (x >= 0.4375) c = 0.5, hi = 4.63647609000806093515e-01;
-    if (x >= 0.6875) c = 1.0, hi = 7.85398163397448278999e-01;
-    if (x >= 1.1875) c = 1.5, hi = 9.82793723247329054082e-01;
+    if (x >= K[15]) c = 0.5, hi = K[11];
+    if (x >= K[16]) c = 1.0, hi = K[12];
+    if (x >= K[17]) c = K[19], hi = K[13];
     double num = x - c, den = fma(c, x, 1.0);
-    if (x >= 2.4375) {
+    if (x >= K[18]) {
         num = -1.0;
         den = x;
-        hi = 1.57079632679489655800e+00;
+        hi = K[14];
     }
     const double t = num * rcp_nr(den);
     const double z = t * t, w = z * z;
-    const double s1 =
-        z * fma(w, fma(w, fma(w, fma(w, fma(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02), 6.66107313738753120669e-02),
-                               9.09088713343650656196e-02),
-                       1.42857142725034663711e-01),
-                3.33333333333329318027e-01);
-    const double s2 = w * fma(w, fma(w, fma(w, fma(w, -3.65315727442169155270e-02, -5.83357013379057348645e-02), -7.69187620504482999495e-02),
-                                     -1.11111104054623557880e-01),
-                              -1.99999999998764832476e-01);
+    // v_fma_f64 with the coefficient as an SGPR operand (left alone the compiler picks v_fmac and
+    // first copies every coefficient into a VGPR pair)
+#define FMA_SK(a, b, k) ({ double r_; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r_) : "v"(a), "v"(b), "s"(k)); r_; })
+    double p1 = FMA_SK(w, K[10], K[8]);   // (K[10] is copied once: two scalar operands are not encodable)
+    p1 = FMA_SK(w, p1, K[6]);
+    p1 = FMA_SK(w, p1, K[4]);
+    p1 = FMA_SK(w, p1, K[2]);
+    p1 = FMA_SK(w, p1, K[0]);
+    double p2 = FMA_SK(w, K[9], K[7]);
+    p2 = FMA_SK(w, p2, K[5]);
+    p2 = FMA_SK(w, p2, K[3]);
+    p2 = FMA_SK(w, p2, K[1]);
+#undef FMA_SK
+    const double s1 = z * p1, s2 = w * p2;
     return hi - (t * (s1 + s2) - t);
 }
 // 1/sqrt(a), a > 0: v_rsq_f64 + 2 Newton steps (<= 1 ulp)
@@ -681,7 +696,7 @@ __device__ __forceinline__ void k7_load(const BaDev& d, const double* __restrict
 #define K7_STAMP(i)
 #endif
 template <int THREADS, bool PREFETCH, bool LOOP>
-__global__ void __launch_bounds__(THREADS) jac_accum_wave_kernel(DevCam cam, BaDev d, int cur, int est, int per_wave) {
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) jac_accum_wave_kernel(DevCam cam, BaDev d, int cur, int est, int per_wave) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Ul = smem;
     double* Ps = smem + (((size_t)d.F * 27 + 1) & ~(size_t)1);
@@ -689,7 +704,8 @@ __global__ void __launch_bounds__(THREADS) jac_accum_wave_kernel(DevCam cam, BaD
     K7_WALL(0)
     const double* __restrict__ pt = d.pt[cur];
     const int n_chunks64 = (d.M + 63) >> 6;
-    const int c_begin = (blockIdx.x * (THREADS / 64) + (tid >> 6)) * per_wave;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: chunk bases live in SGPRs
+    const int c_begin = (blockIdx.x * (THREADS / 64) + wid) * per_wave;
     const int c_end = min(n_chunks64, c_begin + per_wave);
     // first chunk's loads and sigma^2 go out before the LDS prologue, so both latencies overlap it
     K7In in;
@@ -706,6 +722,7 @@ __global__ void __launch_bounds__(THREADS) jac_accum_wave_kernel(DevCam cam, BaD
     double err = 0;
     int nbad = 0;
     K7_STAMP(1)
+#pragma unroll 1
     for (int ci = c_begin; ci < c_end; ci++) {   // (LOOP == false: exactly one chunk per wave, see the break below)
         const int m0 = ci << 6;
         const int m = m0 + lane;
@@ -1772,17 +1789,37 @@ static int ba_prepare_impl(ptam_ba* ba) {
     const int n64_all = (M + 63) / 64;
     ba->k7_loop = ba->use_wave && n64_all > 256 * 24;
     ba->k7_threads = !ba->use_wave ? BA_CHUNK : (ba->k7_loop ? 256 : 512);
-    const void* k7 = !ba->use_wave ? (const void*)jac_accum_kernel
-                     : ba->k7_loop ? (const void*)jac_accum_wave_kernel<256, false, true>
-                                   : (const void*)jac_accum_wave_kernel<512, true, false>;
-    if (ba->smem_acc > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(k7, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba->smem_acc));
-    int per_cu = 0, n_cu = 256;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k7, ba->k7_threads, ba->smem_acc));
+    int n_cu = 256;
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
         n_cu = prop.multiProcessorCount;
+    }
+    auto k7_fn = [&](int threads) -> const void* {
+        return !ba->use_wave ? (const void*)jac_accum_kernel
+               : ba->k7_loop ? (threads == 256 ? (const void*)jac_accum_wave_kernel<256, false, true>
+                                               : (const void*)jac_accum_wave_kernel<512, false, true>)
+                             : (const void*)jac_accum_wave_kernel<512, true, false>;
+    };
+    auto k7_occupancy = [&](int threads, int* per_cu) -> int {
+        const void* k7 = k7_fn(threads);
+        if (ba->smem_acc > 64 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(k7, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba->smem_acc);
+            if (e != hipSuccess) return PTAM_E_HIP;
+        }
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k7, threads, ba->smem_acc) == hipSuccess ? PTAM_OK : PTAM_E_HIP;
+    };
+    int per_cu = 0;
+    if (int rc = k7_occupancy(ba->k7_threads, &per_cu)) return rc;
+    if (ba->k7_loop) {
+        // many cameras: the LDS partials (F*27 + C*12 doubles per workgroup) bound the workgroups per CU,
+        // so the wider workgroup keeps more waves resident
+        int per_cu512 = 0;
+        if (int rc = k7_occupancy(512, &per_cu512)) return rc;
+        if (per_cu512 * 8 > per_cu * 4) {
+            ba->k7_threads = 512;
+            per_cu = per_cu512;
+        }
     }
     per_cu = std::max(1, std::min(per_cu, 8));
     if (ba->use_wave) {
@@ -2010,8 +2047,11 @@ static int ba_pass1_sigma(ptam_ba* ba) {
 static void launch_k7(ptam_ba* ba) {
     ptam_ctx* ctx = ba->ctx;
     if (ba->use_wave) {
-        if (ba->k7_loop)
+        if (ba->k7_loop && ba->k7_threads == 256)
             hipLaunchKernelGGL((jac_accum_wave_kernel<256, false, true>), dim3(ba->d.grid_acc), dim3(256), ba->smem_acc,
+                               ctx->stream, ctx->cam, ba->d, ba->cur, ba->opts.estimator, ba->per_wave);
+        else if (ba->k7_loop)
+            hipLaunchKernelGGL((jac_accum_wave_kernel<512, false, true>), dim3(ba->d.grid_acc), dim3(512), ba->smem_acc,
                                ctx->stream, ctx->cam, ba->d, ba->cur, ba->opts.estimator, ba->per_wave);
         else
             hipLaunchKernelGGL((jac_accum_wave_kernel<512, true, false>), dim3(ba->d.grid_acc), dim3(512), ba->smem_acc,
