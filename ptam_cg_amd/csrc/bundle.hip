@@ -639,7 +639,7 @@ __device__ __forceinline__ void jac_flush(const BaDev& d, const double* Ul, doub
 
 // K7, wave variant (every point has <= 64 measurements): lane = measurement, a wave takes runs of
 // 64 consecutive measurements of the point-major order.  No workgroup barrier inside the loop.
-//  - balance: every wave gets the same number `per_wave` of consecutive 64-measurement chunks, and
+//  - balance: every wave gets `per_wave` (or one more) consecutive 64-measurement chunks, and
 //    the next chunk's inputs are prefetched while the current one is computed;
 //  - poses are staged once per workgroup in LDS (C*96 B); the chunk's points are fetched one per
 //    lane and handed to their measurements by ds_bpermute: ONE global round trip per chunk;
@@ -695,8 +695,12 @@ __device__ __forceinline__ void k7_load(const BaDev& d, const double* __restrict
 #define K7_WALL(i)
 #define K7_STAMP(i)
 #endif
-template <int THREADS, bool PREFETCH, bool LOOP>
-__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) jac_accum_wave_kernel(DevCam cam, BaDev d, int cur, int est, int per_wave) {
+// EST: the M-estimator as a compile-time constant (-1: taken from `est_arg`) — the default Tukey path then
+// carries none of the Cauchy / Huber code (log, sqrt and their constants)
+template <int THREADS, bool PREFETCH, bool LOOP, int EST>
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
+jac_accum_wave_kernel(DevCam cam, BaDev d, int cur, int est_arg, int per_wave, int extra) {
+    const int est = EST >= 0 ? EST : est_arg;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Ul = smem;
     double* Ps = smem + (((size_t)d.F * 27 + 1) & ~(size_t)1);
@@ -705,8 +709,19 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4,
     const double* __restrict__ pt = d.pt[cur];
     const int n_chunks64 = (d.M + 63) >> 6;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: chunk bases live in SGPRs
-    const int c_begin = (blockIdx.x * (THREADS / 64) + wid) * per_wave;
-    const int c_end = min(n_chunks64, c_begin + per_wave);
+    // chunk range of this wave: `per_wave` chunks each, and the first `extra` waves in (wave-in-block major,
+    // block minor) order take one more — the surplus lands on different CUs / SIMDs instead of piling
+    // onto the leading workgroups.  Ranges stay contiguous and ordered by (block, wave).
+    int c_begin, c_end;
+    {
+        constexpr int WPB = THREADS / 64;
+        const int blk = blockIdx.x, grid = gridDim.x;
+        const int full = extra / grid, rem = extra - full * grid;   // waves with wid < full (or == full, blk < rem) are long
+        const int before = blk * full + min(blk, rem) + min(wid, full) + ((wid > full && blk < rem) ? 1 : 0);
+        const int mine = per_wave + ((wid < full || (wid == full && blk < rem)) ? 1 : 0);
+        c_begin = (blk * WPB + wid) * per_wave + before;
+        c_end = min(n_chunks64, c_begin + mine);
+    }
     // first chunk's loads and sigma^2 go out before the LDS prologue, so both latencies overlap it
     K7In in;
     if (PREFETCH && c_begin < c_end) k7_load(d, pt, c_begin << 6, lane, in);
@@ -880,6 +895,19 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4,
     jac_flush<THREADS>(d, Ul, err, nbad);
     K7_STAMP(9)
     K7_WALL(1)
+}
+
+// the wave-variant instantiations: {one chunk per wave | looping, 256 or 512 threads} x {Tukey | run-time estimator}
+static const void* k7_wave_fn(int threads, bool loop, int est) {
+    const bool tukey = est == PTAM_EST_TUKEY;
+    if (!loop)
+        return tukey ? (const void*)jac_accum_wave_kernel<512, true, false, PTAM_EST_TUKEY>
+                     : (const void*)jac_accum_wave_kernel<512, true, false, -1>;
+    if (threads == 256)
+        return tukey ? (const void*)jac_accum_wave_kernel<256, true, true, PTAM_EST_TUKEY>
+                     : (const void*)jac_accum_wave_kernel<256, false, true, -1>;
+    return tukey ? (const void*)jac_accum_wave_kernel<512, true, true, PTAM_EST_TUKEY>
+                 : (const void*)jac_accum_wave_kernel<512, false, true, -1>;
 }
 
 // zero V / epsB of the points that are cut by a 64-measurement chunk boundary (targets of the atomics)
@@ -1593,7 +1621,7 @@ struct ptam_ba {
     int cur = 0;
     size_t smem_acc = 0;
     bool use_wave = false;
-    int per_wave = 1;
+    int per_wave = 1, extra_waves = 0;
     bool trial_is_current = false;   // the last trial was accepted: its new-error pass == pass 1 of the next step
     int k7_threads = BA_CHUNK;
     bool k7_loop = false;
@@ -1796,10 +1824,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
         n_cu = prop.multiProcessorCount;
     }
     auto k7_fn = [&](int threads) -> const void* {
-        return !ba->use_wave ? (const void*)jac_accum_kernel
-               : ba->k7_loop ? (threads == 256 ? (const void*)jac_accum_wave_kernel<256, false, true>
-                                               : (const void*)jac_accum_wave_kernel<512, false, true>)
-                             : (const void*)jac_accum_wave_kernel<512, true, false>;
+        return !ba->use_wave ? (const void*)jac_accum_kernel : k7_wave_fn(threads, ba->k7_loop, ba->opts.estimator);
     };
     auto k7_occupancy = [&](int threads, int* per_cu) -> int {
         const void* k7 = k7_fn(threads);
@@ -1826,9 +1851,19 @@ static int ba_prepare_impl(ptam_ba* ba) {
         // every wave gets the same number of consecutive 64-measurement chunks
         // one 64-measurement chunk per wave (straight-line kernel body: 68 VGPRs instead of ~160 for the
         // looping form, i.e. every chunk of a 250 k-measurement problem is resident at once)
-        const int n64 = (M + 63) / 64, slots = n_cu * per_cu * (ba->k7_threads / 64);
-        ba->per_wave = ba->k7_loop ? std::max(1, (n64 + slots - 1) / slots) : 1;
-        d.grid_acc = std::max(1, (n64 + ba->per_wave * (ba->k7_threads / 64) - 1) / (ba->per_wave * (ba->k7_threads / 64)));
+        const int n64 = (M + 63) / 64;
+        const int wpb = ba->k7_threads / 64;
+        if (ba->k7_loop) {
+            // every resident slot gets a workgroup; chunks are dealt out evenly (q or q + 1 per wave)
+            d.grid_acc = std::max(1, std::min(n_cu * per_cu, n64 / wpb));
+            const int waves = d.grid_acc * wpb;
+            ba->per_wave = n64 / waves;
+            ba->extra_waves = n64 - ba->per_wave * waves;
+        } else {
+            ba->per_wave = 1;
+            ba->extra_waves = 0;
+            d.grid_acc = std::max(1, (n64 + wpb - 1) / wpb);
+        }
     } else
         d.grid_acc = std::max(1, std::min(d.n_chunks, n_cu * per_cu));
 
@@ -2047,17 +2082,11 @@ static int ba_pass1_sigma(ptam_ba* ba) {
 static void launch_k7(ptam_ba* ba) {
     ptam_ctx* ctx = ba->ctx;
     if (ba->use_wave) {
-        if (ba->k7_loop && ba->k7_threads == 256)
-            hipLaunchKernelGGL((jac_accum_wave_kernel<256, false, true>), dim3(ba->d.grid_acc), dim3(256), ba->smem_acc,
-                               ctx->stream, ctx->cam, ba->d, ba->cur, ba->opts.estimator, ba->per_wave);
-        else if (ba->k7_loop)
-            hipLaunchKernelGGL((jac_accum_wave_kernel<512, false, true>), dim3(ba->d.grid_acc), dim3(512), ba->smem_acc,
-                               ctx->stream, ctx->cam, ba->d, ba->cur, ba->opts.estimator, ba->per_wave);
-        else
-            hipLaunchKernelGGL((jac_accum_wave_kernel<512, true, false>), dim3(ba->d.grid_acc), dim3(512), ba->smem_acc,
-                               ctx->stream, ctx->cam, ba->d, ba->cur, ba->opts.estimator, ba->per_wave);
-    }
-    else
+        int est = ba->opts.estimator;
+        void* args[] = {&ctx->cam, &ba->d, &ba->cur, &est, &ba->per_wave, &ba->extra_waves};
+        (void)hipLaunchKernel(k7_wave_fn(ba->k7_threads, ba->k7_loop, est), dim3(ba->d.grid_acc), dim3(ba->k7_threads), args,
+                              ba->smem_acc, ctx->stream);
+    } else
         hipLaunchKernelGGL(jac_accum_kernel, dim3(ba->d.grid_acc), dim3(BA_CHUNK), ba->smem_acc, ctx->stream, ctx->cam, ba->d,
                            ba->cur, ba->opts.estimator);
 }
