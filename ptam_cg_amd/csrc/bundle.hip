@@ -649,7 +649,7 @@ __device__ __forceinline__ void jac_flush(const BaDev& d, const double* Ul, doub
 //    (at most two pieces since n_i <= 64) is completed with fp64 atomics on the zeroed V / epsB —
 //    0 + a + b is order independent, so the result stays deterministic;
 //  - W: 9 coalesced double2 planes.
-// dynamic LDS: Ul[F*27] | poses[C*12]
+// dynamic LDS: Ul[F*27] | poses[C*12] + 1 spare slot
 struct K7In {
     int st, c, p, fidx;
     double2 fo;
@@ -659,33 +659,28 @@ struct K7In {
     int p_prev, p_next;  // point of the measurement just before / after this chunk (-1 at the ends)
 };
 __device__ __forceinline__ void k7_load(const BaDev& d, const double* __restrict__ pt, int m0, int lane, K7In& in) {
+    // every load is unconditional (clamped index, result masked afterwards): with no branch between
+    // them the compiler can wait for the older ones by count instead of draining the whole queue
     const int m = m0 + lane;
-    in.st = MS_DEAD;
-    in.c = 0;
-    in.p = 0;
-    in.fidx = -1;
-    in.fo = make_double2(0, 0);
-    in.sn = 0;
-    in.px = in.py = in.pz = 0;
     const int mlast = min(m0 + 63, d.M - 1);
+    const int mc = min(m, mlast);
     in.pt0 = d.m_pt[m0];
     const int pt1 = d.m_pt[mlast];
-    in.p_prev = m0 > 0 ? d.m_pt[m0 - 1] : -1;
-    in.p_next = m0 + 64 < d.M ? d.m_pt[m0 + 64] : -1;
-    if (m < d.M) {
-        in.st = d.m_state[m];
-        in.c = d.m_cam[m];
-        in.p = d.m_pt[m];
-        in.fidx = d.m_fidx[m];
-        in.fo = d.m_found[m];
-        in.sn = d.m_s[m];
-    }
-    if (in.pt0 + lane <= pt1) {
-        const double* q = pt + 3 * (size_t)(in.pt0 + lane);
-        in.px = q[0];
-        in.py = q[1];
-        in.pz = q[2];
-    }
+    in.p_prev = d.m_pt[max(m0 - 1, 0)];
+    in.p_next = d.m_pt[min(m0 + 64, d.M - 1)];
+    if (m0 == 0) in.p_prev = -1;
+    if (m0 + 64 >= d.M) in.p_next = -1;
+    in.st = d.m_state[mc];
+    in.c = d.m_cam[mc];
+    in.p = d.m_pt[mc];
+    in.fidx = d.m_fidx[mc];
+    in.fo = d.m_found[mc];
+    in.sn = d.m_s[mc];
+    // (lanes past the end hold a copy of the last measurement: the caller masks them)
+    const double* q = pt + 3 * (size_t)min(in.pt0 + lane, pt1);
+    in.px = q[0];
+    in.py = q[1];
+    in.pz = q[2];
 }
 
 #ifdef K7_TIMING
@@ -697,6 +692,17 @@ __device__ __forceinline__ void k7_load(const BaDev& d, const double* __restrict
 #endif
 // EST: the M-estimator as a compile-time constant (-1: taken from `est_arg`) — the default Tukey path then
 // carries none of the Cauchy / Huber code (log, sqrt and their constants)
+// ablation switches for tools/ experiments (never defined in the product build)
+#ifdef K7_NOATOM
+#define K7_UADD(p, v) asm volatile("" ::"v"(v))
+#else
+#define K7_UADD(p, v) atomicAdd(p, v)
+#endif
+#ifdef K7_NOW
+#define K7_WSTORE(dst, v) { const double2 v_ = v; asm volatile("" ::"v"(v_.x), "v"(v_.y)); }
+#else
+#define K7_WSTORE(dst, v) dst = v
+#endif
 template <int THREADS, bool PREFETCH, bool LOOP, int EST>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
 jac_accum_wave_kernel(DevCam cam, BaDev d, int cur, int est_arg, int per_wave, int extra) {
@@ -722,15 +728,27 @@ jac_accum_wave_kernel(DevCam cam, BaDev d, int cur, int est_arg, int per_wave, i
         c_begin = (blk * WPB + wid) * per_wave + before;
         c_end = min(n_chunks64, c_begin + mine);
     }
-    // first chunk's loads and sigma^2 go out before the LDS prologue, so both latencies overlap it
-    K7In in;
-    if (PREFETCH && c_begin < c_end) k7_load(d, pt, c_begin << 6, lane, in);
-    const double sigma_sq = d.sc->sigma_sq;
+    // Global loads leave in the order they are needed: poses (staged to LDS before the barrier), then
+    // the first chunk's inputs and sigma^2 — memory returns in order, so the barrier waits for ONE
+    // round trip while the chunk's second, dependent one (m_pt -> point) is still in flight.
     for (int k = tid; k < d.F * 27; k += THREADS) Ul[k] = 0;
-    {
-        const double* __restrict__ pose = d.pose[cur];
-        for (int k = tid; k < d.C * 12; k += THREADS) Ps[k] = pose[k];
+    const double* __restrict__ pose = d.pose[cur];
+    const int n_pose = d.C * 12;
+    double pv[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int k = tid + i * THREADS;
+        pv[i] = pose[min(k, n_pose - 1)];
     }
+    K7In in;
+    if (PREFETCH) k7_load(d, pt, min(c_begin, n_chunks64 - 1) << 6, lane, in);   // (idle waves load a valid chunk and drop it)
+    const double sigma_sq = d.sc->sigma_sq;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {   // (unconditional like the loads: surplus threads hit the spare slot Ps[n_pose])
+        const int k = tid + i * THREADS;
+        Ps[min(k, n_pose)] = pv[i];
+    }
+    for (int k = tid + 2 * THREADS; k < n_pose; k += THREADS) Ps[k] = pose[k];
     __syncthreads();
     K7_STAMP(0)
     const double inv_sigma_sq = 1.0 / sigma_sq;
@@ -746,7 +764,7 @@ jac_accum_wave_kernel(DevCam cam, BaDev d, int cur, int est_arg, int per_wave, i
         const K7In cu = in;
         K7_STAMP(2)
         if (PREFETCH && LOOP && ci + 1 < c_end) k7_load(d, pt, (ci + 1) << 6, lane, in);   // prefetch the next chunk
-        const int st = cu.st, c = cu.c, p = cu.p, fidx = cu.fidx;
+        const int st = active ? cu.st : MS_DEAD, c = cu.c, p = cu.p, fidx = active ? cu.fidx : -1;
         const int src = p - cu.pt0;   // lane that fetched my point
         const double Xw = __shfl(cu.px, src, 64), Yw = __shfl(cu.py, src, 64), Zw = __shfl(cu.pz, src, 64);
         int pid = active ? p : (-1 - lane);   // inactive lanes: unique ids, never merged
@@ -816,16 +834,16 @@ jac_accum_wave_kernel(DevCam cam, BaDev d, int cur, int est_arg, int per_wave, i
 #pragma unroll
                 for (int a = 0; a < 6; a++)
 #pragma unroll
-                    for (int b = 0; b <= a; b++) atomicAdd(&Uc[k++], A0[a] * A0[b] + A1[a] * A1[b]);   // U_LL :21-26
+                    for (int b = 0; b <= a; b++) K7_UADD(&Uc[k++], A0[a] * A0[b] + A1[a] * A1[b]);   // U_LL :21-26
 #pragma unroll
-                for (int a = 0; a < 6; a++) atomicAdd(&Uc[21 + a], A0[a] * ex + A1[a] * ey);       // epsA :321
+                for (int a = 0; a < 6; a++) K7_UADD(&Uc[21 + a], A0[a] * ex + A1[a] * ey);       // epsA :321
                 __builtin_amdgcn_sched_barrier(0);
                 K7_STAMP(5)
 #pragma unroll
                 for (int q = 0; q < 9; q++) {   // W = A^T B (:331), 9 coalesced double2 planes
                     const int i0 = 2 * q, i1 = 2 * q + 1;
-                    d.W[(size_t)q * d.M + m] = make_double2(A0[i0 / 3] * B0[i0 % 3] + A1[i0 / 3] * B1[i0 % 3],
-                                                            A0[i1 / 3] * B0[i1 % 3] + A1[i1 / 3] * B1[i1 % 3]);
+                    K7_WSTORE(d.W[(size_t)q * d.M + m], make_double2(A0[i0 / 3] * B0[i0 % 3] + A1[i0 / 3] * B1[i0 % 3],
+                                                                     A0[i1 / 3] * B0[i1 % 3] + A1[i1 / 3] * B1[i1 % 3]));
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -860,6 +878,7 @@ jac_accum_wave_kernel(DevCam cam, BaDev d, int cur, int est_arg, int per_wave, i
             _Pragma("unroll") for (int i = 0; i < 9; i++) v[i] += t[i];  \
         }                                                                \
     }
+#ifndef K7_NOSCAN
         SEG_STEP(dpp_row_shr0_i32<1>(pid1), dpp_row_shr_f64<1>(v[i]))
         SEG_STEP(dpp_row_shr0_i32<2>(pid1), dpp_row_shr_f64<2>(v[i]))
         SEG_STEP(dpp_row_shr0_i32<4>(pid1), dpp_row_shr_f64<4>(v[i]))
@@ -867,6 +886,7 @@ jac_accum_wave_kernel(DevCam cam, BaDev d, int cur, int est_arg, int per_wave, i
         // row carries: only rows 1,3 (then 2,3) take part; 0 never matches a point id
         SEG_STEP((dpp_bcastx_i32<0x142>(pid1) & -((lane >> 4) & 1)), dpp_bcastx_f64<0x142>(v[i]))
         SEG_STEP((dpp_bcastx_i32<0x143>(pid1) & -((lane >> 5) & 1)), dpp_bcastx_f64<0x143>(v[i]))
+#endif
 #undef SEG_STEP
         K7_STAMP(7)
         const int pn = __shfl_down(pid, 1, 64);
@@ -1808,7 +1828,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.n_schur_wg = (int)s_wgs.size();
     d.n_schur_entries = (int)s_entries.size();
     // persistent grid of the accumulate kernel: bounded by LDS residency, 2 x 256 CUs by default
-    ba->smem_acc = ((((size_t)F * 27 + 1) & ~(size_t)1) + (ba->use_wave ? (size_t)C * 12 : (size_t)BA_CHUNK * 8)) * sizeof(double);
+    ba->smem_acc = ((((size_t)F * 27 + 1) & ~(size_t)1) + (ba->use_wave ? (size_t)C * 12 + 2 : (size_t)BA_CHUNK * 8)) * sizeof(double);
     // wave variant, two shapes:
     //  - few chunks (every 64-measurement chunk can be resident at once: <= 24 waves per CU):
     //    straight-line kernel, ONE chunk per wave, 512-thread workgroups (64 VGPRs);
@@ -2494,7 +2514,6 @@ int ptam_ba_bench_jacobian(ptam_ba* ba, int reps, double* avg_ms, double* algori
         std::printf("K7 stamps (10 ns ticks since kernel-body start):");
         for (int i = 1; i < 10; i++) std::printf(" [%d] %lld", i, h[i] - h[0]);
         std::printf("\n");
-        std::printf("K7 block 7: body start is %lld ticks after the block's first instruction\n", h[0] - h[16 + 14]);
         const int nb = std::min(ba->d.grid_acc, 2000);
         std::vector<long long> w(2 * nb);
         HIP_TRY(hipMemcpy(w.data(), d.dbg + 16, w.size() * 8, hipMemcpyDeviceToHost));
@@ -2505,6 +2524,7 @@ int ptam_ba_bench_jacobian(ptam_ba* ba, int reps, double* avg_ms, double* algori
         std::sort(st.begin(), st.end());
         std::sort(en.begin(), en.end());
         std::sort(du.begin(), du.end());
+        std::printf("K7 block 7: body starts %lld ticks after the block's first instruction\n", h[0] - w[14]);
         std::printf("K7 wall (10 ns ticks, %d blocks): start p0/p50/p90/p100 %lld %lld %lld %lld | end %lld %lld %lld %lld | dur %lld %lld %lld %lld\n",
                     nb, st[0], st[nb / 2], st[nb * 9 / 10], st[nb - 1], en[0], en[nb / 2], en[nb * 9 / 10], en[nb - 1], du[0], du[nb / 2],
                     du[nb * 9 / 10], du[nb - 1]);
