@@ -2474,7 +2474,7 @@ int ptam_ba_counts(const ptam_ba* ba, int* n_cams, int* n_free, int* n_points, i
     return PTAM_OK;
 }
 
-// K7 alone, HIP-event timed per launch (bench.py roofline leg)
+// K7 alone, HIP-event timed over `reps` launches (bench.py roofline leg)
 int ptam_ba_bench_jacobian(ptam_ba* ba, int reps, double* avg_ms, double* algorithmic_bytes) {
     ARG_TRY(ba && reps > 0);
     ptam_ctx* ctx = ba->ctx;
@@ -2494,16 +2494,16 @@ int ptam_ba_bench_jacobian(ptam_ba* ba, int reps, double* avg_ms, double* algori
         launch_k7(ba);   // (the V / epsB of boundary-cut points keep accumulating across these benchmark
                          //  repetitions; their values are not used: Compute() re-runs pass 1, which clears them)
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    double total = 0;
-    for (int i = 0; i < reps; i++) {
-        HIP_TRY(hipEventRecord(e0, ctx->stream));
-        launch_k7(ba);
-        HIP_TRY(hipEventRecord(e1, ctx->stream));
-        HIP_TRY(hipEventSynchronize(e1));
-        float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-        total += ms;
-    }
+    // one event pair around `reps` back-to-back launches: the average is the kernel's steady-state
+    // duration (an event pair around a single launch adds ~6 us of record / completion latency — an empty
+    // kernel measures 6.3 us that way, tools/membw — and would not agree with rocprofv3's kernel trace)
+    HIP_TRY(hipEventRecord(e0, ctx->stream));
+    for (int i = 0; i < reps; i++) launch_k7(ba);
+    HIP_TRY(hipEventRecord(e1, ctx->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms_total = 0;
+    HIP_TRY(hipEventElapsedTime(&ms_total, e0, e1));
+    const double total = ms_total;
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     ba->prof = prof;

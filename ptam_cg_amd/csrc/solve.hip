@@ -2,24 +2,32 @@
 // `Cholesky<>(mS).backsub(vE)`: TooN's unpivoted LDL^T reading the lower triangle).
 //
 // Blocked right-looking LDL^T, block size 32, ONE launch per block column k.  Every workgroup of
-// step k re-factors the 32x32 diagonal block in LDS (cheap; avoids an extra launch + hand-off) and,
-// in the SAME loop, carries along
+// step k re-factors the 32x32 diagonal block (cheap; avoids an extra launch + hand-off) and, in the
+// SAME loop, carries along
 //   - its panel blocks  X = A_ik * Lkk^-T  (so L_ik = X * D^-1),
 //   - the forward substitution of the right-hand side block  z_k = Lkk^-1 * b_k.
-// The loop advances FOUR columns per iteration: the 4x4 pivot block is factored redundantly in
-// registers by every thread (reciprocals by v_rcp_f64 + 2 Newton steps), so the sequential chain is
-// 8 LDS round trips per block instead of 32.
-// Workgroup roles in step k (rem = NB-k-1): [0] finaliser: writes Lkk, D_k, z_k;
-// [1..rem] panel row i: writes L_ik and b_i -= L_ik z_k; [rest] trailing tile (i,j): A_ij -= X_i D^-1 X_j^T.
-// The factor goes to a separate buffer L, so no workgroup reads a block another one writes in the
-// same launch.  A final single-workgroup kernel does D^-1 and the backward substitution with L^T
-// (diagonal blocks staged in LDS, the 32-step triangular chain in registers of one wave).
+// The sequential chain is what bounds a step, so it is kept as short as the data flow allows:
+//   - thread (r, g) of the 256 owns row r, columns g, g+8, g+16, g+24 (cyclic, so the remaining work
+//     per thread shrinks evenly) of every block the workgroup carries, IN REGISTERS, for the whole step;
+//   - the loop advances FOUR columns per iteration.  Only the panel of the iteration (32 rows x 4
+//     columns per block) goes through LDS, double buffered, so an
+//     iteration is ONE barrier and one LDS round trip: read panel -> factor the 4x4 pivot block
+//     redundantly in registers (reciprocals by v_rcp_f64 + 2 Newton steps) -> substitute my rows ->
+//     rank-4 update of my strips -> the owners of the next panel publish it.
+// Workgroup roles in step k (rem = NB-k-1): [0] finaliser: writes D_k, z_k and — by carrying the
+// identity as its panel block — Lkk^-T, which is all the backward substitution needs of the diagonal
+// block; [1..rem] panel row i: writes L_ik and b_i -= L_ik z_k; [rest] trailing tile (i,j):
+// A_ij -= X_i D^-1 X_j^T.  The factor goes to a separate buffer L, so no workgroup reads a block
+// another one writes in the same launch.
+// A final single-workgroup kernel does D^-1 and the backward substitution with L^T, right-looking:
+// per block a 32x32 mat-vec with Lkk^-T, then every pending block below is updated in parallel.
 #include "bundle.h"
 
 #define NB SOLVE_NB
-#define LDP (NB + 1)        // LDS pitch in doubles (odd -> conflict-free column access)
-#define TPB (NB * NB / 4)   // threads per workgroup: 4 columns of one row per thread (256 @ NB=32, 1024 @ NB=64)
-#define GROUPS (NB / 4)     // column groups: thread (r, g) owns columns g, g+GROUPS, g+2*GROUPS, g+3*GROUPS
+#define LDP (NB + 1)    // LDS pitch in doubles (odd -> conflict-free column access)
+#define TPB 256         // 32 rows x 8 strips
+#define STRIPS (NB / 4)
+static_assert(NB == 32, "the strip decomposition below is written for 32x32 blocks");
 
 __device__ __forceinline__ double fast_rcp(double d) {
     double x = __builtin_amdgcn_rcp(d);
@@ -32,11 +40,15 @@ __device__ __forceinline__ double fast_rcp(double d) {
 struct Micro {
     double l10, l20, l21, l30, l31, l32;
     double i0, i1, i2, i3;
-    double d1, d2, d3, u21, u31, u32;
+    double d0, d1, d2, d3, u10, u20, u30, u21, u31, u32;
 };
 __device__ __forceinline__ Micro micro_factor(double m00, double m10, double m11, double m20, double m21, double m22,
                                               double m30, double m31, double m32, double m33) {
     Micro f;
+    f.d0 = m00;
+    f.u10 = m10;
+    f.u20 = m20;
+    f.u30 = m30;
     f.i0 = fast_rcp(m00);
     f.l10 = m10 * f.i0;
     f.l20 = m20 * f.i0;
@@ -63,18 +75,21 @@ __device__ __forceinline__ void micro_subst(const Micro& f, const double a[4], d
     x[3] = a[3] - x[0] * f.l30 - x[1] * f.l31 - x[2] * f.l32;
 }
 
+struct StepLds {
+    double P[2][3][NB][4];   // the iteration's panel (raw strips of A_kk, A_i, A_j), double buffered
+    double Pb[2][4];         // rhs entries of the pivot rows
+    double Xi[NB * LDP];     // closing phase: X_i (and X_j D^-1) tiles
+    double Xj[NB * LDP];
+    double iD[NB], Dv[NB], z[NB];
+};
+
 __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
-    extern __shared__ __attribute__((aligned(16))) double step_lds[];
-    double* Akk = step_lds;
-    double* Ai = Akk + NB * LDP;
-    double* Aj = Ai + NB * LDP;
-    double* iD = Aj + NB * LDP;
-    double* bz = iD + NB;
+    __shared__ StepLds s;
     const int npad = d.npad, nblk = npad / NB, rem = nblk - k - 1;
     double* __restrict__ S = d.SE;
     double* __restrict__ E = d.SE + (size_t)npad * npad;
     const int tid = threadIdx.x;
-    const int r = tid / GROUPS, g = tid % GROUPS;   // row, column group
+    const int r = tid / STRIPS, g = tid % STRIPS;   // row, column residue (columns g + 8*jj)
     int role, bi = 0, bj = 0;
     const int wg = blockIdx.x;
     if (wg == 0)
@@ -91,157 +106,157 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
         bi = k + 1 + ii;
         bj = k + 1 + (t - ii * (ii + 1) / 2);
     }
-    const bool pan = role != 0;
     const bool two = role == 2 && bi != bj;
-    // load: A_kk mirrored from its lower triangle, panels, rhs
+    // ---- load my columns q = g + 8*jj (A_kk: only its lower triangle is ever read) ----
+    double akk[4], ai[4], aj[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int jj = 0; jj < 4; jj++) {
-        const int q = g + GROUPS * jj;
-        const int rr = r >= q ? r : q, cc = r >= q ? q : r;
-        Akk[r * LDP + q] = S[(size_t)(k * NB + rr) * npad + k * NB + cc];
-        if (pan) Ai[r * LDP + q] = S[(size_t)(bi * NB + r) * npad + k * NB + q];
-        if (two) Aj[r * LDP + q] = S[(size_t)(bj * NB + r) * npad + k * NB + q];
+        const int q = g + STRIPS * jj;
+        akk[jj] = S[(size_t)(k * NB + r) * npad + k * NB + q];
+        if (role == 0)   // the identity rides along as the panel block: its X is Lkk^-T
+            ai[jj] = (q == r) ? 1.0 : 0.0;
+        else
+            ai[jj] = S[(size_t)(bi * NB + r) * npad + k * NB + q];
+        if (two) aj[jj] = S[(size_t)(bj * NB + r) * npad + k * NB + q];
     }
-    if (tid < NB) bz[tid] = E[k * NB + tid];
+    double br = (g == STRIPS - 1) ? E[k * NB + r] : 0.0;   // thread (r, 7) carries b_r
 #ifdef K7_TIMING
     const long long ts0 = (long long)__builtin_readcyclecounter();
 #endif
+    // publish panel 0 (columns 0..3: threads g < 4, register 0)
+    if (g < 4) {
+        s.P[0][0][r][g] = akk[0];
+        s.P[0][1][r][g] = ai[0];
+        s.P[0][2][r][g] = aj[0];
+    }
+    if (g == STRIPS - 1 && r < 4) s.Pb[0][r] = br;
+    __syncthreads();
 
-    for (int c0 = 0; c0 < NB; c0 += 4) {
-        __syncthreads();   // (A) previous panel's writes visible
-        // ---- reads (original values of this panel) ----
-        const Micro f = micro_factor(Akk[c0 * LDP + c0], Akk[(c0 + 1) * LDP + c0], Akk[(c0 + 1) * LDP + c0 + 1],
-                                     Akk[(c0 + 2) * LDP + c0], Akk[(c0 + 2) * LDP + c0 + 1], Akk[(c0 + 2) * LDP + c0 + 2],
-                                     Akk[(c0 + 3) * LDP + c0], Akk[(c0 + 3) * LDP + c0 + 1], Akk[(c0 + 3) * LDP + c0 + 2],
-                                     Akk[(c0 + 3) * LDP + c0 + 3]);
-        // multipliers of my (up to 4) columns q: lq = (row q of Akk through the micro factor) * D^-1
-        double lq[4][4];
+    // Fully unrolled: the panel of iteration t is register t/2 of the threads with g/4 == t%2, so every
+    // register index below is a compile-time constant.
 #pragma unroll
-        for (int jj = 0; jj < 4; jj++) {
-            const int q = g + GROUPS * jj;
-            if (q > c0 + 3) {
-                const double a[4] = {Akk[q * LDP + c0], Akk[q * LDP + c0 + 1], Akk[q * LDP + c0 + 2], Akk[q * LDP + c0 + 3]};
-                double x[4];
-                micro_subst(f, a, x);
-                lq[jj][0] = x[0] * f.i0;
-                lq[jj][1] = x[1] * f.i1;
-                lq[jj][2] = x[2] * f.i2;
-                lq[jj][3] = x[3] * f.i3;
-            } else {
-                lq[jj][0] = lq[jj][1] = lq[jj][2] = lq[jj][3] = 0;
-            }
-        }
-        // my row through the micro factor, in each matrix
-        double xk[4] = {0, 0, 0, 0}, xi[4] = {0, 0, 0, 0}, xj[4] = {0, 0, 0, 0};
-        if (r > c0 + 3) {
-            const double a[4] = {Akk[r * LDP + c0], Akk[r * LDP + c0 + 1], Akk[r * LDP + c0 + 2], Akk[r * LDP + c0 + 3]};
+    for (int t = 0; t < STRIPS; t++) {
+        const int c0 = 4 * t, pb = t & 1, jp = t >> 1, gh = t & 1;
+        const double(*Pk)[4] = s.P[pb][0];
+        const double(*Pi)[4] = s.P[pb][1];
+        const double(*Pj)[4] = s.P[pb][2];
+        const Micro f = micro_factor(Pk[c0][0], Pk[c0 + 1][0], Pk[c0 + 1][1], Pk[c0 + 2][0], Pk[c0 + 2][1], Pk[c0 + 2][2],
+                                     Pk[c0 + 3][0], Pk[c0 + 3][1], Pk[c0 + 3][2], Pk[c0 + 3][3]);
+        // my rows of the panel through the micro factor
+        double xk[4] = {0, 0, 0, 0}, xi[4], xj[4] = {0, 0, 0, 0};
+        const bool below = r > c0 + 3;
+        if (below) {
+            const double a[4] = {Pk[r][0], Pk[r][1], Pk[r][2], Pk[r][3]};
             micro_subst(f, a, xk);
         }
-        if (pan) {
-            const double a[4] = {Ai[r * LDP + c0], Ai[r * LDP + c0 + 1], Ai[r * LDP + c0 + 2], Ai[r * LDP + c0 + 3]};
+        {
+            const double a[4] = {Pi[r][0], Pi[r][1], Pi[r][2], Pi[r][3]};
             micro_subst(f, a, xi);
         }
         if (two) {
-            const double a[4] = {Aj[r * LDP + c0], Aj[r * LDP + c0 + 1], Aj[r * LDP + c0 + 2], Aj[r * LDP + c0 + 3]};
+            const double a[4] = {Pj[r][0], Pj[r][1], Pj[r][2], Pj[r][3]};
             micro_subst(f, a, xj);
         }
-        double z[4];
+        // rank-4 update of my columns right of the panel: the multipliers of column q are row q of the panel
+#pragma unroll
+        for (int jj = jp; jj < 4; jj++) {
+            const int q = g + STRIPS * jj;
+            if (jj > jp || q > c0 + 3) {
+                const double a[4] = {Pk[q][0], Pk[q][1], Pk[q][2], Pk[q][3]};
+                double x[4];
+                micro_subst(f, a, x);
+                const double l0 = x[0] * f.i0, l1 = x[1] * f.i1, l2 = x[2] * f.i2, l3 = x[3] * f.i3;
+                akk[jj] -= xk[0] * l0 + xk[1] * l1 + xk[2] * l2 + xk[3] * l3;
+                ai[jj] -= xi[0] * l0 + xi[1] * l1 + xi[2] * l2 + xi[3] * l3;
+                aj[jj] -= xj[0] * l0 + xj[1] * l1 + xj[2] * l2 + xj[3] * l3;
+            }
+        }
+        if ((g >> 2) == gh) {
+            // my column jp IS panel column n: it takes its final value (X = A * L^-T; pivot rows: D / undivided L*D)
+            const int n = g & 3;
+            const double xkn = n == 0 ? xk[0] : n == 1 ? xk[1] : n == 2 ? xk[2] : xk[3];
+            if (below)
+                akk[jp] = xkn;
+            else if (r == c0 + 1 && n == 1)
+                akk[jp] = f.d1;
+            else if (r == c0 + 2 && n >= 1)
+                akk[jp] = n == 1 ? f.u21 : f.d2;
+            else if (r == c0 + 3 && n >= 1)
+                akk[jp] = n == 1 ? f.u31 : n == 2 ? f.u32 : f.d3;
+            ai[jp] = n == 0 ? xi[0] : n == 1 ? xi[1] : n == 2 ? xi[2] : xi[3];
+            aj[jp] = n == 0 ? xj[0] : n == 1 ? xj[1] : n == 2 ? xj[2] : xj[3];
+        }
+        // right-hand side: z = Lmicro^-1 b (same recurrence), rows below take b_r -= L[r][c0..c0+3] . z
         {
-            const double b4[4] = {bz[c0], bz[c0 + 1], bz[c0 + 2], bz[c0 + 3]};
-            micro_subst(f, b4, z);   // same recurrence: z = Lmicro^-1 b
-        }
-        const double bzr = (g == 1 && r > c0 + 3) ? bz[r] : 0.0;
-        __syncthreads();   // (B) every read of the old panel is done
-        // ---- writes ----
-#pragma unroll
-        for (int jj = 0; jj < 4; jj++) {
-            const int q = g + GROUPS * jj;
-            if (q > c0 + 3) {
-                const double* l = lq[jj];
-                if (q <= r) Akk[r * LDP + q] -= xk[0] * l[0] + xk[1] * l[1] + xk[2] * l[2] + xk[3] * l[3];
-                if (pan) Ai[r * LDP + q] -= xi[0] * l[0] + xi[1] * l[1] + xi[2] * l[2] + xi[3] * l[3];
-                if (two) Aj[r * LDP + q] -= xj[0] * l[0] + xj[1] * l[1] + xj[2] * l[2] + xj[3] * l[3];
+            const double b4[4] = {s.Pb[pb][0], s.Pb[pb][1], s.Pb[pb][2], s.Pb[pb][3]};
+            double z[4];
+            micro_subst(f, b4, z);
+            if (g == STRIPS - 1 && below) br -= xk[0] * f.i0 * z[0] + xk[1] * f.i1 * z[1] + xk[2] * f.i2 * z[2] + xk[3] * f.i3 * z[3];
+            if (tid == 0) {
+                s.z[c0] = z[0], s.z[c0 + 1] = z[1], s.z[c0 + 2] = z[2], s.z[c0 + 3] = z[3];
+                s.iD[c0] = f.i0, s.iD[c0 + 1] = f.i1, s.iD[c0 + 2] = f.i2, s.iD[c0 + 3] = f.i3;
+                s.Dv[c0] = f.d0, s.Dv[c0 + 1] = f.d1, s.Dv[c0 + 2] = f.d2, s.Dv[c0 + 3] = f.d3;
             }
         }
-        if (g == 0) {
-            if (r > c0 + 3) {
-#pragma unroll
-                for (int m = 0; m < 4; m++) Akk[r * LDP + c0 + m] = xk[m];
+        if (t + 1 < STRIPS) {
+            // the owners of the next panel publish it
+            const int jn = (t + 1) >> 1, ghn = (t + 1) & 1;
+            if ((g >> 2) == ghn) {
+                s.P[pb ^ 1][0][r][g & 3] = akk[jn];
+                s.P[pb ^ 1][1][r][g & 3] = ai[jn];
+                s.P[pb ^ 1][2][r][g & 3] = aj[jn];
             }
-            if (pan) {
-#pragma unroll
-                for (int m = 0; m < 4; m++) Ai[r * LDP + c0 + m] = xi[m];
-            }
-            if (two) {
-#pragma unroll
-                for (int m = 0; m < 4; m++) Aj[r * LDP + c0 + m] = xj[m];
-            }
+            if (g == STRIPS - 1 && r >= c0 + 4 && r < c0 + 8) s.Pb[pb ^ 1][r - c0 - 4] = br;
         }
-        if (g == 1 && r > c0 + 3)   // rhs rows below the panel: b_r -= L[r][c0..c0+3] . z
-            bz[r] = bzr - (xk[0] * f.i0 * z[0] + xk[1] * f.i1 * z[1] + xk[2] * f.i2 * z[2] + xk[3] * f.i3 * z[3]);
-        if (tid == 2) {
-            // rows of the pivot block itself: D on the diagonal, undivided L*D below it
-            Akk[(c0 + 1) * LDP + c0 + 1] = f.d1;
-            Akk[(c0 + 2) * LDP + c0 + 1] = f.u21;
-            Akk[(c0 + 2) * LDP + c0 + 2] = f.d2;
-            Akk[(c0 + 3) * LDP + c0 + 1] = f.u31;
-            Akk[(c0 + 3) * LDP + c0 + 2] = f.u32;
-            Akk[(c0 + 3) * LDP + c0 + 3] = f.d3;
-            bz[c0 + 1] = z[1];
-            bz[c0 + 2] = z[2];
-            bz[c0 + 3] = z[3];
-        }
+        __syncthreads();
     }
-    __syncthreads();
 #ifdef K7_TIMING
     const long long ts1 = (long long)__builtin_readcyclecounter();
 #endif
-    if (tid < NB) iD[tid] = fast_rcp(Akk[tid * LDP + tid]);
-    __syncthreads();
-    if (role == 0) {
+    // ---- closing phase ----
+    double id4[4];
 #pragma unroll
-        for (int jj = 0; jj < 4; jj++) {
-            const int q = g + GROUPS * jj;
-            double v = 0.0;
-            if (q < r)
-                v = Akk[r * LDP + q] * iD[q];
-            else if (q == r)
-                v = 1.0;
-            d.L[(size_t)(k * NB + r) * npad + k * NB + q] = v;
-        }
+    for (int jj = 0; jj < 4; jj++) id4[jj] = s.iD[g + STRIPS * jj];
+    if (role == 0) {
+        // diagonal block of the factor buffer: Lkk^-T (upper triangular, unit diagonal) for the backward pass
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) d.L[(size_t)(k * NB + r) * npad + k * NB + g + STRIPS * jj] = ai[jj];
         if (tid < NB) {
-            d.Dg[k * NB + tid] = Akk[tid * LDP + tid];
-            d.y[k * NB + tid] = bz[tid];
+            d.Dg[k * NB + tid] = s.Dv[tid];
+            d.y[k * NB + tid] = s.z[tid];
         }
     } else if (role == 1) {
+        // L_ik = X_i D^-1 ;  b_i -= L_ik z_k : per-thread partial, then the 8 threads of a row (consecutive lanes)
+        double sum = 0;
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
-            const int q = g + GROUPS * jj;
-            d.L[(size_t)(bi * NB + r) * npad + k * NB + q] = Ai[r * LDP + q] * iD[q];
+            const int q = g + STRIPS * jj;
+            const double l = ai[jj] * id4[jj];
+            d.L[(size_t)(bi * NB + r) * npad + k * NB + q] = l;
+            sum += l * s.z[q];
         }
-        if (tid < NB) {
-            double s = 0;
-            for (int c = 0; c < NB; c++) s += (Ai[tid * LDP + c] * iD[c]) * bz[c];
-            E[bi * NB + tid] -= s;
-        }
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        sum += __shfl_xor(sum, 4, 64);
+        if (g == 0) E[bi * NB + r] -= sum;
     } else {
-        // scale X_j by D^-1 once, in place (X_i when the tile is diagonal needs an unscaled copy: use Aj)
-        double* XjD = Aj;
+        // A_ij -= X_i D^-1 X_j^T  through LDS tiles
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
-            const int q = g + GROUPS * jj;
-            XjD[r * LDP + q] = (two ? Aj[r * LDP + q] : Ai[r * LDP + q]) * iD[q];
+            const int q = g + STRIPS * jj;
+            s.Xi[r * LDP + q] = ai[jj];
+            s.Xj[r * LDP + q] = (two ? aj[jj] : ai[jj]) * id4[jj];
         }
         __syncthreads();
         double acc[4] = {0, 0, 0, 0};
 #pragma unroll 8
         for (int c = 0; c < NB; c++) {
-            const double a = Ai[r * LDP + c];
+            const double a = s.Xi[r * LDP + c];
 #pragma unroll
-            for (int jj = 0; jj < 4; jj++) acc[jj] += a * XjD[(g + GROUPS * jj) * LDP + c];
+            for (int jj = 0; jj < 4; jj++) acc[jj] += a * s.Xj[(g + STRIPS * jj) * LDP + c];
         }
 #pragma unroll
-        for (int jj = 0; jj < 4; jj++) S[(size_t)(bi * NB + r) * npad + bj * NB + g + GROUPS * jj] -= acc[jj];
+        for (int jj = 0; jj < 4; jj++) S[(size_t)(bi * NB + r) * npad + bj * NB + g + STRIPS * jj] -= acc[jj];
     }
 #ifdef K7_TIMING
     if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && k == 2) {
@@ -254,47 +269,58 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
 #endif
 }
 
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
-    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-// w = D^-1 z ; L^T x = w, blocked backwards.  One workgroup of 1024 threads.
-#define BW_PART (1024 / NB)   // row partitions of the GEMV part
+// w = D^-1 z ; L^T x = w, blocked backwards and right-looking.  One workgroup of 1024 threads:
+// thread (rr, c) = (tid / 32, tid % 32).  Per block k:  x_k = Lkk^-T (w_k - pending_k)  is a 32x32
+// mat-vec (row rr, 32-lane reduction), then  pending_j += L[k-block rows][j] . x_k  for every column j
+// of the blocks above, four row-slices per column.
 __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur) {
     extern __shared__ __attribute__((aligned(16))) double bw_lds[];
     const int npad = d.npad, nblk = npad / NB;
-    double* xs = bw_lds;                       // npad
-    double* part = xs + npad;                  // BW_PART x (NB + 1)
-    double* Lk = part + BW_PART * (NB + 1);    // NB x LDP
+    double* xs = bw_lds;         // npad: the solution
+    double* pend = xs + npad;    // npad: sum_{blocks below} L^T x
+    double* wv = pend + npad;    // npad: D^-1 z
     const int tid = threadIdx.x;
-    const int c = tid % NB, pr = tid / NB;     // column within block, row partition
-    for (int k = nblk - 1; k >= 0; k--) {
-        // stage the diagonal block of L (independent of the running solution)
-        for (int rr = pr; rr < NB; rr += BW_PART) Lk[rr * LDP + c] = d.L[(size_t)(k * NB + rr) * npad + k * NB + c];
-        // s[c] = sum_{r > block k} L[r][k*NB + c] * x[r]
-        double s = 0;
-        for (int rr = (k + 1) * NB + pr; rr < npad; rr += BW_PART) s += d.L[(size_t)rr * npad + k * NB + c] * xs[rr];
-        part[pr * (NB + 1) + c] = s;
-        __syncthreads();
-        if (tid < 64) {
-            // unit upper-triangular solve Lkk^T x = v in registers of one wave (lanes 0..NB-1)
-            double vt = 0;
-            if (tid < NB) {
-                double t = 0;
-                for (int p = 0; p < BW_PART; p++) t += part[p * (NB + 1) + tid];
-                vt = d.y[k * NB + tid] / d.Dg[k * NB + tid] - t;
-            }
-            for (int cc = NB - 1; cc > 0; cc--) {
-                const double xv = readlane_f64(vt, cc);
-                if (tid < cc) vt -= Lk[cc * LDP + tid] * xv;
-            }
-            if (tid < NB) xs[k * NB + tid] = vt;
-        }
-        __syncthreads();
+    const int c = tid % NB, rr = tid / NB;
+    for (int i = tid; i < npad; i += 1024) {
+        pend[i] = 0.0;
+        wv[i] = d.y[i] / d.Dg[i];
     }
+    double wnext = d.L[(size_t)((nblk - 1) * NB + rr) * npad + (nblk - 1) * NB + c];   // Lkk^-T element (rr, c)
+    for (int k = nblk - 1; k >= 0; k--) {
+        const double w = wnext;
+        if (k > 0) wnext = d.L[(size_t)((k - 1) * NB + rr) * npad + (k - 1) * NB + c];   // prefetch the next block
+        // first round of this block's update operands (independent of x_k): in flight during the mat-vec
+        const int ncol = k * NB;
+        const bool upd = tid < ncol * 4;
+        const int j0 = upd ? tid % ncol : 0, sl0 = upd ? tid / ncol : 0;
+        double lreg[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) lreg[q] = upd ? d.L[(size_t)(k * NB + sl0 * 8 + q) * npad + j0] : 0.0;
+        __syncthreads();   // (A) pending sums of the previous block are complete
+        double p = (c >= rr) ? w * (wv[k * NB + c] - pend[k * NB + c]) : 0.0;   // upper triangular
+        p += __shfl_xor(p, 16, 64);
+        p += __shfl_xor(p, 8, 64);
+        p += __shfl_xor(p, 4, 64);
+        p += __shfl_xor(p, 2, 64);
+        p += __shfl_xor(p, 1, 64);
+        if (c == 0) xs[k * NB + rr] = p;
+        __syncthreads();   // (B) x_k visible
+        // pending sums of the blocks above: column j, rows of block k in four slices of 8
+        if (upd) {
+            double a = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) a += lreg[q] * xs[k * NB + sl0 * 8 + q];
+            atomicAdd(&pend[j0], a);   // LDS; four addends per column
+        }
+        for (int idx = tid + 1024; idx < ncol * 4; idx += 1024) {
+            const int j = idx % ncol, sl = idx / ncol;
+            double a = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) a += d.L[(size_t)(k * NB + sl * 8 + q) * npad + j] * xs[k * NB + sl * 8 + q];
+            atomicAdd(&pend[j], a);
+        }
+    }
+    __syncthreads();
     for (int i = tid; i < npad; i += 1024) d.da[i] = xs[i];
     // trial poses  exp(da_j) * se3CfW  (src/Bundle.cc:496-501) and |da|^2, straight from LDS: saves the
     // separate pose-update launch
@@ -325,9 +351,7 @@ __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur) {
     }
 }
 
-#define STEP_LDS_BYTES ((3 * NB * LDP + 2 * NB) * sizeof(double))
 int ba_solve_init() {
-    HIP_TRY(hipFuncSetAttribute((const void*)ldlt_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)STEP_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute((const void*)ldlt_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return PTAM_OK;
 }
@@ -337,9 +361,9 @@ int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
     for (int k = 0; k < nblk; k++) {
         const int rem = nblk - k - 1;
         const int nwg = 1 + rem + rem * (rem + 1) / 2;
-        hipLaunchKernelGGL(ldlt_step_kernel, dim3(nwg), dim3(TPB), STEP_LDS_BYTES, ctx->stream, d, k);
+        hipLaunchKernelGGL(ldlt_step_kernel, dim3(nwg), dim3(TPB), 0, ctx->stream, d, k);
     }
-    const size_t bw_bytes = ((size_t)d.npad + BW_PART * (NB + 1) + NB * LDP) * sizeof(double);
+    const size_t bw_bytes = (size_t)3 * d.npad * sizeof(double);
     hipLaunchKernelGGL(ldlt_backward_kernel, dim3(1), dim3(1024), bw_bytes, ctx->stream, d, cur);
     HIP_TRY(hipGetLastError());
     return PTAM_OK;
