@@ -25,8 +25,10 @@
 
 #define NB SOLVE_NB
 #define LDP (NB + 1)    // LDS pitch in doubles (odd -> conflict-free column access)
-#define TPB 256         // 32 rows x 8 strips
-#define STRIPS (NB / 4)
+#define STRIPS 8                  // column residues: thread (r, g) owns columns g + STRIPS*jj
+#define CPT (NB / STRIPS)         // columns per thread
+#define TPB (NB * STRIPS)         // 256 threads (512 = two waves per SIMD measured slower: the barrier grows, the chain does not shrink)
+#define NITER (NB / 4)
 static_assert(NB == 32, "the strip decomposition below is written for 32x32 blocks");
 
 __device__ __forceinline__ double fast_rcp(double d) {
@@ -108,10 +110,11 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
     }
     const bool two = role == 2 && bi != bj;
     // ---- load my columns q = g + 8*jj (A_kk: only its lower triangle is ever read) ----
-    double akk[4], ai[4], aj[4] = {0, 0, 0, 0};
+    double akk[CPT], ai[CPT], aj[CPT];
 #pragma unroll
-    for (int jj = 0; jj < 4; jj++) {
+    for (int jj = 0; jj < CPT; jj++) {
         const int q = g + STRIPS * jj;
+        aj[jj] = 0.0;
         akk[jj] = S[(size_t)(k * NB + r) * npad + k * NB + q];
         if (role == 0)   // the identity rides along as the panel block: its X is Lkk^-T
             ai[jj] = (q == r) ? 1.0 : 0.0;
@@ -120,6 +123,16 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
         if (two) aj[jj] = S[(size_t)(bj * NB + r) * npad + k * NB + q];
     }
     double br = (g == STRIPS - 1) ? E[k * NB + r] : 0.0;   // thread (r, 7) carries b_r
+    // operands of the closing read-modify-writes, fetched now so that the step does not end on a load
+    const int mw = tid >> 6, mlane = tid & 63;
+    const int qi = mw >> 1, qj = mw & 1;   // role 2: wave w owns the 16x16 output quadrant (w>>1, w&1)
+    double sij[4] = {0, 0, 0, 0};
+    if (role == 2) {
+#pragma unroll
+        for (int v = 0; v < 4; v++)
+            sij[v] = S[(size_t)(bi * NB + 16 * qi + (mlane >> 4) + 4 * v) * npad + bj * NB + 16 * qj + (mlane & 15)];
+    }
+    const double e_old = (role == 1 && g == 0) ? E[bi * NB + r] : 0.0;
 #ifdef K7_TIMING
     const long long ts0 = (long long)__builtin_readcyclecounter();
 #endif
@@ -135,8 +148,8 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
     // Fully unrolled: the panel of iteration t is register t/2 of the threads with g/4 == t%2, so every
     // register index below is a compile-time constant.
 #pragma unroll
-    for (int t = 0; t < STRIPS; t++) {
-        const int c0 = 4 * t, pb = t & 1, jp = t >> 1, gh = t & 1;
+    for (int t = 0; t < NITER; t++) {
+        const int c0 = 4 * t, pb = t & 1, jp = c0 / STRIPS, gh = (c0 % STRIPS) / 4;
         const double(*Pk)[4] = s.P[pb][0];
         const double(*Pi)[4] = s.P[pb][1];
         const double(*Pj)[4] = s.P[pb][2];
@@ -159,7 +172,7 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
         }
         // rank-4 update of my columns right of the panel: the multipliers of column q are row q of the panel
 #pragma unroll
-        for (int jj = jp; jj < 4; jj++) {
+        for (int jj = jp; jj < CPT; jj++) {
             const int q = g + STRIPS * jj;
             if (jj > jp || q > c0 + 3) {
                 const double a[4] = {Pk[q][0], Pk[q][1], Pk[q][2], Pk[q][3]};
@@ -198,9 +211,9 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
                 s.Dv[c0] = f.d0, s.Dv[c0 + 1] = f.d1, s.Dv[c0 + 2] = f.d2, s.Dv[c0 + 3] = f.d3;
             }
         }
-        if (t + 1 < STRIPS) {
+        if (t + 1 < NITER) {
             // the owners of the next panel publish it
-            const int jn = (t + 1) >> 1, ghn = (t + 1) & 1;
+            const int jn = (c0 + 4) / STRIPS, ghn = ((c0 + 4) % STRIPS) / 4;
             if ((g >> 2) == ghn) {
                 s.P[pb ^ 1][0][r][g & 3] = akk[jn];
                 s.P[pb ^ 1][1][r][g & 3] = ai[jn];
@@ -214,13 +227,13 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
     const long long ts1 = (long long)__builtin_readcyclecounter();
 #endif
     // ---- closing phase ----
-    double id4[4];
+    double id4[CPT];
 #pragma unroll
-    for (int jj = 0; jj < 4; jj++) id4[jj] = s.iD[g + STRIPS * jj];
+    for (int jj = 0; jj < CPT; jj++) id4[jj] = s.iD[g + STRIPS * jj];
     if (role == 0) {
         // diagonal block of the factor buffer: Lkk^-T (upper triangular, unit diagonal) for the backward pass
 #pragma unroll
-        for (int jj = 0; jj < 4; jj++) d.L[(size_t)(k * NB + r) * npad + k * NB + g + STRIPS * jj] = ai[jj];
+        for (int jj = 0; jj < CPT; jj++) d.L[(size_t)(k * NB + r) * npad + k * NB + g + STRIPS * jj] = ai[jj];
         if (tid < NB) {
             d.Dg[k * NB + tid] = s.Dv[tid];
             d.y[k * NB + tid] = s.z[tid];
@@ -229,7 +242,7 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
         // L_ik = X_i D^-1 ;  b_i -= L_ik z_k : per-thread partial, then the 8 threads of a row (consecutive lanes)
         double sum = 0;
 #pragma unroll
-        for (int jj = 0; jj < 4; jj++) {
+        for (int jj = 0; jj < CPT; jj++) {
             const int q = g + STRIPS * jj;
             const double l = ai[jj] * id4[jj];
             d.L[(size_t)(bi * NB + r) * npad + k * NB + q] = l;
@@ -238,25 +251,33 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
         sum += __shfl_xor(sum, 1, 64);
         sum += __shfl_xor(sum, 2, 64);
         sum += __shfl_xor(sum, 4, 64);
-        if (g == 0) E[bi * NB + r] -= sum;
+        if (STRIPS == 16) sum += __shfl_xor(sum, 8, 64);
+        if (g == 0) E[bi * NB + r] = e_old - sum;
     } else {
         // A_ij -= X_i D^-1 X_j^T  through LDS tiles
 #pragma unroll
-        for (int jj = 0; jj < 4; jj++) {
+        for (int jj = 0; jj < CPT; jj++) {
             const int q = g + STRIPS * jj;
             s.Xi[r * LDP + q] = ai[jj];
             s.Xj[r * LDP + q] = (two ? aj[jj] : ai[jj]) * id4[jj];
         }
         __syncthreads();
-        double acc[4] = {0, 0, 0, 0};
-#pragma unroll 8
-        for (int c = 0; c < NB; c++) {
-            const double a = s.Xi[r * LDP + c];
+        // 32x32x32 product on the matrix cores: each wave chains
+        // eight v_mfma_f64_16x16x4_f64 (A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15];
+        // D: column lane&15, row (lane>>4) + 4*v).  The vector version of this product was latency bound
+        // (five LDS reads per four FMAs, one wave per SIMD) and took as long as three chain iterations.
+        typedef double v4f64 __attribute__((ext_vector_type(4)));
+        const int lane = mlane;
+        const double* pa = s.Xi + (16 * qi + (lane & 15)) * LDP + (lane >> 4);
+        const double* pbq = s.Xj + (16 * qj + (lane & 15)) * LDP + (lane >> 4);
+        v4f64 acc = {0, 0, 0, 0};
 #pragma unroll
-            for (int jj = 0; jj < 4; jj++) acc[jj] += a * s.Xj[(g + STRIPS * jj) * LDP + c];
+        for (int kk = 0; kk < NB / 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * kk], pbq[4 * kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int row = 16 * qi + (lane >> 4) + 4 * v, col = 16 * qj + (lane & 15);
+            S[(size_t)(bi * NB + row) * npad + bj * NB + col] = sij[v] - acc[v];
         }
-#pragma unroll
-        for (int jj = 0; jj < 4; jj++) S[(size_t)(bi * NB + r) * npad + bj * NB + g + STRIPS * jj] -= acc[jj];
     }
 #ifdef K7_TIMING
     if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && k == 2) {
