@@ -153,31 +153,39 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
         const double(*Pk)[4] = s.P[pb][0];
         const double(*Pi)[4] = s.P[pb][1];
         const double(*Pj)[4] = s.P[pb][2];
-        const Micro f = micro_factor(Pk[c0][0], Pk[c0 + 1][0], Pk[c0 + 1][1], Pk[c0 + 2][0], Pk[c0 + 2][1], Pk[c0 + 2][2],
-                                     Pk[c0 + 3][0], Pk[c0 + 3][1], Pk[c0 + 3][2], Pk[c0 + 3][3]);
-        // my rows of the panel through the micro factor
-        double xk[4] = {0, 0, 0, 0}, xi[4], xj[4] = {0, 0, 0, 0};
+        // every LDS operand of the iteration is fetched up front (one wave per SIMD: a read that is issued
+        // at its point of use costs its full latency)
         const bool below = r > c0 + 3;
-        if (below) {
-            const double a[4] = {Pk[r][0], Pk[r][1], Pk[r][2], Pk[r][3]};
-            micro_subst(f, a, xk);
+        double pv[4][4], rk[4], ri[4], rj[4], cq[CPT][4], b4[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int n = 0; n < 4; n++) pv[m][n] = Pk[c0 + m][n];
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            rk[n] = Pk[r][n];
+            ri[n] = Pi[r][n];
+            rj[n] = Pj[r][n];
+            b4[n] = s.Pb[pb][n];
         }
-        {
-            const double a[4] = {Pi[r][0], Pi[r][1], Pi[r][2], Pi[r][3]};
-            micro_subst(f, a, xi);
-        }
-        if (two) {
-            const double a[4] = {Pj[r][0], Pj[r][1], Pj[r][2], Pj[r][3]};
-            micro_subst(f, a, xj);
-        }
+#pragma unroll
+        for (int jj = jp; jj < CPT; jj++)
+#pragma unroll
+            for (int n = 0; n < 4; n++) cq[jj][n] = Pk[g + STRIPS * jj][n];
+        const Micro f = micro_factor(pv[0][0], pv[1][0], pv[1][1], pv[2][0], pv[2][1], pv[2][2], pv[3][0], pv[3][1], pv[3][2],
+                                     pv[3][3]);
+        // my rows of the panel through the micro factor
+        double xk[4] = {0, 0, 0, 0}, xi[4], xj[4];
+        if (below) micro_subst(f, rk, xk);
+        micro_subst(f, ri, xi);
+        micro_subst(f, rj, xj);   // (zeros unless the workgroup carries a second panel block)
         // rank-4 update of my columns right of the panel: the multipliers of column q are row q of the panel
 #pragma unroll
         for (int jj = jp; jj < CPT; jj++) {
             const int q = g + STRIPS * jj;
             if (jj > jp || q > c0 + 3) {
-                const double a[4] = {Pk[q][0], Pk[q][1], Pk[q][2], Pk[q][3]};
                 double x[4];
-                micro_subst(f, a, x);
+                micro_subst(f, cq[jj], x);
                 const double l0 = x[0] * f.i0, l1 = x[1] * f.i1, l2 = x[2] * f.i2, l3 = x[3] * f.i3;
                 akk[jj] -= xk[0] * l0 + xk[1] * l1 + xk[2] * l2 + xk[3] * l3;
                 ai[jj] -= xi[0] * l0 + xi[1] * l1 + xi[2] * l2 + xi[3] * l3;
@@ -201,7 +209,6 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
         }
         // right-hand side: z = Lmicro^-1 b (same recurrence), rows below take b_r -= L[r][c0..c0+3] . z
         {
-            const double b4[4] = {s.Pb[pb][0], s.Pb[pb][1], s.Pb[pb][2], s.Pb[pb][3]};
             double z[4];
             micro_subst(f, b4, z);
             if (g == STRIPS - 1 && below) br -= xk[0] * f.i0 * z[0] + xk[1] * f.i1 * z[1] + xk[2] * f.i2 * z[2] + xk[3] * f.i3 * z[3];
