@@ -19,6 +19,7 @@
 // The lambda-trial control flow, convergence test and abort polling stay on the host, one readback of
 // a 64-byte scalar block per trial.
 #include <algorithm>
+#include <atomic>
 #include <numeric>
 #include <utility>
 
@@ -1584,6 +1585,22 @@ __global__ void __launch_bounds__(256) purge_kernel(BaDev d) {
     }
 }
 
+// outlier-list length at the end of LM step `step` (read back once, after the last step)
+__global__ void record_step_kernel(BaDev d, int step) { d.step_out[step] = d.sc->n_outliers; }
+
+// The host's per-trial decision needs the scalars: one thread copies them into host-mapped memory and
+// then bumps a sequence word the host spins on (a D2H copy + stream synchronise costs ~30 us of idle
+// GPU per trial; this costs the kernel boundary).
+__global__ void publish_scalars_kernel(const BaScalars* sc, BaScalars* host_sc, volatile unsigned long long* host_seq,
+                                       unsigned long long seq) {
+    const unsigned long long* src = (const unsigned long long*)sc;
+    volatile unsigned long long* dst = (volatile unsigned long long*)host_sc;
+    static_assert(sizeof(BaScalars) % 8 == 0, "copied as 64-bit words");
+    for (unsigned i = 0; i < sizeof(BaScalars) / 8; i++) dst[i] = src[i];
+    __threadfence_system();
+    *host_seq = seq;
+}
+
 __global__ void set_scalars_kernel(BaDev d, double cur_err, int n_bad) {
     d.sc->cur_err = cur_err;
     d.sc->n_bad = n_bad;
@@ -1642,6 +1659,15 @@ struct ptam_ba {
     size_t smem_acc = 0;
     bool use_wave = false;
     int per_wave = 1, extra_waves = 0;
+    // host-mapped mailbox the device publishes BaScalars into (the LM loop's one host decision per trial)
+    struct Mailbox {
+        BaScalars sc;
+        volatile unsigned long long seq;
+    };
+    Mailbox* mbox = nullptr;       // host address
+    Mailbox* mbox_dev = nullptr;   // device address of the same memory
+    unsigned long long mbox_seq = 0;
+    int step_cap = 0;
     bool trial_is_current = false;   // the last trial was accepted: its new-error pass == pass 1 of the next step
     int k7_threads = BA_CHUNK;
     bool k7_loop = false;
@@ -1908,7 +1934,9 @@ static int ba_prepare_impl(ptam_ba* ba) {
     const size_t npad = std::max(d.npad, SOLVE_NB);
     const size_t o_SE = cv.take((npad * npad + npad) * 8), o_L = cv.take(npad * npad * 8), o_Dg = cv.take(npad * 8),
                  o_y = cv.take(npad * 8), o_da = cv.take(npad * 8);
-    const size_t o_out = cv.take(Mz * 4), o_sc = cv.take(sizeof(BaScalars)), o_dbg = cv.take(32768);
+    ba->step_cap = std::max(ba->opts.max_iterations, 0) + 8;
+    const size_t o_out = cv.take(Mz * 4), o_stepout = cv.take((size_t)ba->step_cap * 4), o_sc = cv.take(sizeof(BaScalars)),
+                 o_dbg = cv.take(32768);
     ba->block_bytes = cv.off;
     HIP_TRY(hipMalloc(&ba->block, ba->block_bytes));
     HIP_TRY(hipMemsetAsync(ba->block, 0, ba->block_bytes, ctx->stream));
@@ -1951,6 +1979,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.y = (double*)(base + o_y);
     d.da = (double*)(base + o_da);
     d.outliers = (int*)(base + o_out);
+    d.step_out = (int*)(base + o_stepout);
     d.sc = (BaScalars*)(base + o_sc);
     d.dbg = (long long*)(base + o_dbg);
 
@@ -2169,12 +2198,39 @@ static int ba_trial(ptam_ba* ba, double lambda) {
 }
 
 static int ba_read_scalars(ptam_ba* ba, BaScalars* out) {
-    void* pin;
-    int rc = ctx_pinned(ba->ctx, sizeof(BaScalars), &pin);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(pin, ba->d.sc, sizeof(BaScalars), hipMemcpyDeviceToHost, ba->ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ba->ctx->stream));
-    std::memcpy(out, pin, sizeof(BaScalars));
+    ptam_ctx* ctx = ba->ctx;
+    if (!ba->mbox) {
+        void* h = nullptr;
+        HIP_TRY(hipHostMalloc(&h, sizeof(ptam_ba::Mailbox), hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(h, 0, sizeof(ptam_ba::Mailbox));
+        void* dv = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&dv, h, 0));
+        ba->mbox = (ptam_ba::Mailbox*)h;
+        ba->mbox_dev = (ptam_ba::Mailbox*)dv;
+    }
+    const unsigned long long seq = ++ba->mbox_seq;
+    hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(1), 0, ctx->stream, (const BaScalars*)ba->d.sc, &ba->mbox_dev->sc,
+                       &ba->mbox_dev->seq, seq);
+    HIP_TRY(hipGetLastError());
+    if (ba->prof) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));   // the profiling events must have completed as well
+    } else {
+        // spin on the sequence word; every ~0.2 ms ask the runtime whether the stream died instead
+        unsigned spins = 0;
+        while (ba->mbox->seq != seq) {
+            if (++spins == 200000) {
+                spins = 0;
+                const hipError_t q = hipStreamQuery(ctx->stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return PTAM_E_HIP;
+                if (q == hipSuccess && ba->mbox->seq != seq) {   // finished without publishing: cannot happen, do not hang
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                    if (ba->mbox->seq != seq) return PTAM_E_HIP;
+                }
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    std::memcpy(out, (const void*)&ba->mbox->sc, sizeof(BaScalars));
     prof_collect(ba);
     return PTAM_OK;
 }
@@ -2211,6 +2267,7 @@ int ptam_ba_destroy(ptam_ba* ba) {
     hipSetDevice(ba->ctx->device);
     hipStreamSynchronize(ba->ctx->stream);
     ba_free_device(ba);
+    if (ba->mbox) hipHostFree(ba->mbox);
     if (ba->ev_ok)
         for (int k = 0; k < PTAM_K_COUNT; k++) {
             hipEventDestroy(ba->ev[k][0]);
@@ -2327,6 +2384,8 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     ba->accepted = 0;
     ba->trials.clear();
     std::vector<int> step_outlier_end;   // outlier-list length after every LM step
+    std::vector<int> late_ends;
+    int n_steps = 0;
     auto aborted = [&]() { return abort_flag && *abort_flag; };
     BaScalars sc;
     std::memset(&sc, 0, sizeof sc);
@@ -2386,10 +2445,23 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
             ba->trial_is_current = true;
         }
         if (d.M > 0) hipLaunchKernelGGL(purge_kernel, dim3((d.M + 255) / 256), dim3(256), 0, ctx->stream, d);   // :536-547
-        HIP_TRY(hipGetLastError());
-        rc = ba_read_scalars(ba, &sc);
-        if (rc) return rc;
-        step_outlier_end.push_back(sc.n_outliers);
+        // (the list length after this step is only needed for the final ordering: recorded on the device)
+        if (n_steps < ba->step_cap) {
+            hipLaunchKernelGGL(record_step_kernel, dim3(1), dim3(1), 0, ctx->stream, d, n_steps);
+            HIP_TRY(hipGetLastError());
+        } else {   // more steps than trials allowed (steps that ran no trial): read it the slow way
+            rc = ba_read_scalars(ba, &sc);
+            if (rc) return rc;
+            late_ends.push_back(sc.n_outliers);
+        }
+        n_steps++;
+    }
+    if (n_steps > 0) {
+        const int n_dev = std::min(n_steps, ba->step_cap);
+        step_outlier_end.resize(n_dev);
+        HIP_TRY(hipMemcpyAsync(step_outlier_end.data(), d.step_out, (size_t)n_dev * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        step_outlier_end.insert(step_outlier_end.end(), late_ends.begin(), late_ends.end());
     }
 #ifdef K7_TIMING
     {
