@@ -107,7 +107,6 @@ struct BaDev {
     double* da;             // [npad] camera update
     // outliers
     int* outliers;          // [M] original indices, in purge order
-    int* step_out;          // [max_iterations + 8] outlier-list length after every LM step
     BaScalars* sc;
     long long* dbg;         // 16 cycle stamps (only written by -DK7_TIMING builds)
 };

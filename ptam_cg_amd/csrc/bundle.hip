@@ -1585,20 +1585,15 @@ __global__ void __launch_bounds__(256) purge_kernel(BaDev d) {
     }
 }
 
-// outlier-list length at the end of LM step `step` (read back once, after the last step)
-__global__ void record_step_kernel(BaDev d, int step) { d.step_out[step] = d.sc->n_outliers; }
-
-// The host's per-trial decision needs the scalars: one thread copies them into host-mapped memory and
-// then bumps a sequence word the host spins on (a D2H copy + stream synchronise costs ~30 us of idle
-// GPU per trial; this costs the kernel boundary).
-__global__ void publish_scalars_kernel(const BaScalars* sc, BaScalars* host_sc, volatile unsigned long long* host_seq,
-                                       unsigned long long seq) {
-    const unsigned long long* src = (const unsigned long long*)sc;
-    volatile unsigned long long* dst = (volatile unsigned long long*)host_sc;
-    static_assert(sizeof(BaScalars) % 8 == 0, "copied as 64-bit words");
-    for (unsigned i = 0; i < sizeof(BaScalars) / 8; i++) dst[i] = src[i];
-    __threadfence_system();
-    *host_seq = seq;
+// The host's per-trial decision needs the scalars: they are written into host-mapped memory as
+// (word, sequence) pairs, one 16-byte store per lane, and the host spins until every pair carries the
+// expected sequence number — no system-scope fence on the device, no D2H copy + stream synchronise
+// (~30 us of idle GPU per trial) on the host.
+#define MBOX_WORDS (sizeof(BaScalars) / 8)
+static_assert(sizeof(BaScalars) % 8 == 0 && MBOX_WORDS <= 64, "published as 64-bit words by one wave");
+__global__ void __launch_bounds__(64) publish_scalars_kernel(const BaScalars* sc, ulonglong2* host_slots, unsigned long long seq) {
+    const unsigned i = threadIdx.x;
+    if (i < MBOX_WORDS) host_slots[i] = make_ulonglong2(((const unsigned long long*)sc)[i], seq);
 }
 
 __global__ void set_scalars_kernel(BaDev d, double cur_err, int n_bad) {
@@ -1661,13 +1656,13 @@ struct ptam_ba {
     int per_wave = 1, extra_waves = 0;
     // host-mapped mailbox the device publishes BaScalars into (the LM loop's one host decision per trial)
     struct Mailbox {
-        BaScalars sc;
-        volatile unsigned long long seq;
+        struct Slot {
+            volatile unsigned long long v, seq;
+        } slot[sizeof(BaScalars) / 8];
     };
     Mailbox* mbox = nullptr;       // host address
     Mailbox* mbox_dev = nullptr;   // device address of the same memory
     unsigned long long mbox_seq = 0;
-    int step_cap = 0;
     bool trial_is_current = false;   // the last trial was accepted: its new-error pass == pass 1 of the next step
     int k7_threads = BA_CHUNK;
     bool k7_loop = false;
@@ -1934,9 +1929,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     const size_t npad = std::max(d.npad, SOLVE_NB);
     const size_t o_SE = cv.take((npad * npad + npad) * 8), o_L = cv.take(npad * npad * 8), o_Dg = cv.take(npad * 8),
                  o_y = cv.take(npad * 8), o_da = cv.take(npad * 8);
-    ba->step_cap = std::max(ba->opts.max_iterations, 0) + 8;
-    const size_t o_out = cv.take(Mz * 4), o_stepout = cv.take((size_t)ba->step_cap * 4), o_sc = cv.take(sizeof(BaScalars)),
-                 o_dbg = cv.take(32768);
+    const size_t o_out = cv.take(Mz * 4), o_sc = cv.take(sizeof(BaScalars)), o_dbg = cv.take(32768);
     ba->block_bytes = cv.off;
     HIP_TRY(hipMalloc(&ba->block, ba->block_bytes));
     HIP_TRY(hipMemsetAsync(ba->block, 0, ba->block_bytes, ctx->stream));
@@ -1979,7 +1972,6 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.y = (double*)(base + o_y);
     d.da = (double*)(base + o_da);
     d.outliers = (int*)(base + o_out);
-    d.step_out = (int*)(base + o_stepout);
     d.sc = (BaScalars*)(base + o_sc);
     d.dbg = (long long*)(base + o_dbg);
 
@@ -2209,28 +2201,36 @@ static int ba_read_scalars(ptam_ba* ba, BaScalars* out) {
         ba->mbox_dev = (ptam_ba::Mailbox*)dv;
     }
     const unsigned long long seq = ++ba->mbox_seq;
-    hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(1), 0, ctx->stream, (const BaScalars*)ba->d.sc, &ba->mbox_dev->sc,
-                       &ba->mbox_dev->seq, seq);
+    hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(64), 0, ctx->stream, (const BaScalars*)ba->d.sc,
+                       (ulonglong2*)ba->mbox_dev, seq);
     HIP_TRY(hipGetLastError());
+    constexpr unsigned NW = sizeof(BaScalars) / 8;
+    auto arrived = [&]() {
+        for (unsigned i = 0; i < NW; i++)
+            if (ba->mbox->slot[i].seq != seq) return false;
+        return true;
+    };
     if (ba->prof) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));   // the profiling events must have completed as well
     } else {
-        // spin on the sequence word; every ~0.2 ms ask the runtime whether the stream died instead
+        // spin on the sequence words; every now and then ask the runtime whether the stream died instead
         unsigned spins = 0;
-        while (ba->mbox->seq != seq) {
-            if (++spins == 200000) {
+        while (!arrived()) {
+            if (++spins == 100000) {
                 spins = 0;
                 const hipError_t q = hipStreamQuery(ctx->stream);
                 if (q != hipSuccess && q != hipErrorNotReady) return PTAM_E_HIP;
-                if (q == hipSuccess && ba->mbox->seq != seq) {   // finished without publishing: cannot happen, do not hang
-                    std::atomic_thread_fence(std::memory_order_acquire);
-                    if (ba->mbox->seq != seq) return PTAM_E_HIP;
-                }
             }
         }
-        std::atomic_thread_fence(std::memory_order_acquire);
     }
-    std::memcpy(out, (const void*)&ba->mbox->sc, sizeof(BaScalars));
+    unsigned long long words[NW];
+    for (;;) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        for (unsigned i = 0; i < NW; i++) words[i] = ba->mbox->slot[i].v;
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (arrived()) break;   // (cannot change again before the next publish; re-checked for torn 16-byte reads)
+    }
+    std::memcpy(out, words, sizeof(BaScalars));
     prof_collect(ba);
     return PTAM_OK;
 }
@@ -2384,8 +2384,8 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     ba->accepted = 0;
     ba->trials.clear();
     std::vector<int> step_outlier_end;   // outlier-list length after every LM step
-    std::vector<int> late_ends;
     int n_steps = 0;
+    bool prev_end_pending = false;   // the previous step's outlier-list length has not been read yet
     auto aborted = [&]() { return abort_flag && *abort_flag; };
     BaScalars sc;
     std::memset(&sc, 0, sizeof sc);
@@ -2408,6 +2408,10 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
             rc = ba_read_scalars(ba, &sc);
             if (rc) return rc;
             if (!have_cur) {
+                // (every step runs at least one trial: this first read of step s also carries the outlier-list
+                //  length left by the purge that closed step s-1 — no separate read-back for it)
+                if (prev_end_pending) step_outlier_end.push_back(sc.n_outliers);
+                prev_end_pending = false;
                 have_cur = true;
                 cur_err = sc.cur_err;
                 new_err = cur_err + 9999;   // :337
@@ -2444,24 +2448,20 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
             ba->trials.back().accepted = 1;
             ba->trial_is_current = true;
         }
-        if (d.M > 0) hipLaunchKernelGGL(purge_kernel, dim3((d.M + 255) / 256), dim3(256), 0, ctx->stream, d);   // :536-547
-        // (the list length after this step is only needed for the final ordering: recorded on the device)
-        if (n_steps < ba->step_cap) {
-            hipLaunchKernelGGL(record_step_kernel, dim3(1), dim3(1), 0, ctx->stream, d, n_steps);
-            HIP_TRY(hipGetLastError());
-        } else {   // more steps than trials allowed (steps that ran no trial): read it the slow way
+        if (prev_end_pending) {   // a step that ran no trial (abort raised in between): read the length the slow way
             rc = ba_read_scalars(ba, &sc);
             if (rc) return rc;
-            late_ends.push_back(sc.n_outliers);
+            step_outlier_end.push_back(sc.n_outliers);
         }
+        if (d.M > 0) hipLaunchKernelGGL(purge_kernel, dim3((d.M + 255) / 256), dim3(256), 0, ctx->stream, d);   // :536-547
+        prev_end_pending = true;
+        HIP_TRY(hipGetLastError());
         n_steps++;
     }
-    if (n_steps > 0) {
-        const int n_dev = std::min(n_steps, ba->step_cap);
-        step_outlier_end.resize(n_dev);
-        HIP_TRY(hipMemcpyAsync(step_outlier_end.data(), d.step_out, (size_t)n_dev * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        step_outlier_end.insert(step_outlier_end.end(), late_ends.begin(), late_ends.end());
+    if (n_steps > 0) {   // the last step's purge
+        rc = ba_read_scalars(ba, &sc);
+        if (rc) return rc;
+        step_outlier_end.push_back(sc.n_outliers);
     }
 #ifdef K7_TIMING
     {
