@@ -1342,6 +1342,221 @@ __global__ void __launch_bounds__(256) schur_tile_kernel(BaDev d) {
     }
 }
 
+// ---- K8 on the matrix cores ------------------------------------------------------------------------
+// Same work decomposition and loaders as above; what changes is the product.  A round's 16 entries
+// are laid out as two dense 48 x 48 operands  Y[6*slot + param][3*entry + coord]  and  W[...][...]
+// (absent cameras: zero blocks), and the 48x48 partial tile is  Y W^T : nine 16x16 output tiles, the
+// k dimension (point coordinates) taken four at a time by v_mfma_f64_16x16x4_f64
+// (A[i = lane&15][k = lane>>4], B[k][j = lane&15]; D: column lane&15, row (lane>>4) + 4*v).  The four
+// waves split the k-steps.  fp64 MFMA has the vector FMA rate on this chip, so the gain is not flops:
+// one MFMA replaces sixteen FMA instructions and their LDS operand traffic (6 ds_read_b64 per 9 MFMAs
+// instead of 18 ds_read_b128 per 108 FMAs), and it runs in the matrix pipe while the VALU stages the
+// next round (the vector version spent 57 % of its issue slots outside the FMAs).
+#define SCH_K (3 * SCHUR_BATCH)   // k-values per round
+#define SCH_LD (SCH_K + 1)        // row pitch in doubles (odd: the 16 rows of a fragment fall into distinct banks)
+#define SCH_ROWS (SCHUR_TC * 6)
+static_assert(SCH_ROWS == 48 && SCH_K % 4 == 0, "three 16-row fragments per operand");
+struct SchurStageM {
+    double Y[SCH_ROWS][SCH_LD];
+    double W[SCH_ROWS][SCH_LD];
+    double eB[SCH_K];
+};
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned schur_put_m(SchurStageM& st, int le, bool roleA, bool diag, int slot, const double w[18],
+                                                const double v[9]) {
+    double* yb = &st.Y[slot * 6][3 * le];
+    double* wb = &st.W[slot * 6][3 * le];
+    if (roleA) {
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) yb[r * SCH_LD + c] = w[r * 3] * v[c] + w[r * 3 + 1] * v[3 + c] + w[r * 3 + 2] * v[6 + c];
+    }
+    if (!roleA || diag) {
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) wb[r * SCH_LD + c] = w[r * 3 + c];
+    }
+    return 1u << slot;
+}
+
+__device__ __forceinline__ void schur_store_m(const BaDev& d, SchurStageM& st, const SchurPre& p, bool diag, int a, int b, int le,
+                                              int ls, int lane) {
+    double v[9];
+#pragma unroll
+    for (int q = 0; q < 9; q++) v[q] = __shfl(p.vq, (lane & 48) | q, 64);
+    const bool roleA = diag || ls < 8;
+    unsigned bit = 0;
+    if (ls < 3) st.eB[3 * le + ls] = p.have ? p.eb : 0.0;
+    if (p.have) {
+        if (p.m >= 0 && p.f >= 0) bit = schur_put_m(st, le, roleA, diag, p.f - (roleA ? a : b) * SCHUR_TC, p.w, v);
+        // rare: more measurements in the tile range than loader lanes (fixed cameras interleaved)
+        const int na = p.ent.na_nb & 0xffff, nbm = (p.ent.na_nb >> 16) & 0xffff;
+        const int step = diag ? 16 : 8, n = roleA ? na : nbm;
+        for (int l = (roleA ? ls : ls - 8) + step; l < n; l += step) {
+            const int m = (roleA ? p.ent.ma : p.ent.mb) + l;
+            const int f = d.m_fidx[m];
+            if (f >= 0) {
+                double w[18];
+#pragma unroll
+                for (int q = 0; q < 9; q++) {
+                    const double2 t = d.W[(size_t)q * d.M + m];
+                    w[2 * q] = t.x;
+                    w[2 * q + 1] = t.y;
+                }
+                bit |= schur_put_m(st, le, roleA, diag, f - (roleA ? a : b) * SCHUR_TC, w, v);
+            }
+        }
+    }
+    // presence of each camera slot: OR over the entry's loader lanes (a-role and b-role halves separately)
+    unsigned ba = roleA ? bit : 0u, bb = roleA ? 0u : bit;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        ba |= __shfl_xor(ba, o, 64);
+        bb |= __shfl_xor(bb, o, 64);
+    }
+    // absent slots (and whole entries past the end of the list) must read as zero blocks
+    const int slot = ls & 7;
+    const bool zy = ls < 8 && !((ba >> slot) & 1u);
+    const bool zw = diag ? zy : (ls >= 8 && !((bb >> slot) & 1u));
+    if (zy) {
+        double* yb = &st.Y[slot * 6][3 * le];
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) yb[r * SCH_LD + c] = 0.0;
+    }
+    if (zw) {
+        double* wb = &st.W[slot * 6][3 * le];
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) wb[r * SCH_LD + c] = 0.0;
+    }
+}
+
+__global__ void __launch_bounds__(256) schur_tile_mfma_kernel(BaDev d) {
+    extern __shared__ __attribute__((aligned(16))) double schur_lds[];
+    SchurStageM* stage = reinterpret_cast<SchurStageM*>(schur_lds);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const SchurWG wg = d.s_wgs[blockIdx.x];
+    int a = (int)((sqrt(8.0 * wg.pair + 1.0) - 1.0) * 0.5);
+    while ((a + 1) * (a + 2) / 2 <= wg.pair) a++;
+    while (a * (a + 1) / 2 > wg.pair) a--;
+    const int b = wg.pair - a * (a + 1) / 2;
+    const bool diag = a == b;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int le = tid >> 4, ls = tid & 15;   // loader role: local entry, lane within the entry
+    v4f64 acc[3][3];
+    double accE[3] = {0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) acc[i][j] = (v4f64){0, 0, 0, 0};
+    const int n_ent = wg.e_end - wg.e_begin;
+    const int n_rounds = (n_ent + SCHUR_BATCH - 1) / SCHUR_BATCH;
+    const SchurEntry none = {0, 0, 0, 0};
+    auto entry_at = [&](int round, bool& have) {
+        const int e = wg.e_begin + round * SCHUR_BATCH + le;
+        have = round < n_rounds && e < wg.e_end;
+        return have ? d.s_entries[e] : none;
+    };
+    // prologue: round 0 into stage 0, entries of round 1 in registers
+    SchurPre pre;
+    bool have0, have_next;
+    const SchurEntry e0 = entry_at(0, have0);
+    schur_fetch(d, e0, have0, diag, ls, pre);
+    SchurEntry ent_next = entry_at(1, have_next);
+    schur_store_m(d, stage[0], pre, diag, a, b, le, ls, lane);
+    __syncthreads();
+    for (int i = 0; i < n_rounds; i++) {
+        const bool more = i + 1 < n_rounds;
+        if (more) schur_fetch(d, ent_next, have_next, diag, ls, pre);   // round i+1's data: loads in flight
+        bool have2;
+        const SchurEntry ent2 = entry_at(i + 2, have2);                  // round i+2's work-list entries
+        // ---- round i on the matrix cores ----
+        const SchurStageM& st = stage[i & 1];
+        const int nb_ent = min(SCHUR_BATCH, n_ent - i * SCHUR_BATCH);
+        const int n_ks = (3 * nb_ent + 3) >> 2;   // k-steps that hold data (the rest of the stage is zero)
+        for (int s4 = wid; s4 < n_ks; s4 += 4) {
+            const int kc = 4 * s4 + l4;
+            double af[3], bf[3];
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                af[t] = st.Y[16 * t + l15][kc];
+                bf[t] = st.W[16 * t + l15][kc];
+            }
+#pragma unroll
+            for (int ti = 0; ti < 3; ti++)
+#pragma unroll
+                for (int tj = 0; tj < 3; tj++) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ti], bf[tj], acc[ti][tj], 0, 0, 0);
+            if (diag) {
+                const double eb = st.eB[kc];
+#pragma unroll
+                for (int t = 0; t < 3; t++) accE[t] = fma(af[t], eb, accE[t]);
+            }
+        }
+        // ---- stage round i+1 ----
+        if (more) schur_store_m(d, stage[(i + 1) & 1], pre, diag, a, b, le, ls, lane);
+        ent_next = ent2;
+        have_next = have2;
+        __syncthreads();
+    }
+    // E partials: sum the four k-quarters of a row (lanes l15 + 16 q)
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        accE[t] += __shfl_xor(accE[t], 16, 64);
+        accE[t] += __shfl_xor(accE[t], 32, 64);
+    }
+    // stages dead: the buffer becomes the cross-wave reduction scratch
+    double(*red)[64][40] = reinterpret_cast<double(*)[64][40]>(schur_lds);
+    double flat[39];
+#pragma unroll
+    for (int ti = 0; ti < 3; ti++)
+#pragma unroll
+        for (int tj = 0; tj < 3; tj++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) flat[(ti * 3 + tj) * 4 + v] = acc[ti][tj][v];
+#pragma unroll
+    for (int t = 0; t < 3; t++) flat[36 + t] = accE[t];
+    // cross-wave reduction in fixed order: (w2 -> w0, w3 -> w1), then (w1 -> w0)
+    if (wid >= 2) {
+#pragma unroll
+        for (int i = 0; i < 39; i++) red[wid - 2][lane][i] = flat[i];
+    }
+    __syncthreads();
+    if (wid < 2) {
+#pragma unroll
+        for (int i = 0; i < 39; i++) flat[i] += red[wid][lane][i];
+    }
+    __syncthreads();
+    if (wid == 1) {
+#pragma unroll
+        for (int i = 0; i < 39; i++) red[0][lane][i] = flat[i];
+    }
+    __syncthreads();
+    if (wid == 0) {
+        double* out = d.s_part + (size_t)blockIdx.x * SCHUR_TILE_ELEMS;
+#pragma unroll
+        for (int ti = 0; ti < 3; ti++)
+#pragma unroll
+            for (int tj = 0; tj < 3; tj++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const int row = 16 * ti + l4 + 4 * v, col = 16 * tj + l15;
+                    const int j = row / 6, r = row - 6 * j, k = col / 6, c = col - 6 * k;
+                    const int i = (ti * 3 + tj) * 4 + v;
+                    out[(size_t)(j * SCHUR_TC + k) * 36 + r * 6 + c] = flat[i] + red[0][lane][i];
+                }
+        if (l4 == 0) {
+#pragma unroll
+            for (int t = 0; t < 3; t++) out[SCHUR_TC * SCHUR_TC * 36 + 16 * t + l15] = flat[36 + t] + red[0][lane][36 + t];
+        }
+    }
+}
+
 // grid (tile pair, slice): fixed-order sum of the partial tiles, add U* / epsA, write S (lower) and E.
 // Every rank adds its OWN partial U* and epsA ((1+lambda) diag(U) is linear, so the sharded partials
 // fold into the one all-reduce); the padding identity is added on rank 0 only.
@@ -2011,8 +2226,8 @@ static int ba_prepare_impl(ptam_ba* ba) {
         const int rc_s = ba_solve_init();
         if (rc_s) return rc_s;
     }
-    HIP_TRY(hipFuncSetAttribute((const void*)schur_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(2 * sizeof(SchurStage))));
+    HIP_TRY(hipFuncSetAttribute((const void*)schur_tile_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(2 * sizeof(SchurStageM))));
     HIP_TRY(hipMalloc((void**)&ba->d_xchg, 4096));
     ba->cur = 0;
     ba->prepared = true;
@@ -2159,7 +2374,7 @@ static int ba_trial(ptam_ba* ba, double lambda) {
     if (d.F > 0) {
         prof_begin(ba, PTAM_K_SCHUR);
         if (d.n_schur_wg > 0)
-            hipLaunchKernelGGL(schur_tile_kernel, dim3(d.n_schur_wg), dim3(256), 2 * sizeof(SchurStage), ctx->stream, d);
+            hipLaunchKernelGGL(schur_tile_mfma_kernel, dim3(d.n_schur_wg), dim3(256), 2 * sizeof(SchurStageM), ctx->stream, d);
         hipLaunchKernelGGL(schur_reduce_kernel, dim3(d.n_pairs, SRED_SLICES), dim3(256), 0, ctx->stream, d, lambda,
                            (ba->world > 1 && ba->rank != 0) ? 0 : 1);
         prof_end(ba, PTAM_K_SCHUR);
