@@ -1344,7 +1344,7 @@ __global__ void __launch_bounds__(256) schur_tile_kernel(BaDev d) {
 
 // ---- K8 on the matrix cores ------------------------------------------------------------------------
 // Same work decomposition and loaders as above; what changes is the product.  A round's 16 entries
-// are laid out as two dense 48 x 48 operands  Y[6*slot + param][3*entry + coord]  and  W[...][...]
+// are laid out as two dense 48 x 48 operands  Y[3*entry + coord][6*slot + param]  and  W[...][...]
 // (absent cameras: zero blocks), and the 48x48 partial tile is  Y W^T : nine 16x16 output tiles, the
 // k dimension (point coordinates) taken four at a time by v_mfma_f64_16x16x4_f64
 // (A[i = lane&15][k = lane>>4], B[k][j = lane&15]; D: column lane&15, row (lane>>4) + 4*v).  The four
@@ -1353,40 +1353,65 @@ __global__ void __launch_bounds__(256) schur_tile_kernel(BaDev d) {
 // instead of 18 ds_read_b128 per 108 FMAs), and it runs in the matrix pipe while the VALU stages the
 // next round (the vector version spent 57 % of its issue slots outside the FMAs).
 #define SCH_K (3 * SCHUR_BATCH)   // k-values per round
-#define SCH_LD (SCH_K + 1)        // row pitch in doubles (odd: the 16 rows of a fragment fall into distinct banks)
 #define SCH_ROWS (SCHUR_TC * 6)
+#define SCH_LD (SCH_ROWS + 2)     // pitch of one k-row in doubles (even: a camera's six values are three 16-byte stores)
 static_assert(SCH_ROWS == 48 && SCH_K % 4 == 0, "three 16-row fragments per operand");
-struct SchurStageM {
-    double Y[SCH_ROWS][SCH_LD];
-    double W[SCH_ROWS][SCH_LD];
+struct SchurStageM {              // k-major: [3*entry + coord][6*slot + param] — a fragment reads 16 consecutive doubles
+    double Y[SCH_K][SCH_LD];
+    double W[SCH_K][SCH_LD];
     double eB[SCH_K];
 };
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned schur_put_m(SchurStageM& st, int le, bool roleA, bool diag, int slot, const double w[18],
                                                 const double v[9]) {
-    double* yb = &st.Y[slot * 6][3 * le];
-    double* wb = &st.W[slot * 6][3 * le];
     if (roleA) {
+        double y[18];
 #pragma unroll
         for (int r = 0; r < 6; r++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) yb[r * SCH_LD + c] = w[r * 3] * v[c] + w[r * 3 + 1] * v[3 + c] + w[r * 3 + 2] * v[6 + c];
+            for (int c = 0; c < 3; c++) y[r * 3 + c] = w[r * 3] * v[c] + w[r * 3 + 1] * v[3 + c] + w[r * 3 + 2] * v[6 + c];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            double2* dst = (double2*)&st.Y[3 * le + c][6 * slot];
+#pragma unroll
+            for (int h = 0; h < 3; h++) dst[h] = make_double2(y[(2 * h) * 3 + c], y[(2 * h + 1) * 3 + c]);
+        }
     }
     if (!roleA || diag) {
 #pragma unroll
-        for (int r = 0; r < 6; r++)
+        for (int c = 0; c < 3; c++) {
+            double2* dst = (double2*)&st.W[3 * le + c][6 * slot];
 #pragma unroll
-            for (int c = 0; c < 3; c++) wb[r * SCH_LD + c] = w[r * 3 + c];
+            for (int h = 0; h < 3; h++) dst[h] = make_double2(w[(2 * h) * 3 + c], w[(2 * h + 1) * 3 + c]);
+        }
     }
     return 1u << slot;
 }
 
+// value of lane q of my 16-lane DPP row (row_newbcast), both halves of a double — VALU only, no LDS round trip
+template <int Q>
+__device__ __forceinline__ double row_bcast_f64(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x150 + Q, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + Q, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// OR over the 16 lanes of my DPP row (row rotations)
+__device__ __forceinline__ unsigned row_or_u32(unsigned x) {
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, true);   // row_ror:8
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x124, 0xf, 0xf, true);   // row_ror:4
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x122, 0xf, 0xf, true);   // row_ror:2
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x121, 0xf, 0xf, true);   // row_ror:1
+    return x;
+}
+
 __device__ __forceinline__ void schur_store_m(const BaDev& d, SchurStageM& st, const SchurPre& p, bool diag, int a, int b, int le,
                                               int ls, int lane) {
-    double v[9];
-#pragma unroll
-    for (int q = 0; q < 9; q++) v[q] = __shfl(p.vq, (lane & 48) | q, 64);
+    // V*^-1 of the entry: element q lives in lane q of the entry's 16 loader lanes (= one DPP row)
+    const double v[9] = {row_bcast_f64<0>(p.vq), row_bcast_f64<1>(p.vq), row_bcast_f64<2>(p.vq),
+                         row_bcast_f64<3>(p.vq), row_bcast_f64<4>(p.vq), row_bcast_f64<5>(p.vq),
+                         row_bcast_f64<6>(p.vq), row_bcast_f64<7>(p.vq), row_bcast_f64<8>(p.vq)};
     const bool roleA = diag || ls < 8;
     unsigned bit = 0;
     if (ls < 3) st.eB[3 * le + ls] = p.have ? p.eb : 0.0;
@@ -1411,29 +1436,23 @@ __device__ __forceinline__ void schur_store_m(const BaDev& d, SchurStageM& st, c
         }
     }
     // presence of each camera slot: OR over the entry's loader lanes (a-role and b-role halves separately)
-    unsigned ba = roleA ? bit : 0u, bb = roleA ? 0u : bit;
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-        ba |= __shfl_xor(ba, o, 64);
-        bb |= __shfl_xor(bb, o, 64);
-    }
+    const unsigned ba = row_or_u32(roleA ? bit : 0u), bb = row_or_u32(roleA ? 0u : bit);
     // absent slots (and whole entries past the end of the list) must read as zero blocks
     const int slot = ls & 7;
     const bool zy = ls < 8 && !((ba >> slot) & 1u);
     const bool zw = diag ? zy : (ls >= 8 && !((bb >> slot) & 1u));
+    const double2 z2 = make_double2(0.0, 0.0);
     if (zy) {
-        double* yb = &st.Y[slot * 6][3 * le];
 #pragma unroll
-        for (int r = 0; r < 6; r++)
+        for (int c = 0; c < 3; c++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) yb[r * SCH_LD + c] = 0.0;
+            for (int h = 0; h < 3; h++) ((double2*)&st.Y[3 * le + c][6 * slot])[h] = z2;
     }
     if (zw) {
-        double* wb = &st.W[slot * 6][3 * le];
 #pragma unroll
-        for (int r = 0; r < 6; r++)
+        for (int c = 0; c < 3; c++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) wb[r * SCH_LD + c] = 0.0;
+            for (int h = 0; h < 3; h++) ((double2*)&st.W[3 * le + c][6 * slot])[h] = z2;
     }
 }
 
@@ -1463,6 +1482,10 @@ __global__ void __launch_bounds__(256) schur_tile_mfma_kernel(BaDev d) {
         have = round < n_rounds && e < wg.e_end;
         return have ? d.s_entries[e] : none;
     };
+#ifdef K7_TIMING
+    long long t_comp = 0, t_store = 0, t_fetch = 0, t_bar = 0;
+    const long long t_start = (long long)__builtin_readcyclecounter();
+#endif
     // prologue: round 0 into stage 0, entries of round 1 in registers
     SchurPre pre;
     bool have0, have_next;
@@ -1473,20 +1496,23 @@ __global__ void __launch_bounds__(256) schur_tile_mfma_kernel(BaDev d) {
     __syncthreads();
     for (int i = 0; i < n_rounds; i++) {
         const bool more = i + 1 < n_rounds;
-        if (more) schur_fetch(d, ent_next, have_next, diag, ls, pre);   // round i+1's data: loads in flight
+        SCH_T(t_fetch, if (more) schur_fetch(d, ent_next, have_next, diag, ls, pre));   // round i+1's data: loads in flight
         bool have2;
         const SchurEntry ent2 = entry_at(i + 2, have2);                  // round i+2's work-list entries
         // ---- round i on the matrix cores ----
         const SchurStageM& st = stage[i & 1];
         const int nb_ent = min(SCHUR_BATCH, n_ent - i * SCHUR_BATCH);
         const int n_ks = (3 * nb_ent + 3) >> 2;   // k-steps that hold data (the rest of the stage is zero)
+#ifdef K7_TIMING
+        const long long tc0 = (long long)__builtin_readcyclecounter();
+#endif
         for (int s4 = wid; s4 < n_ks; s4 += 4) {
             const int kc = 4 * s4 + l4;
             double af[3], bf[3];
 #pragma unroll
             for (int t = 0; t < 3; t++) {
-                af[t] = st.Y[16 * t + l15][kc];
-                bf[t] = st.W[16 * t + l15][kc];
+                af[t] = st.Y[kc][16 * t + l15];
+                bf[t] = st.W[kc][16 * t + l15];
             }
 #pragma unroll
             for (int ti = 0; ti < 3; ti++)
@@ -1498,12 +1524,25 @@ __global__ void __launch_bounds__(256) schur_tile_mfma_kernel(BaDev d) {
                 for (int t = 0; t < 3; t++) accE[t] = fma(af[t], eb, accE[t]);
             }
         }
+#ifdef K7_TIMING
+        t_comp += (long long)__builtin_readcyclecounter() - tc0;
+#endif
         // ---- stage round i+1 ----
-        if (more) schur_store_m(d, stage[(i + 1) & 1], pre, diag, a, b, le, ls, lane);
+        SCH_T(t_store, if (more) schur_store_m(d, stage[(i + 1) & 1], pre, diag, a, b, le, ls, lane));
         ent_next = ent2;
         have_next = have2;
-        __syncthreads();
+        SCH_T(t_bar, __syncthreads());
     }
+#ifdef K7_TIMING
+    if (blockIdx.x == 100 && tid == 0) {
+        d.dbg[10] = (long long)__builtin_readcyclecounter() - t_start;
+        d.dbg[11] = t_fetch;
+        d.dbg[12] = t_comp;
+        d.dbg[13] = t_store;
+        d.dbg[14] = t_bar;
+        d.dbg[15] = n_rounds;
+    }
+#endif
     // E partials: sum the four k-quarters of a row (lanes l15 + 16 q)
 #pragma unroll
     for (int t = 0; t < 3; t++) {
