@@ -8,7 +8,7 @@
 //                             V += B^T B, epsB, W = A^T B.  Roofline kernel (HBM-bound, ~185 B/meas).
 //       reduce_partials_kernel  fixed-order sum of the per-workgroup camera partials
 //   K8a vinv_kernel           V*^-1 (:341-359)
-//   K8  schur_tile_kernel     S = U* - sum_i (W V*^-1) W^T, E = epsA - sum_i W V*^-1 epsB (:374-446),
+//   K8  schur_tile_mfma_kernel S = U* - sum_i (W V*^-1) W^T, E = epsA - sum_i W V*^-1 epsB (:374-446),
 //                             output-stationary over 8x8-camera tiles; schur_reduce_kernel sums the
 //                             tile partials in fixed order (deterministic) and writes S lower / E
 //   K9  solve.hip             blocked LDL^T + substitutions (:457-458)
@@ -1104,19 +1104,11 @@ __global__ void __launch_bounds__(256) vinv_kernel(BaDev d, double lambda) {
 #define SCHUR_TILE_ELEMS (SCHUR_TC * SCHUR_TC * 36 + SCHUR_TC * 6)   // 2304 + 48
 #define SCHUR_BATCH 16                                                 // entries staged per LDS round
 
-// Workgroup = (tile pair (a,b), a slice of the points touching both tiles), SOFTWARE PIPELINED:
-// while the four waves compute round i out of one LDS stage (lane (j,k) accumulates the 6x6 block
-// Y_j W_k^T of every entry in 36 registers, E_j on the diagonal pair), the global loads of round i+1
+// Workgroup = (tile pair (a,b) of 8 x 8 cameras, a slice of the points touching both tiles), SOFTWARE
+// PIPELINED: while the four waves multiply round i out of one LDS stage, the global loads of round i+1
 // (16 entries x 16 loader lanes: the W blocks of the point's measurements in tile a / tile b, V*^-1,
-// epsB) are in flight, and the work-list entries of round i+2 are being fetched.  After the compute the
-// loaders form Y = W V*^-1 and drop Y / W into the OTHER LDS stage; one barrier per round.  Absent
-// cameras are skipped through per-entry presence masks built with DPP ORs (no zeroing, no atomics).
-struct SchurStage {
-    double PY[SCHUR_BATCH][SCHUR_TC][18];
-    double PW[SCHUR_BATCH][SCHUR_TC][18];
-    double eB[SCHUR_BATCH][4];
-    unsigned pmA[SCHUR_BATCH], pmB[SCHUR_BATCH];
-};
+// epsB) are in flight, and the work-list entries of round i+2 are being fetched.  After the product the
+// loaders form Y = W V*^-1 and drop Y / W into the OTHER LDS stage; one barrier per round.
 struct SchurPre {      // one loader lane's prefetched share of a round
     SchurEntry ent;
     int have;          // this lane's entry exists
@@ -1153,205 +1145,17 @@ __device__ __forceinline__ void schur_fetch(const BaDev& d, const SchurEntry& en
     if (ls < 3) p.eb = d.epsB[(size_t)ent.pt * 3 + ls];
 }
 
-// write one measurement's blocks into the stage; returns its presence bit
-__device__ __forceinline__ unsigned schur_put(SchurStage& st, int le, bool roleA, bool diag, int slot, const double w[18],
-                                              const double v[9]) {
-    if (roleA) {
-#pragma unroll
-        for (int r = 0; r < 6; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-                st.PY[le][slot][r * 3 + c] = w[r * 3] * v[c] + w[r * 3 + 1] * v[3 + c] + w[r * 3 + 2] * v[6 + c];
-        if (diag) {
-#pragma unroll
-            for (int q = 0; q < 18; q++) st.PW[le][slot][q] = w[q];
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < 18; q++) st.PW[le][slot][q] = w[q];
-    }
-    return 1u << slot;
-}
-
-__device__ __forceinline__ void schur_store(const BaDev& d, SchurStage& st, const SchurPre& p, bool diag, int a, int b,
-                                            int le, int ls, int lane) {
-    // V*^-1 of the entry: element q lives in lane q of the entry's 16-lane group
-    double v[9];
-#pragma unroll
-    for (int q = 0; q < 9; q++) v[q] = __shfl(p.vq, (lane & 48) | q, 64);
-    const bool roleA = diag || ls < 8;
-    unsigned bit = 0;
-    if (p.have) {
-        if (ls < 3) st.eB[le][ls] = p.eb;
-        if (p.m >= 0 && p.f >= 0) bit = schur_put(st, le, roleA, diag, p.f - (roleA ? a : b) * SCHUR_TC, p.w, v);
-        // rare: more measurements in the tile range than loader lanes (fixed cameras interleaved)
-        const int na = p.ent.na_nb & 0xffff, nbm = (p.ent.na_nb >> 16) & 0xffff;
-        const int step = diag ? 16 : 8, n = roleA ? na : nbm;
-        for (int l = (roleA ? ls : ls - 8) + step; l < n; l += step) {
-            const int m = (roleA ? p.ent.ma : p.ent.mb) + l;
-            const int f = d.m_fidx[m];
-            if (f >= 0) {
-                double w[18];
-#pragma unroll
-                for (int q = 0; q < 9; q++) {
-                    const double2 t = d.W[(size_t)q * d.M + m];
-                    w[2 * q] = t.x;
-                    w[2 * q + 1] = t.y;
-                }
-                bit |= schur_put(st, le, roleA, diag, f - (roleA ? a : b) * SCHUR_TC, w, v);
-            }
-        }
-    }
-    // presence masks: OR over the entry's loader lanes (a-role and b-role halves separately)
-    unsigned ba = roleA ? bit : 0u, bb = roleA ? 0u : bit;
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-        ba |= __shfl_xor(ba, o, 64);
-        bb |= __shfl_xor(bb, o, 64);
-    }
-    if (ls == 0) {
-        st.pmA[le] = ba;
-        st.pmB[le] = diag ? ba : bb;
-    }
-}
-
-__global__ void __launch_bounds__(256) schur_tile_kernel(BaDev d) {
-    extern __shared__ __attribute__((aligned(16))) double schur_lds[];
-    SchurStage* stage = reinterpret_cast<SchurStage*>(schur_lds);
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const SchurWG wg = d.s_wgs[blockIdx.x];
-    int a = (int)((sqrt(8.0 * wg.pair + 1.0) - 1.0) * 0.5);
-    while ((a + 1) * (a + 2) / 2 <= wg.pair) a++;
-    while (a * (a + 1) / 2 > wg.pair) a--;
-    const int b = wg.pair - a * (a + 1) / 2;
-    const bool diag = a == b;
-    const int j = lane >> 3, k = lane & 7;
-    const int le = tid >> 4, ls = tid & 15;   // loader role: local entry, lane within the entry
-    double acc[36], accE[6];
-#pragma unroll
-    for (int i = 0; i < 36; i++) acc[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) accE[i] = 0;
-    const int n_ent = wg.e_end - wg.e_begin;
-    const int n_rounds = (n_ent + SCHUR_BATCH - 1) / SCHUR_BATCH;
-    const SchurEntry none = {0, 0, 0, 0};
-    auto entry_at = [&](int round, bool& have) {
-        const int e = wg.e_begin + round * SCHUR_BATCH + le;
-        have = round < n_rounds && e < wg.e_end;
-        return have ? d.s_entries[e] : none;
-    };
-#ifdef K7_TIMING
-    long long t_comp = 0, t_store = 0, t_fetch = 0, t_bar = 0;
-    const long long t_start = (long long)__builtin_readcyclecounter();
-#define SCH_T(acc, stmt) { const long long t0_ = (long long)__builtin_readcyclecounter(); stmt; acc += (long long)__builtin_readcyclecounter() - t0_; }
-#else
-#define SCH_T(acc, stmt) { stmt; }
-#endif
-    // prologue: round 0 into stage 0, entries of round 1 in registers
-    SchurPre pre;
-    bool have0, have_next;
-    const SchurEntry e0 = entry_at(0, have0);
-    schur_fetch(d, e0, have0, diag, ls, pre);
-    SchurEntry ent_next = entry_at(1, have_next);
-    schur_store(d, stage[0], pre, diag, a, b, le, ls, lane);
-    __syncthreads();
-    for (int i = 0; i < n_rounds; i++) {
-        const bool more = i + 1 < n_rounds;
-        SCH_T(t_fetch, if (more) schur_fetch(d, ent_next, have_next, diag, ls, pre));   // round i+1's data: loads in flight
-        bool have2;
-        const SchurEntry ent2 = entry_at(i + 2, have2);                  // round i+2's work-list entries
-        // ---- compute round i ----
-        const SchurStage& st = stage[i & 1];
-        const int nb_ent = min(SCHUR_BATCH, n_ent - i * SCHUR_BATCH);
-#ifdef K7_TIMING
-        const long long tc0 = (long long)__builtin_readcyclecounter();
-#endif
-        for (int e = wid; e < nb_ent; e += 4) {
-            const unsigned pa = st.pmA[e], pb = st.pmB[e];
-            if (((pa >> j) & 1u) && ((pb >> k) & 1u)) {
-                double Yj[18], Wk[18];
-#pragma unroll
-                for (int q = 0; q < 18; q++) {
-                    Yj[q] = st.PY[e][j][q];
-                    Wk[q] = st.PW[e][k][q];
-                }
-#pragma unroll
-                for (int r = 0; r < 6; r++)
-#pragma unroll
-                    for (int c = 0; c < 6; c++)   // three chained FMAs straight into the accumulator
-                        acc[r * 6 + c] = fma(Yj[r * 3 + 2], Wk[c * 3 + 2],
-                                             fma(Yj[r * 3 + 1], Wk[c * 3 + 1], fma(Yj[r * 3], Wk[c * 3], acc[r * 6 + c])));
-                if (diag && k == j) {
-                    const double b0 = st.eB[e][0], b1 = st.eB[e][1], b2 = st.eB[e][2];
-#pragma unroll
-                    for (int r = 0; r < 6; r++) accE[r] = fma(Yj[r * 3 + 2], b2, fma(Yj[r * 3 + 1], b1, fma(Yj[r * 3], b0, accE[r])));
-                }
-            }
-        }
-#ifdef K7_TIMING
-        t_comp += (long long)__builtin_readcyclecounter() - tc0;
-#endif
-        // ---- stage round i+1 ----
-        SCH_T(t_store, if (more) schur_store(d, stage[(i + 1) & 1], pre, diag, a, b, le, ls, lane));
-        ent_next = ent2;
-        have_next = have2;
-        SCH_T(t_bar, __syncthreads());
-    }
-#ifdef K7_TIMING
-    if (blockIdx.x == 100 && tid == 0) {
-        d.dbg[10] = (long long)__builtin_readcyclecounter() - t_start;
-        d.dbg[11] = t_fetch;
-        d.dbg[12] = t_comp;
-        d.dbg[13] = t_store;
-        d.dbg[14] = t_bar;
-        d.dbg[15] = n_rounds;
-    }
-#endif
-    // stages dead: the buffer becomes the cross-wave reduction scratch
-    double(*red)[64][42] = reinterpret_cast<double(*)[64][42]>(schur_lds);
-    // cross-wave reduction in fixed order: (w2 -> w0, w3 -> w1), then (w1 -> w0)
-    if (wid >= 2) {
-#pragma unroll
-        for (int i = 0; i < 36; i++) red[wid - 2][lane][i] = acc[i];
-#pragma unroll
-        for (int i = 0; i < 6; i++) red[wid - 2][lane][36 + i] = accE[i];
-    }
-    __syncthreads();
-    if (wid < 2) {
-#pragma unroll
-        for (int i = 0; i < 36; i++) acc[i] += red[wid][lane][i];
-#pragma unroll
-        for (int i = 0; i < 6; i++) accE[i] += red[wid][lane][36 + i];
-    }
-    __syncthreads();
-    if (wid == 1) {
-#pragma unroll
-        for (int i = 0; i < 36; i++) red[0][lane][i] = acc[i];
-#pragma unroll
-        for (int i = 0; i < 6; i++) red[0][lane][36 + i] = accE[i];
-    }
-    __syncthreads();
-    if (wid == 0) {
-        double* out = d.s_part + (size_t)blockIdx.x * SCHUR_TILE_ELEMS;
-#pragma unroll
-        for (int i = 0; i < 36; i++) out[(size_t)lane * 36 + i] = acc[i] + red[0][lane][i];
-        if (k == j) {
-#pragma unroll
-            for (int i = 0; i < 6; i++) out[SCHUR_TC * SCHUR_TC * 36 + j * 6 + i] = accE[i] + red[0][lane][36 + i];
-        }
-    }
-}
-
-// ---- K8 on the matrix cores ------------------------------------------------------------------------
-// Same work decomposition and loaders as above; what changes is the product.  A round's 16 entries
+// ---- the product, on the matrix cores ---------------------------------------------------------------
+// A round's 16 entries
 // are laid out as two dense 48 x 48 operands  Y[3*entry + coord][6*slot + param]  and  W[...][...]
 // (absent cameras: zero blocks), and the 48x48 partial tile is  Y W^T : nine 16x16 output tiles, the
 // k dimension (point coordinates) taken four at a time by v_mfma_f64_16x16x4_f64
 // (A[i = lane&15][k = lane>>4], B[k][j = lane&15]; D: column lane&15, row (lane>>4) + 4*v).  The four
-// waves split the k-steps.  fp64 MFMA has the vector FMA rate on this chip, so the gain is not flops:
-// one MFMA replaces sixteen FMA instructions and their LDS operand traffic (6 ds_read_b64 per 9 MFMAs
-// instead of 18 ds_read_b128 per 108 FMAs), and it runs in the matrix pipe while the VALU stages the
-// next round (the vector version spent 57 % of its issue slots outside the FMAs).
+// waves split the k-steps.  fp64 MFMA shares the vector FMA pipe on this chip (tools/pipes: the two do
+// not overlap, and the MFMA sustains ~10 FMA/clk/SIMD against ~13 for v_fma_f64), so the gain is not
+// flops: one MFMA replaces sixteen FMA instructions and their LDS operand traffic (6 ds_read_b64 per 9
+// MFMAs instead of 18 ds_read_b128 per 108 FMAs).  A lane-per-block vector version of this product
+// (36 accumulators per lane, operands re-read from LDS per entry) measured 99 us against 72 us.
 #define SCH_K (3 * SCHUR_BATCH)   // k-values per round
 #define SCH_ROWS (SCHUR_TC * 6)
 #define SCH_LD (SCH_ROWS + 2)     // pitch of one k-row in doubles (even: a camera's six values are three 16-byte stores)
@@ -1517,7 +1321,9 @@ __global__ void __launch_bounds__(256) schur_tile_mfma_kernel(BaDev d) {
 #pragma unroll
             for (int ti = 0; ti < 3; ti++)
 #pragma unroll
-                for (int tj = 0; tj < 3; tj++) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ti], bf[tj], acc[ti][tj], 0, 0, 0);
+                for (int tj = 0; tj < 3; tj++)
+                    if (ti >= tj || !diag)   // a diagonal pair only needs its lower triangle (those tiles stay zero)
+                        acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ti], bf[tj], acc[ti][tj], 0, 0, 0);
             if (diag) {
                 const double eb = st.eB[kc];
 #pragma unroll
