@@ -1260,6 +1260,11 @@ __device__ __forceinline__ void schur_store_m(const BaDev& d, SchurStageM& st, c
     }
 }
 
+#ifdef K7_TIMING
+#define SCH_T(acc, stmt) { const long long t0_ = (long long)__builtin_readcyclecounter(); stmt; acc += (long long)__builtin_readcyclecounter() - t0_; }
+#else
+#define SCH_T(acc, stmt) { stmt; }
+#endif
 __global__ void __launch_bounds__(256) schur_tile_mfma_kernel(BaDev d) {
     extern __shared__ __attribute__((aligned(16))) double schur_lds[];
     SchurStageM* stage = reinterpret_cast<SchurStageM*>(schur_lds);
