@@ -99,6 +99,20 @@ def tracking_bench(hip, host, synth, frames=200):
             "pose_gn_us": stage["pose"] * 1e6, "patches_per_frame": int(len(q)), "pose_meas": int(n)}
 
 
+def pmc_traffic(workload):
+    """HBM bytes per K7 launch from the committed rocprofv3 PMC passes (profiles/k7_pmc_traffic.json, written by
+    tools/profile_k7.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be collected from inside this process, so the
+    number is only reported for the workload it was measured on; anything else gets null."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "k7_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        return float(rec[workload]["traffic_bytes_per_launch"]) if workload in rec else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -190,9 +204,9 @@ def main():
         pb = new_bundle(args.steps)
         avg_ms, alg_bytes = pb.bench_jacobian(args.jac_reps)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "jac_accum_kernel", "achieved": achieved,
+        out["roofline"] = {"bound": "hbm", "kernel": "jac_accum_wave_kernel", "achieved": achieved,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                           "traffic": pmc_traffic(out["config"]["workload"]), "algorithmic_bytes_per_launch": alg_bytes,
                            "avg_launch_us": avg_ms * 1e3, "launches_timed": args.jac_reps}
         pb.close()
         # context only (NOT the graded number): the same kernel on the config-5 problem shape,
@@ -201,7 +215,7 @@ def main():
             big = synth.make_ba_problem(200, 50000, synth.SEED_BA_GLOBAL, window=16)
             bb = synth.load_into(host.Bundle(ctx), big)
             bms, bby = bb.bench_jacobian(20)
-            out["roofline_config5_shape"] = {"kernel": "jac_accum_kernel", "measurements": int(len(big["cam_idx"])),
+            out["roofline_config5_shape"] = {"kernel": "jac_accum_wave_kernel", "measurements": int(len(big["cam_idx"])),
                                              "achieved": bby / (bms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                              "frac": bby / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_us": bms * 1e3}
             bb.close()
