@@ -157,6 +157,28 @@ BA_CASES = {
 }
 
 
+# BASELINE.json's full sizes and the shapes that select the other K7 forms: a few lambda trials each so that the
+# single-thread oracle stays within seconds
+BA_BIG_CASES = {
+    "headline_50x5000": dict(n_cams=50, n_pts=5000, seed=synth.SEED_BA_HEADLINE),                 # one chunk per wave
+    "loop256_60x7000": dict(n_cams=60, n_pts=7000, seed=11),                                      # looping K7, 256 threads
+    "loop512_200x26000_w16": dict(n_cams=200, n_pts=26000, seed=synth.SEED_BA_GLOBAL, window=16),   # LDS-bound: 512 threads
+}
+
+
+@pytest.mark.parametrize("case", list(BA_BIG_CASES))
+def test_bundle_full_size_trial_by_trial(hip, oracle, case):
+    prob = synth.make_ba_problem(**BA_BIG_CASES[case])
+    rh = util.run_ba(hip, prob, max_iterations=4)
+    ro = util.run_ba(oracle, prob, max_iterations=4)
+    util.assert_ba_equal(rh, ro, rel=1e-6)
+    assert len(rh["trials"]) == 4 and rh["accepted"] > 0
+    # size-independent properties: every accepted trial lowers the robust error, rejected ones do not move the state
+    t = rh["trials"]
+    assert all(x["err_new"] < x["err_old"] for x in t if x["accepted"])
+    assert all(not (x["err_new"] < x["err_old"]) for x in t if not x["accepted"])
+
+
 @pytest.mark.parametrize("case", list(BA_CASES))
 def test_bundle_trial_by_trial(hip, oracle, case):
     prob = synth.make_ba_problem(**BA_CASES[case])
