@@ -345,15 +345,19 @@ __global__ void __launch_bounds__(GN_THREADS) pose_gn_kernel(DevCam cam, int n, 
 #define GS_THREADS 256
 #define GS_WAVES (GS_THREADS / 64)
 #define GS_MPT 4   // measurements per thread: n <= 1024
+#define GS_BINS 2048   // 11-bit digits of the order-statistic select
 
 struct GnSmallShared {
     double pose[12];
     double mu[6];
     double red[GS_WAVES][27];
     double keys[GS_THREADS * GS_MPT];
-    unsigned hist[256];
-    int sel_digit, sel_k;
+    unsigned hist[GS_BINS];
+    int sel_digit, sel_k, sel_cnt;
     int wcount[GS_WAVES];
+    int scan[GS_WAVES];
+    unsigned long long cand[64];
+    int n_cand;
 };
 
 // wave sum by DPP: row shifts 1,2,4,8 then row broadcasts; the total lands in lane 63
@@ -367,57 +371,91 @@ __device__ __forceinline__ double wave_sum_f64_dpp(double v) {
     return v;
 }
 
-// exact k-th smallest of sh.keys[0..n) (non-found entries hold +inf): MSB radix select, 8-bit digits
+// exact k-th smallest of sh.keys[0..n) (non-found entries hold +inf), bit patterns compared as unsigned
+// 64-bit integers.  MSB radix select with 11-bit digits; as soon as the selected digit holds at most 64
+// keys (after two digits = 22 leading bits that is the rule: one or two keys) the wave-wide finisher
+// ranks them directly.  The 8-bit version needed 8 passes x 3 barriers per Gauss-Newton iteration and
+// was ~45 % of the pose solve.
 __device__ double small_select_kth(GnSmallShared& sh, int n, int k) {
     unsigned long long prefix = 0;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     unsigned long long key[GS_MPT];
 #pragma unroll
     for (int q = 0; q < GS_MPT; q++) {
         const int i = tid + q * GS_THREADS;
         key[q] = i < n ? (unsigned long long)__double_as_longlong(sh.keys[i]) : ~0ull;
     }
-    for (int pass = 0; pass < 8; pass++) {
-        const int shift = 56 - 8 * pass;
-        sh.hist[tid] = 0;
+    int top = 64;   // bits [top, 64) of the answer are fixed in `prefix`
+    while (top > 0) {
+        const int bits = top >= 11 ? 11 : top, shift = top - bits;
+        const unsigned mask = (1u << bits) - 1u;
+        for (int b = tid; b < GS_BINS; b += GS_THREADS) sh.hist[b] = 0;
+        if (tid == 0) sh.n_cand = 0;
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < GS_MPT; q++)
-            if (tid + q * GS_THREADS < n && (pass == 0 || (key[q] >> (shift + 8)) == (prefix >> (shift + 8))))
-                atomicAdd(&sh.hist[(key[q] >> shift) & 255], 1u);
+            if (tid + q * GS_THREADS < n && (top == 64 || (key[q] >> top) == (prefix >> top)))
+                atomicAdd(&sh.hist[(unsigned)(key[q] >> shift) & mask], 1u);
         __syncthreads();
-        if (tid < 64) {
-            const unsigned c0 = sh.hist[4 * tid], c1 = sh.hist[4 * tid + 1], c2 = sh.hist[4 * tid + 2],
-                           c3 = sh.hist[4 * tid + 3];
-            const int s = (int)(c0 + c1 + c2 + c3);
-            int incl = s;
+        // block-wide exclusive scan over GS_BINS / GS_THREADS bins per thread
+        constexpr int BPT = GS_BINS / GS_THREADS;
+        unsigned c[BPT];
+        int s = 0;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int v = __shfl_up(incl, o, 64);
-                if (tid >= o) incl += v;
-            }
-            const int excl = incl - s;
-            if (excl <= k && k < incl) {
-                int kk = k - excl, dg = 4 * tid;
-                if (kk >= (int)c0) {
-                    kk -= c0;
+        for (int b = 0; b < BPT; b++) {
+            c[b] = sh.hist[BPT * tid + b];
+            s += (int)c[b];
+        }
+        int incl = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) sh.scan[wid] = incl;
+        __syncthreads();
+        int off = 0;
+#pragma unroll
+        for (int w = 0; w < GS_WAVES; w++)
+            if (w < wid) off += sh.scan[w];
+        const int excl = off + incl - s;
+        if (excl <= k && k < excl + s) {
+            int kk = k - excl, dg = BPT * tid;
+#pragma unroll
+            for (int b = 0; b < BPT - 1; b++)
+                if (kk >= (int)c[b] && dg == BPT * tid + b) {
+                    kk -= (int)c[b];
                     dg++;
-                    if (kk >= (int)c1) {
-                        kk -= c1;
-                        dg++;
-                        if (kk >= (int)c2) {
-                            kk -= c2;
-                            dg++;
-                        }
-                    }
                 }
-                sh.sel_digit = dg;
-                sh.sel_k = kk;
-            }
+            sh.sel_digit = dg;
+            sh.sel_k = kk;
+            sh.sel_cnt = (int)sh.hist[dg];
         }
         __syncthreads();
         prefix |= (unsigned long long)sh.sel_digit << shift;
         k = sh.sel_k;
+        top = shift;
+        const int cnt = sh.sel_cnt;
+        if (top > 0 && cnt <= 64) {
+            // finisher: the keys that share the fixed bits, ranked by one wave
+#pragma unroll
+            for (int q = 0; q < GS_MPT; q++)
+                if (tid + q * GS_THREADS < n && (key[q] >> top) == (prefix >> top)) sh.cand[atomicAdd(&sh.n_cand, 1)] = key[q];
+            __syncthreads();
+            if (wid == 0) {
+                const unsigned long long mine = lane < cnt ? sh.cand[lane] : ~0ull;
+                int rank = 0;
+                for (int j = 0; j < cnt; j++) {
+                    const unsigned long long o = sh.cand[j];
+                    rank += (o < mine || (o == mine && j < lane)) ? 1 : 0;
+                }
+                if (lane < cnt && rank == k) sh.cand[63] = mine;   // exactly one lane (ties broken by index)
+            }
+            __syncthreads();
+            const unsigned long long r = sh.cand[63];
+            __syncthreads();   // sh.cand / n_cand are reused by the next call
+            return __longlong_as_double((long long)r);
+        }
     }
     return __longlong_as_double((long long)prefix);
 }
