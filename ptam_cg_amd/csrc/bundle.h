@@ -53,7 +53,9 @@ struct BaScalars {
     int sel_bin;            // first-level bin of the order statistic
     int sel_k;              // residual rank inside that bin
     int n_cand;             // compacted candidates
-    int pad_;
+    int sel_bin2;           // sharded select: second-level bin (-1: clamped first-level bin, all candidates count)
+    int sel_k2;             //                 residual rank inside it
+    int select_overflow;    //                 a rank had more last-stage candidates than its exchange slot holds
 };
 
 struct BaDev {

@@ -512,6 +512,151 @@ __global__ void __launch_bounds__(1024) select_final_kernel(BaDev d, int est, do
     }
 }
 
+// ---- sharded exact select: three small all-reduces, no host round trip ---------------------------------
+// Every rank histograms its own e^2; the first-level histogram is all-reduced, every rank finds the same
+// bin and compacts its own candidates + second-level histogram; that is all-reduced too; the few keys
+// that share both bins (a 2^-16 relative window around the order statistic) are exchanged through
+// fixed-size per-rank slots of a zero-initialised buffer (sum all-reduce = concatenation), and every rank
+// finishes with the same radix select.  Histograms travel as doubles (the hook reduces fp64; counts are
+// exact).  A rank with more last-stage candidates than its slot holds raises select_overflow: the host
+// then repeats the LM step with the gather-everything path (thousands of bit-identical errors only).
+#define XCAND_CAP_DEFAULT 4096   // keys per rank slot (PTAM_XCAND_CAP overrides it: the tests force the overflow path)
+__global__ void hist_to_f64_kernel(const unsigned* __restrict__ h, double* __restrict__ out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (double)h[i];
+}
+__global__ void f64_to_hist_kernel(const double* __restrict__ in, unsigned* __restrict__ h, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) h[i] = (unsigned)(in[i] + 0.5);
+}
+
+// stage 2: second-level bin from the all-reduced histogram; my candidates of that bin go into my slot.
+// xchg: [world counts][world x cap keys], zeroed beforehand.
+__global__ void __launch_bounds__(1024) select_stage_kernel(BaDev d, double* __restrict__ xchg, int rank, int world, int XCAND_CAP) {
+    __shared__ long long wsum[16];
+    __shared__ int s_bin2, s_k2, s_cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int n = d.sc->n_cand;
+    const int bin1 = d.sc->sel_bin;
+    const unsigned* hist2 = d.hist + HIST_BINS;
+    const bool clamped = bin1 == 0 || bin1 == HIST_BINS - 1;   // members do not share their top bits: all of them count
+    if (tid == 0) {
+        s_cnt = 0;
+        s_bin2 = -1;
+        s_k2 = d.sc->sel_k;
+    }
+    unsigned c[4];
+    long long s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        c[j] = hist2[4 * tid + j];
+        s += c[j];
+    }
+    long long incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        long long run = 0;
+        for (int i = 0; i < 16; i++) {
+            const long long v = wsum[i];
+            wsum[i] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    if (bin1 >= 0 && !clamped) {
+        const long long k1 = d.sc->sel_k;
+        const long long excl = wsum[wid] + incl - s;
+        if (excl <= k1 && k1 < excl + s) {
+            long long kk = k1 - excl;
+            int bb = 4 * tid;
+            for (int j = 0; j < 3; j++)
+                if (kk >= c[j]) {
+                    kk -= c[j];
+                    bb++;
+                } else
+                    break;
+            s_bin2 = bb;
+            s_k2 = (int)kk;
+        }
+    }
+    __syncthreads();
+    const int bin2 = s_bin2;
+    double* slot = xchg + world + (size_t)rank * XCAND_CAP;
+    if (bin1 >= 0)
+        for (int i = tid; i < n; i += 1024) {
+            const double key = d.cand[i];
+            if (clamped || e2_bin2(key) == bin2) {
+                const int pos = atomicAdd(&s_cnt, 1);
+                if (pos < XCAND_CAP) slot[pos] = key;
+            }
+        }
+    __syncthreads();
+    if (tid == 0) {
+        xchg[rank] = (double)s_cnt;
+        d.sc->sel_bin2 = bin2;
+        d.sc->sel_k2 = s_k2;
+    }
+}
+
+// stage 3: concatenate the exchanged candidates, select, derive sigma^2 (tail of select_final_kernel)
+__global__ void __launch_bounds__(1024) select_finish_kernel(BaDev d, const double* __restrict__ xchg, double* __restrict__ list,
+                                                             int world, int XCAND_CAP, int est, double min_sigma_sq) {
+    __shared__ unsigned hist[256];
+    __shared__ int s_digit, s_k, s_over;
+    __shared__ int offs[34];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int run = 0, over = 0;
+        for (int r = 0; r < world; r++) {
+            int c = (int)(xchg[r] + 0.5);
+            if (c > XCAND_CAP) {
+                over = 1;
+                c = XCAND_CAP;
+            }
+            offs[r] = run;
+            run += c;
+        }
+        offs[world] = run;
+        s_over = over;
+    }
+    __syncthreads();
+    const int total = offs[world];
+    for (int r = 0; r < world; r++) {
+        const int c = offs[r + 1] - offs[r];
+        const double* slot = xchg + world + (size_t)r * XCAND_CAP;
+        for (int i = tid; i < c; i += 1024) list[offs[r] + i] = slot[i];
+    }
+    __syncthreads();
+    const int bin1 = d.sc->sel_bin, bin2 = d.sc->sel_bin2;
+    unsigned long long result = 0;
+    const bool any = bin1 >= 0 && total > 0;
+    if (any) {
+        if (bin2 < 0)
+            result = block_radix_select(list, total, d.sc->sel_k2, 0ull, 56, hist, &s_digit, &s_k);
+        else {
+            const unsigned long long top = ((unsigned long long)(bin1 + E2_BIN_BASE) << 48) | ((unsigned long long)bin2 << 36);
+            result = block_radix_select(list, total, d.sc->sel_k2, top, 32, hist, &s_digit, &s_k);
+        }
+    }
+    for (int b = tid; b < 2 * HIST_BINS; b += 1024) d.hist[b] = 0;
+    if (tid == 0) {
+        const double med = any ? __longlong_as_double((long long)result) : 0.0;
+        d.sc->median = med;
+        double s2 = est_sigma_sq_from_median(est, med, (unsigned long long)d.sc->n_valid);
+        if (s2 < min_sigma_sq) s2 = min_sigma_sq;   // :234-237
+        d.sc->sigma_sq = s2;
+        d.sc->n_bad = 0;
+        d.sc->n_cand = 0;
+        d.sc->select_overflow = s_over;
+    }
+}
+
 // compact this rank's valid e^2 (sharded mode)
 __global__ void __launch_bounds__(256) compact_valid_kernel(BaDev d, double* __restrict__ out, int* __restrict__ counter) {
     const int lane = threadIdx.x & 63;
@@ -1736,6 +1881,10 @@ struct ptam_ba {
     double* d_gather = nullptr;
     size_t gather_cap = 0;
     double* d_xchg = nullptr;   // small exchange buffer (counts, scalars)
+    double* d_sel = nullptr;    // sharded select: [4096 histogram words][world counts][world x XCAND_CAP keys][same again: list]
+    int xcand_cap = XCAND_CAP_DEFAULT;
+    bool cur_pending = false;   // sharded: (current error, bad count) are waiting behind S|E for the next all-reduce
+    bool slow_select = false;   // sharded select fell back to gathering every key (after a select_overflow)
     // profiling
     bool prof = false;
     hipEvent_t ev[PTAM_K_COUNT][2];
@@ -1753,6 +1902,8 @@ static void ba_free_device(ptam_ba* ba) {
     if (ba->block) hipFree(ba->block);
     if (ba->d_gather) hipFree(ba->d_gather);
     if (ba->d_xchg) hipFree(ba->d_xchg);
+    if (ba->d_sel) hipFree(ba->d_sel);
+    ba->d_sel = nullptr;
     ba->block = nullptr;
     ba->d_gather = nullptr;
     ba->d_xchg = nullptr;
@@ -1992,7 +2143,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
                  o_spw = cv.take((size_t)(n_pairs + 1) * 4),
                  o_spart = cv.take(std::max<size_t>(1, s_wgs.size()) * SCHUR_TILE_ELEMS * 8);
     const size_t npad = std::max(d.npad, SOLVE_NB);
-    const size_t o_SE = cv.take((npad * npad + npad) * 8), o_L = cv.take(npad * npad * 8), o_Dg = cv.take(npad * 8),
+    const size_t o_SE = cv.take((npad * npad + npad + 2) * 8), o_L = cv.take(npad * npad * 8), o_Dg = cv.take(npad * 8),
                  o_y = cv.take(npad * 8), o_da = cv.take(npad * 8);
     const size_t o_out = cv.take(Mz * 4), o_sc = cv.take(sizeof(BaScalars)), o_dbg = cv.take(32768);
     ba->block_bytes = cv.off;
@@ -2079,6 +2230,10 @@ static int ba_prepare_impl(ptam_ba* ba) {
     HIP_TRY(hipFuncSetAttribute((const void*)schur_tile_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(2 * sizeof(SchurStageM))));
     HIP_TRY(hipMalloc((void**)&ba->d_xchg, 4096));
+    if (ba->world > 1) {
+        if (const char* e = getenv("PTAM_XCAND_CAP")) ba->xcand_cap = std::max(1, std::min(atoi(e), 1 << 20));
+        HIP_TRY(hipMalloc((void**)&ba->d_sel, (HIST_BINS + (size_t)ba->world * (1 + 2 * (size_t)ba->xcand_cap)) * sizeof(double)));
+    }
     ba->cur = 0;
     ba->prepared = true;
     return PTAM_OK;
@@ -2123,18 +2278,47 @@ static int ba_pass1_sigma(ptam_ba* ba) {
     BaDev& d = ba->d;
     const bool sharded = ba->comm && ba->world > 1;
     const double min_s2 = ba->opts.min_sigma * ba->opts.min_sigma;
+    const int build_hist = (sharded && ba->slow_select) ? 0 : 1;   // (the gather-everything path histograms the gathered keys)
     prof_begin(ba, PTAM_K_PROJECT);
     if (ba->trial_is_current && d.M > 0)
         hipLaunchKernelGGL(pass1_from_trial_kernel, dim3(std::min((d.M + 255) / 256, 512)), dim3(256), 0, ctx->stream, d,
-                           sharded ? 0 : 1);
+                           build_hist);
     else if (d.n_chunks > 0)
         hipLaunchKernelGGL(project_e2_kernel, dim3(std::min(d.n_chunks, 512)), dim3(BA_CHUNK), 0, ctx->stream, ctx->cam, d,
-                           ba->cur, sharded ? 0 : 1);
+                           ba->cur, build_hist);
     prof_end(ba, PTAM_K_PROJECT);
     prof_begin(ba, PTAM_K_SELECT);
     if (!sharded) {
         hipLaunchKernelGGL(select_compact_kernel, dim3(std::max(1, std::min((d.M + 1023) / 1024, 256))), dim3(256), 0,
                            ctx->stream, d, (const double*)d.m_e2, (long long)d.M, (const uint8_t*)d.m_state);
+    } else if (!ba->slow_select) {
+        double* hx = ba->d_sel;                  // histogram exchange
+        double* xc = ba->d_sel + HIST_BINS;      // candidate exchange
+        const int cap = ba->xcand_cap;
+        double* list = xc + (size_t)ba->world * (1 + (size_t)cap);
+        const size_t n_xc = (size_t)ba->world * (1 + (size_t)cap);
+        auto reduce_hist = [&](unsigned* h) -> int {
+            hipLaunchKernelGGL(hist_to_f64_kernel, dim3(HIST_BINS / 256), dim3(256), 0, ctx->stream, (const unsigned*)h, hx, HIST_BINS);
+            const int rc = ba_allreduce(ba, hx, HIST_BINS);
+            if (rc) return rc;
+            hipLaunchKernelGGL(f64_to_hist_kernel, dim3(HIST_BINS / 256), dim3(256), 0, ctx->stream, (const double*)hx, h, HIST_BINS);
+            return PTAM_OK;
+        };
+        int rc = reduce_hist(d.hist);
+        if (rc) return rc;
+        hipLaunchKernelGGL(select_compact_kernel, dim3(std::max(1, std::min((d.M + 1023) / 1024, 256))), dim3(256), 0,
+                           ctx->stream, d, (const double*)d.m_e2, (long long)d.M, (const uint8_t*)d.m_state);
+        rc = reduce_hist(d.hist + HIST_BINS);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(xc, 0, n_xc * sizeof(double), ctx->stream));
+        hipLaunchKernelGGL(select_stage_kernel, dim3(1), dim3(1024), 0, ctx->stream, d, xc, ba->rank, ba->world, cap);
+        rc = ba_allreduce(ba, xc, n_xc);
+        if (rc) return rc;
+        hipLaunchKernelGGL(select_finish_kernel, dim3(1), dim3(1024), 0, ctx->stream, d, (const double*)xc, list, ba->world, cap,
+                           ba->opts.estimator, min_s2);
+        prof_end(ba, PTAM_K_SELECT);
+        HIP_TRY(hipGetLastError());
+        return PTAM_OK;
     } else {
         // all-gather of the valid e^2 built from two all-reduces (counts, then a zero-padded vector)
         int* d_cnt = (int*)(ba->d_xchg + 256);
@@ -2207,10 +2391,17 @@ static int ba_pass2(ptam_ba* ba) {
                        d, d.grid_acc);
     HIP_TRY(hipGetLastError());
     if (ba->comm && ba->world > 1) {
-        hipLaunchKernelGGL(pack2_kernel, dim3(1), dim3(1), 0, ctx->stream, (const BaScalars*)d.sc, ba->d_xchg, 0);
-        int rc = ba_allreduce(ba, ba->d_xchg, 2);
-        if (rc) return rc;
-        hipLaunchKernelGGL(unpack2_kernel, dim3(1), dim3(1), 0, ctx->stream, d.sc, (const double*)ba->d_xchg, 0);
+        if (d.F > 0) {
+            // current error / bad count ride behind S|E in the step's first camera-system all-reduce
+            hipLaunchKernelGGL(pack2_kernel, dim3(1), dim3(1), 0, ctx->stream, (const BaScalars*)d.sc,
+                               d.SE + (size_t)d.npad * d.npad + d.npad, 0);
+            ba->cur_pending = true;
+        } else {
+            hipLaunchKernelGGL(pack2_kernel, dim3(1), dim3(1), 0, ctx->stream, (const BaScalars*)d.sc, ba->d_xchg, 0);
+            int rc = ba_allreduce(ba, ba->d_xchg, 2);
+            if (rc) return rc;
+            hipLaunchKernelGGL(unpack2_kernel, dim3(1), dim3(1), 0, ctx->stream, d.sc, (const double*)ba->d_xchg, 0);
+        }
     }
     return PTAM_OK;
 }
@@ -2229,8 +2420,13 @@ static int ba_trial(ptam_ba* ba, double lambda) {
                            (ba->world > 1 && ba->rank != 0) ? 0 : 1);
         prof_end(ba, PTAM_K_SCHUR);
         HIP_TRY(hipGetLastError());
-        int rc = ba_allreduce(ba, d.SE, (size_t)d.npad * d.npad + d.npad);   // the path's one exchange step
+        const size_t n_se = (size_t)d.npad * d.npad + d.npad;
+        int rc = ba_allreduce(ba, d.SE, n_se + (ba->cur_pending ? 2 : 0));   // the path's one exchange step
         if (rc) return rc;
+        if (ba->cur_pending) {
+            hipLaunchKernelGGL(unpack2_kernel, dim3(1), dim3(1), 0, ctx->stream, d.sc, (const double*)(d.SE + n_se), 0);
+            ba->cur_pending = false;
+        }
         prof_begin(ba, PTAM_K_SOLVE);
         rc = ba_solve(ctx, d, ba->cur);
         prof_end(ba, PTAM_K_SOLVE);
@@ -2443,6 +2639,8 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     BaDev& d = ba->d;
     double lambda = 0.0001, lambda_factor = 2.0;   // :125-126
     ba->converged = false;
+    ba->cur_pending = false;
+    ba->slow_select = false;
     ba->trial_is_current = false;
     bool hit_max = false;
     int counter = 0;
@@ -2463,7 +2661,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
         if (rc) return rc;
         bool have_cur = false;
         double cur_err = 0, new_err = 0;
-        bool ran_any = false;
+        bool ran_any = false, redo_step = false;
         // while(dNewError > dCurrentError && !converged && !hitmax && !abort)  :338
         for (;;) {
             if (have_cur && !(new_err > cur_err)) break;
@@ -2477,6 +2675,14 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
                 //  length left by the purge that closed step s-1 — no separate read-back for it)
                 if (prev_end_pending) step_outlier_end.push_back(sc.n_outliers);
                 prev_end_pending = false;
+                if (sc.select_overflow && !ba->slow_select) {
+                    // sharded select: a rank's exchange slot overflowed (thousands of bit-identical errors), so this
+                    // step ran with a wrong sigma^2.  Nothing has been committed: repeat it with the gather path.
+                    ba->slow_select = true;
+                    if (getenv("PTAM_DEBUG_SELECT")) std::fprintf(stderr, "[ptam] rank %d: select overflow, repeating the step on the gather path\n", ba->rank);
+                    redo_step = true;
+                    break;
+                }
                 have_cur = true;
                 cur_err = sc.cur_err;
                 new_err = cur_err + 9999;   // :337
@@ -2504,6 +2710,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
             if (counter >= ba->opts.max_iterations) hit_max = true;   // :518-520
             ba->trials.push_back(t);
         }
+        if (redo_step) continue;   // (keeps trial_is_current: pass 1 may still adopt the previous trial's errors)
         ba->trial_is_current = false;
         if (ran_any && new_err < cur_err) {   // :523-533
             lambda_factor = 2.0;

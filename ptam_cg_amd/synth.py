@@ -200,11 +200,13 @@ def make_pvs_case(n=4000, seed=0x5EED0007, camera=DEFAULT_CAMERA, size=(640, 480
 # bundle problems
 # ---------------------------------------------------------------------------------------------
 def make_ba_problem(n_cams, n_pts, seed, window=None, camera=DEFAULT_CAMERA, size=(640, 480),
-                    outlier_frac=0.02, n_fixed=1, pt_noise=0.01, pose_noise=0.005):
+                    outlier_frac=0.02, n_fixed=1, pt_noise=0.01, pose_noise=0.005, dup=1):
     """Cameras on a 120 degree arc (radius 2 m, height 1 m) looking at the origin; points in
     [-0.5,0.5]^2 x [-0.1,0.1].  window=k limits each point to k consecutive cameras (banded
     covisibility).  Measurements are emitted in the reference's marshalling order: keyframe
-    order, then point order (src/MapMaker.cc:871-882)."""
+    order, then point order (src/MapMaker.cc:871-882).  dup=k replicates every point (position,
+    start value and measurements) k times: thousands of bit-identical errors, the degenerate input of
+    the order-statistic select."""
     rng = np.random.Generator(np.random.PCG64(seed))
     cam = AtanCam(camera, size)
     ang = np.linspace(-np.pi / 3, np.pi / 3, n_cams)
@@ -233,10 +235,18 @@ def make_ba_problem(n_cams, n_pts, seed, window=None, camera=DEFAULT_CAMERA, siz
         poses[c] = se3_mul(se3_exp(rng.normal(0, pose_noise, 6)), poses_true[c])
     fixed = np.zeros(n_cams, np.uint8)
     fixed[:n_fixed] = 1
-    return {"poses": poses, "fixed": fixed, "points": pts_true + rng.normal(0, pt_noise, (n_pts, 3)),
+    prob = {"poses": poses, "fixed": fixed, "points": pts_true + rng.normal(0, pt_noise, (n_pts, 3)),
             "cam_idx": np.concatenate(cam_idx), "pt_idx": np.concatenate(pt_idx),
             "found": np.concatenate(found), "sigma_sq": np.concatenate(sig),
             "poses_true": poses_true, "points_true": pts_true}
+    if dup > 1:
+        j = np.arange(dup, dtype=np.int32)
+        prob["points"] = np.repeat(prob["points"], dup, axis=0)
+        prob["points_true"] = np.repeat(pts_true, dup, axis=0)
+        prob["pt_idx"] = (prob["pt_idx"][:, None] * dup + j[None, :]).reshape(-1).astype(np.int32)
+        for k in ("cam_idx", "found", "sigma_sq"):
+            prob[k] = np.repeat(prob[k], dup, axis=0)
+    return prob
 
 
 def load_into(bundle, prob):

@@ -21,7 +21,7 @@ def free_port():
     return p
 
 
-def run_sharded(which, world, case, timeout=300):
+def run_sharded(which, world, case, timeout=300, extra_env=None):
     """launch `world` worker processes (gloo on 127.0.0.1); returns rank 0's result dict"""
     out = tempfile.mktemp(suffix=".pkl")
     port = str(free_port())
@@ -29,6 +29,7 @@ def run_sharded(which, world, case, timeout=300):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
                    PTAM_DIST_CASE=repr(case), OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), which, out],
                                       env=env, cwd=ROOT))
     try:

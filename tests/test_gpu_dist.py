@@ -20,6 +20,16 @@ def test_sharded_hip_matches_single_process_oracle(oracle, world, case):
     dist_util.check_sharded_equals_single(res, oracle, case, rel=1e-6)
 
 
+def test_sharded_select_with_ties_and_slot_overflow(oracle):
+    """every point replicated 24 times: bit-identical errors in runs of 24.  With 6-key exchange slots the
+    last stage of the sharded select overflows, the host repeats the step on the gather-everything path,
+    and the result must still equal the single-process run; with the default slots the ties fit."""
+    case = dict(n_cams=8, n_pts=40, seed=12, dup=24)
+    for env in ({"PTAM_XCAND_CAP": "6"}, None):
+        res = dist_util.run_sharded("hip", 2, case, extra_env=env)
+        dist_util.check_sharded_equals_single(res, oracle, case, rel=1e-6)
+
+
 def test_rccl_single_rank_allreduce(hip):
     ctx = host.Context(lib=hip)
     ident = (C.c_uint8 * 128)()
