@@ -46,6 +46,22 @@ int main() {
                         pf.GetCoarsePosAsVector()[1], pf.ZMSSDAtPoint(kf, 0, c));
             break;
         }
+    // warped template out of the same keyframe: an identity warp reproduces the 8x8 window, a second call for the
+    // same point with an almost identical warp is served from the reuse test, a rotated warp regenerates
+    for (auto& c : L0.vCorners)
+        if (c.x >= 20 && c.y >= 20 && c.x < 140 && c.y < 100) {
+            PatchFinder pf(ctx);
+            const int pointId = 1;
+            const double wi_id[4] = {1, 0, 0, 1}, wi_close[4] = {1.01, 0, 0, 1.01}, wi_rot[4] = {0.8, -0.6, 0.6, 0.8};
+            pf.MakeTemplateCoarseCont(&pointId, kf, 0, c, wi_id, 0);
+            const int z0 = pf.ZMSSDAtPoint(kf, 0, c);
+            pf.MakeTemplateCoarseCont(&pointId, kf, 0, c, wi_close, 0);   // |dm2| < 0.07: template kept
+            const int z1 = pf.ZMSSDAtPoint(kf, 0, c);
+            pf.MakeTemplateCoarseCont(&pointId, kf, 0, c, wi_rot, 0);
+            const int z2 = pf.ZMSSDAtPoint(kf, 0, c);
+            std::printf("WARP %d %d %d %d %d %d\n", c.x, c.y, z0, z1, z2, (int)pf.TemplateBad());
+            break;
+        }
     // a toy bundle: 3 cameras on a line looking down +z, 12 points on a grid, exact measurements of a
     // pinhole-ish projection perturbed deterministically
     Context c640({1.0803, 1.43987, 0.519983, 0.548655, 0.244943}, {640, 480});

@@ -157,6 +157,32 @@ typedef struct {
 int ptam_subpix_batch(ptam_ctx* ctx, const ptam_kf* kf, int n, const ptam_subpix_query* queries,
                       const uint8_t* templates, ptam_subpix_result* results);
 
+/* ---- PatchFinder::MakeTemplateCoarseCont (src/PatchFinder.cc:98-127): the 8x8 search template warped out
+ *      of the map point's source keyframe by CVD::transform, then MakeTemplateSums.
+ *      CVD::transform / CVD::sample are libCVD (not vendored by the reference): restated from its published
+ *      source — positions advance by repeated addition (p += across per pixel, += down - 8*across per row),
+ *      bilinear value (1-y)*((1-x)*a + x*b) + y*((1-x)*c + x*d) in double, converted to a byte by
+ *      truncation; pixels whose source position leaves [0,w-1)x[0,h-1) become 0 and count as outside
+ *      (checked per pixel only when the patch's bounding box is not wholly inside).
+ *      The "same map point, warp moved < 0.07" reuse test (:103-111) is host state and stays with the
+ *      caller (ptam::PatchFinder / host.PatchFinder keep mpLastTemplateMapPoint and mm2LastWarpMatrix). */
+typedef struct {
+    const ptam_kf* src_kf;      /* MapPoint::pPatchSourceKF */
+    int32_t src_level;          /* MapPoint::nSourceLevel */
+    int32_t search_level;       /* mnSearchLevel from CalcSearchLevelAndWarpMatrix; < 0 = template bad, skipped */
+    int32_t center_x, center_y; /* MapPoint::irCenter, source-level pixels */
+    double warp_inverse[4];     /* mm2WarpInverse row-major (ptam_pvs_result::warp_inverse) */
+} ptam_template_query;
+typedef struct {
+    int32_t bad;                /* mbTemplateBad = (bool)nOutside (1 also when the query was skipped) */
+    int32_t n_outside;          /* return value of CVD::transform */
+    int32_t sum, sum_sq;        /* mnTemplateSum, mnTemplateSumSq */
+    double m2[4];               /* the warp matrix used: M2Inverse(mm2WarpInverse) * LevelScale(mnSearchLevel) */
+} ptam_template_result;
+/* templates_out: n * 64 bytes (8x8 row-major), the layout ptam_find_patch_coarse_batch takes */
+int ptam_make_templates_batch(ptam_ctx* ctx, int n, const ptam_template_query* queries, uint8_t* templates_out,
+                              ptam_template_result* results);
+
 /* ---- TrackerData::Project / ProjectAndDerivs + ATANCamera (include/Tracker.h:70-94,
  *      src/ATANCamera.cc:109-121, 179-209) ------------------------------------------------------- */
 typedef struct {

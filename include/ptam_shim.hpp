@@ -149,6 +149,45 @@ public:
         mnSearchLevel = nSearchLevel;
         mbTemplateBad = bBad;
     }
+    // void MakeTemplateCoarseCont(MapPoint& p)  include/PatchFinder.h:70, src/PatchFinder.cc:98-127.
+    // The MapPoint fields it reads are passed explicitly: pPatchSourceKF, nSourceLevel, irCenter; mm2WarpInverse and
+    // mnSearchLevel are what CalcSearchLevelAndWarpMatrix left (TrackMapPVS returns both per point).  `pPointId`
+    // stands for the MapPoint's address in the reuse test ("same point and the warp moved < 0.07": keep the template).
+    void MakeTemplateCoarseCont(const void* pPointId, KeyFrame& kfSource, int nSourceLevel, ImageRef irCenter,
+                                const double mm2WarpInverse[4], int nSearchLevel) {
+        mnSearchLevel = nSearchLevel;
+        if (nSearchLevel < 0) {   // CalcSearchLevelAndWarpMatrix returned -1 and set mbTemplateBad (src/PatchFinder.cc:78-81)
+            mbTemplateBad = true;
+            return;
+        }
+        // m2 = M2Inverse(mm2WarpInverse) * LevelScale(mnSearchLevel)   (include/Tools.h:54-65)
+        const double det = mm2WarpInverse[0] * mm2WarpInverse[3] - mm2WarpInverse[2] * mm2WarpInverse[1];
+        const double inv = 1.0 / det, sc = (double)(1 << nSearchLevel);
+        const double m2[4] = {mm2WarpInverse[3] * inv * sc, -mm2WarpInverse[1] * inv * sc, -mm2WarpInverse[2] * inv * sc,
+                              mm2WarpInverse[0] * inv * sc};
+        bool refresh = pPointId != mpLastTemplateMapPoint;
+        for (int i = 0; !refresh && i < 2; i++) {   // columns of m2 against the last warp matrix
+            const double d0 = m2[i] - mm2LastWarpMatrix[i], d1 = m2[2 + i] - mm2LastWarpMatrix[2 + i];
+            if (d0 * d0 + d1 * d1 > 0.07 * 0.07) refresh = true;
+        }
+        if (!refresh) return;
+        ptam_template_query q{kfSource.handle(), nSourceLevel, nSearchLevel, irCenter.x, irCenter.y,
+                              {mm2WarpInverse[0], mm2WarpInverse[1], mm2WarpInverse[2], mm2WarpInverse[3]}};
+        ptam_template_result r;
+        check(ptam_make_templates_batch(ctx_->handle(), 1, &q, tmpl_, &r), "ptam_make_templates_batch");
+        mbTemplateBad = r.bad != 0;
+        mpLastTemplateMapPoint = pPointId;
+        for (int i = 0; i < 4; i++) mm2LastWarpMatrix[i] = r.m2[i];
+    }
+    // the batched form for SearchForPoints: every template of a frame in one launch (no reuse test: callers that want
+    // it keep (point id, m2) per point and drop the unchanged queries before the call)
+    static void MakeTemplatesBatch(Context& c, const std::vector<ptam_template_query>& q, std::vector<uint8_t>& templates64,
+                                   std::vector<ptam_template_result>& out) {
+        templates64.resize(q.size() * 64);
+        out.resize(q.size());
+        check(ptam_make_templates_batch(c.handle(), (int)q.size(), q.data(), templates64.data(), out.data()),
+              "ptam_make_templates_batch");
+    }
     // bool FindPatchCoarse(CVD::ImageRef ir, KeyFrame& kf, unsigned int nRange)  include/PatchFinder.h:78
     bool FindPatchCoarse(ImageRef irPos, KeyFrame& kf, unsigned int nRange) {
         ptam_patch_query q{irPos.x, irPos.y, mbTemplateBad ? -1 : mnSearchLevel, nRange};
@@ -191,6 +230,8 @@ private:
     uint8_t tmpl_[64] = {0};
     int mnSearchLevel = 0;
     bool mbTemplateBad = false, mbFound = false;
+    const void* mpLastTemplateMapPoint = nullptr;            // include/PatchFinder.h:135-136
+    double mm2LastWarpMatrix[4] = {9999.9, 0, 0, 9999.9};    // src/PatchFinder.cc:21-22
     Vec<2> mv2CoarsePos{0, 0}, mv2SubPixPos{0, 0};
 };
 

@@ -123,6 +123,56 @@ def zmssd(im, x, y, tmpl):
     return trunc_div(2 * SA * SB - SA * SA - SB * SB, 64) + int((I * I).sum()) + int((T * T).sum()) - 2 * int((I * T).sum())
 
 
+def make_template_coarse_cont(im, cx, cy, search_level, warp_inverse):
+    """PatchFinder::MakeTemplateCoarseCont (src/PatchFinder.cc:98-127) without the host-side reuse test:
+    CVD::transform of level image `im` (2-D uint8) with M = M2Inverse(mm2WarpInverse) * LevelScale(search_level),
+    inOrig = (cx, cy), outOrig = (4, 4), then MakeTemplateSums.  libCVD's transform / sample restated from the
+    library's published vision.h (unpinned): sequential position updates, bilinear value in double, truncation.
+    Returns (template uint8[64], dict(bad, n_outside, sum, sum_sq, m2))."""
+    wi = [float(v) for v in np.asarray(warp_inverse, dtype=np.float64).reshape(4)]
+    det = wi[0] * wi[3] - wi[2] * wi[1]
+    inv = 1.0 / det
+    sc = float(1 << search_level)
+    m00, m11, m10, m01 = wi[3] * inv * sc, wi[0] * inv * sc, -wi[2] * inv * sc, -wi[1] * inv * sc
+    ih, iw = im.shape
+    w = h = 8
+    ax, ay, dx, dy = m00, m10, m01, m11
+    p0x = float(cx) - (m00 * 4.0 + m01 * 4.0)
+    p0y = float(cy) - (m10 * 4.0 + m11 * 4.0)
+    min_x = max_x = p0x
+    min_y = max_y = p0y
+    if ax < 0: min_x += w * ax
+    else: max_x += w * ax
+    if dx < 0: min_x += h * dx
+    else: max_x += h * dx
+    if ay < 0: min_y += w * ay
+    else: max_y += w * ay
+    if dy < 0: min_y += h * dy
+    else: max_y += h * dy
+    crx, cry = dx - w * ax, dy - w * ay
+    all_inside = min_x >= 0 and min_y >= 0 and max_x < iw - 1 and max_y < ih - 1
+    out = np.zeros(64, dtype=np.uint8)
+    count = 0
+    px, py = p0x, p0y
+    for i in range(h):
+        for j in range(w):
+            if all_inside or (0 <= px and 0 <= py and px < iw - 1 and py < ih - 1):
+                lx, ly = int(px), int(py)
+                x, y = px - lx, py - ly
+                a, b, c, d = float(im[ly, lx]), float(im[ly, lx + 1]), float(im[ly + 1, lx]), float(im[ly + 1, lx + 1])
+                v = (1 - y) * ((1 - x) * a + x * b) + y * ((1 - x) * c + x * d)
+                out[i * 8 + j] = int(v)
+            else:
+                count += 1
+            px += ax
+            py += ay
+        px += crx
+        py += cry
+    t = out.astype(np.int64)
+    return out, dict(bad=int(count != 0), n_outside=count, sum=int(t.sum()), sum_sq=int((t * t).sum()),
+                     m2=np.array([m00, m01, m10, m11]))
+
+
 def find_patch_coarse(levels, q, tmpl):
     x, y, level, rng = int(q["x"]), int(q["y"]), int(q["level"]), int(q["range"])
     res = dict(found=0, best_ssd=MAX_SSD + 1, best_x=-1, best_y=-1, n_scored=0, pos=(0.0, 0.0))

@@ -1213,6 +1213,60 @@ struct OCtx {
 }   // namespace
 
 // ================================================================================================
+// PatchFinder::MakeTemplateCoarseCont (src/PatchFinder.cc:98-127) minus the host-side reuse test:
+// m2 = M2Inverse(mm2WarpInverse) * LevelScale(mnSearchLevel) (include/Tools.h:54-65), CVD::transform of
+// the source level into the 8x8 template with inOrig = irCenter, outOrig = (4,4), then MakeTemplateSums.
+// CVD::transform / CVD::sample belong to libCVD (absent from the reference tree): restated from the
+// library's published vision.h — UNPINNED like the rest of this file.  Statement by statement:
+//   across = M.T()[0], down = M.T()[1], p0 = inOrig - M*outOrig; bounding box from p0 with w*across / h*down
+//   added on the side of their sign; if the box lies in [0, iw-1) x [0, ih-1): sample every pixel, else test
+//   each position (0 <= p && p < bound) and write byte() = 0 + count it; the position advances by
+//   p += across per pixel and p += (down - w*across) per row; sample = bilinear in double,
+//   (1-y)*((1-x)*a + x*b) + y*((1-x)*c + x*d), converted by static_cast<byte>.
+static void make_template_coarse_cont(const Level& src, int cx, int cy, int search_level, const double wi[4], uint8_t out[64],
+                                      ptam_template_result& r) {
+    const double det = wi[0] * wi[3] - wi[2] * wi[1];
+    const double inv = 1.0 / det;
+    const double sc = (double)(1 << search_level);
+    const double m00 = wi[3] * inv * sc, m11 = wi[0] * inv * sc, m10 = -wi[2] * inv * sc, m01 = -wi[1] * inv * sc;
+    r.m2[0] = m00, r.m2[1] = m01, r.m2[2] = m10, r.m2[3] = m11;
+    const int w = 8, h = 8, iw = src.w, ih = src.h;
+    const double ax = m00, ay = m10, dx = m01, dy = m11;
+    const double p0x = (double)cx - (m00 * 4.0 + m01 * 4.0), p0y = (double)cy - (m10 * 4.0 + m11 * 4.0);
+    double min_x = p0x, min_y = p0y, max_x = p0x, max_y = p0y;
+    if (ax < 0) min_x += w * ax; else max_x += w * ax;
+    if (dx < 0) min_x += h * dx; else max_x += h * dx;
+    if (ay < 0) min_y += w * ay; else max_y += w * ay;
+    if (dy < 0) min_y += h * dy; else max_y += h * dy;
+    const double crx = dx - w * ax, cry = dy - w * ay;
+    const bool all_inside = min_x >= 0 && min_y >= 0 && max_x < iw - 1 && max_y < ih - 1;
+    const double x_bound = iw - 1, y_bound = ih - 1;
+    int count = 0;
+    double px = p0x, py = p0y;
+    for (int i = 0; i < h; ++i, px += crx, py += cry)
+        for (int j = 0; j < w; ++j, px += ax, py += ay) {
+            if (all_inside || (0 <= px && 0 <= py && px < x_bound && py < y_bound)) {
+                const int lx = (int)px, ly = (int)py;
+                const double x = px - lx, y = py - ly;
+                const uint8_t* p = src.im.data() + (size_t)ly * iw + lx;
+                const double v = (1 - y) * ((1 - x) * p[0] + x * p[1]) + y * ((1 - x) * p[iw] + x * p[iw + 1]);
+                out[i * 8 + j] = static_cast<uint8_t>(v);
+            } else {
+                out[i * 8 + j] = 0;
+                ++count;
+            }
+        }
+    r.n_outside = count;
+    r.bad = count != 0;
+    int s1 = 0, s2 = 0;
+    for (int k = 0; k < 64; k++) {
+        s1 += out[k];
+        s2 += out[k] * out[k];
+    }
+    r.sum = s1;
+    r.sum_sq = s2;
+}
+
 // C entry points (ptamo_*): same structs and argument meaning as include/ptam_hip.h
 // ================================================================================================
 extern "C" {
@@ -1320,6 +1374,22 @@ int ptamo_kf_read_rest(ptamo_ctx*, const ptamo_kf* k, int l, ptam_int2* mc, doub
 int ptamo_find_patch_coarse_batch(ptamo_ctx*, const ptamo_kf* k, int n, const ptam_patch_query* q,
                                   const uint8_t* tmpl, ptam_patch_result* res) {
     for (int i = 0; i < n; i++) find_patch_coarse(k->kf, q[i], tmpl + (size_t)i * 64, res[i]);
+    return PTAM_OK;
+}
+int ptamo_make_templates_batch(ptamo_ctx*, int n, const ptam_template_query* q, uint8_t* tmpl, ptam_template_result* res) {
+    for (int i = 0; i < n; i++) {
+        ptam_template_result& r = res[i];
+        std::memset(&r, 0, sizeof r);
+        uint8_t* out = tmpl + (size_t)i * 64;
+        if (q[i].search_level < 0) {
+            r.bad = 1;
+            std::memset(out, 0, 64);
+            continue;
+        }
+        const ptamo_kf* k = reinterpret_cast<const ptamo_kf*>(q[i].src_kf);
+        if (!k || q[i].src_level < 0 || q[i].src_level >= PTAM_LEVELS || q[i].search_level >= PTAM_LEVELS) return PTAM_E_ARG;
+        make_template_coarse_cont(k->kf.lev[q[i].src_level], q[i].center_x, q[i].center_y, q[i].search_level, q[i].warp_inverse, out, r);
+    }
     return PTAM_OK;
 }
 int ptamo_zmssd_at_points(ptamo_ctx*, const ptamo_kf* k, int level, int n, const ptam_int2* pts,

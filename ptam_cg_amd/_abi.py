@@ -47,6 +47,15 @@ class SubpixResult(C.Structure):
     _fields_ = [("converged", C.c_int32), ("iterations", C.c_int32), ("pos", C.c_double * 2), ("mean_diff", C.c_double)]
 
 
+class TemplateQuery(C.Structure):
+    _fields_ = [("src_kf", C.c_void_p), ("src_level", C.c_int32), ("search_level", C.c_int32), ("center_x", C.c_int32),
+                ("center_y", C.c_int32), ("warp_inverse", C.c_double * 4)]
+
+
+class TemplateResult(C.Structure):
+    _fields_ = [("bad", C.c_int32), ("n_outside", C.c_int32), ("sum", C.c_int32), ("sum_sq", C.c_int32), ("m2", C.c_double * 4)]
+
+
 class PvsPoint(C.Structure):
     _fields_ = [("world", C.c_double * 3), ("pixel_right_w", C.c_double * 3), ("pixel_down_w", C.c_double * 3)]
 
@@ -112,6 +121,7 @@ PROTOTYPES = {
     "zmssd_at_points": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "project_points": (_i, [_vp, _i, _vp, _pd, _vp]),
     "subpix_batch": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "make_templates_batch": (_i, [_vp, _i, _vp, _vp, _vp]),
     "track_pvs": (_i, [_vp, _i, _vp, _pd, _vp, _vp]),
     "gn_opts_default": (None, [C.POINTER(GnOpts)]),
     "pose_gn": (_i, [_vp, _i, _vp, _vp, _pd, C.POINTER(GnOpts), _vp, _vp]),

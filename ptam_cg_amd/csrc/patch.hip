@@ -8,7 +8,32 @@
 // disc test) with a ballot and then walks the surviving bits in ascending order, which preserves the
 // reference's "first strict minimum" tie-break (raster order).
 #include "common.h"
+#include <vector>
+
 #include "keyframe.h"
+
+// fp64 primitives that are never contracted into FMAs (hipcc's __dmul_rn / __dadd_rn / __dsub_rn are plain operators
+// under -ffp-contract=fast and WOULD be fused): each rounds on its own, like the reference's x86-64 build
+__device__ __forceinline__ double nc_mul(double a, double b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ double nc_add(double a, double b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ double nc_sub(double a, double b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ float nc_mulf(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float nc_addf(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
 
 // integer zero-mean SSD; the /64 is a C division truncating toward zero (numerator <= 0)
 __device__ __forceinline__ int zmssd_finish(int SA, int SB, int isumsq, int tsumsq, int cross) {
@@ -211,9 +236,9 @@ __global__ void __launch_bounds__(256) subpix_kernel(KfLevels L, int n, const pt
             double d0 = 0, d1 = 0, d2 = 0;
             if (inner) {
                 const uint8_t* p = im + (size_t)(iby + py) * w + ibx + px;
-                const float fPixel = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(fTL, (float)p[0]), __fmul_rn(fTR, (float)p[1])),
-                                                         __fmul_rn(fBL, (float)p[w])),
-                                               __fmul_rn(fBR, (float)p[w + 1]));
+                const float fPixel = nc_addf(nc_addf(nc_addf(nc_mulf(fTL, (float)p[0]), nc_mulf(fTR, (float)p[1])),
+                                                     nc_mulf(fBL, (float)p[w])),
+                                             nc_mulf(fBR, (float)p[w + 1]));
                 const double dDiff = (double)fPixel - (double)T + mean_diff;
                 d0 = dDiff * jx;
                 d1 = dDiff * jy;
@@ -236,6 +261,100 @@ __global__ void __launch_bounds__(256) subpix_kernel(KfLevels L, int n, const pt
         res.mean_diff = mean_diff;
     }
     if (lane == 0) results[qi] = res;
+}
+
+// =================================================================================================
+// MakeTemplateCoarseCont (src/PatchFinder.cc:98-127): CVD::transform of the source patch + template sums
+// =================================================================================================
+struct TemplateJob {          // device-side form of ptam_template_query (keyframe handle resolved to its level image)
+    const uint8_t* im;
+    int w, h;
+    int search_level;
+    int cx, cy;
+    double wi[4];
+};
+
+// One wave per template, lane = output pixel (i = lane / 8 row, j = lane % 8 column).  The source position is
+// NOT evaluated in closed form: the reference walks p += across / += carriage_return pixel by pixel, and the
+// lane replays that exact sequence of fp64 additions (<= 70 of them) so the sampled positions are bit-identical.
+// Every product and sum goes through the nc_* primitives below: no FMA contraction.
+__global__ void __launch_bounds__(256) make_templates_kernel(int n, const TemplateJob* __restrict__ jobs, uint8_t* __restrict__ tmpl,
+                                                             ptam_template_result* __restrict__ res) {
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= n) return;
+    const TemplateJob jb = jobs[q];
+    ptam_template_result r;
+    r.bad = 1;
+    r.n_outside = 0;
+    r.sum = r.sum_sq = 0;
+    r.m2[0] = r.m2[1] = r.m2[2] = r.m2[3] = 0;
+    if (jb.search_level < 0 || jb.im == nullptr) {
+        tmpl[(size_t)q * 64 + lane] = 0;
+        if (lane == 0) res[q] = r;
+        return;
+    }
+    // m2 = M2Inverse(mm2WarpInverse) * LevelScale(mnSearchLevel)   (include/Tools.h:54-65)
+    const double det = nc_sub(nc_mul(jb.wi[0], jb.wi[3]), nc_mul(jb.wi[2], jb.wi[1]));
+    const double inv = 1.0 / det;
+    const double sc = (double)(1 << jb.search_level);
+    const double m00 = nc_mul(nc_mul(jb.wi[3], inv), sc), m11 = nc_mul(nc_mul(jb.wi[0], inv), sc);
+    const double m10 = nc_mul(nc_mul(-jb.wi[2], inv), sc), m01 = nc_mul(nc_mul(-jb.wi[1], inv), sc);
+    // CVD::transform(in, out, M, inOrig = vec(irCenter), outOrig = (4,4))
+    const int w = 8, h = 8;
+    const double ax = m00, ay = m10;   // across = M.T()[0]
+    const double dx = m01, dy = m11;   // down   = M.T()[1]
+    const double p0x = nc_sub((double)jb.cx, nc_add(nc_mul(m00, 4.0), nc_mul(m01, 4.0)));
+    const double p0y = nc_sub((double)jb.cy, nc_add(nc_mul(m10, 4.0), nc_mul(m11, 4.0)));
+    double min_x = p0x, min_y = p0y, max_x = p0x, max_y = p0y;
+    if (ax < 0) min_x = nc_add(min_x, nc_mul(w, ax)); else max_x = nc_add(max_x, nc_mul(w, ax));
+    if (dx < 0) min_x = nc_add(min_x, nc_mul(h, dx)); else max_x = nc_add(max_x, nc_mul(h, dx));
+    if (ay < 0) min_y = nc_add(min_y, nc_mul(w, ay)); else max_y = nc_add(max_y, nc_mul(w, ay));
+    if (dy < 0) min_y = nc_add(min_y, nc_mul(h, dy)); else max_y = nc_add(max_y, nc_mul(h, dy));
+    const double crx = nc_sub(dx, nc_mul(w, ax)), cry = nc_sub(dy, nc_mul(w, ay));   // carriage_return
+    const bool all_inside = min_x >= 0 && min_y >= 0 && max_x < jb.w - 1 && max_y < jb.h - 1;
+    // replay the walk up to my pixel
+    const int i = lane >> 3, j = lane & 7;
+    double px = p0x, py = p0y;
+    for (int rr = 0; rr < 7; rr++)
+        if (rr < i) {
+#pragma unroll
+            for (int cc = 0; cc < 8; cc++) {
+                px = nc_add(px, ax);
+                py = nc_add(py, ay);
+            }
+            px = nc_add(px, crx);
+            py = nc_add(py, cry);
+        }
+    for (int cc = 0; cc < 7; cc++)
+        if (cc < j) {
+            px = nc_add(px, ax);
+            py = nc_add(py, ay);
+        }
+    int v = 0, outside = 0;
+    if (all_inside || (0 <= px && 0 <= py && px < (double)(jb.w - 1) && py < (double)(jb.h - 1))) {
+        // CVD::sample
+        const int lx = (int)px, ly = (int)py;
+        const double x = nc_sub(px, (double)lx), y = nc_sub(py, (double)ly);
+        const uint8_t* row0 = jb.im + (size_t)ly * jb.w + lx;
+        const double a = row0[0], b = row0[1], c = row0[jb.w], d = row0[jb.w + 1];
+        const double omx = nc_sub(1.0, x), omy = nc_sub(1.0, y);
+        const double top = nc_add(nc_mul(omx, a), nc_mul(x, b));
+        const double bot = nc_add(nc_mul(omx, c), nc_mul(x, d));
+        const double val = nc_add(nc_mul(omy, top), nc_mul(y, bot));
+        v = (int)(unsigned char)val;   // scalar_convert<byte, byte, double>: static_cast
+    } else {
+        outside = 1;   // defaultValue = byte()
+    }
+    tmpl[(size_t)q * 64 + lane] = (uint8_t)v;
+    const int n_out = wave_sum_i32(outside), s1 = wave_sum_i32(v), s2 = wave_sum_i32(v * v);
+    if (lane == 0) {
+        r.n_outside = n_out;
+        r.bad = n_out != 0;
+        r.sum = s1;      // MakeTemplateSums src/PatchFinder.cc:326-... : sum and sum of squares of all 64 pixels
+        r.sum_sq = s2;
+        r.m2[0] = m00, r.m2[1] = m01, r.m2[2] = m10, r.m2[3] = m11;
+        res[q] = r;
+    }
 }
 
 extern "C" {
@@ -314,6 +433,46 @@ int ptam_zmssd_at_points(ptam_ctx* ctx, const ptam_kf* kf, int level, int n, con
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(ssd_out, d_o, bo, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PTAM_OK;
+}
+
+int ptam_make_templates_batch(ptam_ctx* ctx, int n, const ptam_template_query* queries, uint8_t* templates_out,
+                              ptam_template_result* results) {
+    ARG_TRY(ctx && n >= 0);
+    if (n == 0) return PTAM_OK;
+    ARG_TRY(queries && templates_out && results);
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<TemplateJob> jobs((size_t)n);
+    for (int i = 0; i < n; i++) {
+        const ptam_template_query& q = queries[i];
+        TemplateJob& j = jobs[(size_t)i];
+        j.im = nullptr;
+        j.w = j.h = 0;
+        j.search_level = q.search_level;
+        j.cx = q.center_x;
+        j.cy = q.center_y;
+        for (int k = 0; k < 4; k++) j.wi[k] = q.warp_inverse[k];
+        if (q.search_level >= 0) {
+            ARG_TRY(q.src_kf && q.src_level >= 0 && q.src_level < PTAM_LEVELS && q.search_level < PTAM_LEVELS);
+            ARG_TRY(q.src_kf->device == ctx->device);
+            j.im = q.src_kf->L.im[q.src_level];
+            j.w = q.src_kf->L.w[q.src_level];
+            j.h = q.src_kf->L.h[q.src_level];
+        }
+    }
+    const size_t bj = (size_t)n * sizeof(TemplateJob), bt = (size_t)n * 64, br = (size_t)n * sizeof(ptam_template_result);
+    void* s;
+    int rc = ctx_scratch(ctx, bj + br + bt, &s);
+    if (rc) return rc;
+    TemplateJob* d_j = (TemplateJob*)s;
+    ptam_template_result* d_r = (ptam_template_result*)((char*)s + bj);
+    uint8_t* d_t = (uint8_t*)s + bj + br;
+    HIP_TRY(hipMemcpyAsync(d_j, jobs.data(), bj, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(make_templates_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, n, (const TemplateJob*)d_j, d_t, d_r);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(templates_out, d_t, bt, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(results, d_r, br, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // (jobs[] is pageable: the H2D copy above has been staged by now)
     return PTAM_OK;
 }
 

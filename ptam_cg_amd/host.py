@@ -26,6 +26,9 @@ POSE_UPDATE_MEAS_DT = np.dtype([("found", "<f8", (2,)), ("image", "<f8", (2,)), 
                                 ("jac", "<f8", (12,))])
 SUBPIX_QUERY_DT = np.dtype([("coarse_pos", "<f8", (2,)), ("level", "<i4"), ("max_its", "<i4")])
 SUBPIX_RESULT_DT = np.dtype([("converged", "<i4"), ("iterations", "<i4"), ("pos", "<f8", (2,)), ("mean_diff", "<f8")])
+TEMPLATE_QUERY_DT = np.dtype([("src_kf", "<u8"), ("src_level", "<i4"), ("search_level", "<i4"), ("center_x", "<i4"),
+                              ("center_y", "<i4"), ("warp_inverse", "<f8", (4,))])
+TEMPLATE_RESULT_DT = np.dtype([("bad", "<i4"), ("n_outside", "<i4"), ("sum", "<i4"), ("sum_sq", "<i4"), ("m2", "<f8", (4,))])
 PVS_POINT_DT = np.dtype([("world", "<f8", (3,)), ("pixel_right_w", "<f8", (3,)), ("pixel_down_w", "<f8", (3,))])
 PVS_RESULT_DT = np.dtype([("proj", PROJECTION_DT), ("warp_inverse", "<f8", (4,)), ("level", "<i4"), ("pad_", "<i4")])
 BA_TRIAL_DT = np.dtype([("lambda", "<f8"), ("sigma_sq", "<f8"), ("err_old", "<f8"), ("err_new", "<f8"),
@@ -223,6 +226,23 @@ class PatchFinder:
         res = np.zeros(n, dtype=SUBPIX_RESULT_DT)
         self.ctx._check(self.lib.subpix_batch(self.ctx.h, kf.h, n, _ptr(q), _ptr(templates), _ptr(res)), "subpix_batch")
         return res
+
+    def MakeTemplateCoarseCont(self, src_kfs, src_levels, centers, search_levels, warp_inverses):
+        """PatchFinder::MakeTemplateCoarseCont for a batch (src/PatchFinder.cc:98-127): `src_kfs` is one KeyFrame or a
+        sequence of them (MapPoint::pPatchSourceKF).  Returns (templates uint8 [n,64], results).  The reference's
+        "same point, warp moved < 0.07" reuse test is the caller's (it needs the previous call's state)."""
+        n = len(src_levels)
+        q = np.zeros(n, dtype=TEMPLATE_QUERY_DT)
+        kfs = [src_kfs] * n if isinstance(src_kfs, KeyFrame) else list(src_kfs)
+        q["src_kf"] = [k.h.value if hasattr(k.h, "value") else int(k.h) for k in kfs]
+        q["src_level"], q["search_level"] = src_levels, search_levels
+        c = np.asarray(centers, dtype=np.int32).reshape(n, 2)
+        q["center_x"], q["center_y"] = c[:, 0], c[:, 1]
+        q["warp_inverse"] = np.asarray(warp_inverses, dtype=np.float64).reshape(n, 4)
+        tm = np.zeros((n, 64), dtype=np.uint8)
+        res = np.zeros(n, dtype=TEMPLATE_RESULT_DT)
+        self.ctx._check(self.lib.make_templates_batch(self.ctx.h, n, _ptr(q), _ptr(tm), _ptr(res)), "make_templates_batch")
+        return tm, res
 
     def ZMSSDAtPoint(self, kf, level, points, template):
         points = np.ascontiguousarray(points, dtype=np.int32).reshape(-1, 2)

@@ -196,6 +196,36 @@ def make_pvs_case(n=4000, seed=0x5EED0007, camera=DEFAULT_CAMERA, size=(640, 480
     return {"world": world, "pixel_right_w": right, "pixel_down_w": down, "pose": cur_pose}
 
 
+def make_template_cases(size, n=600, seed=0x5EED0008):
+    """Inputs of PatchFinder::MakeTemplateCoarseCont against a keyframe of level-0 size `size` (w, h): source level
+    (50/25/15/10 mix), patch centre at that level (mostly interior, some hugging the border so that the walk
+    leaves the image), search level, and warp-inverse matrices like CalcSearchLevelAndWarpMatrix produces them
+    (rotation x anisotropic scale with determinant in the accepted band 0.25..3 after the level shift).
+    Entry 0 is a skipped query (search level -1), entry 1 sits in the corner."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    src_level = rng.choice(4, size=n, p=LEVEL_MIX).astype(np.int32)
+    search_level = rng.integers(0, 4, n).astype(np.int32)
+    w = (size[0] >> src_level).astype(np.int64)
+    h = (size[1] >> src_level).astype(np.int64)
+    cx = rng.integers(0, w)
+    cy = rng.integers(0, h)
+    inner = rng.random(n) < 0.8
+    cx = np.where(inner, np.clip(cx, np.minimum(14, w // 2), np.maximum(w - 15, w // 2)), cx)
+    cy = np.where(inner, np.clip(cy, np.minimum(14, h // 2), np.maximum(h - 15, h // 2)), cy)
+    ang = rng.uniform(-np.pi, np.pi, n)
+    det_at_level = rng.uniform(0.3, 2.8, n)                # dDet after the *0.25 steps
+    det = det_at_level * 4.0 ** search_level
+    aniso = rng.uniform(0.7, 1.4, n)
+    sx, sy = np.sqrt(det) * aniso, np.sqrt(det) / aniso
+    c, s_ = np.cos(ang), np.sin(ang)
+    shear = rng.normal(0, 0.1, n)
+    wi = np.stack([c * sx, -s_ * sy + shear * sx, s_ * sx, c * sy], axis=1)
+    search_level[0] = -1
+    cx[1], cy[1], src_level[1] = 1, 1, 0
+    return {"src_level": src_level, "search_level": search_level,
+            "center": np.stack([cx, cy], axis=1).astype(np.int32), "warp_inverse": wi}
+
+
 # ---------------------------------------------------------------------------------------------
 # bundle problems
 # ---------------------------------------------------------------------------------------------

@@ -55,6 +55,20 @@ def main():
                         n_scored=np.array([r["n_scored"] for r in res], np.int32),
                         pos=np.array([r["pos"] for r in res], np.float64))
     print("patch found", sum(r["found"] for r in res), "of", len(res))
+    # --- warped search templates (MakeTemplateCoarseCont) out of frame A ---
+    tc = synth.make_template_cases((a.shape[1], a.shape[0]), n=300)
+    tm, bad, nout, tsum, tsq, m2 = [], [], [], [], [], []
+    for i in range(300):
+        if tc["search_level"][i] < 0:
+            t_, r_ = np.zeros(64, np.uint8), dict(bad=1, n_outside=0, sum=0, sum_sq=0, m2=np.zeros(4))
+        else:
+            t_, r_ = npo.make_template_coarse_cont(la[int(tc["src_level"][i])]["im"], int(tc["center"][i][0]), int(tc["center"][i][1]),
+                                                    int(tc["search_level"][i]), tc["warp_inverse"][i])
+        tm.append(t_); bad.append(r_["bad"]); nout.append(r_["n_outside"]); tsum.append(r_["sum"]); tsq.append(r_["sum_sq"]); m2.append(r_["m2"])
+    np.savez_compressed(os.path.join(OUT, "template_cont_160x128.npz"), im=a, templates=np.array(tm, np.uint8),
+                        bad=np.array(bad, np.int32), n_outside=np.array(nout, np.int32), sum=np.array(tsum, np.int32),
+                        sum_sq=np.array(tsq, np.int32), m2=np.array(m2), **tc)
+    print("templates with pixels outside", int(np.count_nonzero(np.array(nout))), "of 300")
     # --- sub-pixel refinement of the found patches ---
     ok = np.flatnonzero([r["found"] for r in res])
     sp = [npo.subpix(lb, res[i]["pos"], int(q[i]["level"]), t[i], 8) for i in ok]

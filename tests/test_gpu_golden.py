@@ -29,6 +29,10 @@ def test_subpix(hip):
     G.check_subpix(hip)
 
 
+def test_template_cont(hip):
+    G.check_template_cont(hip)
+
+
 def test_pvs(hip):
     G.check_pvs(hip)
 

@@ -243,6 +243,31 @@ def test_subpix_matches_oracle(hip, oracle):
     assert so["converged"].mean() > 0.8
 
 
+def test_make_template_coarse_cont_bit_exact(hip, oracle):
+    """MakeTemplateCoarseCont: warped template bytes, outside counts, sums and the warp matrix, full-size frame,
+    templates then fed to the coarse search on both sides"""
+    a, b = synth.make_frame_pair()
+    tc = synth.make_template_cases((a.shape[1], a.shape[0]), n=2000)
+    out = {}
+    for name, lib in (("hip", hip), ("oracle", oracle)):
+        ctx = host.Context(lib=lib)
+        kfa, kfb = host.KeyFrame(ctx).MakeKeyFrame_Lite(a), host.KeyFrame(ctx).MakeKeyFrame_Lite(b)
+        pf = host.PatchFinder(ctx)
+        tm, r = pf.MakeTemplateCoarseCont(kfa, tc["src_level"], tc["center"], tc["search_level"], tc["warp_inverse"])
+        q = np.zeros(len(tm), dtype=host.PATCH_QUERY_DT)
+        lvl0 = tc["center"].astype(np.int64) << tc["src_level"][:, None]
+        q["x"], q["y"], q["range"] = lvl0[:, 0] + 3, lvl0[:, 1] - 2, 12
+        q["level"] = np.where(r["bad"] != 0, -1, tc["search_level"])
+        out[name] = (tm, r, pf.FindPatchCoarse(kfb, q, tm))
+    (th, rh, fh), (to, ro, fo) = out["hip"], out["oracle"]
+    assert np.array_equal(th, to)
+    for f in ("bad", "n_outside", "sum", "sum_sq", "m2"):
+        assert np.array_equal(rh[f], ro[f]), f
+    for f in ("found", "best_ssd", "best_x", "best_y", "n_scored"):
+        assert np.array_equal(fh[f], fo[f]), f
+    assert 0 < np.count_nonzero(ro["n_outside"]) < len(to) // 2 and ro["bad"][0] == 1
+
+
 def test_track_pvs_matches_oracle(hip, oracle):
     pv = synth.make_pvs_case()
     rh, ch = host.Context(lib=hip).track_pvs(pv["world"], pv["pixel_right_w"], pv["pixel_down_w"], pv["pose"])

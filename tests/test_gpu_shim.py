@@ -49,6 +49,16 @@ def test_shim_demo_matches_oracle(oracle, tmp_path):
     # patch: template taken at the corner itself -> found, ZMSSD 0 at that corner
     p = next(x for x in lines if x[0] == "PATCH")
     assert int(p[3]) == 1 and int(p[6]) == 0
+    # warped template: identity warp = the raw window (ZMSSD 0 at the corner), reused for the nearby warp, and the
+    # rotated warp gives exactly what the oracle's template scores at that corner
+    wline = next(x for x in lines if x[0] == "WARP")
+    cx, cy, z0, z1, z2, bad = [int(v) for v in wline[1:]]
+    assert z0 == 0 and z1 == 0 and bad == 0
+    octx = host.Context(lib=oracle, size=(im.shape[1], im.shape[0]))
+    okf = host.KeyFrame(octx).MakeKeyFrame_Lite(im)
+    opf = host.PatchFinder(octx)
+    tm, tr = opf.MakeTemplateCoarseCont(okf, [0], [[cx, cy]], [0], [[0.8, -0.6, 0.6, 0.8]])
+    assert tr["bad"][0] == 0 and z2 == int(opf.ZMSSDAtPoint(okf, 0, [[cx, cy]], tm[0])[0]) and z2 > 0
     # bundle: replicate the toy problem through the oracle
     ctx = host.Context(lib=oracle)
     ba = host.Bundle(ctx)

@@ -27,6 +27,10 @@ def test_subpix(oracle):
     G.check_subpix(oracle)
 
 
+def test_template_cont(oracle):
+    G.check_template_cont(oracle)
+
+
 def test_pvs(oracle):
     G.check_pvs(oracle)
 
