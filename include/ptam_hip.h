@@ -183,6 +183,35 @@ typedef struct {
 int ptam_make_templates_batch(ptam_ctx* ctx, int n, const ptam_template_query* queries, uint8_t* templates_out,
                               ptam_template_result* results);
 
+/* ---- MapMaker::AddPointEpipolar: the corner scan (src/MapMaker.cc:598-637)   --------------
+ * The line geometry (:541-596) stays with the caller — it is per-candidate scalar code on poses and depth
+ * statistics; what moves to the device is the O(candidates x corners) part: MakeTemplateCoarseNoWarp of the
+ * candidate in the source keyframe (:599, src/PatchFinder.cc:137-148), the in-plane corner table of the target
+ * level (:604-614), the band / segment test of every target corner (:620-630) and ZMSSDAtPoint of the survivors
+ * (:631-635), first strict minimum in corner order. */
+/* Level::vImplaneCorners: UnProject(ir(LevelZeroPos(corner, level))) of every FAST corner of the level, built once
+ * per (keyframe, level) and cached on the device (bImplaneCornersCached).  out_xy (nullable): room for cap corners,
+ * 2 doubles each; n_out (nullable): the corner count. */
+int ptam_kf_implane_corners(ptam_ctx* ctx, ptam_kf* kf, int level, double* out_xy, int cap, int* n_out);
+typedef struct {
+    int32_t level_x, level_y;   /* candidate.irLevelPos in the SOURCE keyframe, level pixels */
+    double normal[2];           /* v2Normal */
+    double norm_dist;           /* dNormDist */
+    double along[2];            /* v2AlongProjectedLine */
+    double min_len, max_len;    /* dMinLen, dMaxLen (after the +-2.0 clamps) */
+    double max_dist_sq;         /* dMaxDistSq = (OnePixelDist() * (4 + nLevelScale))^2 */
+} ptam_epipolar_query;
+typedef struct {
+    int32_t best;               /* nBest: index into the target level's vCorners, -1 = none */
+    int32_t best_zmssd;         /* nBestZMSSD (PTAM_MAX_SSD + 1 when none) */
+    int32_t n_scored;           /* corners that reached ZMSSDAtPoint */
+    int32_t template_bad;       /* Finder.TemplateBad() after MakeTemplateCoarseNoWarp */
+} ptam_epipolar_result;
+int ptam_epipolar_search_batch(ptam_ctx* ctx, const ptam_kf* src, ptam_kf* target, int level, int n,
+                               const ptam_epipolar_query* queries, ptam_epipolar_result* results);
+/* ATANCamera::OnePixelDist() (src/ATANCamera.cc:69-75) for max_dist_sq */
+int ptam_ctx_one_pixel_dist(ptam_ctx* ctx, double* out);
+
 /* ---- TrackerData::Project / ProjectAndDerivs + ATANCamera (include/Tracker.h:70-94,
  *      src/ATANCamera.cc:109-121, 179-209) ------------------------------------------------------- */
 typedef struct {

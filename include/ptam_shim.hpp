@@ -204,6 +204,16 @@ public:
         check(ptam_find_patch_coarse_batch(c.handle(), kf.handle(), (int)q.size(), q.data(), templates64.data(), out.data()),
               "ptam_find_patch_coarse_batch");
     }
+    // the corner scan of MapMaker::AddPointEpipolar (src/MapMaker.cc:598-637) for every candidate of a source
+    // keyframe level at once: MakeTemplateCoarseNoWarp + band / segment test over kTarget's in-plane corners +
+    // ZMSSDAtPoint; result[i].best indexes kTarget.aLevels(nLevel).vCorners.  The caller keeps the line geometry
+    // (:541-596) and fills one ptam_epipolar_query per candidate; max_dist_sq = (OnePixelDist * (4 + nLevelScale))^2.
+    static void EpipolarSearchBatch(Context& c, KeyFrame& kSrc, KeyFrame& kTarget, int nLevel,
+                                    const std::vector<ptam_epipolar_query>& q, std::vector<ptam_epipolar_result>& out) {
+        out.resize(q.size());
+        check(ptam_epipolar_search_batch(c.handle(), kSrc.handle(), kTarget.handle(), nLevel, (int)q.size(), q.data(), out.data()),
+              "ptam_epipolar_search_batch");
+    }
     // int ZMSSDAtPoint(CVD::BasicImage<CVD::byte>&, const CVD::ImageRef&)   include/PatchFinder.h:79
     int ZMSSDAtPoint(KeyFrame& kf, int nLevel, ImageRef ir) {
         ptam_int2 p{ir.x, ir.y};

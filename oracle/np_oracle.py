@@ -123,6 +123,61 @@ def zmssd(im, x, y, tmpl):
     return trunc_div(2 * SA * SB - SA * SA - SB * SB, 64) + int((I * I).sum()) + int((T * T).sum()) - 2 * int((I * T).sum())
 
 
+def unproject(cam, u, v):
+    """ATANCamera::UnProject (src/ATANCamera.cc:125-140) with math.* scalars; cam: Camera below (focal, centre, w, k = 2 tan(w/2))"""
+    import math
+    dx = (u - cam.centre[0]) * (1.0 / cam.focal[0])
+    dy = (v - cam.centre[1]) * (1.0 / cam.focal[1])
+    dr = math.sqrt(dx * dx + dy * dy)
+    rr = dr if cam.w == 0.0 else math.tan(dr * cam.w) * (1.0 / cam.k)
+    f = rr / dr if dr > 0.01 else 1.0
+    return f * dx, f * dy
+
+
+def one_pixel_dist(cam):
+    """mdOnePixelDist (src/ATANCamera.cc:69-75)"""
+    import math
+    a = unproject(cam, cam.size[0] / 2, cam.size[1] / 2)
+    b = unproject(cam, cam.size[0] / 2 + 1, cam.size[1] / 2 + 1)
+    return math.sqrt((a[0] - b[0]) ** 2 + (a[1] - b[1]) ** 2) / math.sqrt(2.0)
+
+
+def implane_corners(cam, corners, level):
+    """Level::vImplaneCorners (src/MapMaker.cc:605-614)"""
+    scale = 1 << level
+    out = np.zeros((len(corners), 2))
+    for i, (x, y) in enumerate(corners):
+        out[i] = unproject(cam, float(int((x + 0.5) * scale - 0.5)), float(int((y + 0.5) * scale - 0.5)))
+    return out
+
+
+def epipolar_search(src_level, tgt_level, ip, q):
+    """corner scan of MapMaker::AddPointEpipolar (src/MapMaker.cc:598-637).  src_level / tgt_level: dict(im, corners);
+    ip: in-plane corners of the target level; q: one query record.  -> dict(best, best_zmssd, n_scored, template_bad)"""
+    im = src_level["im"]
+    h, w = im.shape
+    x0, y0 = int(q["level_x"]), int(q["level_y"])
+    if not (x0 >= 5 and y0 >= 5 and x0 < w - 5 and y0 < h - 5):
+        return dict(best=-1, best_zmssd=MAX_SSD + 1, n_scored=0, template_bad=1)
+    tmpl = im[y0 - 4:y0 + 4, x0 - 4:x0 + 4].reshape(64)
+    best, bz, ns = -1, MAX_SSD + 1, 0
+    nx, ny, ax, ay = float(q["normal"][0]), float(q["normal"][1]), float(q["along"][0]), float(q["along"][1])
+    nd, lo, hi, md = float(q["norm_dist"]), float(q["min_len"]), float(q["max_len"]), float(q["max_dist_sq"])
+    for i, (cx, cy) in enumerate(tgt_level["corners"]):
+        vx, vy = float(ip[i][0]), float(ip[i][1])
+        dd = nd - (vx * nx + vy * ny)
+        if dd * dd > md:
+            continue
+        al = vx * ax + vy * ay
+        if al < lo or al > hi:
+            continue
+        z = zmssd(tgt_level["im"], int(cx), int(cy), tmpl)
+        ns += 1
+        if z < bz:
+            best, bz = i, z
+    return dict(best=best, best_zmssd=bz, n_scored=ns, template_bad=0)
+
+
 def make_template_coarse_cont(im, cx, cy, search_level, warp_inverse):
     """PatchFinder::MakeTemplateCoarseCont (src/PatchFinder.cc:98-127) without the host-side reuse test:
     CVD::transform of level image `im` (2-D uint8) with M = M2Inverse(mm2WarpInverse) * LevelScale(search_level),

@@ -287,6 +287,25 @@ struct ATANCamera {
         if (w == 0.0) return r;
         return std::tan(r * w) * one_over_two_tan;
     }
+    // ATANCamera::UnProject src/ATANCamera.cc:125-140 (mvInvFocal = 1 / mvFocal, :38-39)
+    void UnProject(const double im[2], double cam[2]) const {
+        const double inv_focal[2] = {1.0 / focal[0], 1.0 / focal[1]};
+        const double dc[2] = {(im[0] - centre[0]) * inv_focal[0], (im[1] - centre[1]) * inv_focal[1]};
+        const double dist_r = std::sqrt(dc[0] * dc[0] + dc[1] * dc[1]);
+        const double r = invrtrans(dist_r);
+        const double factor = dist_r > 0.01 ? r / dist_r : 1.0;
+        cam[0] = factor * dc[0];
+        cam[1] = factor * dc[1];
+    }
+    // mdOnePixelDist src/ATANCamera.cc:69-75
+    double OnePixelDist() const {
+        const double c0[2] = {size[0] / 2, size[1] / 2}, c1[2] = {size[0] / 2 + 1, size[1] / 2 + 1};
+        double a[2], b[2];
+        UnProject(c0, a);
+        UnProject(c1, b);
+        const double d[2] = {a[0] - b[0], a[1] - b[1]};
+        return std::sqrt(d[0] * d[0] + d[1] * d[1]) / std::sqrt(2.0);
+    }
     void Project(const double cam[2], double im[2]) {
         last_cam[0] = cam[0];
         last_cam[1] = cam[1];
@@ -1213,6 +1232,49 @@ struct OCtx {
 }   // namespace
 
 // ================================================================================================
+// MapMaker::AddPointEpipolar, lines 598-637: template without warp, in-plane corner table, band / segment test,
+// ZMSSD of the survivors, first strict minimum in corner order.
+static void implane_corners(const ATANCamera& cam, const Level& L, int level, std::vector<double>& out) {
+    out.resize(L.corners.size() * 2);
+    const int scale = 1 << level;
+    for (size_t i = 0; i < L.corners.size(); i++) {
+        // imUnProj[ir(Level::LevelZeroPos(vIR[i], nLevel))]  :611-612 — ir() truncates
+        const double im[2] = {(double)(int)((L.corners[i].x + 0.5) * scale - 0.5), (double)(int)((L.corners[i].y + 0.5) * scale - 0.5)};
+        cam.UnProject(im, &out[2 * i]);
+    }
+}
+static void epipolar_search(const Level& src, const Level& tgt, const std::vector<double>& ip, const ptam_epipolar_query& q,
+                            ptam_epipolar_result& r) {
+    r.best = -1;
+    r.best_zmssd = PTAM_MAX_SSD + 1;
+    r.n_scored = 0;
+    r.template_bad = 0;
+    const int b = PTAM_PATCH / 2 + 1;   // MakeTemplateCoarseNoWarp src/PatchFinder.cc:141
+    if (!(q.level_x >= b && q.level_y >= b && q.level_x < src.w - b && q.level_y < src.h - b)) {
+        r.template_bad = 1;
+        return;
+    }
+    uint8_t tmpl[64];
+    for (int y = 0; y < 8; y++)
+        for (int x = 0; x < 8; x++) tmpl[y * 8 + x] = src.im[(size_t)(q.level_y - 4 + y) * src.w + q.level_x - 4 + x];
+    int tsum, tsumsq;
+    template_sums(tmpl, tsum, tsumsq);
+    for (size_t i = 0; i < tgt.corners.size(); i++) {
+        const double vx = ip[2 * i], vy = ip[2 * i + 1];
+        const double dd = q.norm_dist - (vx * q.normal[0] + vy * q.normal[1]);
+        if (dd * dd > q.max_dist_sq) continue;
+        const double al = vx * q.along[0] + vy * q.along[1];
+        if (al < q.min_len) continue;
+        if (al > q.max_len) continue;
+        const int z = zmssd_at_point(tgt, tgt.corners[i].x, tgt.corners[i].y, tmpl, tsum, tsumsq, PTAM_MAX_SSD);
+        r.n_scored++;
+        if (z < r.best_zmssd) {
+            r.best = (int)i;
+            r.best_zmssd = z;
+        }
+    }
+}
+
 // PatchFinder::MakeTemplateCoarseCont (src/PatchFinder.cc:98-127) minus the host-side reuse test:
 // m2 = M2Inverse(mm2WarpInverse) * LevelScale(mnSearchLevel) (include/Tools.h:54-65), CVD::transform of
 // the source level into the 8x8 template with inOrig = irCenter, outOrig = (4,4), then MakeTemplateSums.
@@ -1374,6 +1436,30 @@ int ptamo_kf_read_rest(ptamo_ctx*, const ptamo_kf* k, int l, ptam_int2* mc, doub
 int ptamo_find_patch_coarse_batch(ptamo_ctx*, const ptamo_kf* k, int n, const ptam_patch_query* q,
                                   const uint8_t* tmpl, ptam_patch_result* res) {
     for (int i = 0; i < n; i++) find_patch_coarse(k->kf, q[i], tmpl + (size_t)i * 64, res[i]);
+    return PTAM_OK;
+}
+int ptamo_ctx_one_pixel_dist(ptamo_ctx* c, double* out) {
+    *out = ATANCamera(c->c.cam).OnePixelDist();
+    return PTAM_OK;
+}
+int ptamo_kf_implane_corners(ptamo_ctx* c, ptamo_kf* k, int level, double* out_xy, int cap, int* n_out) {
+    if (!c || !k || level < 0 || level >= PTAM_LEVELS) return PTAM_E_ARG;
+    std::vector<double> ip;
+    implane_corners(ATANCamera(c->c.cam), k->kf.lev[level], level, ip);
+    const int nc = (int)(ip.size() / 2);
+    if (n_out) *n_out = nc;
+    if (out_xy) {
+        if (cap < nc) return PTAM_E_ARG;
+        std::memcpy(out_xy, ip.data(), ip.size() * 8);
+    }
+    return PTAM_OK;
+}
+int ptamo_epipolar_search_batch(ptamo_ctx* c, const ptamo_kf* src, ptamo_kf* tgt, int level, int n, const ptam_epipolar_query* q,
+                                ptam_epipolar_result* res) {
+    if (!c || !src || !tgt || level < 0 || level >= PTAM_LEVELS) return PTAM_E_ARG;
+    std::vector<double> ip;
+    implane_corners(ATANCamera(c->c.cam), tgt->kf.lev[level], level, ip);
+    for (int i = 0; i < n; i++) epipolar_search(src->kf.lev[level], tgt->kf.lev[level], ip, q[i], res[i]);
     return PTAM_OK;
 }
 int ptamo_make_templates_batch(ptamo_ctx*, int n, const ptam_template_query* q, uint8_t* tmpl, ptam_template_result* res) {

@@ -56,6 +56,15 @@ class TemplateResult(C.Structure):
     _fields_ = [("bad", C.c_int32), ("n_outside", C.c_int32), ("sum", C.c_int32), ("sum_sq", C.c_int32), ("m2", C.c_double * 4)]
 
 
+class EpipolarQuery(C.Structure):
+    _fields_ = [("level_x", C.c_int32), ("level_y", C.c_int32), ("normal", C.c_double * 2), ("norm_dist", C.c_double),
+                ("along", C.c_double * 2), ("min_len", C.c_double), ("max_len", C.c_double), ("max_dist_sq", C.c_double)]
+
+
+class EpipolarResult(C.Structure):
+    _fields_ = [("best", C.c_int32), ("best_zmssd", C.c_int32), ("n_scored", C.c_int32), ("template_bad", C.c_int32)]
+
+
 class PvsPoint(C.Structure):
     _fields_ = [("world", C.c_double * 3), ("pixel_right_w", C.c_double * 3), ("pixel_down_w", C.c_double * 3)]
 
@@ -122,6 +131,9 @@ PROTOTYPES = {
     "project_points": (_i, [_vp, _i, _vp, _pd, _vp]),
     "subpix_batch": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "make_templates_batch": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "kf_implane_corners": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
+    "epipolar_search_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "ctx_one_pixel_dist": (_i, [_vp, _pd]),
     "track_pvs": (_i, [_vp, _i, _vp, _pd, _vp, _vp]),
     "gn_opts_default": (None, [C.POINTER(GnOpts)]),
     "pose_gn": (_i, [_vp, _i, _vp, _vp, _pd, C.POINTER(GnOpts), _vp, _vp]),

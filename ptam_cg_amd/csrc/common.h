@@ -39,6 +39,8 @@ struct DevCam {
     double w, two_tan, w_inv, dist_enabled;
     double largest_radius, max_r;
     double width, height;
+    double inv_fx, inv_fy, one_over_two_tan;   // mvInvFocal, mdOneOver2Tan (UnProject)
+    double one_pixel_dist;                     // mdOnePixelDist
 };
 
 struct ptam_ctx {

@@ -67,6 +67,23 @@ static DevCam make_devcam(const ptam_cam_params& p) {
     const double r = std::sqrt(vx * vx + vy * vy);
     c.largest_radius = (c.w == 0.0) ? r : std::tan(r * c.w) * one_over_two_tan;   // invrtrans
     c.max_r = 1.5 * c.largest_radius;
+    c.inv_fx = 1.0 / c.fx;   // :38-39
+    c.inv_fy = 1.0 / c.fy;
+    c.one_over_two_tan = one_over_two_tan;
+    // mdOnePixelDist :69-75 — UnProject at the image centre and one pixel down-right of it
+    auto unproject = [&](double u, double v, double out[2]) {
+        const double dx = (u - c.cx) * c.inv_fx, dy = (v - c.cy) * c.inv_fy;
+        const double dr = std::sqrt(dx * dx + dy * dy);
+        const double rr = (c.w == 0.0) ? dr : std::tan(dr * c.w) * one_over_two_tan;
+        const double f = dr > 0.01 ? rr / dr : 1.0;
+        out[0] = f * dx;
+        out[1] = f * dy;
+    };
+    double a[2], b[2];
+    unproject(p.width / 2.0, p.height / 2.0, a);           // mvImageSize is a Vector<2> of doubles
+    unproject(p.width / 2.0 + 1, p.height / 2.0 + 1, b);
+    const double ddx = a[0] - b[0], ddy = a[1] - b[1];
+    c.one_pixel_dist = std::sqrt(ddx * ddx + ddy * ddy) / std::sqrt(2.0);
     return c;
 }
 
@@ -171,6 +188,12 @@ int ptam_ctx_camera_constants(ptam_ctx* ctx, double out[8]) {
     out[5] = ctx->cam.w_inv;
     out[6] = ctx->cam.largest_radius;
     out[7] = ctx->cam.max_r;
+    return PTAM_OK;
+}
+
+int ptam_ctx_one_pixel_dist(ptam_ctx* ctx, double* out) {
+    ARG_TRY(ctx && out);
+    *out = ctx->cam.one_pixel_dist;
     return PTAM_OK;
 }
 

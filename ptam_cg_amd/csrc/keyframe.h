@@ -31,6 +31,10 @@ struct ptam_kf {
     int n_max[PTAM_LEVELS];       // host copy, valid iff rest_valid
     int rest_valid;
     size_t off_rest_clear, bytes_rest_clear;   // score maps + maximal-corner masks: zeroed per call
+    // Level::vImplaneCorners (src/MapMaker.cc:605-614), built on first use by the epipolar search
+    double2* implane[PTAM_LEVELS];
+    int implane_cap[PTAM_LEVELS];
+    int implane_valid[PTAM_LEVELS];   // bImplaneCornersCached
 };
 
 int kf_fetch_counts(ptam_ctx* ctx, const ptam_kf* kf);

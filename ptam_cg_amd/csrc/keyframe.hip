@@ -363,6 +363,7 @@ static int kf_alloc(ptam_ctx* ctx, int w, int h, ptam_kf** out) {
 }
 
 static int kf_run(ptam_ctx* ctx, ptam_kf* kf, const uint8_t* d_src) {
+    for (int l = 0; l < PTAM_LEVELS; l++) kf->implane_valid[l] = 0;   // new corners: the in-plane cache is stale
     PyrArgs a;
     a.src = d_src;
     for (int l = 0; l < PTAM_LEVELS; l++) {
@@ -406,6 +407,8 @@ int ptam_kf_destroy(ptam_kf* kf) {
     hipSetDevice(kf->device);
     hipDeviceSynchronize();
     hipFree(kf->base);
+    for (int l = 0; l < PTAM_LEVELS; l++)
+        if (kf->implane[l]) hipFree(kf->implane[l]);
     delete kf;
     return PTAM_OK;
 }

@@ -357,6 +357,89 @@ __global__ void __launch_bounds__(256) make_templates_kernel(int n, const Templa
     }
 }
 
+// =================================================================================================
+// AddPointEpipolar: in-plane corner table and the corner scan (src/MapMaker.cc:598-637)
+// =================================================================================================
+// ATANCamera::UnProject (src/ATANCamera.cc:125-140)
+__device__ __forceinline__ void cam_unproject(const DevCam& c, double u, double v, double& x, double& y) {
+    const double dx = (u - c.cx) * c.inv_fx, dy = (v - c.cy) * c.inv_fy;
+    const double dr = sqrt(dx * dx + dy * dy);
+    const double rr = (c.w == 0.0) ? dr : tan(dr * c.w) * c.one_over_two_tan;   // invrtrans include/ATANCamera.h:152-157
+    const double f = dr > 0.01 ? rr / dr : 1.0;
+    x = f * dx;
+    y = f * dy;
+}
+
+// vv2Corners.push_back(imUnProj[ir(Level::LevelZeroPos(vIR[i], nLevel))])  :611-612
+__global__ void __launch_bounds__(256) implane_corners_kernel(DevCam cam, KfLevels L, int lev, double2* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= L.ncorners[lev]) return;
+    const ptam_int2 c = L.corners[lev][i];
+    const int scale = 1 << lev;
+    const int u = (int)((c.x + 0.5) * scale - 0.5), v = (int)((c.y + 0.5) * scale - 0.5);   // ir(): truncation
+    double x, y;
+    cam_unproject(cam, (double)u, (double)v, x, y);
+    out[i] = make_double2(x, y);
+}
+
+// one wave per candidate: template = the 8x8 window of the source level (lane = pixel), then the target level's
+// corners 64 at a time through the band / segment test, the survivors scored in corner order
+__global__ void __launch_bounds__(256) epipolar_search_kernel(KfLevels S, KfLevels T, int lev, const double2* __restrict__ implane,
+                                                              int n, const ptam_epipolar_query* __restrict__ queries,
+                                                              ptam_epipolar_result* __restrict__ results) {
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= n) return;
+    const ptam_epipolar_query q = queries[qi];
+    ptam_epipolar_result res;
+    res.best = -1;
+    res.best_zmssd = PTAM_MAX_SSD + 1;
+    res.n_scored = 0;
+    res.template_bad = 0;
+    const int sw = S.w[lev], sh = S.h[lev];
+    // MakeTemplateCoarseNoWarp: in_image_with_border(irLevelPos, mnPatchSize / 2 + 1)
+    if (!(q.level_x >= 5 && q.level_y >= 5 && q.level_x < sw - 5 && q.level_y < sh - 5)) {
+        res.template_bad = 1;
+        if (lane == 0) results[qi] = res;
+        return;
+    }
+    const int Tp = S.im[lev][(size_t)(q.level_y - 4 + (lane >> 3)) * sw + (q.level_x - 4 + (lane & 7))];
+    const int tsum = wave_sum_i32(Tp), tsumsq = wave_sum_i32(Tp * Tp);
+    const int tw = T.w[lev], th = T.h[lev];
+    const uint8_t* im = T.im[lev];
+    const ptam_int2* corners = T.corners[lev];
+    const int nc = T.ncorners[lev];
+    int best = PTAM_MAX_SSD + 1, bi = -1, nsc = 0;
+    for (int base = 0; base < nc; base += 64) {
+        const int idx = base + lane;
+        bool pass = false;
+        ptam_int2 c = {0, 0};
+        if (idx < nc) {
+            const double2 v = implane[idx];
+            const double dd = q.norm_dist - (v.x * q.normal[0] + v.y * q.normal[1]);   // :623
+            const double al = v.x * q.along[0] + v.y * q.along[1];
+            pass = !(dd * dd > q.max_dist_sq) && !(al < q.min_len) && !(al > q.max_len);
+            c = corners[idx];
+        }
+        unsigned long long m = __ballot(pass);
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int cx = __shfl(c.x, b, 64), cy = __shfl(c.y, b, 64);
+            const int ssd = wave_zmssd(im, tw, th, cx, cy, Tp, tsum, tsumsq, lane);
+            nsc++;
+            if (ssd < best) {
+                best = ssd;
+                bi = base + b;
+            }
+        }
+    }
+    res.best = bi;
+    res.best_zmssd = best;
+    res.n_scored = nsc;
+    if (lane == 0) results[qi] = res;
+}
+
 extern "C" {
 
 int ptam_subpix_batch(ptam_ctx* ctx, const ptam_kf* kf, int n, const ptam_subpix_query* queries, const uint8_t* templates,
@@ -473,6 +556,67 @@ int ptam_make_templates_batch(ptam_ctx* ctx, int n, const ptam_template_query* q
     HIP_TRY(hipMemcpyAsync(templates_out, d_t, bt, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(results, d_r, br, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));   // (jobs[] is pageable: the H2D copy above has been staged by now)
+    return PTAM_OK;
+}
+
+static int kf_build_implane(ptam_ctx* ctx, ptam_kf* kf, int level) {
+    int rc = kf_fetch_counts(ctx, kf);
+    if (rc) return rc;
+    const int nc = kf->n_corners[level];
+    if (kf->implane_valid[level]) return PTAM_OK;
+    if (nc > kf->implane_cap[level]) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (kf->implane[level]) HIP_TRY(hipFree(kf->implane[level]));
+        kf->implane[level] = nullptr;
+        kf->implane_cap[level] = 0;
+        const int cap = nc + nc / 4 + 64;
+        HIP_TRY(hipMalloc((void**)&kf->implane[level], (size_t)cap * sizeof(double2)));
+        kf->implane_cap[level] = cap;
+    }
+    if (nc > 0)
+        hipLaunchKernelGGL(implane_corners_kernel, dim3((nc + 255) / 256), dim3(256), 0, ctx->stream, ctx->cam, kf->L, level,
+                           kf->implane[level]);
+    HIP_TRY(hipGetLastError());
+    kf->implane_valid[level] = 1;
+    return PTAM_OK;
+}
+
+int ptam_kf_implane_corners(ptam_ctx* ctx, ptam_kf* kf, int level, double* out_xy, int cap, int* n_out) {
+    ARG_TRY(ctx && kf && level >= 0 && level < PTAM_LEVELS && cap >= 0);
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = kf_build_implane(ctx, kf, level);
+    if (rc) return rc;
+    const int nc = kf->n_corners[level];
+    if (n_out) *n_out = nc;
+    if (out_xy) {
+        ARG_TRY(cap >= nc);
+        if (nc > 0) HIP_TRY(hipMemcpyAsync(out_xy, kf->implane[level], (size_t)nc * 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return PTAM_OK;
+}
+
+int ptam_epipolar_search_batch(ptam_ctx* ctx, const ptam_kf* src, ptam_kf* target, int level, int n,
+                               const ptam_epipolar_query* queries, ptam_epipolar_result* results) {
+    ARG_TRY(ctx && src && target && level >= 0 && level < PTAM_LEVELS && n >= 0);
+    if (n == 0) return PTAM_OK;
+    ARG_TRY(queries && results);
+    ARG_TRY(src->device == ctx->device && target->device == ctx->device);
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = kf_build_implane(ctx, target, level);
+    if (rc) return rc;
+    const size_t bq = (size_t)n * sizeof(ptam_epipolar_query), br = (size_t)n * sizeof(ptam_epipolar_result);
+    void* s;
+    rc = ctx_scratch(ctx, bq + br, &s);
+    if (rc) return rc;
+    ptam_epipolar_query* d_q = (ptam_epipolar_query*)s;
+    ptam_epipolar_result* d_r = (ptam_epipolar_result*)((char*)s + bq);
+    HIP_TRY(hipMemcpyAsync(d_q, queries, bq, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(epipolar_search_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, src->L, target->L, level,
+                       (const double2*)target->implane[level], n, (const ptam_epipolar_query*)d_q, d_r);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(results, d_r, br, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PTAM_OK;
 }
 

@@ -28,6 +28,9 @@ SUBPIX_QUERY_DT = np.dtype([("coarse_pos", "<f8", (2,)), ("level", "<i4"), ("max
 SUBPIX_RESULT_DT = np.dtype([("converged", "<i4"), ("iterations", "<i4"), ("pos", "<f8", (2,)), ("mean_diff", "<f8")])
 TEMPLATE_QUERY_DT = np.dtype([("src_kf", "<u8"), ("src_level", "<i4"), ("search_level", "<i4"), ("center_x", "<i4"),
                               ("center_y", "<i4"), ("warp_inverse", "<f8", (4,))])
+EPIPOLAR_QUERY_DT = np.dtype([("level_x", "<i4"), ("level_y", "<i4"), ("normal", "<f8", (2,)), ("norm_dist", "<f8"),
+                              ("along", "<f8", (2,)), ("min_len", "<f8"), ("max_len", "<f8"), ("max_dist_sq", "<f8")])
+EPIPOLAR_RESULT_DT = np.dtype([("best", "<i4"), ("best_zmssd", "<i4"), ("n_scored", "<i4"), ("template_bad", "<i4")])
 TEMPLATE_RESULT_DT = np.dtype([("bad", "<i4"), ("n_outside", "<i4"), ("sum", "<i4"), ("sum_sq", "<i4"), ("m2", "<f8", (4,))])
 PVS_POINT_DT = np.dtype([("world", "<f8", (3,)), ("pixel_right_w", "<f8", (3,)), ("pixel_down_w", "<f8", (3,))])
 PVS_RESULT_DT = np.dtype([("proj", PROJECTION_DT), ("warp_inverse", "<f8", (4,)), ("level", "<i4"), ("pad_", "<i4")])
@@ -82,6 +85,12 @@ class Context:
         self._check(self.lib.ctx_camera_constants(self.h, _pd(out)), "camera_constants")
         return dict(zip(["focal_x", "focal_y", "centre_x", "centre_y", "two_tan", "w_inv",
                          "largest_radius", "max_r"], out))
+
+    def one_pixel_dist(self):
+        """ATANCamera::OnePixelDist() (src/ATANCamera.cc:69-75)"""
+        out = np.zeros(1)
+        self._check(self.lib.ctx_one_pixel_dist(self.h, _pd(out)), "one_pixel_dist")
+        return float(out[0])
 
     def close(self):
         if getattr(self, "h", None):
@@ -197,6 +206,14 @@ class KeyFrame:
                         "kf_read_level")
         return {"im": im, "corners": corners, "rowlut": lut}
 
+    def implane_corners(self, l):
+        """Level::vImplaneCorners (src/MapMaker.cc:605-614): (n, 2) float64"""
+        n = C.c_int()
+        self.ctx._check(self.lib.kf_implane_corners(self.ctx.h, self.h, l, None, 0, C.byref(n)), "kf_implane_corners")
+        out = np.zeros((n.value, 2))
+        self.ctx._check(self.lib.kf_implane_corners(self.ctx.h, self.h, l, _ptr(out), n.value, None), "kf_implane_corners")
+        return out
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.kf_destroy(self.h)
@@ -243,6 +260,14 @@ class PatchFinder:
         res = np.zeros(n, dtype=TEMPLATE_RESULT_DT)
         self.ctx._check(self.lib.make_templates_batch(self.ctx.h, n, _ptr(q), _ptr(tm), _ptr(res)), "make_templates_batch")
         return tm, res
+
+    def EpipolarSearch(self, src_kf, target_kf, level, queries):
+        """the corner scan of MapMaker::AddPointEpipolar (src/MapMaker.cc:598-637) for a batch of candidates"""
+        q = np.ascontiguousarray(queries, dtype=EPIPOLAR_QUERY_DT)
+        res = np.zeros(len(q), dtype=EPIPOLAR_RESULT_DT)
+        self.ctx._check(self.lib.epipolar_search_batch(self.ctx.h, src_kf.h, target_kf.h, level, len(q), _ptr(q), _ptr(res)),
+                        "epipolar_search_batch")
+        return res
 
     def ZMSSDAtPoint(self, kf, level, points, template):
         points = np.ascontiguousarray(points, dtype=np.int32).reshape(-1, 2)

@@ -92,6 +92,16 @@ class AtanCam:
             f = np.where((r < 0.001) | (self.w == 0), 1.0, np.arctan(r * self.two_tan) / (self.w * np.where(r == 0, 1, r)))
         return self.centre + self.focal * (f[..., None] * xy), r
 
+    def unproject(self, im):
+        """ATANCamera::UnProject (src/ATANCamera.cc:125-140), vectorised"""
+        im = np.asarray(im, dtype=np.float64)
+        dc = (im - self.centre) * (1.0 / self.focal)
+        dr = np.hypot(dc[..., 0], dc[..., 1])
+        rr = np.tan(dr * self.w) / self.two_tan if self.w != 0 else dr
+        with np.errstate(divide="ignore", invalid="ignore"):
+            f = np.where(dr > 0.01, rr / np.where(dr == 0, 1, dr), 1.0)
+        return f[..., None] * dc
+
     def visible(self, pose, X):
         """TrackerData::Project visibility (include/Tracker.h:70-85) -> (mask, image coords)"""
         R, t = pose[:9].reshape(3, 3), pose[9:]
@@ -224,6 +234,36 @@ def make_template_cases(size, n=600, seed=0x5EED0008):
     cx[1], cy[1], src_level[1] = 1, 1, 0
     return {"src_level": src_level, "search_level": search_level,
             "center": np.stack([cx, cy], axis=1).astype(np.int32), "warp_inverse": wi}
+
+
+def make_epipolar_queries(cam, corners_a, level, one_pixel_dist, n=400, seed=0x5EED0009, shift=(3, -2)):
+    """Queries for the corner scan of MapMaker::AddPointEpipolar between the synthetic frame pair: candidates are
+    corners of frame A at `level`; the epipolar segment of each is a random line through (or, for a quarter of
+    them, a few pixels beside) the in-plane position of its true match in frame B, with a random extent.
+    `cam`: AtanCam-like with unproject(); corners_a: (m, 2) int32.  Entry 0 is a candidate in the border (bad
+    template), entry 1 has an empty segment."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    scale = 1 << level
+    idx = rng.integers(0, len(corners_a), n)
+    q = np.zeros(n, dtype=[("level_x", "<i4"), ("level_y", "<i4"), ("normal", "<f8", (2,)), ("norm_dist", "<f8"),
+                           ("along", "<f8", (2,)), ("min_len", "<f8"), ("max_len", "<f8"), ("max_dist_sq", "<f8")])
+    c = corners_a[idx].astype(np.float64)
+    lvl0 = (c + 0.5) * scale - 0.5 + np.asarray(shift, dtype=np.float64)
+    v = cam.unproject(lvl0)
+    ang = rng.uniform(0, np.pi, n)
+    along = np.stack([np.cos(ang), np.sin(ang)], axis=1)
+    normal = np.stack([along[:, 1], -along[:, 0]], axis=1)
+    off = np.where(rng.random(n) < 0.25, rng.normal(0, 6.0, n), rng.normal(0, 1.0, n)) * one_pixel_dist
+    a = (v * along).sum(1)
+    q["level_x"], q["level_y"] = corners_a[idx][:, 0], corners_a[idx][:, 1]
+    q["normal"], q["along"] = normal, along
+    q["norm_dist"] = (v * normal).sum(1) + off
+    q["min_len"] = a - rng.uniform(0.01, 0.3, n)
+    q["max_len"] = a + rng.uniform(0.01, 0.3, n)
+    q["max_dist_sq"] = (one_pixel_dist * (4.0 + scale)) ** 2
+    q["level_x"][0], q["level_y"][0] = 2, 3
+    q["min_len"][1], q["max_len"][1] = 5.0, 5.5
+    return q
 
 
 # ---------------------------------------------------------------------------------------------

@@ -69,6 +69,20 @@ def main():
                         bad=np.array(bad, np.int32), n_outside=np.array(nout, np.int32), sum=np.array(tsum, np.int32),
                         sum_sq=np.array(tsq, np.int32), m2=np.array(m2), **tc)
     print("templates with pixels outside", int(np.count_nonzero(np.array(nout))), "of 300")
+    # --- epipolar corner scan (MapMaker::AddPointEpipolar :598-637) between the pair, levels 0 and 2 ---
+    ncam = npo.Camera(CAM, (a.shape[1], a.shape[0]))
+    scam = synth.AtanCam(CAM, (a.shape[1], a.shape[0]))
+    opd = npo.one_pixel_dist(ncam)
+    ep = {"im_a": a, "im_b": b, "one_pixel_dist": opd}
+    for lv_ in (0, 2):
+        eq = synth.make_epipolar_queries(scam, la[lv_]["corners"], lv_, opd, n=150, seed=0x5EED0009 + lv_)
+        ip = npo.implane_corners(ncam, lb[lv_]["corners"], lv_)
+        r = [npo.epipolar_search(la[lv_], lb[lv_], ip, eq[i]) for i in range(len(eq))]
+        ep[f"queries{lv_}"], ep[f"implane{lv_}"] = eq, ip
+        for f in ("best", "best_zmssd", "n_scored", "template_bad"):
+            ep[f"{f}{lv_}"] = np.array([x[f] for x in r], np.int32)
+        print("epipolar level", lv_, "matched", int(np.count_nonzero(ep[f"best{lv_}"] >= 0)), "scored/query", float(ep[f"n_scored{lv_}"].mean()))
+    np.savez_compressed(os.path.join(OUT, "epipolar_160x128.npz"), **ep)
     # --- sub-pixel refinement of the found patches ---
     ok = np.flatnonzero([r["found"] for r in res])
     sp = [npo.subpix(lb, res[i]["pos"], int(q[i]["level"]), t[i], 8) for i in ok]

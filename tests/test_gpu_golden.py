@@ -33,6 +33,10 @@ def test_template_cont(hip):
     G.check_template_cont(hip)
 
 
+def test_epipolar(hip):
+    G.check_epipolar(hip)
+
+
 def test_pvs(hip):
     G.check_pvs(hip)
 

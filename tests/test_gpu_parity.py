@@ -268,6 +268,26 @@ def test_make_template_coarse_cont_bit_exact(hip, oracle):
     assert 0 < np.count_nonzero(ro["n_outside"]) < len(to) // 2 and ro["bad"][0] == 1
 
 
+@pytest.mark.parametrize("level", [0, 1, 3])
+def test_epipolar_corner_scan_matches_oracle(hip, oracle, level):
+    """AddPointEpipolar's scan on the full-size frame pair: in-plane corner table (tan() differs by an ulp between
+    libm and the device), and per candidate the best corner index / ZMSSD / scored count, all exact"""
+    a, b = synth.make_frame_pair()
+    cam = synth.AtanCam()
+    out = {}
+    for name, lib in (("hip", hip), ("oracle", oracle)):
+        ctx = host.Context(lib=lib)
+        kfa, kfb = host.KeyFrame(ctx).MakeKeyFrame_Lite(a), host.KeyFrame(ctx).MakeKeyFrame_Lite(b)
+        opd = ctx.one_pixel_dist()
+        q = synth.make_epipolar_queries(cam, kfa.level(level)["corners"], level, opd, n=1500, seed=77 + level)
+        out[name] = (opd, kfb.implane_corners(level), host.PatchFinder(ctx).EpipolarSearch(kfa, kfb, level, q))
+    (oh, ih, rh), (oo, io, ro) = out["hip"], out["oracle"]
+    assert abs(oh - oo) <= 1e-16 and np.allclose(ih, io, rtol=1e-14, atol=1e-16)
+    for f in ("best", "best_zmssd", "n_scored", "template_bad"):
+        assert np.array_equal(rh[f], ro[f]), f
+    assert np.count_nonzero(ro["best"] >= 0) > 700 and ro["n_scored"].max() > 5
+
+
 def test_track_pvs_matches_oracle(hip, oracle):
     pv = synth.make_pvs_case()
     rh, ch = host.Context(lib=hip).track_pvs(pv["world"], pv["pixel_right_w"], pv["pixel_down_w"], pv["pose"])

@@ -31,6 +31,10 @@ def test_template_cont(oracle):
     G.check_template_cont(oracle)
 
 
+def test_epipolar(oracle):
+    G.check_epipolar(oracle)
+
+
 def test_pvs(oracle):
     G.check_pvs(oracle)
 
