@@ -2230,10 +2230,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     HIP_TRY(hipFuncSetAttribute((const void*)schur_tile_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(2 * sizeof(SchurStageM))));
     HIP_TRY(hipMalloc((void**)&ba->d_xchg, 4096));
-    if (ba->world > 1) {
-        if (const char* e = getenv("PTAM_XCAND_CAP")) ba->xcand_cap = std::max(1, std::min(atoi(e), 1 << 20));
-        HIP_TRY(hipMalloc((void**)&ba->d_sel, (HIST_BINS + (size_t)ba->world * (1 + 2 * (size_t)ba->xcand_cap)) * sizeof(double)));
-    }
+
     ba->cur = 0;
     ba->prepared = true;
     return PTAM_OK;
@@ -2292,6 +2289,10 @@ static int ba_pass1_sigma(ptam_ba* ba) {
         hipLaunchKernelGGL(select_compact_kernel, dim3(std::max(1, std::min((d.M + 1023) / 1024, 256))), dim3(256), 0,
                            ctx->stream, d, (const double*)d.m_e2, (long long)d.M, (const uint8_t*)d.m_state);
     } else if (!ba->slow_select) {
+        if (!ba->d_sel) {   // sized by the world the communicator was set for (ptam_ba_set_comm drops it on a change)
+            if (const char* e = getenv("PTAM_XCAND_CAP")) ba->xcand_cap = std::max(1, std::min(atoi(e), 1 << 20));
+            HIP_TRY(hipMalloc((void**)&ba->d_sel, (HIST_BINS + (size_t)ba->world * (1 + 2 * (size_t)ba->xcand_cap)) * sizeof(double)));
+        }
         double* hx = ba->d_sel;                  // histogram exchange
         double* xc = ba->d_sel + HIST_BINS;      // candidate exchange
         const int cap = ba->xcand_cap;
@@ -2622,6 +2623,12 @@ int ptam_ba_set_comm(ptam_ba* ba, int rank, int world, ptam_allreduce_f64_fn fn,
     ARG_TRY(ba && world >= 1 && rank >= 0 && rank < world);
     ARG_TRY(world == 1 || fn);
     ARG_TRY(world <= 32);
+    if (ba->d_sel && world != ba->world) {   // the select's exchange buffer is sized by the world
+        HIP_TRY(hipSetDevice(ba->ctx->device));
+        HIP_TRY(hipStreamSynchronize(ba->ctx->stream));
+        HIP_TRY(hipFree(ba->d_sel));
+        ba->d_sel = nullptr;
+    }
     ba->rank = rank;
     ba->world = world;
     ba->comm = fn;
