@@ -56,10 +56,13 @@ struct BaScalars {
     int sel_bin2;           // sharded select: second-level bin (-1: clamped first-level bin, all candidates count)
     int sel_k2;             //                 residual rank inside it
     int select_overflow;    //                 a rank had more last-stage candidates than its exchange slot holds
+    int end_step;           // after a trial: the LM step is over (accepted, converged or out of trials)
+    int spec_go;            //                and the next step will run with the trial state as current
 };
 
 struct BaDev {
     int C, F, P, M;
+    int guard;              // 0: run; 1: run only if sc->spec_go; 2: only if sc->end_step (speculatively enqueued kernels)
     int n, npad;            // camera system order 6F and its padding to SOLVE_NB
     int n_chunks, grid_acc; // measurement chunks; persistent grid of the accumulate kernel
     int n_wchunks;          // wave chunks (<= 64 measurements, whole points); 0 = block variant only

@@ -41,6 +41,14 @@ __device__ __forceinline__ int e2_bin2(double e2) {   // next 12 bits
     return (int)(((unsigned long long)__double_as_longlong(e2) >> 36) & (HIST_BINS - 1));
 }
 
+// Kernels of the NEXT LM step are enqueued before the host has seen the trial's outcome (the GPU would idle ~10 us
+// per trial otherwise).  They carry d.guard != 0 and leave at once unless finalize_new_kernel decided on the device
+// what the host is about to decide from the same numbers.
+__device__ __forceinline__ bool ba_guard_blocks(const BaDev& d) {
+    if (d.guard == 0) return false;
+    return d.guard == 1 ? d.sc->spec_go == 0 : d.sc->end_step == 0;
+}
+
 // project one measurement: returns false (bad) if z <= 0  (ProjectAndFindSquaredError :164-180).
 // Same arithmetic as cam_project / cam_derivs (common.h) with the divisions replaced by three
 // Newton-refined reciprocals (1/z, 1/r, 1/(1+k^2 r^2)); pass 1, pass 2 and the new-error pass all
@@ -213,6 +221,7 @@ __global__ void __launch_bounds__(BA_CHUNK) project_e2_kernel(DevCam cam, BaDev 
 // adopts its squared errors and z <= 0 flags, clears the accumulators of boundary-cut points and builds
 // the histogram — no projection (K5 proper is project_e2_kernel above).
 __global__ void __launch_bounds__(256) pass1_from_trial_kernel(BaDev d, int build_hist) {
+    if (ba_guard_blocks(d)) return;
     __shared__ unsigned hist[HIST_BINS];
     const int tid = threadIdx.x;
     if (build_hist)
@@ -328,6 +337,7 @@ __device__ void block_find_bin(const unsigned* __restrict__ hist, long long& tot
 // one global atomic per flush.
 __global__ void __launch_bounds__(256) select_compact_kernel(BaDev d, const double* __restrict__ keys, long long n,
                                                              const uint8_t* __restrict__ state) {
+    if (ba_guard_blocks(d)) return;
     __shared__ double buf[CAND_BUF];
     __shared__ unsigned h2[HIST_BINS];
     __shared__ int cnt, gpos;
@@ -427,6 +437,7 @@ __device__ unsigned long long block_radix_select(const double* src, int n, int k
 // one block: second-level bin from hist2, collect its (few) members in LDS, finish the select there;
 // sigma^2; reset both histograms
 __global__ void __launch_bounds__(1024) select_final_kernel(BaDev d, int est, double min_sigma_sq) {
+    if (ba_guard_blocks(d)) return;
     __shared__ double sm[SMALL_CAP];
     __shared__ unsigned hist[256];
     __shared__ long long wsum[16];
@@ -852,6 +863,7 @@ __device__ __forceinline__ void k7_load(const BaDev& d, const double* __restrict
 template <int THREADS, bool PREFETCH, bool LOOP, int EST>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
 jac_accum_wave_kernel(DevCam cam, BaDev d, int cur, int est_arg, int per_wave, int extra) {
+    if (ba_guard_blocks(d)) return;
     const int est = EST >= 0 ? EST : est_arg;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Ul = smem;
@@ -1093,6 +1105,7 @@ __global__ void __launch_bounds__(256) zero_cut_points_kernel(BaDev d) {
 // K7, block variant (points with up to BA_CHUNK measurements): a workgroup owns whole points.
 // dynamic LDS: Ul[F*27] camera partials | Bs[BA_CHUNK][8] per-measurement B (2x3) and weighted eps
 __global__ void __launch_bounds__(BA_CHUNK) jac_accum_kernel(DevCam cam, BaDev d, int cur, int est) {
+    if (ba_guard_blocks(d)) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Ul = smem;
     double* Bs = smem + (((size_t)d.F * 27 + 1) & ~(size_t)1);
@@ -1158,6 +1171,7 @@ __global__ void __launch_bounds__(BA_CHUNK) jac_accum_kernel(DevCam cam, BaDev d
 // Block (0,0) also reduces the error / bad-count partials.
 #define RSPLIT 16
 __global__ void __launch_bounds__(256) reduce_partials_kernel(BaDev d, int grid_acc) {
+    if (ba_guard_blocks(d)) return;
     __shared__ double comb[4][64];
     __shared__ double werr[4];
     __shared__ int wbad[4];
@@ -1198,6 +1212,7 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(BaDev d, int grid_
 // K8a: V*^-1  (:341-359)   TooN Cholesky<3>::get_inverse
 // =================================================================================================
 __global__ void __launch_bounds__(256) vinv_kernel(BaDev d, double lambda) {
+    if (ba_guard_blocks(d)) return;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= d.P) return;
     const double* v = d.V + (size_t)p * 6;
@@ -1758,7 +1773,7 @@ __global__ void __launch_bounds__(BA_CHUNK) point_update_kernel(DevCam cam, BaDe
     }
 }
 
-__global__ void __launch_bounds__(256) finalize_new_kernel(BaDev d) {
+__global__ void __launch_bounds__(256) finalize_new_kernel(BaDev d, double conv_limit, int last_allowed) {
     __shared__ double w[4][2];
     double e = 0, s = 0;
     // fixed assignment + fixed combine order: deterministic
@@ -1774,13 +1789,21 @@ __global__ void __launch_bounds__(256) finalize_new_kernel(BaDev d) {
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        d.sc->new_err = w[0][0] + w[1][0] + w[2][0] + w[3][0];
-        d.sc->sumsq_pt = w[0][1] + w[1][1] + w[2][1] + w[3][1];
+        const double ne = w[0][0] + w[1][0] + w[2][0] + w[3][0], sp = w[0][1] + w[1][1] + w[2][1] + w[3][1];
+        d.sc->new_err = ne;
+        d.sc->sumsq_pt = sp;
+        // the host's decision (src/Bundle.cc:338, :488-490, :518-533), taken here as well for the guarded kernels
+        const double ce = d.sc->cur_err;
+        const bool conv = d.sc->sumsq_cam + sp < conv_limit;
+        const bool end_step = !(ne > ce) || conv || last_allowed != 0;
+        d.sc->end_step = end_step ? 1 : 0;
+        d.sc->spec_go = (end_step && ne < ce && !conv && last_allowed == 0) ? 1 : 0;
     }
 }
 
 // erase bad measurements, append to the outlier list (:536-547)
 __global__ void __launch_bounds__(256) purge_kernel(BaDev d) {
+    if (ba_guard_blocks(d)) return;
     const int m = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool bad = m < d.M && d.m_state[m] == MS_BAD;
@@ -2370,16 +2393,19 @@ static int ba_pass1_sigma(ptam_ba* ba) {
     return PTAM_OK;
 }
 
-static void launch_k7(ptam_ba* ba) {
+static void launch_k7(ptam_ba* ba, int guard = 0) {
     ptam_ctx* ctx = ba->ctx;
+    BaDev d = ba->d;
+    d.guard = guard;
+    int cur = guard ? (ba->cur ^ 1) : ba->cur;   // a guarded launch belongs to the next step: the trial state is current there
     if (ba->use_wave) {
         int est = ba->opts.estimator;
-        void* args[] = {&ctx->cam, &ba->d, &ba->cur, &est, &ba->per_wave, &ba->extra_waves};
-        (void)hipLaunchKernel(k7_wave_fn(ba->k7_threads, ba->k7_loop, est), dim3(ba->d.grid_acc), dim3(ba->k7_threads), args,
+        void* args[] = {&ctx->cam, &d, &cur, &est, &ba->per_wave, &ba->extra_waves};
+        (void)hipLaunchKernel(k7_wave_fn(ba->k7_threads, ba->k7_loop, est), dim3(d.grid_acc), dim3(ba->k7_threads), args,
                               ba->smem_acc, ctx->stream);
     } else
-        hipLaunchKernelGGL(jac_accum_kernel, dim3(ba->d.grid_acc), dim3(BA_CHUNK), ba->smem_acc, ctx->stream, ctx->cam, ba->d,
-                           ba->cur, ba->opts.estimator);
+        hipLaunchKernelGGL(jac_accum_kernel, dim3(d.grid_acc), dim3(BA_CHUNK), ba->smem_acc, ctx->stream, ctx->cam, d, cur,
+                           ba->opts.estimator);
 }
 
 static int ba_pass2(ptam_ba* ba) {
@@ -2407,11 +2433,11 @@ static int ba_pass2(ptam_ba* ba) {
     return PTAM_OK;
 }
 
-static int ba_trial(ptam_ba* ba, double lambda) {
+static int ba_trial(ptam_ba* ba, double lambda, bool skip_vinv, int last_allowed) {
     ptam_ctx* ctx = ba->ctx;
     BaDev& d = ba->d;
     prof_begin(ba, PTAM_K_VINV);
-    if (d.P > 0) hipLaunchKernelGGL(vinv_kernel, dim3((d.P + 255) / 256), dim3(256), 0, ctx->stream, d, lambda);
+    if (d.P > 0 && !skip_vinv) hipLaunchKernelGGL(vinv_kernel, dim3((d.P + 255) / 256), dim3(256), 0, ctx->stream, d, lambda);
     prof_end(ba, PTAM_K_VINV);
     if (d.F > 0) {
         prof_begin(ba, PTAM_K_SCHUR);
@@ -2439,7 +2465,7 @@ static int ba_trial(ptam_ba* ba, double lambda) {
     if (d.n_chunks > 0)
         hipLaunchKernelGGL(point_update_kernel, dim3(d.n_chunks), dim3(BA_CHUNK), 0, ctx->stream, ctx->cam, d, ba->cur,
                            ba->opts.estimator);
-    hipLaunchKernelGGL(finalize_new_kernel, dim3(1), dim3(256), 0, ctx->stream, d);
+    hipLaunchKernelGGL(finalize_new_kernel, dim3(1), dim3(256), 0, ctx->stream, d, ba->opts.update_sq_conv_limit, last_allowed);
     prof_end(ba, PTAM_K_UPDATE);
     HIP_TRY(hipGetLastError());
     if (ba->comm && ba->world > 1) {
@@ -2451,7 +2477,37 @@ static int ba_trial(ptam_ba* ba, double lambda) {
     return PTAM_OK;
 }
 
+// The next LM step's prologue behind the device-side decision: purge (if the step ended), then — if the trial was
+// accepted and the loop goes on — pass 1 from the trial's errors, the select, K7 with the trial state as current, the
+// partial reduction and V*^-1 for lambda * 0.3.  Enqueued right after the scalars were published, i.e. while the host
+// is still waiting for them.
+static int ba_enqueue_speculative(ptam_ba* ba, double lambda_next) {
+    ptam_ctx* ctx = ba->ctx;
+    BaDev d = ba->d;
+    const double min_s2 = ba->opts.min_sigma * ba->opts.min_sigma;
+    d.guard = 2;
+    if (d.M > 0) hipLaunchKernelGGL(purge_kernel, dim3((d.M + 255) / 256), dim3(256), 0, ctx->stream, d);
+    d.guard = 1;
+    hipLaunchKernelGGL(pass1_from_trial_kernel, dim3(std::min((d.M + 255) / 256, 512)), dim3(256), 0, ctx->stream, d, 1);
+    hipLaunchKernelGGL(select_compact_kernel, dim3(std::max(1, std::min((d.M + 1023) / 1024, 256))), dim3(256), 0, ctx->stream, d,
+                       (const double*)d.m_e2, (long long)d.M, (const uint8_t*)d.m_state);
+    hipLaunchKernelGGL(select_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, d, ba->opts.estimator, min_s2);
+    launch_k7(ba, 1);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(std::max(1, (d.F * 27 + 63) / 64), RSPLIT), dim3(256), 0, ctx->stream, d,
+                       d.grid_acc);
+    if (d.P > 0) hipLaunchKernelGGL(vinv_kernel, dim3((d.P + 255) / 256), dim3(256), 0, ctx->stream, d, lambda_next);
+    HIP_TRY(hipGetLastError());
+    return PTAM_OK;
+}
+
+static int ba_publish_scalars(ptam_ba* ba);
+static int ba_wait_scalars(ptam_ba* ba, BaScalars* out);
 static int ba_read_scalars(ptam_ba* ba, BaScalars* out) {
+    const int rc = ba_publish_scalars(ba);
+    return rc ? rc : ba_wait_scalars(ba, out);
+}
+
+static int ba_publish_scalars(ptam_ba* ba) {
     ptam_ctx* ctx = ba->ctx;
     if (!ba->mbox) {
         void* h = nullptr;
@@ -2466,6 +2522,12 @@ static int ba_read_scalars(ptam_ba* ba, BaScalars* out) {
     hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(64), 0, ctx->stream, (const BaScalars*)ba->d.sc,
                        (ulonglong2*)ba->mbox_dev, seq);
     HIP_TRY(hipGetLastError());
+    return PTAM_OK;
+}
+
+static int ba_wait_scalars(ptam_ba* ba, BaScalars* out) {
+    ptam_ctx* ctx = ba->ctx;
+    const unsigned long long seq = ba->mbox_seq;
     constexpr unsigned NW = sizeof(BaScalars) / 8;
     auto arrived = [&]() {
         for (unsigned i = 0; i < NW; i++)
@@ -2660,12 +2722,21 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     BaScalars sc;
     std::memset(&sc, 0, sizeof sc);
     const bool empty = d.M == 0;
+    // speculative step prologue (ba_enqueue_speculative): single device, not while per-kernel events are being taken
+    const bool spec = !(ba->comm && ba->world > 1) && !ba->prof && d.n_chunks > 0 && !getenv("PTAM_NO_SPECULATION");
+    bool spec_ready = false;   // pass 1 .. V*^-1 of the coming step are already running behind the device-side flag
     while (!empty && !ba->converged && !hit_max && !aborted()) {
         // ---- Do_LM_Step :209-551 ----
-        rc = ba_pass1_sigma(ba);
-        if (rc) return rc;
-        rc = ba_pass2(ba);
-        if (rc) return rc;
+        bool skip_vinv = false;
+        if (spec_ready) {
+            spec_ready = false;
+            skip_vinv = true;
+        } else {
+            rc = ba_pass1_sigma(ba);
+            if (rc) return rc;
+            rc = ba_pass2(ba);
+            if (rc) return rc;
+        }
         bool have_cur = false;
         double cur_err = 0, new_err = 0;
         bool ran_any = false, redo_step = false;
@@ -2673,9 +2744,16 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
         for (;;) {
             if (have_cur && !(new_err > cur_err)) break;
             if (ba->converged || hit_max || aborted()) break;
-            rc = ba_trial(ba, lambda);
+            rc = ba_trial(ba, lambda, skip_vinv, counter + 1 >= ba->opts.max_iterations ? 1 : 0);
+            skip_vinv = false;
             if (rc) return rc;
-            rc = ba_read_scalars(ba, &sc);
+            rc = ba_publish_scalars(ba);
+            if (rc) return rc;
+            if (spec) {   // what follows an accepted trial, queued while the host waits for the verdict
+                rc = ba_enqueue_speculative(ba, lambda * 0.3);
+                if (rc) return rc;
+            }
+            rc = ba_wait_scalars(ba, &sc);
             if (rc) return rc;
             if (!have_cur) {
                 // (every step runs at least one trial: this first read of step s also carries the outlier-list
@@ -2732,7 +2810,11 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
             if (rc) return rc;
             step_outlier_end.push_back(sc.n_outliers);
         }
-        if (d.M > 0) hipLaunchKernelGGL(purge_kernel, dim3((d.M + 255) / 256), dim3(256), 0, ctx->stream, d);   // :536-547
+        // the device took the same decision for the guarded kernels: accepted and the loop goes on -> they ran
+        // (purge of this step included); otherwise they left at once and the step is closed here
+        spec_ready = spec && ran_any && new_err < cur_err && !ba->converged && !hit_max;
+        if (!spec_ready && d.M > 0)
+            hipLaunchKernelGGL(purge_kernel, dim3((d.M + 255) / 256), dim3(256), 0, ctx->stream, d);   // :536-547
         prev_end_pending = true;
         HIP_TRY(hipGetLastError());
         n_steps++;
