@@ -19,6 +19,7 @@
 // The lambda-trial control flow, convergence test and abort polling stay on the host, one readback of
 // a 64-byte scalar block per trial.
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <numeric>
 #include <utility>
@@ -1878,6 +1879,8 @@ struct ptam_ba {
     int accepted = 0;
     std::vector<ptam_ba_trial> trials;
     std::vector<std::pair<int, int>> outliers;   // (point, camera)
+    std::vector<int> raw_out, raw_out_ends;      // measurement indices as purged + segment ends (per LM step), not yet digested
+    int raw_out_base = 0, raw_out_done = 0;
     // device
     bool prepared = false;
     BaDev d;
@@ -1943,8 +1946,10 @@ struct Carver {
     }
 };
 
+static void ba_finish_outliers(ptam_ba* ba);
 static int ba_prepare_impl(ptam_ba* ba) {
     ptam_ctx* ctx = ba->ctx;
+    ba_finish_outliers(ba);   // erased measurements of earlier Compute() calls leave the problem here
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ba_free_device(ba);
@@ -2559,6 +2564,25 @@ static int ba_wait_scalars(ptam_ba* ba, BaScalars* out) {
     return PTAM_OK;
 }
 
+// digest the purged-measurement indices of finished Compute() calls: per LM step sorted by insertion index, appended
+// to the (point, camera) list, and the measurements marked erased for the next prepare
+static void ba_finish_outliers(ptam_ba* ba) {
+    int begin = ba->raw_out_done;
+    for (size_t k = 0; k < ba->raw_out_ends.size(); k++) {
+        const int end = ba->raw_out_ends[k];
+        if (end <= begin) continue;
+        std::sort(ba->raw_out.begin() + begin, ba->raw_out.begin() + end);
+        for (int i = begin; i < end; i++) {
+            const int o = ba->raw_out[i];
+            ba->outliers.push_back(std::make_pair(ba->m_pt[o], ba->m_cam[o]));
+            ba->m_dead[o] = 1;
+        }
+        begin = end;
+    }
+    ba->raw_out_done = begin;
+    ba->raw_out_ends.clear();
+}
+
 extern "C" {
 
 void ptam_ba_opts_default(ptam_ba_opts* o) {
@@ -2721,6 +2745,11 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     auto aborted = [&]() { return abort_flag && *abort_flag; };
     BaScalars sc;
     std::memset(&sc, 0, sizeof sc);
+#ifdef K7_TIMING
+    auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double ht0 = now_us();
+    double ht_first = 0;
+#endif
     const bool empty = d.M == 0;
     // speculative step prologue (ba_enqueue_speculative): single device, not while per-kernel events are being taken
     const bool spec = !(ba->comm && ba->world > 1) && !ba->prof && d.n_chunks > 0 && !getenv("PTAM_NO_SPECULATION");
@@ -2755,6 +2784,9 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
             }
             rc = ba_wait_scalars(ba, &sc);
             if (rc) return rc;
+#ifdef K7_TIMING
+            if (ht_first == 0) ht_first = now_us();
+#endif
             if (!have_cur) {
                 // (every step runs at least one trial: this first read of step s also carries the outlier-list
                 //  length left by the purge that closed step s-1 — no separate read-back for it)
@@ -2825,6 +2857,9 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
         step_outlier_end.push_back(sc.n_outliers);
     }
 #ifdef K7_TIMING
+    const double ht_loop = now_us();
+#endif
+#ifdef K7_TIMING
     {
         long long h[16];
         HIP_TRY(hipMemcpy(h, d.dbg, sizeof h, hipMemcpyDeviceToHost));
@@ -2834,29 +2869,37 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
                     h[12], h[13], h[14], h[15]);
     }
 #endif
-    // ---- read back results ----
-    HIP_TRY(hipMemcpyAsync(ba->cam_pose.data(), d.pose[ba->cur], (size_t)d.C * 96, hipMemcpyDeviceToHost, ctx->stream));
-    if (d.P > 0) HIP_TRY(hipMemcpyAsync(ba->pts.data(), d.pt[ba->cur], (size_t)d.P * 24, hipMemcpyDeviceToHost, ctx->stream));
+    // ---- read back results: one pinned staging buffer, one synchronisation (pageable destinations cost ~100 us each) ----
     const int n_out = step_outlier_end.empty() ? 0 : step_outlier_end.back();
     std::vector<int> out_idx(std::max(n_out, 1));
-    if (n_out > 0) HIP_TRY(hipMemcpyAsync(out_idx.data(), d.outliers, (size_t)n_out * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    // outlier list in the reference's order: LM step, then list (insertion) order
-    int begin = 0;
-    for (int end : step_outlier_end) {
-        std::sort(out_idx.begin() + begin, out_idx.begin() + end);
-        for (int i = begin; i < end; i++) {
-            const int o = out_idx[i];
-            ba->outliers.push_back(std::make_pair(ba->m_pt[o], ba->m_cam[o]));
-            ba->m_dead[o] = 1;
-        }
-        begin = end;
+    {
+        const size_t b_pose = (size_t)d.C * 96, b_pts = (size_t)d.P * 24, b_out = (size_t)n_out * 4;
+        void* pin = nullptr;
+        rc = ctx_pinned(ctx, b_pose + b_pts + b_out + 64, &pin);
+        if (rc) return rc;
+        char* hp = (char*)pin;
+        HIP_TRY(hipMemcpyAsync(hp, d.pose[ba->cur], b_pose, hipMemcpyDeviceToHost, ctx->stream));
+        if (d.P > 0) HIP_TRY(hipMemcpyAsync(hp + b_pose, d.pt[ba->cur], b_pts, hipMemcpyDeviceToHost, ctx->stream));
+        if (n_out > 0) HIP_TRY(hipMemcpyAsync(hp + b_pose + b_pts, d.outliers, b_out, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        std::memcpy(ba->cam_pose.data(), hp, b_pose);
+        if (d.P > 0) std::memcpy(ba->pts.data(), hp + b_pose, b_pts);
+        if (n_out > 0) std::memcpy(out_idx.data(), hp + b_pose + b_pts, b_out);
     }
+    // the outlier list (reference order: LM step, then insertion order) is put together when somebody asks for it
+    // (ba_finish_outliers): sorting ~10 k indices costs as much as a whole lambda trial
+    ba->raw_out.insert(ba->raw_out.end(), out_idx.begin(), out_idx.begin() + n_out);
+    for (int end : step_outlier_end) ba->raw_out_ends.push_back(ba->raw_out_base + end);
+    ba->raw_out_base += n_out;
     // the device copy stays valid for another Compute(): poses/points are current in pose[cur]; the
     // outlier counter restarts
     if (n_out > 0) {
         ba->prepared = false;   // rebuild without the erased measurements on the next Compute
     }
+#ifdef K7_TIMING
+    std::printf("HOST Compute: first trial read at %.1f us, loop end %.1f us, total %.1f us (%zu trials)\n", ht_first - ht0, ht_loop - ht0,
+                now_us() - ht0, ba->trials.size());
+#endif
     if (accepted_out) *accepted_out = ba->accepted;
     return PTAM_OK;
 }
@@ -2881,6 +2924,7 @@ int ptam_ba_get_all(const ptam_ba* ba, double* poses12, double* points3) {
 }
 int ptam_ba_get_outliers(const ptam_ba* ba, int32_t* pairs, int cap) {
     if (!ba) return PTAM_E_ARG;
+    ba_finish_outliers(const_cast<ptam_ba*>(ba));
     const int n = (int)ba->outliers.size();
     for (int i = 0; i < n && i < cap && pairs; i++) {
         pairs[2 * i] = ba->outliers[i].first;
@@ -2898,6 +2942,7 @@ int ptam_ba_counts(const ptam_ba* ba, int* n_cams, int* n_free, int* n_points, i
     ARG_TRY(ba);
     int f = 0;
     for (uint8_t x : ba->cam_fixed) f += x ? 0 : 1;
+    ba_finish_outliers(const_cast<ptam_ba*>(ba));
     int live = 0;
     for (uint8_t x : ba->m_dead) live += x ? 0 : 1;
     if (n_cams) *n_cams = (int)ba->cam_fixed.size();
