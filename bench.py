@@ -35,7 +35,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20,
+                    help="lambda trials in the timed Compute() (default 20 = Bundle.MaxIterations, src/Bundle.cc:40)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cams", type=int, default=50)
     ap.add_argument("--points", type=int, default=5000)
