@@ -271,6 +271,13 @@ int ptam_pose_gn(ptam_ctx* ctx, int n, const ptam_pose_meas* meas, const ptam_pr
                  double pose_inout[12], const ptam_gn_opts* opts,
                  int32_t* outlier_flags, double* updates_out);
 
+/* device-resident variant: every pointer is a device pointer (d_entry, d_outlier_flags, d_updates nullable; d_updates
+ * holds 32*6 doubles), asynchronous on the context's stream — the measurements of a tracked frame are produced on
+ * the device (patch search / sub-pixel results), so the frame needs no upload and only the 96-byte pose comes back.
+ * n must be >= 1. */
+int ptam_pose_gn_dev(ptam_ctx* ctx, int n, const ptam_pose_meas* d_meas, const ptam_projection* d_entry,
+                     double* d_pose_inout, const ptam_gn_opts* opts, int32_t* d_outlier_flags, double* d_updates);
+
 /* One Tracker::CalcPoseUpdate (src/Tracker.cc:928-1005) on caller-provided Jacobians. */
 typedef struct {
     double found[2];

@@ -756,6 +756,34 @@ int ptam_pose_gn(ptam_ctx* ctx, int n, const ptam_pose_meas* meas, const ptam_pr
     return PTAM_OK;
 }
 
+int ptam_pose_gn_dev(ptam_ctx* ctx, int n, const ptam_pose_meas* d_meas, const ptam_projection* d_entry, double* d_pose_inout,
+                     const ptam_gn_opts* opts, int32_t* d_outlier_flags, double* d_updates) {
+    ARG_TRY(ctx && n >= 1 && d_meas && d_pose_inout);
+    ptam_gn_opts o;
+    if (opts)
+        o = *opts;
+    else
+        ptam_gn_opts_default(&o);
+    ARG_TRY(o.iterations >= 0 && o.iterations <= 32);
+    HIP_TRY(hipSetDevice(ctx->device));
+    // the kernels write the per-iteration updates unconditionally: give them the context's scratch when the caller
+    // does not want them (the general kernel also keeps its per-measurement state there)
+    const size_t bs = n > GS_THREADS * GS_MPT ? (size_t)n * sizeof(PoseState) : 0, bu = (size_t)6 * 32 * 8;
+    void* s;
+    int rc = ctx_scratch(ctx, bs + bu + 64, &s);
+    if (rc) return rc;
+    PoseState* d_s = (PoseState*)s;
+    double* d_u = d_updates ? d_updates : (double*)((char*)s + bs);
+    if (n <= GS_THREADS * GS_MPT)
+        hipLaunchKernelGGL(pose_gn_small_kernel, dim3(1), dim3(GS_THREADS), 0, ctx->stream, ctx->cam, n, d_meas, d_entry,
+                           d_pose_inout, o, d_outlier_flags, d_u);
+    else
+        hipLaunchKernelGGL(pose_gn_kernel, dim3(1), dim3(GN_THREADS), 0, ctx->stream, ctx->cam, n, d_meas, d_entry, d_pose_inout, o,
+                           d_s, d_outlier_flags, d_u);
+    HIP_TRY(hipGetLastError());
+    return PTAM_OK;
+}
+
 int ptam_calc_pose_update(ptam_ctx* ctx, int n, const ptam_pose_update_meas* meas, double override_sigma_sq,
                           int estimator, double prior, double mu_out[6], int32_t* weight_zero_flags) {
     ARG_TRY(ctx && n >= 0 && mu_out);

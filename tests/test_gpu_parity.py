@@ -1,6 +1,8 @@
 """-m gpu: parity of the HIP path (through the C ABI) against the CPU oracle on identical inputs.
 Integers (pyramid pixels, corner lists, LUTs, ZMSSD, best index) bit-exact; fp64 pose / bundle
 results within the tolerances written in each test (north_star: 1e-6 relative on the post-LM error)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -115,6 +117,30 @@ def test_pose_gn(hip, oracle, stage):
     if stage == "fine":
         assert fh.sum() >= 0.8 * pc["is_outlier"].sum()
     assert np.abs(ph - pc["true_pose"]).max() < 5e-3
+
+
+def test_pose_gn_device_resident_equals_host_entry(hip):
+    """ptam_pose_gn_dev on resident buffers = ptam_pose_gn on host buffers, bit for bit (same kernel)"""
+    pc = synth.make_pose_case()
+    ctx = host.Context(lib=hip)
+    ref, flags_ref, _ = ctx.pose_gn(pc["world"], pc["found"], pc["sqrt_inv_noise"], pc["init_pose"])
+    n = len(pc["world"])
+    meas = np.zeros(n, dtype=host.POSE_MEAS_DT)
+    meas["world"], meas["found"], meas["sqrt_inv_noise"] = pc["world"], pc["found"], pc["sqrt_inv_noise"]
+    d_m, d_p, d_f = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    for ptr, nbytes in ((d_m, meas.nbytes), (d_p, 96), (d_f, 4 * n)):
+        ctx._check(hip.dev_alloc(ctx.h, nbytes, C.byref(ptr)), "alloc")
+    pose = pc["init_pose"].copy()
+    ctx._check(hip.dev_upload(ctx.h, d_m, meas.ctypes.data, meas.nbytes), "up")
+    ctx._check(hip.dev_upload(ctx.h, d_p, pose.ctypes.data, 96), "up")
+    opts = ctx.gn_opts()
+    ctx._check(hip.pose_gn_dev(ctx.h, n, d_m, None, d_p, C.byref(opts), d_f, None), "pose_gn_dev")
+    out, flags = np.zeros(12), np.zeros(n, dtype=np.int32)
+    ctx._check(hip.dev_download(ctx.h, out.ctypes.data, d_p, 96), "down")
+    ctx._check(hip.dev_download(ctx.h, flags.ctypes.data, d_f, 4 * n), "down")
+    assert np.array_equal(out, ref) and np.array_equal(flags, flags_ref)
+    for ptr in (d_m, d_p, d_f):
+        hip.dev_free(ctx.h, ptr)
 
 
 def test_pose_gn_entry_state_and_empty(hip, oracle):
