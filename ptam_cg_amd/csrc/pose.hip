@@ -738,9 +738,20 @@ int ptam_pose_gn(ptam_ctx* ctx, int n, const ptam_pose_meas* meas, const ptam_pr
     double* d_u = (double*)p;
     p += bu;
     int* d_f = (int*)p;
-    HIP_TRY(hipMemcpyAsync(d_m, meas, bm, hipMemcpyHostToDevice, ctx->stream));
-    if (entry) HIP_TRY(hipMemcpyAsync(d_e, entry, be, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_pose, pose_inout, 96, hipMemcpyHostToDevice, ctx->stream));
+    // host buffers are pageable: going through the context's pinned staging keeps every copy asynchronous, so the call
+    // has ONE synchronisation (a pageable hipMemcpyAsync blocks until its staging copy is done, each time)
+    const size_t bo = 96 + (outlier_flags ? bf : 0) + (updates_out ? sizeof(double) * 6 * o.iterations : 0);
+    void* pin;
+    rc = ctx_pinned(ctx, bm + be + 96 + bo + 64, &pin);
+    if (rc) return rc;
+    char* hp = (char*)pin;
+    std::memcpy(hp, meas, bm);
+    if (entry) std::memcpy(hp + bm, entry, be);
+    std::memcpy(hp + bm + be, pose_inout, 96);
+    char* ho = hp + bm + be + 96;
+    HIP_TRY(hipMemcpyAsync(d_m, hp, bm, hipMemcpyHostToDevice, ctx->stream));
+    if (entry) HIP_TRY(hipMemcpyAsync(d_e, hp + bm, be, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_pose, hp + bm + be, 96, hipMemcpyHostToDevice, ctx->stream));
     if (n <= GS_THREADS * GS_MPT)
         hipLaunchKernelGGL(pose_gn_small_kernel, dim3(1), dim3(GS_THREADS), 0, ctx->stream, ctx->cam, n, d_m, d_e, d_pose,
                            o, d_f, d_u);
@@ -748,11 +759,15 @@ int ptam_pose_gn(ptam_ctx* ctx, int n, const ptam_pose_meas* meas, const ptam_pr
         hipLaunchKernelGGL(pose_gn_kernel, dim3(1), dim3(GN_THREADS), 0, ctx->stream, ctx->cam, n, d_m, d_e, d_pose, o,
                            d_s, d_f, d_u);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(pose_inout, d_pose, 96, hipMemcpyDeviceToHost, ctx->stream));
-    if (outlier_flags) HIP_TRY(hipMemcpyAsync(outlier_flags, d_f, bf, hipMemcpyDeviceToHost, ctx->stream));
-    if (updates_out)
-        HIP_TRY(hipMemcpyAsync(updates_out, d_u, sizeof(double) * 6 * o.iterations, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ho, d_pose, 96, hipMemcpyDeviceToHost, ctx->stream));
+    char* hf = ho + 96;
+    char* hu = hf + (outlier_flags ? bf : 0);
+    if (outlier_flags) HIP_TRY(hipMemcpyAsync(hf, d_f, bf, hipMemcpyDeviceToHost, ctx->stream));
+    if (updates_out) HIP_TRY(hipMemcpyAsync(hu, d_u, sizeof(double) * 6 * o.iterations, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::memcpy(pose_inout, ho, 96);
+    if (outlier_flags) std::memcpy(outlier_flags, hf, bf);
+    if (updates_out) std::memcpy(updates_out, hu, sizeof(double) * 6 * o.iterations);
     return PTAM_OK;
 }
 
