@@ -346,6 +346,7 @@ __global__ void __launch_bounds__(GN_THREADS) pose_gn_kernel(DevCam cam, int n, 
 #define GS_WAVES (GS_THREADS / 64)
 #define GS_MPT 4   // measurements per thread: n <= 1024
 #define GS_BINS 2048   // 11-bit digits of the order-statistic select
+#define GS_TR_PITCH (8 * 33 + 1)   // 8 slices of 32 threads, padded so that slices and rows fall into different banks
 
 struct GnSmallShared {
     double pose[12];
@@ -358,6 +359,7 @@ struct GnSmallShared {
     int scan[GS_WAVES];
     unsigned long long cand[64];
     int n_cand;
+    double tr[27][GS_TR_PITCH];   // transposed per-thread partials of the 27 sums (row = sum, column = thread)
 };
 
 // wave sum by DPP: row shifts 1,2,4,8 then row broadcasts; the total lands in lane 63
@@ -629,11 +631,30 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
                     for (int a = 0; a < 6; a++) acc[21 + a] += er[r] * Jw[a];
                 }
             }
+            // 27 sums over 256 threads through LDS: every thread drops its partials column-wise, then 27 x 8 threads
+            // each add a 32-thread slice and the 8 slices of a sum meet by shuffles — ~100 instructions per thread
+            // instead of 27 six-step DPP reductions (~490) plus a serial four-wave combine (fixed order: deterministic)
+            const int tcol = (tid >> 5) * 33 + (tid & 31);
 #pragma unroll
-            for (int k = 0; k < 27; k++) {
-                const double v = wave_sum_f64_dpp(acc[k]);
-                if (lane == 63) sh.red[wid][k] = v;
+            for (int k = 0; k < 27; k++) sh.tr[k][tcol] = acc[k];
+        }
+        __syncthreads();
+        if (nf > 0 && tid < 27 * 8) {
+            const int k = tid >> 3, part = tid & 7;
+            const double* src = &sh.tr[k][part * 33];
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+            for (int j = 0; j < 32; j += 4) {
+                a0 += src[j];
+                a1 += src[j + 1];
+                a2 += src[j + 2];
+                a3 += src[j + 3];
             }
+            double v = (a0 + a1) + (a2 + a3);
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 4, 64);
+            if (part == 0) sh.red[0][k] = v;
         }
         __syncthreads();
         if (tid == 0) {
@@ -643,13 +664,12 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
                 int k = 0;
                 for (int a = 0; a < 6; a++)
                     for (int c = 0; c <= a; c++) {
-                        const double s4 = ((sh.red[0][k] + sh.red[1][k]) + sh.red[2][k]) + sh.red[3][k];
-                        C[a * 6 + c] = C[c * 6 + a] = s4;
+                        C[a * 6 + c] = C[c * 6 + a] = sh.red[0][k];
                         k++;
                     }
                 for (int a = 0; a < 6; a++) {
                     C[a * 6 + a] += opts.prior;   // add_prior :974
-                    b[a] = ((sh.red[0][21 + a] + sh.red[1][21 + a]) + sh.red[2][21 + a]) + sh.red[3][21 + a];
+                    b[a] = sh.red[0][21 + a];
                 }
                 ldlt6_solve(C, b, x);
             }
