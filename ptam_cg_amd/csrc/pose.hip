@@ -374,89 +374,120 @@ __device__ __forceinline__ double wave_sum_f64_dpp(double v) {
 }
 
 // exact k-th smallest of sh.keys[0..n) (non-found entries hold +inf), bit patterns compared as unsigned
-// 64-bit integers.  MSB radix select with 11-bit digits; as soon as the selected digit holds at most 64
-// keys (after two digits = 22 leading bits that is the rule: one or two keys) the wave-wide finisher
-// ranks them directly.  The 8-bit version needed 8 passes x 3 barriers per Gauss-Newton iteration and
-// was ~45 % of the pose solve.
-__device__ double small_select_kth(GnSmallShared& sh, int n, int k) {
-    unsigned long long prefix = 0;
+// 64-bit integers.
+//  - fast path: ONE histogram over the top 16 bits (sign, exponent, 4 mantissa bits = 16 bins per binade) relative to
+//    2^-40, clamped to 2048 bins.  A thousand squared errors spread over ~10 binades leave a handful of keys in the
+//    selected bin; they are gathered and ranked by one wave.  sh.hist must be zero on entry and is left zero (the scan
+//    phase clears the bins it reads), so no zeroing pass and five barriers in all;
+//  - general path (selected bin clamped or holding more than 64 keys): MSB radix select with 11-bit digits, switching
+//    to the same finisher as soon as the selected digit holds at most 64 keys.
+// The 8-bit radix version needed 24 barriers per Gauss-Newton iteration and was ~45 % of the pose solve.
+#define GS_KEY_BASE ((1023 - 40) << 4)
+__device__ __forceinline__ int small_key_bin(unsigned long long key) {
+    const int t = (int)(key >> 48) - GS_KEY_BASE;
+    return t < 0 ? 0 : (t > GS_BINS - 1 ? GS_BINS - 1 : t);
+}
+// rank the keys for which `mine` holds among themselves (cnt <= 64 of them): returns the k-th smallest
+__device__ double small_select_finish(GnSmallShared& sh, const unsigned long long key[GS_MPT], const bool mine[GS_MPT], int cnt, int k) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < GS_MPT; q++)
+        if (mine[q]) sh.cand[atomicAdd(&sh.n_cand, 1)] = key[q];
+    __syncthreads();
+    if (wid == 0) {
+        const unsigned long long me = lane < cnt ? sh.cand[lane] : ~0ull;
+        int rank = 0;
+        for (int j = 0; j < cnt; j++) {
+            const unsigned long long o = sh.cand[j];
+            rank += (o < me || (o == me && j < lane)) ? 1 : 0;
+        }
+        if (lane < cnt && rank == k) sh.cand[63] = me;   // exactly one lane (ties broken by index); read below
+    }
+    __syncthreads();
+    return __longlong_as_double((long long)sh.cand[63]);
+}
+// block-wide scan of sh.hist (GS_BINS / GS_THREADS bins per thread); the owner of rank k publishes bin / residual rank /
+// count and resets the candidate counter.  clear: zero the bins while reading them.
+__device__ void small_select_scan(GnSmallShared& sh, int k, bool clear) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    constexpr int BPT = GS_BINS / GS_THREADS;
+    unsigned c[BPT];
+    int s = 0;
+#pragma unroll
+    for (int b = 0; b < BPT; b++) {
+        c[b] = sh.hist[BPT * tid + b];
+        if (clear) sh.hist[BPT * tid + b] = 0;
+        s += (int)c[b];
+    }
+    int incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) sh.scan[wid] = incl;
+    __syncthreads();
+    int off = 0;
+#pragma unroll
+    for (int w = 0; w < GS_WAVES; w++)
+        if (w < wid) off += sh.scan[w];
+    const int excl = off + incl - s;
+    if (excl <= k && k < excl + s) {
+        int kk = k - excl, dg = BPT * tid;
+#pragma unroll
+        for (int b = 0; b < BPT - 1; b++)
+            if (kk >= (int)c[b] && dg == BPT * tid + b) {
+                kk -= (int)c[b];
+                dg++;
+            }
+        sh.sel_digit = dg;
+        sh.sel_k = kk;
+        sh.sel_cnt = (int)c[dg - BPT * tid];
+        sh.n_cand = 0;
+    }
+    __syncthreads();
+}
+__device__ double small_select_kth(GnSmallShared& sh, int n, int k) {
+    const int tid = threadIdx.x;
     unsigned long long key[GS_MPT];
+    bool mine[GS_MPT];
 #pragma unroll
     for (int q = 0; q < GS_MPT; q++) {
         const int i = tid + q * GS_THREADS;
         key[q] = i < n ? (unsigned long long)__double_as_longlong(sh.keys[i]) : ~0ull;
+        if (i < n) atomicAdd(&sh.hist[small_key_bin(key[q])], 1u);
     }
+    __syncthreads();
+    small_select_scan(sh, k, true);
+    {
+        const int bin = sh.sel_digit, cnt = sh.sel_cnt;
+        if (bin != 0 && bin != GS_BINS - 1 && cnt <= 64) {
+#pragma unroll
+            for (int q = 0; q < GS_MPT; q++) mine[q] = tid + q * GS_THREADS < n && small_key_bin(key[q]) == bin;
+            return small_select_finish(sh, key, mine, cnt, sh.sel_k);
+        }
+    }
+    // general path
+    unsigned long long prefix = 0;
     int top = 64;   // bits [top, 64) of the answer are fixed in `prefix`
     while (top > 0) {
         const int bits = top >= 11 ? 11 : top, shift = top - bits;
         const unsigned mask = (1u << bits) - 1u;
-        for (int b = tid; b < GS_BINS; b += GS_THREADS) sh.hist[b] = 0;
-        if (tid == 0) sh.n_cand = 0;
-        __syncthreads();
+        __syncthreads();   // (the previous round's reads of sel_* are done; hist is zero)
 #pragma unroll
         for (int q = 0; q < GS_MPT; q++)
             if (tid + q * GS_THREADS < n && (top == 64 || (key[q] >> top) == (prefix >> top)))
                 atomicAdd(&sh.hist[(unsigned)(key[q] >> shift) & mask], 1u);
         __syncthreads();
-        // block-wide exclusive scan over GS_BINS / GS_THREADS bins per thread
-        constexpr int BPT = GS_BINS / GS_THREADS;
-        unsigned c[BPT];
-        int s = 0;
-#pragma unroll
-        for (int b = 0; b < BPT; b++) {
-            c[b] = sh.hist[BPT * tid + b];
-            s += (int)c[b];
-        }
-        int incl = s;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += v;
-        }
-        if (lane == 63) sh.scan[wid] = incl;
-        __syncthreads();
-        int off = 0;
-#pragma unroll
-        for (int w = 0; w < GS_WAVES; w++)
-            if (w < wid) off += sh.scan[w];
-        const int excl = off + incl - s;
-        if (excl <= k && k < excl + s) {
-            int kk = k - excl, dg = BPT * tid;
-#pragma unroll
-            for (int b = 0; b < BPT - 1; b++)
-                if (kk >= (int)c[b] && dg == BPT * tid + b) {
-                    kk -= (int)c[b];
-                    dg++;
-                }
-            sh.sel_digit = dg;
-            sh.sel_k = kk;
-            sh.sel_cnt = (int)sh.hist[dg];
-        }
-        __syncthreads();
+        small_select_scan(sh, k, true);
         prefix |= (unsigned long long)sh.sel_digit << shift;
         k = sh.sel_k;
         top = shift;
         const int cnt = sh.sel_cnt;
         if (top > 0 && cnt <= 64) {
-            // finisher: the keys that share the fixed bits, ranked by one wave
 #pragma unroll
-            for (int q = 0; q < GS_MPT; q++)
-                if (tid + q * GS_THREADS < n && (key[q] >> top) == (prefix >> top)) sh.cand[atomicAdd(&sh.n_cand, 1)] = key[q];
-            __syncthreads();
-            if (wid == 0) {
-                const unsigned long long mine = lane < cnt ? sh.cand[lane] : ~0ull;
-                int rank = 0;
-                for (int j = 0; j < cnt; j++) {
-                    const unsigned long long o = sh.cand[j];
-                    rank += (o < mine || (o == mine && j < lane)) ? 1 : 0;
-                }
-                if (lane < cnt && rank == k) sh.cand[63] = mine;   // exactly one lane (ties broken by index)
-            }
-            __syncthreads();
-            const unsigned long long r = sh.cand[63];
-            __syncthreads();   // sh.cand / n_cand are reused by the next call
-            return __longlong_as_double((long long)r);
+            for (int q = 0; q < GS_MPT; q++) mine[q] = tid + q * GS_THREADS < n && (key[q] >> top) == (prefix >> top);
+            return small_select_finish(sh, key, mine, cnt, k);
         }
     }
     return __longlong_as_double((long long)prefix);
@@ -514,6 +545,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid < 12) sh.pose[tid] = pose_io[tid];
     if (tid < 6) sh.mu[tid] = 0;
+    for (int b = tid; b < GS_BINS; b += GS_THREADS) sh.hist[b] = 0;   // small_select_kth keeps it zero between calls
     SmallMeas t[GS_MPT];
 #pragma unroll
     for (int q = 0; q < GS_MPT; q++) {

@@ -119,6 +119,18 @@ def test_pose_gn(hip, oracle, stage):
     assert np.abs(ph - pc["true_pose"]).max() < 5e-3
 
 
+def test_pose_gn_with_massive_ties(hip, oracle):
+    """12 distinct measurements, each repeated 80 times: the squared errors tie in runs of 80, so the order-statistic
+    select cannot finish from one histogram bin and has to take its general radix path"""
+    pc = synth.make_pose_case(n=12)
+    rep = lambda a: np.repeat(a, 80, axis=0)
+    ch, co = host.Context(lib=hip), host.Context(lib=oracle)
+    ph, fh, uh = ch.pose_gn(rep(pc["world"]), rep(pc["found"]), rep(pc["sqrt_inv_noise"]), pc["init_pose"])
+    po, fo, uo = co.pose_gn(rep(pc["world"]), rep(pc["found"]), rep(pc["sqrt_inv_noise"]), pc["init_pose"])
+    assert np.allclose(ph, po, rtol=0, atol=1e-10) and np.array_equal(fh, fo)
+    assert np.allclose(uh, uo, rtol=1e-6, atol=1e-12)
+
+
 def test_pose_gn_device_resident_equals_host_entry(hip):
     """ptam_pose_gn_dev on resident buffers = ptam_pose_gn on host buffers, bit for bit (same kernel)"""
     pc = synth.make_pose_case()
