@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(1024) select_final_kernel(BaDev d, int est, do
 // finishes with the same radix select.  Histograms travel as doubles (the hook reduces fp64; counts are
 // exact).  A rank with more last-stage candidates than its slot holds raises select_overflow: the host
 // then repeats the LM step with the gather-everything path (thousands of bit-identical errors only).
-#define XCAND_CAP_DEFAULT 4096   // keys per rank slot (PTAM_XCAND_CAP overrides it: the tests force the overflow path)
+#define XCAND_CAP_DEFAULT 1024   // keys per rank slot (a 2^-16 relative window around the median holds ~1e-5 of the keys) (PTAM_XCAND_CAP overrides it: the tests force the overflow path)
 __global__ void hist_to_f64_kernel(const unsigned* __restrict__ h, double* __restrict__ out, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = (double)h[i];
