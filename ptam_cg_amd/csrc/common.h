@@ -53,7 +53,9 @@ struct ptam_ctx {
     void* d_scratch;
     size_t d_scratch_cap;
     void* h_pinned;
+    void* d_pinned;          // device address of h_pinned (host-mapped): kernels publish small results into it
     size_t h_pinned_cap;
+    unsigned long long pose_seq;
 };
 
 int ctx_scratch(ptam_ctx* ctx, size_t bytes, void** out);     // device scratch >= bytes

@@ -33,8 +33,10 @@ int ctx_pinned(ptam_ctx* ctx, size_t bytes, void** out) {
         ctx->h_pinned = nullptr;
         ctx->h_pinned_cap = 0;
         size_t cap = bytes + bytes / 2 + 4096;
-        HIP_TRY(hipHostMalloc(&ctx->h_pinned, cap, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&ctx->h_pinned, cap, hipHostMallocMapped | hipHostMallocCoherent));
         ctx->h_pinned_cap = cap;
+        std::memset(ctx->h_pinned, 0, cap);
+        HIP_TRY(hipHostGetDevicePointer(&ctx->d_pinned, ctx->h_pinned, 0));
     }
     *out = ctx->h_pinned;
     return PTAM_OK;

@@ -7,6 +7,8 @@
 // pose lives in LDS, per-measurement state in an L2-resident scratch array, the median is an exact
 // 8x8-bit MSB radix select over LDS histograms, the 27 normal-equation sums are reduced by wavefront
 // shuffles + a fixed-order cross-wave pass (deterministic), thread 0 solves and applies exp().
+#include <atomic>
+
 #include "common.h"
 
 struct PoseState {
@@ -540,7 +542,8 @@ __device__ __forceinline__ void small_project(const DevCam& cam, const double* p
 __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, int n, const ptam_pose_meas* __restrict__ meas,
                                                                    const ptam_projection* __restrict__ entry,
                                                                    double* __restrict__ pose_io, ptam_gn_opts opts,
-                                                                   int* __restrict__ flags, double* __restrict__ updates) {
+                                                                   int* __restrict__ flags, double* __restrict__ updates,
+                                                                   ulonglong2* __restrict__ host_slots, unsigned long long seq) {
     __shared__ GnSmallShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid < 12) sh.pose[tid] = pose_io[tid];
@@ -715,6 +718,9 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
         __syncthreads();
     }
     if (tid < 12) pose_io[tid] = sh.pose[tid];
+    // the refined pose also goes straight into host-mapped memory as (word, sequence) pairs the host spins on: the call
+    // returns one PCIe write after the last iteration instead of a D2H copy plus a stream synchronisation later
+    if (host_slots && tid < 12) host_slots[tid] = make_ulonglong2((unsigned long long)__double_as_longlong(sh.pose[tid]), seq);
 }
 
 __global__ void __launch_bounds__(GN_THREADS) calc_pose_update_kernel(int n, const ptam_pose_update_meas* __restrict__ meas,
@@ -775,51 +781,81 @@ int ptam_pose_gn(ptam_ctx* ctx, int n, const ptam_pose_meas* meas, const ptam_pr
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t bm = (size_t)n * sizeof(ptam_pose_meas), be = entry ? (size_t)n * sizeof(ptam_projection) : 0,
                  bs = (size_t)n * sizeof(PoseState), bf = (size_t)n * 4, bu = (size_t)6 * 32 * 8;
+    const size_t b_in = bm + be + 96;   // [measurements | entry state | pose]: ONE upload
     void* s;
-    int rc = ctx_scratch(ctx, bm + be + bs + bf + bu + 96 + 64, &s);
+    int rc = ctx_scratch(ctx, b_in + bs + bf + bu + 64, &s);
     if (rc) return rc;
     char* p = (char*)s;
     ptam_pose_meas* d_m = (ptam_pose_meas*)p;
-    p += bm;
-    ptam_projection* d_e = entry ? (ptam_projection*)p : nullptr;
-    p += be;
+    ptam_projection* d_e = entry ? (ptam_projection*)(p + bm) : nullptr;
+    double* d_pose = (double*)(p + bm + be);
+    p += b_in;
     PoseState* d_s = (PoseState*)p;
     p += bs;
-    double* d_pose = (double*)p;
-    p += 96;
     double* d_u = (double*)p;
     p += bu;
     int* d_f = (int*)p;
-    // host buffers are pageable: going through the context's pinned staging keeps every copy asynchronous, so the call
-    // has ONE synchronisation (a pageable hipMemcpyAsync blocks until its staging copy is done, each time)
-    const size_t bo = 96 + (outlier_flags ? bf : 0) + (updates_out ? sizeof(double) * 6 * o.iterations : 0);
+    // host buffers are pageable: everything goes through the context's pinned staging so that no copy blocks
+    // pinned layout: [inputs b_in][12 result slots of 16 B][flags][updates]
+    const bool small = n <= GS_THREADS * GS_MPT;
+    const size_t b_slots = 12 * 16, b_upd = sizeof(double) * 6 * o.iterations;
     void* pin;
-    rc = ctx_pinned(ctx, bm + be + 96 + bo + 64, &pin);
+    rc = ctx_pinned(ctx, b_in + b_slots + bf + b_upd + 64, &pin);
     if (rc) return rc;
     char* hp = (char*)pin;
     std::memcpy(hp, meas, bm);
     if (entry) std::memcpy(hp + bm, entry, be);
     std::memcpy(hp + bm + be, pose_inout, 96);
-    char* ho = hp + bm + be + 96;
-    HIP_TRY(hipMemcpyAsync(d_m, hp, bm, hipMemcpyHostToDevice, ctx->stream));
-    if (entry) HIP_TRY(hipMemcpyAsync(d_e, hp + bm, be, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_pose, hp + bm + be, 96, hipMemcpyHostToDevice, ctx->stream));
-    if (n <= GS_THREADS * GS_MPT)
-        hipLaunchKernelGGL(pose_gn_small_kernel, dim3(1), dim3(GS_THREADS), 0, ctx->stream, ctx->cam, n, d_m, d_e, d_pose,
-                           o, d_f, d_u);
+    const size_t o_slots = (b_in + 15) & ~(size_t)15;
+    volatile unsigned long long* slots = (volatile unsigned long long*)(hp + o_slots);
+    char* hf = hp + o_slots + b_slots;
+    char* hu = hf + bf;
+    for (int i = 0; i < 12; i++) slots[2 * i + 1] = 0;   // (the staging buffer is shared: no stale sequence numbers)
+    HIP_TRY(hipMemcpyAsync(d_m, hp, b_in, hipMemcpyHostToDevice, ctx->stream));
+    const unsigned long long seq = ++ctx->pose_seq;
+    if (small)
+        hipLaunchKernelGGL(pose_gn_small_kernel, dim3(1), dim3(GS_THREADS), 0, ctx->stream, ctx->cam, n, d_m, d_e, d_pose, o, d_f,
+                           d_u, (ulonglong2*)((char*)ctx->d_pinned + o_slots), seq);
     else
         hipLaunchKernelGGL(pose_gn_kernel, dim3(1), dim3(GN_THREADS), 0, ctx->stream, ctx->cam, n, d_m, d_e, d_pose, o,
                            d_s, d_f, d_u);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(ho, d_pose, 96, hipMemcpyDeviceToHost, ctx->stream));
-    char* hf = ho + 96;
-    char* hu = hf + (outlier_flags ? bf : 0);
+    const bool extras = outlier_flags || updates_out;
     if (outlier_flags) HIP_TRY(hipMemcpyAsync(hf, d_f, bf, hipMemcpyDeviceToHost, ctx->stream));
-    if (updates_out) HIP_TRY(hipMemcpyAsync(hu, d_u, sizeof(double) * 6 * o.iterations, hipMemcpyDeviceToHost, ctx->stream));
+    if (updates_out) HIP_TRY(hipMemcpyAsync(hu, d_u, b_upd, hipMemcpyDeviceToHost, ctx->stream));
+    if (small && !extras) {
+        // only the pose is wanted: spin on the twelve (word, sequence) pairs the kernel writes into host-mapped memory
+        auto arrived = [&]() {
+            for (int i = 0; i < 12; i++)
+                if (slots[2 * i + 1] != seq) return false;
+            return true;
+        };
+        unsigned spins = 0;
+        while (!arrived()) {
+            if (++spins == 100000) {
+                spins = 0;
+                const hipError_t q = hipStreamQuery(ctx->stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return PTAM_E_HIP;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        for (int i = 0; i < 12; i++) {
+            const unsigned long long w = slots[2 * i];
+            std::memcpy(&pose_inout[i], &w, 8);
+        }
+        return PTAM_OK;
+    }
+    if (!small) HIP_TRY(hipMemcpyAsync(hp + o_slots, d_pose, 96, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    std::memcpy(pose_inout, ho, 96);
+    if (small) {
+        for (int i = 0; i < 12; i++) {
+            const unsigned long long w = slots[2 * i];
+            std::memcpy(&pose_inout[i], &w, 8);
+        }
+    } else
+        std::memcpy(pose_inout, hp + o_slots, 96);
     if (outlier_flags) std::memcpy(outlier_flags, hf, bf);
-    if (updates_out) std::memcpy(updates_out, hu, sizeof(double) * 6 * o.iterations);
+    if (updates_out) std::memcpy(updates_out, hu, b_upd);
     return PTAM_OK;
 }
 
@@ -843,7 +879,7 @@ int ptam_pose_gn_dev(ptam_ctx* ctx, int n, const ptam_pose_meas* d_meas, const p
     double* d_u = d_updates ? d_updates : (double*)((char*)s + bs);
     if (n <= GS_THREADS * GS_MPT)
         hipLaunchKernelGGL(pose_gn_small_kernel, dim3(1), dim3(GS_THREADS), 0, ctx->stream, ctx->cam, n, d_meas, d_entry,
-                           d_pose_inout, o, d_outlier_flags, d_u);
+                           d_pose_inout, o, d_outlier_flags, d_u, (ulonglong2*)nullptr, 0ull);
     else
         hipLaunchKernelGGL(pose_gn_kernel, dim3(1), dim3(GN_THREADS), 0, ctx->stream, ctx->cam, n, d_meas, d_entry, d_pose_inout, o,
                            d_s, d_outlier_flags, d_u);
