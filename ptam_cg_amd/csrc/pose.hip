@@ -498,9 +498,9 @@ __device__ double small_select_kth(GnSmallShared& sh, int n, int k) {
 // CalcJacobian (include/Tracker.h:125-136) from the cached camera-frame point and derivatives.  The
 // fast path does not store J: v3Cam / m2CamDerivs only change on non-linear iterations, so
 // re-deriving J from them in the linear iterations gives the very values the reference keeps.
-__device__ __forceinline__ void small_jacobian(const double cam3[3], const double D[4], double J[12]) {
+// (iz = 1.0 / Z is cached with the point: v3Cam only changes on non-linear iterations, the quotient is the same value)
+__device__ __forceinline__ void small_jacobian(const double cam3[3], double iz, const double D[4], double J[12]) {
     const double X = cam3[0], Y = cam3[1], Z = cam3[2];
-    const double iz = 1.0 / Z;
     const double gx[6] = {1, 0, 0, 0, Z, -Y};
     const double gy[6] = {0, 1, 0, -Z, 0, X};
     const double gz[6] = {0, 0, 1, Y, -X, 0};
@@ -515,7 +515,7 @@ __device__ __forceinline__ void small_jacobian(const double cam3[3], const doubl
 
 struct SmallMeas {
     double world[3], fnd[2], sn;
-    double cam3[3], img[2], D[4];
+    double cam3[3], iz, img[2], D[4];
     int found;
 };
 
@@ -523,6 +523,7 @@ struct SmallMeas {
 __device__ __forceinline__ void small_project(const DevCam& cam, const double* pose, SmallMeas& t, bool& in_image) {
     in_image = false;
     se3_apply(pose, t.world[0], t.world[1], t.world[2], t.cam3[0], t.cam3[1], t.cam3[2]);
+    t.iz = 1.0 / t.cam3[2];
     if (t.cam3[2] < 0.001) return;
     const double x = t.cam3[0] / t.cam3[2], y = t.cam3[1] / t.cam3[2];
     if (x * x + y * y > cam.largest_radius * cam.largest_radius) return;
@@ -556,6 +557,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
         t[q].found = 0;
         t[q].cam3[0] = t[q].cam3[1] = 0;
         t[q].cam3[2] = 1;
+        t[q].iz = 1;
         t[q].img[0] = t[q].img[1] = 0;
         t[q].D[0] = t[q].D[1] = t[q].D[2] = t[q].D[3] = 0;
         t[q].world[0] = t[q].world[1] = t[q].world[2] = t[q].fnd[0] = t[q].fnd[1] = t[q].sn = 0;
@@ -576,6 +578,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
             if (entry) {
 #pragma unroll
                 for (int k = 0; k < 3; k++) t[q].cam3[k] = entry[i].cam[k];
+                t[q].iz = 1.0 / t[q].cam3[2];
                 t[q].img[0] = entry[i].image[0];
                 t[q].img[1] = entry[i].image[1];
 #pragma unroll
@@ -602,7 +605,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
                     small_project(cam, sh.pose, t[q], in_image);
                 } else if (iter != 0) {   // LinearUpdate include/Tracker.h:139-142
                     double J[12];
-                    small_jacobian(t[q].cam3, t[q].D, J);
+                    small_jacobian(t[q].cam3, t[q].iz, t[q].D, J);
                     double a = 0, b = 0;
 #pragma unroll
                     for (int m = 0; m < 6; m++) {
@@ -647,7 +650,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
                     continue;
                 }
                 double Jm[12];
-                small_jacobian(t[q].cam3, t[q].D, Jm);
+                small_jacobian(t[q].cam3, t[q].iz, t[q].D, Jm);
                 const double er[2] = {ex[q], ey[q]};
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
