@@ -1774,7 +1774,8 @@ __global__ void __launch_bounds__(BA_CHUNK) point_update_kernel(DevCam cam, BaDe
     }
 }
 
-__global__ void __launch_bounds__(256) finalize_new_kernel(BaDev d, double conv_limit, int last_allowed) {
+__global__ void __launch_bounds__(256) finalize_new_kernel(BaDev d, double conv_limit, int last_allowed, ulonglong2* host_slots,
+                                                            unsigned long long seq) {
     __shared__ double w[4][2];
     double e = 0, s = 0;
     // fixed assignment + fixed combine order: deterministic
@@ -1799,6 +1800,13 @@ __global__ void __launch_bounds__(256) finalize_new_kernel(BaDev d, double conv_
         const bool end_step = !(ne > ce) || conv || last_allowed != 0;
         d.sc->end_step = end_step ? 1 : 0;
         d.sc->spec_go = (end_step && ne < ce && !conv && last_allowed == 0) ? 1 : 0;
+    }
+    // single-device runs publish the scalars from here (publish_scalars_kernel's job, one launch less per trial)
+    if (host_slots) {
+        __threadfence_block();
+        __syncthreads();
+        if (threadIdx.x < sizeof(BaScalars) / 8)
+            host_slots[threadIdx.x] = make_ulonglong2(((const volatile unsigned long long*)d.sc)[threadIdx.x], seq);
     }
 }
 
@@ -1899,6 +1907,7 @@ struct ptam_ba {
     Mailbox* mbox = nullptr;       // host address
     Mailbox* mbox_dev = nullptr;   // device address of the same memory
     unsigned long long mbox_seq = 0;
+    bool published_by_finalize = false;
     bool trial_is_current = false;   // the last trial was accepted: its new-error pass == pass 1 of the next step
     int k7_threads = BA_CHUNK;
     bool k7_loop = false;
@@ -2438,6 +2447,18 @@ static int ba_pass2(ptam_ba* ba) {
     return PTAM_OK;
 }
 
+static int ba_ensure_mailbox(ptam_ba* ba) {
+    if (ba->mbox) return PTAM_OK;
+    void* h = nullptr;
+    HIP_TRY(hipHostMalloc(&h, sizeof(ptam_ba::Mailbox), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(h, 0, sizeof(ptam_ba::Mailbox));
+    void* dv = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dv, h, 0));
+    ba->mbox = (ptam_ba::Mailbox*)h;
+    ba->mbox_dev = (ptam_ba::Mailbox*)dv;
+    return PTAM_OK;
+}
+
 static int ba_trial(ptam_ba* ba, double lambda, bool skip_vinv, int last_allowed) {
     ptam_ctx* ctx = ba->ctx;
     BaDev& d = ba->d;
@@ -2470,7 +2491,21 @@ static int ba_trial(ptam_ba* ba, double lambda, bool skip_vinv, int last_allowed
     if (d.n_chunks > 0)
         hipLaunchKernelGGL(point_update_kernel, dim3(d.n_chunks), dim3(BA_CHUNK), 0, ctx->stream, ctx->cam, d, ba->cur,
                            ba->opts.estimator);
-    hipLaunchKernelGGL(finalize_new_kernel, dim3(1), dim3(256), 0, ctx->stream, d, ba->opts.update_sq_conv_limit, last_allowed);
+    {
+        // single device, no per-kernel events: finalize publishes the scalars itself
+        const bool fuse = !(ba->comm && ba->world > 1) && !ba->prof;
+        ulonglong2* slots = nullptr;
+        unsigned long long seq = 0;
+        if (fuse) {
+            const int rcm = ba_ensure_mailbox(ba);
+            if (rcm) return rcm;
+            slots = (ulonglong2*)ba->mbox_dev;
+            seq = ++ba->mbox_seq;
+            ba->published_by_finalize = true;
+        }
+        hipLaunchKernelGGL(finalize_new_kernel, dim3(1), dim3(256), 0, ctx->stream, d, ba->opts.update_sq_conv_limit, last_allowed,
+                           slots, seq);
+    }
     prof_end(ba, PTAM_K_UPDATE);
     HIP_TRY(hipGetLastError());
     if (ba->comm && ba->world > 1) {
@@ -2514,14 +2549,11 @@ static int ba_read_scalars(ptam_ba* ba, BaScalars* out) {
 
 static int ba_publish_scalars(ptam_ba* ba) {
     ptam_ctx* ctx = ba->ctx;
-    if (!ba->mbox) {
-        void* h = nullptr;
-        HIP_TRY(hipHostMalloc(&h, sizeof(ptam_ba::Mailbox), hipHostMallocMapped | hipHostMallocCoherent));
-        std::memset(h, 0, sizeof(ptam_ba::Mailbox));
-        void* dv = nullptr;
-        HIP_TRY(hipHostGetDevicePointer(&dv, h, 0));
-        ba->mbox = (ptam_ba::Mailbox*)h;
-        ba->mbox_dev = (ptam_ba::Mailbox*)dv;
+    int rc = ba_ensure_mailbox(ba);
+    if (rc) return rc;
+    if (ba->published_by_finalize) {   // the trial's finalize kernel already wrote sequence number mbox_seq
+        ba->published_by_finalize = false;
+        return PTAM_OK;
     }
     const unsigned long long seq = ++ba->mbox_seq;
     hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(64), 0, ctx->stream, (const BaScalars*)ba->d.sc,
