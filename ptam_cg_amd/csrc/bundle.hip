@@ -2764,6 +2764,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     BaDev& d = ba->d;
     double lambda = 0.0001, lambda_factor = 2.0;   // :125-126
     ba->converged = false;
+    ba->published_by_finalize = false;
     ba->cur_pending = false;
     ba->slow_select = false;
     ba->trial_is_current = false;

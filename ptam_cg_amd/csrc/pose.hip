@@ -112,7 +112,7 @@ __device__ void ldlt6_solve(double A[36], const double b[6], double x[6]) {
         for (int j = 0; j < i; j++) val -= A[i * 6 + j] * y[j];
         y[i] = val;
     }
-    for (int i = 0; i < 6; i++) y[i] /= A[i * 6 + i];
+    for (int i = 0; i < 6; i++) y[i] /= A[i * 6 + i];   // (kept as divisions: bit-identical D-scale to TooN's backsub)
     for (int i = 5; i >= 0; i--) {
         double val = y[i];
         for (int j = i + 1; j < 6; j++) val -= A[j * 6 + i] * x[j];
@@ -712,7 +712,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
                 ldlt6_solve(C, b, x);
             }
             double np[12];
-            se3_exp_mul(x, sh.pose, np);   // mse3CamFromWorld = SE3<>::exp(v6Update) * mse3CamFromWorld
+            se3_exp_mul<true>(x, sh.pose, np);   // mse3CamFromWorld = SE3<>::exp(v6Update) * mse3CamFromWorld
             for (int k = 0; k < 12; k++) sh.pose[k] = np[k];
             for (int k = 0; k < 6; k++) sh.mu[k] = x[k];
             if (updates)
