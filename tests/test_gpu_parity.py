@@ -228,6 +228,29 @@ def test_bundle_trial_by_trial(hip, oracle, case):
     assert np.abs(rh["points"] - prob["points_true"]).mean() < np.abs(prob["points"] - prob["points_true"]).mean()
 
 
+def _fuzz_cases(n=18, seed=2024):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        n_cams = int(rng.integers(3, 71))
+        n_pts = int(rng.integers(6, 500))
+        window = None if rng.random() < 0.4 else int(rng.integers(2, max(3, n_cams)))
+        out.append(dict(n_cams=n_cams, n_pts=n_pts, seed=1000 + i, window=window, n_fixed=int(rng.integers(1, min(4, n_cams))),
+                        outlier_frac=float(rng.choice([0.0, 0.02, 0.1])), pt_noise=float(rng.choice([0.002, 0.01, 0.03]))))
+    return out
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(), ids=lambda c: f"{c['n_cams']}x{c['n_pts']}w{c['window']}f{c['n_fixed']}")
+def test_bundle_random_shapes(hip, oracle, case):
+    """random camera counts (tile / block padding of the Schur and LDL^T kernels), covisibility windows (absent-camera
+    zero blocks, banded systems), several fixed cameras, outlier rates: trial by trial against the oracle"""
+    prob = synth.make_ba_problem(**case)
+    if len(prob["cam_idx"]) == 0:
+        pytest.skip("no measurement survived the visibility test")
+    est = [_abi.EST_TUKEY, _abi.EST_CAUCHY, _abi.EST_HUBER][case["seed"] % 3]
+    util.assert_ba_equal(util.run_ba(hip, prob, estimator=est), util.run_ba(oracle, prob, estimator=est), rel=1e-6)
+
+
 @pytest.mark.parametrize("est", [_abi.EST_CAUCHY, _abi.EST_HUBER])
 def test_bundle_other_estimators(hip, oracle, est):
     prob = synth.make_ba_problem(10, 150, 9)
