@@ -1438,6 +1438,9 @@ __global__ void __launch_bounds__(256) schur_tile_mfma_kernel(BaDev d) {
     const bool diag = a == b;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int le = tid >> 4, ls = tid & 15;   // loader role: local entry, lane within the entry
+    // 16-row fragments that hold cameras at all: the last tile of a system is usually partial (F = 50: two cameras =
+    // one fragment of three), and its empty fragments are not multiplied
+    const int rb_a = (6 * min(SCHUR_TC, d.F - a * SCHUR_TC) + 15) >> 4, rb_b = (6 * min(SCHUR_TC, d.F - b * SCHUR_TC) + 15) >> 4;
     v4f64 acc[3][3];
     double accE[3] = {0, 0, 0};
 #pragma unroll
@@ -1488,7 +1491,7 @@ __global__ void __launch_bounds__(256) schur_tile_mfma_kernel(BaDev d) {
             for (int ti = 0; ti < 3; ti++)
 #pragma unroll
                 for (int tj = 0; tj < 3; tj++)
-                    if (ti >= tj || !diag)   // a diagonal pair only needs its lower triangle (those tiles stay zero)
+                    if ((ti >= tj || !diag) && ti < rb_a && tj < rb_b)   // a diagonal pair only needs its lower triangle
                         acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ti], bf[tj], acc[ti][tj], 0, 0, 0);
             if (diag) {
                 const double eb = st.eB[kc];
@@ -2075,7 +2078,9 @@ static int ba_prepare_impl(ptam_ba* ba) {
     {
         size_t total = 0;
         for (auto& v : per_pair) total += v.size();
-        // ~2 resident workgroups per CU x 256 CUs in ONE round; whole LDS batches per workgroup
+        // ~2 resident workgroups per CU x 256 CUs in ONE round; whole LDS batches per workgroup.  Entries are dealt out
+        // evenly although pairs with a partial last tile multiply fewer fragments: weighting by MFMA count measured
+        // SLOWER (103 vs 83 us) — the staging of an entry costs more than its fragments
         int per_wg = (int)std::min<size_t>(2048, std::max<size_t>(64, total / 500 + 1));
         per_wg = (per_wg + SCHUR_BATCH - 1) / SCHUR_BATCH * SCHUR_BATCH;
         for (int pr = 0; pr < n_pairs; pr++) {
