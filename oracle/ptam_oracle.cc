@@ -1021,6 +1021,9 @@ struct Bundle {
 
         const int n = mnCamsToUpdate * 6;
         double dNewError = dCurrentError + 9999;
+        // NaN / inf current error: the reference never enters the trial loop below, returns true, and Compute() calls it
+        // again for ever.  The restatement (and the product) give up instead, so that a test cannot hang.
+        if (!(dNewError > dCurrentError)) mbHitMaxIterations = true;
         int nBadSoFar = 0;
         for (auto& m : mMeasList) nBadSoFar += m.bBad;
         {

@@ -395,7 +395,8 @@ __device__ unsigned long long block_radix_select(const double* src, int n, int k
         __syncthreads();
         for (int i = tid; i < n; i += 1024) {
             const unsigned long long key = (unsigned long long)__double_as_longlong(src[i]);
-            if ((key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 255], 1u);
+            // (shift + 8 == 64 on a full-width first pass: nothing is fixed yet, and a 64-bit shift by 64 is undefined)
+            if (shift + 8 >= 64 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 255], 1u);
         }
         __syncthreads();
         if (tid < 64) {
@@ -2580,12 +2581,23 @@ static int ba_wait_scalars(ptam_ba* ba, BaScalars* out) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));   // the profiling events must have completed as well
     } else {
         // spin on the sequence words; every now and then ask the runtime whether the stream died instead
-        unsigned spins = 0;
+        unsigned spins = 0, idle_polls = 0, dbg_polls = 0;
         while (!arrived()) {
             if (++spins == 100000) {
                 spins = 0;
                 const hipError_t q = hipStreamQuery(ctx->stream);
                 if (q != hipSuccess && q != hipErrorNotReady) return PTAM_E_HIP;
+                if (getenv("PTAM_DEBUG_WAIT") && (++dbg_polls % 100) == 0) {
+                    std::fprintf(stderr, "[ptam] waiting for seq %llu: stream %s, slots", seq, q == hipSuccess ? "drained" : "busy");
+                    for (unsigned i = 0; i < NW; i++) std::fprintf(stderr, " %llu", (unsigned long long)ba->mbox->slot[i].seq);
+                    std::fprintf(stderr, "\n");
+                }
+                if (q == hipSuccess && !arrived() && ++idle_polls > 50) {
+                    // the stream has drained and nothing published this sequence number: a logic error, not a wait
+                    ptam_set_error("scalar mailbox: sequence %llu never arrived (slot 0 holds %llu)", seq,
+                                   (unsigned long long)ba->mbox->slot[0].seq);
+                    return PTAM_E_STATE;
+                }
             }
         }
     }
@@ -2760,12 +2772,17 @@ int ptam_ba_set_comm(ptam_ba* ba, int rank, int world, ptam_allreduce_f64_fn fn,
 }
 
 // Bundle::Compute src/Bundle.cc:116-158
+#define BA_DBG(...) do { if (dbg_) { std::fprintf(stderr, "[ptam] " __VA_ARGS__); std::fprintf(stderr, "\n"); } } while (0)
 int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* accepted_out) {
     ARG_TRY(ba);
     ptam_ctx* ctx = ba->ctx;
+    const bool dbg_ = getenv("PTAM_DEBUG_WAIT") != nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
+    BA_DBG("compute: prepare");
     int rc = ptam_ba_prepare(ba);
     if (rc) return rc;
+    BA_DBG("compute: prepared M=%d P=%d F=%d chunks=%d wchunks=%d grid_acc=%d schur_wg=%d", ba->d.M, ba->d.P, ba->d.F, ba->d.n_chunks,
+           ba->d.n_wchunks, ba->d.grid_acc, ba->d.n_schur_wg);
     BaDev& d = ba->d;
     double lambda = 0.0001, lambda_factor = 2.0;   // :125-126
     ba->converged = false;
@@ -2806,11 +2823,12 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
         }
         bool have_cur = false;
         double cur_err = 0, new_err = 0;
-        bool ran_any = false, redo_step = false;
+        bool ran_any = false, redo_step = false, nan_stop = false;
         // while(dNewError > dCurrentError && !converged && !hitmax && !abort)  :338
         for (;;) {
             if (have_cur && !(new_err > cur_err)) break;
             if (ba->converged || hit_max || aborted()) break;
+            BA_DBG("trial %d lambda %g", counter, lambda);
             rc = ba_trial(ba, lambda, skip_vinv, counter + 1 >= ba->opts.max_iterations ? 1 : 0);
             skip_vinv = false;
             if (rc) return rc;
@@ -2820,8 +2838,11 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
                 rc = ba_enqueue_speculative(ba, lambda * 0.3);
                 if (rc) return rc;
             }
+            BA_DBG("trial %d enqueued, waiting", counter);
             rc = ba_wait_scalars(ba, &sc);
             if (rc) return rc;
+            BA_DBG("trial %d read: cur %g new %g sigma2 %g median %g n_valid %lld n_bad %d sumsq %g %g", counter, sc.cur_err, sc.new_err,
+                   sc.sigma_sq, sc.median, sc.n_valid, sc.n_bad, sc.sumsq_cam, sc.sumsq_pt);
 #ifdef K7_TIMING
             if (ht_first == 0) ht_first = now_us();
 #endif
@@ -2841,7 +2862,12 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
                 have_cur = true;
                 cur_err = sc.cur_err;
                 new_err = cur_err + 9999;   // :337
-                if (!(new_err > cur_err)) break;   // NaN/inf current error: the reference never enters the loop
+                if (!(new_err > cur_err)) {
+                    // NaN / inf current error: the reference never enters its trial loop and then calls Do_LM_Step again
+                    // for ever (src/Bundle.cc:118-123 has no exit for it).  A library must not hang: give up here.
+                    nan_stop = true;
+                    break;
+                }
             }
             ran_any = true;
             new_err = sc.new_err;
@@ -2866,6 +2892,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
             ba->trials.push_back(t);
         }
         if (redo_step) continue;   // (keeps trial_is_current: pass 1 may still adopt the previous trial's errors)
+        if (nan_stop) hit_max = true;
         ba->trial_is_current = false;
         if (ran_any && new_err < cur_err) {   // :523-533
             lambda_factor = 2.0;
@@ -2889,6 +2916,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
         HIP_TRY(hipGetLastError());
         n_steps++;
     }
+    BA_DBG("loop done, steps %d", n_steps);
     if (n_steps > 0) {   // the last step's purge
         rc = ba_read_scalars(ba, &sc);
         if (rc) return rc;

@@ -274,6 +274,31 @@ def test_bundle_noise_free_is_fixed_point(hip):
     assert len(r["outliers"]) == 0
 
 
+def test_bundle_tiny_errors_and_degenerate_systems(hip, oracle):
+    """(a) errors far below 2^-24 (the first-level bin of the select is then the clamped end bin: a full-width radix
+    pass — a 64-bit shift by 64 once returned garbage there); (b) one point seen by six cameras: five free cameras
+    constrained by twelve equations, a singular camera system that only the damping keeps solvable — both sides must
+    walk the same trials and must terminate"""
+    prob = synth.make_ba_problem(6, 80, 2, outlier_frac=0.0)
+    cam = synth.AtanCam()
+    f = np.zeros_like(prob["found"])
+    for i, (c, p) in enumerate(zip(prob["cam_idx"], prob["pt_idx"])):
+        _, im = cam.visible(prob["poses_true"][c], prob["points_true"][p:p + 1])
+        f[i] = im[0]
+    prob["found"] = f + np.random.default_rng(3).normal(0, 1e-6, f.shape)      # e^2 ~ 1e-12
+    prob["poses"], prob["points"] = prob["poses_true"].copy(), prob["points_true"].copy()
+    rh, ro = util.run_ba(hip, prob, max_iterations=4), util.run_ba(oracle, prob, max_iterations=4)
+    util.assert_ba_equal(rh, ro, rel=1e-6)
+    assert rh["trials"]["sigma_sq"].max() < 1.0          # = MinTukeySigma^2, not a garbage order statistic
+    p = synth.make_ba_problem(6, 40, 3)
+    keep = p["pt_idx"] == 0
+    q = {k: (v[keep] if k in ("cam_idx", "pt_idx", "found", "sigma_sq") else v) for k, v in p.items()}
+    q["points"], q["points_true"] = p["points"][:1], p["points_true"][:1]
+    rh, ro = util.run_ba(hip, q, max_iterations=6), util.run_ba(oracle, q, max_iterations=6)
+    assert len(rh["trials"]) == len(ro["trials"]) and np.array_equal(rh["trials"]["accepted"], ro["trials"]["accepted"])
+    assert np.allclose(rh["trials"]["sigma_sq"], ro["trials"]["sigma_sq"], rtol=1e-6)
+
+
 def test_bundle_abort_and_limits(hip):
     prob = synth.make_ba_problem(6, 60, 5)
     ctx = host.Context(lib=hip)
