@@ -2805,6 +2805,22 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     const double ht0 = now_us();
     double ht_first = 0;
 #endif
+    if (ba->comm && ba->world > 1) {
+        // every rank must walk the same sequence of collectives: a rank without measurements would leave the loop below
+        // at once and the others would wait for it for ever.  One tiny all-reduce up front makes the refusal unanimous.
+        const double mine[2] = {d.M == 0 ? 1.0 : 0.0, (double)d.M};
+        double all[2];
+        HIP_TRY(hipMemcpyAsync(ba->d_xchg, mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
+        rc = ba_allreduce(ba, ba->d_xchg, 2);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(all, ba->d_xchg, sizeof all, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (all[0] > 0.5) {
+            ptam_set_error("sharded bundle: %d of %d ranks hold no measurement (shard the points so that every rank gets some)",
+                           (int)(all[0] + 0.5), ba->world);
+            return PTAM_E_STATE;
+        }
+    }
     const bool empty = d.M == 0;
     // speculative step prologue (ba_enqueue_speculative): single device, not while per-kernel events are being taken
     const bool spec = !(ba->comm && ba->world > 1) && !ba->prof && d.n_chunks > 0 && !getenv("PTAM_NO_SPECULATION");

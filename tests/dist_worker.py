@@ -30,7 +30,17 @@ def main():
     ctx = host.Context(lib=lib)
     ba = synth.load_into(host.Bundle(ctx), mine)
     ba.set_comm(rank, world, torch_allreduce_hook(ctx, device_ptr=(which == "hip")))
-    acc = ba.Compute()
+    try:
+        acc = ba.Compute()
+    except host.PtamError as e:          # (every rank raises together: the refusal is decided by a collective)
+        errs = [None] * world
+        dist.all_gather_object(errs, str(e))
+        if rank == 0:
+            with open(out_path, "wb") as f:
+                pickle.dump(dict(error=errs), f)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     poses, pts = ba.get_all()
 
     def all_gather(obj):

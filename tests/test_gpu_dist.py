@@ -30,6 +30,13 @@ def test_sharded_select_with_ties_and_slot_overflow(oracle):
         dist_util.check_sharded_equals_single(res, oracle, case, rel=1e-6)
 
 
+def test_sharded_rank_without_measurements_is_refused_by_all_ranks():
+    """two points over three ranks: rank 2 owns nothing.  It must not drop out of the collectives silently (the others
+    would wait for ever): every rank returns the same error"""
+    res = dist_util.run_sharded("hip", 3, dict(n_cams=4, n_pts=2, seed=1), timeout=120)
+    assert "error" in res and len(res["error"]) == 3 and all("no measurement" in e for e in res["error"])
+
+
 def test_rccl_single_rank_allreduce(hip):
     ctx = host.Context(lib=hip)
     ident = (C.c_uint8 * 128)()
