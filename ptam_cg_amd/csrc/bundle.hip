@@ -860,7 +860,12 @@ __device__ __forceinline__ void k7_load(const BaDev& d, const double* __restrict
 #ifdef K7_NOW
 #define K7_WSTORE(dst, v) { const double2 v_ = v; asm volatile("" ::"v"(v_.x), "v"(v_.y)); }
 #else
-#define K7_WSTORE(dst, v) dst = v
+// W is written once and read by the NEXT kernel from every XCD: write-through (sc1) 16-byte stores leave no dirty
+// lines for the end-of-kernel L2 write-back (measured -7 % launch time at 50 x 5000; `nt` is slower).
+// The s_nop covers the gfx940+ hazard the compiler cannot see inside the asm: a VALU write of the data registers
+// of a > 64-bit global store needs two wait states after it.
+typedef double k7_d2 __attribute__((ext_vector_type(2)));
+#define K7_WSTORE(dst, v) { const double2 v_ = v; const k7_d2 w_ = {v_.x, v_.y}; asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(&(dst)), "v"(w_) : "memory"); }
 #endif
 template <int THREADS, bool PREFETCH, bool LOOP, int EST>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
@@ -2116,6 +2121,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     //    which amortises the LDS prologue and the camera-partial flush.
     const int n64_all = (M + 63) / 64;
     ba->k7_loop = ba->use_wave && n64_all > 256 * 24;
+    if (const char* e = getenv("PTAM_K7_LOOP")) ba->k7_loop = ba->use_wave && atoi(e) != 0;   // shape sweeps (tools/k7_only.py)
     ba->k7_threads = !ba->use_wave ? BA_CHUNK : (ba->k7_loop ? 256 : 512);
     int n_cu = 256;
     {
@@ -2147,6 +2153,17 @@ static int ba_prepare_impl(ptam_ba* ba) {
         }
     }
     per_cu = std::max(1, std::min(per_cu, 8));
+    if (ba->use_wave && ba->k7_loop) {
+        if (const char* e = getenv("PTAM_K7_THREADS")) {
+            const int t = atoi(e);
+            if (t == 256 || t == 512) {
+                ba->k7_threads = t;
+                if (int rc = k7_occupancy(t, &per_cu)) return rc;
+                per_cu = std::max(1, std::min(per_cu, 8));
+            }
+        }
+        if (const char* e = getenv("PTAM_K7_WG_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));
+    }
     if (ba->use_wave) {
         // every wave gets the same number of consecutive 64-measurement chunks
         // one 64-measurement chunk per wave (straight-line kernel body: 68 VGPRs instead of ~160 for the
