@@ -75,6 +75,8 @@ struct BaDev {
     double* V;
     double* epsB;
     double* Vinv;
+    double* cut;            // wave variant of K7: [2 * ceil(M/64)][9] V|epsB pieces of the points a 64-measurement chunk
+                            // boundary cuts (slot 2c: the chunk's leading segment, 2c+1: its trailing one); null otherwise
     int* rowptr;
     // measurements
     int* m_cam;

@@ -180,17 +180,6 @@ __global__ void __launch_bounds__(BA_CHUNK) project_e2_kernel(DevCam cam, BaDev 
         const int m = ch.m_begin + tid;
         if (m < ch.m_end) {
             const int st = d.m_state[m];
-            if ((m & 63) == 0 && m > 0) {
-                // a point cut by a 64-measurement boundary is completed by atomics in K7's wave
-                // variant: clear its accumulators here, one pass ahead
-                const int pc = d.m_pt[m];
-                if (d.rowptr[pc] < m) {
-#pragma unroll
-                    for (int i = 0; i < 6; i++) d.V[(size_t)pc * 6 + i] = 0;
-#pragma unroll
-                    for (int i = 0; i < 3; i++) d.epsB[(size_t)pc * 3 + i] = 0;
-                }
-            }
             if (st != MS_DEAD) {
                 const int c = d.m_cam[m], p = d.m_pt[m];
                 BaProj pr;
@@ -218,44 +207,93 @@ __global__ void __launch_bounds__(BA_CHUNK) project_e2_kernel(DevCam cam, BaDev 
 }
 
 // Pass 1 of the step that follows an ACCEPTED trial: the trial's new-error pass (point_update_kernel)
-// already projected every measurement with what are now the current poses / points, so this kernel only
-// adopts its squared errors and z <= 0 flags, clears the accumulators of boundary-cut points and builds
-// the histogram — no projection (K5 proper is project_e2_kernel above).
+// already projected every measurement with what are now the current poses / points, so this only
+// adopts its squared errors and z <= 0 flags and builds the histogram — no projection (K5 proper is project_e2_kernel above).  With PURGE it first closes the
+// finished step (purge_kernel's body: erase bad measurements, append to the outlier list :536-547).
+// P1_U measurements per thread, every load issued (clamped, unconditional) before the first use: the
+// kernel is a chain of dependent round trips otherwise (state -> flag -> e^2), ~1 us each.
+#ifndef P1_U
+#define P1_U 8
+#endif
+template <bool PURGE>
+__device__ __forceinline__ void pass1_adopt(const BaDev& d, bool adopt, bool build_hist, unsigned* hist) {
+    constexpr int U = P1_U;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int m_end = (d.M + 63) & ~63;   // whole waves stay together for the ballot
+    for (int base = blockIdx.x * (256 * U); base < m_end; base += gridDim.x * (256 * U)) {
+        int m[U], st[U], zb[U];
+        double e2[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            m[u] = base + u * 256 + tid;
+            const int mc = min(m[u], d.M - 1);
+            st[u] = m[u] < d.M ? (int)d.m_state[mc] : (int)MS_DEAD;
+            zb[u] = d.m_zbad_t[mc];
+            e2[u] = d.m_e2t[mc];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool in = m[u] < d.M;
+            if (PURGE) {
+                const bool bad = st[u] == MS_BAD;
+                const unsigned long long mask = __ballot(bad);
+                if (mask != 0) {
+                    int at = 0;
+                    if (lane == 0) at = atomicAdd(&d.sc->n_outliers, __popcll(mask));   // one atomic per wave
+                    at = __shfl(at, 0, 64);
+                    if (bad) {
+                        d.outliers[at + __popcll(mask & ((1ull << lane) - 1ull))] = d.m_orig[m[u]];
+                        d.m_state[m[u]] = MS_DEAD;
+                        st[u] = MS_DEAD;
+                    }
+                }
+            }
+            if (!adopt || !in) continue;
+            if (st[u] == MS_DEAD) continue;
+            if (zb[u]) {
+                d.m_state[m[u]] = MS_BAD;
+            } else {
+                d.m_e2[m[u]] = e2[u];
+                if (st[u] != MS_ALIVE) d.m_state[m[u]] = MS_ALIVE;
+#ifndef P1_NOLDS
+                if (build_hist) atomicAdd(&hist[e2_bin(e2[u])], 1u);
+#endif
+            }
+        }
+    }
+}
+__device__ __forceinline__ void hist_clear(unsigned* hist) {
+    for (int b = threadIdx.x; b < HIST_BINS; b += 256) hist[b] = 0;
+    __syncthreads();
+}
+__device__ __forceinline__ void hist_flush(const BaDev& d, const unsigned* hist) {
+    __syncthreads();
+    for (int b = threadIdx.x; b < HIST_BINS; b += 256) {
+        const unsigned c = hist[b];
+#ifndef P1_NOFLUSH
+        if (c) atomicAdd(&d.hist[b], c);
+#else
+        if (c == 0xffffffffu) d.hist[b] = c;
+#endif
+    }
+}
 __global__ void __launch_bounds__(256) pass1_from_trial_kernel(BaDev d, int build_hist) {
     if (ba_guard_blocks(d)) return;
     __shared__ unsigned hist[HIST_BINS];
-    const int tid = threadIdx.x;
-    if (build_hist)
-        for (int b = tid; b < HIST_BINS; b += 256) hist[b] = 0;
-    __syncthreads();
-    for (int m = blockIdx.x * 256 + tid; m < d.M; m += gridDim.x * 256) {
-        if ((m & 63) == 0 && m > 0) {
-            const int pc = d.m_pt[m];
-            if (d.rowptr[pc] < m) {
-#pragma unroll
-                for (int i = 0; i < 6; i++) d.V[(size_t)pc * 6 + i] = 0;
-#pragma unroll
-                for (int i = 0; i < 3; i++) d.epsB[(size_t)pc * 3 + i] = 0;
-            }
-        }
-        const int st = d.m_state[m];
-        if (st == MS_DEAD) continue;
-        if (d.m_zbad_t[m]) {
-            d.m_state[m] = MS_BAD;
-        } else {
-            const double e2 = d.m_e2t[m];
-            d.m_e2[m] = e2;
-            if (st != MS_ALIVE) d.m_state[m] = MS_ALIVE;
-            if (build_hist) atomicAdd(&hist[e2_bin(e2)], 1u);
-        }
-    }
-    if (build_hist) {
-        __syncthreads();
-        for (int b = tid; b < HIST_BINS; b += 256) {
-            const unsigned c = hist[b];
-            if (c) atomicAdd(&d.hist[b], c);
-        }
-    }
+    if (build_hist) hist_clear(hist);
+    pass1_adopt<false>(d, true, build_hist != 0, hist);
+    if (build_hist) hist_flush(d, hist);
+}
+// The speculative step prologue's first launch: the purge that closes the finished step (guarded by end_step)
+// and, if the loop goes on from an accepted trial (spec_go), pass 1 from the trial's errors — one dependent
+// launch (~2.3 us) less than purge_kernel + pass1_from_trial_kernel.
+__global__ void __launch_bounds__(256) purge_pass1_kernel(BaDev d) {
+    if (d.sc->end_step == 0) return;
+    const bool go = d.sc->spec_go != 0;
+    __shared__ unsigned hist[HIST_BINS];
+    if (go) hist_clear(hist);
+    pass1_adopt<true>(d, go, go, hist);
+    if (go) hist_flush(d, hist);
 }
 
 // =================================================================================================
@@ -804,9 +842,9 @@ __device__ __forceinline__ void jac_flush(const BaDev& d, const double* Ul, doub
 //    lane and handed to their measurements by ds_bpermute: ONE global round trip per chunk;
 //  - U / epsA: ds_add_f64 into the workgroup's LDS partials;
 //  - V / epsB: segmented inclusive scan over the wave (DPP row shifts + row broadcasts, fixed tree).
-//    A point lying inside the chunk is stored by its last lane; a point cut by a chunk boundary
-//    (at most two pieces since n_i <= 64) is completed with fp64 atomics on the zeroed V / epsB —
-//    0 + a + b is order independent, so the result stays deterministic;
+//    A point lying inside the chunk is stored by its last lane; a point cut by a chunk boundary leaves
+//    one piece per chunk in d.cut (plain stores) and vinv_kernel adds them in chunk order — no global
+//    atomics (device-scope fp64 atomics cost this launch ~1.9 us at 50 x 5000), no zeroing pass;
 //  - W: 9 coalesced double2 planes.
 // dynamic LDS: Ul[F*27] | poses[C*12] + 1 spare slot
 struct K7In {
@@ -1056,22 +1094,16 @@ jac_accum_wave_kernel(DevCam cam, BaDev d, int cur, int est_arg, int per_wave, i
         K7_STAMP(7)
         const int pn = __shfl_down(pid, 1, 64);
         if (active && (lane == 63 || pn != pid)) {
-            double* Vp = d.V + (size_t)pid * 6;
-            double* Ep = d.epsB + (size_t)pid * 3;
+            // a point cut by a chunk boundary leaves its piece in the chunk's slot (leading segment: 2c, trailing:
+            // 2c + 1); vinv_kernel adds the pieces in chunk order — plain stores, no zeroing pass, fixed order
             const bool whole = pid != cu.p_prev && pid != cu.p_next;
-            if (whole) {
+            double* Vp = whole ? d.V + (size_t)pid * 6 : d.cut + (size_t)(2 * ci + (pid == cu.p_prev ? 0 : 1)) * 9;
+            double* Ep = whole ? d.epsB + (size_t)pid * 3 : Vp + 6;
 #pragma unroll
-                for (int i = 0; i < 6; i++) Vp[i] = v[i];
-                Ep[0] = v[6];
-                Ep[1] = v[7];
-                Ep[2] = v[8];
-            } else {   // the point is cut by a chunk boundary: two pieces meet in the zeroed slot
-#pragma unroll
-                for (int i = 0; i < 6; i++) atomicAdd(&Vp[i], v[i]);
-                atomicAdd(&Ep[0], v[6]);
-                atomicAdd(&Ep[1], v[7]);
-                atomicAdd(&Ep[2], v[8]);
-            }
+            for (int i = 0; i < 6; i++) Vp[i] = v[i];
+            Ep[0] = v[6];
+            Ep[1] = v[7];
+            Ep[2] = v[8];
         }
         if (!LOOP) break;
     }
@@ -1093,20 +1125,6 @@ static const void* k7_wave_fn(int threads, bool loop, int est) {
                      : (const void*)jac_accum_wave_kernel<256, false, true, -1>;
     return tukey ? (const void*)jac_accum_wave_kernel<512, true, true, PTAM_EST_TUKEY>
                  : (const void*)jac_accum_wave_kernel<512, false, true, -1>;
-}
-
-// zero V / epsB of the points that are cut by a 64-measurement chunk boundary (targets of the atomics)
-__global__ void __launch_bounds__(256) zero_cut_points_kernel(BaDev d) {
-    const int ci = blockIdx.x * 256 + threadIdx.x + 1;   // boundary before chunk ci
-    const int m0 = ci << 6;
-    if (m0 >= d.M) return;
-    const int p = d.m_pt[m0];
-    if (d.rowptr[p] < m0) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) d.V[(size_t)p * 6 + i] = 0;
-#pragma unroll
-        for (int i = 0; i < 3; i++) d.epsB[(size_t)p * 3 + i] = 0;
-    }
 }
 
 // K7, block variant (points with up to BA_CHUNK measurements): a workgroup owns whole points.
@@ -1177,15 +1195,14 @@ __global__ void __launch_bounds__(BA_CHUNK) jac_accum_kernel(DevCam cam, BaDev d
 // consumers (schur_reduce_kernel sums the RSPLIT values of the 27 numbers it needs per camera).
 // Block (0,0) also reduces the error / bad-count partials.
 #define RSPLIT 16
-__global__ void __launch_bounds__(256) reduce_partials_kernel(BaDev d, int grid_acc) {
-    if (ba_guard_blocks(d)) return;
+__device__ __forceinline__ void reduce_partials_body(const BaDev& d, int grid_acc, int bx, int by) {
     __shared__ double comb[4][64];
     __shared__ double werr[4];
     __shared__ int wbad[4];
     const int total = d.F * 27;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + lane;
-    const int split = blockIdx.y;
+    const int col = bx * 64 + lane;
+    const int split = by;
     const int rows_per = (grid_acc + RSPLIT - 1) / RSPLIT;
     const int r0 = split * rows_per, r1 = min(grid_acc, r0 + rows_per);
     double s = 0;
@@ -1194,7 +1211,7 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(BaDev d, int grid_
     comb[wid][lane] = s;
     __syncthreads();
     if (wid == 0 && col < total) d.Usplit[(size_t)split * total + col] = ((comb[0][lane] + comb[1][lane]) + comb[2][lane]) + comb[3][lane];
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
+    if (bx == 0 && by == 0) {
         double e = 0;
         int nb = 0;
         for (int b = threadIdx.x; b < grid_acc; b += 256) {
@@ -1215,14 +1232,40 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(BaDev d, int grid_
     }
 }
 
+__global__ void __launch_bounds__(256) reduce_partials_kernel(BaDev d, int grid_acc) {
+    if (ba_guard_blocks(d)) return;
+    reduce_partials_body(d, grid_acc, blockIdx.x, blockIdx.y);
+}
+
 // =================================================================================================
 // K8a: V*^-1  (:341-359)   TooN Cholesky<3>::get_inverse
 // =================================================================================================
-__global__ void __launch_bounds__(256) vinv_kernel(BaDev d, double lambda) {
-    if (ba_guard_blocks(d)) return;
-    const int p = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void vinv_body(const BaDev& d, double lambda, int bx) {
+    const int p = bx * 256 + threadIdx.x;
     if (p >= d.P) return;
-    const double* v = d.V + (size_t)p * 6;
+    double v[6];
+    const int r0 = d.rowptr[p], r1 = d.rowptr[p + 1];
+    const int c0 = r0 >> 6, c1 = (r1 - 1) >> 6;
+    if (d.cut != nullptr && r1 > r0 && c0 != c1) {
+        // the point's measurements span chunks c0..c1 of K7's wave variant: trailing segment of c0, then the leading
+        // segments of c0+1..c1, added in that order; epsB is completed here for the Schur / back-substitution kernels
+        const double* q = d.cut + (size_t)(2 * c0 + 1) * 9;
+        double e[3] = {q[6], q[7], q[8]};
+#pragma unroll
+        for (int i = 0; i < 6; i++) v[i] = q[i];
+        for (int c = c0 + 1; c <= c1; c++) {
+            q = d.cut + (size_t)(2 * c) * 9;
+#pragma unroll
+            for (int i = 0; i < 6; i++) v[i] += q[i];
+#pragma unroll
+            for (int i = 0; i < 3; i++) e[i] += q[6 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) d.epsB[(size_t)p * 3 + i] = e[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; i++) v[i] = d.V[(size_t)p * 6 + i];
+    }
     double A[9] = {v[0], v[1], v[3], v[1], v[2], v[4], v[3], v[4], v[5]};
     double* out = d.Vinv + (size_t)p * 9;
     if (A[0] * A[4] * A[8] == 0) {
@@ -1263,6 +1306,21 @@ __global__ void __launch_bounds__(256) vinv_kernel(BaDev d, double lambda) {
         }
         for (int r = 0; r < 3; r++) out[r * 3 + c] = x[r];
     }
+}
+
+__global__ void __launch_bounds__(256) vinv_kernel(BaDev d, double lambda) {
+    if (ba_guard_blocks(d)) return;
+    vinv_body(d, lambda, blockIdx.x);
+}
+// The partial reduction and V*^-1 both only depend on K7 and not on each other: one launch, the first
+// nx * RSPLIT workgroups reduce, the rest invert (a dependent launch costs ~2.3 us on this chip).
+__global__ void __launch_bounds__(256) reduce_vinv_kernel(BaDev d, int grid_acc, int nx, double lambda) {
+    if (ba_guard_blocks(d)) return;
+    const int b = blockIdx.x, nr = nx * RSPLIT;
+    if (b < nr)
+        reduce_partials_body(d, grid_acc, b % nx, b / nx);
+    else
+        vinv_body(d, lambda, b - nr);
 }
 
 // =================================================================================================
@@ -2189,7 +2247,8 @@ static int ba_prepare_impl(ptam_ba* ba) {
     const size_t Mz = std::max(M, 1), Pz = std::max(P, 1), Cz = std::max(C, 1), Fz = std::max(F, 1);
     const size_t o_pose0 = cv.take(Cz * 96), o_pose1 = cv.take(Cz * 96), o_camfree = cv.take(Cz * 4);
     const size_t o_pt0 = cv.take(Pz * 24), o_pt1 = cv.take(Pz * 24), o_V = cv.take(Pz * 48), o_epsB = cv.take(Pz * 24),
-                 o_Vinv = cv.take(Pz * 72), o_rowptr = cv.take((Pz + 1) * 4);
+                 o_Vinv = cv.take(Pz * 72), o_rowptr = cv.take((Pz + 1) * 4),
+                 o_cut = cv.take(ba->use_wave ? (size_t)((M + 63) / 64) * 2 * 72 : 8);
     const size_t o_mcam = cv.take(Mz * 4), o_mpt = cv.take(Mz * 4), o_mfound = cv.take(Mz * 16), o_ms = cv.take(Mz * 8),
                  o_morig = cv.take(Mz * 4), o_mfidx = cv.take(Mz * 4), o_mstate = cv.take(Mz), o_me2 = cv.take(Mz * 8), o_me2t = cv.take(Mz * 8), o_zbad = cv.take(Mz), o_W = cv.take(Mz * 144);
     const size_t o_U = cv.take(Fz * 27 * 8 * 16), o_Upart = cv.take((size_t)d.grid_acc * Fz * 27 * 8);
@@ -2218,6 +2277,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.V = (double*)(base + o_V);
     d.epsB = (double*)(base + o_epsB);
     d.Vinv = (double*)(base + o_Vinv);
+    d.cut = ba->use_wave ? (double*)(base + o_cut) : nullptr;
     d.rowptr = (int*)(base + o_rowptr);
     d.m_cam = (int*)(base + o_mcam);
     d.m_pt = (int*)(base + o_mpt);
@@ -2338,7 +2398,7 @@ static int ba_pass1_sigma(ptam_ba* ba) {
     const int build_hist = (sharded && ba->slow_select) ? 0 : 1;   // (the gather-everything path histograms the gathered keys)
     prof_begin(ba, PTAM_K_PROJECT);
     if (ba->trial_is_current && d.M > 0)
-        hipLaunchKernelGGL(pass1_from_trial_kernel, dim3(std::min((d.M + 255) / 256, 512)), dim3(256), 0, ctx->stream, d,
+        hipLaunchKernelGGL(pass1_from_trial_kernel, dim3(std::max(1, std::min((d.M + 256 * P1_U - 1) / (256 * P1_U), 512))), dim3(256), 0, ctx->stream, d,
                            build_hist);
     else if (d.n_chunks > 0)
         hipLaunchKernelGGL(project_e2_kernel, dim3(std::min(d.n_chunks, 512)), dim3(BA_CHUNK), 0, ctx->stream, ctx->cam, d,
@@ -2544,21 +2604,28 @@ static int ba_trial(ptam_ba* ba, double lambda, bool skip_vinv, int last_allowed
 // accepted and the loop goes on — pass 1 from the trial's errors, the select, K7 with the trial state as current, the
 // partial reduction and V*^-1 for lambda * 0.3.  Enqueued right after the scalars were published, i.e. while the host
 // is still waiting for them.
+static int ba_p1_blocks() {   // workgroup cap of the pass-1 kernels (each flushes its LDS histogram with global atomics)
+    static const int n = [] {
+        const char* e = getenv("PTAM_P1_BLOCKS");
+        return e ? std::max(1, atoi(e)) : 512;
+    }();
+    return n;
+}
 static int ba_enqueue_speculative(ptam_ba* ba, double lambda_next) {
     ptam_ctx* ctx = ba->ctx;
     BaDev d = ba->d;
     const double min_s2 = ba->opts.min_sigma * ba->opts.min_sigma;
-    d.guard = 2;
-    if (d.M > 0) hipLaunchKernelGGL(purge_kernel, dim3((d.M + 255) / 256), dim3(256), 0, ctx->stream, d);
     d.guard = 1;
-    hipLaunchKernelGGL(pass1_from_trial_kernel, dim3(std::min((d.M + 255) / 256, 512)), dim3(256), 0, ctx->stream, d, 1);
+    hipLaunchKernelGGL(purge_pass1_kernel, dim3(std::max(1, std::min((d.M + 256 * P1_U - 1) / (256 * P1_U), ba_p1_blocks()))), dim3(256), 0, ctx->stream, d);
     hipLaunchKernelGGL(select_compact_kernel, dim3(std::max(1, std::min((d.M + 1023) / 1024, 256))), dim3(256), 0, ctx->stream, d,
                        (const double*)d.m_e2, (long long)d.M, (const uint8_t*)d.m_state);
     hipLaunchKernelGGL(select_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, d, ba->opts.estimator, min_s2);
     launch_k7(ba, 1);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(std::max(1, (d.F * 27 + 63) / 64), RSPLIT), dim3(256), 0, ctx->stream, d,
-                       d.grid_acc);
-    if (d.P > 0) hipLaunchKernelGGL(vinv_kernel, dim3((d.P + 255) / 256), dim3(256), 0, ctx->stream, d, lambda_next);
+    {
+        const int nx = std::max(1, (d.F * 27 + 63) / 64);
+        hipLaunchKernelGGL(reduce_vinv_kernel, dim3(nx * RSPLIT + (d.P + 255) / 256), dim3(256), 0, ctx->stream, d, d.grid_acc, nx,
+                           lambda_next);
+    }
     HIP_TRY(hipGetLastError());
     return PTAM_OK;
 }
@@ -3068,8 +3135,7 @@ int ptam_ba_bench_jacobian(ptam_ba* ba, int reps, double* avg_ms, double* algori
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     for (int i = 0; i < 3; i++)
-        launch_k7(ba);   // (the V / epsB of boundary-cut points keep accumulating across these benchmark
-                         //  repetitions; their values are not used: Compute() re-runs pass 1, which clears them)
+        launch_k7(ba);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     // one event pair around `reps` back-to-back launches: the average is the kernel's steady-state
     // duration (an event pair around a single launch adds ~6 us of record / completion latency — an empty
