@@ -380,10 +380,27 @@ __global__ void __launch_bounds__(256) select_compact_kernel(BaDev d, const doub
     __shared__ double buf[CAND_BUF];
     __shared__ unsigned h2[HIST_BINS];
     __shared__ int cnt, gpos;
+    const int tid = threadIdx.x;
+    // the block's keys are fetched 4 per thread, unconditionally (clamped), and the first batch leaves BEFORE the
+    // histogram scan below: one exposed round trip instead of state -> key per 256-key slice
+    constexpr int U = 4;
+    const long long per = (n + gridDim.x - 1) / gridDim.x;
+    const long long i0 = (long long)blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+    double key[U], nkey[U];
+    bool ok[U], nok[U];
+    auto fetch = [&](long long base, double* kq, bool* oq) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const long long i = base + u * 256 + tid;
+            const long long ic = i < n ? i : (n > 0 ? n - 1 : 0);
+            kq[u] = keys[ic];
+            oq[u] = i < i1 && (!state || state[ic] == MS_ALIVE);
+        }
+    };
+    fetch(i0, key, ok);
     long long total;
     int bin, k1;
     block_find_bin(d.hist, total, bin, k1);
-    const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0) {
         d.sc->n_valid = total;
         d.sc->sel_bin = bin;
@@ -393,20 +410,18 @@ __global__ void __launch_bounds__(256) select_compact_kernel(BaDev d, const doub
     for (int b = tid; b < HIST_BINS; b += 256) h2[b] = 0;
     if (tid == 0) cnt = 0;
     __syncthreads();
-    const long long per = (n + gridDim.x - 1) / gridDim.x;
-    const long long i0 = (long long)blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
-    for (long long base = i0; base < i1; base += 256) {
-        const long long i = base + tid;
-        if (i < i1 && (!state || state[i] == MS_ALIVE)) {
-            const double key = keys[i];
-            if (e2_bin(key) == bin) {
+    for (long long base = i0; base < i1; base += 256 * U) {
+        const bool last = base + 256 * U >= i1;
+        if (!last) fetch(base + 256 * U, nkey, nok);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (ok[u] && e2_bin(key[u]) == bin) {
                 const int pos = atomicAdd(&cnt, 1);
-                buf[pos] = key;
-                atomicAdd(&h2[e2_bin2(key)], 1u);
+                buf[pos] = key[u];
+                atomicAdd(&h2[e2_bin2(key[u])], 1u);
             }
-        }
         __syncthreads();
-        if (cnt > CAND_BUF - 256 || base + 256 >= i1) {
+        if (cnt > CAND_BUF - 256 * U || last) {
             const int c = cnt;
             if (tid == 0 && c > 0) gpos = atomicAdd(&d.sc->n_cand, c);
             __syncthreads();
@@ -414,6 +429,11 @@ __global__ void __launch_bounds__(256) select_compact_kernel(BaDev d, const doub
             __syncthreads();
             if (tid == 0) cnt = 0;
             __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            key[u] = nkey[u];
+            ok[u] = nok[u];
         }
     }
     unsigned* hist2 = d.hist + HIST_BINS;
