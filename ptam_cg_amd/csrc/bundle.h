@@ -121,3 +121,19 @@ struct BaDev {
 // solve.hip
 int ba_solve(ptam_ctx* ctx, BaDev& d, int cur);   // also writes the trial poses pose[cur^1] and |da|^2
 int ba_solve_init();   // raises the dynamic-LDS limits of the solve kernels (once per process/device)
+
+// -DK7_TIMING builds only (tools/): device-side timeline, one (kernel id, 100 MHz time stamp) pair per launch
+#ifdef K7_TIMING
+#define TL_BASE 4096
+#define TL_MAX 1900
+#define TL_MARK(d, kid)                                                                                   \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                                         \
+        const unsigned long long q_ = atomicAdd((unsigned long long*)&(d).dbg[TL_BASE], 1ull);            \
+        if (q_ < TL_MAX) {                                                                                \
+            (d).dbg[TL_BASE + 2 + 2 * q_] = (kid);                                                        \
+            (d).dbg[TL_BASE + 3 + 2 * q_] = (long long)__builtin_amdgcn_s_memrealtime();                  \
+        }                                                                                                 \
+    }
+#else
+#define TL_MARK(d, kid)
+#endif

@@ -168,6 +168,7 @@ __device__ __forceinline__ double ba_objective(int est, double e2, double s2, do
 // K5: pass 1
 // =================================================================================================
 __global__ void __launch_bounds__(BA_CHUNK) project_e2_kernel(DevCam cam, BaDev d, int cur, int build_hist) {
+    TL_MARK(d, 13)
     __shared__ unsigned hist[HIST_BINS];
     const int tid = threadIdx.x;
     if (build_hist)
@@ -278,6 +279,7 @@ __device__ __forceinline__ void hist_flush(const BaDev& d, const unsigned* hist)
     }
 }
 __global__ void __launch_bounds__(256) pass1_from_trial_kernel(BaDev d, int build_hist) {
+    TL_MARK(d, 14)
     if (ba_guard_blocks(d)) return;
     __shared__ unsigned hist[HIST_BINS];
     if (build_hist) hist_clear(hist);
@@ -288,6 +290,7 @@ __global__ void __launch_bounds__(256) pass1_from_trial_kernel(BaDev d, int buil
 // and, if the loop goes on from an accepted trial (spec_go), pass 1 from the trial's errors — one dependent
 // launch (~2.3 us) less than purge_kernel + pass1_from_trial_kernel.
 __global__ void __launch_bounds__(256) purge_pass1_kernel(BaDev d) {
+    TL_MARK(d, 1)
     if (d.sc->end_step == 0) return;
     const bool go = d.sc->spec_go != 0;
     __shared__ unsigned hist[HIST_BINS];
@@ -376,6 +379,7 @@ __device__ void block_find_bin(const unsigned* __restrict__ hist, long long& tot
 // one global atomic per flush.
 __global__ void __launch_bounds__(256) select_compact_kernel(BaDev d, const double* __restrict__ keys, long long n,
                                                              const uint8_t* __restrict__ state) {
+    TL_MARK(d, 2)
     if (ba_guard_blocks(d)) return;
     __shared__ double buf[CAND_BUF];
     __shared__ unsigned h2[HIST_BINS];
@@ -497,6 +501,7 @@ __device__ unsigned long long block_radix_select(const double* src, int n, int k
 // one block: second-level bin from hist2, collect its (few) members in LDS, finish the select there;
 // sigma^2; reset both histograms
 __global__ void __launch_bounds__(1024) select_final_kernel(BaDev d, int est, double min_sigma_sq) {
+    TL_MARK(d, 3)
     if (ba_guard_blocks(d)) return;
     __shared__ double sm[SMALL_CAP];
     __shared__ unsigned hist[256];
@@ -928,6 +933,7 @@ typedef double k7_d2 __attribute__((ext_vector_type(2)));
 template <int THREADS, bool PREFETCH, bool LOOP, int EST>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
 jac_accum_wave_kernel(DevCam cam, BaDev d, int cur, int est_arg, int per_wave, int extra) {
+    TL_MARK(d, 4)
     if (ba_guard_blocks(d)) return;
     const int est = EST >= 0 ? EST : est_arg;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1253,6 +1259,7 @@ __device__ __forceinline__ void reduce_partials_body(const BaDev& d, int grid_ac
 }
 
 __global__ void __launch_bounds__(256) reduce_partials_kernel(BaDev d, int grid_acc) {
+    TL_MARK(d, 16)
     if (ba_guard_blocks(d)) return;
     reduce_partials_body(d, grid_acc, blockIdx.x, blockIdx.y);
 }
@@ -1329,12 +1336,14 @@ __device__ __forceinline__ void vinv_body(const BaDev& d, double lambda, int bx)
 }
 
 __global__ void __launch_bounds__(256) vinv_kernel(BaDev d, double lambda) {
+    TL_MARK(d, 6)
     if (ba_guard_blocks(d)) return;
     vinv_body(d, lambda, blockIdx.x);
 }
 // The partial reduction and V*^-1 both only depend on K7 and not on each other: one launch, the first
 // nx * RSPLIT workgroups reduce, the rest invert (a dependent launch costs ~2.3 us on this chip).
 __global__ void __launch_bounds__(256) reduce_vinv_kernel(BaDev d, int grid_acc, int nx, double lambda) {
+    TL_MARK(d, 5)
     if (ba_guard_blocks(d)) return;
     const int b = blockIdx.x, nr = nx * RSPLIT;
     if (b < nr)
@@ -1511,6 +1520,7 @@ __device__ __forceinline__ void schur_store_m(const BaDev& d, SchurStageM& st, c
 #define SCH_T(acc, stmt) { stmt; }
 #endif
 __global__ void __launch_bounds__(256) schur_tile_mfma_kernel(BaDev d) {
+    TL_MARK(d, 7)
     extern __shared__ __attribute__((aligned(16))) double schur_lds[];
     SchurStageM* stage = reinterpret_cast<SchurStageM*>(schur_lds);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1660,6 +1670,7 @@ __global__ void __launch_bounds__(256) schur_tile_mfma_kernel(BaDev d) {
 // fold into the one all-reduce); the padding identity is added on rank 0 only.
 #define SRED_SLICES 10   // 9 x 256 tile elements + 1 slice for E and the padding rows
 __global__ void __launch_bounds__(256) schur_reduce_kernel(BaDev d, double lambda, int pad_identity) {
+    TL_MARK(d, 8)
     const int pair = blockIdx.x, slice = blockIdx.y;
     int a = (int)((sqrt(8.0 * pair + 1.0) - 1.0) * 0.5);
     while ((a + 1) * (a + 2) / 2 <= pair) a++;
@@ -1757,6 +1768,7 @@ __global__ void __launch_bounds__(64) pose_update_kernel(BaDev d, int cur) {
 
 // delta b, trial points, new robust error; block owns whole points
 __global__ void __launch_bounds__(BA_CHUNK) point_update_kernel(DevCam cam, BaDev d, int cur, int est) {
+    TL_MARK(d, 11)
     __shared__ double Ts[BA_CHUNK][3];
     __shared__ double Np[BA_CHUNK][3];
     __shared__ double wred[BA_CHUNK / 64][2];
@@ -1863,6 +1875,7 @@ __global__ void __launch_bounds__(BA_CHUNK) point_update_kernel(DevCam cam, BaDe
 
 __global__ void __launch_bounds__(256) finalize_new_kernel(BaDev d, double conv_limit, int last_allowed, ulonglong2* host_slots,
                                                             unsigned long long seq) {
+    TL_MARK(d, 12)
     __shared__ double w[4][2];
     double e = 0, s = 0;
     // fixed assignment + fixed combine order: deterministic
@@ -1899,6 +1912,7 @@ __global__ void __launch_bounds__(256) finalize_new_kernel(BaDev d, double conv_
 
 // erase bad measurements, append to the outlier list (:536-547)
 __global__ void __launch_bounds__(256) purge_kernel(BaDev d) {
+    TL_MARK(d, 15)
     if (ba_guard_blocks(d)) return;
     const int m = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -2284,7 +2298,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     const size_t npad = std::max(d.npad, SOLVE_NB);
     const size_t o_SE = cv.take((npad * npad + npad + 2) * 8), o_L = cv.take(npad * npad * 8), o_Dg = cv.take(npad * 8),
                  o_y = cv.take(npad * 8), o_da = cv.take(npad * 8);
-    const size_t o_out = cv.take(Mz * 4), o_sc = cv.take(sizeof(BaScalars)), o_dbg = cv.take(32768);
+    const size_t o_out = cv.take(Mz * 4), o_sc = cv.take(sizeof(BaScalars)), o_dbg = cv.take(65536);
     ba->block_bytes = cv.off;
     HIP_TRY(hipMalloc(&ba->block, ba->block_bytes));
     HIP_TRY(hipMemsetAsync(ba->block, 0, ba->block_bytes, ctx->stream));
@@ -2908,6 +2922,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double ht0 = now_us();
     double ht_first = 0;
+    (void)hipMemsetAsync(ba->d.dbg + TL_BASE, 0, 8, ba->ctx->stream);
 #endif
     if (ba->comm && ba->world > 1) {
         // every rank must walk the same sequence of collectives: a rank without measurements would leave the loop below
@@ -3085,6 +3100,16 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
 #ifdef K7_TIMING
     std::printf("HOST Compute: first trial read at %.1f us, loop end %.1f us, total %.1f us (%zu trials)\n", ht_first - ht0, ht_loop - ht0,
                 now_us() - ht0, ba->trials.size());
+    if (getenv("PTAM_TIMELINE")) {
+        std::vector<long long> tl(2 + 2 * TL_MAX);
+        HIP_TRY(hipMemcpy(tl.data(), d.dbg + TL_BASE, tl.size() * 8, hipMemcpyDeviceToHost));
+        const long long n_tl = std::min<long long>(tl[0], TL_MAX);
+        static const char* nm[] = {"?", "purge_pass1", "select_compact", "select_final", "K7", "reduce_vinv", "vinv", "schur_tile", "schur_reduce",
+                                   "ldlt_step0", "backward", "point_update", "finalize", "project_e2", "pass1_trial", "purge", "reduce_partials", "publish"};
+        for (long long i = 0; i < n_tl; i++)
+            std::printf("TL %4lld %-16s start %9.2f us  (+%.2f)\n", i, nm[tl[2 + 2 * i] < 18 ? tl[2 + 2 * i] : 0], (tl[3 + 2 * i] - tl[3]) * 0.01,
+                        i ? (tl[3 + 2 * i] - tl[1 + 2 * i]) * 0.01 : 0.0);
+    }
 #endif
     if (accepted_out) *accepted_out = ba->accepted;
     return PTAM_OK;

@@ -86,6 +86,7 @@ struct StepLds {
 };
 
 __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
+    if (k == 0) { TL_MARK(d, 9) }
     __shared__ StepLds s;
     const int npad = d.npad, nblk = npad / NB, rem = nblk - k - 1;
     double* __restrict__ S = d.SE;
@@ -302,6 +303,7 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
 // mat-vec (row rr, 32-lane reduction), then  pending_j += L[k-block rows][j] . x_k  for every column j
 // of the blocks above, four row-slices per column.
 __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur) {
+    TL_MARK(d, 10)
     extern __shared__ __attribute__((aligned(16))) double bw_lds[];
     const int npad = d.npad, nblk = npad / NB;
     double* xs = bw_lds;         // npad: the solution
