@@ -278,6 +278,29 @@ int ptam_pose_gn(ptam_ctx* ctx, int n, const ptam_pose_meas* meas, const ptam_pr
 int ptam_pose_gn_dev(ptam_ctx* ctx, int n, const ptam_pose_meas* d_meas, const ptam_projection* d_entry,
                      double* d_pose_inout, const ptam_gn_opts* opts, int32_t* d_outlier_flags, double* d_updates);
 
+/* The same with the measurement count in device memory (d_n, clamped to [0, n_cap]; 0 = pose unchanged, zero updates,
+ * src/Tracker.cc:955-956): the list ptam_gather_pose_meas_dev compacted is consumed without a host round trip.
+ * Outlier flags are written for the first *d_n entries only.  pose_host_in (nullable, HOST pointer, 12 doubles): the entry
+ * pose (the motion model's prediction) handed over as a kernel argument instead of being read from d_pose_inout — no
+ * copy of its own.  pose_host_out (nullable, HOST pointer, 12 doubles): when
+ * given, the call returns once the refined pose has arrived there — the kernel writes it into host-mapped memory, so a
+ * tracked frame ends with one PCIe write instead of a D2H copy + stream synchronise; d_pose_inout is updated either way. */
+int ptam_pose_gn_dev_counted(ptam_ctx* ctx, int n_cap, const int32_t* d_n, const ptam_pose_meas* d_meas,
+                             const ptam_projection* d_entry, double* d_pose_inout, const ptam_gn_opts* opts,
+                             int32_t* d_outlier_flags, double* d_updates, const double* pose_host_in, double* pose_host_out);
+
+/* ---- Tracker::SearchForPoints' bookkeeping for a batch (src/Tracker.cc:883-909), device resident, asynchronous:
+ *      query i with level >= 0 whose patch was found (d_results[i].found) — and, when d_subpix is given, whose
+ *      sub-pixel refinement converged (:898-904) — becomes the next pose measurement, in query order:
+ *      {v3WorldPos_i, v2Found = coarse position (:908) or sub-pixel position (:905), dSqrtInvNoise = 1 / LevelScale(level) (:889)}.
+ *      d_world: the points' world positions, 3 doubles every world_stride_bytes (24 for packed xyz, sizeof(ptam_pvs_point) to
+ *      read them out of the PVS input).  d_src_index (nullable): query index of every measurement (routes the outlier flags of
+ *      the pose solve back to the map points).  d_count: number of measurements written.  d_level_found (nullable, 4 ints):
+ *      manMeasFound per level (:892, :901). */
+int ptam_gather_pose_meas_dev(ptam_ctx* ctx, int n, const ptam_patch_query* d_queries, const ptam_patch_result* d_results,
+                              const ptam_subpix_result* d_subpix, const void* d_world, int world_stride_bytes,
+                              ptam_pose_meas* d_meas_out, int32_t* d_src_index, int32_t* d_count, int32_t* d_level_found);
+
 /* One Tracker::CalcPoseUpdate (src/Tracker.cc:928-1005) on caller-provided Jacobians. */
 typedef struct {
     double found[2];

@@ -138,6 +138,8 @@ PROTOTYPES = {
     "gn_opts_default": (None, [C.POINTER(GnOpts)]),
     "pose_gn": (_i, [_vp, _i, _vp, _vp, _pd, C.POINTER(GnOpts), _vp, _vp]),
     "pose_gn_dev": (_i, [_vp, _i, _vp, _vp, _vp, C.POINTER(GnOpts), _vp, _vp]),
+    "pose_gn_dev_counted": (_i, [_vp, _i, _vp, _vp, _vp, _vp, C.POINTER(GnOpts), _vp, _vp, _pd, _pd]),
+    "gather_pose_meas_dev": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "calc_pose_update": (_i, [_vp, _i, _vp, _d, _i, _d, _pd, _vp]),
     "ba_opts_default": (None, [C.POINTER(BaOpts)]),
     "ba_create": (_i, [_vp, C.POINTER(BaOpts), _ppv]),

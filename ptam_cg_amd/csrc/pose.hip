@@ -254,14 +254,22 @@ __device__ __forceinline__ void td_jacobian(PoseState& st) {
     }
 }
 
+// entry pose handed over by value (kernel argument): a tracked frame's prediction comes from the host's motion model,
+// 96 bytes that need no copy of their own
+struct PoseIn {
+    double v[12];
+    int use;
+};
+
 __global__ void __launch_bounds__(GN_THREADS) pose_gn_kernel(DevCam cam, int n, const ptam_pose_meas* __restrict__ meas,
                                                              const ptam_projection* __restrict__ entry,
                                                              double* __restrict__ pose_io, ptam_gn_opts opts,
                                                              PoseState* __restrict__ st, int* __restrict__ flags,
-                                                             double* __restrict__ updates) {
+                                                             double* __restrict__ updates, const int* __restrict__ n_dev, PoseIn pin) {
     __shared__ GnShared sh;
     const int tid = threadIdx.x;
-    if (tid < 12) sh.pose[tid] = pose_io[tid];
+    if (n_dev) n = min(n, max(*n_dev, 0));   // counted variant: the measurement list was compacted on the device
+    if (tid < 12) sh.pose[tid] = pin.use ? pin.v[tid] : pose_io[tid];
     __syncthreads();
     for (int i = tid; i < n; i += GN_THREADS) {
         PoseState s;
@@ -544,10 +552,12 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
                                                                    const ptam_projection* __restrict__ entry,
                                                                    double* __restrict__ pose_io, ptam_gn_opts opts,
                                                                    int* __restrict__ flags, double* __restrict__ updates,
-                                                                   ulonglong2* __restrict__ host_slots, unsigned long long seq) {
+                                                                   ulonglong2* __restrict__ host_slots, unsigned long long seq,
+                                                                   const int* __restrict__ n_dev, PoseIn pin) {
     __shared__ GnSmallShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid < 12) sh.pose[tid] = pose_io[tid];
+    if (n_dev) n = min(n, max(*n_dev, 0));   // counted variant: the measurement list was compacted on the device
+    if (tid < 12) sh.pose[tid] = pin.use ? pin.v[tid] : pose_io[tid];
     if (tid < 6) sh.mu[tid] = 0;
     for (int b = tid; b < GS_BINS; b += GS_THREADS) sh.hist[b] = 0;   // small_select_kth keeps it zero between calls
     SmallMeas t[GS_MPT];
@@ -818,10 +828,10 @@ int ptam_pose_gn(ptam_ctx* ctx, int n, const ptam_pose_meas* meas, const ptam_pr
     const unsigned long long seq = ++ctx->pose_seq;
     if (small)
         hipLaunchKernelGGL(pose_gn_small_kernel, dim3(1), dim3(GS_THREADS), 0, ctx->stream, ctx->cam, n, d_m, d_e, d_pose, o, d_f,
-                           d_u, (ulonglong2*)((char*)ctx->d_pinned + o_slots), seq);
+                           d_u, (ulonglong2*)((char*)ctx->d_pinned + o_slots), seq, (const int*)nullptr, PoseIn{});
     else
         hipLaunchKernelGGL(pose_gn_kernel, dim3(1), dim3(GN_THREADS), 0, ctx->stream, ctx->cam, n, d_m, d_e, d_pose, o,
-                           d_s, d_f, d_u);
+                           d_s, d_f, d_u, (const int*)nullptr, PoseIn{});
     HIP_TRY(hipGetLastError());
     const bool extras = outlier_flags || updates_out;
     if (outlier_flags) HIP_TRY(hipMemcpyAsync(hf, d_f, bf, hipMemcpyDeviceToHost, ctx->stream));
@@ -862,9 +872,15 @@ int ptam_pose_gn(ptam_ctx* ctx, int n, const ptam_pose_meas* meas, const ptam_pr
     return PTAM_OK;
 }
 
-int ptam_pose_gn_dev(ptam_ctx* ctx, int n, const ptam_pose_meas* d_meas, const ptam_projection* d_entry, double* d_pose_inout,
-                     const ptam_gn_opts* opts, int32_t* d_outlier_flags, double* d_updates) {
+static int pose_gn_dev_impl(ptam_ctx* ctx, int n, const int32_t* d_n, const ptam_pose_meas* d_meas, const ptam_projection* d_entry,
+                            double* d_pose_inout, const ptam_gn_opts* opts, int32_t* d_outlier_flags, double* d_updates,
+                            const double* pose_host_in, double* pose_host_out) {
     ARG_TRY(ctx && n >= 1 && d_meas && d_pose_inout);
+    PoseIn pin{};
+    if (pose_host_in) {
+        std::memcpy(pin.v, pose_host_in, 96);
+        pin.use = 1;
+    }
     ptam_gn_opts o;
     if (opts)
         o = *opts;
@@ -874,18 +890,145 @@ int ptam_pose_gn_dev(ptam_ctx* ctx, int n, const ptam_pose_meas* d_meas, const p
     HIP_TRY(hipSetDevice(ctx->device));
     // the kernels write the per-iteration updates unconditionally: give them the context's scratch when the caller
     // does not want them (the general kernel also keeps its per-measurement state there)
-    const size_t bs = n > GS_THREADS * GS_MPT ? (size_t)n * sizeof(PoseState) : 0, bu = (size_t)6 * 32 * 8;
+    const bool small = n <= GS_THREADS * GS_MPT;
+    const size_t bs = small ? 0 : (size_t)n * sizeof(PoseState), bu = (size_t)6 * 32 * 8;
     void* s;
     int rc = ctx_scratch(ctx, bs + bu + 64, &s);
     if (rc) return rc;
     PoseState* d_s = (PoseState*)s;
     double* d_u = d_updates ? d_updates : (double*)((char*)s + bs);
-    if (n <= GS_THREADS * GS_MPT)
+    // pose_host_out: the fast kernel publishes the pose into host-mapped memory as (word, sequence) pairs
+    volatile unsigned long long* slots = nullptr;
+    ulonglong2* d_slots = nullptr;
+    unsigned long long seq = 0;
+    if (pose_host_out) {
+        void* pin;
+        rc = ctx_pinned(ctx, 12 * 16 + 64, &pin);
+        if (rc) return rc;
+        slots = (volatile unsigned long long*)pin;
+        d_slots = (ulonglong2*)ctx->d_pinned;
+        for (int i = 0; i < 12; i++) slots[2 * i + 1] = 0;
+        seq = ++ctx->pose_seq;
+    }
+    if (small)
         hipLaunchKernelGGL(pose_gn_small_kernel, dim3(1), dim3(GS_THREADS), 0, ctx->stream, ctx->cam, n, d_meas, d_entry,
-                           d_pose_inout, o, d_outlier_flags, d_u, (ulonglong2*)nullptr, 0ull);
+                           d_pose_inout, o, d_outlier_flags, d_u, d_slots, seq, (const int*)d_n, pin);
     else
         hipLaunchKernelGGL(pose_gn_kernel, dim3(1), dim3(GN_THREADS), 0, ctx->stream, ctx->cam, n, d_meas, d_entry, d_pose_inout, o,
-                           d_s, d_outlier_flags, d_u);
+                           d_s, d_outlier_flags, d_u, (const int*)d_n, pin);
+    HIP_TRY(hipGetLastError());
+    if (!pose_host_out) return PTAM_OK;
+    if (!small) {
+        HIP_TRY(hipMemcpyAsync((void*)slots, d_pose_inout, 96, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        std::memcpy(pose_host_out, (const void*)slots, 96);
+        return PTAM_OK;
+    }
+    auto arrived = [&]() {
+        for (int i = 0; i < 12; i++)
+            if (slots[2 * i + 1] != seq) return false;
+        return true;
+    };
+    unsigned spins = 0;
+    while (!arrived()) {
+        if (++spins == 100000) {
+            spins = 0;
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q != hipSuccess && q != hipErrorNotReady) return PTAM_E_HIP;
+            if (q == hipSuccess && !arrived()) return PTAM_E_HIP;   // the stream drained without the kernel publishing
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    for (int i = 0; i < 12; i++) {
+        const unsigned long long w = slots[2 * i];
+        std::memcpy(&pose_host_out[i], &w, 8);
+    }
+    return PTAM_OK;
+}
+
+int ptam_pose_gn_dev(ptam_ctx* ctx, int n, const ptam_pose_meas* d_meas, const ptam_projection* d_entry, double* d_pose_inout,
+                     const ptam_gn_opts* opts, int32_t* d_outlier_flags, double* d_updates) {
+    return pose_gn_dev_impl(ctx, n, nullptr, d_meas, d_entry, d_pose_inout, opts, d_outlier_flags, d_updates, nullptr, nullptr);
+}
+
+int ptam_pose_gn_dev_counted(ptam_ctx* ctx, int n_cap, const int32_t* d_n, const ptam_pose_meas* d_meas,
+                             const ptam_projection* d_entry, double* d_pose_inout, const ptam_gn_opts* opts,
+                             int32_t* d_outlier_flags, double* d_updates, const double* pose_host_in, double* pose_host_out) {
+    ARG_TRY(d_n);
+    return pose_gn_dev_impl(ctx, n_cap, d_n, d_meas, d_entry, d_pose_inout, opts, d_outlier_flags, d_updates, pose_host_in,
+                            pose_host_out);
+}
+
+// ---- Tracker::SearchForPoints' bookkeeping for a batch (src/Tracker.cc:883-909): every patch that was found (and, when
+// sub-pixel results are given, whose refinement converged :898-904) becomes one measurement of the pose solve,
+// {v3WorldPos, v2Found = coarse / sub-pixel position, dSqrtInvNoise = 1 / LevelScale(level)}, in query order.
+// One workgroup, stable compaction: per 1024-slice a ballot per wave, wave offsets through LDS.
+__global__ void __launch_bounds__(1024) gather_pose_meas_kernel(int n, const ptam_patch_query* __restrict__ q,
+                                                                const ptam_patch_result* __restrict__ res,
+                                                                const ptam_subpix_result* __restrict__ sub,
+                                                                const char* __restrict__ world, int world_stride,
+                                                                ptam_pose_meas* __restrict__ out, int* __restrict__ src_index,
+                                                                int* __restrict__ count, int* __restrict__ level_found) {
+    __shared__ int wcnt[16];
+    __shared__ int base_s;
+    __shared__ int lvl[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) base_s = 0;
+    if (tid < 4) lvl[tid] = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + tid;
+        bool ok = false;
+        int level = 0;
+        double fx = 0, fy = 0;
+        if (i < n) {
+            level = q[i].level;
+            ok = level >= 0 && res[i].found != 0;
+            fx = res[i].pos[0];
+            fy = res[i].pos[1];
+            if (ok && sub) {
+                ok = sub[i].converged != 0;
+                fx = sub[i].pos[0];
+                fy = sub[i].pos[1];
+            }
+        }
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) wcnt[wid] = __popcll(m);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wid; w++) off += wcnt[w];
+        if (ok) {
+            const int o = off + __popcll(m & ((1ull << lane) - 1ull));
+            const double* wp = (const double*)(world + (size_t)i * world_stride);
+            out[o].world[0] = wp[0];
+            out[o].world[1] = wp[1];
+            out[o].world[2] = wp[2];
+            out[o].found[0] = fx;
+            out[o].found[1] = fy;
+            out[o].sqrt_inv_noise = 1.0 / (double)(1 << level);
+            if (src_index) src_index[o] = i;
+            if (level < 4) atomicAdd(&lvl[level], 1);   // manMeasFound :892
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; w++) t += wcnt[w];
+            base_s += t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *count = base_s;
+    if (level_found && tid < 4) level_found[tid] = lvl[tid];
+}
+
+int ptam_gather_pose_meas_dev(ptam_ctx* ctx, int n, const ptam_patch_query* d_queries, const ptam_patch_result* d_results,
+                              const ptam_subpix_result* d_subpix, const void* d_world, int world_stride_bytes,
+                              ptam_pose_meas* d_meas_out, int32_t* d_src_index, int32_t* d_count, int32_t* d_level_found) {
+    ARG_TRY(ctx && n >= 0 && d_count && (n == 0 || (d_queries && d_results && d_world && d_meas_out)));
+    ARG_TRY(world_stride_bytes >= 24 && world_stride_bytes % 8 == 0);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(gather_pose_meas_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, d_queries, d_results, d_subpix,
+                       (const char*)d_world, world_stride_bytes, d_meas_out, d_src_index, d_count, d_level_found);
     HIP_TRY(hipGetLastError());
     return PTAM_OK;
 }

@@ -278,6 +278,78 @@ class PatchFinder:
         return out
 
 
+class DevBuf:
+    """A device allocation of the context (ptam_dev_alloc / upload / download / free)."""
+
+    def __init__(self, ctx, nbytes_or_array):
+        self.ctx = ctx
+        arr = nbytes_or_array if isinstance(nbytes_or_array, np.ndarray) else None
+        self.nbytes = int(arr.nbytes if arr is not None else nbytes_or_array)
+        self.p = C.c_void_p()
+        ctx._check(ctx.lib.dev_alloc(ctx.h, max(self.nbytes, 8), C.byref(self.p)), "dev_alloc")
+        if arr is not None and arr.nbytes:
+            self.upload(arr)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        self.ctx._check(self.ctx.lib.dev_upload(self.ctx.h, self.p, arr.ctypes.data, arr.nbytes), "dev_upload")
+
+    def download(self, dtype, count):
+        out = np.zeros(count, dtype=dtype)
+        if out.nbytes:
+            self.ctx._check(self.ctx.lib.dev_download(self.ctx.h, out.ctypes.data, self.p, out.nbytes), "dev_download")
+        return out
+
+    def free(self):
+        if self.p:
+            self.ctx.lib.dev_free(self.ctx.h, self.p)
+            self.p = None
+
+
+class FrameTracker:
+    """The per-frame fine stage of Tracker::TrackMap with everything resident on the device: SearchForPoints over a
+    batch of queries (src/Tracker.cc:867-912: FindPatchCoarse, found patches become pose measurements) followed by the
+    ten pose iterations (:613-643).  Only the 96-byte pose comes back to the host."""
+
+    def __init__(self, ctx, capacity):
+        self.ctx, self.lib, self.cap = ctx, ctx.lib, int(capacity)
+        self.d_res = DevBuf(ctx, self.cap * PATCH_RESULT_DT.itemsize)
+        self.d_meas = DevBuf(ctx, self.cap * POSE_MEAS_DT.itemsize)
+        self.d_src = DevBuf(ctx, self.cap * 4)
+        self.d_flags = DevBuf(ctx, self.cap * 4)
+        self.d_count = DevBuf(ctx, 32)      # count | manMeasFound[4]
+        self.d_pose = DevBuf(ctx, 96)
+
+    def search_and_update(self, kf, n, d_queries, d_templates, d_world, world_stride, pose, opts=None, d_subpix=None):
+        """d_* are DevBuf (or raw device pointers).  pose: the prediction, or None to go on from the resident pose of
+        the previous frame.  Returns the refined pose (12 doubles)."""
+        raw = lambda b: b.p if isinstance(b, DevBuf) else b
+        assert 1 <= n <= self.cap
+        chk, lib, h = self.ctx._check, self.lib, self.ctx.h
+        pose_in = None if pose is None else np.array(pose, dtype=np.float64).reshape(12).copy()
+        opts = opts or self.ctx.gn_opts()
+        chk(lib.find_patch_coarse_batch_dev(h, kf.h, n, raw(d_queries), raw(d_templates), self.d_res.p), "find_patch_coarse_dev")
+        cnt = C.c_void_p(self.d_count.p.value)
+        lvl = C.c_void_p(self.d_count.p.value + 8)
+        chk(lib.gather_pose_meas_dev(h, n, raw(d_queries), self.d_res.p, raw(d_subpix) if d_subpix is not None else None,
+                                     raw(d_world), world_stride, self.d_meas.p, self.d_src.p, cnt, lvl), "gather_pose_meas_dev")
+        out = np.zeros(12)
+        chk(lib.pose_gn_dev_counted(h, n, cnt, self.d_meas.p, None, self.d_pose.p, C.byref(opts), self.d_flags.p, None,
+                                    _pd(pose_in) if pose_in is not None else None, _pd(out)), "pose_gn_dev_counted")
+        return out
+
+    def last_measurements(self):
+        """(count, measurements, source query indices, outlier flags, found-per-level) of the last frame"""
+        head = self.d_count.download(np.int32, 8)
+        n = int(head[0])
+        return (n, self.d_meas.download(POSE_MEAS_DT, n), self.d_src.download(np.int32, n), self.d_flags.download(np.int32, n),
+                head[2:6].copy())
+
+    def close(self):
+        for b in (self.d_res, self.d_meas, self.d_src, self.d_flags, self.d_count, self.d_pose):
+            b.free()
+
+
 class Bundle:
     """Bundle (include/Bundle.h:106-152)."""
 

@@ -155,6 +155,53 @@ def test_pose_gn_device_resident_equals_host_entry(hip):
         hip.dev_free(ctx.h, ptr)
 
 
+def test_device_resident_frame_equals_host_path(hip):
+    """SearchForPoints' bookkeeping + pose solve with nothing leaving the device (ptam_gather_pose_meas_dev,
+    ptam_pose_gn_dev_counted) against the same steps through the host entries: src/Tracker.cc:883-909 restated in numpy
+    for the measurement list, then bit-identical poses / outlier flags (same kernels, same list)."""
+    ctx = host.Context(lib=hip)
+    a, b = synth.make_frame_pair()
+    kfa = host.KeyFrame(ctx).MakeKeyFrame_Lite(a)
+    q, t = synth.make_patch_queries([kfa.level(l) for l in range(4)], n=1000)
+    q = q.copy()
+    q["level"][::37] = -1                       # TemplateBad: never searched, never a measurement
+    kfb = host.KeyFrame(ctx).MakeKeyFrame_Lite(b)
+    pc = synth.make_pose_case()
+    rng = np.random.default_rng(3)
+    world = pc["world"][rng.integers(0, len(pc["world"]), len(q))]
+    pvs = np.zeros(len(q), dtype=[("world", "<f8", (3,)), ("r", "<f8", (3,)), ("d", "<f8", (3,))])   # ptam_pvs_point layout
+    pvs["world"] = world
+    pf = host.PatchFinder(ctx)
+    res = pf.FindPatchCoarse(kfb, q, t)
+    sub = pf.SubPix(kfb, res["pos"], np.where(res["found"] != 0, q["level"], -1), t)
+    ft = host.FrameTracker(ctx, len(q))
+    d_q, d_t, d_w, d_sub = host.DevBuf(ctx, q), host.DevBuf(ctx, t), host.DevBuf(ctx, pvs), host.DevBuf(ctx, sub)
+    for use_sub in (False, True):
+        keep = (q["level"] >= 0) & (res["found"] != 0)
+        if use_sub:
+            keep &= sub["converged"] != 0
+        idx = np.nonzero(keep)[0]
+        found = (sub if use_sub else res)["pos"][idx]
+        sn = 1.0 / (1 << q["level"][idx]).astype(np.float64)
+        ref_pose, ref_flags, _ = ctx.pose_gn(world[idx], found, sn, pc["init_pose"])
+        pose = ft.search_and_update(kfb, len(q), d_q, d_t, d_w, pvs.itemsize, pc["init_pose"], d_subpix=d_sub if use_sub else None)
+        n, meas, src, flags, per_level = ft.last_measurements()
+        assert n == len(idx) and n > 300 and np.array_equal(src, idx)
+        assert np.array_equal(meas["world"], world[idx]) and np.array_equal(meas["found"], found)
+        assert np.array_equal(meas["sqrt_inv_noise"], sn)
+        assert np.array_equal(per_level, np.bincount(q["level"][idx], minlength=4))
+        assert np.array_equal(pose, ref_pose) and np.array_equal(flags, ref_flags)
+    # nothing found: zero measurements, pose unchanged (src/Tracker.cc:955-956)
+    q0 = q.copy()
+    q0["level"] = -1
+    d_q0 = host.DevBuf(ctx, q0)
+    pose = ft.search_and_update(kfb, len(q), d_q0, d_t, d_w, pvs.itemsize, pc["init_pose"])
+    assert ft.last_measurements()[0] == 0 and np.array_equal(pose, pc["init_pose"])
+    for buf in (d_q, d_t, d_w, d_sub, d_q0):
+        buf.free()
+    ft.close()
+
+
 def test_pose_gn_entry_state_and_empty(hip, oracle):
     pc = synth.make_pose_case(n=300)
     ch, co = host.Context(lib=hip), host.Context(lib=oracle)
