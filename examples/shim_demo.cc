@@ -62,6 +62,59 @@ int main() {
             std::printf("WARP %d %d %d %d %d %d\n", c.x, c.y, z0, z1, z2, (int)pf.TemplateBad());
             break;
         }
+    // a whole frame's fine stage, twice: patch by patch through PatchFinder + host vectors, and with the resident tracker
+    // (same queries, templates and world points kept on the device) — the poses must agree bit for bit
+    {
+        std::vector<ptam_patch_query> q;
+        std::vector<uint8_t> tm;
+        std::vector<double> world;
+        std::vector<TrackerDataLite> vTD;
+        for (auto& c : L0.vCorners)
+            if (c.x >= 8 && c.y >= 8 && c.x < 152 && c.y < 112 && q.size() < 200) {
+                uint8_t t[64];
+                for (int r = 0; r < 8; r++)
+                    for (int k = 0; k < 8; k++) t[r * 8 + k] = L0.im[(c.y - 4 + r) * 160 + c.x - 4 + k];
+                q.push_back({c.x + 1, c.y, 0, 10u});
+                tm.insert(tm.end(), t, t + 64);
+                // a point on the z = 2 plane that projects (pinhole part of the model) near the corner
+                const double X = (c.x - 160 * 0.519983 + 0.5) / (160 * 1.0803) * 2.0, Y = (c.y - 120 * 0.548655 + 0.5) / (120 * 1.43987) * 2.0;
+                world.insert(world.end(), {X, Y, 2.0});
+                PatchFinder pf(ctx);
+                pf.SetTemplate(t, 0);
+                if (pf.FindPatchCoarse({c.x + 1, c.y}, kf, 10)) {
+                    TrackerDataLite td;
+                    td.v3WorldPos = {X, Y, 2.0};
+                    td.v2Found = {pf.GetCoarsePosAsVector()[0], pf.GetCoarsePosAsVector()[1]};
+                    td.dSqrtInvNoise = 1.0;
+                    vTD.push_back(td);
+                }
+            }
+        SE3 T0 = SE3::from12(std::vector<double>{1, 0, 0, 0, 1, 0, 0, 0, 1, 0.01, -0.01, 0.02}.data());
+        const SE3 Thost = TrackMapPoseIterations(ctx, vTD, T0);
+        void *dq, *dt, *dw;
+        check(ptam_dev_alloc(ctx.handle(), q.size() * sizeof(ptam_patch_query), &dq), "alloc");
+        check(ptam_dev_alloc(ctx.handle(), tm.size(), &dt), "alloc");
+        check(ptam_dev_alloc(ctx.handle(), world.size() * 8, &dw), "alloc");
+        check(ptam_dev_upload(ctx.handle(), dq, q.data(), q.size() * sizeof(ptam_patch_query)), "upload");
+        check(ptam_dev_upload(ctx.handle(), dt, tm.data(), tm.size()), "upload");
+        check(ptam_dev_upload(ctx.handle(), dw, world.data(), world.size() * 8), "upload");
+        ResidentFrameTracker rt(ctx, (int)q.size());
+        const SE3 Tdev = rt.SearchAndUpdatePose(kf, (int)q.size(), (const ptam_patch_query*)dq, (const uint8_t*)dt, dw, 24, T0);
+        std::vector<int32_t> src, outl;
+        const int n = rt.ReadBack(src, outl);
+        int n_out_dev = 0, n_out_host = 0;
+        for (int v : outl) n_out_dev += v != 0;
+        for (auto& td : vTD) n_out_host += td.bOutlier;
+        double a[12], b[12];
+        Thost.to12(a);
+        Tdev.to12(b);
+        bool same = true;
+        for (int i = 0; i < 12; i++) same = same && a[i] == b[i];
+        std::printf("RESIDENT %zu %d %zu %d %d %d\n", q.size(), n, vTD.size(), (int)same, n_out_dev, n_out_host);
+        ptam_dev_free(ctx.handle(), dq);
+        ptam_dev_free(ctx.handle(), dt);
+        ptam_dev_free(ctx.handle(), dw);
+    }
     // a toy bundle: 3 cameras on a line looking down +z, 12 points on a grid, exact measurements of a
     // pinhole-ish projection perturbed deterministically
     Context c640({1.0803, 1.43987, 0.519983, 0.548655, 0.244943}, {640, 480});

@@ -292,6 +292,71 @@ inline SE3 TrackMapPoseIterations(Context& c, std::vector<TrackerDataLite>& vTD,
     return SE3::from12(pose);
 }
 
+// The fine stage of a tracked frame with nothing but the pose crossing PCIe: SearchForPoints over the potentially
+// visible set (src/Tracker.cc:867-912: FindPatchCoarse per point, every found patch becomes a measurement with
+// v2Found = coarse position and dSqrtInvNoise = 1 / LevelScale) followed by the ten pose iterations (:613-643).
+// Queries / templates / world positions are device buffers the caller filled (ptam_dev_upload, or the outputs of
+// ptam_track_pvs / ptam_make_templates_batch kept resident); results stay resident for the caller to read lazily
+// (outlier flags + source indices route nMEstimatorOutlierCount back to the map points).
+class ResidentFrameTracker {
+public:
+    ResidentFrameTracker(Context& c, int nCapacity) : c_(c), cap_(nCapacity) {
+        alloc(&res_, sizeof(ptam_patch_result) * (size_t)cap_);
+        alloc(&meas_, sizeof(ptam_pose_meas) * (size_t)cap_);
+        alloc(&src_, 4 * (size_t)cap_);
+        alloc(&flags_, 4 * (size_t)cap_);
+        alloc(&count_, 32);
+        alloc(&pose_, 96);
+    }
+    ~ResidentFrameTracker() {
+        for (void* p : {res_, meas_, src_, flags_, count_, pose_})
+            if (p) ptam_dev_free(c_.handle(), p);
+    }
+    ResidentFrameTracker(const ResidentFrameTracker&) = delete;
+    ResidentFrameTracker& operator=(const ResidentFrameTracker&) = delete;
+
+    // d_world: 3 doubles per query every nWorldStrideBytes (sizeof(ptam_pvs_point) reads them out of the PVS input)
+    SE3 SearchAndUpdatePose(KeyFrame& kfCurrent, int n, const ptam_patch_query* d_queries, const uint8_t* d_templates,
+                            const void* d_world, int nWorldStrideBytes, const SE3& se3Predicted, int nEstimator = PTAM_EST_TUKEY) {
+        check(ptam_find_patch_coarse_batch_dev(c_.handle(), kfCurrent.handle(), n, d_queries, d_templates,
+                                               (ptam_patch_result*)res_), "ptam_find_patch_coarse_batch_dev");
+        int32_t* cnt = (int32_t*)count_;
+        check(ptam_gather_pose_meas_dev(c_.handle(), n, d_queries, (const ptam_patch_result*)res_, nullptr, d_world,
+                                        nWorldStrideBytes, (ptam_pose_meas*)meas_, (int32_t*)src_, cnt, cnt + 2),
+              "ptam_gather_pose_meas_dev");
+        ptam_gn_opts o;
+        ptam_gn_opts_default(&o);
+        o.estimator = nEstimator;
+        double in[12], out[12];
+        se3Predicted.to12(in);
+        check(ptam_pose_gn_dev_counted(c_.handle(), n, cnt, (const ptam_pose_meas*)meas_, nullptr, (double*)pose_, &o,
+                                       (int32_t*)flags_, nullptr, in, out), "ptam_pose_gn_dev_counted");
+        return SE3::from12(out);
+    }
+    // measurements of the last frame: count, manMeasFound per level (src/Tracker.cc:892), and per measurement the query it
+    // came from and whether iteration 9 weighted it to zero
+    int ReadBack(std::vector<int32_t>& vnSourceQuery, std::vector<int32_t>& vnOutlier, int anMeasFound[PTAM_LEVELS] = nullptr) {
+        int32_t head[8];
+        check(ptam_dev_download(c_.handle(), head, count_, sizeof head), "ptam_dev_download");
+        const int n = head[0];
+        vnSourceQuery.resize(n);
+        vnOutlier.resize(n);
+        if (n > 0) {
+            check(ptam_dev_download(c_.handle(), vnSourceQuery.data(), src_, 4 * (size_t)n), "ptam_dev_download");
+            check(ptam_dev_download(c_.handle(), vnOutlier.data(), flags_, 4 * (size_t)n), "ptam_dev_download");
+        }
+        if (anMeasFound)
+            for (int l = 0; l < PTAM_LEVELS; l++) anMeasFound[l] = head[2 + l];
+        return n;
+    }
+
+private:
+    void alloc(void** p, size_t bytes) { check(ptam_dev_alloc(c_.handle(), bytes, p), "ptam_dev_alloc"); }
+    Context& c_;
+    int cap_;
+    void *res_ = nullptr, *meas_ = nullptr, *src_ = nullptr, *flags_ = nullptr, *count_ = nullptr, *pose_ = nullptr;
+};
+
 // class Bundle (include/Bundle.h:106-152)
 class Bundle {
 public:

@@ -59,6 +59,9 @@ def test_shim_demo_matches_oracle(oracle, tmp_path):
     opf = host.PatchFinder(octx)
     tm, tr = opf.MakeTemplateCoarseCont(okf, [0], [[cx, cy]], [0], [[0.8, -0.6, 0.6, 0.8]])
     assert tr["bad"][0] == 0 and z2 == int(opf.ZMSSDAtPoint(okf, 0, [[cx, cy]], tm[0])[0]) and z2 > 0
+    # the resident frame tracker: same measurement list, same pose (bit for bit) and outlier count as the host-vector path
+    r = [int(v) for v in next(x for x in lines if x[0] == "RESIDENT")[1:]]
+    assert r[0] > 20 and r[1] == r[2] and r[1] > 10 and r[3] == 1 and r[4] == r[5]
     # bundle: replicate the toy problem through the oracle
     ctx = host.Context(lib=oracle)
     ba = host.Bundle(ctx)
