@@ -144,12 +144,21 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
         s.P[0][2][r][g] = aj[0];
     }
     if (g == STRIPS - 1 && r < 4) s.Pb[0][r] = br;
+    // the last block column ends in identity padding (npad - n rows): its pivots are 1, its multipliers 0 and its
+    // right-hand side 0, so the iterations that would only walk over padding are skipped
+    const int ncols = min(NB, d.n - k * NB), niter = (ncols + 3) / 4;
+    if (tid < NB) {
+        s.iD[tid] = 1.0;
+        s.Dv[tid] = 1.0;
+        s.z[tid] = 0.0;
+    }
     __syncthreads();
 
     // Fully unrolled: the panel of iteration t is register t/2 of the threads with g/4 == t%2, so every
     // register index below is a compile-time constant.
 #pragma unroll
     for (int t = 0; t < NITER; t++) {
+        if (t >= niter) break;   // (uniform; the register indices below stay compile-time constants)
         const int c0 = 4 * t, pb = t & 1, jp = c0 / STRIPS, gh = (c0 % STRIPS) / 4;
         const double(*Pk)[4] = s.P[pb][0];
         const double(*Pi)[4] = s.P[pb][1];
