@@ -47,7 +47,7 @@ def parse():
     return ap.parse_args()
 
 
-def tracking_bench(hip, host, synth, frames=200):
+def tracking_bench(hip, host, synth, frames=250):
     """tracked frames/s: K1+K2 (keyframe) + K3 (1000 patches) + K4 (pose GN, 10 iterations)."""
     C = ctypes
     ctx = host.Context(lib=hip)
@@ -71,7 +71,7 @@ def tracking_bench(hip, host, synth, frames=200):
     meas["world"], meas["found"], meas["sqrt_inv_noise"] = pc["world"], pc["found"], pc["sqrt_inv_noise"]
     opts = ctx.gn_opts()
     pose = pc["init_pose"].copy()
-    stage = {}
+    stage, spread = {}, {}
     # device-resident frame: SearchForPoints' bookkeeping (gather) and the pose solve consume device data only; the
     # pose prediction travels as a kernel argument and the refined pose comes back through host-mapped memory.  (As in
     # the staged variant the synthetic patch queries and the pose case are separate workloads: the gather runs on the
@@ -101,14 +101,21 @@ def tracking_bench(hip, host, synth, frames=200):
     for name, parts in (("frame", ("kf", "patch", "gather", "pose_dev")), ("frame_staged", ("kf", "patch", "pose")),
                         ("keyframe", ("kf",)), ("patch", ("kf", "patch")), ("gather", ("gather",)), ("pose_dev", ("pose_dev",)),
                         ("pose", ("pose",))):
-        for _ in range(50):   # (the single-workgroup pose kernel follows the clock: let the power state settle)
+        for _ in range(50):
             one(parts)
         ctx.sync()
-        t0 = time.perf_counter()
-        for _ in range(frames):
-            one(parts)
-        ctx.sync()
-        stage[name] = (time.perf_counter() - t0) / frames
+        # five blocks, the median block counts: these are tiny launches on an otherwise idle chip, and every few runs one
+        # block lands in a low power state (the single-workgroup pose kernel then takes 2.7x as long; min / max are reported)
+        blocks = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for _ in range(frames // 5):
+                one(parts)
+            ctx.sync()
+            blocks.append((time.perf_counter() - t0) / (frames // 5))
+        blocks.sort()
+        stage[name] = blocks[2]
+        spread[name] = (blocks[0], blocks[-1])
     # the resident solve is the host-entry solve: same kernel, same list
     ref = pose.copy()
     chk(hip.pose_gn(ctx.h, n, meas.ctypes.data, None, ref.ctypes.data_as(C.POINTER(C.c_double)), C.byref(opts), None, None), "pose")
@@ -121,7 +128,8 @@ def tracking_bench(hip, host, synth, frames=200):
             "keyframe_us": stage["keyframe"] * 1e6, "keyframe_plus_patch_us": stage["patch"] * 1e6,
             "pose_gn_us": stage["pose_dev"] * 1e6, "pose_gn_host_buffers_us": stage["pose"] * 1e6,
             "frame_host_staged_pose_us": stage["frame_staged"] * 1e6,
-            "gather_us": stage["gather"] * 1e6, "patches_per_frame": int(len(q)), "pose_meas": int(n),
+            "gather_us": stage["gather"] * 1e6,
+            "frame_us_min_max_of_5_blocks": [spread["frame"][0] * 1e6, spread["frame"][1] * 1e6], "patches_per_frame": int(len(q)), "pose_meas": int(n),
             "note": "frame = pyramid + FAST + 1000-patch ZMSSD search + measurement gather + 10-iteration pose solve, device resident"}
 
 
