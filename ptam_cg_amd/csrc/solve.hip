@@ -156,52 +156,85 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
 
     // Fully unrolled: the panel of iteration t is register t/2 of the threads with g/4 == t%2, so every
     // register index below is a compile-time constant.
+    // Software pipelined around the barrier.  The chain that bounds a step is
+    //     panel in LDS -> micro factor -> my rows through it -> the NEXT panel's columns updated -> published -> barrier,
+    // so only that much happens before the barrier; the rank-4 update of all my other columns, the final values of the
+    // panel columns and the bookkeeping follow AFTER it, behind the LDS reads of the next iteration's operands — work
+    // that used to sit on the chain now fills the read latency (one wave per SIMD: nothing else would).
+    struct IterOps {
+        double pv[10];                                 // pivot block, lower triangle 00 10 11 20 21 22 30 31 32 33
+        double rk[4], ri[4], rj[4], b4[4], cq[CPT][4];   // my row of the three panels, rhs pivots, multiplier rows of my columns
+    };
+    auto load_ops = [&](int t, IterOps& o) {
+        const int c0 = 4 * t, pb = t & 1, jp = c0 / STRIPS;
+        const double(*Pk)[4] = s.P[pb][0];
+        const double(*Pi)[4] = s.P[pb][1];
+        const double(*Pj)[4] = s.P[pb][2];
+        int q = 0;
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int n = 0; n <= m; n++) o.pv[q++] = Pk[c0 + m][n];
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            o.rk[n] = Pk[r][n];
+            o.ri[n] = Pi[r][n];
+            o.rj[n] = Pj[r][n];
+            o.b4[n] = s.Pb[pb][n];
+        }
+#pragma unroll
+        for (int jj = 0; jj < CPT; jj++)
+#pragma unroll
+            for (int n = 0; n < 4; n++) o.cq[jj][n] = jj >= jp ? Pk[g + STRIPS * jj][n] : 0.0;
+    };
+    IterOps cur;
+    load_ops(0, cur);
 #pragma unroll
     for (int t = 0; t < NITER; t++) {
         if (t >= niter) break;   // (uniform; the register indices below stay compile-time constants)
         const int c0 = 4 * t, pb = t & 1, jp = c0 / STRIPS, gh = (c0 % STRIPS) / 4;
-        const double(*Pk)[4] = s.P[pb][0];
-        const double(*Pi)[4] = s.P[pb][1];
-        const double(*Pj)[4] = s.P[pb][2];
-        // every LDS operand of the iteration is fetched up front (one wave per SIMD: a read that is issued
-        // at its point of use costs its full latency)
+        const bool has_next = t + 1 < NITER;
+        const int jn = (c0 + 4) / STRIPS, ghn = ((c0 + 4) % STRIPS) / 4;   // register / thread half of the next panel
         const bool below = r > c0 + 3;
-        double pv[4][4], rk[4], ri[4], rj[4], cq[CPT][4], b4[4];
-#pragma unroll
-        for (int m = 0; m < 4; m++)
-#pragma unroll
-            for (int n = 0; n < 4; n++) pv[m][n] = Pk[c0 + m][n];
-#pragma unroll
-        for (int n = 0; n < 4; n++) {
-            rk[n] = Pk[r][n];
-            ri[n] = Pi[r][n];
-            rj[n] = Pj[r][n];
-            b4[n] = s.Pb[pb][n];
-        }
-#pragma unroll
-        for (int jj = jp; jj < CPT; jj++)
-#pragma unroll
-            for (int n = 0; n < 4; n++) cq[jj][n] = Pk[g + STRIPS * jj][n];
-        const Micro f = micro_factor(pv[0][0], pv[1][0], pv[1][1], pv[2][0], pv[2][1], pv[2][2], pv[3][0], pv[3][1], pv[3][2],
-                                     pv[3][3]);
+        const Micro f = micro_factor(cur.pv[0], cur.pv[1], cur.pv[2], cur.pv[3], cur.pv[4], cur.pv[5], cur.pv[6], cur.pv[7], cur.pv[8],
+                                     cur.pv[9]);
         // my rows of the panel through the micro factor
         double xk[4] = {0, 0, 0, 0}, xi[4], xj[4];
-        if (below) micro_subst(f, rk, xk);
-        micro_subst(f, ri, xi);
-        micro_subst(f, rj, xj);   // (zeros unless the workgroup carries a second panel block)
-        // rank-4 update of my columns right of the panel: the multipliers of column q are row q of the panel
-#pragma unroll
-        for (int jj = jp; jj < CPT; jj++) {
+        if (below) micro_subst(f, cur.rk, xk);
+        micro_subst(f, cur.ri, xi);
+        micro_subst(f, cur.rj, xj);   // (zeros unless the workgroup carries a second panel block)
+        // rank-4 update of one of my columns right of the panel: the multipliers of column q are row q of the panel
+        auto update_col = [&](int jj) {
             const int q = g + STRIPS * jj;
             if (jj > jp || q > c0 + 3) {
                 double x[4];
-                micro_subst(f, cq[jj], x);
+                micro_subst(f, cur.cq[jj], x);
                 const double l0 = x[0] * f.i0, l1 = x[1] * f.i1, l2 = x[2] * f.i2, l3 = x[3] * f.i3;
                 akk[jj] -= xk[0] * l0 + xk[1] * l1 + xk[2] * l2 + xk[3] * l3;
                 ai[jj] -= xi[0] * l0 + xi[1] * l1 + xi[2] * l2 + xi[3] * l3;
                 aj[jj] -= xj[0] * l0 + xj[1] * l1 + xj[2] * l2 + xj[3] * l3;
             }
+        };
+        // ---- on the chain: the next panel's columns and the right-hand side, then publish ----
+        double z[4];
+        micro_subst(f, cur.b4, z);   // z = Lmicro^-1 b (same recurrence), rows below take b_r -= L[r][c0..c0+3] . z
+        if (g == STRIPS - 1 && below) br -= xk[0] * f.i0 * z[0] + xk[1] * f.i1 * z[1] + xk[2] * f.i2 * z[2] + xk[3] * f.i3 * z[3];
+        if (has_next) {
+            update_col(jn);
+            if ((g >> 2) == ghn) {
+                s.P[pb ^ 1][0][r][g & 3] = akk[jn];
+                s.P[pb ^ 1][1][r][g & 3] = ai[jn];
+                s.P[pb ^ 1][2][r][g & 3] = aj[jn];
+            }
+            if (g == STRIPS - 1 && r >= c0 + 4 && r < c0 + 8) s.Pb[pb ^ 1][r - c0 - 4] = br;
         }
+        __syncthreads();
+        // ---- off the chain: next operands requested, then everything else of this iteration ----
+        IterOps nxt;
+        if (has_next) load_ops(t + 1, nxt);
+#pragma unroll
+        for (int jj = jp; jj < CPT; jj++)
+            if (!(has_next && jj == jn)) update_col(jj);
         if ((g >> 2) == gh) {
             // my column jp IS panel column n: it takes its final value (X = A * L^-T; pivot rows: D / undivided L*D)
             const int n = g & 3;
@@ -217,29 +250,14 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
             ai[jp] = n == 0 ? xi[0] : n == 1 ? xi[1] : n == 2 ? xi[2] : xi[3];
             aj[jp] = n == 0 ? xj[0] : n == 1 ? xj[1] : n == 2 ? xj[2] : xj[3];
         }
-        // right-hand side: z = Lmicro^-1 b (same recurrence), rows below take b_r -= L[r][c0..c0+3] . z
-        {
-            double z[4];
-            micro_subst(f, b4, z);
-            if (g == STRIPS - 1 && below) br -= xk[0] * f.i0 * z[0] + xk[1] * f.i1 * z[1] + xk[2] * f.i2 * z[2] + xk[3] * f.i3 * z[3];
-            if (tid == 0) {
-                s.z[c0] = z[0], s.z[c0 + 1] = z[1], s.z[c0 + 2] = z[2], s.z[c0 + 3] = z[3];
-                s.iD[c0] = f.i0, s.iD[c0 + 1] = f.i1, s.iD[c0 + 2] = f.i2, s.iD[c0 + 3] = f.i3;
-                s.Dv[c0] = f.d0, s.Dv[c0 + 1] = f.d1, s.Dv[c0 + 2] = f.d2, s.Dv[c0 + 3] = f.d3;
-            }
+        if (tid == 0) {
+            s.z[c0] = z[0], s.z[c0 + 1] = z[1], s.z[c0 + 2] = z[2], s.z[c0 + 3] = z[3];
+            s.iD[c0] = f.i0, s.iD[c0 + 1] = f.i1, s.iD[c0 + 2] = f.i2, s.iD[c0 + 3] = f.i3;
+            s.Dv[c0] = f.d0, s.Dv[c0 + 1] = f.d1, s.Dv[c0 + 2] = f.d2, s.Dv[c0 + 3] = f.d3;
         }
-        if (t + 1 < NITER) {
-            // the owners of the next panel publish it
-            const int jn = (c0 + 4) / STRIPS, ghn = ((c0 + 4) % STRIPS) / 4;
-            if ((g >> 2) == ghn) {
-                s.P[pb ^ 1][0][r][g & 3] = akk[jn];
-                s.P[pb ^ 1][1][r][g & 3] = ai[jn];
-                s.P[pb ^ 1][2][r][g & 3] = aj[jn];
-            }
-            if (g == STRIPS - 1 && r >= c0 + 4 && r < c0 + 8) s.Pb[pb ^ 1][r - c0 - 4] = br;
-        }
-        __syncthreads();
+        if (has_next) cur = nxt;
     }
+    __syncthreads();   // the bookkeeping of the last iteration (s.z / s.iD / s.Dv) is read by the closing phase
 #ifdef K7_TIMING
     const long long ts1 = (long long)__builtin_readcyclecounter();
 #endif
