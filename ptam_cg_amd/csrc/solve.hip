@@ -355,12 +355,14 @@ __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur) {
         for (int q = 0; q < 8; q++) lreg[q] = upd ? d.L[(size_t)(k * NB + sl0 * 8 + q) * npad + j0] : 0.0;
         __syncthreads();   // (A) pending sums of the previous block are complete
         double p = (c >= rr) ? w * (wv[k * NB + c] - pend[k * NB + c]) : 0.0;   // upper triangular
-        p += __shfl_xor(p, 16, 64);
-        p += __shfl_xor(p, 8, 64);
-        p += __shfl_xor(p, 4, 64);
-        p += __shfl_xor(p, 2, 64);
-        p += __shfl_xor(p, 1, 64);
-        if (c == 0) xs[k * NB + rr] = p;
+        // 32-lane sum on the VALU (DPP row shifts, then lane 15 of rows 0 / 2 into rows 1 / 3): five ds_bpermute
+        // round trips sat on the block's critical path
+        p += dpp_row_shr_f64<1>(p);
+        p += dpp_row_shr_f64<2>(p);
+        p += dpp_row_shr_f64<4>(p);
+        p += dpp_row_shr_f64<8>(p);
+        p += dpp_bcast_f64<0x142, 0xA>(p);
+        if (c == NB - 1) xs[k * NB + rr] = p;
         __syncthreads();   // (B) x_k visible
         // pending sums of the blocks above: column j, rows of block k in four slices of 8
         if (upd) {
