@@ -252,14 +252,28 @@ __device__ __forceinline__ double dpp_bcastx_f64(double src) {
     const int hi = dpp_bcastx_i32<CTRL>((int)(b >> 32));
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+// Sum over the 64 lanes, result in every lane.  On the VALU: inclusive scan inside the 16-lane rows (DPP row_shr
+// 1, 2, 4, 8), lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast15), lane 31 into rows 2 / 3 (row_bcast31) — the total is
+// in lane 63 — and one v_readlane per 32 bits.  (Six __shfl_xor steps are six ds_bpermute round trips per 32 bits:
+// ~1.4 us of a single-workgroup kernel's critical path for two fp64 sums.)  Fixed order: deterministic.
 __device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_row_shr0_i32<1>(v);
+    v += dpp_row_shr0_i32<2>(v);
+    v += dpp_row_shr0_i32<4>(v);
+    v += dpp_row_shr0_i32<8>(v);
+    v += dpp_bcast_i32<0x142, 0xA>(0, v);
+    v += dpp_bcast_i32<0x143, 0xC>(0, v);
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_row_shr_f64<1>(v);
+    v += dpp_row_shr_f64<2>(v);
+    v += dpp_row_shr_f64<4>(v);
+    v += dpp_row_shr_f64<8>(v);
+    v += dpp_bcast_f64<0x142, 0xA>(v);
+    v += dpp_bcast_f64<0x143, 0xC>(v);
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 #endif
