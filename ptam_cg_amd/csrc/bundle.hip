@@ -330,12 +330,7 @@ __device__ void block_find_bin(const unsigned* __restrict__ hist, long long& tot
         c[j] = hist[16 * tid + j];
         s += c[j];
     }
-    long long incl = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const long long v = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += v;
-    }
+    const long long incl = wave_incl_scan_i64(s);
     if (lane == 63) wsum[wid] = incl;
     if (tid == 0) {
         s_bin = -1;
@@ -464,12 +459,7 @@ __device__ unsigned long long block_radix_select(const double* src, int n, int k
         if (tid < 64) {
             const unsigned c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
             const int s = (int)(c0 + c1 + c2 + c3);
-            int incl = s;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int v = __shfl_up(incl, o, 64);
-                if (tid >= o) incl += v;
-            }
+            const int incl = wave_incl_scan_i32(s);
             const int excl = incl - s;
             if (excl <= k && k < incl) {
                 int kk = k - excl, dg = 4 * tid;
@@ -526,12 +516,7 @@ __global__ void __launch_bounds__(1024) select_final_kernel(BaDev d, int est, do
             c[j] = hist2[4 * tid + j];
             s += c[j];
         }
-        long long incl = s;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const long long v = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += v;
-        }
+        const long long incl = wave_incl_scan_i64(s);
         if (lane == 63) wsum[wid] = incl;
         if (tid == 0) s_cnt = 0;
         __syncthreads();
@@ -628,12 +613,7 @@ __global__ void __launch_bounds__(1024) select_stage_kernel(BaDev d, double* __r
         c[j] = hist2[4 * tid + j];
         s += c[j];
     }
-    long long incl = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const long long v = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += v;
-    }
+    const long long incl = wave_incl_scan_i64(s);
     if (lane == 63) wsum[wid] = incl;
     __syncthreads();
     if (tid == 0) {

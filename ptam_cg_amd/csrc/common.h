@@ -252,6 +252,38 @@ __device__ __forceinline__ double dpp_bcastx_f64(double src) {
     const int hi = dpp_bcastx_i32<CTRL>((int)(b >> 32));
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+// Inclusive prefix sums over the 64 lanes, on the VALU (same DPP steps as the sums below; a __shfl_up ladder is six
+// ds_bpermute round trips per 32 bits)
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+    v += dpp_row_shr0_i32<1>(v);
+    v += dpp_row_shr0_i32<2>(v);
+    v += dpp_row_shr0_i32<4>(v);
+    v += dpp_row_shr0_i32<8>(v);
+    v += dpp_bcast_i32<0x142, 0xA>(0, v);
+    v += dpp_bcast_i32<0x143, 0xC>(0, v);
+    return v;
+}
+template <int SHR>
+__device__ __forceinline__ long long dpp_row_shr_i64(long long b) {
+    const int lo = dpp_row_shr0_i32<SHR>((int)(b & 0xffffffffll));
+    const int hi = dpp_row_shr0_i32<SHR>((int)(b >> 32));
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ long long dpp_bcast_i64(long long b) {
+    const int lo = dpp_bcast_i32<CTRL, ROWMASK>(0, (int)(b & 0xffffffffll));
+    const int hi = dpp_bcast_i32<CTRL, ROWMASK>(0, (int)(b >> 32));
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+__device__ __forceinline__ long long wave_incl_scan_i64(long long v) {
+    v += dpp_row_shr_i64<1>(v);
+    v += dpp_row_shr_i64<2>(v);
+    v += dpp_row_shr_i64<4>(v);
+    v += dpp_row_shr_i64<8>(v);
+    v += dpp_bcast_i64<0x142, 0xA>(v);
+    v += dpp_bcast_i64<0x143, 0xC>(v);
+    return v;
+}
 // Sum over the 64 lanes, result in every lane.  On the VALU: inclusive scan inside the 16-lane rows (DPP row_shr
 // 1, 2, 4, 8), lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast15), lane 31 into rows 2 / 3 (row_bcast31) — the total is
 // in lane 63 — and one v_readlane per 32 bits.  (Six __shfl_xor steps are six ds_bpermute round trips per 32 bits:

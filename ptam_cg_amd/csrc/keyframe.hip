@@ -173,13 +173,8 @@ __global__ void __launch_bounds__(1024) fast_compact_kernel(KfLevels L, int rest
     int cnt = 0;
     for (int e = e0; e < e1; e++) cnt += __popcll(mask[e]);
     // block exclusive scan
-    int incl = cnt;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += v;
-    }
+    const int incl = wave_incl_scan_i32(cnt);
     if (lane == 63) wsum[wid] = incl;
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -57,12 +57,7 @@ __device__ double block_select_kth(GnShared& sh, const PoseState* __restrict__ s
             const unsigned c0 = sh.hist[4 * tid], c1 = sh.hist[4 * tid + 1], c2 = sh.hist[4 * tid + 2],
                            c3 = sh.hist[4 * tid + 3];
             const int s = (int)(c0 + c1 + c2 + c3);
-            int incl = s;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int v = __shfl_up(incl, o, 64);
-                if (tid >= o) incl += v;
-            }
+            const int incl = wave_incl_scan_i32(s);
             const int excl = incl - s;
             if (excl <= k && k < incl) {
                 int kk = k - excl, d = 4 * tid;
@@ -429,12 +424,7 @@ __device__ void small_select_scan(GnSmallShared& sh, int k, bool clear) {
         if (clear) sh.hist[BPT * tid + b] = 0;
         s += (int)c[b];
     }
-    int incl = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += v;
-    }
+    const int incl = wave_incl_scan_i32(s);
     if (lane == 63) sh.scan[wid] = incl;
     __syncthreads();
     int off = 0;
