@@ -689,10 +689,10 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
                 a3 += src[j + 3];
             }
             double v = (a0 + a1) + (a2 + a3);
-            v += __shfl_xor(v, 1, 64);
-            v += __shfl_xor(v, 2, 64);
-            v += __shfl_xor(v, 4, 64);
-            if (part == 0) sh.red[0][k] = v;
+            v += dpp_row_shr_f64<1>(v);   // the 8 slices of a sum sit in 8 consecutive lanes of a DPP row: lane 7 collects
+            v += dpp_row_shr_f64<2>(v);
+            v += dpp_row_shr_f64<4>(v);
+            if (part == 7) sh.red[0][k] = v;
         }
         __syncthreads();
         if (tid == 0) {

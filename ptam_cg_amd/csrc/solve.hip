@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
         for (int v = 0; v < 4; v++)
             sij[v] = S[(size_t)(bi * NB + 16 * qi + (mlane >> 4) + 4 * v) * npad + bj * NB + 16 * qj + (mlane & 15)];
     }
-    const double e_old = (role == 1 && g == 0) ? E[bi * NB + r] : 0.0;
+    const double e_old = (role == 1 && g == STRIPS - 1) ? E[bi * NB + r] : 0.0;
 #ifdef K7_TIMING
     const long long ts0 = (long long)__builtin_readcyclecounter();
 #endif
@@ -283,11 +283,11 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
             d.L[(size_t)(bi * NB + r) * npad + k * NB + q] = l;
             sum += l * s.z[q];
         }
-        sum += __shfl_xor(sum, 1, 64);
-        sum += __shfl_xor(sum, 2, 64);
-        sum += __shfl_xor(sum, 4, 64);
-        if (STRIPS == 16) sum += __shfl_xor(sum, 8, 64);
-        if (g == 0) E[bi * NB + r] = e_old - sum;
+        sum += dpp_row_shr_f64<1>(sum);   // the 8 threads of a row are 8 consecutive lanes of a DPP row: lane 7 collects
+        sum += dpp_row_shr_f64<2>(sum);
+        sum += dpp_row_shr_f64<4>(sum);
+        static_assert(STRIPS == 8, "row sums below collect 8 lanes");
+        if (g == STRIPS - 1) E[bi * NB + r] = e_old - sum;
     } else {
         // A_ij -= X_i D^-1 X_j^T  through LDS tiles
 #pragma unroll
