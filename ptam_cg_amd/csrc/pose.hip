@@ -514,6 +514,8 @@ __device__ __forceinline__ void small_jacobian(const double cam3[3], double iz, 
 struct SmallMeas {
     double world[3], fnd[2], sn;
     double cam3[3], iz, img[2], D[4];
+    double J[12];   // m26Jacobian of the last CalcJacobian (include/Tracker.h:125-136): refreshed when cam3 / D change, i.e. on
+                    // nonlinear iterations only — with one wave per SIMD the 512-register file holds it for all four measurements
     int found;
 };
 
@@ -560,6 +562,8 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
         t[q].iz = 1;
         t[q].img[0] = t[q].img[1] = 0;
         t[q].D[0] = t[q].D[1] = t[q].D[2] = t[q].D[3] = 0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) t[q].J[k] = 0;
         t[q].world[0] = t[q].world[1] = t[q].world[2] = t[q].fnd[0] = t[q].fnd[1] = t[q].sn = 0;
         if (i < n) {
 #pragma unroll
@@ -588,44 +592,65 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
                 small_project(cam, sh.pose, t[q], in_image);
                 if (!in_image) t[q].found = 0;   // not in the potentially-visible set (src/Tracker.cc:456-458)
             }
+            if (t[q].found) small_jacobian(t[q].cam3, t[q].iz, t[q].D, t[q].J);   // (stays zero otherwise)
             if (flags) flags[i] = 0;
         }
     }
+#ifdef K7_TIMING
+    long long ph[6] = {0, 0, 0, 0, 0, 0};
+#define PH(i) { const long long n_ = (long long)__builtin_readcyclecounter(); ph[i] += n_ - pt_; pt_ = n_; }
+#else
+#define PH(i)
+#endif
     for (int iter = 0; iter < opts.iterations; iter++) {
+#ifdef K7_TIMING
+        long long pt_ = (long long)__builtin_readcyclecounter();
+#endif
         const bool nonlinear = (opts.nonlinear_mask >> iter) & 1u;
         const double ov = iter > opts.override_after ? opts.override_sigma_sq : 0.0;
         double ex[GS_MPT], ey[GS_MPT], e2[GS_MPT];
         int cnt = 0;
+        // The four measurements of a thread are kept in straight-line code (selects instead of per-measurement branches):
+        // with one wave per SIMD the only latency hiding there is comes from interleaving their dependence chains, and
+        // an exec-mask branch per measurement fences the scheduler.  Slots without a measurement hold benign values
+        // (zero Jacobian, zero noise scale) and are masked out of the keys, the count and the weights.
+        if (iter != 0 && nonlinear) {
 #pragma unroll
-        for (int q = 0; q < GS_MPT; q++) {
-            ex[q] = ey[q] = e2[q] = 0;
-            if (t[q].found) {
-                if (iter != 0 && nonlinear) {
+            for (int q = 0; q < GS_MPT; q++)
+                if (t[q].found) {
                     bool in_image;
                     small_project(cam, sh.pose, t[q], in_image);
-                } else if (iter != 0) {   // LinearUpdate include/Tracker.h:139-142
-                    double J[12];
-                    small_jacobian(t[q].cam3, t[q].iz, t[q].D, J);
-                    double a = 0, b = 0;
-#pragma unroll
-                    for (int m = 0; m < 6; m++) {
-                        a += J[m] * sh.mu[m];
-                        b += J[6 + m] * sh.mu[m];
-                    }
-                    t[q].img[0] += a;
-                    t[q].img[1] += b;
+                    small_jacobian(t[q].cam3, t[q].iz, t[q].D, t[q].J);
                 }
-                // CalcPoseUpdate :946-954
-                ex[q] = t[q].sn * (t[q].fnd[0] - t[q].img[0]);
-                ey[q] = t[q].sn * (t[q].fnd[1] - t[q].img[1]);
-                e2[q] = ex[q] * ex[q] + ey[q] * ey[q];
-                cnt++;
+        } else if (iter != 0) {   // LinearUpdate include/Tracker.h:139-142
+            double mu[6];
+#pragma unroll
+            for (int m = 0; m < 6; m++) mu[m] = sh.mu[m];
+#pragma unroll
+            for (int q = 0; q < GS_MPT; q++) {
+                double a = 0, b = 0;
+#pragma unroll
+                for (int m = 0; m < 6; m++) {
+                    a += t[q].J[m] * mu[m];
+                    b += t[q].J[6 + m] * mu[m];
+                }
+                t[q].img[0] += a;   // (J == 0 where there is no measurement)
+                t[q].img[1] += b;
             }
+        }
+#pragma unroll
+        for (int q = 0; q < GS_MPT; q++) {
+            // CalcPoseUpdate :946-954
+            ex[q] = t[q].sn * (t[q].fnd[0] - t[q].img[0]);
+            ey[q] = t[q].sn * (t[q].fnd[1] - t[q].img[1]);
+            e2[q] = ex[q] * ex[q] + ey[q] * ey[q];
+            cnt += t[q].found;
             if (!(ov > 0)) sh.keys[tid + q * GS_THREADS] = t[q].found ? e2[q] : __longlong_as_double(0x7ff0000000000000ll);
         }
         cnt = wave_sum_i32(cnt);
         if (lane == 0) sh.wcount[wid] = cnt;
         __syncthreads();   // also: every thread is done reading sh.mu (linear update) and sh.pose
+        PH(0)
         int nf = 0;
 #pragma unroll
         for (int i = 0; i < GS_WAVES; i++) nf += sh.wcount[i];
@@ -637,20 +662,16 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
                 const double med = small_select_kth(sh, n, nf / 2);
                 sigma_sq = est_sigma_sq_from_median(opts.estimator, med, (unsigned long long)nf);
             }
+            PH(1)
             // WLS<6> :973-1002: C += (w J_r)(J_r)^T, b += e_r (w J_r), J_r scaled by dSqrtInvNoise
             double acc[27];
 #pragma unroll
             for (int k = 0; k < 27; k++) acc[k] = 0;
 #pragma unroll
             for (int q = 0; q < GS_MPT; q++) {
-                if (!t[q].found) continue;
-                const double wgt = est_weight(opts.estimator, e2[q], sigma_sq);
-                if (wgt == 0.0) {
-                    if (iter == opts.mark_outliers_iter && flags) flags[tid + q * GS_THREADS] = 1;
-                    continue;
-                }
-                double Jm[12];
-                small_jacobian(t[q].cam3, t[q].iz, t[q].D, Jm);
+                // weight 0 (an outlier, or no measurement in this slot): every product below is an exact zero
+                const double wgt = t[q].found ? est_weight(opts.estimator, e2[q], sigma_sq) : 0.0;
+                const double* Jm = t[q].J;
                 const double er[2] = {ex[q], ey[q]};
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
@@ -668,6 +689,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
 #pragma unroll
                     for (int a = 0; a < 6; a++) acc[21 + a] += er[r] * Jw[a];
                 }
+                if (iter == opts.mark_outliers_iter && flags && t[q].found && wgt == 0.0) flags[tid + q * GS_THREADS] = 1;
             }
             // 27 sums over 256 threads through LDS: every thread drops its partials column-wise, then 27 x 8 threads
             // each add a 32-thread slice and the 8 slices of a sum meet by shuffles — ~100 instructions per thread
@@ -676,7 +698,9 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
 #pragma unroll
             for (int k = 0; k < 27; k++) sh.tr[k][tcol] = acc[k];
         }
+        PH(2)
         __syncthreads();
+        PH(3)
         if (nf > 0 && tid < 27 * 8) {
             const int k = tid >> 3, part = tid & 7;
             const double* src = &sh.tr[k][part * 33];
@@ -695,6 +719,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
             if (part == 7) sh.red[0][k] = v;
         }
         __syncthreads();
+        PH(4)
         if (tid == 0) {
             double x[6] = {0, 0, 0, 0, 0, 0};
             if (nf > 0) {
@@ -719,7 +744,12 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
                 for (int k = 0; k < 6; k++) updates[6 * iter + k] = x[k];
         }
         __syncthreads();
+        PH(5)
     }
+#ifdef K7_TIMING
+    if (tid == 0 && updates)
+        for (int i = 0; i < 6; i++) updates[6 * 20 + i] = (double)ph[i];
+#endif
     if (tid < 12) pose_io[tid] = sh.pose[tid];
     // the refined pose also goes straight into host-mapped memory as (word, sequence) pairs the host spins on: the call
     // returns one PCIe write after the last iteration instead of a D2H copy plus a stream synchronisation later
