@@ -199,26 +199,35 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
         const Micro f = micro_factor(cur.pv[0], cur.pv[1], cur.pv[2], cur.pv[3], cur.pv[4], cur.pv[5], cur.pv[6], cur.pv[7], cur.pv[8],
                                      cur.pv[9]);
         // my rows of the panel through the micro factor
-        double xk[4] = {0, 0, 0, 0}, xi[4], xj[4];
-        if (below) micro_subst(f, cur.rk, xk);
+        // (selects, not branches, on the chain: with one wave per SIMD the scheduler's freedom to interleave the
+        //  independent substitutions is the only latency hiding there is, and an exec-mask branch fences it)
+        double xk[4], xi[4], xj[4];
+        micro_subst(f, cur.rk, xk);
+#pragma unroll
+        for (int n = 0; n < 4; n++) xk[n] = below ? xk[n] : 0.0;
         micro_subst(f, cur.ri, xi);
         micro_subst(f, cur.rj, xj);   // (zeros unless the workgroup carries a second panel block)
         // rank-4 update of one of my columns right of the panel: the multipliers of column q are row q of the panel
         auto update_col = [&](int jj) {
-            const int q = g + STRIPS * jj;
-            if (jj > jp || q > c0 + 3) {
-                double x[4];
-                micro_subst(f, cur.cq[jj], x);
-                const double l0 = x[0] * f.i0, l1 = x[1] * f.i1, l2 = x[2] * f.i2, l3 = x[3] * f.i3;
-                akk[jj] -= xk[0] * l0 + xk[1] * l1 + xk[2] * l2 + xk[3] * l3;
-                ai[jj] -= xi[0] * l0 + xi[1] * l1 + xi[2] * l2 + xi[3] * l3;
-                aj[jj] -= xj[0] * l0 + xj[1] * l1 + xj[2] * l2 + xj[3] * l3;
-            }
+            if (jj == jp && (c0 % STRIPS) != 0) return;   // (compile time: none of my columns in register jp lies right of the panel)
+            const bool on = jj > jp || g > 3;             // register jp, first half of the block: columns g > 3 only
+            double x[4];
+            micro_subst(f, cur.cq[jj], x);
+            const double l0 = x[0] * f.i0, l1 = x[1] * f.i1, l2 = x[2] * f.i2, l3 = x[3] * f.i3;
+            const double nk = akk[jj] - (xk[0] * l0 + xk[1] * l1 + xk[2] * l2 + xk[3] * l3);
+            const double ni = ai[jj] - (xi[0] * l0 + xi[1] * l1 + xi[2] * l2 + xi[3] * l3);
+            const double nj = aj[jj] - (xj[0] * l0 + xj[1] * l1 + xj[2] * l2 + xj[3] * l3);
+            akk[jj] = on ? nk : akk[jj];
+            ai[jj] = on ? ni : ai[jj];
+            aj[jj] = on ? nj : aj[jj];
         };
         // ---- on the chain: the next panel's columns and the right-hand side, then publish ----
         double z[4];
         micro_subst(f, cur.b4, z);   // z = Lmicro^-1 b (same recurrence), rows below take b_r -= L[r][c0..c0+3] . z
-        if (g == STRIPS - 1 && below) br -= xk[0] * f.i0 * z[0] + xk[1] * f.i1 * z[1] + xk[2] * f.i2 * z[2] + xk[3] * f.i3 * z[3];
+        {
+            const double nb = br - (xk[0] * f.i0 * z[0] + xk[1] * f.i1 * z[1] + xk[2] * f.i2 * z[2] + xk[3] * f.i3 * z[3]);
+            br = (g == STRIPS - 1 && below) ? nb : br;
+        }
         if (has_next) {
             update_col(jn);
             if ((g >> 2) == ghn) {
