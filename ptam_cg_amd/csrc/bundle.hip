@@ -556,7 +556,23 @@ __global__ void __launch_bounds__(1024) select_final_kernel(BaDev d, int est, do
         const int m = s_cnt;
         // bits 63..36 are fixed by (bin, bin2)
         const unsigned long long top = ((unsigned long long)(bin1 + E2_BIN_BASE) << 48) | ((unsigned long long)bin2 << 36);
-        if (m <= SMALL_CAP)
+        if (m <= 128) {
+            // the usual case, a handful of keys share both bins: rank by counting, one barrier (five radix passes with
+            // three barriers each are ~1 us of this single-workgroup kernel).  Keys are positive doubles: their bit
+            // patterns order like the values; ties are broken by position, so exactly one key has rank k2.
+            __shared__ unsigned long long s_res;
+            if (tid < m) {
+                const unsigned long long mine = (unsigned long long)__double_as_longlong(sm[tid]);
+                int rank = 0;
+                for (int j = 0; j < m; j++) {
+                    const unsigned long long o = (unsigned long long)__double_as_longlong(sm[j]);
+                    rank += (o < mine || (o == mine && j < tid)) ? 1 : 0;
+                }
+                if (rank == k2) s_res = mine;
+            }
+            __syncthreads();
+            result = s_res;
+        } else if (m <= SMALL_CAP)
             result = block_radix_select(sm, m, k2, top, 32, hist, &s_digit, &s_k);
         else   // pathological (thousands of near-identical keys): same passes straight from global
             result = block_radix_select(d.cand, n, k2, top, 32, hist, &s_digit, &s_k);
