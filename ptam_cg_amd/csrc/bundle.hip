@@ -1772,62 +1772,77 @@ __global__ void __launch_bounds__(BA_CHUNK) point_update_kernel(DevCam cam, BaDe
     const BaChunk ch = d.chunks[blockIdx.x];
     const int m = ch.m_begin + tid;
     const bool active = m < ch.m_end;
-    int st = MS_DEAD, c = 0, p = 0;
+    // every per-measurement load leaves at once (clamped index, masked afterwards): W does not wait for the
+    // state -> camera -> free-index chain, and the inputs of the new-error pass are here long before they are used
+    const int mc = min(m, d.M - 1);
+    double w[18];
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+        const double2 t = d.W[(size_t)q * d.M + mc];
+        w[2 * q] = t.x;
+        w[2 * q + 1] = t.y;
+    }
+    const int st = active ? (int)d.m_state[mc] : (int)MS_DEAD;
+    const int c = d.m_cam[mc], p = d.m_pt[mc];
+    const double2 fo = d.m_found[mc];
+    const double sn = d.m_s[mc];
+    const int f = d.cam_free[c];
     double t0 = 0, t1 = 0, t2 = 0;
-    if (active) {
-        st = d.m_state[m];
-        c = d.m_cam[m];
-        p = d.m_pt[m];
-        const int f = d.cam_free[c];
-        if (st == MS_ALIVE && f >= 0) {   // non-fixed, non-bad  (:469-474)
-            double w[18];
+    if (st == MS_ALIVE && f >= 0) {   // non-fixed, non-bad  (:469-474)
+        const double* da = d.da + 6 * f;
 #pragma unroll
-            for (int q = 0; q < 9; q++) {
-                const double2 t = d.W[(size_t)q * d.M + m];
-                w[2 * q] = t.x;
-                w[2 * q + 1] = t.y;
-            }
-            const double* da = d.da + 6 * f;
-#pragma unroll
-            for (int r = 0; r < 6; r++) {
-                const double a = da[r];
-                t0 += w[r * 3] * a;
-                t1 += w[r * 3 + 1] * a;
-                t2 += w[r * 3 + 2] * a;
-            }
+        for (int r = 0; r < 6; r++) {
+            const double a = da[r];
+            t0 += w[r * 3] * a;
+            t1 += w[r * 3 + 1] * a;
+            t2 += w[r * 3 + 2] * a;
         }
     }
     Ts[tid][0] = t0;
     Ts[tid][1] = t1;
     Ts[tid][2] = t2;
     __syncthreads();
+    // per point: eight threads add strided slices of its measurements' terms, the slices meet in a fixed order (DPP)
     const int npts = ch.pt_end - ch.pt_begin;
     double sq = 0;
-    for (int pi = tid; pi < npts; pi += BA_CHUNK) {
-        const int pp = ch.pt_begin + pi;
-        const int r0 = d.rowptr[pp] - ch.m_begin, r1 = d.rowptr[pp + 1] - ch.m_begin;
+    for (int base = 0; base < npts; base += BA_CHUNK / 8) {
+        const int pi = base + (tid >> 3), sub = tid & 7;
+        const bool on = pi < npts;
+        const int pp = ch.pt_begin + (on ? pi : 0);
+        const int r0 = d.rowptr[pp] - ch.m_begin, r1 = on ? d.rowptr[pp + 1] - ch.m_begin : r0;
+        const double* eb = d.epsB + (size_t)pp * 3;
+        const double* Vi = d.Vinv + (size_t)pp * 9;
+        const double* X = d.pt[cur] + (size_t)pp * 3;
+        const double e0 = eb[0], e1 = eb[1], e2 = eb[2];
+        double vi[9], x[3];
+#pragma unroll
+        for (int i = 0; i < 9; i++) vi[i] = Vi[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) x[i] = X[i];
         double s0 = 0, s1 = 0, s2 = 0;
-        for (int rr = r0; rr < r1; rr++) {
+        for (int rr = r0 + sub; rr < r1; rr += 8) {
             s0 += Ts[rr][0];
             s1 += Ts[rr][1];
             s2 += Ts[rr][2];
         }
-        const double* eb = d.epsB + (size_t)pp * 3;
-        const double v0 = eb[0] - s0, v1 = eb[1] - s1, v2 = eb[2] - s2;
-        const double* Vi = d.Vinv + (size_t)pp * 9;
-        const double d0 = Vi[0] * v0 + Vi[1] * v1 + Vi[2] * v2;
-        const double d1 = Vi[3] * v0 + Vi[4] * v1 + Vi[5] * v2;
-        const double d2 = Vi[6] * v0 + Vi[7] * v1 + Vi[8] * v2;
-        sq += d0 * d0 + d1 * d1 + d2 * d2;
-        const double* X = d.pt[cur] + (size_t)pp * 3;
-        const double n0 = X[0] + d0, n1 = X[1] + d1, n2 = X[2] + d2;   // :503-504
-        double* Xn = d.pt[cur ^ 1] + (size_t)pp * 3;
-        Xn[0] = n0;
-        Xn[1] = n1;
-        Xn[2] = n2;
-        Np[pi][0] = n0;
-        Np[pi][1] = n1;
-        Np[pi][2] = n2;
+        s0 += dpp_row_shr_f64<1>(s0), s1 += dpp_row_shr_f64<1>(s1), s2 += dpp_row_shr_f64<1>(s2);
+        s0 += dpp_row_shr_f64<2>(s0), s1 += dpp_row_shr_f64<2>(s1), s2 += dpp_row_shr_f64<2>(s2);
+        s0 += dpp_row_shr_f64<4>(s0), s1 += dpp_row_shr_f64<4>(s1), s2 += dpp_row_shr_f64<4>(s2);
+        if (on && sub == 7) {   // (lane 7 of the group holds the sum of its eight slices)
+            const double v0 = e0 - s0, v1 = e1 - s1, v2 = e2 - s2;
+            const double d0 = vi[0] * v0 + vi[1] * v1 + vi[2] * v2;
+            const double d1 = vi[3] * v0 + vi[4] * v1 + vi[5] * v2;
+            const double d2 = vi[6] * v0 + vi[7] * v1 + vi[8] * v2;
+            sq += d0 * d0 + d1 * d1 + d2 * d2;
+            const double n0 = x[0] + d0, n1 = x[1] + d1, n2 = x[2] + d2;   // :503-504
+            double* Xn = d.pt[cur ^ 1] + (size_t)pp * 3;
+            Xn[0] = n0;
+            Xn[1] = n1;
+            Xn[2] = n2;
+            Np[pi][0] = n0;
+            Np[pi][1] = n1;
+            Np[pi][2] = n2;
+        }
     }
     __syncthreads();
     double err = 0;
@@ -1839,9 +1854,7 @@ __global__ void __launch_bounds__(BA_CHUNK) point_update_kernel(DevCam cam, BaDe
             err = 1.0;
             d.m_zbad_t[m] = 1;
         } else {
-            const double2 fo = d.m_found[m];
-            const double s = d.m_s[m];
-            const double ex = s * (fo.x - pr.u), ey = s * (fo.y - pr.v);
+            const double ex = sn * (fo.x - pr.u), ey = sn * (fo.y - pr.v);
             const double s2 = d.sc->sigma_sq;
             const double e2n = ex * ex + ey * ey;
             err = ba_objective(est, e2n, s2, 1.0 / s2);
