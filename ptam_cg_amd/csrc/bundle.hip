@@ -2854,10 +2854,19 @@ int ptam_ba_add_measurements(ptam_ba* ba, int n, const int32_t* cam, const int32
     return PTAM_OK;
 }
 
+static int ba_ensure_mailbox(ptam_ba* ba);
 int ptam_ba_prepare(ptam_ba* ba) {
     ARG_TRY(ba);
     if (ba->prepared) return PTAM_OK;
-    return ba_prepare_impl(ba);
+    int rc = ba_prepare_impl(ba);
+    if (rc) return rc;
+    // Every allocation Compute() would otherwise make on first use happens here: the mailbox and the pinned read-back
+    // staging.  Mapping new host memory into the GPU's address space while kernels are queued makes the driver evict and
+    // restore the queues — measured as a 10-28 ms wait for the first trial's scalars in about every third Compute().
+    rc = ba_ensure_mailbox(ba);
+    if (rc) return rc;
+    void* pin = nullptr;
+    return ctx_pinned(ba->ctx, (size_t)ba->d.C * 96 + (size_t)ba->d.P * 24 + (size_t)ba->d.M * 4 + 64, &pin);
 }
 
 int ptam_ba_set_profiling(ptam_ba* ba, int on) {
@@ -2973,7 +2982,13 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
             if (have_cur && !(new_err > cur_err)) break;
             if (ba->converged || hit_max || aborted()) break;
             BA_DBG("trial %d lambda %g", counter, lambda);
+            const auto q0 = std::chrono::steady_clock::now();
             rc = ba_trial(ba, lambda, skip_vinv, counter + 1 >= ba->opts.max_iterations ? 1 : 0);
+            {
+                const double qms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - q0).count();
+                if (qms > 3.0 && getenv("PTAM_DEBUG_STALL"))
+                    std::fprintf(stderr, "[ptam] stall: trial %d took %.2f ms to enqueue\n", counter, qms);
+            }
             skip_vinv = false;
             if (rc) return rc;
             rc = ba_publish_scalars(ba);
@@ -2983,7 +2998,13 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
                 if (rc) return rc;
             }
             BA_DBG("trial %d enqueued, waiting", counter);
-            rc = ba_wait_scalars(ba, &sc);
+            {
+                const auto w0 = std::chrono::steady_clock::now();
+                rc = ba_wait_scalars(ba, &sc);
+                const double wms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+                if (wms > 3.0 && getenv("PTAM_DEBUG_STALL"))
+                    std::fprintf(stderr, "[ptam] stall: trial %d waited %.2f ms for its scalars\n", counter, wms);
+            }
             if (rc) return rc;
             BA_DBG("trial %d read: cur %g new %g sigma2 %g median %g n_valid %lld n_bad %d sumsq %g %g", counter, sc.cur_err, sc.new_err,
                    sc.sigma_sq, sc.median, sc.n_valid, sc.n_bad, sc.sumsq_cam, sc.sumsq_pt);
