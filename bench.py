@@ -269,7 +269,7 @@ def main():
             big = synth.make_ba_problem(200, 50000, synth.SEED_BA_GLOBAL, window=16)
             bb = synth.load_into(host.Bundle(ctx), big)
             bb.bench_jacobian(300)
-            bms, bby = bb.bench_jacobian(20)
+            bms, bby = bb.bench_jacobian(50)
             out["roofline_config5_shape"] = {"kernel": "jac_accum_wave_kernel", "measurements": int(len(big["cam_idx"])),
                                              "achieved": bby / (bms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                              "frac": bby / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_us": bms * 1e3}

@@ -2003,7 +2003,7 @@ struct ptam_ba {
     bool prepared = false;
     BaDev d;
     void* block = nullptr;
-    size_t block_bytes = 0;
+    size_t block_bytes = 0, block_cap = 0;
     int cur = 0;
     size_t smem_acc = 0;
     bool use_wave = false;
@@ -2044,7 +2044,11 @@ struct ptam_ba {
 };
 
 static void ba_free_device(ptam_ba* ba) {
-    if (ba->block) hipFree(ba->block);
+    if (ba->block) {
+        // the block's kernels may still be queued: the next owner only touches it through the same stream
+        void* drop = ctx_cache_give(ba->ctx->dev_cache, ba->block, ba->block_cap);
+        if (drop) hipFree(drop);
+    }
     if (ba->d_gather) hipFree(ba->d_gather);
     if (ba->d_xchg) hipFree(ba->d_xchg);
     if (ba->d_sel) hipFree(ba->d_sel);
@@ -2309,7 +2313,10 @@ static int ba_prepare_impl(ptam_ba* ba) {
                  o_y = cv.take(npad * 8), o_da = cv.take(npad * 8);
     const size_t o_out = cv.take(Mz * 4), o_sc = cv.take(sizeof(BaScalars)), o_dbg = cv.take(65536);
     ba->block_bytes = cv.off;
-    HIP_TRY(hipMalloc(&ba->block, ba->block_bytes));
+    if (!ctx_cache_take(ctx->dev_cache, ba->block_bytes, &ba->block, &ba->block_cap)) {   // (a released bundle's block, if it fits)
+        HIP_TRY(hipMalloc(&ba->block, ba->block_bytes));
+        ba->block_cap = ba->block_bytes;
+    }
     HIP_TRY(hipMemsetAsync(ba->block, 0, ba->block_bytes, ctx->stream));
     char* base = (char*)ba->block;
     d.pose[0] = (double*)(base + o_pose0);
@@ -2576,7 +2583,9 @@ static int ba_pass2(ptam_ba* ba) {
 static int ba_ensure_mailbox(ptam_ba* ba) {
     if (ba->mbox) return PTAM_OK;
     void* h = nullptr;
-    HIP_TRY(hipHostMalloc(&h, sizeof(ptam_ba::Mailbox), hipHostMallocMapped | hipHostMallocCoherent));
+    size_t cap = 0;
+    if (!ctx_cache_take(ba->ctx->host_cache, sizeof(ptam_ba::Mailbox), &h, &cap))
+        HIP_TRY(hipHostMalloc(&h, sizeof(ptam_ba::Mailbox), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(h, 0, sizeof(ptam_ba::Mailbox));
     void* dv = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&dv, h, 0));
@@ -2791,7 +2800,10 @@ int ptam_ba_destroy(ptam_ba* ba) {
     hipSetDevice(ba->ctx->device);
     hipStreamSynchronize(ba->ctx->stream);
     ba_free_device(ba);
-    if (ba->mbox) hipHostFree(ba->mbox);
+    if (ba->mbox) {
+        void* drop = ctx_cache_give(ba->ctx->host_cache, ba->mbox, sizeof(ptam_ba::Mailbox));
+        if (drop) hipHostFree(drop);
+    }
     if (ba->ev_ok)
         for (int k = 0; k < PTAM_K_COUNT; k++) {
             hipEventDestroy(ba->ev[k][0]);

@@ -56,7 +56,18 @@ struct ptam_ctx {
     void* d_pinned;          // device address of h_pinned (host-mapped): kernels publish small results into it
     size_t h_pinned_cap;
     unsigned long long pose_seq;
+    // Released bundle memory is kept for the next bundle of this context (MapMaker builds a new Bundle for every
+    // adjustment, src/MapMaker.cc:838-845): hipMalloc / hipFree / hipHostMalloc around queued work cost far more than their
+    // own time here — mapping memory into the GPU's address space makes the driver evict and restore the queues (10-28 ms).
+    struct Cached {
+        void* p;
+        size_t bytes;
+    };
+    Cached dev_cache[2];    // device blocks
+    Cached host_cache[2];   // host-mapped mailboxes
 };
+int ctx_cache_take(ptam_ctx::Cached* c, size_t bytes, void** out, size_t* cap);   // smallest cached block >= bytes, or null
+void* ctx_cache_give(ptam_ctx::Cached* c, void* p, size_t bytes);                 // returns the pointer the caller must free (or null)
 
 int ctx_scratch(ptam_ctx* ctx, size_t bytes, void** out);     // device scratch >= bytes
 int ctx_pinned(ptam_ctx* ctx, size_t bytes, void** out);      // pinned host staging >= bytes

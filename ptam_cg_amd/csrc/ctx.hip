@@ -26,6 +26,36 @@ int ctx_scratch(ptam_ctx* ctx, size_t bytes, void** out) {
     return PTAM_OK;
 }
 
+int ctx_cache_take(ptam_ctx::Cached* c, size_t bytes, void** out, size_t* cap) {
+    int best = -1;
+    for (int i = 0; i < 2; i++)
+        if (c[i].p && c[i].bytes >= bytes && (best < 0 || c[i].bytes < c[best].bytes)) best = i;
+    *out = nullptr;
+    *cap = 0;
+    if (best >= 0) {
+        *out = c[best].p;
+        *cap = c[best].bytes;
+        c[best].p = nullptr;
+        c[best].bytes = 0;
+    }
+    return best >= 0;
+}
+void* ctx_cache_give(ptam_ctx::Cached* c, void* p, size_t bytes) {
+    if (!p) return nullptr;
+    for (int i = 0; i < 2; i++)
+        if (!c[i].p) {
+            c[i].p = p;
+            c[i].bytes = bytes;
+            return nullptr;
+        }
+    const int small = c[0].bytes <= c[1].bytes ? 0 : 1;   // both slots taken: keep the two largest
+    if (bytes <= c[small].bytes) return p;
+    void* drop = c[small].p;
+    c[small].p = p;
+    c[small].bytes = bytes;
+    return drop;
+}
+
 int ctx_pinned(ptam_ctx* ctx, size_t bytes, void** out) {
     if (bytes > ctx->h_pinned_cap) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -160,6 +190,10 @@ int ptam_ctx_destroy(ptam_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     if (ctx->d_scratch) hipFree(ctx->d_scratch);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->dev_cache[i].p) hipFree(ctx->dev_cache[i].p);
+        if (ctx->host_cache[i].p) hipHostFree(ctx->host_cache[i].p);
+    }
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return PTAM_OK;
