@@ -1687,6 +1687,16 @@ __global__ void __launch_bounds__(256) schur_reduce_kernel(BaDev d, double lambd
         double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
         const double* p = d.s_part + (size_t)wg0 * SCHUR_TILE_ELEMS + idx;
         int w = wg0;
+        // (eight, then four partial tiles per round trip: the loop is a chain of dependent global round trips otherwise)
+        for (; w + 8 <= wg1; w += 8, p += 8 * (size_t)SCHUR_TILE_ELEMS) {
+            const double q0 = p[0], q1 = p[SCHUR_TILE_ELEMS], q2 = p[2 * (size_t)SCHUR_TILE_ELEMS], q3 = p[3 * (size_t)SCHUR_TILE_ELEMS];
+            const double q4 = p[4 * (size_t)SCHUR_TILE_ELEMS], q5 = p[5 * (size_t)SCHUR_TILE_ELEMS], q6 = p[6 * (size_t)SCHUR_TILE_ELEMS],
+                         q7 = p[7 * (size_t)SCHUR_TILE_ELEMS];
+            s0 += q0 + q4;
+            s1 += q1 + q5;
+            s2 += q2 + q6;
+            s3 += q3 + q7;
+        }
         for (; w + 4 <= wg1; w += 4, p += 4 * (size_t)SCHUR_TILE_ELEMS) {
             s0 += p[0];
             s1 += p[SCHUR_TILE_ELEMS];
