@@ -202,6 +202,32 @@ def test_device_resident_frame_equals_host_path(hip):
     ft.close()
 
 
+def test_bundle_memory_is_reused_across_bundles(hip):
+    """A context keeps a released bundle's device block and mailbox for the next bundle (MapMaker builds a new Bundle per
+    adjustment).  Bundles of changing size created, run and destroyed in a row — two alive at a time — must give
+    what a fresh context gives (stale contents, stale mailbox sequence numbers and too-small blocks would all show)."""
+    cases = [dict(n_cams=6, n_pts=120, seed=1), dict(n_cams=12, n_pts=700, seed=2), dict(n_cams=5, n_pts=60, seed=3),
+             dict(n_cams=12, n_pts=700, seed=2), dict(n_cams=20, n_pts=1500, seed=4, window=6), dict(n_cams=6, n_pts=120, seed=1)]
+    fresh = []
+    for c in cases:
+        fresh.append(util.run_ba(hip, synth.make_ba_problem(**c)))
+    ctx = host.Context(lib=hip)
+    prev = None
+    for c, ref in zip(cases, fresh):
+        prob = synth.make_ba_problem(**c)
+        ba = synth.load_into(host.Bundle(ctx), prob)
+        acc = ba.Compute()
+        poses, pts = ba.get_all()
+        got = {"accepted": acc, "converged": ba.Converged(), "trials": ba.trials(), "poses": poses, "points": pts,
+               "outliers": ba.GetOutlierMeasurements()}
+        util.assert_ba_equal(got, ref, rel=1e-6)   # (not bit for bit: K7's LDS atomics are unordered)
+        if prev is not None:
+            prev.close()   # (released only now: the next bundle finds one cached block, the one after that two)
+        prev = ba
+    prev.close()
+    ctx.close()
+
+
 def test_pose_gn_entry_state_and_empty(hip, oracle):
     pc = synth.make_pose_case(n=300)
     ch, co = host.Context(lib=hip), host.Context(lib=oracle)
