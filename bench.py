@@ -219,9 +219,12 @@ def main():
     barrier()
     t0 = time.perf_counter()
     ba.Compute()
+    t_c = time.perf_counter()
     ctx.sync()
     barrier()
     dt = time.perf_counter() - t0
+    if os.environ.get("PTAM_DEBUG_STALL"):
+        sys.stderr.write(f"[bench] timed region {dt * 1e3:.3f} ms, of which Compute() {1e3 * (t_c - t0):.3f} ms\n")
     trials = ba.trials()
     assert len(trials) == args.steps, (len(trials), args.steps)
     if world > 1:

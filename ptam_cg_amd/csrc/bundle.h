@@ -64,6 +64,7 @@ struct BaDev {
     int C, F, P, M;
     int guard;              // 0: run; 1: run only if sc->spec_go; 2: only if sc->end_step (speculatively enqueued kernels)
     int n, npad;            // camera system order 6F and its padding to SOLVE_NB
+    int band;               // block bandwidth of S (in SOLVE_NB blocks): |block(row) - block(col)| <= band wherever two cameras share a point
     int n_chunks, grid_acc; // measurement chunks; persistent grid of the accumulate kernel
     int n_wchunks;          // wave chunks (<= 64 measurements, whole points); 0 = block variant only
     int n_tiles, n_pairs, n_schur_wg, n_schur_entries;

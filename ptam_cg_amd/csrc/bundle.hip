@@ -20,6 +20,7 @@
 // a 64-byte scalar block per trial.
 #include <algorithm>
 #include <chrono>
+#include <climits>
 #include <atomic>
 #include <numeric>
 #include <utility>
@@ -1951,6 +1952,20 @@ __global__ void __launch_bounds__(256) purge_kernel(BaDev d) {
 // (word, sequence) pairs, one 16-byte store per lane, and the host spins until every pair carries the
 // expected sequence number — no system-scope fence on the device, no D2H copy + stream synchronise
 // (~30 us of idle GPU per trial) on the host.
+// Results leave the device through kernels too: poses, points and the outlier indices are stored straight into the
+// context's host-mapped staging buffer, and a second (stream-ordered) launch stamps a sequence word the host spins on.
+// The copy engine + hipStreamSynchronize pair this replaces slept on an interrupt and, about one Compute() in eight,
+// took 7 ms instead of 70 us to wake up (PTAM_DEBUG_STALL: "compute total" against "compute loop").
+__global__ void __launch_bounds__(256) readback_kernel(const double* __restrict__ pose, size_t n_pose, const double* __restrict__ pts,
+                                                       size_t n_pts, const int* __restrict__ out, size_t n_out, double* __restrict__ h_pose,
+                                                       double* __restrict__ h_pts, int* __restrict__ h_out) {
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    for (size_t i = i0; i < n_pose; i += stride) h_pose[i] = pose[i];
+    for (size_t i = i0; i < n_pts; i += stride) h_pts[i] = pts[i];
+    for (size_t i = i0; i < n_out; i += stride) h_out[i] = out[i];
+}
+__global__ void stamp_kernel(volatile unsigned long long* slot, unsigned long long seq) { *slot = seq; }
+
 #define MBOX_WORDS (sizeof(BaScalars) / 8)
 static_assert(sizeof(BaScalars) % 8 == 0 && MBOX_WORDS <= 64, "published as 64-bit words by one wave");
 __global__ void __launch_bounds__(64) publish_scalars_kernel(const BaScalars* sc, ulonglong2* host_slots, unsigned long long seq) {
@@ -2014,6 +2029,7 @@ struct ptam_ba {
     BaDev d;
     void* block = nullptr;
     size_t block_bytes = 0, block_cap = 0;
+    int band_local = 0;     // block bandwidth of S needed by THIS process' points (ba->d.band: the one in force)
     int cur = 0;
     size_t smem_acc = 0;
     bool use_wave = false;
@@ -2383,6 +2399,23 @@ static int ba_prepare_impl(ptam_ba* ba) {
         h_found[2 * i] = ba->m_found[2 * o];
         h_found[2 * i + 1] = ba->m_found[2 * o + 1];
         h_s[i] = ba->m_s[o];
+    }
+    // block bandwidth of the camera system: S_jk != 0 only if cameras j, k share a point.  Keyframes that see the same
+    // points are neighbours in time (src/MapMaker.cc adds them in order), so for a long trajectory S is banded and the
+    // blocked LDL^T never leaves the band (no pivoting -> no fill outside it).  A sharded bundle only knows its own
+    // points: it keeps the full width (the other ranks' points may couple other cameras).
+    {
+        int band = 0;
+        for (int p = 0; p < P; p++) {
+            int lo = INT_MAX, hi = -1;
+            for (int i = rowptr[p]; i < rowptr[p + 1]; i++)
+                if (h_fidx[i] >= 0) {
+                    lo = std::min(lo, h_fidx[i]);
+                    hi = std::max(hi, h_fidx[i]);
+                }
+            if (hi >= 0) band = std::max(band, (6 * hi + 5) / SOLVE_NB - (6 * lo) / SOLVE_NB);
+        }
+        d.band = ba->band_local = band;
     }
 #define UP(dst, src, bytes)                                                                        \
     if ((bytes) > 0) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream))
@@ -2888,7 +2921,7 @@ int ptam_ba_prepare(ptam_ba* ba) {
     rc = ba_ensure_mailbox(ba);
     if (rc) return rc;
     void* pin = nullptr;
-    return ctx_pinned(ba->ctx, (size_t)ba->d.C * 96 + (size_t)ba->d.P * 24 + (size_t)ba->d.M * 4 + 64, &pin);
+    return ctx_pinned(ba->ctx, 64 + (size_t)ba->d.C * 96 + (size_t)ba->d.P * 24 + (size_t)ba->d.M * 4 + 64, &pin);
 }
 
 int ptam_ba_set_profiling(ptam_ba* ba, int on) {
@@ -2958,6 +2991,8 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     auto aborted = [&]() { return abort_flag && *abort_flag; };
     BaScalars sc;
     std::memset(&sc, 0, sizeof sc);
+    double dbg_enq_ms = 0, dbg_wait_ms = 0;   // host time spent enqueueing trials / waiting for their scalars (PTAM_DEBUG_STALL)
+    const auto dbg_t0 = std::chrono::steady_clock::now();
 #ifdef K7_TIMING
     auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double ht0 = now_us();
@@ -2967,13 +3002,26 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     if (ba->comm && ba->world > 1) {
         // every rank must walk the same sequence of collectives: a rank without measurements would leave the loop below
         // at once and the others would wait for it for ever.  One tiny all-reduce up front makes the refusal unanimous.
-        const double mine[2] = {d.M == 0 ? 1.0 : 0.0, (double)d.M};
-        double all[2];
-        HIP_TRY(hipMemcpyAsync(ba->d_xchg, mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
-        rc = ba_allreduce(ba, ba->d_xchg, 2);
+        // The same exchange settles the block bandwidth of the camera system: every rank marks the bandwidth its own
+        // points need (one-hot, the collective only sums), the widest one wins — S is the sum of all ranks' parts.
+        const int nblk_x = d.npad / SOLVE_NB;
+        const bool band_fits = nblk_x + 2 <= 512;   // d_xchg holds 512 doubles
+        std::vector<double> mine(band_fits ? 2 + nblk_x : 2, 0.0), all(mine.size(), 0.0);
+        mine[0] = d.M == 0 ? 1.0 : 0.0;
+        mine[1] = (double)d.M;
+        if (band_fits && nblk_x > 0) mine[2 + std::min(ba->band_local, nblk_x - 1)] = 1.0;
+        HIP_TRY(hipMemcpyAsync(ba->d_xchg, mine.data(), mine.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        rc = ba_allreduce(ba, ba->d_xchg, mine.size());
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(all, ba->d_xchg, sizeof all, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(all.data(), ba->d_xchg, all.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ba->d.band = nblk_x;
+        if (band_fits)
+            for (int b = nblk_x - 1; b >= 0; b--)
+                if (all[2 + b] > 0.5) {
+                    ba->d.band = b;
+                    break;
+                }
         if (all[0] > 0.5) {
             ptam_set_error("sharded bundle: %d of %d ranks hold no measurement (shard the points so that every rank gets some)",
                            (int)(all[0] + 0.5), ba->world);
@@ -3008,6 +3056,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
             rc = ba_trial(ba, lambda, skip_vinv, counter + 1 >= ba->opts.max_iterations ? 1 : 0);
             {
                 const double qms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - q0).count();
+                dbg_enq_ms += qms;
                 if (qms > 3.0 && getenv("PTAM_DEBUG_STALL"))
                     std::fprintf(stderr, "[ptam] stall: trial %d took %.2f ms to enqueue\n", counter, qms);
             }
@@ -3024,6 +3073,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
                 const auto w0 = std::chrono::steady_clock::now();
                 rc = ba_wait_scalars(ba, &sc);
                 const double wms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+                dbg_wait_ms += wms;
                 if (wms > 3.0 && getenv("PTAM_DEBUG_STALL"))
                     std::fprintf(stderr, "[ptam] stall: trial %d waited %.2f ms for its scalars\n", counter, wms);
             }
@@ -3104,6 +3154,10 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
         n_steps++;
     }
     BA_DBG("loop done, steps %d", n_steps);
+    if (getenv("PTAM_DEBUG_STALL"))
+        std::fprintf(stderr, "[ptam] compute loop: %zu trials in %.3f ms; host enqueueing trials %.3f ms, waiting for scalars %.3f ms\n",
+                     ba->trials.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0).count(),
+                     dbg_enq_ms, dbg_wait_ms);
     if (n_steps > 0) {   // the last step's purge
         rc = ba_read_scalars(ba, &sc);
         if (rc) return rc;
@@ -3128,13 +3182,29 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     {
         const size_t b_pose = (size_t)d.C * 96, b_pts = (size_t)d.P * 24, b_out = (size_t)n_out * 4;
         void* pin = nullptr;
-        rc = ctx_pinned(ctx, b_pose + b_pts + b_out + 64, &pin);
+        rc = ctx_pinned(ctx, 64 + b_pose + b_pts + b_out + 64, &pin);
         if (rc) return rc;
-        char* hp = (char*)pin;
-        HIP_TRY(hipMemcpyAsync(hp, d.pose[ba->cur], b_pose, hipMemcpyDeviceToHost, ctx->stream));
-        if (d.P > 0) HIP_TRY(hipMemcpyAsync(hp + b_pose, d.pt[ba->cur], b_pts, hipMemcpyDeviceToHost, ctx->stream));
-        if (n_out > 0) HIP_TRY(hipMemcpyAsync(hp + b_pose + b_pts, d.outliers, b_out, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        char* hp = (char*)pin + 64;   // [sequence word | poses | points | outlier indices]
+        char* dp = (char*)ctx->d_pinned + 64;
+        volatile unsigned long long* slot = (volatile unsigned long long*)pin;
+        const unsigned long long seq = ++ctx->pose_seq;
+        *slot = 0;
+        const size_t n_all = (size_t)d.C * 12 + (size_t)d.P * 3 + (size_t)n_out;
+        hipLaunchKernelGGL(readback_kernel, dim3((unsigned)std::max<size_t>(1, std::min<size_t>((n_all + 255) / 256, 1024))), dim3(256), 0,
+                           ctx->stream, (const double*)d.pose[ba->cur], (size_t)d.C * 12, (const double*)d.pt[ba->cur], (size_t)d.P * 3,
+                           (const int*)d.outliers, (size_t)n_out, (double*)dp, (double*)(dp + b_pose), (int*)(dp + b_pose + b_pts));
+        hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, ctx->stream, (volatile unsigned long long*)ctx->d_pinned, seq);
+        HIP_TRY(hipGetLastError());
+        unsigned spins = 0;
+        while (*slot != seq) {
+            if (++spins == 100000) {
+                spins = 0;
+                const hipError_t q = hipStreamQuery(ctx->stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return PTAM_E_HIP;
+                if (q == hipSuccess && *slot != seq) return PTAM_E_HIP;   // drained without the stamp: something failed
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
         std::memcpy(ba->cam_pose.data(), hp, b_pose);
         if (d.P > 0) std::memcpy(ba->pts.data(), hp + b_pose, b_pts);
         if (n_out > 0) std::memcpy(out_idx.data(), hp + b_pose + b_pts, b_out);
@@ -3163,6 +3233,9 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
                         i ? (tl[3 + 2 * i] - tl[1 + 2 * i]) * 0.01 : 0.0);
     }
 #endif
+    if (getenv("PTAM_DEBUG_STALL"))
+        std::fprintf(stderr, "[ptam] compute total %.3f ms\n",
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0).count());
     if (accepted_out) *accepted_out = ba->accepted;
     return PTAM_OK;
 }

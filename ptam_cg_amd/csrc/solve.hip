@@ -14,7 +14,7 @@
 //     iteration is ONE barrier and one LDS round trip: read panel -> factor the 4x4 pivot block
 //     redundantly in registers (reciprocals by v_rcp_f64 + 2 Newton steps) -> substitute my rows ->
 //     rank-4 update of my strips -> the owners of the next panel publish it.
-// Workgroup roles in step k (rem = NB-k-1): [0] finaliser: writes D_k, z_k and — by carrying the
+// Workgroup roles in step k (rem = min(blocks below k, block bandwidth of S): outside the band S, and therefore L, is zero): [0] finaliser: writes D_k, z_k and — by carrying the
 // identity as its panel block — Lkk^-T, which is all the backward substitution needs of the diagonal
 // block; [1..rem] panel row i: writes L_ik and b_i -= L_ik z_k; [rest] trailing tile (i,j):
 // A_ij -= X_i D^-1 X_j^T.  The factor goes to a separate buffer L, so no workgroup reads a block
@@ -88,7 +88,7 @@ struct StepLds {
 __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
     if (k == 0) { TL_MARK(d, 9) }
     __shared__ StepLds s;
-    const int npad = d.npad, nblk = npad / NB, rem = nblk - k - 1;
+    const int npad = d.npad, nblk = npad / NB, rem = min(nblk - k - 1, d.band);   // (rows below the band hold zeros in column k)
     double* __restrict__ S = d.SE;
     double* __restrict__ E = d.SE + (size_t)npad * npad;
     const int tid = threadIdx.x;
@@ -356,9 +356,10 @@ __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur) {
         const double w = wnext;
         if (k > 0) wnext = d.L[(size_t)((k - 1) * NB + rr) * npad + (k - 1) * NB + c];   // prefetch the next block
         // first round of this block's update operands (independent of x_k): in flight during the mat-vec
-        const int ncol = k * NB;
+        // columns of the blocks above that row block k reaches: all of them, or — S banded — the last `band` blocks
+        const int jlo = max(0, k - d.band) * NB, ncol = k * NB - jlo;
         const bool upd = tid < ncol * 4;
-        const int j0 = upd ? tid % ncol : 0, sl0 = upd ? tid / ncol : 0;
+        const int j0 = jlo + (upd ? tid % ncol : 0), sl0 = upd ? tid / ncol : 0;
         double lreg[8];
 #pragma unroll
         for (int q = 0; q < 8; q++) lreg[q] = upd ? d.L[(size_t)(k * NB + sl0 * 8 + q) * npad + j0] : 0.0;
@@ -381,7 +382,7 @@ __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur) {
             atomicAdd(&pend[j0], a);   // LDS; four addends per column
         }
         for (int idx = tid + 1024; idx < ncol * 4; idx += 1024) {
-            const int j = idx % ncol, sl = idx / ncol;
+            const int j = jlo + idx % ncol, sl = idx / ncol;
             double a = 0;
 #pragma unroll
             for (int q = 0; q < 8; q++) a += d.L[(size_t)(k * NB + sl * 8 + q) * npad + j] * xs[k * NB + sl * 8 + q];
@@ -427,7 +428,7 @@ int ba_solve_init() {
 int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
     const int nblk = d.npad / NB;
     for (int k = 0; k < nblk; k++) {
-        const int rem = nblk - k - 1;
+        const int rem = std::min(nblk - k - 1, d.band);
         const int nwg = 1 + rem + rem * (rem + 1) / 2;
         hipLaunchKernelGGL(ldlt_step_kernel, dim3(nwg), dim3(TPB), 0, ctx->stream, d, k);
     }
