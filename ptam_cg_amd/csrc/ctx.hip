@@ -1,4 +1,5 @@
 // ctx.hip — context, error reporting, device-memory helpers, projection batch (a8/a12/a13).
+#include <chrono>
 #include <cstdarg>
 
 #include "common.h"
@@ -208,6 +209,18 @@ int ptam_ctx_set_halfsample(ptam_ctx* ctx, int variant) {
 int ptam_ctx_sync(ptam_ctx* ctx) {
     ARG_TRY(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
+    // poll for a while before sleeping: hipStreamSynchronize waits on an interrupt, and waking from it was measured at
+    // up to 7 ms on this platform — the calls made per frame / per adjustment finish within microseconds
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        if (q == hipSuccess) return PTAM_OK;
+        if (q != hipErrorNotReady) {
+            (void)hipGetLastError();
+            HIP_TRY(q);
+        }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PTAM_OK;
 }
