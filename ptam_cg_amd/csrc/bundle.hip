@@ -287,6 +287,30 @@ __global__ void __launch_bounds__(256) pass1_from_trial_kernel(BaDev d, int buil
     pass1_adopt<false>(d, true, build_hist != 0, hist);
     if (build_hist) hist_flush(d, hist);
 }
+// Pass 1 of a step that follows a step WITHOUT an accepted trial (every trial rejected until the iteration cap, or —
+// at the noise floor — a trial whose error equals the current one bit for bit): poses and points have not moved, so the
+// squared errors of the previous pass 1 still stand for every measurement that survived the purge; only the histogram
+// has to be rebuilt over them.  (The z <= 0 cases of that state were marked then and have been purged since.)
+__global__ void __launch_bounds__(256) pass1_keep_kernel(BaDev d) {
+    __shared__ unsigned hist[HIST_BINS];
+    hist_clear(hist);
+    constexpr int U = P1_U;
+    for (int base = blockIdx.x * (256 * U); base < d.M; base += gridDim.x * (256 * U)) {
+        int st[U];
+        double e2[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int m = base + u * 256 + threadIdx.x, mc = min(m, d.M - 1);
+            st[u] = m < d.M ? (int)d.m_state[mc] : (int)MS_DEAD;
+            e2[u] = d.m_e2[mc];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (st[u] == MS_ALIVE) atomicAdd(&hist[e2_bin(e2[u])], 1u);
+    }
+    hist_flush(d, hist);
+}
+
 // The speculative step prologue's first launch: the purge that closes the finished step (guarded by end_step)
 // and, if the loop goes on from an accepted trial (spec_go), pass 1 from the trial's errors — one dependent
 // launch (~2.3 us) less than purge_kernel + pass1_from_trial_kernel.
@@ -2029,6 +2053,7 @@ struct ptam_ba {
     BaDev d;
     void* block = nullptr;
     size_t block_bytes = 0, block_cap = 0;
+    bool e2_is_current = false;   // m_e2 / m_state hold pass 1 of the CURRENT poses and points (the last step accepted nothing)
     int band_local = 0;     // block bandwidth of S needed by THIS process' points (ba->d.band: the one in force)
     int cur = 0;
     size_t smem_acc = 0;
@@ -2493,7 +2518,10 @@ static int ba_pass1_sigma(ptam_ba* ba) {
     if (ba->trial_is_current && d.M > 0)
         hipLaunchKernelGGL(pass1_from_trial_kernel, dim3(std::max(1, std::min((d.M + 256 * P1_U - 1) / (256 * P1_U), 512))), dim3(256), 0, ctx->stream, d,
                            build_hist);
-    else if (d.n_chunks > 0)
+    else if (ba->e2_is_current && d.M > 0) {
+        if (build_hist)
+            hipLaunchKernelGGL(pass1_keep_kernel, dim3(std::max(1, std::min((d.M + 256 * P1_U - 1) / (256 * P1_U), 512))), dim3(256), 0, ctx->stream, d);
+    } else if (d.n_chunks > 0)
         hipLaunchKernelGGL(project_e2_kernel, dim3(std::min(d.n_chunks, 512)), dim3(BA_CHUNK), 0, ctx->stream, ctx->cam, d,
                            ba->cur, build_hist);
     prof_end(ba, PTAM_K_PROJECT);
@@ -2981,6 +3009,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     ba->cur_pending = false;
     ba->slow_select = false;
     ba->trial_is_current = false;
+    ba->e2_is_current = false;
     bool hit_max = false;
     int counter = 0;
     ba->accepted = 0;
@@ -3131,6 +3160,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
         if (redo_step) continue;   // (keeps trial_is_current: pass 1 may still adopt the previous trial's errors)
         if (nan_stop) hit_max = true;
         ba->trial_is_current = false;
+        ba->e2_is_current = ran_any && !(new_err < cur_err);   // nothing committed: the step's own pass 1 still describes the state
         if (ran_any && new_err < cur_err) {   // :523-533
             lambda_factor = 2.0;
             lambda *= 0.3;
