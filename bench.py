@@ -203,8 +203,8 @@ def main():
     ba = new_bundle(args.steps)
     # Spin-up: blocks of 1000 back-to-back K7 launches on a LOCAL copy of the shard (no communicator: ranks may need
     # different block counts) until the launch time has settled (at least 6, at most 150 blocks) — the launch time is the
-    # clock probe.  Without it about every third run starts its timed region with the GPU / the launching core still in
-    # an idle power state and runs 2.4x slower throughout (PTAM_DEBUG_STALL=1 shows the first trial waiting 10-28 ms).
+    # clock probe.  Without it a Compute() that starts on an idle chip has its first trial wait 10-28 ms for its scalars
+    # (PTAM_DEBUG_STALL=1 reports it; DESIGN.md section 5 lists the three causes of the once bimodal bench).
     sb = synth.load_into(host.Bundle(ctx), prob)
     best, calm, spin = None, 0, []
     for blk in range(150):
