@@ -2125,7 +2125,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     ptam_ctx* ctx = ba->ctx;
     ba_finish_outliers(ba);   // erased measurements of earlier Compute() calls leave the problem here
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ptam_stream_wait(ctx->stream));
     ba_free_device(ba);
     BaDev& d = ba->d;
     std::memset(&d, 0, sizeof d);
@@ -2460,7 +2460,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     UP(d.s_wgs, s_wgs.data(), s_wgs.size() * sizeof(SchurWG));
     UP(d.s_pair_wg_begin, pair_wg_begin.data(), pair_wg_begin.size() * 4);
 #undef UP
-    HIP_TRY(hipStreamSynchronize(ctx->stream));   // host staging vectors die here
+    HIP_TRY(ptam_stream_wait(ctx->stream));   // host staging vectors die here
     {
         const int rc_s = ba_solve_init();
         if (rc_s) return rc_s;
@@ -2569,14 +2569,14 @@ static int ba_pass1_sigma(ptam_ba* ba) {
                            ctx->stream, d, d.cand, d_cnt);
         int n_local = 0;
         HIP_TRY(hipMemcpyAsync(&n_local, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ptam_stream_wait(ctx->stream));
         std::vector<double> counts(ba->world, 0.0);
         counts[ba->rank] = n_local;
         HIP_TRY(hipMemcpyAsync(ba->d_xchg, counts.data(), ba->world * 8, hipMemcpyHostToDevice, ctx->stream));
         int rc = ba_allreduce(ba, ba->d_xchg, ba->world);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(counts.data(), ba->d_xchg, ba->world * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ptam_stream_wait(ctx->stream));
         long long total = 0, off = 0;
         for (int r = 0; r < ba->world; r++) {
             if (r == ba->rank) off = total;
@@ -2785,7 +2785,7 @@ static int ba_wait_scalars(ptam_ba* ba, BaScalars* out) {
         return true;
     };
     if (ba->prof) {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));   // the profiling events must have completed as well
+        HIP_TRY(ptam_stream_wait(ctx->stream));   // the profiling events must have completed as well
     } else {
         // spin on the sequence words; every now and then ask the runtime whether the stream died instead
         unsigned spins = 0, idle_polls = 0, dbg_polls = 0;
@@ -2869,7 +2869,7 @@ int ptam_ba_create(ptam_ctx* ctx, const ptam_ba_opts* opts, ptam_ba** out) {
 int ptam_ba_destroy(ptam_ba* ba) {
     if (!ba) return PTAM_OK;
     hipSetDevice(ba->ctx->device);
-    hipStreamSynchronize(ba->ctx->stream);
+    ptam_stream_wait(ba->ctx->stream);
     ba_free_device(ba);
     if (ba->mbox) {
         void* drop = ctx_cache_give(ba->ctx->host_cache, ba->mbox, sizeof(ptam_ba::Mailbox));
@@ -2979,7 +2979,7 @@ int ptam_ba_set_comm(ptam_ba* ba, int rank, int world, ptam_allreduce_f64_fn fn,
     ARG_TRY(world <= 32);
     if (ba->d_sel && world != ba->world) {   // the select's exchange buffer is sized by the world
         HIP_TRY(hipSetDevice(ba->ctx->device));
-        HIP_TRY(hipStreamSynchronize(ba->ctx->stream));
+        HIP_TRY(ptam_stream_wait(ba->ctx->stream));
         HIP_TRY(hipFree(ba->d_sel));
         ba->d_sel = nullptr;
     }
@@ -3043,7 +3043,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
         rc = ba_allreduce(ba, ba->d_xchg, mine.size());
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(all.data(), ba->d_xchg, all.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ptam_stream_wait(ctx->stream));
         ba->d.band = nblk_x;
         if (band_fits)
             for (int b = nblk_x - 1; b >= 0; b--)
@@ -3336,7 +3336,7 @@ int ptam_ba_bench_jacobian(ptam_ba* ba, int reps, double* avg_ms, double* algori
     HIP_TRY(hipEventCreate(&e1));
     for (int i = 0; i < 3; i++)
         launch_k7(ba);
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ptam_stream_wait(ctx->stream));
     // one event pair around `reps` back-to-back launches: the average is the kernel's steady-state
     // duration (an event pair around a single launch adds ~6 us of record / completion latency — an empty
     // kernel measures 6.3 us that way, tools/membw — and would not agree with rocprofv3's kernel trace)

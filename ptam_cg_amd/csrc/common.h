@@ -69,6 +69,9 @@ struct ptam_ctx {
 int ctx_cache_take(ptam_ctx::Cached* c, size_t bytes, void** out, size_t* cap);   // smallest cached block >= bytes, or null
 void* ctx_cache_give(ptam_ctx::Cached* c, void* p, size_t bytes);                 // returns the pointer the caller must free (or null)
 
+// hipStreamSynchronize sleeps on an interrupt, and waking from it was measured at up to 7 ms on this platform; the waits
+// of this library end within microseconds to a few milliseconds, so every one of them polls first (2 ms) and only then sleeps.
+hipError_t ptam_stream_wait(hipStream_t stream);
 int ctx_scratch(ptam_ctx* ctx, size_t bytes, void** out);     // device scratch >= bytes
 int ctx_pinned(ptam_ctx* ctx, size_t bytes, void** out);      // pinned host staging >= bytes
 

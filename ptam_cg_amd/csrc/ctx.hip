@@ -15,7 +15,7 @@ void ptam_set_error(const char* fmt, ...) {
 
 int ctx_scratch(ptam_ctx* ctx, size_t bytes, void** out) {
     if (bytes > ctx->d_scratch_cap) {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ptam_stream_wait(ctx->stream));
         if (ctx->d_scratch) HIP_TRY(hipFree(ctx->d_scratch));
         ctx->d_scratch = nullptr;
         ctx->d_scratch_cap = 0;
@@ -25,6 +25,17 @@ int ctx_scratch(ptam_ctx* ctx, size_t bytes, void** out) {
     }
     *out = ctx->d_scratch;
     return PTAM_OK;
+}
+
+hipError_t ptam_stream_wait(hipStream_t stream) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(stream);
+        if (q != hipErrorNotReady) return q;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    (void)hipGetLastError();   // (hipErrorNotReady is sticky in the last-error slot)
+    return hipStreamSynchronize(stream);
 }
 
 int ctx_cache_take(ptam_ctx::Cached* c, size_t bytes, void** out, size_t* cap) {
@@ -59,7 +70,7 @@ void* ctx_cache_give(ptam_ctx::Cached* c, void* p, size_t bytes) {
 
 int ctx_pinned(ptam_ctx* ctx, size_t bytes, void** out) {
     if (bytes > ctx->h_pinned_cap) {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ptam_stream_wait(ctx->stream));
         if (ctx->h_pinned) HIP_TRY(hipHostFree(ctx->h_pinned));
         ctx->h_pinned = nullptr;
         ctx->h_pinned_cap = 0;
@@ -188,7 +199,7 @@ int ptam_ctx_create(const ptam_cam_params* cam, int device, ptam_ctx** out) {
 int ptam_ctx_destroy(ptam_ctx* ctx) {
     if (!ctx) return PTAM_OK;
     hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    ptam_stream_wait(ctx->stream);
     if (ctx->d_scratch) hipFree(ctx->d_scratch);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
     for (int i = 0; i < 2; i++) {
@@ -209,19 +220,7 @@ int ptam_ctx_set_halfsample(ptam_ctx* ctx, int variant) {
 int ptam_ctx_sync(ptam_ctx* ctx) {
     ARG_TRY(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
-    // poll for a while before sleeping: hipStreamSynchronize waits on an interrupt, and waking from it was measured at
-    // up to 7 ms on this platform — the calls made per frame / per adjustment finish within microseconds
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-        const hipError_t q = hipStreamQuery(ctx->stream);
-        if (q == hipSuccess) return PTAM_OK;
-        if (q != hipErrorNotReady) {
-            (void)hipGetLastError();
-            HIP_TRY(q);
-        }
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
-    }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ptam_stream_wait(ctx->stream));
     return PTAM_OK;
 }
 
@@ -255,7 +254,7 @@ int ptam_dev_alloc(ptam_ctx* ctx, size_t bytes, void** dptr) {
 int ptam_dev_free(ptam_ctx* ctx, void* dptr) {
     ARG_TRY(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ptam_stream_wait(ctx->stream));
     HIP_TRY(hipFree(dptr));
     return PTAM_OK;
 }
@@ -263,14 +262,14 @@ int ptam_dev_upload(ptam_ctx* ctx, void* dptr, const void* host, size_t bytes) {
     ARG_TRY(ctx && dptr && host);
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ptam_stream_wait(ctx->stream));
     return PTAM_OK;
 }
 int ptam_dev_download(ptam_ctx* ctx, void* host, const void* dptr, size_t bytes) {
     ARG_TRY(ctx && dptr && host);
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ptam_stream_wait(ctx->stream));
     return PTAM_OK;
 }
 
@@ -292,7 +291,7 @@ int ptam_project_points(ptam_ctx* ctx, int n, const double* world_xyz, const dou
                        d_world, d_pose, d_out);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, d_out, ob, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ptam_stream_wait(ctx->stream));
     return PTAM_OK;
 }
 

@@ -384,7 +384,7 @@ int kf_fetch_counts(ptam_ctx* ctx, const ptam_kf* kf_c) {
     ptam_kf* kf = const_cast<ptam_kf*>(kf_c);
     if (kf->counts_valid) return PTAM_OK;
     HIP_TRY(hipMemcpyAsync(kf->n_corners, kf->L.ncorners, sizeof kf->n_corners, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ptam_stream_wait(ctx->stream));
     kf->counts_valid = 1;
     return PTAM_OK;
 }
@@ -451,7 +451,7 @@ static int kf_fetch_rest(ptam_ctx* ctx, const ptam_kf* kf_c) {
     ptam_kf* kf = const_cast<ptam_kf*>(kf_c);
     if (kf->rest_valid) return PTAM_OK;
     HIP_TRY(hipMemcpyAsync(kf->n_max, kf->L.nmax, sizeof kf->n_max, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ptam_stream_wait(ctx->stream));
     kf->rest_valid = 1;
     return PTAM_OK;
 }
@@ -476,7 +476,7 @@ int ptam_kf_read_rest(ptam_ctx* ctx, const ptam_kf* kf, int level, ptam_int2* ma
                                ctx->stream));
     if (n > 0 && st_scores)
         HIP_TRY(hipMemcpyAsync(st_scores, kf->L.st[level], (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ptam_stream_wait(ctx->stream));
     return PTAM_OK;
 }
 
@@ -518,7 +518,7 @@ int ptam_kf_read_level(ptam_ctx* ctx, const ptam_kf* kf, int level, uint8_t* px,
         HIP_TRY(hipMemcpyAsync(corners, kf->L.corners[level], (size_t)n * sizeof(ptam_int2), hipMemcpyDeviceToHost,
                                ctx->stream));
     if (rowlut) HIP_TRY(hipMemcpyAsync(rowlut, kf->L.rowlut[level], (size_t)h * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ptam_stream_wait(ctx->stream));
     return PTAM_OK;
 }
 

@@ -460,7 +460,7 @@ int ptam_subpix_batch(ptam_ctx* ctx, const ptam_kf* kf, int n, const ptam_subpix
     hipLaunchKernelGGL(subpix_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, kf->L, n, d_q, d_t, d_r);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(results, d_r, br, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ptam_stream_wait(ctx->stream));
     return PTAM_OK;
 }
 
@@ -493,7 +493,7 @@ int ptam_find_patch_coarse_batch(ptam_ctx* ctx, const ptam_kf* kf, int n, const 
     rc = ptam_find_patch_coarse_batch_dev(ctx, kf, n, d_q, d_t, d_r);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(results, d_r, br, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ptam_stream_wait(ctx->stream));
     return PTAM_OK;
 }
 
@@ -515,7 +515,7 @@ int ptam_zmssd_at_points(ptam_ctx* ctx, const ptam_kf* kf, int level, int n, con
     hipLaunchKernelGGL(zmssd_points_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, kf->L, level, n, d_p, d_t, d_o);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(ssd_out, d_o, bo, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ptam_stream_wait(ctx->stream));
     return PTAM_OK;
 }
 
@@ -555,7 +555,7 @@ int ptam_make_templates_batch(ptam_ctx* ctx, int n, const ptam_template_query* q
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(templates_out, d_t, bt, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(results, d_r, br, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));   // (jobs[] is pageable: the H2D copy above has been staged by now)
+    HIP_TRY(ptam_stream_wait(ctx->stream));   // (jobs[] is pageable: the H2D copy above has been staged by now)
     return PTAM_OK;
 }
 
@@ -565,7 +565,7 @@ static int kf_build_implane(ptam_ctx* ctx, ptam_kf* kf, int level) {
     const int nc = kf->n_corners[level];
     if (kf->implane_valid[level]) return PTAM_OK;
     if (nc > kf->implane_cap[level]) {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ptam_stream_wait(ctx->stream));
         if (kf->implane[level]) HIP_TRY(hipFree(kf->implane[level]));
         kf->implane[level] = nullptr;
         kf->implane_cap[level] = 0;
@@ -591,7 +591,7 @@ int ptam_kf_implane_corners(ptam_ctx* ctx, ptam_kf* kf, int level, double* out_x
     if (out_xy) {
         ARG_TRY(cap >= nc);
         if (nc > 0) HIP_TRY(hipMemcpyAsync(out_xy, kf->implane[level], (size_t)nc * 16, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ptam_stream_wait(ctx->stream));
     }
     return PTAM_OK;
 }
@@ -616,7 +616,7 @@ int ptam_epipolar_search_batch(ptam_ctx* ctx, const ptam_kf* src, ptam_kf* targe
                        (const double2*)target->implane[level], n, (const ptam_epipolar_query*)d_q, d_r);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(results, d_r, br, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ptam_stream_wait(ctx->stream));
     return PTAM_OK;
 }
 

@@ -879,7 +879,7 @@ int ptam_pose_gn(ptam_ctx* ctx, int n, const ptam_pose_meas* meas, const ptam_pr
         return PTAM_OK;
     }
     if (!small) HIP_TRY(hipMemcpyAsync(hp + o_slots, d_pose, 96, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ptam_stream_wait(ctx->stream));
     if (small) {
         for (int i = 0; i < 12; i++) {
             const unsigned long long w = slots[2 * i];
@@ -940,7 +940,7 @@ static int pose_gn_dev_impl(ptam_ctx* ctx, int n, const int32_t* d_n, const ptam
     if (!pose_host_out) return PTAM_OK;
     if (!small) {
         HIP_TRY(hipMemcpyAsync((void*)slots, d_pose_inout, 96, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ptam_stream_wait(ctx->stream));
         std::memcpy(pose_host_out, (const void*)slots, 96);
         return PTAM_OK;
     }
@@ -1080,7 +1080,7 @@ int ptam_calc_pose_update(ptam_ctx* ctx, int n, const ptam_pose_update_meas* mea
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(mu_out, d_mu, 48, hipMemcpyDeviceToHost, ctx->stream));
     if (weight_zero_flags) HIP_TRY(hipMemcpyAsync(weight_zero_flags, d_f, bf, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ptam_stream_wait(ctx->stream));
     return PTAM_OK;
 }
 

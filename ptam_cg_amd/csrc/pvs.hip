@@ -96,6 +96,6 @@ extern "C" int ptam_track_pvs(ptam_ctx* ctx, int n, const ptam_pvs_point* points
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(results, d_r, br, hipMemcpyDeviceToHost, ctx->stream));
     if (counts) HIP_TRY(hipMemcpyAsync(counts, d_c, 16, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ptam_stream_wait(ctx->stream));
     return PTAM_OK;
 }
