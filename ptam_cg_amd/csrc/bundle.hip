@@ -3381,3 +3381,43 @@ int ptam_ba_bench_jacobian(ptam_ba* ba, int reps, double* avg_ms, double* algori
 }
 
 }   // extern "C"
+
+// every kernel of this file resolved once, when a context is created: the first launch of a kernel otherwise pays for
+// loading the code object / resolving the function — 10-28 ms in the middle of the first frame or the first adjustment
+void ba_preload_kernels() {
+    ptam_preload((const void*)project_e2_kernel);
+    ptam_preload((const void*)pass1_from_trial_kernel);
+    ptam_preload((const void*)pass1_keep_kernel);
+    ptam_preload((const void*)purge_pass1_kernel);
+    ptam_preload((const void*)hist_keys_kernel);
+    ptam_preload((const void*)select_compact_kernel);
+    ptam_preload((const void*)select_final_kernel);
+    ptam_preload((const void*)hist_to_f64_kernel);
+    ptam_preload((const void*)f64_to_hist_kernel);
+    ptam_preload((const void*)select_stage_kernel);
+    ptam_preload((const void*)select_finish_kernel);
+    ptam_preload((const void*)compact_valid_kernel);
+    ptam_preload((const void*)jac_accum_kernel);
+    ptam_preload((const void*)reduce_partials_kernel);
+    ptam_preload((const void*)vinv_kernel);
+    ptam_preload((const void*)reduce_vinv_kernel);
+    ptam_preload((const void*)schur_tile_mfma_kernel);
+    ptam_preload((const void*)schur_reduce_kernel);
+    ptam_preload((const void*)pose_update_kernel);
+    ptam_preload((const void*)point_update_kernel);
+    ptam_preload((const void*)finalize_new_kernel);
+    ptam_preload((const void*)purge_kernel);
+    ptam_preload((const void*)readback_kernel);
+    ptam_preload((const void*)stamp_kernel);
+    ptam_preload((const void*)publish_scalars_kernel);
+    ptam_preload((const void*)set_scalars_kernel);
+    ptam_preload((const void*)set_new_kernel);
+    ptam_preload((const void*)pack2_kernel);
+    ptam_preload((const void*)unpack2_kernel);
+    ptam_preload((const void*)place_keys_kernel);
+    for (int est = 0; est < 2; est++) {
+        ptam_preload(k7_wave_fn(512, false, est ? PTAM_EST_CAUCHY : PTAM_EST_TUKEY));
+        ptam_preload(k7_wave_fn(256, true, est ? PTAM_EST_CAUCHY : PTAM_EST_TUKEY));
+        ptam_preload(k7_wave_fn(512, true, est ? PTAM_EST_CAUCHY : PTAM_EST_TUKEY));
+    }
+}

@@ -72,6 +72,13 @@ void* ctx_cache_give(ptam_ctx::Cached* c, void* p, size_t bytes);               
 // hipStreamSynchronize sleeps on an interrupt, and waking from it was measured at up to 7 ms on this platform; the waits
 // of this library end within microseconds to a few milliseconds, so every one of them polls first (2 ms) and only then sleeps.
 hipError_t ptam_stream_wait(hipStream_t stream);
+void ptam_preload(const void* kernel);   // hipFuncGetAttributes: forces the kernel's code object to be loaded
+void ba_preload_kernels();
+void solve_preload_kernels();
+void pose_preload_kernels();
+void patch_preload_kernels();
+void kf_preload_kernels();
+void pvs_preload_kernels();
 int ctx_scratch(ptam_ctx* ctx, size_t bytes, void** out);     // device scratch >= bytes
 int ctx_pinned(ptam_ctx* ctx, size_t bytes, void** out);      // pinned host staging >= bytes
 

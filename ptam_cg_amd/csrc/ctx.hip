@@ -27,6 +27,11 @@ int ctx_scratch(ptam_ctx* ctx, size_t bytes, void** out) {
     return PTAM_OK;
 }
 
+void ptam_preload(const void* kernel) {
+    hipFuncAttributes a;
+    if (hipFuncGetAttributes(&a, kernel) != hipSuccess) (void)hipGetLastError();
+}
+
 hipError_t ptam_stream_wait(hipStream_t stream) {
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
@@ -192,6 +197,13 @@ int ptam_ctx_create(const ptam_cam_params* cam, int device, ptam_ctx** out) {
         delete c;
         return PTAM_E_HIP;
     }
+    ptam_preload((const void*)project_points_kernel);
+    ba_preload_kernels();
+    solve_preload_kernels();
+    pose_preload_kernels();
+    patch_preload_kernels();
+    kf_preload_kernels();
+    pvs_preload_kernels();
     *out = c;
     return PTAM_OK;
 }

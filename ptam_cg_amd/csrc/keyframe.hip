@@ -523,3 +523,15 @@ int ptam_kf_read_level(ptam_ctx* ctx, const ptam_kf* kf, int level, uint8_t* px,
 }
 
 }   // extern "C"
+
+// every kernel of this file resolved once, when a context is created: the first launch of a kernel otherwise pays for
+// loading the code object / resolving the function — 10-28 ms in the middle of the first frame or the first adjustment
+void kf_preload_kernels() {
+    ptam_preload((const void*)fast_detect_kernel);
+    ptam_preload((const void*)fast_compact_kernel);
+    ptam_preload((const void*)fast_score_kernel);
+    ptam_preload((const void*)fast_nonmax_kernel);
+    ptam_preload((const void*)shi_tomasi_kernel);
+    ptam_preload((const void*)pyramid_kernel<PTAM_HALFSAMPLE_R>);
+    ptam_preload((const void*)pyramid_kernel<PTAM_HALFSAMPLE_T>);
+}

@@ -621,3 +621,14 @@ int ptam_epipolar_search_batch(ptam_ctx* ctx, const ptam_kf* src, ptam_kf* targe
 }
 
 }   // extern "C"
+
+// every kernel of this file resolved once, when a context is created: the first launch of a kernel otherwise pays for
+// loading the code object / resolving the function — 10-28 ms in the middle of the first frame or the first adjustment
+void patch_preload_kernels() {
+    ptam_preload((const void*)zmssd_search_kernel);
+    ptam_preload((const void*)zmssd_points_kernel);
+    ptam_preload((const void*)subpix_kernel);
+    ptam_preload((const void*)make_templates_kernel);
+    ptam_preload((const void*)implane_corners_kernel);
+    ptam_preload((const void*)epipolar_search_kernel);
+}

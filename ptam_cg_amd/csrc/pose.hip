@@ -1085,3 +1085,12 @@ int ptam_calc_pose_update(ptam_ctx* ctx, int n, const ptam_pose_update_meas* mea
 }
 
 }   // extern "C"
+
+// every kernel of this file resolved once, when a context is created: the first launch of a kernel otherwise pays for
+// loading the code object / resolving the function — 10-28 ms in the middle of the first frame or the first adjustment
+void pose_preload_kernels() {
+    ptam_preload((const void*)pose_gn_kernel);
+    ptam_preload((const void*)pose_gn_small_kernel);
+    ptam_preload((const void*)calc_pose_update_kernel);
+    ptam_preload((const void*)gather_pose_meas_kernel);
+}

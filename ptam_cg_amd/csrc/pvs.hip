@@ -99,3 +99,9 @@ extern "C" int ptam_track_pvs(ptam_ctx* ctx, int n, const ptam_pvs_point* points
     HIP_TRY(ptam_stream_wait(ctx->stream));
     return PTAM_OK;
 }
+
+// every kernel of this file resolved once, when a context is created: the first launch of a kernel otherwise pays for
+// loading the code object / resolving the function — 10-28 ms in the middle of the first frame or the first adjustment
+void pvs_preload_kernels() {
+    ptam_preload((const void*)track_pvs_kernel);
+}

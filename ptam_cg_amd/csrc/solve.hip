@@ -437,3 +437,10 @@ int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
     HIP_TRY(hipGetLastError());
     return PTAM_OK;
 }
+
+// every kernel of this file resolved once, when a context is created: the first launch of a kernel otherwise pays for
+// loading the code object / resolving the function — 10-28 ms in the middle of the first frame or the first adjustment
+void solve_preload_kernels() {
+    ptam_preload((const void*)ldlt_step_kernel);
+    ptam_preload((const void*)ldlt_backward_kernel);
+}
