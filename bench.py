@@ -195,16 +195,14 @@ def main():
         torch.cuda.synchronize() if torch.cuda.is_available() else None
         ctx.sync()
 
-    # Both bundles are built and made resident first, so that the W untimed warm-up trials run IMMEDIATELY before the timed
-    # region: building a bundle is ~100 ms of host work (sort + upload) during which the GPU idles into a low power state,
-    # and the first launches after that wait 12-28 ms for the chip to come back (measured: PTAM_DEBUG_STALL=1 reports the
-    # first trial's wait) — a property of the platform's power management, not of the path being measured.
+    # All bundles are built and made resident first, so that the W untimed warm-up trials run IMMEDIATELY before the timed
+    # region (building a bundle is ~100 ms of host work with nothing queued).  DESIGN.md section 5 lists what once made
+    # this bench bimodal (first-launch code loading, allocation under queued work, interrupt sleeps) and what was changed.
     wb = new_bundle(args.warmup) if args.warmup > 0 else None
     ba = new_bundle(args.steps)
     # Spin-up: blocks of 1000 back-to-back K7 launches on a LOCAL copy of the shard (no communicator: ranks may need
     # different block counts) until the launch time has settled (at least 6, at most 150 blocks) — the launch time is the
-    # clock probe.  Without it a Compute() that starts on an idle chip has its first trial wait 10-28 ms for its scalars
-    # (PTAM_DEBUG_STALL=1 reports it; DESIGN.md section 5 lists the three causes of the once bimodal bench).
+    # clock probe (a precaution against clock ramps; PTAM_DEBUG_STALL=1 reports any wait above 3 ms inside Compute()).
     sb = synth.load_into(host.Bundle(ctx), prob)
     best, calm, spin = None, 0, []
     for blk in range(150):
