@@ -663,6 +663,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
                 sigma_sq = est_sigma_sq_from_median(opts.estimator, med, (unsigned long long)nf);
             }
             PH(1)
+            const double inv_sigma_sq = 1.0 / sigma_sq;   // (one division for the workgroup's weights instead of one per measurement)
             // WLS<6> :973-1002: C += (w J_r)(J_r)^T, b += e_r (w J_r), J_r scaled by dSqrtInvNoise
             double acc[27];
 #pragma unroll
@@ -670,7 +671,15 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
 #pragma unroll
             for (int q = 0; q < GS_MPT; q++) {
                 // weight 0 (an outlier, or no measurement in this slot): every product below is an exact zero
-                const double wgt = t[q].found ? est_weight(opts.estimator, e2[q], sigma_sq) : 0.0;
+                double wgt;   // Weight() of include/Tools.h:128-228 with e^2 / sigma^2 as a product
+                if (opts.estimator == PTAM_EST_TUKEY) {
+                    const double r = e2[q] > sigma_sq ? 0.0 : 1.0 - e2[q] * inv_sigma_sq;
+                    wgt = r * r;
+                } else if (opts.estimator == PTAM_EST_CAUCHY)
+                    wgt = 1.0 / (1.0 + e2[q] * inv_sigma_sq);
+                else
+                    wgt = e2[q] < sigma_sq ? 1.0 : sqrt(sigma_sq / e2[q]);
+                wgt = t[q].found ? wgt : 0.0;
                 const double* Jm = t[q].J;
                 const double er[2] = {ex[q], ey[q]};
 #pragma unroll
