@@ -86,15 +86,22 @@ __device__ double block_select_kth(GnShared& sh, const PoseState* __restrict__ s
 }
 
 // TooN Cholesky<6> (unpivoted LDL^T, lower triangle) + backsub, run by one thread
+// (reciprocals by v_rcp_f64 + two Newton steps, as everywhere in the bundle kernels: one thread runs this on the critical
+//  path of every iteration, and an IEEE division is a dependent chain of ~12 instructions — twelve of them were half of it)
 __device__ void ldlt6_solve(double A[36], const double b[6], double x[6]) {
+    double inv_d[6];
+#pragma unroll
     for (int col = 0; col < 6; col++) {
         double inv_diag = 1;
+#pragma unroll
         for (int row = col; row < 6; row++) {
             double val = A[row * 6 + col];
+#pragma unroll
             for (int c2 = 0; c2 < col; c2++) val -= A[c2 * 6 + col] * A[row * 6 + c2];
             if (row == col) {
                 A[row * 6 + col] = val;
-                inv_diag = 1 / val;
+                inv_diag = rcp_nr(val);
+                inv_d[col] = inv_diag;
             } else {
                 A[col * 6 + row] = val;
                 A[row * 6 + col] = val * inv_diag;
@@ -102,14 +109,19 @@ __device__ void ldlt6_solve(double A[36], const double b[6], double x[6]) {
         }
     }
     double y[6];
+#pragma unroll
     for (int i = 0; i < 6; i++) {
         double val = b[i];
+#pragma unroll
         for (int j = 0; j < i; j++) val -= A[i * 6 + j] * y[j];
         y[i] = val;
     }
-    for (int i = 0; i < 6; i++) y[i] /= A[i * 6 + i];   // (kept as divisions: bit-identical D-scale to TooN's backsub)
+#pragma unroll
+    for (int i = 0; i < 6; i++) y[i] *= inv_d[i];
+#pragma unroll
     for (int i = 5; i >= 0; i--) {
         double val = y[i];
+#pragma unroll
         for (int j = i + 1; j < 6; j++) val -= A[j * 6 + i] * x[j];
         x[i] = val;
     }
