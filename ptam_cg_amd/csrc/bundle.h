@@ -58,11 +58,14 @@ struct BaScalars {
     int select_overflow;    //                 a rank had more last-stage candidates than its exchange slot holds
     int end_step;           // after a trial: the LM step is over (accepted, converged or out of trials)
     int spec_go;            //                and the next step will run with the trial state as current
+    int spec_stay;          //                or: the step is over WITHOUT an accepted trial (new == current error) and the
+                            //                next one starts from the unchanged state with the unchanged lambda
+    int pad_;
 };
 
 struct BaDev {
     int C, F, P, M;
-    int guard;              // 0: run; 1: run only if sc->spec_go; 2: only if sc->end_step (speculatively enqueued kernels)
+    int guard;              // 0: run; 1: run only if sc->spec_go or sc->spec_stay; 2: only if sc->end_step (speculatively enqueued kernels)
     int n, npad;            // camera system order 6F and its padding to SOLVE_NB
     int band;               // block bandwidth of S (in SOLVE_NB blocks): |block(row) - block(col)| <= band wherever two cameras share a point
     int n_chunks, grid_acc; // measurement chunks; persistent grid of the accumulate kernel

@@ -48,7 +48,7 @@ __device__ __forceinline__ int e2_bin2(double e2) {   // next 12 bits
 // what the host is about to decide from the same numbers.
 __device__ __forceinline__ bool ba_guard_blocks(const BaDev& d) {
     if (d.guard == 0) return false;
-    return d.guard == 1 ? d.sc->spec_go == 0 : d.sc->end_step == 0;
+    return d.guard == 1 ? (d.sc->spec_go == 0 && d.sc->spec_stay == 0) : d.sc->end_step == 0;
 }
 
 // project one measurement: returns false (bad) if z <= 0  (ProjectAndFindSquaredError :164-180).
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(BA_CHUNK) project_e2_kernel(DevCam cam, BaDev 
 #define P1_U 8
 #endif
 template <bool PURGE>
-__device__ __forceinline__ void pass1_adopt(const BaDev& d, bool adopt, bool build_hist, unsigned* hist) {
+__device__ __forceinline__ void pass1_adopt(const BaDev& d, bool adopt, bool build_hist, unsigned* hist, bool keep = false) {
     constexpr int U = P1_U;
     const int tid = threadIdx.x, lane = tid & 63;
     const int m_end = (d.M + 63) & ~63;   // whole waves stay together for the ballot
@@ -231,7 +231,7 @@ __device__ __forceinline__ void pass1_adopt(const BaDev& d, bool adopt, bool bui
             const int mc = min(m[u], d.M - 1);
             st[u] = m[u] < d.M ? (int)d.m_state[mc] : (int)MS_DEAD;
             zb[u] = d.m_zbad_t[mc];
-            e2[u] = d.m_e2t[mc];
+            e2[u] = keep ? d.m_e2[mc] : d.m_e2t[mc];   // (keep: the state did not move, pass 1's own errors stand — pass1_keep_kernel)
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -249,6 +249,10 @@ __device__ __forceinline__ void pass1_adopt(const BaDev& d, bool adopt, bool bui
                         st[u] = MS_DEAD;
                     }
                 }
+            }
+            if (keep) {
+                if (in && st[u] == MS_ALIVE && build_hist) atomicAdd(&hist[e2_bin(e2[u])], 1u);
+                continue;
             }
             if (!adopt || !in) continue;
             if (st[u] == MS_DEAD) continue;
@@ -317,11 +321,11 @@ __global__ void __launch_bounds__(256) pass1_keep_kernel(BaDev d) {
 __global__ void __launch_bounds__(256) purge_pass1_kernel(BaDev d) {
     TL_MARK(d, 1)
     if (d.sc->end_step == 0) return;
-    const bool go = d.sc->spec_go != 0;
+    const bool go = d.sc->spec_go != 0, stay = d.sc->spec_stay != 0;
     __shared__ unsigned hist[HIST_BINS];
-    if (go) hist_clear(hist);
-    pass1_adopt<true>(d, go, go, hist);
-    if (go) hist_flush(d, hist);
+    if (go || stay) hist_clear(hist);
+    pass1_adopt<true>(d, go, go || stay, hist, stay);
+    if (go || stay) hist_flush(d, hist);
 }
 
 // =================================================================================================
@@ -956,6 +960,7 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4,
 jac_accum_wave_kernel(DevCam cam, BaDev d, int cur, int est_arg, int per_wave, int extra) {
     TL_MARK(d, 4)
     if (ba_guard_blocks(d)) return;
+    if (d.guard == 1 && d.sc->spec_stay) cur ^= 1;   // (launched for the trial state; "stay": the unchanged current one)
     const int est = EST >= 0 ? EST : est_arg;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Ul = smem;
@@ -1363,9 +1368,10 @@ __global__ void __launch_bounds__(256) vinv_kernel(BaDev d, double lambda) {
 }
 // The partial reduction and V*^-1 both only depend on K7 and not on each other: one launch, the first
 // nx * RSPLIT workgroups reduce, the rest invert (a dependent launch costs ~2.3 us on this chip).
-__global__ void __launch_bounds__(256) reduce_vinv_kernel(BaDev d, int grid_acc, int nx, double lambda) {
+__global__ void __launch_bounds__(256) reduce_vinv_kernel(BaDev d, int grid_acc, int nx, double lambda, double lambda_stay) {
     TL_MARK(d, 5)
     if (ba_guard_blocks(d)) return;
+    if (d.guard == 1 && d.sc->spec_stay) lambda = lambda_stay;
     const int b = blockIdx.x, nr = nx * RSPLIT;
     if (b < nr)
         reduce_partials_body(d, grid_acc, b % nx, b / nx);
@@ -1944,6 +1950,7 @@ __global__ void __launch_bounds__(256) finalize_new_kernel(BaDev d, double conv_
         const bool end_step = !(ne > ce) || conv || last_allowed != 0;
         d.sc->end_step = end_step ? 1 : 0;
         d.sc->spec_go = (end_step && ne < ce && !conv && last_allowed == 0) ? 1 : 0;
+        d.sc->spec_stay = (end_step && !(ne < ce) && !conv && last_allowed == 0) ? 1 : 0;
     }
     // single-device runs publish the scalars from here (publish_scalars_kernel's job, one launch less per trial)
     if (host_slots) {
@@ -2734,7 +2741,7 @@ static int ba_p1_blocks() {   // workgroup cap of the pass-1 kernels (each flush
     }();
     return n;
 }
-static int ba_enqueue_speculative(ptam_ba* ba, double lambda_next) {
+static int ba_enqueue_speculative(ptam_ba* ba, double lambda_next, double lambda_stay) {
     ptam_ctx* ctx = ba->ctx;
     BaDev d = ba->d;
     const double min_s2 = ba->opts.min_sigma * ba->opts.min_sigma;
@@ -2747,7 +2754,7 @@ static int ba_enqueue_speculative(ptam_ba* ba, double lambda_next) {
     {
         const int nx = std::max(1, (d.F * 27 + 63) / 64);
         hipLaunchKernelGGL(reduce_vinv_kernel, dim3(nx * RSPLIT + (d.P + 255) / 256), dim3(256), 0, ctx->stream, d, d.grid_acc, nx,
-                           lambda_next);
+                           lambda_next, lambda_stay);
     }
     HIP_TRY(hipGetLastError());
     return PTAM_OK;
@@ -3094,7 +3101,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
             rc = ba_publish_scalars(ba);
             if (rc) return rc;
             if (spec) {   // what follows an accepted trial, queued while the host waits for the verdict
-                rc = ba_enqueue_speculative(ba, lambda * 0.3);
+                rc = ba_enqueue_speculative(ba, lambda * 0.3, lambda);
                 if (rc) return rc;
             }
             BA_DBG("trial %d enqueued, waiting", counter);
@@ -3176,7 +3183,10 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
         }
         // the device took the same decision for the guarded kernels: accepted and the loop goes on -> they ran
         // (purge of this step included); otherwise they left at once and the step is closed here
-        spec_ready = spec && ran_any && new_err < cur_err && !ba->converged && !hit_max;
+        // ... or took the third way: the step ended with new == current error (nothing accepted, nothing rejected — the
+        // update no longer moves a coordinate): the guarded kernels ran for the UNCHANGED state and lambda ("stay")
+        const bool stayed = spec && ran_any && !(new_err < cur_err) && !(new_err > cur_err) && !ba->converged && !hit_max;
+        spec_ready = (spec && ran_any && new_err < cur_err && !ba->converged && !hit_max) || stayed;
         if (!spec_ready && d.M > 0)
             hipLaunchKernelGGL(purge_kernel, dim3((d.M + 255) / 256), dim3(256), 0, ctx->stream, d);   // :536-547
         prev_end_pending = true;
