@@ -1577,7 +1577,7 @@ __global__ void __launch_bounds__(256) schur_tile_mfma_kernel(BaDev d) {
         return have ? d.s_entries[e] : none;
     };
 #ifdef K7_TIMING
-    long long t_comp = 0, t_store = 0, t_fetch = 0, t_bar = 0;
+    long long t_comp = 0, t_store = 0, t_fetch = 0, t_bar = 0, t_wait = 0;
     const long long t_start = (long long)__builtin_readcyclecounter();
 #endif
     // prologue: round 0 into stage 0, entries of round 1 in registers
@@ -1624,6 +1624,9 @@ __global__ void __launch_bounds__(256) schur_tile_mfma_kernel(BaDev d) {
         t_comp += (long long)__builtin_readcyclecounter() - tc0;
 #endif
         // ---- stage round i+1 ----
+#ifdef K7_TIMING
+        SCH_T(t_wait, asm volatile("s_waitcnt vmcnt(0)" ::: "memory"));
+#endif
         SCH_T(t_store, if (more) schur_store_m(d, stage[(i + 1) & 1], pre, diag, a, b, le, ls, lane));
         ent_next = ent2;
         have_next = have2;
@@ -1637,6 +1640,7 @@ __global__ void __launch_bounds__(256) schur_tile_mfma_kernel(BaDev d) {
         d.dbg[13] = t_store;
         d.dbg[14] = t_bar;
         d.dbg[15] = n_rounds;
+        d.dbg[9] = t_wait;
     }
 #endif
     // E partials: sum the four k-quarters of a row (lanes l15 + 16 q)
@@ -3212,8 +3216,8 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
         HIP_TRY(hipMemcpy(h, d.dbg, sizeof h, hipMemcpyDeviceToHost));
         std::printf("LDLT step2 wg0: loop %lld tail %lld | last wg (role %lld): loop %lld tail %lld\n", h[1] - h[0], h[2] - h[1], h[7],
                     h[5] - h[4], h[6] - h[5]);
-        std::printf("SCHUR wg100 cycles: total %lld fetch %lld compute %lld store %lld barrier %lld rounds %lld\n", h[10], h[11],
-                    h[12], h[13], h[14], h[15]);
+        std::printf("SCHUR wg100 cycles: total %lld fetch %lld compute %lld wait-for-loads %lld store %lld barrier %lld rounds %lld\n", h[10], h[11],
+                    h[12], h[9], h[13], h[14], h[15]);
     }
 #endif
     // ---- read back results: one pinned staging buffer, one synchronisation (pageable destinations cost ~100 us each) ----
