@@ -27,2017 +27,12 @@
 
 #include "bundle.h"
 
-// =================================================================================================
-// device helpers
-// =================================================================================================
-// First-level bin of the order-statistic select: the top 16 bits of the fp64 pattern (exponent + 4
-// mantissa bits = 16 sub-bins per binade) relative to 2^-24, clamped to [0, 4095] — monotone in the
-// value, 256 binades wide (6e-8 .. 7e69).  A rank that lands in a clamped end bin takes the generic
-// full-width radix path of select_final_kernel.
-#define E2_BIN_BASE ((1023 - 24) << 4)
-__device__ __forceinline__ int e2_bin(double e2) {
-    const int t = (int)((unsigned long long)__double_as_longlong(e2) >> 48) - E2_BIN_BASE;
-    return t < 0 ? 0 : (t > HIST_BINS - 1 ? HIST_BINS - 1 : t);
-}
-__device__ __forceinline__ int e2_bin2(double e2) {   // next 12 bits
-    return (int)(((unsigned long long)__double_as_longlong(e2) >> 36) & (HIST_BINS - 1));
-}
-
-// Kernels of the NEXT LM step are enqueued before the host has seen the trial's outcome (the GPU would idle ~10 us
-// per trial otherwise).  They carry d.guard != 0 and leave at once unless finalize_new_kernel decided on the device
-// what the host is about to decide from the same numbers.
-__device__ __forceinline__ bool ba_guard_blocks(const BaDev& d) {
-    if (d.guard == 0) return false;
-    return d.guard == 1 ? (d.sc->spec_go == 0 && d.sc->spec_stay == 0) : d.sc->end_step == 0;
-}
-
-// project one measurement: returns false (bad) if z <= 0  (ProjectAndFindSquaredError :164-180).
-// Same arithmetic as cam_project / cam_derivs (common.h) with the divisions replaced by three
-// Newton-refined reciprocals (1/z, 1/r, 1/(1+k^2 r^2)); pass 1, pass 2 and the new-error pass all
-// go through this one function, so they see bit-identical projections.
-struct BaProj {
-    double X, Y, Z;      // v3Cam
-    double x, y;         // z = 1 plane
-    double u, v;         // image
-    double r, ir, f;     // radius, 1/r, rtrans_factor
-};
-// atan for x >= 0 in ~45 VALU instructions (the library call is ~80 and sits in K7's critical VALU
-// budget): argument reduction atan(x) = atan(c) + atan((x - c) / (1 + c x)) with c in {0, 1/2, 1, 3/2}
-// (x >= 39/16: pi/2 - atan(1/x)) and the classic 11-term odd minimax polynomial on |t| < 7/16
-// (Sun fdlibm's published coefficients); the quotient uses rcp + 2 Newton steps.  Measured against
-// libm over [1e-8, 1e3]: <= 2 ulp (constants: tests/test_oracle_kat.py::test_atan_reduction_constants;
-// the device code itself is covered by the BA parity tests).
-// The constants come from a __constant__ table: uniform loads put them in SGPRs, which a VOP3 fp64
-// instruction reads directly — as literals each use would cost two v_mov_b32 and a VGPR pair.
-__constant__ double BA_ATAN_K[20] = {
-    3.33333333333329318027e-01,  -1.99999999998764832476e-01, 1.42857142725034663711e-01,  -1.11111104054623557880e-01,
-    9.09088713343650656196e-02,  -7.69187620504482999495e-02, 6.66107313738753120669e-02,  -5.83357013379057348645e-02,
-    4.97687799461593236017e-02,  -3.65315727442169155270e-02, 1.62858201153657823623e-02,
-    4.63647609000806093515e-01,  7.85398163397448278999e-01,  9.82793723247329054082e-01,  1.57079632679489655800e+00,
-    0.4375, 0.6875, 1.1875, 2.4375, 1.5};
-__device__ __forceinline__ double ba_atan_pos(double x) {
-    const double* __restrict__ K = BA_ATAN_K;
-    double c = 0.0, hi = 0.0;
-    if (x >= K[15]) c = 0.5, hi = K[11];
-    if (x >= K[16]) c = 1.0, hi = K[12];
-    if (x >= K[17]) c = K[19], hi = K[13];
-    double num = x - c, den = fma(c, x, 1.0);
-    if (x >= K[18]) {
-        num = -1.0;
-        den = x;
-        hi = K[14];
-    }
-    const double t = num * rcp_nr(den);
-    const double z = t * t, w = z * z;
-    // v_fma_f64 with the coefficient as an SGPR operand (left alone the compiler picks v_fmac and
-    // first copies every coefficient into a VGPR pair)
-#define FMA_SK(a, b, k) ({ double r_; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r_) : "v"(a), "v"(b), "s"(k)); r_; })
-    double p1 = FMA_SK(w, K[10], K[8]);   // (K[10] is copied once: two scalar operands are not encodable)
-    p1 = FMA_SK(w, p1, K[6]);
-    p1 = FMA_SK(w, p1, K[4]);
-    p1 = FMA_SK(w, p1, K[2]);
-    p1 = FMA_SK(w, p1, K[0]);
-    double p2 = FMA_SK(w, K[9], K[7]);
-    p2 = FMA_SK(w, p2, K[5]);
-    p2 = FMA_SK(w, p2, K[3]);
-    p2 = FMA_SK(w, p2, K[1]);
-#undef FMA_SK
-    const double s1 = z * p1, s2 = w * p2;
-    return hi - (t * (s1 + s2) - t);
-}
-// 1/sqrt(a), a > 0: v_rsq_f64 + 2 Newton steps (<= 1 ulp)
-__device__ __forceinline__ double rsq_nr(double a) {
-    double y = __builtin_amdgcn_rsq(a);
-    const double h = 0.5 * a;
-    y = fma(y, fma(-h * y, y, 0.5), y);
-    y = fma(y, fma(-h * y, y, 0.5), y);
-    return y;
-}
-__device__ __forceinline__ bool ba_project(const DevCam& cam, const double* __restrict__ T, const double* __restrict__ X,
-                                           BaProj& p) {
-    se3_apply(T, X[0], X[1], X[2], p.X, p.Y, p.Z);
-    if (p.Z <= 0) return false;
-    const double iz = rcp_nr(p.Z);
-    p.x = p.X * iz;
-    p.y = p.Y * iz;
-    const double r2 = p.x * p.x + p.y * p.y;
-    if (r2 < 1e-6 || cam.w == 0.0) {   // r < 0.001  (src/ATANCamera.h:105-111)
-        p.r = r2 > 0 ? r2 * rsq_nr(r2) : 0.0;
-        p.ir = 0;
-        p.f = 1.0;
-    } else {
-        p.ir = rsq_nr(r2);
-        p.r = r2 * p.ir;
-        const double t = p.r * cam.two_tan;   // (negative only for a negative FOV parameter)
-        p.f = cam.w_inv * copysign(ba_atan_pos(fabs(t)), t) * p.ir;
-    }
-    p.u = cam.cx + cam.fx * (p.f * p.x);
-    p.v = cam.cy + cam.fy * (p.f * p.y);
-    return true;
-}
-// GetProjectionDerivs (src/ATANCamera.cc:179-209): dFdx = x*g, dFdy = y*g with the common factor
-// g = [ (k/w)/(1+k^2 r^2) - f ] / r^2
-__device__ __forceinline__ void ba_derivs(const DevCam& cam, const BaProj& p, double D[4]) {
-    const double r = p.r * cam.dist_enabled;
-    double g = 0.0;
-    if (!(r < 0.01)) {
-        const double k = cam.two_tan;
-        const double iden = rcp_nr(1 + k * k * r * r);
-        g = (cam.w_inv * k * iden - p.f) * (p.ir * p.ir);
-    }
-    const double dx = p.x * g, dy = p.y * g;
-    D[0] = cam.fx * (dx * p.x + p.f);
-    D[2] = cam.fy * (dx * p.y);
-    D[1] = cam.fx * (dy * p.x);
-    D[3] = cam.fy * (dy * p.y + p.f);
-}
-// Tukey with a precomputed 1/sigma^2 (other estimators keep their general form)
-__device__ __forceinline__ double ba_sqrt_weight(int est, double e2, double s2, double is2) {
-    if (est == PTAM_EST_TUKEY) return e2 > s2 ? 0.0 : 1.0 - e2 * is2;
-    return est_sqrt_weight(est, e2, s2);
-}
-__device__ __forceinline__ double ba_objective(int est, double e2, double s2, double is2) {
-    if (est == PTAM_EST_TUKEY) {
-        if (e2 > s2) return 1.0;
-        const double dd = 1.0 - e2 * is2;
-        return 1.0 - dd * dd * dd;
-    }
-    return est_objective(est, e2, s2);
-}
-
-// =================================================================================================
-// K5: pass 1
-// =================================================================================================
-__global__ void __launch_bounds__(BA_CHUNK) project_e2_kernel(DevCam cam, BaDev d, int cur, int build_hist) {
-    TL_MARK(d, 13)
-    __shared__ unsigned hist[HIST_BINS];
-    const int tid = threadIdx.x;
-    if (build_hist)
-        for (int b = tid; b < HIST_BINS; b += BA_CHUNK) hist[b] = 0;
-    __syncthreads();
-    const double* __restrict__ pose = d.pose[cur];
-    const double* __restrict__ pt = d.pt[cur];
-    for (int ci = blockIdx.x; ci < d.n_chunks; ci += gridDim.x) {
-        const BaChunk ch = d.chunks[ci];
-        const int m = ch.m_begin + tid;
-        if (m < ch.m_end) {
-            const int st = d.m_state[m];
-            if (st != MS_DEAD) {
-                const int c = d.m_cam[m], p = d.m_pt[m];
-                BaProj pr;
-                if (!ba_project(cam, pose + 12 * c, pt + 3 * p, pr)) {
-                    d.m_state[m] = MS_BAD;
-                } else {
-                    const double2 fo = d.m_found[m];
-                    const double s = d.m_s[m];
-                    const double ex = s * (fo.x - pr.u), ey = s * (fo.y - pr.v);
-                    const double e2 = ex * ex + ey * ey;
-                    d.m_e2[m] = e2;
-                    if (st != MS_ALIVE) d.m_state[m] = MS_ALIVE;
-                    if (build_hist) atomicAdd(&hist[e2_bin(e2)], 1u);
-                }
-            }
-        }
-    }
-    if (build_hist) {
-        __syncthreads();
-        for (int b = tid; b < HIST_BINS; b += BA_CHUNK) {
-            const unsigned c = hist[b];
-            if (c) atomicAdd(&d.hist[b], c);
-        }
-    }
-}
-
-// Pass 1 of the step that follows an ACCEPTED trial: the trial's new-error pass (point_update_kernel)
-// already projected every measurement with what are now the current poses / points, so this only
-// adopts its squared errors and z <= 0 flags and builds the histogram — no projection (K5 proper is project_e2_kernel above).  With PURGE it first closes the
-// finished step (purge_kernel's body: erase bad measurements, append to the outlier list :536-547).
-// P1_U measurements per thread, every load issued (clamped, unconditional) before the first use: the
-// kernel is a chain of dependent round trips otherwise (state -> flag -> e^2), ~1 us each.
-#ifndef P1_U
-#define P1_U 8
-#endif
-template <bool PURGE>
-__device__ __forceinline__ void pass1_adopt(const BaDev& d, bool adopt, bool build_hist, unsigned* hist, bool keep = false) {
-    constexpr int U = P1_U;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int m_end = (d.M + 63) & ~63;   // whole waves stay together for the ballot
-    for (int base = blockIdx.x * (256 * U); base < m_end; base += gridDim.x * (256 * U)) {
-        int m[U], st[U], zb[U];
-        double e2[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            m[u] = base + u * 256 + tid;
-            const int mc = min(m[u], d.M - 1);
-            st[u] = m[u] < d.M ? (int)d.m_state[mc] : (int)MS_DEAD;
-            zb[u] = d.m_zbad_t[mc];
-            e2[u] = keep ? d.m_e2[mc] : d.m_e2t[mc];   // (keep: the state did not move, pass 1's own errors stand — pass1_keep_kernel)
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const bool in = m[u] < d.M;
-            if (PURGE) {
-                const bool bad = st[u] == MS_BAD;
-                const unsigned long long mask = __ballot(bad);
-                if (mask != 0) {
-                    int at = 0;
-                    if (lane == 0) at = atomicAdd(&d.sc->n_outliers, __popcll(mask));   // one atomic per wave
-                    at = __shfl(at, 0, 64);
-                    if (bad) {
-                        d.outliers[at + __popcll(mask & ((1ull << lane) - 1ull))] = d.m_orig[m[u]];
-                        d.m_state[m[u]] = MS_DEAD;
-                        st[u] = MS_DEAD;
-                    }
-                }
-            }
-            if (keep) {
-                if (in && st[u] == MS_ALIVE && build_hist) atomicAdd(&hist[e2_bin(e2[u])], 1u);
-                continue;
-            }
-            if (!adopt || !in) continue;
-            if (st[u] == MS_DEAD) continue;
-            if (zb[u]) {
-                d.m_state[m[u]] = MS_BAD;
-            } else {
-                d.m_e2[m[u]] = e2[u];
-                if (st[u] != MS_ALIVE) d.m_state[m[u]] = MS_ALIVE;
-#ifndef P1_NOLDS
-                if (build_hist) atomicAdd(&hist[e2_bin(e2[u])], 1u);
-#endif
-            }
-        }
-    }
-}
-__device__ __forceinline__ void hist_clear(unsigned* hist) {
-    for (int b = threadIdx.x; b < HIST_BINS; b += 256) hist[b] = 0;
-    __syncthreads();
-}
-__device__ __forceinline__ void hist_flush(const BaDev& d, const unsigned* hist) {
-    __syncthreads();
-    for (int b = threadIdx.x; b < HIST_BINS; b += 256) {
-        const unsigned c = hist[b];
-#ifndef P1_NOFLUSH
-        if (c) atomicAdd(&d.hist[b], c);
-#else
-        if (c == 0xffffffffu) d.hist[b] = c;
-#endif
-    }
-}
-__global__ void __launch_bounds__(256) pass1_from_trial_kernel(BaDev d, int build_hist) {
-    TL_MARK(d, 14)
-    if (ba_guard_blocks(d)) return;
-    __shared__ unsigned hist[HIST_BINS];
-    if (build_hist) hist_clear(hist);
-    pass1_adopt<false>(d, true, build_hist != 0, hist);
-    if (build_hist) hist_flush(d, hist);
-}
-// Pass 1 of a step that follows a step WITHOUT an accepted trial (every trial rejected until the iteration cap, or —
-// at the noise floor — a trial whose error equals the current one bit for bit): poses and points have not moved, so the
-// squared errors of the previous pass 1 still stand for every measurement that survived the purge; only the histogram
-// has to be rebuilt over them.  (The z <= 0 cases of that state were marked then and have been purged since.)
-__global__ void __launch_bounds__(256) pass1_keep_kernel(BaDev d) {
-    __shared__ unsigned hist[HIST_BINS];
-    hist_clear(hist);
-    constexpr int U = P1_U;
-    for (int base = blockIdx.x * (256 * U); base < d.M; base += gridDim.x * (256 * U)) {
-        int st[U];
-        double e2[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int m = base + u * 256 + threadIdx.x, mc = min(m, d.M - 1);
-            st[u] = m < d.M ? (int)d.m_state[mc] : (int)MS_DEAD;
-            e2[u] = d.m_e2[mc];
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++)
-            if (st[u] == MS_ALIVE) atomicAdd(&hist[e2_bin(e2[u])], 1u);
-    }
-    hist_flush(d, hist);
-}
-
-// The speculative step prologue's first launch: the purge that closes the finished step (guarded by end_step)
-// and, if the loop goes on from an accepted trial (spec_go), pass 1 from the trial's errors — one dependent
-// launch (~2.3 us) less than purge_kernel + pass1_from_trial_kernel.
-__global__ void __launch_bounds__(256) purge_pass1_kernel(BaDev d) {
-    TL_MARK(d, 1)
-    if (d.sc->end_step == 0) return;
-    const bool go = d.sc->spec_go != 0, stay = d.sc->spec_stay != 0;
-    __shared__ unsigned hist[HIST_BINS];
-    if (go || stay) hist_clear(hist);
-    pass1_adopt<true>(d, go, go || stay, hist, stay);
-    if (go || stay) hist_flush(d, hist);
-}
-
-// =================================================================================================
-// K6: exact order statistic
-// =================================================================================================
-// histogram of an explicit key array (sharded mode: the gathered e^2 of all ranks)
-__global__ void __launch_bounds__(256) hist_keys_kernel(const double* __restrict__ keys, long long n, unsigned* __restrict__ ghist) {
-    __shared__ unsigned hist[HIST_BINS];
-    for (int b = threadIdx.x; b < HIST_BINS; b += 256) hist[b] = 0;
-    __syncthreads();
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-        atomicAdd(&hist[e2_bin(keys[i])], 1u);
-    __syncthreads();
-    for (int b = threadIdx.x; b < HIST_BINS; b += 256) {
-        const unsigned c = hist[b];
-        if (c) atomicAdd(&ghist[b], c);
-    }
-}
-
-// block-wide: locate the first-level bin that holds rank total/2 (every block computes the same
-// answer from the global histogram; saves a launch + hand-off).  256 threads, 16 bins each.
-__device__ void block_find_bin(const unsigned* __restrict__ hist, long long& total_out, int& bin_out, int& k_out) {
-    __shared__ long long wsum[4];
-    __shared__ long long s_total;
-    __shared__ int s_bin, s_k;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    unsigned c[16];
-    long long s = 0;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        c[j] = hist[16 * tid + j];
-        s += c[j];
-    }
-    const long long incl = wave_incl_scan_i64(s);
-    if (lane == 63) wsum[wid] = incl;
-    if (tid == 0) {
-        s_bin = -1;
-        s_k = 0;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        long long run = 0;
-        for (int i = 0; i < 4; i++) {
-            const long long v = wsum[i];
-            wsum[i] = run;
-            run += v;
-        }
-        s_total = run;
-    }
-    __syncthreads();
-    const long long total = s_total;
-    const long long k = total / 2;   // vdErrorSquared[size()/2]
-    const long long excl = wsum[wid] + incl - s;
-    if (total > 0 && excl <= k && k < excl + s) {
-        long long kk = k - excl;
-        int bb = 16 * tid;
-        for (int j = 0; j < 15; j++)
-            if (kk >= c[j]) {
-                kk -= c[j];
-                bb++;
-            } else
-                break;
-        s_bin = bb;
-        s_k = (int)kk;
-    }
-    __syncthreads();
-    total_out = total;
-    bin_out = s_bin;
-    k_out = s_k;
-}
-
-#define CAND_BUF 2048
-// gather the keys of the selected first-level bin (keys = m_e2 masked by state, or an explicit
-// array) and histogram their next 12 bits (47..36).  Candidates are staged in LDS and appended with
-// one global atomic per flush.
-__global__ void __launch_bounds__(256) select_compact_kernel(BaDev d, const double* __restrict__ keys, long long n,
-                                                             const uint8_t* __restrict__ state) {
-    TL_MARK(d, 2)
-    if (ba_guard_blocks(d)) return;
-    __shared__ double buf[CAND_BUF];
-    __shared__ unsigned h2[HIST_BINS];
-    __shared__ int cnt, gpos;
-    const int tid = threadIdx.x;
-    // the block's keys are fetched 4 per thread, unconditionally (clamped), and the first batch leaves BEFORE the
-    // histogram scan below: one exposed round trip instead of state -> key per 256-key slice
-    constexpr int U = 4;
-    const long long per = (n + gridDim.x - 1) / gridDim.x;
-    const long long i0 = (long long)blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
-    double key[U], nkey[U];
-    bool ok[U], nok[U];
-    auto fetch = [&](long long base, double* kq, bool* oq) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const long long i = base + u * 256 + tid;
-            const long long ic = i < n ? i : (n > 0 ? n - 1 : 0);
-            kq[u] = keys[ic];
-            oq[u] = i < i1 && (!state || state[ic] == MS_ALIVE);
-        }
-    };
-    fetch(i0, key, ok);
-    long long total;
-    int bin, k1;
-    block_find_bin(d.hist, total, bin, k1);
-    if (blockIdx.x == 0 && tid == 0) {
-        d.sc->n_valid = total;
-        d.sc->sel_bin = bin;
-        d.sc->sel_k = k1;
-    }
-    if (bin < 0) return;
-    for (int b = tid; b < HIST_BINS; b += 256) h2[b] = 0;
-    if (tid == 0) cnt = 0;
-    __syncthreads();
-    for (long long base = i0; base < i1; base += 256 * U) {
-        const bool last = base + 256 * U >= i1;
-        if (!last) fetch(base + 256 * U, nkey, nok);
-#pragma unroll
-        for (int u = 0; u < U; u++)
-            if (ok[u] && e2_bin(key[u]) == bin) {
-                const int pos = atomicAdd(&cnt, 1);
-                buf[pos] = key[u];
-                atomicAdd(&h2[e2_bin2(key[u])], 1u);
-            }
-        __syncthreads();
-        if (cnt > CAND_BUF - 256 * U || last) {
-            const int c = cnt;
-            if (tid == 0 && c > 0) gpos = atomicAdd(&d.sc->n_cand, c);
-            __syncthreads();
-            for (int j = tid; j < c; j += 256) d.cand[gpos + j] = buf[j];
-            __syncthreads();
-            if (tid == 0) cnt = 0;
-            __syncthreads();
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            key[u] = nkey[u];
-            ok[u] = nok[u];
-        }
-    }
-    unsigned* hist2 = d.hist + HIST_BINS;
-    for (int b = tid; b < HIST_BINS; b += 256) {
-        const unsigned c = h2[b];
-        if (c) atomicAdd(&hist2[b], c);
-    }
-}
-
-// MSB-first 8-bit radix select of rank k among src[0..n) restricted to keys whose bits above
-// (first_shift + 8) equal those of `prefix`.  1024 threads.
-__device__ unsigned long long block_radix_select(const double* src, int n, int k, unsigned long long prefix,
-                                                 int first_shift, unsigned* hist, int* s_digit, int* s_k) {
-    const int tid = threadIdx.x;
-    for (int shift = first_shift; shift >= 0; shift -= 8) {
-        if (tid < 256) hist[tid] = 0;
-        __syncthreads();
-        for (int i = tid; i < n; i += 1024) {
-            const unsigned long long key = (unsigned long long)__double_as_longlong(src[i]);
-            // (shift + 8 == 64 on a full-width first pass: nothing is fixed yet, and a 64-bit shift by 64 is undefined)
-            if (shift + 8 >= 64 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 255], 1u);
-        }
-        __syncthreads();
-        if (tid < 64) {
-            const unsigned c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
-            const int s = (int)(c0 + c1 + c2 + c3);
-            const int incl = wave_incl_scan_i32(s);
-            const int excl = incl - s;
-            if (excl <= k && k < incl) {
-                int kk = k - excl, dg = 4 * tid;
-                if (kk >= (int)c0) {
-                    kk -= c0;
-                    dg++;
-                    if (kk >= (int)c1) {
-                        kk -= c1;
-                        dg++;
-                        if (kk >= (int)c2) {
-                            kk -= c2;
-                            dg++;
-                        }
-                    }
-                }
-                *s_digit = dg;
-                *s_k = kk;
-            }
-        }
-        __syncthreads();
-        prefix |= (unsigned long long)(*s_digit) << shift;
-        k = *s_k;
-        __syncthreads();
-    }
-    return prefix;
-}
-
-#define SMALL_CAP 4096
-// one block: second-level bin from hist2, collect its (few) members in LDS, finish the select there;
-// sigma^2; reset both histograms
-__global__ void __launch_bounds__(1024) select_final_kernel(BaDev d, int est, double min_sigma_sq) {
-    TL_MARK(d, 3)
-    if (ba_guard_blocks(d)) return;
-    __shared__ double sm[SMALL_CAP];
-    __shared__ unsigned hist[256];
-    __shared__ long long wsum[16];
-    __shared__ int s_digit, s_k, s_bin2, s_k2, s_cnt;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int n = d.sc->n_cand;
-    unsigned* hist2 = d.hist + HIST_BINS;
-    unsigned long long result = 0;
-    const int bin1 = d.sc->sel_bin;
-    if (n > 0 && (bin1 == 0 || bin1 == HIST_BINS - 1)) {
-        // clamped end bin: its members do not share their top bits; plain 8-pass select over them
-        if (tid == 0) s_cnt = 0;
-        __syncthreads();
-        result = block_radix_select(d.cand, n, d.sc->sel_k, 0ull, 56, hist, &s_digit, &s_k);
-    } else if (n > 0) {
-        // second-level bin
-        unsigned c[4];
-        long long s = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            c[j] = hist2[4 * tid + j];
-            s += c[j];
-        }
-        const long long incl = wave_incl_scan_i64(s);
-        if (lane == 63) wsum[wid] = incl;
-        if (tid == 0) s_cnt = 0;
-        __syncthreads();
-        if (tid == 0) {
-            long long run = 0;
-            for (int i = 0; i < 16; i++) {
-                const long long v = wsum[i];
-                wsum[i] = run;
-                run += v;
-            }
-        }
-        __syncthreads();
-        const long long k1 = d.sc->sel_k;
-        const long long excl = wsum[wid] + incl - s;
-        if (excl <= k1 && k1 < excl + s) {
-            long long kk = k1 - excl;
-            int bb = 4 * tid;
-            for (int j = 0; j < 3; j++)
-                if (kk >= c[j]) {
-                    kk -= c[j];
-                    bb++;
-                } else
-                    break;
-            s_bin2 = bb;
-            s_k2 = (int)kk;
-        }
-        __syncthreads();
-        const int bin2 = s_bin2, k2 = s_k2;
-        for (int i = tid; i < n; i += 1024) {
-            const double key = d.cand[i];
-            if (e2_bin2(key) == bin2) {
-                const int pos = atomicAdd(&s_cnt, 1);
-                if (pos < SMALL_CAP) sm[pos] = key;
-            }
-        }
-        __syncthreads();
-        const int m = s_cnt;
-        // bits 63..36 are fixed by (bin, bin2)
-        const unsigned long long top = ((unsigned long long)(bin1 + E2_BIN_BASE) << 48) | ((unsigned long long)bin2 << 36);
-        if (m <= 128) {
-            // the usual case, a handful of keys share both bins: rank by counting, one barrier (five radix passes with
-            // three barriers each are ~1 us of this single-workgroup kernel).  Keys are positive doubles: their bit
-            // patterns order like the values; ties are broken by position, so exactly one key has rank k2.
-            __shared__ unsigned long long s_res;
-            if (tid < m) {
-                const unsigned long long mine = (unsigned long long)__double_as_longlong(sm[tid]);
-                int rank = 0;
-                for (int j = 0; j < m; j++) {
-                    const unsigned long long o = (unsigned long long)__double_as_longlong(sm[j]);
-                    rank += (o < mine || (o == mine && j < tid)) ? 1 : 0;
-                }
-                if (rank == k2) s_res = mine;
-            }
-            __syncthreads();
-            result = s_res;
-        } else if (m <= SMALL_CAP)
-            result = block_radix_select(sm, m, k2, top, 32, hist, &s_digit, &s_k);
-        else   // pathological (thousands of near-identical keys): same passes straight from global
-            result = block_radix_select(d.cand, n, k2, top, 32, hist, &s_digit, &s_k);
-    }
-    for (int b = tid; b < 2 * HIST_BINS; b += 1024) d.hist[b] = 0;
-    if (tid == 0) {
-        const double med = n > 0 ? __longlong_as_double((long long)result) : 0.0;
-        d.sc->median = med;
-        double s2 = est_sigma_sq_from_median(est, med, (unsigned long long)d.sc->n_valid);
-        if (s2 < min_sigma_sq) s2 = min_sigma_sq;   // :234-237
-        d.sc->sigma_sq = s2;
-        d.sc->n_bad = 0;
-        d.sc->n_cand = 0;
-    }
-}
-
-// ---- sharded exact select: three small all-reduces, no host round trip ---------------------------------
-// Every rank histograms its own e^2; the first-level histogram is all-reduced, every rank finds the same
-// bin and compacts its own candidates + second-level histogram; that is all-reduced too; the few keys
-// that share both bins (a 2^-16 relative window around the order statistic) are exchanged through
-// fixed-size per-rank slots of a zero-initialised buffer (sum all-reduce = concatenation), and every rank
-// finishes with the same radix select.  Histograms travel as doubles (the hook reduces fp64; counts are
-// exact).  A rank with more last-stage candidates than its slot holds raises select_overflow: the host
-// then repeats the LM step with the gather-everything path (thousands of bit-identical errors only).
-#define XCAND_CAP_DEFAULT 1024   // keys per rank slot (a 2^-16 relative window around the median holds ~1e-5 of the keys) (PTAM_XCAND_CAP overrides it: the tests force the overflow path)
-__global__ void hist_to_f64_kernel(const unsigned* __restrict__ h, double* __restrict__ out, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = (double)h[i];
-}
-__global__ void f64_to_hist_kernel(const double* __restrict__ in, unsigned* __restrict__ h, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) h[i] = (unsigned)(in[i] + 0.5);
-}
-
-// stage 2: second-level bin from the all-reduced histogram; my candidates of that bin go into my slot.
-// xchg: [world counts][world x cap keys], zeroed beforehand.
-__global__ void __launch_bounds__(1024) select_stage_kernel(BaDev d, double* __restrict__ xchg, int rank, int world, int XCAND_CAP) {
-    __shared__ long long wsum[16];
-    __shared__ int s_bin2, s_k2, s_cnt;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int n = d.sc->n_cand;
-    const int bin1 = d.sc->sel_bin;
-    const unsigned* hist2 = d.hist + HIST_BINS;
-    const bool clamped = bin1 == 0 || bin1 == HIST_BINS - 1;   // members do not share their top bits: all of them count
-    if (tid == 0) {
-        s_cnt = 0;
-        s_bin2 = -1;
-        s_k2 = d.sc->sel_k;
-    }
-    unsigned c[4];
-    long long s = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        c[j] = hist2[4 * tid + j];
-        s += c[j];
-    }
-    const long long incl = wave_incl_scan_i64(s);
-    if (lane == 63) wsum[wid] = incl;
-    __syncthreads();
-    if (tid == 0) {
-        long long run = 0;
-        for (int i = 0; i < 16; i++) {
-            const long long v = wsum[i];
-            wsum[i] = run;
-            run += v;
-        }
-    }
-    __syncthreads();
-    if (bin1 >= 0 && !clamped) {
-        const long long k1 = d.sc->sel_k;
-        const long long excl = wsum[wid] + incl - s;
-        if (excl <= k1 && k1 < excl + s) {
-            long long kk = k1 - excl;
-            int bb = 4 * tid;
-            for (int j = 0; j < 3; j++)
-                if (kk >= c[j]) {
-                    kk -= c[j];
-                    bb++;
-                } else
-                    break;
-            s_bin2 = bb;
-            s_k2 = (int)kk;
-        }
-    }
-    __syncthreads();
-    const int bin2 = s_bin2;
-    double* slot = xchg + world + (size_t)rank * XCAND_CAP;
-    if (bin1 >= 0)
-        for (int i = tid; i < n; i += 1024) {
-            const double key = d.cand[i];
-            if (clamped || e2_bin2(key) == bin2) {
-                const int pos = atomicAdd(&s_cnt, 1);
-                if (pos < XCAND_CAP) slot[pos] = key;
-            }
-        }
-    __syncthreads();
-    if (tid == 0) {
-        xchg[rank] = (double)s_cnt;
-        d.sc->sel_bin2 = bin2;
-        d.sc->sel_k2 = s_k2;
-    }
-}
-
-// stage 3: concatenate the exchanged candidates, select, derive sigma^2 (tail of select_final_kernel)
-__global__ void __launch_bounds__(1024) select_finish_kernel(BaDev d, const double* __restrict__ xchg, double* __restrict__ list,
-                                                             int world, int XCAND_CAP, int est, double min_sigma_sq) {
-    __shared__ unsigned hist[256];
-    __shared__ int s_digit, s_k, s_over;
-    __shared__ int offs[34];
-    const int tid = threadIdx.x;
-    if (tid == 0) {
-        int run = 0, over = 0;
-        for (int r = 0; r < world; r++) {
-            int c = (int)(xchg[r] + 0.5);
-            if (c > XCAND_CAP) {
-                over = 1;
-                c = XCAND_CAP;
-            }
-            offs[r] = run;
-            run += c;
-        }
-        offs[world] = run;
-        s_over = over;
-    }
-    __syncthreads();
-    const int total = offs[world];
-    for (int r = 0; r < world; r++) {
-        const int c = offs[r + 1] - offs[r];
-        const double* slot = xchg + world + (size_t)r * XCAND_CAP;
-        for (int i = tid; i < c; i += 1024) list[offs[r] + i] = slot[i];
-    }
-    __syncthreads();
-    const int bin1 = d.sc->sel_bin, bin2 = d.sc->sel_bin2;
-    unsigned long long result = 0;
-    const bool any = bin1 >= 0 && total > 0;
-    if (any) {
-        if (bin2 < 0)
-            result = block_radix_select(list, total, d.sc->sel_k2, 0ull, 56, hist, &s_digit, &s_k);
-        else {
-            const unsigned long long top = ((unsigned long long)(bin1 + E2_BIN_BASE) << 48) | ((unsigned long long)bin2 << 36);
-            result = block_radix_select(list, total, d.sc->sel_k2, top, 32, hist, &s_digit, &s_k);
-        }
-    }
-    for (int b = tid; b < 2 * HIST_BINS; b += 1024) d.hist[b] = 0;
-    if (tid == 0) {
-        const double med = any ? __longlong_as_double((long long)result) : 0.0;
-        d.sc->median = med;
-        double s2 = est_sigma_sq_from_median(est, med, (unsigned long long)d.sc->n_valid);
-        if (s2 < min_sigma_sq) s2 = min_sigma_sq;   // :234-237
-        d.sc->sigma_sq = s2;
-        d.sc->n_bad = 0;
-        d.sc->n_cand = 0;
-        d.sc->select_overflow = s_over;
-    }
-}
-
-// compact this rank's valid e^2 (sharded mode)
-__global__ void __launch_bounds__(256) compact_valid_kernel(BaDev d, double* __restrict__ out, int* __restrict__ counter) {
-    const int lane = threadIdx.x & 63;
-    for (int base = blockIdx.x * 256; base < d.M; base += gridDim.x * 256) {
-        const int i = base + threadIdx.x;
-        const bool take = i < d.M && d.m_state[i] == MS_ALIVE;
-        const unsigned long long m = __ballot(take);
-        if (m) {
-            int pos = 0;
-            if (lane == 0) pos = atomicAdd(counter, __popcll(m));
-            pos = __shfl(pos, 0, 64);
-            if (take) out[pos + __popcll(m & ((1ull << lane) - 1ull))] = d.m_e2[i];
-        }
-    }
-}
-
-// =================================================================================================
-// K7: fused Jacobian + normal-equation accumulation (pass 2, :250-332)
-// =================================================================================================
-// One measurement of pass 2: weight, Jacobians, camera accumulation (LDS atomics into Ul), W store.
-// Returns B (2x3) and the weighted error for the caller's per-point reduction.
-__device__ __forceinline__ void jac_measure(const DevCam& cam, const BaDev& d, const double* __restrict__ pose,
-                                            const double* __restrict__ pt, double sigma_sq, double inv_sigma_sq, int est,
-                                            int m, double* Ul,
-                                            double& err, int& nbad, double B0[3], double B1[3], double& ex, double& ey) {
-    double Wv[18];
-#pragma unroll
-    for (int k = 0; k < 18; k++) Wv[k] = 0;
-    const int st = d.m_state[m];
-    if (st == MS_BAD) {   // z <= 0 in pass 1  (:259-263)
-        err += 1.0;
-        nbad++;
-    } else if (st == MS_ALIVE) {
-        const int c = d.m_cam[m], p = d.m_pt[m];
-        const double* __restrict__ T = pose + 12 * c;
-        BaProj pr;
-        ba_project(cam, T, pt + 3 * p, pr);
-        const double X = pr.X, Y = pr.Y, Z = pr.Z;
-        const double2 fo = d.m_found[m];
-        const double s = d.m_s[m];
-        ex = s * (fo.x - pr.u);
-        ey = s * (fo.y - pr.v);
-        const double e2 = ex * ex + ey * ey;
-        const double w = ba_sqrt_weight(est, e2, sigma_sq, inv_sigma_sq);
-        ex *= w;   // meas.v2Epsilon = dWeight * meas.v2Epsilon  (:272)
-        ey *= w;
-        if (w == 0) {   // :274-279
-            d.m_state[m] = MS_BAD;
-            err += 1.0;
-            nbad++;
-            ex = ey = 0;
-        } else {
-            err += ba_objective(est, e2, sigma_sq, inv_sigma_sq);
-            double D[4];
-            ba_derivs(cam, pr, D);
-            // fold sqrt-weight and dSqrtInvNoise into the camera derivatives (:285, :302)
-            const double D0 = s * w * D[0], D1 = s * w * D[1], D2 = s * w * D[2], D3 = s * w * D[3];
-            const double iz = rcp_nr(Z);
-            // B: point Jacobian, motion = m-th column of R_cw (:306-313)
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const double g0 = T[k], g1 = T[3 + k], g2 = T[6 + k];
-                const double mx = (g0 - X * g2 * iz) * iz, my = (g1 - Y * g2 * iz) * iz;
-                B0[k] = D0 * mx + D1 * my;
-                B1[k] = D2 * mx + D3 * my;
-            }
-            const int fidx = d.m_fidx[m];
-            if (fidx >= 0) {
-                // A: camera Jacobian, SE3 generator fields (:291-303)
-                const double gx[6] = {1, 0, 0, 0, Z, -Y};
-                const double gy[6] = {0, 1, 0, -Z, 0, X};
-                const double gz[6] = {0, 0, 1, Y, -X, 0};
-                double A0[6], A1[6];
-#pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    const double mx = (gx[k] - X * gz[k] * iz) * iz, my = (gy[k] - Y * gz[k] * iz) * iz;
-                    A0[k] = D0 * mx + D1 * my;
-                    A1[k] = D2 * mx + D3 * my;
-                }
-                double* Uc = Ul + fidx * 27;
-                int k = 0;
-#pragma unroll
-                for (int a = 0; a < 6; a++)
-#pragma unroll
-                    for (int b = 0; b <= a; b++) atomicAdd(&Uc[k++], A0[a] * A0[b] + A1[a] * A1[b]);   // U_LL :21-26
-#pragma unroll
-                for (int a = 0; a < 6; a++) atomicAdd(&Uc[21 + a], A0[a] * ex + A1[a] * ey);       // epsA :321
-#pragma unroll
-                for (int a = 0; a < 6; a++)
-#pragma unroll
-                    for (int b = 0; b < 3; b++) Wv[a * 3 + b] = A0[a] * B0[b] + A1[a] * B1[b];   // W = A^T B :331
-            }
-        }
-    }
-    // W planes: 9 x double2, coalesced across the wave
-#pragma unroll
-    for (int k = 0; k < 9; k++) d.W[(size_t)k * d.M + m] = make_double2(Wv[2 * k], Wv[2 * k + 1]);
-}
-
-// flush a workgroup's camera partials + error partial (end of both accumulate kernels)
-template <int THREADS>
-__device__ __forceinline__ void jac_flush(const BaDev& d, const double* Ul, double err, int nbad) {
-    __shared__ double werr[THREADS / 64];
-    __shared__ int wbad[THREADS / 64];
-    const int tid = threadIdx.x;
-    double* up = d.Upart + (size_t)blockIdx.x * d.F * 27;
-    for (int k = tid; k < d.F * 27; k += THREADS) up[k] = Ul[k];
-    err = wave_sum_f64(err);
-    nbad = wave_sum_i32(nbad);
-    if ((tid & 63) == 0) {
-        werr[tid >> 6] = err;
-        wbad[tid >> 6] = nbad;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double e = 0;
-        int b = 0;
-        for (int i = 0; i < THREADS / 64; i++) {
-            e += werr[i];
-            b += wbad[i];
-        }
-        d.err_part[2 * blockIdx.x] = e;
-        d.bad_part[blockIdx.x] = b;
-    }
-}
-
-// K7, wave variant (every point has <= 64 measurements): lane = measurement, a wave takes runs of
-// 64 consecutive measurements of the point-major order.  No workgroup barrier inside the loop.
-//  - balance: every wave gets `per_wave` (or one more) consecutive 64-measurement chunks, and
-//    the next chunk's inputs are prefetched while the current one is computed;
-//  - poses are staged once per workgroup in LDS (C*96 B); the chunk's points are fetched one per
-//    lane and handed to their measurements by ds_bpermute: ONE global round trip per chunk;
-//  - U / epsA: ds_add_f64 into the workgroup's LDS partials;
-//  - V / epsB: segmented inclusive scan over the wave (DPP row shifts + row broadcasts, fixed tree).
-//    A point lying inside the chunk is stored by its last lane; a point cut by a chunk boundary leaves
-//    one piece per chunk in d.cut (plain stores) and vinv_kernel adds them in chunk order — no global
-//    atomics (device-scope fp64 atomics cost this launch ~1.9 us at 50 x 5000), no zeroing pass;
-//  - W: 9 coalesced double2 planes.
-// dynamic LDS: Ul[F*27] | poses[C*12] + 1 spare slot
-struct K7In {
-    int st, c, p, fidx;
-    double2 fo;
-    double sn;
-    double px, py, pz;   // point (pt0 + lane), fetched one per lane
-    int pt0;
-    int p_prev, p_next;  // point of the measurement just before / after this chunk (-1 at the ends)
-};
-__device__ __forceinline__ void k7_load(const BaDev& d, const double* __restrict__ pt, int m0, int lane, K7In& in) {
-    // every load is unconditional (clamped index, result masked afterwards): with no branch between
-    // them the compiler can wait for the older ones by count instead of draining the whole queue
-    const int m = m0 + lane;
-    const int mlast = min(m0 + 63, d.M - 1);
-    const int mc = min(m, mlast);
-    in.pt0 = d.m_pt[m0];
-    const int pt1 = d.m_pt[mlast];
-    in.p_prev = d.m_pt[max(m0 - 1, 0)];
-    in.p_next = d.m_pt[min(m0 + 64, d.M - 1)];
-    if (m0 == 0) in.p_prev = -1;
-    if (m0 + 64 >= d.M) in.p_next = -1;
-    in.st = d.m_state[mc];
-    in.c = d.m_cam[mc];
-    in.p = d.m_pt[mc];
-    in.fidx = d.m_fidx[mc];
-    in.fo = d.m_found[mc];
-    in.sn = d.m_s[mc];
-    // (lanes past the end hold a copy of the last measurement: the caller masks them)
-    const double* q = pt + 3 * (size_t)min(in.pt0 + lane, pt1);
-    in.px = q[0];
-    in.py = q[1];
-    in.pz = q[2];
-}
-
-#ifdef K7_TIMING
-#define K7_STAMP(i) if (blockIdx.x == 7 && tid == 0) d.dbg[i] = (long long)__builtin_amdgcn_s_memrealtime();
-#define K7_WALL(i) if (tid == 0 && blockIdx.x < 2000) d.dbg[16 + 2 * blockIdx.x + i] = (long long)__builtin_amdgcn_s_memrealtime();
-#else
-#define K7_WALL(i)
-#define K7_STAMP(i)
-#endif
-// EST: the M-estimator as a compile-time constant (-1: taken from `est_arg`) — the default Tukey path then
-// carries none of the Cauchy / Huber code (log, sqrt and their constants)
-// ablation switches for tools/ experiments (never defined in the product build)
-#ifdef K7_NOATOM
-#define K7_UADD(p, v) asm volatile("" ::"v"(v))
-#else
-#define K7_UADD(p, v) atomicAdd(p, v)
-#endif
-#ifdef K7_NOW
-#define K7_WSTORE(dst, v) { const double2 v_ = v; asm volatile("" ::"v"(v_.x), "v"(v_.y)); }
-#else
-// W is written once and read by the NEXT kernel from every XCD: write-through (sc1) 16-byte stores leave no dirty
-// lines for the end-of-kernel L2 write-back (measured -7 % launch time at 50 x 5000; `nt` is slower).
-// The s_nop covers the gfx940+ hazard the compiler cannot see inside the asm: a VALU write of the data registers
-// of a > 64-bit global store needs two wait states after it.
-typedef double k7_d2 __attribute__((ext_vector_type(2)));
-#define K7_WSTORE(dst, v) { const double2 v_ = v; const k7_d2 w_ = {v_.x, v_.y}; asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(&(dst)), "v"(w_) : "memory"); }
-#endif
-template <int THREADS, bool PREFETCH, bool LOOP, int EST>
-__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
-jac_accum_wave_kernel(DevCam cam, BaDev d, int cur, int est_arg, int per_wave, int extra) {
-    TL_MARK(d, 4)
-    if (ba_guard_blocks(d)) return;
-    if (d.guard == 1 && d.sc->spec_stay) cur ^= 1;   // (launched for the trial state; "stay": the unchanged current one)
-    const int est = EST >= 0 ? EST : est_arg;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* Ul = smem;
-    double* Ps = smem + (((size_t)d.F * 27 + 1) & ~(size_t)1);
-    const int tid = threadIdx.x, lane = tid & 63;
-    K7_WALL(0)
-    const double* __restrict__ pt = d.pt[cur];
-    const int n_chunks64 = (d.M + 63) >> 6;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: chunk bases live in SGPRs
-    // chunk range of this wave: `per_wave` chunks each, and the first `extra` waves in (wave-in-block major,
-    // block minor) order take one more — the surplus lands on different CUs / SIMDs instead of piling
-    // onto the leading workgroups.  Ranges stay contiguous and ordered by (block, wave).
-    int c_begin, c_end;
-    {
-        constexpr int WPB = THREADS / 64;
-        const int blk = blockIdx.x, grid = gridDim.x;
-        const int full = extra / grid, rem = extra - full * grid;   // waves with wid < full (or == full, blk < rem) are long
-        const int before = blk * full + min(blk, rem) + min(wid, full) + ((wid > full && blk < rem) ? 1 : 0);
-        const int mine = per_wave + ((wid < full || (wid == full && blk < rem)) ? 1 : 0);
-        c_begin = (blk * WPB + wid) * per_wave + before;
-        c_end = min(n_chunks64, c_begin + mine);
-    }
-    // Global loads leave in the order they are needed: poses (staged to LDS before the barrier), then
-    // the first chunk's inputs and sigma^2 — memory returns in order, so the barrier waits for ONE
-    // round trip while the chunk's second, dependent one (m_pt -> point) is still in flight.
-    for (int k = tid; k < d.F * 27; k += THREADS) Ul[k] = 0;
-    const double* __restrict__ pose = d.pose[cur];
-    const int n_pose = d.C * 12;
-    double pv[2];
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int k = tid + i * THREADS;
-        pv[i] = pose[min(k, n_pose - 1)];
-    }
-    K7In in;
-    if (PREFETCH) k7_load(d, pt, min(c_begin, n_chunks64 - 1) << 6, lane, in);   // (idle waves load a valid chunk and drop it)
-    const double sigma_sq = d.sc->sigma_sq;
-#pragma unroll
-    for (int i = 0; i < 2; i++) {   // (unconditional like the loads: surplus threads hit the spare slot Ps[n_pose])
-        const int k = tid + i * THREADS;
-        Ps[min(k, n_pose)] = pv[i];
-    }
-    for (int k = tid + 2 * THREADS; k < n_pose; k += THREADS) Ps[k] = pose[k];
-    __syncthreads();
-    K7_STAMP(0)
-    const double inv_sigma_sq = 1.0 / sigma_sq;
-    double err = 0;
-    int nbad = 0;
-    K7_STAMP(1)
-#pragma unroll 1
-    for (int ci = c_begin; ci < c_end; ci++) {   // (LOOP == false: exactly one chunk per wave, see the break below)
-        const int m0 = ci << 6;
-        const int m = m0 + lane;
-        const bool active = m < d.M;
-        if (!PREFETCH) k7_load(d, pt, m0, lane, in);
-        const K7In cu = in;
-        K7_STAMP(2)
-        if (PREFETCH && LOOP && ci + 1 < c_end) k7_load(d, pt, (ci + 1) << 6, lane, in);   // prefetch the next chunk
-        const int st = active ? cu.st : MS_DEAD, c = cu.c, p = cu.p, fidx = active ? cu.fidx : -1;
-        const int src = p - cu.pt0;   // lane that fetched my point
-        const double Xw = __shfl(cu.px, src, 64), Yw = __shfl(cu.py, src, 64), Zw = __shfl(cu.pz, src, 64);
-        int pid = active ? p : (-1 - lane);   // inactive lanes: unique ids, never merged
-        double v[9];
-#pragma unroll
-        for (int i = 0; i < 9; i++) v[i] = 0;
-        bool full = false;
-        BaProj pr;
-        double ex = 0, ey = 0, w = 0;
-        const double* T = Ps + 12 * c;
-        if (st == MS_BAD) {   // z <= 0 in pass 1  (:259-263)
-            err += 1.0;
-            nbad++;
-        } else if (st == MS_ALIVE) {
-            const double Xp[3] = {Xw, Yw, Zw};
-            ba_project(cam, T, Xp, pr);
-            ex = cu.sn * (cu.fo.x - pr.u);
-            ey = cu.sn * (cu.fo.y - pr.v);
-            const double e2 = ex * ex + ey * ey;
-            w = ba_sqrt_weight(est, e2, sigma_sq, inv_sigma_sq);
-            if (w == 0) {   // :274-279
-                d.m_state[m] = MS_BAD;
-                err += 1.0;
-                nbad++;
-            } else {
-                err += ba_objective(est, e2, sigma_sq, inv_sigma_sq);
-                full = true;
-            }
-        }
-        K7_STAMP(3)
-        if (full) {
-            ex *= w;   // meas.v2Epsilon = dWeight * meas.v2Epsilon  (:272)
-            ey *= w;
-            double D[4];
-            ba_derivs(cam, pr, D);
-            const double sw = cu.sn * w;   // fold sqrt-weight and dSqrtInvNoise into the derivatives (:285, :302)
-            const double D0 = sw * D[0], D1 = sw * D[1], D2 = sw * D[2], D3 = sw * D[3];
-            const double X = pr.X, Y = pr.Y, Z = pr.Z;
-            const double iz = rcp_nr(Z);
-            __builtin_amdgcn_sched_barrier(0);   // phase fences keep live ranges short (128-VGPR budget)
-            double B0[3], B1[3];
-#pragma unroll
-            for (int k = 0; k < 3; k++) {   // B: motion = k-th column of R_cw (:306-313)
-                const double g0 = T[k], g1 = T[3 + k], g2 = T[6 + k];
-                const double mx = (g0 - X * g2 * iz) * iz, my = (g1 - Y * g2 * iz) * iz;
-                B0[k] = D0 * mx + D1 * my;
-                B1[k] = D2 * mx + D3 * my;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (fidx >= 0) {
-                // A: SE3 generator fields (:291-303): e_k for k<3 ; (0,-Z,Y) (Z,0,-X) (-Y,X,0)
-                const double zx = -X * iz * iz, zy = -Y * iz * iz;   // d(x)/dZ, d(y)/dZ
-                double A0[6], A1[6];
-                {
-                    const double mxs[6] = {iz, 0, zx, zx * Y, iz * Z - zx * X, -iz * Y};
-                    const double mys[6] = {0, iz, zy, -iz * Z + zy * Y, -zy * X, iz * X};
-#pragma unroll
-                    for (int k = 0; k < 6; k++) {
-                        A0[k] = D0 * mxs[k] + D1 * mys[k];
-                        A1[k] = D2 * mxs[k] + D3 * mys[k];
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                K7_STAMP(4)
-                double* Uc = Ul + fidx * 27;
-                int k = 0;
-#pragma unroll
-                for (int a = 0; a < 6; a++)
-#pragma unroll
-                    for (int b = 0; b <= a; b++) K7_UADD(&Uc[k++], A0[a] * A0[b] + A1[a] * A1[b]);   // U_LL :21-26
-#pragma unroll
-                for (int a = 0; a < 6; a++) K7_UADD(&Uc[21 + a], A0[a] * ex + A1[a] * ey);       // epsA :321
-                __builtin_amdgcn_sched_barrier(0);
-                K7_STAMP(5)
-#pragma unroll
-                for (int q = 0; q < 9; q++) {   // W = A^T B (:331), 9 coalesced double2 planes
-                    const int i0 = 2 * q, i1 = 2 * q + 1;
-                    K7_WSTORE(d.W[(size_t)q * d.M + m], make_double2(A0[i0 / 3] * B0[i0 % 3] + A1[i0 / 3] * B1[i0 % 3],
-                                                                     A0[i1 / 3] * B0[i1 % 3] + A1[i1 / 3] * B1[i1 % 3]));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            v[0] = B0[0] * B0[0] + B1[0] * B1[0];   // V_LL 00,10,11,20,21,22  (:325)
-            v[1] = B0[1] * B0[0] + B1[1] * B1[0];
-            v[2] = B0[1] * B0[1] + B1[1] * B1[1];
-            v[3] = B0[2] * B0[0] + B1[2] * B1[0];
-            v[4] = B0[2] * B0[1] + B1[2] * B1[1];
-            v[5] = B0[2] * B0[2] + B1[2] * B1[2];
-            v[6] = B0[0] * ex + B1[0] * ey;         // epsB (:326)
-            v[7] = B0[1] * ex + B1[1] * ey;
-            v[8] = B0[2] * ex + B1[2] * ey;
-        }
-        if (active && !(full && fidx >= 0)) {
-            const double2 z2 = make_double2(0, 0);
-#pragma unroll
-            for (int q = 0; q < 9; q++) d.W[(size_t)q * d.M + m] = z2;
-        }
-        // segmented inclusive scan keyed by the point id: 4 in-row steps (DPP row_shr 1,2,4,8), then
-        // the row carries (row_bcast15 into rows 1,3; row_bcast31 into rows 2,3).  Segments are
-        // contiguous, so "the source lane has my point id" implies every lane in between has it too.
-        K7_STAMP(6)
-        // ids are compared as pid + 1 so that the 0 a row-shift returns for "no source lane" never
-        // matches a real point (inactive lanes carry zeros, a spurious match there adds 0)
-        const int pid1 = pid + 1;
-#define SEG_STEP(GETP, GETV)                                             \
-    {                                                                    \
-        const int po = GETP;                                             \
-        double t[9];                                                     \
-        _Pragma("unroll") for (int i = 0; i < 9; i++) t[i] = GETV;       \
-        if (po == pid1) {                                                \
-            _Pragma("unroll") for (int i = 0; i < 9; i++) v[i] += t[i];  \
-        }                                                                \
-    }
-#ifndef K7_NOSCAN
-        SEG_STEP(dpp_row_shr0_i32<1>(pid1), dpp_row_shr_f64<1>(v[i]))
-        SEG_STEP(dpp_row_shr0_i32<2>(pid1), dpp_row_shr_f64<2>(v[i]))
-        SEG_STEP(dpp_row_shr0_i32<4>(pid1), dpp_row_shr_f64<4>(v[i]))
-        SEG_STEP(dpp_row_shr0_i32<8>(pid1), dpp_row_shr_f64<8>(v[i]))
-        // row carries: only rows 1,3 (then 2,3) take part; 0 never matches a point id
-        SEG_STEP((dpp_bcastx_i32<0x142>(pid1) & -((lane >> 4) & 1)), dpp_bcastx_f64<0x142>(v[i]))
-        SEG_STEP((dpp_bcastx_i32<0x143>(pid1) & -((lane >> 5) & 1)), dpp_bcastx_f64<0x143>(v[i]))
-#endif
-#undef SEG_STEP
-        K7_STAMP(7)
-        const int pn = __shfl_down(pid, 1, 64);
-        if (active && (lane == 63 || pn != pid)) {
-            // a point cut by a chunk boundary leaves its piece in the chunk's slot (leading segment: 2c, trailing:
-            // 2c + 1); vinv_kernel adds the pieces in chunk order — plain stores, no zeroing pass, fixed order
-            const bool whole = pid != cu.p_prev && pid != cu.p_next;
-            double* Vp = whole ? d.V + (size_t)pid * 6 : d.cut + (size_t)(2 * ci + (pid == cu.p_prev ? 0 : 1)) * 9;
-            double* Ep = whole ? d.epsB + (size_t)pid * 3 : Vp + 6;
-#pragma unroll
-            for (int i = 0; i < 6; i++) Vp[i] = v[i];
-            Ep[0] = v[6];
-            Ep[1] = v[7];
-            Ep[2] = v[8];
-        }
-        if (!LOOP) break;
-    }
-    K7_STAMP(8)
-    __syncthreads();
-    jac_flush<THREADS>(d, Ul, err, nbad);
-    K7_STAMP(9)
-    K7_WALL(1)
-}
-
-// the wave-variant instantiations: {one chunk per wave | looping, 256 or 512 threads} x {Tukey | run-time estimator}
-static const void* k7_wave_fn(int threads, bool loop, int est) {
-    const bool tukey = est == PTAM_EST_TUKEY;
-    if (!loop)
-        return tukey ? (const void*)jac_accum_wave_kernel<512, true, false, PTAM_EST_TUKEY>
-                     : (const void*)jac_accum_wave_kernel<512, true, false, -1>;
-    if (threads == 256)
-        return tukey ? (const void*)jac_accum_wave_kernel<256, true, true, PTAM_EST_TUKEY>
-                     : (const void*)jac_accum_wave_kernel<256, false, true, -1>;
-    return tukey ? (const void*)jac_accum_wave_kernel<512, true, true, PTAM_EST_TUKEY>
-                 : (const void*)jac_accum_wave_kernel<512, false, true, -1>;
-}
-
-// K7, block variant (points with up to BA_CHUNK measurements): a workgroup owns whole points.
-// dynamic LDS: Ul[F*27] camera partials | Bs[BA_CHUNK][8] per-measurement B (2x3) and weighted eps
-__global__ void __launch_bounds__(BA_CHUNK) jac_accum_kernel(DevCam cam, BaDev d, int cur, int est) {
-    if (ba_guard_blocks(d)) return;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* Ul = smem;
-    double* Bs = smem + (((size_t)d.F * 27 + 1) & ~(size_t)1);
-    const int tid = threadIdx.x;
-    for (int k = tid; k < d.F * 27; k += BA_CHUNK) Ul[k] = 0;
-    __syncthreads();
-    const double* __restrict__ pose = d.pose[cur];
-    const double* __restrict__ pt = d.pt[cur];
-    const double sigma_sq = d.sc->sigma_sq;
-    const double inv_sigma_sq = 1.0 / sigma_sq;
-    double err = 0;
-    int nbad = 0;
-    for (int ci = blockIdx.x; ci < d.n_chunks; ci += gridDim.x) {
-        const BaChunk ch = d.chunks[ci];
-        const int m = ch.m_begin + tid;
-        double B0[3] = {0, 0, 0}, B1[3] = {0, 0, 0}, ex = 0, ey = 0;
-        if (m < ch.m_end) jac_measure(cam, d, pose, pt, sigma_sq, inv_sigma_sq, est, m, Ul, err, nbad, B0, B1, ex, ey);
-        double* bs = Bs + tid * 8;
-        bs[0] = B0[0];
-        bs[1] = B0[1];
-        bs[2] = B0[2];
-        bs[3] = B1[0];
-        bs[4] = B1[1];
-        bs[5] = B1[2];
-        bs[6] = ex;
-        bs[7] = ey;
-        __syncthreads();
-        // V_LL += B^T B, epsB += B^T eps : this block owns every measurement of its points, so the
-        // sums are complete and written once, in measurement order (deterministic)  (:325-326)
-        const int npts = ch.pt_end - ch.pt_begin;
-        for (int task = tid; task < npts * 9; task += BA_CHUNK) {
-            const int pi = task / 9, o = task - pi * 9;
-            const int p = ch.pt_begin + pi;
-            const int r0 = d.rowptr[p] - ch.m_begin, r1 = d.rowptr[p + 1] - ch.m_begin;
-            double acc = 0;
-            if (o < 6) {
-                const int a = o < 1 ? 0 : (o < 3 ? 1 : 2);
-                const int b = o - (a * (a + 1)) / 2;
-                for (int rr = r0; rr < r1; rr++) {
-                    const double* q = Bs + rr * 8;
-                    acc += q[a] * q[b] + q[3 + a] * q[3 + b];
-                }
-                d.V[(size_t)p * 6 + o] = acc;
-            } else {
-                const int a = o - 6;
-                for (int rr = r0; rr < r1; rr++) {
-                    const double* q = Bs + rr * 8;
-                    acc += q[a] * q[6] + q[3 + a] * q[7];
-                }
-                d.epsB[(size_t)p * 3 + a] = acc;
-            }
-        }
-        __syncthreads();
-    }
-    __syncthreads();
-    jac_flush<BA_CHUNK>(d, Ul, err, nbad);
-}
-
-// fixed-order sum over the accumulate grid.  Stage A (this kernel): grid (column groups of 64,
-// RSPLIT row splits); wave w of a block sums rows w, w+4, ... of its split with coalesced 512-byte
-// loads, the four waves combine in fixed order -> Usplit[split][F*27].  Stage B is folded into the
-// consumers (schur_reduce_kernel sums the RSPLIT values of the 27 numbers it needs per camera).
-// Block (0,0) also reduces the error / bad-count partials.
-#define RSPLIT 16
-__device__ __forceinline__ void reduce_partials_body(const BaDev& d, int grid_acc, int bx, int by) {
-    __shared__ double comb[4][64];
-    __shared__ double werr[4];
-    __shared__ int wbad[4];
-    const int total = d.F * 27;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int col = bx * 64 + lane;
-    const int split = by;
-    const int rows_per = (grid_acc + RSPLIT - 1) / RSPLIT;
-    const int r0 = split * rows_per, r1 = min(grid_acc, r0 + rows_per);
-    double s = 0;
-    if (col < total)
-        for (int b = r0 + wid; b < r1; b += 4) s += d.Upart[(size_t)b * total + col];
-    comb[wid][lane] = s;
-    __syncthreads();
-    if (wid == 0 && col < total) d.Usplit[(size_t)split * total + col] = ((comb[0][lane] + comb[1][lane]) + comb[2][lane]) + comb[3][lane];
-    if (bx == 0 && by == 0) {
-        double e = 0;
-        int nb = 0;
-        for (int b = threadIdx.x; b < grid_acc; b += 256) {
-            e += d.err_part[2 * b];
-            nb += d.bad_part[b];
-        }
-        e = wave_sum_f64(e);
-        nb = wave_sum_i32(nb);
-        if (lane == 0) {
-            werr[wid] = e;
-            wbad[wid] = nb;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            d.sc->cur_err = ((werr[0] + werr[1]) + werr[2]) + werr[3];
-            d.sc->n_bad = wbad[0] + wbad[1] + wbad[2] + wbad[3];
-        }
-    }
-}
-
-__global__ void __launch_bounds__(256) reduce_partials_kernel(BaDev d, int grid_acc) {
-    TL_MARK(d, 16)
-    if (ba_guard_blocks(d)) return;
-    reduce_partials_body(d, grid_acc, blockIdx.x, blockIdx.y);
-}
-
-// =================================================================================================
-// K8a: V*^-1  (:341-359)   TooN Cholesky<3>::get_inverse
-// =================================================================================================
-__device__ __forceinline__ void vinv_body(const BaDev& d, double lambda, int bx) {
-    const int p = bx * 256 + threadIdx.x;
-    if (p >= d.P) return;
-    double v[6];
-    const int r0 = d.rowptr[p], r1 = d.rowptr[p + 1];
-    const int c0 = r0 >> 6, c1 = (r1 - 1) >> 6;
-    if (d.cut != nullptr && r1 > r0 && c0 != c1) {
-        // the point's measurements span chunks c0..c1 of K7's wave variant: trailing segment of c0, then the leading
-        // segments of c0+1..c1, added in that order; epsB is completed here for the Schur / back-substitution kernels
-        const double* q = d.cut + (size_t)(2 * c0 + 1) * 9;
-        double e[3] = {q[6], q[7], q[8]};
-#pragma unroll
-        for (int i = 0; i < 6; i++) v[i] = q[i];
-        for (int c = c0 + 1; c <= c1; c++) {
-            q = d.cut + (size_t)(2 * c) * 9;
-#pragma unroll
-            for (int i = 0; i < 6; i++) v[i] += q[i];
-#pragma unroll
-            for (int i = 0; i < 3; i++) e[i] += q[6 + i];
-        }
-#pragma unroll
-        for (int i = 0; i < 3; i++) d.epsB[(size_t)p * 3 + i] = e[i];
-    } else {
-#pragma unroll
-        for (int i = 0; i < 6; i++) v[i] = d.V[(size_t)p * 6 + i];
-    }
-    double A[9] = {v[0], v[1], v[3], v[1], v[2], v[4], v[3], v[4], v[5]};
-    double* out = d.Vinv + (size_t)p * 9;
-    if (A[0] * A[4] * A[8] == 0) {
-#pragma unroll
-        for (int i = 0; i < 9; i++) out[i] = 0;
-        return;
-    }
-    A[0] *= (1.0 + lambda);
-    A[4] *= (1.0 + lambda);
-    A[8] *= (1.0 + lambda);
-    // LDL^T, lower triangle; strict upper caches the undivided column
-    for (int col = 0; col < 3; col++) {
-        double inv_diag = 1;
-        for (int row = col; row < 3; row++) {
-            double val = A[row * 3 + col];
-            for (int c2 = 0; c2 < col; c2++) val -= A[c2 * 3 + col] * A[row * 3 + c2];
-            if (row == col) {
-                A[row * 3 + col] = val;
-                inv_diag = 1 / val;
-            } else {
-                A[col * 3 + row] = val;
-                A[row * 3 + col] = val * inv_diag;
-            }
-        }
-    }
-    for (int c = 0; c < 3; c++) {
-        double y[3], x[3];
-        for (int i = 0; i < 3; i++) {
-            double val = (i == c) ? 1.0 : 0.0;
-            for (int j = 0; j < i; j++) val -= A[i * 3 + j] * y[j];
-            y[i] = val;
-        }
-        for (int i = 0; i < 3; i++) y[i] /= A[i * 3 + i];
-        for (int i = 2; i >= 0; i--) {
-            double val = y[i];
-            for (int j = i + 1; j < 3; j++) val -= A[j * 3 + i] * x[j];
-            x[i] = val;
-        }
-        for (int r = 0; r < 3; r++) out[r * 3 + c] = x[r];
-    }
-}
-
-__global__ void __launch_bounds__(256) vinv_kernel(BaDev d, double lambda) {
-    TL_MARK(d, 6)
-    if (ba_guard_blocks(d)) return;
-    vinv_body(d, lambda, blockIdx.x);
-}
-// The partial reduction and V*^-1 both only depend on K7 and not on each other: one launch, the first
-// nx * RSPLIT workgroups reduce, the rest invert (a dependent launch costs ~2.3 us on this chip).
-__global__ void __launch_bounds__(256) reduce_vinv_kernel(BaDev d, int grid_acc, int nx, double lambda, double lambda_stay) {
-    TL_MARK(d, 5)
-    if (ba_guard_blocks(d)) return;
-    if (d.guard == 1 && d.sc->spec_stay) lambda = lambda_stay;
-    const int b = blockIdx.x, nr = nx * RSPLIT;
-    if (b < nr)
-        reduce_partials_body(d, grid_acc, b % nx, b / nx);
-    else
-        vinv_body(d, lambda, b - nr);
-}
-
-// =================================================================================================
-// K8: Schur complement, output-stationary camera-tile pairs
-// =================================================================================================
-#define SCHUR_TILE_ELEMS (SCHUR_TC * SCHUR_TC * 36 + SCHUR_TC * 6)   // 2304 + 48
-#define SCHUR_BATCH 16                                                 // entries staged per LDS round
-
-// Workgroup = (tile pair (a,b) of 8 x 8 cameras, a slice of the points touching both tiles), SOFTWARE
-// PIPELINED: while the four waves multiply round i out of one LDS stage, the global loads of round i+1
-// (16 entries x 16 loader lanes: the W blocks of the point's measurements in tile a / tile b, V*^-1,
-// epsB) are in flight, and the work-list entries of round i+2 are being fetched.  After the product the
-// loaders form Y = W V*^-1 and drop Y / W into the OTHER LDS stage; one barrier per round.
-struct SchurPre {      // one loader lane's prefetched share of a round
-    SchurEntry ent;
-    int have;          // this lane's entry exists
-    int m;             // measurement index (first iteration), -1 if none
-    int f;             // its free-camera index
-    double w[18];
-    double vq;         // lane q < 9 of the entry carries Vinv[q]
-    double eb;         // lane q < 3 carries epsB[q]
-};
-
-__device__ __forceinline__ void schur_fetch(const BaDev& d, const SchurEntry& ent, bool have, bool diag, int ls, SchurPre& p) {
-    p.ent = ent;
-    p.have = have;
-    p.m = -1;
-    p.f = -1;
-    p.vq = 0;
-    p.eb = 0;
-    if (!have) return;
-    const int na = ent.na_nb & 0xffff, nbm = (ent.na_nb >> 16) & 0xffff;
-    const bool roleA = diag || ls < 8;
-    const int l = roleA ? ls : ls - 8;
-    const int n = roleA ? na : nbm;
-    if (l < n) {
-        p.m = (roleA ? ent.ma : ent.mb) + l;
-        p.f = d.m_fidx[p.m];
-#pragma unroll
-        for (int q = 0; q < 9; q++) {
-            const double2 t = d.W[(size_t)q * d.M + p.m];
-            p.w[2 * q] = t.x;
-            p.w[2 * q + 1] = t.y;
-        }
-    }
-    if (ls < 9) p.vq = d.Vinv[(size_t)ent.pt * 9 + ls];
-    if (ls < 3) p.eb = d.epsB[(size_t)ent.pt * 3 + ls];
-}
-
-// ---- the product, on the matrix cores ---------------------------------------------------------------
-// A round's 16 entries
-// are laid out as two dense 48 x 48 operands  Y[3*entry + coord][6*slot + param]  and  W[...][...]
-// (absent cameras: zero blocks), and the 48x48 partial tile is  Y W^T : nine 16x16 output tiles, the
-// k dimension (point coordinates) taken four at a time by v_mfma_f64_16x16x4_f64
-// (A[i = lane&15][k = lane>>4], B[k][j = lane&15]; D: column lane&15, row (lane>>4) + 4*v).  The four
-// waves split the k-steps.  fp64 MFMA shares the vector FMA pipe on this chip (tools/pipes: the two do
-// not overlap, and the MFMA sustains ~10 FMA/clk/SIMD against ~13 for v_fma_f64), so the gain is not
-// flops: one MFMA replaces sixteen FMA instructions and their LDS operand traffic (6 ds_read_b64 per 9
-// MFMAs instead of 18 ds_read_b128 per 108 FMAs).  A lane-per-block vector version of this product
-// (36 accumulators per lane, operands re-read from LDS per entry) measured 99 us against 72 us.
-#define SCH_K (3 * SCHUR_BATCH)   // k-values per round
-#define SCH_ROWS (SCHUR_TC * 6)
-#define SCH_LD (SCH_ROWS + 2)     // pitch of one k-row in doubles (even: a camera's six values are three 16-byte stores)
-static_assert(SCH_ROWS == 48 && SCH_K % 4 == 0, "three 16-row fragments per operand");
-struct SchurStageM {              // k-major: [3*entry + coord][6*slot + param] — a fragment reads 16 consecutive doubles
-    double Y[SCH_K][SCH_LD];
-    double W[SCH_K][SCH_LD];
-    double eB[SCH_K];
-};
-typedef double v4f64 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ unsigned schur_put_m(SchurStageM& st, int le, bool roleA, bool diag, int slot, const double w[18],
-                                                const double v[9]) {
-    if (roleA) {
-        double y[18];
-#pragma unroll
-        for (int r = 0; r < 6; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) y[r * 3 + c] = w[r * 3] * v[c] + w[r * 3 + 1] * v[3 + c] + w[r * 3 + 2] * v[6 + c];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            double2* dst = (double2*)&st.Y[3 * le + c][6 * slot];
-#pragma unroll
-            for (int h = 0; h < 3; h++) dst[h] = make_double2(y[(2 * h) * 3 + c], y[(2 * h + 1) * 3 + c]);
-        }
-    }
-    if (!roleA || diag) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            double2* dst = (double2*)&st.W[3 * le + c][6 * slot];
-#pragma unroll
-            for (int h = 0; h < 3; h++) dst[h] = make_double2(w[(2 * h) * 3 + c], w[(2 * h + 1) * 3 + c]);
-        }
-    }
-    return 1u << slot;
-}
-
-// value of lane q of my 16-lane DPP row (row_newbcast), both halves of a double — VALU only, no LDS round trip
-template <int Q>
-__device__ __forceinline__ double row_bcast_f64(double x) {
-    const long long b = __double_as_longlong(x);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x150 + Q, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + Q, 0xf, 0xf, true);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-// OR over the 16 lanes of my DPP row (row rotations)
-__device__ __forceinline__ unsigned row_or_u32(unsigned x) {
-    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, true);   // row_ror:8
-    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x124, 0xf, 0xf, true);   // row_ror:4
-    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x122, 0xf, 0xf, true);   // row_ror:2
-    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x121, 0xf, 0xf, true);   // row_ror:1
-    return x;
-}
-
-__device__ __forceinline__ void schur_store_m(const BaDev& d, SchurStageM& st, const SchurPre& p, bool diag, int a, int b, int le,
-                                              int ls, int lane) {
-    // V*^-1 of the entry: element q lives in lane q of the entry's 16 loader lanes (= one DPP row)
-    const double v[9] = {row_bcast_f64<0>(p.vq), row_bcast_f64<1>(p.vq), row_bcast_f64<2>(p.vq),
-                         row_bcast_f64<3>(p.vq), row_bcast_f64<4>(p.vq), row_bcast_f64<5>(p.vq),
-                         row_bcast_f64<6>(p.vq), row_bcast_f64<7>(p.vq), row_bcast_f64<8>(p.vq)};
-    const bool roleA = diag || ls < 8;
-    unsigned bit = 0;
-    if (ls < 3) st.eB[3 * le + ls] = p.have ? p.eb : 0.0;
-    if (p.have) {
-        if (p.m >= 0 && p.f >= 0) bit = schur_put_m(st, le, roleA, diag, p.f - (roleA ? a : b) * SCHUR_TC, p.w, v);
-        // rare: more measurements in the tile range than loader lanes (fixed cameras interleaved)
-        const int na = p.ent.na_nb & 0xffff, nbm = (p.ent.na_nb >> 16) & 0xffff;
-        const int step = diag ? 16 : 8, n = roleA ? na : nbm;
-        for (int l = (roleA ? ls : ls - 8) + step; l < n; l += step) {
-            const int m = (roleA ? p.ent.ma : p.ent.mb) + l;
-            const int f = d.m_fidx[m];
-            if (f >= 0) {
-                double w[18];
-#pragma unroll
-                for (int q = 0; q < 9; q++) {
-                    const double2 t = d.W[(size_t)q * d.M + m];
-                    w[2 * q] = t.x;
-                    w[2 * q + 1] = t.y;
-                }
-                bit |= schur_put_m(st, le, roleA, diag, f - (roleA ? a : b) * SCHUR_TC, w, v);
-            }
-        }
-    }
-    // presence of each camera slot: OR over the entry's loader lanes (a-role and b-role halves separately)
-    const unsigned ba = row_or_u32(roleA ? bit : 0u), bb = row_or_u32(roleA ? 0u : bit);
-    // absent slots (and whole entries past the end of the list) must read as zero blocks
-    const int slot = ls & 7;
-    const bool zy = ls < 8 && !((ba >> slot) & 1u);
-    const bool zw = diag ? zy : (ls >= 8 && !((bb >> slot) & 1u));
-    const double2 z2 = make_double2(0.0, 0.0);
-    if (zy) {
-#pragma unroll
-        for (int c = 0; c < 3; c++)
-#pragma unroll
-            for (int h = 0; h < 3; h++) ((double2*)&st.Y[3 * le + c][6 * slot])[h] = z2;
-    }
-    if (zw) {
-#pragma unroll
-        for (int c = 0; c < 3; c++)
-#pragma unroll
-            for (int h = 0; h < 3; h++) ((double2*)&st.W[3 * le + c][6 * slot])[h] = z2;
-    }
-}
-
-#ifdef K7_TIMING
-#define SCH_T(acc, stmt) { const long long t0_ = (long long)__builtin_readcyclecounter(); stmt; acc += (long long)__builtin_readcyclecounter() - t0_; }
-#else
-#define SCH_T(acc, stmt) { stmt; }
-#endif
-__global__ void __launch_bounds__(256) schur_tile_mfma_kernel(BaDev d) {
-    TL_MARK(d, 7)
-    extern __shared__ __attribute__((aligned(16))) double schur_lds[];
-    SchurStageM* stage = reinterpret_cast<SchurStageM*>(schur_lds);
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const SchurWG wg = d.s_wgs[blockIdx.x];
-    int a = (int)((sqrt(8.0 * wg.pair + 1.0) - 1.0) * 0.5);
-    while ((a + 1) * (a + 2) / 2 <= wg.pair) a++;
-    while (a * (a + 1) / 2 > wg.pair) a--;
-    const int b = wg.pair - a * (a + 1) / 2;
-    const bool diag = a == b;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const int le = tid >> 4, ls = tid & 15;   // loader role: local entry, lane within the entry
-    // 16-row fragments that hold cameras at all: the last tile of a system is usually partial (F = 50: two cameras =
-    // one fragment of three), and its empty fragments are not multiplied
-    const int rb_a = (6 * min(SCHUR_TC, d.F - a * SCHUR_TC) + 15) >> 4, rb_b = (6 * min(SCHUR_TC, d.F - b * SCHUR_TC) + 15) >> 4;
-    v4f64 acc[3][3];
-    double accE[3] = {0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) acc[i][j] = (v4f64){0, 0, 0, 0};
-    const int n_ent = wg.e_end - wg.e_begin;
-    const int n_rounds = (n_ent + SCHUR_BATCH - 1) / SCHUR_BATCH;
-    const SchurEntry none = {0, 0, 0, 0};
-    auto entry_at = [&](int round, bool& have) {
-        const int e = wg.e_begin + round * SCHUR_BATCH + le;
-        have = round < n_rounds && e < wg.e_end;
-        return have ? d.s_entries[e] : none;
-    };
-#ifdef K7_TIMING
-    long long t_comp = 0, t_store = 0, t_fetch = 0, t_bar = 0, t_wait = 0;
-    const long long t_start = (long long)__builtin_readcyclecounter();
-#endif
-    // prologue: round 0 into stage 0, entries of round 1 in registers
-    SchurPre pre;
-    bool have0, have_next;
-    const SchurEntry e0 = entry_at(0, have0);
-    schur_fetch(d, e0, have0, diag, ls, pre);
-    SchurEntry ent_next = entry_at(1, have_next);
-    schur_store_m(d, stage[0], pre, diag, a, b, le, ls, lane);
-    __syncthreads();
-    for (int i = 0; i < n_rounds; i++) {
-        const bool more = i + 1 < n_rounds;
-        SCH_T(t_fetch, if (more) schur_fetch(d, ent_next, have_next, diag, ls, pre));   // round i+1's data: loads in flight
-        bool have2;
-        const SchurEntry ent2 = entry_at(i + 2, have2);                  // round i+2's work-list entries
-        // ---- round i on the matrix cores ----
-        const SchurStageM& st = stage[i & 1];
-        const int nb_ent = min(SCHUR_BATCH, n_ent - i * SCHUR_BATCH);
-        const int n_ks = (3 * nb_ent + 3) >> 2;   // k-steps that hold data (the rest of the stage is zero)
-#ifdef K7_TIMING
-        const long long tc0 = (long long)__builtin_readcyclecounter();
-#endif
-        for (int s4 = wid; s4 < n_ks; s4 += 4) {
-            const int kc = 4 * s4 + l4;
-            double af[3], bf[3];
-#pragma unroll
-            for (int t = 0; t < 3; t++) {
-                af[t] = st.Y[kc][16 * t + l15];
-                bf[t] = st.W[kc][16 * t + l15];
-            }
-#pragma unroll
-            for (int ti = 0; ti < 3; ti++)
-#pragma unroll
-                for (int tj = 0; tj < 3; tj++)
-                    if ((ti >= tj || !diag) && ti < rb_a && tj < rb_b)   // a diagonal pair only needs its lower triangle
-                        acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ti], bf[tj], acc[ti][tj], 0, 0, 0);
-            if (diag) {
-                const double eb = st.eB[kc];
-#pragma unroll
-                for (int t = 0; t < 3; t++) accE[t] = fma(af[t], eb, accE[t]);
-            }
-        }
-#ifdef K7_TIMING
-        t_comp += (long long)__builtin_readcyclecounter() - tc0;
-#endif
-        // ---- stage round i+1 ----
-#ifdef K7_TIMING
-        SCH_T(t_wait, asm volatile("s_waitcnt vmcnt(0)" ::: "memory"));
-#endif
-        SCH_T(t_store, if (more) schur_store_m(d, stage[(i + 1) & 1], pre, diag, a, b, le, ls, lane));
-        ent_next = ent2;
-        have_next = have2;
-        SCH_T(t_bar, __syncthreads());
-    }
-#ifdef K7_TIMING
-    if (blockIdx.x == 100 && tid == 0) {
-        d.dbg[10] = (long long)__builtin_readcyclecounter() - t_start;
-        d.dbg[11] = t_fetch;
-        d.dbg[12] = t_comp;
-        d.dbg[13] = t_store;
-        d.dbg[14] = t_bar;
-        d.dbg[15] = n_rounds;
-        d.dbg[9] = t_wait;
-    }
-#endif
-    // E partials: sum the four k-quarters of a row (lanes l15 + 16 q)
-#pragma unroll
-    for (int t = 0; t < 3; t++) {
-        accE[t] += __shfl_xor(accE[t], 16, 64);
-        accE[t] += __shfl_xor(accE[t], 32, 64);
-    }
-    // stages dead: the buffer becomes the cross-wave reduction scratch
-    double(*red)[64][40] = reinterpret_cast<double(*)[64][40]>(schur_lds);
-    double flat[39];
-#pragma unroll
-    for (int ti = 0; ti < 3; ti++)
-#pragma unroll
-        for (int tj = 0; tj < 3; tj++)
-#pragma unroll
-            for (int v = 0; v < 4; v++) flat[(ti * 3 + tj) * 4 + v] = acc[ti][tj][v];
-#pragma unroll
-    for (int t = 0; t < 3; t++) flat[36 + t] = accE[t];
-    // cross-wave reduction in fixed order: (w2 -> w0, w3 -> w1), then (w1 -> w0)
-    if (wid >= 2) {
-#pragma unroll
-        for (int i = 0; i < 39; i++) red[wid - 2][lane][i] = flat[i];
-    }
-    __syncthreads();
-    if (wid < 2) {
-#pragma unroll
-        for (int i = 0; i < 39; i++) flat[i] += red[wid][lane][i];
-    }
-    __syncthreads();
-    if (wid == 1) {
-#pragma unroll
-        for (int i = 0; i < 39; i++) red[0][lane][i] = flat[i];
-    }
-    __syncthreads();
-    if (wid == 0) {
-        double* out = d.s_part + (size_t)blockIdx.x * SCHUR_TILE_ELEMS;
-#pragma unroll
-        for (int ti = 0; ti < 3; ti++)
-#pragma unroll
-            for (int tj = 0; tj < 3; tj++)
-#pragma unroll
-                for (int v = 0; v < 4; v++) {
-                    const int row = 16 * ti + l4 + 4 * v, col = 16 * tj + l15;
-                    const int j = row / 6, r = row - 6 * j, k = col / 6, c = col - 6 * k;
-                    const int i = (ti * 3 + tj) * 4 + v;
-                    out[(size_t)(j * SCHUR_TC + k) * 36 + r * 6 + c] = flat[i] + red[0][lane][i];
-                }
-        if (l4 == 0) {
-#pragma unroll
-            for (int t = 0; t < 3; t++) out[SCHUR_TC * SCHUR_TC * 36 + 16 * t + l15] = flat[36 + t] + red[0][lane][36 + t];
-        }
-    }
-}
-
-// grid (tile pair, slice): fixed-order sum of the partial tiles, add U* / epsA, write S (lower) and E.
-// Every rank adds its OWN partial U* and epsA ((1+lambda) diag(U) is linear, so the sharded partials
-// fold into the one all-reduce); the padding identity is added on rank 0 only.
-#define SRED_SLICES 10   // 9 x 256 tile elements + 1 slice for E and the padding rows
-__global__ void __launch_bounds__(256) schur_reduce_kernel(BaDev d, double lambda, int pad_identity) {
-    TL_MARK(d, 8)
-    const int pair = blockIdx.x, slice = blockIdx.y;
-    int a = (int)((sqrt(8.0 * pair + 1.0) - 1.0) * 0.5);
-    while ((a + 1) * (a + 2) / 2 <= pair) a++;
-    while (a * (a + 1) / 2 > pair) a--;
-    const int b = pair - a * (a + 1) / 2;
-    const int wg0 = d.s_pair_wg_begin[pair], wg1 = d.s_pair_wg_begin[pair + 1];
-    double* S = d.SE;
-    double* E = d.SE + (size_t)d.npad * d.npad;
-    const int npad = d.npad;
-    const size_t FS = (size_t)d.F * 27;
-    if (slice < 9) {
-        const int idx = slice * 256 + threadIdx.x;
-        const int jk = idx / 36, rc = idx - jk * 36;
-        const int j = jk >> 3, k = jk & 7, r = rc / 6, c = rc - r * 6;
-        const int fa = a * SCHUR_TC + j, fb = b * SCHUR_TC + k;
-        if (fa >= d.F || fb >= d.F) return;
-        if (a == b && j < k) return;   // strict upper blocks are never read
-        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        const double* p = d.s_part + (size_t)wg0 * SCHUR_TILE_ELEMS + idx;
-        int w = wg0;
-        // (eight, then four partial tiles per round trip: the loop is a chain of dependent global round trips otherwise)
-        for (; w + 8 <= wg1; w += 8, p += 8 * (size_t)SCHUR_TILE_ELEMS) {
-            const double q0 = p[0], q1 = p[SCHUR_TILE_ELEMS], q2 = p[2 * (size_t)SCHUR_TILE_ELEMS], q3 = p[3 * (size_t)SCHUR_TILE_ELEMS];
-            const double q4 = p[4 * (size_t)SCHUR_TILE_ELEMS], q5 = p[5 * (size_t)SCHUR_TILE_ELEMS], q6 = p[6 * (size_t)SCHUR_TILE_ELEMS],
-                         q7 = p[7 * (size_t)SCHUR_TILE_ELEMS];
-            s0 += q0 + q4;
-            s1 += q1 + q5;
-            s2 += q2 + q6;
-            s3 += q3 + q7;
-        }
-        for (; w + 4 <= wg1; w += 4, p += 4 * (size_t)SCHUR_TILE_ELEMS) {
-            s0 += p[0];
-            s1 += p[SCHUR_TILE_ELEMS];
-            s2 += p[2 * (size_t)SCHUR_TILE_ELEMS];
-            s3 += p[3 * (size_t)SCHUR_TILE_ELEMS];
-        }
-        for (; w < wg1; w++, p += SCHUR_TILE_ELEMS) s0 += p[0];
-        double val = -((s0 + s1) + (s2 + s3));
-        if (a == b && j == k) {
-            // U* : symmetrised U with diag * (1 + lambda)  (:383-390)
-            const int rr = r >= c ? r : c, cc = r >= c ? c : r;
-            double u = 0;
-#pragma unroll
-            for (int sp = 0; sp < RSPLIT; sp++) u += d.Usplit[sp * FS + fa * 27 + rr * (rr + 1) / 2 + cc];
-            if (r == c) u *= (1.0 + lambda);
-            val += u;
-        }
-        S[(size_t)(6 * fa + r) * npad + 6 * fb + c] = val;
-        return;
-    }
-    if (a == b && threadIdx.x < SCHUR_TC * 6) {
-        const int idx = threadIdx.x;
-        const int j = idx / 6, r = idx - j * 6;
-        const int fa = a * SCHUR_TC + j;
-        if (fa < d.F) {
-            double s = 0;
-            for (int w = wg0; w < wg1; w++) s += d.s_part[(size_t)w * SCHUR_TILE_ELEMS + SCHUR_TC * SCHUR_TC * 36 + idx];
-            double ea = 0;
-#pragma unroll
-            for (int sp = 0; sp < RSPLIT; sp++) ea += d.Usplit[sp * FS + fa * 27 + 21 + r];
-            E[6 * fa + r] = ea - s;
-        }
-    }
-    if (pair == 0) {
-        // padding rows n..npad-1: identity so that the blocked factorisation is well defined
-        const int np = d.npad - d.n;
-        for (int idx = threadIdx.x; idx < np * d.npad; idx += 256) {
-            const int r = d.n + idx / d.npad, c = idx % d.npad;
-            if (c <= r) S[(size_t)r * npad + c] = (r == c && pad_identity) ? 1.0 : 0.0;
-        }
-        for (int idx = threadIdx.x; idx < np; idx += 256) E[d.n + idx] = 0.0;
-    }
-}
-
-// =================================================================================================
-// K10
-// =================================================================================================
-__global__ void __launch_bounds__(64) pose_update_kernel(BaDev d, int cur) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c < d.C) {
-        const double* T = d.pose[cur] + 12 * c;
-        double* Tn = d.pose[cur ^ 1] + 12 * c;
-        const int f = d.cam_free[c];
-        if (f < 0) {
-#pragma unroll
-            for (int i = 0; i < 12; i++) Tn[i] = T[i];
-        } else {
-            double mu[6], Tl[12], o[12];
-#pragma unroll
-            for (int i = 0; i < 6; i++) mu[i] = d.da[6 * f + i];
-#pragma unroll
-            for (int i = 0; i < 12; i++) Tl[i] = T[i];
-            se3_exp_mul(mu, Tl, o);   // exp(da_j) * se3CfW  (:501)
-#pragma unroll
-            for (int i = 0; i < 12; i++) Tn[i] = o[i];
-        }
-    }
-    if (blockIdx.x == 0) {
-        double s = 0;
-        for (int i = threadIdx.x; i < d.n; i += 64) s += d.da[i] * d.da[i];
-        s = wave_sum_f64(s);
-        if (threadIdx.x == 0) d.sc->sumsq_cam = s;
-    }
-}
-
-// delta b, trial points, new robust error; block owns whole points
-__global__ void __launch_bounds__(BA_CHUNK) point_update_kernel(DevCam cam, BaDev d, int cur, int est) {
-    TL_MARK(d, 11)
-    __shared__ double Ts[BA_CHUNK][3];
-    __shared__ double Np[BA_CHUNK][3];
-    __shared__ double wred[BA_CHUNK / 64][2];
-    const int tid = threadIdx.x;
-    const BaChunk ch = d.chunks[blockIdx.x];
-    const int m = ch.m_begin + tid;
-    const bool active = m < ch.m_end;
-    // every per-measurement load leaves at once (clamped index, masked afterwards): W does not wait for the
-    // state -> camera -> free-index chain, and the inputs of the new-error pass are here long before they are used
-    const int mc = min(m, d.M - 1);
-    double w[18];
-#pragma unroll
-    for (int q = 0; q < 9; q++) {
-        const double2 t = d.W[(size_t)q * d.M + mc];
-        w[2 * q] = t.x;
-        w[2 * q + 1] = t.y;
-    }
-    const int st = active ? (int)d.m_state[mc] : (int)MS_DEAD;
-    const int c = d.m_cam[mc], p = d.m_pt[mc];
-    const double2 fo = d.m_found[mc];
-    const double sn = d.m_s[mc];
-    const int f = d.cam_free[c];
-    double t0 = 0, t1 = 0, t2 = 0;
-    if (st == MS_ALIVE && f >= 0) {   // non-fixed, non-bad  (:469-474)
-        const double* da = d.da + 6 * f;
-#pragma unroll
-        for (int r = 0; r < 6; r++) {
-            const double a = da[r];
-            t0 += w[r * 3] * a;
-            t1 += w[r * 3 + 1] * a;
-            t2 += w[r * 3 + 2] * a;
-        }
-    }
-    Ts[tid][0] = t0;
-    Ts[tid][1] = t1;
-    Ts[tid][2] = t2;
-    __syncthreads();
-    // per point: eight threads add strided slices of its measurements' terms, the slices meet in a fixed order (DPP)
-    const int npts = ch.pt_end - ch.pt_begin;
-    double sq = 0;
-    for (int base = 0; base < npts; base += BA_CHUNK / 8) {
-        const int pi = base + (tid >> 3), sub = tid & 7;
-        const bool on = pi < npts;
-        const int pp = ch.pt_begin + (on ? pi : 0);
-        const int r0 = d.rowptr[pp] - ch.m_begin, r1 = on ? d.rowptr[pp + 1] - ch.m_begin : r0;
-        const double* eb = d.epsB + (size_t)pp * 3;
-        const double* Vi = d.Vinv + (size_t)pp * 9;
-        const double* X = d.pt[cur] + (size_t)pp * 3;
-        const double e0 = eb[0], e1 = eb[1], e2 = eb[2];
-        double vi[9], x[3];
-#pragma unroll
-        for (int i = 0; i < 9; i++) vi[i] = Vi[i];
-#pragma unroll
-        for (int i = 0; i < 3; i++) x[i] = X[i];
-        double s0 = 0, s1 = 0, s2 = 0;
-        for (int rr = r0 + sub; rr < r1; rr += 8) {
-            s0 += Ts[rr][0];
-            s1 += Ts[rr][1];
-            s2 += Ts[rr][2];
-        }
-        s0 += dpp_row_shr_f64<1>(s0), s1 += dpp_row_shr_f64<1>(s1), s2 += dpp_row_shr_f64<1>(s2);
-        s0 += dpp_row_shr_f64<2>(s0), s1 += dpp_row_shr_f64<2>(s1), s2 += dpp_row_shr_f64<2>(s2);
-        s0 += dpp_row_shr_f64<4>(s0), s1 += dpp_row_shr_f64<4>(s1), s2 += dpp_row_shr_f64<4>(s2);
-        if (on && sub == 7) {   // (lane 7 of the group holds the sum of its eight slices)
-            const double v0 = e0 - s0, v1 = e1 - s1, v2 = e2 - s2;
-            const double d0 = vi[0] * v0 + vi[1] * v1 + vi[2] * v2;
-            const double d1 = vi[3] * v0 + vi[4] * v1 + vi[5] * v2;
-            const double d2 = vi[6] * v0 + vi[7] * v1 + vi[8] * v2;
-            sq += d0 * d0 + d1 * d1 + d2 * d2;
-            const double n0 = x[0] + d0, n1 = x[1] + d1, n2 = x[2] + d2;   // :503-504
-            double* Xn = d.pt[cur ^ 1] + (size_t)pp * 3;
-            Xn[0] = n0;
-            Xn[1] = n1;
-            Xn[2] = n2;
-            Np[pi][0] = n0;
-            Np[pi][1] = n1;
-            Np[pi][2] = n2;
-        }
-    }
-    __syncthreads();
-    double err = 0;
-    if (active && st != MS_DEAD) {   // FindNewError over every listed measurement (:188-207)
-        const double* T = d.pose[cur ^ 1] + 12 * c;
-        const double* X = Np[p - ch.pt_begin];
-        BaProj pr;
-        if (!ba_project(cam, T, X, pr)) {
-            err = 1.0;
-            d.m_zbad_t[m] = 1;
-        } else {
-            const double ex = sn * (fo.x - pr.u), ey = sn * (fo.y - pr.v);
-            const double s2 = d.sc->sigma_sq;
-            const double e2n = ex * ex + ey * ey;
-            err = ba_objective(est, e2n, s2, 1.0 / s2);
-            // if this trial is accepted, these ARE pass 1's results of the next LM step (same poses,
-            // points and projection code): keep them so that the next step can skip its projection pass
-            d.m_e2t[m] = e2n;
-            d.m_zbad_t[m] = 0;
-        }
-    }
-    err = wave_sum_f64(err);
-    sq = wave_sum_f64(sq);
-    if ((tid & 63) == 0) {
-        wred[tid >> 6][0] = err;
-        wred[tid >> 6][1] = sq;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double e = 0, s = 0;
-        for (int i = 0; i < BA_CHUNK / 64; i++) {
-            e += wred[i][0];
-            s += wred[i][1];
-        }
-        d.err_part[2 * blockIdx.x] = e;
-        d.err_part[2 * blockIdx.x + 1] = s;
-    }
-}
-
-__global__ void __launch_bounds__(256) finalize_new_kernel(BaDev d, double conv_limit, int last_allowed, ulonglong2* host_slots,
-                                                            unsigned long long seq) {
-    TL_MARK(d, 12)
-    __shared__ double w[4][2];
-    double e = 0, s = 0;
-    // fixed assignment + fixed combine order: deterministic
-    for (int i = threadIdx.x; i < d.n_chunks; i += 256) {
-        e += d.err_part[2 * i];
-        s += d.err_part[2 * i + 1];
-    }
-    e = wave_sum_f64(e);
-    s = wave_sum_f64(s);
-    if ((threadIdx.x & 63) == 0) {
-        w[threadIdx.x >> 6][0] = e;
-        w[threadIdx.x >> 6][1] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double ne = w[0][0] + w[1][0] + w[2][0] + w[3][0], sp = w[0][1] + w[1][1] + w[2][1] + w[3][1];
-        d.sc->new_err = ne;
-        d.sc->sumsq_pt = sp;
-        // the host's decision (src/Bundle.cc:338, :488-490, :518-533), taken here as well for the guarded kernels
-        const double ce = d.sc->cur_err;
-        const bool conv = d.sc->sumsq_cam + sp < conv_limit;
-        const bool end_step = !(ne > ce) || conv || last_allowed != 0;
-        d.sc->end_step = end_step ? 1 : 0;
-        d.sc->spec_go = (end_step && ne < ce && !conv && last_allowed == 0) ? 1 : 0;
-        d.sc->spec_stay = (end_step && !(ne < ce) && !conv && last_allowed == 0) ? 1 : 0;
-    }
-    // single-device runs publish the scalars from here (publish_scalars_kernel's job, one launch less per trial)
-    if (host_slots) {
-        __threadfence_block();
-        __syncthreads();
-        if (threadIdx.x < sizeof(BaScalars) / 8)
-            host_slots[threadIdx.x] = make_ulonglong2(((const volatile unsigned long long*)d.sc)[threadIdx.x], seq);
-    }
-}
-
-// erase bad measurements, append to the outlier list (:536-547)
-__global__ void __launch_bounds__(256) purge_kernel(BaDev d) {
-    TL_MARK(d, 15)
-    if (ba_guard_blocks(d)) return;
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool bad = m < d.M && d.m_state[m] == MS_BAD;
-    const unsigned long long mask = __ballot(bad);
-    if (mask == 0) return;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&d.sc->n_outliers, __popcll(mask));   // one atomic per wave
-    base = __shfl(base, 0, 64);
-    if (bad) {
-        d.outliers[base + __popcll(mask & ((1ull << lane) - 1ull))] = d.m_orig[m];
-        d.m_state[m] = MS_DEAD;
-    }
-}
-
-// The host's per-trial decision needs the scalars: they are written into host-mapped memory as
-// (word, sequence) pairs, one 16-byte store per lane, and the host spins until every pair carries the
-// expected sequence number — no system-scope fence on the device, no D2H copy + stream synchronise
-// (~30 us of idle GPU per trial) on the host.
-// Results leave the device through kernels too: poses, points and the outlier indices are stored straight into the
-// context's host-mapped staging buffer, and a second (stream-ordered) launch stamps a sequence word the host spins on.
-// The copy engine + hipStreamSynchronize pair this replaces slept on an interrupt and, about one Compute() in eight,
-// took 7 ms instead of 70 us to wake up (PTAM_DEBUG_STALL: "compute total" against "compute loop").
-__global__ void __launch_bounds__(256) readback_kernel(const double* __restrict__ pose, size_t n_pose, const double* __restrict__ pts,
-                                                       size_t n_pts, const int* __restrict__ out, size_t n_out, double* __restrict__ h_pose,
-                                                       double* __restrict__ h_pts, int* __restrict__ h_out) {
-    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
-    for (size_t i = i0; i < n_pose; i += stride) h_pose[i] = pose[i];
-    for (size_t i = i0; i < n_pts; i += stride) h_pts[i] = pts[i];
-    for (size_t i = i0; i < n_out; i += stride) h_out[i] = out[i];
-}
-__global__ void stamp_kernel(volatile unsigned long long* slot, unsigned long long seq) { *slot = seq; }
-
-#define MBOX_WORDS (sizeof(BaScalars) / 8)
-static_assert(sizeof(BaScalars) % 8 == 0 && MBOX_WORDS <= 64, "published as 64-bit words by one wave");
-__global__ void __launch_bounds__(64) publish_scalars_kernel(const BaScalars* sc, ulonglong2* host_slots, unsigned long long seq) {
-    const unsigned i = threadIdx.x;
-    if (i < MBOX_WORDS) host_slots[i] = make_ulonglong2(((const unsigned long long*)sc)[i], seq);
-}
-
-__global__ void set_scalars_kernel(BaDev d, double cur_err, int n_bad) {
-    d.sc->cur_err = cur_err;
-    d.sc->n_bad = n_bad;
-}
-__global__ void set_new_kernel(BaDev d, double new_err, double sumsq_pt) {
-    d.sc->new_err = new_err;
-    d.sc->sumsq_pt = sumsq_pt;
-}
-__global__ void pack2_kernel(const BaScalars* sc, double* out, int which) {
-    if (which == 0) {
-        out[0] = sc->cur_err;
-        out[1] = (double)sc->n_bad;
-    } else {
-        out[0] = sc->new_err;
-        out[1] = sc->sumsq_pt;
-    }
-}
-__global__ void unpack2_kernel(BaScalars* sc, const double* in, int which) {
-    if (which == 0) {
-        sc->cur_err = in[0];
-        sc->n_bad = (int)(in[1] + 0.5);
-    } else {
-        sc->new_err = in[0];
-        sc->sumsq_pt = in[1];
-    }
-}
-__global__ void place_keys_kernel(const double* __restrict__ src, int n, double* __restrict__ dst) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dst[i] = src[i];
-}
+#include "ba_math.inc"
+#include "ba_pass1.inc"
+#include "ba_select.inc"
+#include "ba_jacobian.inc"
+#include "ba_schur.inc"
+#include "ba_update.inc"
 
 // =================================================================================================
 // host

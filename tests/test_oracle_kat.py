@@ -324,7 +324,7 @@ def test_fast_score_and_nonmax_semantics(oracle):
 
 def test_atan_reduction_constants():
     """The BA kernels evaluate atan with the classic 4-interval reduction + 11-term polynomial
-    (ptam_cg_amd/csrc/bundle.hip ba_atan_pos).  The same scheme in float64 numpy must agree with libm to
+    (ptam_cg_amd/csrc/ba_math.inc ba_atan_pos).  The same scheme in float64 numpy must agree with libm to
     a couple of ulp — a wrong digit in any coefficient shows up as >= 1e-13."""
     aT = [3.33333333333329318027e-01, -1.99999999998764832476e-01, 1.42857142725034663711e-01,
           -1.11111104054623557880e-01, 9.09088713343650656196e-02, -7.69187620504482999495e-02,
