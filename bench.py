@@ -133,6 +133,17 @@ def tracking_bench(hip, host, synth, frames=250):
             "note": "frame = pyramid + FAST + 1000-patch ZMSSD search + measurement gather + 10-iteration pose solve, device resident"}
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def pmc_traffic(workload):
     """HBM bytes per K7 launch from the committed rocprofv3 PMC passes (profiles/k7_pmc_traffic.json, written by
     tools/profile_k7.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as
@@ -295,7 +306,7 @@ def main():
             cpu = {"value": len(otr) / cdt, "unit": "LM iterations/s", "cores": 1, "kind": "port",
                    "sample": f"same {args.cams}x{args.points} problem, {len(otr)} lambda trials, oracle/ptam_oracle.cc "
                              f"(single-thread restatement of src/Bundle.cc; the upstream binary cannot be built here)",
-                   "host_cores_available": os.cpu_count()}
+                   "host_cores_available": os.cpu_count(), "cpu_model": cpu_model()}
             if not args.no_tracking:
                 a, b = synth.make_frame_pair()
                 kfa = host.KeyFrame(octx).MakeKeyFrame_Lite(a)
