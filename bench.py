@@ -9,10 +9,14 @@
   step    : one lambda trial.  W warm-up trials run in a separate Compute(); the timed region is ONE
             Compute() with max_iterations = K and the convergence limit disabled, so exactly K trials
             execute.  Inputs are resident in HBM (ptam_ba_prepare) before the clock starts.
-  N > 1   : weak scaling of sharded global BA: 50 shared keyframes, 5000 points PER RANK, points
-            (and all their measurements) sharded by point id modulo N; per trial one RCCL
-            all-reduce of the camera system S|E (+ two scalar pairs, + the e^2 gather for the
-            exact global median).  value = N * trials/s (50x5000-shard iterations per second).
+  N > 1   : STRONG scaling of the global adjustment north_star shards (BASELINE.json configs[4]): ONE
+            problem of 200 keyframes x 50 000 points, 16-camera covisibility window (M ~ 0.8 M), its
+            points (and all their measurements) dealt out by point id modulo N; per trial one RCCL
+            all-reduce of the in-band lower-triangle blocks of S + E (+ three small exchanges for the
+            exact global median, + two scalar pairs).  value = trials of that ONE problem per second
+            (never multiplied by N).  The same line carries `single_gpu_same_workload` (rank 0 alone,
+            same run) so that the speed-up can be read off one record; the N = 1 default line carries
+            the same single-GPU measurement as `global_ba_single_gpu`.
   roofline: K7 (fused Jacobian + normal-equation kernel), algorithmic bytes / HIP-event time.
   cpu_baseline: the CPU oracle (oracle/ptam_oracle.cc, a single-thread restatement of the
             reference's loops — kind "port") on the same problem, rank 0, N = 1 only.
@@ -38,9 +42,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=20,
                     help="lambda trials in the timed Compute() (default 20 = Bundle.MaxIterations, src/Bundle.cc:40)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--cams", type=int, default=50)
-    ap.add_argument("--points", type=int, default=5000)
-    ap.add_argument("--window", type=int, default=0, help="covisibility window (0 = dense)")
+    ap.add_argument("--cams", type=int, default=None, help="keyframes (default: 50 at N = 1, 200 at N > 1)")
+    ap.add_argument("--points", type=int, default=None, help="map points (default: 5000 at N = 1, 50000 at N > 1)")
+    ap.add_argument("--window", type=int, default=None, help="covisibility window, 0 = dense (default: 0 at N = 1, 16 at N > 1)")
+    ap.add_argument("--no-global", action="store_true", help="skip the single-GPU run of the 200 x 50000 global adjustment")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tracking", action="store_true")
     ap.add_argument("--jac-reps", type=int, default=200)
@@ -158,6 +163,13 @@ def pmc_traffic(workload):
         return None
 
 
+GLOBAL_BA = dict(cams=200, points=50000, window=16)   # BASELINE.json configs[4]
+
+
+def workload_name(cams, points, window):
+    return f"bundle_{cams}kf_x_{points}pts" + (f"_window{window}" if window else "_dense")
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -176,12 +188,25 @@ def main():
     device = local_rank if world > 1 else 0
     ctx = host.Context(lib=hip, device=device)
 
-    n_pts_total = args.points * world
-    prob_full = synth.make_ba_problem(args.cams, n_pts_total, synth.SEED_BA_HEADLINE,
-                                      window=args.window if args.window > 0 else None)
+    # ---- the workload -------------------------------------------------------------------------------------------
+    # N = 1: the configuration BASELINE.json's metric is quoted on, 50 keyframes x 5000 points (dense).
+    # N > 1: STRONG scaling of BASELINE.json configs[4], the global adjustment that north_star shards: 200 keyframes x
+    #        50 000 points, 16-camera covisibility window, ONE problem whose points are dealt out over the N ranks.
+    #        value = lambda trials of that one global problem per second (a trial over N shards is one trial).
+    # --cams / --points / --window override either.
+    dflt = GLOBAL_BA if world > 1 else dict(cams=50, points=5000, window=0)
+    if args.cams is None and args.points is None and args.window is None:
+        args.cams, args.points, args.window = dflt["cams"], dflt["points"], dflt["window"]
+    else:   # an explicit shape: what is not given is dense / the single-GPU default
+        args.cams = 50 if args.cams is None else args.cams
+        args.points = 5000 if args.points is None else args.points
+        args.window = 0 if args.window is None else args.window
+    is_global = (args.cams, args.points, args.window) == (GLOBAL_BA["cams"], GLOBAL_BA["points"], GLOBAL_BA["window"])
+    seed = synth.SEED_BA_GLOBAL if is_global else synth.SEED_BA_HEADLINE
+    prob_full = synth.make_ba_problem(args.cams, args.points, seed, window=args.window if args.window > 0 else None)
     prob = shard_problem(prob_full, rank, world)
 
-    comm = None
+    comm = hook = None
     if world > 1:
         ident = (ctypes.c_uint8 * 128)()
         if rank == 0:
@@ -193,9 +218,9 @@ def main():
         ctx._check(hip.rccl_create(ctx.h, ident, rank, world, ctypes.byref(comm)), "rccl_create")
         hook = ctypes.cast(hip.lib.ptam_rccl_allreduce_f64, _abi.ALLREDUCE_FN)
 
-    def new_bundle(max_it):
-        ba = synth.load_into(host.Bundle(ctx, max_iterations=max_it, update_sq_conv_limit=0.0), prob)
-        if comm is not None:
+    def new_bundle(max_it, problem=None, sharded=True):
+        ba = synth.load_into(host.Bundle(ctx, max_iterations=max_it, update_sq_conv_limit=0.0), prob if problem is None else problem)
+        if comm is not None and sharded:
             ba.set_comm(rank, world, hook, comm)
         ba.prepare()     # sort + upload: inputs resident in HBM before any timed region
         return ba
@@ -206,65 +231,119 @@ def main():
         torch.cuda.synchronize() if torch.cuda.is_available() else None
         ctx.sync()
 
-    # All bundles are built and made resident first, so that the W untimed warm-up trials run IMMEDIATELY before the timed
-    # region (building a bundle is ~100 ms of host work with nothing queued).  DESIGN.md section 5 lists what once made
-    # this bench bimodal (first-launch code loading, allocation under queued work, interrupt sleeps) and what was changed.
-    wb = new_bundle(args.warmup) if args.warmup > 0 else None
-    ba = new_bundle(args.steps)
-    # Spin-up: blocks of 1000 back-to-back K7 launches on a LOCAL copy of the shard (no communicator: ranks may need
-    # different block counts) until the launch time has settled (at least 6, at most 150 blocks) — the launch time is the
-    # clock probe (a precaution against clock ramps; PTAM_DEBUG_STALL=1 reports any wait above 3 ms inside Compute()).
-    sb = synth.load_into(host.Bundle(ctx), prob)
-    best, calm, spin = None, 0, []
-    for blk in range(150):
-        ms1, _ = sb.bench_jacobian(1000)
-        spin.append(ms1)
-        calm = calm + 1 if best is not None and ms1 <= best * 1.03 else 0
-        best = ms1 if best is None else min(best, ms1)
-        if blk >= 5 and calm >= 3:
-            break
-    if wb is not None:
-        wb.Compute()
-    barrier()
-    t0 = time.perf_counter()
-    ba.Compute()
-    t_c = time.perf_counter()
-    ctx.sync()
-    barrier()
-    dt = time.perf_counter() - t0
-    if os.environ.get("PTAM_DEBUG_STALL"):
-        sys.stderr.write(f"[bench] timed region {dt * 1e3:.3f} ms, of which Compute() {1e3 * (t_c - t0):.3f} ms\n")
-    trials = ba.trials()
-    assert len(trials) == args.steps, (len(trials), args.steps)
+    def spin_up(problem):
+        # blocks of 1000 back-to-back K7 launches on a LOCAL copy (no communicator: ranks may need different block
+        # counts) until the launch time has settled (at least 6, at most 150 blocks) — the launch time is the clock probe
+        sb = synth.load_into(host.Bundle(ctx), problem)
+        best, calm, spin = None, 0, []
+        for blk in range(150):
+            ms1, _ = sb.bench_jacobian(1000)
+            spin.append(ms1)
+            calm = calm + 1 if best is not None and ms1 <= best * 1.03 else 0
+            best = ms1 if best is None else min(best, ms1)
+            if blk >= 5 and calm >= 3:
+                break
+        sb.close()
+        return spin
+
+    def timed_compute(problem, steps, warmup, sharded=True, sync_ranks=True):
+        """W warm-up trials in their own Compute(), then ONE timed Compute() of exactly `steps` trials, bracketed by
+        barrier + synchronise on both sides.  All bundles are built and made resident first, so that the warm-up runs
+        IMMEDIATELY before the timed region (building a bundle is ~100 ms of host work with nothing queued).  DESIGN.md
+        section 5 lists what once made this bench bimodal and what was changed."""
+        wb = new_bundle(warmup, problem, sharded) if warmup > 0 else None
+        ba = new_bundle(steps, problem, sharded)
+        spin = spin_up(problem)
+        if wb is not None:
+            wb.Compute()
+        if sync_ranks:
+            barrier()
+        else:
+            ctx.sync()
+        t0 = time.perf_counter()
+        ba.Compute()
+        ctx.sync()
+        if sync_ranks:
+            barrier()
+        dt = time.perf_counter() - t0
+        trials = ba.trials()
+        assert len(trials) == steps, (len(trials), steps)
+        counts = ba.counts()
+        ba.close()
+        if wb is not None:
+            wb.close()
+        return dt, trials, counts, spin
+
+    def trial_mix(tr):
+        acc = int(tr["accepted"].sum())
+        stay = int(((tr["err_new"] == tr["err_old"]) & (tr["accepted"] == 0)).sum())
+        return {"accepted": acc, "rejected": int(len(tr) - acc - stay), "stay": stay}
+
+    def kernel_breakdown(problem, steps, sharded=True):
+        kb = new_bundle(steps, problem, sharded)
+        kb.set_profiling(True)
+        kb.Compute()
+        out = {k: (ms / n) for k, (ms, n) in kb.kernel_times().items() if n > 0}
+        kb.close()
+        return out
+
+    dt, trials, (n_cams, n_free, n_points, n_meas), spin = timed_compute(prob, args.steps, args.warmup)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    n_cams, n_free, n_points, n_meas = ba.counts()
-    ba.close()
-    sb.close()
-    if wb is not None:
-        wb.close()
 
     out = None
     if rank == 0:
-        value = world * args.steps / dt
+        value = args.steps / dt   # trials of the ONE (global) problem per second — never multiplied by the rank count
+        wl = workload_name(args.cams, args.points, args.window)
         out = {
-            "metric": "BA LM iterations/s (50 KF x 5k pts per GPU) [+ tracked frames/s @640x480 in 'tracking']",
+            "metric": "BA LM iterations/s" + (" (global BA, 200 KF x 50k pts, points sharded)" if is_global else
+                                              " (50 KF x 5k pts)" if (args.cams, args.points) == (50, 5000) else "")
+                      + " [+ tracked frames/s @640x480 in 'tracking']",
             "value": value, "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"bundle_{args.cams}kf_x_{args.points}pts_per_gpu"
-                                   + (f"_window{args.window}" if args.window else "_dense"),
-                       "keyframes": args.cams, "points_total": n_pts_total,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wl + (f"_strong_x{world}" if world > 1 else ""),
+                       "keyframes": args.cams, "points_total": args.points,
+                       "measurements_total": int(len(prob_full["cam_idx"])),
                        "measurements_rank0": int(len(prob["cam_idx"])), "estimator": "Tukey",
-                       "parallelism": f"points sharded x{world}, RCCL all-reduce of S|E" if world > 1 else "1 GPU",
+                       "parallelism": (f"points sharded x{world} (p % {world}), per trial one RCCL all-reduce of the in-band "
+                                       f"lower-triangle blocks of S + E, camera solve replicated") if world > 1 else "1 GPU",
                        "halfsample": "R"},
+            "trial_mix": trial_mix(trials),
             "accepted_trials": int(trials["accepted"].sum()),
             "spinup_k7_us_first_last_blocks": [spin[0] * 1e3, spin[-1] * 1e3, len(spin)],
             "err_first_last": [float(trials["err_old"][0]), float(trials["err_new"][-1])],
         }
+    if world > 1:
+        # per-kernel breakdown of the sharded run (HIP events, separate Compute; every rank takes part in its collectives)
+        kms = kernel_breakdown(prob, args.steps)
+        if rank == 0:
+            out["kernel_ms_per_trial"] = kms
+        # the SAME global problem on ONE device in the same run (rank 0 alone; the others wait at the barrier): the
+        # denominator of the strong-scaling speed-up, so that one JSON line carries both
+        barrier()
+        if rank == 0:
+            dt1, tr1, _, _ = timed_compute(prob_full, args.steps, args.warmup, sharded=False, sync_ranks=False)
+            out["single_gpu_same_workload"] = {"value": args.steps / dt1, "unit": "LM iterations/s", "ms_per_step": 1e3 * dt1 / args.steps,
+                                               "workload": wl, "trial_mix": trial_mix(tr1),
+                                               "kernel_ms_per_trial": kernel_breakdown(prob_full, args.steps, sharded=False)}
+            out["speedup_vs_single_gpu"] = out["value"] / out["single_gpu_same_workload"]["value"]
+        barrier()
     if world == 1:
+        # ---- steady accepted-trial rate: a Compute() of exactly the leading accepted trials of this problem ----------
+        n_lead = 0
+        for a in trials["accepted"]:
+            if not a:
+                break
+            n_lead += 1
+        if n_lead >= 2:
+            dta, tra, _, _ = timed_compute(prob, n_lead, args.warmup)
+            if int(tra["accepted"].sum()) == n_lead:
+                out["accepted_trial_us"] = 1e6 * dta / n_lead
+                out["accepted_trial_note"] = (f"one Compute() of {n_lead} trials, all accepted (includes the first step's full "
+                                              f"projection pass and the read-back at the end of Compute())")
         # ---- roofline leg: K7 alone, HIP events on the library's stream -------------------------
         pb = new_bundle(args.steps)
         pb.bench_jacobian(1000)   # (untimed: the bundle was just built, the chip idled meanwhile — see the spin-up above)
@@ -275,71 +354,40 @@ def main():
                            "traffic": pmc_traffic(out["config"]["workload"]), "algorithmic_bytes_per_launch": alg_bytes,
                            "avg_launch_us": avg_ms * 1e3, "launches_timed": args.jac_reps}
         pb.close()
-        # context only (NOT the graded number): the same kernel on the config-5 problem shape,
-        # 200 keyframes x 50 000 points, 16-camera covisibility window (M ~ 0.8 M)
-        if not args.no_tracking:
-            big = synth.make_ba_problem(200, 50000, synth.SEED_BA_GLOBAL, window=16)
+        # the same bracket with the working set COLD in the 256 MB Infinity Cache: copies of the problem launched
+        # round-robin, (n - 1) x bytes-per-launch >= 768 MB between two launches on the same copy
+        n_rot = max(4, int(768e6 // alg_bytes) + 2)
+        rot = [new_bundle(args.steps) for _ in range(n_rot)]
+        host.Bundle.bench_jacobian_rotating(rot, 20)
+        cold_ms = host.Bundle.bench_jacobian_rotating(rot, max(3, args.jac_reps // n_rot))
+        for b_ in rot:
+            b_.close()
+        out["roofline"].update({"achieved_cold": alg_bytes / (cold_ms * 1e-3) / 1e9,
+                                "frac_cold": alg_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "avg_launch_us_cold": cold_ms * 1e3, "cold_copies": n_rot,
+                                "cold_note": f"{n_rot} copies of the problem launched round-robin in one event bracket: "
+                                             f"{(n_rot - 1) * alg_bytes / 1e6:.0f} MB of other working sets pass between two launches "
+                                             f"on the same copy (Infinity Cache 256 MB + L2 32 MB)"})
+        out["kernel_ms_per_trial"] = kernel_breakdown(prob, args.steps)
+        # ---- BASELINE configs[4] on ONE device: the N = 1 point of the strong-scaling curve that `--gpus N` measures ----
+        if not is_global and not args.no_global:
+            big = synth.make_ba_problem(GLOBAL_BA["cams"], GLOBAL_BA["points"], synth.SEED_BA_GLOBAL, window=GLOBAL_BA["window"])
+            dtg, trg, cg, _ = timed_compute(big, args.steps, args.warmup)
+            gb = {"workload": workload_name(**GLOBAL_BA), "value": args.steps / dtg, "unit": "LM iterations/s",
+                  "ms_per_step": 1e3 * dtg / args.steps, "steps": args.steps, "measurements": int(cg[3]),
+                  "trial_mix": trial_mix(trg), "kernel_ms_per_trial": kernel_breakdown(big, args.steps)}
             bb = synth.load_into(host.Bundle(ctx), big)
             bb.bench_jacobian(300)
             bms, bby = bb.bench_jacobian(50)
-            out["roofline_config5_shape"] = {"kernel": "jac_accum_wave_kernel", "measurements": int(len(big["cam_idx"])),
-                                             "achieved": bby / (bms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                             "frac": bby / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_us": bms * 1e3}
+            gb["roofline_k7"] = {"kernel": "jac_accum_wave_kernel", "achieved": bby / (bms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": bby / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_us": bms * 1e3,
+                                 "algorithmic_bytes_per_launch": bby}
             bb.close()
-        # ---- per-kernel breakdown of one profiled Compute (HIP events; not the timed run) -------
-        kb = new_bundle(args.steps)
-        kb.set_profiling(True)
-        kb.Compute()
-        out["kernel_ms_per_trial"] = {k: (ms / max(n, 1)) for k, (ms, n) in kb.kernel_times().items()}
-        kb.close()
+            out["global_ba_single_gpu"] = gb
         if not args.no_tracking:
             out["tracking"] = tracking_bench(hip, host, synth)
         if not args.no_cpu_baseline:
-            from tests.oracle_lib import load_oracle
-            oracle = load_oracle()
-            octx = host.Context(lib=oracle)
-            ob = synth.load_into(host.Bundle(octx, max_iterations=args.steps, update_sq_conv_limit=0.0), prob)
-            t0 = time.perf_counter()
-            ob.Compute()
-            cdt = time.perf_counter() - t0
-            otr = ob.trials()
-            cpu = {"value": len(otr) / cdt, "unit": "LM iterations/s", "cores": 1, "kind": "port",
-                   "sample": f"same {args.cams}x{args.points} problem, {len(otr)} lambda trials, oracle/ptam_oracle.cc "
-                             f"(single-thread restatement of src/Bundle.cc; the upstream binary cannot be built here)",
-                   "host_cores_available": os.cpu_count(), "cpu_model": cpu_model()}
-            if not args.no_tracking:
-                a, b = synth.make_frame_pair()
-                kfa = host.KeyFrame(octx).MakeKeyFrame_Lite(a)
-                q, t = synth.make_patch_queries([kfa.level(l) for l in range(4)], n=1000)
-                kfb = host.KeyFrame(octx)
-                pc = synth.make_pose_case()
-                pf = host.PatchFinder(octx)
-                t0 = time.perf_counter()
-                nf = 100
-                for _ in range(nf):
-                    kfb.MakeKeyFrame_Lite(b)
-                    pf.FindPatchCoarse(kfb, q, t)
-                    octx.pose_gn(pc["world"], pc["found"], pc["sqrt_inv_noise"], pc["init_pose"])
-                cpu["tracked_fps"] = nf / (time.perf_counter() - t0)
-            # per-node figure: one independent problem per host core, the same restatement
-            import threading
-            n_rep = max(1, min(os.cpu_count() or 1, 64))
-            reps = []
-            for _ in range(n_rep):
-                rc = host.Context(lib=oracle)
-                reps.append((rc, synth.load_into(host.Bundle(rc, max_iterations=args.steps, update_sq_conv_limit=0.0), prob)))
-            th = [threading.Thread(target=b.Compute) for _, b in reps]   # ctypes drops the GIL inside the call
-            t0 = time.perf_counter()
-            for t_ in th:
-                t_.start()
-            for t_ in th:
-                t_.join()
-            rdt = time.perf_counter() - t0
-            cpu["node_replicas"] = {"value": sum(len(b.trials()) for _, b in reps) / rdt, "unit": "LM iterations/s",
-                                    "cores": n_rep, "note": "one independent copy of the problem per host core"}
-            for _, b in reps:
-                b.close()
-            out["cpu_baseline"] = cpu
+            out["cpu_baseline"], otr = cpu_baseline(args, host, synth, prob)
             # parity of the timed workload itself (oracle as checker, cheap: it already ran)
             rel = abs(otr["err_new"][-1] - trials["err_new"][-1]) / abs(otr["err_new"][-1])
             out["parity_rel_err_final_trial"] = float(rel)
@@ -350,6 +398,64 @@ def main():
             hip.rccl_destroy(comm)
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cpu_baseline(args, host, synth, prob):
+    """the oracle (kind "port") on the host cores: one thread on the timed problem (a bounded sample: at most 20 trials),
+    a tracked-frame loop, and one independent replica per PHYSICAL core for the per-node figure"""
+    from tests.oracle_lib import load_oracle
+    oracle = load_oracle()
+    octx = host.Context(lib=oracle)
+    ob = synth.load_into(host.Bundle(octx, max_iterations=args.steps, update_sq_conv_limit=0.0), prob)
+    t0 = time.perf_counter()
+    ob.Compute()
+    cdt = time.perf_counter() - t0
+    otr = ob.trials()
+    cpu = {"value": len(otr) / cdt, "unit": "LM iterations/s", "cores": 1, "kind": "port",
+           "sample": f"same {args.cams}x{args.points} problem, {len(otr)} lambda trials, oracle/ptam_oracle.cc "
+                     f"(single-thread restatement of src/Bundle.cc; the upstream binary cannot be built here)",
+           "host_threads_available": os.cpu_count(), "cpu_model": cpu_model()}
+    if not args.no_tracking:
+        a, b = synth.make_frame_pair()
+        kfa = host.KeyFrame(octx).MakeKeyFrame_Lite(a)
+        q, t = synth.make_patch_queries([kfa.level(l) for l in range(4)], n=1000)
+        kfb = host.KeyFrame(octx)
+        pc = synth.make_pose_case()
+        pf = host.PatchFinder(octx)
+        t0 = time.perf_counter()
+        nf = 100
+        for _ in range(nf):
+            kfb.MakeKeyFrame_Lite(b)
+            pf.FindPatchCoarse(kfb, q, t)
+            octx.pose_gn(pc["world"], pc["found"], pc["sqrt_inv_noise"], pc["init_pose"])
+        cpu["tracked_fps"] = nf / (time.perf_counter() - t0)
+    # per-node figure: one independent problem per physical core, the same restatement (each replica holds ~0.6 KB per
+    # measurement: the replica count is also bounded by a quarter of the free memory)
+    import threading
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or (os.cpu_count() or 1)
+        mem_cap = int(psutil.virtual_memory().available * 0.25 // (len(prob["cam_idx"]) * 1024 + (64 << 20)))
+    except Exception:
+        phys, mem_cap = max(1, (os.cpu_count() or 2) // 2), 64
+    n_rep = max(1, min(phys, mem_cap))
+    reps = []
+    for _ in range(n_rep):
+        rc = host.Context(lib=oracle)
+        reps.append((rc, synth.load_into(host.Bundle(rc, max_iterations=args.steps, update_sq_conv_limit=0.0), prob)))
+    th = [threading.Thread(target=b.Compute) for _, b in reps]   # ctypes drops the GIL inside the call
+    t0 = time.perf_counter()
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    rdt = time.perf_counter() - t0
+    cpu["node_replicas"] = {"value": sum(len(b.trials()) for _, b in reps) / rdt, "unit": "LM iterations/s",
+                            "cores": n_rep, "physical_cores": phys,
+                            "note": "one independent copy of the problem per physical host core (fewer if memory bounds it)"}
+    for _, b in reps:
+        b.close()
+    return cpu, otr
 
 
 if __name__ == "__main__":

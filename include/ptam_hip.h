@@ -347,7 +347,14 @@ int ptam_ba_add_points(ptam_ba* ba, int n, const double* pos3);
 int ptam_ba_add_measurements(ptam_ba* ba, int n, const int32_t* cam, const int32_t* point,
                              const double* found2, const double* sigma_sq);
 /* Bundle::Compute src/Bundle.cc:116-158.  *abort_flag (nullable) is polled on the host between
- * device trials (src/Bundle.cc:134,338).  *accepted_out = mnAccepted, or -1 on numerical failure. */
+ * device trials (src/Bundle.cc:134,338); a sharded bundle sums the flags of all ranks with every trial's
+ * scalars and acts on the sum, so that all ranks stop at the same trial (one trial later than a local
+ * test would).  *accepted_out = mnAccepted, always >= 0: the reference's `return -1` (src/Bundle.cc:149-150)
+ * is dead code there — Do_LM_Step returns true unconditionally (:550), TooN's LDL^T signals nothing — and
+ * a singular or non-finite system shows up as it does in the reference: NaN errors, rejected trials, and
+ * (where the reference would loop for ever, :118-123) an early stop.  Errors of the call itself (< 0
+ * status: PTAM_E_LIMIT for a point seen by more than 256 cameras, PTAM_E_ARG for a duplicate
+ * measurement, HIP / communicator failures) are the return value, not *accepted_out. */
 int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* accepted_out);
 int ptam_ba_converged(const ptam_ba* ba);                    /* include/Bundle.h:115 */
 int ptam_ba_get_point(const ptam_ba* ba, int n, double pos[3]);      /* src/Bundle.cc:613 */
@@ -368,7 +375,8 @@ enum {
     PTAM_K_SCHUR = 4,       /* K8 */
     PTAM_K_SOLVE = 5,       /* K9 */
     PTAM_K_UPDATE = 6,      /* K10 back-substitution + apply + new error */
-    PTAM_K_COUNT = 7
+    PTAM_K_EXCHANGE = 7,    /* sharded bundles only: the all-reduce of S|E (the path's one exchange step) */
+    PTAM_K_COUNT = 8
 };
 int ptam_ba_set_profiling(ptam_ba* ba, int on);
 int ptam_ba_kernel_time(const ptam_ba* ba, int kernel, double* total_ms, int* launches);
@@ -378,6 +386,9 @@ int ptam_ba_prepare(ptam_ba* ba);
  * once: done internally), HIP-event timed; returns average ms per launch and the algorithmic
  * byte count of one launch. */
 int ptam_ba_bench_jacobian(ptam_ba* ba, int reps, double* avg_ms, double* algorithmic_bytes);
+/* the same bracket over `n` bundles of one context (copies of one problem) launched round-robin: with
+ * (n - 1) working sets larger than the 256 MB Infinity Cache every launch finds its data in HBM only. */
+int ptam_ba_bench_jacobian_rotating(ptam_ba** bas, int n, int reps, double* avg_ms);
 
 /* ---- sharded global BA: measurements sharded by point across ranks ----------- */
 /* A collective hook: all-reduce (sum) `count` doubles in place at device pointer `dptr`,

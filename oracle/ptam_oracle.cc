@@ -926,6 +926,13 @@ struct Bundle {
             if (rc != 0) std::fprintf(stderr, "oracle: allreduce hook failed (%d)\n", rc);
         }
     }
+    // the abort flag (src/Bundle.cc:134,338): sharded, the decision has to be the same on every rank at the same point of
+    // the control flow (every trial runs collectives), so the local flags are summed; identity without a communicator
+    bool Aborted(const volatile unsigned char* pb) {
+        double a = (pb && *pb) ? 1.0 : 0.0;
+        allreduce(&a, 1);
+        return a > 0.5;
+    }
     // gather every rank's squared errors (all-gather built from two all-reduces)
     void gather_errors(std::vector<double>& v) {
         if (!(comm && world > 1)) return;
@@ -1031,7 +1038,7 @@ struct Bundle {
             allreduce(&nb, 1);
             nBadSoFar = (int)(nb + 0.5);
         }
-        while (dNewError > dCurrentError && !mbConverged && !mbHitMaxIterations && !(pbAbort && *pbAbort)) {
+        while (dNewError > dCurrentError && !mbConverged && !mbHitMaxIterations && !Aborted(pbAbort)) {
             for (auto& point : mvPoints) {   // V*^-1 :341-359
                 double V[9];
                 std::memcpy(V, point.m3V, sizeof V);
@@ -1111,9 +1118,17 @@ struct Bundle {
                     assert(nKRow < nJRow);
                 }
             }
-            if (comm && world > 1) {   // the one exchange step of the path
-                allreduce(mS.data(), mS.size());
-                allreduce(vE.data(), vE.size());
+            if (comm && world > 1) {   // the one exchange step of the path: lower triangle of S, then E
+                std::vector<double> pk((size_t)n * (n + 1) / 2 + n);
+                size_t q = 0;
+                for (int i = 0; i < n; i++)
+                    for (int j = 0; j <= i; j++) pk[q++] = mS[(size_t)i * n + j];
+                for (int i = 0; i < n; i++) pk[q++] = vE[i];
+                allreduce(pk.data(), pk.size());
+                q = 0;
+                for (int i = 0; i < n; i++)
+                    for (int j = 0; j <= i; j++) mS[(size_t)i * n + j] = pk[q++];
+                for (int i = 0; i < n; i++) vE[i] = pk[q++];
             }
             for (int i = 0; i < n; i++)   // mirror :451-453
                 for (int j = 0; j < i; j++) mS[(size_t)j * n + i] = mS[(size_t)i * n + j];
@@ -1212,7 +1227,7 @@ struct Bundle {
         mnCounter = 0;
         mnAccepted = 0;
         trials.clear();
-        while (!mbConverged && !mbHitMaxIterations && !(pbAbort && *pbAbort)) {
+        while (!mbConverged && !mbHitMaxIterations && !Aborted(pbAbort)) {
             bool ok;
             if (opts.estimator == PTAM_EST_CAUCHY)
                 ok = Do_LM_Step<Cauchy>(pbAbort);

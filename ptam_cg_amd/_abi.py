@@ -11,8 +11,8 @@ LEVELS = 4
 MAX_SSD = 8 * 8 * 500
 HALFSAMPLE_R, HALFSAMPLE_T = 0, 1
 EST_TUKEY, EST_CAUCHY, EST_HUBER = 0, 1, 2
-K_PROJECT, K_SELECT, K_JACOBIAN, K_VINV, K_SCHUR, K_SOLVE, K_UPDATE, K_COUNT = range(8)
-KERNEL_NAMES = ["project", "select", "jacobian", "vinv", "schur", "solve", "update"]
+K_PROJECT, K_SELECT, K_JACOBIAN, K_VINV, K_SCHUR, K_SOLVE, K_UPDATE, K_EXCHANGE, K_COUNT = range(9)
+KERNEL_NAMES = ["project", "select", "jacobian", "vinv", "schur", "solve", "update", "exchange"]
 
 
 class Int2(C.Structure):
@@ -162,6 +162,7 @@ PROTOTYPES = {
     "ba_kernel_time": (_i, [_vp, _i, _pd, C.POINTER(_i)]),
     "ba_prepare": (_i, [_vp]),
     "ba_bench_jacobian": (_i, [_vp, _i, _pd, _pd]),
+    "ba_bench_jacobian_rotating": (_i, [_vp, _i, _i, _pd]),
     "ba_set_comm": (_i, [_vp, _i, _i, ALLREDUCE_FN, _vp]),
     "rccl_unique_id": (_i, [_vp]),
     "rccl_create": (_i, [_vp, _vp, _i, _i, _ppv]),

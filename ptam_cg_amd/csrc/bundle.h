@@ -11,8 +11,12 @@
 //   points:  pt[2][P][3] (current / trial), V[P][6] (lower 00,10,11,20,21,22), epsB[P][3],
 //            Vinv[P][9]
 //   cameras: pose[2][C][12] (current / trial), Usplit[16][F][27] (U lower triangle 21 + epsA 6)
-//   camera system: SE = [ S (npad x npad, lower triangle valid) | E (npad) ] contiguous so that the
-//            sharded path all-reduces ONE buffer; L (npad x npad) + Dg (npad) hold the LDL^T factor.
+//   camera system: SE = [ S | E (npad) | 3 scalars ] contiguous so that the sharded path all-reduces ONE
+//            buffer.  S is stored BLOCK-BANDED: only the 32x32 blocks (bi, bj) of the lower triangle with
+//            bi - band <= bj <= bi exist (band = block bandwidth of the covisibility, se_blk below), each
+//            block 8 KB contiguous, block rows one after another — the upper half is redundant
+//            (src/Bundle.cc:451-453 mirrors it) and outside the band S is zero, so neither is stored,
+//            factored or exchanged.  L (same layout) + Dg (npad) hold the LDL^T factor.
 #pragma once
 #include "common.h"
 
@@ -60,7 +64,7 @@ struct BaScalars {
     int spec_go;            //                and the next step will run with the trial state as current
     int spec_stay;          //                or: the step is over WITHOUT an accepted trial (new == current error) and the
                             //                next one starts from the unchanged state with the unchanged lambda
-    int pad_;
+    int abort_any;          // sharded: some rank's abort flag was up when this trial was enqueued (summed with the trial's scalars)
 };
 
 struct BaDev {
@@ -121,6 +125,23 @@ struct BaDev {
     BaScalars* sc;
     long long* dbg;         // 16 cycle stamps (only written by -DK7_TIMING builds)
 };
+
+// ---- block-banded packed storage of S and L (lower triangle, 32x32 blocks inside the band) ----
+__host__ __device__ __forceinline__ size_t se_blocks_before_row(int bi, int band) {
+    return bi <= band ? (size_t)bi * (bi + 1) / 2 : (size_t)(band + 1) * (band + 2) / 2 + (size_t)(bi - band - 1) * (band + 1);
+}
+// offset (in doubles) of block (bi, bj), bi - band <= bj <= bi; element (r, c) of the block sits at + r * SOLVE_NB + c
+__host__ __device__ __forceinline__ size_t se_blk(int bi, int bj, int band) {
+    const int j0 = bi - band > 0 ? bi - band : 0;
+    return (se_blocks_before_row(bi, band) + (size_t)(bj - j0)) * (SOLVE_NB * SOLVE_NB);
+}
+// doubles of S (or L) for nblk block rows; E follows S at this offset
+__host__ __device__ __forceinline__ size_t se_size(int nblk, int band) { return se_blocks_before_row(nblk, band) * (SOLVE_NB * SOLVE_NB); }
+__host__ __device__ __forceinline__ int se_band(const BaDev& d) {
+    const int nblk = d.npad / SOLVE_NB;
+    return d.band < nblk - 1 ? d.band : (nblk > 0 ? nblk - 1 : 0);
+}
+__host__ __device__ __forceinline__ double* se_E(const BaDev& d) { return d.SE + se_size(d.npad / SOLVE_NB, se_band(d)); }
 
 // solve.hip
 int ba_solve(ptam_ctx* ctx, BaDev& d, int cur);   // also writes the trial poses pose[cur^1] and |da|^2

@@ -366,7 +366,10 @@ static int ba_prepare_impl(ptam_ba* ba) {
                  o_spw = cv.take((size_t)(n_pairs + 1) * 4),
                  o_spart = cv.take(std::max<size_t>(1, s_wgs.size()) * SCHUR_TILE_ELEMS * 8);
     const size_t npad = std::max(d.npad, SOLVE_NB);
-    const size_t o_SE = cv.take((npad * npad + npad + 2) * 8), o_L = cv.take(npad * npad * 8), o_Dg = cv.take(npad * 8),
+    // S and L block-banded (bundle.h: se_blk); sized for the full lower triangle, because a sharded bundle only learns the
+    // bandwidth in force (the widest over all ranks) in Compute()'s first exchange
+    const size_t se_full = se_size((int)(npad / SOLVE_NB), (int)(npad / SOLVE_NB) - 1);
+    const size_t o_SE = cv.take((se_full + npad + 8) * 8), o_L = cv.take(se_full * 8), o_Dg = cv.take(npad * 8),
                  o_y = cv.take(npad * 8), o_da = cv.take(npad * 8);
     const size_t o_out = cv.take(Mz * 4), o_sc = cv.take(sizeof(BaScalars)), o_dbg = cv.take(65536);
     ba->block_bytes = cv.off;
@@ -644,11 +647,10 @@ static int ba_pass2(ptam_ba* ba) {
     if (ba->comm && ba->world > 1) {
         if (d.F > 0) {
             // current error / bad count ride behind S|E in the step's first camera-system all-reduce
-            hipLaunchKernelGGL(pack2_kernel, dim3(1), dim3(1), 0, ctx->stream, (const BaScalars*)d.sc,
-                               d.SE + (size_t)d.npad * d.npad + d.npad, 0);
+            hipLaunchKernelGGL(pack2_kernel, dim3(1), dim3(1), 0, ctx->stream, (const BaScalars*)d.sc, se_E(d) + d.npad, 0, 0);
             ba->cur_pending = true;
         } else {
-            hipLaunchKernelGGL(pack2_kernel, dim3(1), dim3(1), 0, ctx->stream, (const BaScalars*)d.sc, ba->d_xchg, 0);
+            hipLaunchKernelGGL(pack2_kernel, dim3(1), dim3(1), 0, ctx->stream, (const BaScalars*)d.sc, ba->d_xchg, 0, 0);
             int rc = ba_allreduce(ba, ba->d_xchg, 2);
             if (rc) return rc;
             hipLaunchKernelGGL(unpack2_kernel, dim3(1), dim3(1), 0, ctx->stream, d.sc, (const double*)ba->d_xchg, 0);
@@ -671,7 +673,7 @@ static int ba_ensure_mailbox(ptam_ba* ba) {
     return PTAM_OK;
 }
 
-static int ba_trial(ptam_ba* ba, double lambda, bool skip_vinv, int last_allowed) {
+static int ba_trial(ptam_ba* ba, double lambda, bool skip_vinv, int last_allowed, int abort_local) {
     ptam_ctx* ctx = ba->ctx;
     BaDev& d = ba->d;
     prof_begin(ba, PTAM_K_VINV);
@@ -685,8 +687,12 @@ static int ba_trial(ptam_ba* ba, double lambda, bool skip_vinv, int last_allowed
                            (ba->world > 1 && ba->rank != 0) ? 0 : 1);
         prof_end(ba, PTAM_K_SCHUR);
         HIP_TRY(hipGetLastError());
-        const size_t n_se = (size_t)d.npad * d.npad + d.npad;
-        int rc = ba_allreduce(ba, d.SE, n_se + (ba->cur_pending ? 2 : 0));   // the path's one exchange step
+        // the path's one exchange step: the in-band lower-triangle blocks of S, then E (+ the step's two scalars) — one buffer
+        const size_t n_se = se_size(d.npad / SOLVE_NB, se_band(d)) + d.npad;
+        const bool sharded = ba->comm && ba->world > 1;
+        if (sharded) prof_begin(ba, PTAM_K_EXCHANGE);
+        int rc = ba_allreduce(ba, d.SE, n_se + (ba->cur_pending ? 2 : 0));
+        if (sharded) prof_end(ba, PTAM_K_EXCHANGE);
         if (rc) return rc;
         if (ba->cur_pending) {
             hipLaunchKernelGGL(unpack2_kernel, dim3(1), dim3(1), 0, ctx->stream, d.sc, (const double*)(d.SE + n_se), 0);
@@ -721,8 +727,8 @@ static int ba_trial(ptam_ba* ba, double lambda, bool skip_vinv, int last_allowed
     prof_end(ba, PTAM_K_UPDATE);
     HIP_TRY(hipGetLastError());
     if (ba->comm && ba->world > 1) {
-        hipLaunchKernelGGL(pack2_kernel, dim3(1), dim3(1), 0, ctx->stream, (const BaScalars*)d.sc, ba->d_xchg, 1);
-        int rc = ba_allreduce(ba, ba->d_xchg, 2);
+        hipLaunchKernelGGL(pack2_kernel, dim3(1), dim3(1), 0, ctx->stream, (const BaScalars*)d.sc, ba->d_xchg, 1, abort_local);
+        int rc = ba_allreduce(ba, ba->d_xchg, 3);
         if (rc) return rc;
         hipLaunchKernelGGL(unpack2_kernel, dim3(1), dim3(1), 0, ctx->stream, d.sc, (const double*)ba->d_xchg, 1);
     }
@@ -1004,8 +1010,10 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     const bool dbg_ = getenv("PTAM_DEBUG_WAIT") != nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
     BA_DBG("compute: prepare");
+    const bool sharded = ba->comm && ba->world > 1;
     int rc = ptam_ba_prepare(ba);
-    if (rc) return rc;
+    if (rc && !sharded) return rc;
+    const int rc_prepare = rc;   // sharded: a local failure is made unanimous by the first exchange below
     BA_DBG("compute: prepared M=%d P=%d F=%d chunks=%d wchunks=%d grid_acc=%d schur_wg=%d", ba->d.M, ba->d.P, ba->d.F, ba->d.n_chunks,
            ba->d.n_wchunks, ba->d.grid_acc, ba->d.n_schur_wg);
     BaDev& d = ba->d;
@@ -1023,7 +1031,12 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     std::vector<int> step_outlier_end;   // outlier-list length after every LM step
     int n_steps = 0;
     bool prev_end_pending = false;   // the previous step's outlier-list length has not been read yet
-    auto aborted = [&]() { return abort_flag && *abort_flag; };
+    // The abort flag (src/Bundle.cc:134,338).  Sharded, every trial runs collectives, so the decision must be the same on
+    // every rank at the same trial: the local flag is sampled when a trial is enqueued, summed over the ranks with the
+    // trial's scalars, and only the summed value (abort_all) is acted upon — one trial later than a local test would.
+    bool abort_all = false;
+    auto abort_local = [&]() { return abort_flag && *abort_flag; };
+    auto aborted = [&]() { return sharded ? abort_all : abort_local(); };
     BaScalars sc;
     std::memset(&sc, 0, sizeof sc);
     double dbg_enq_ms = 0, dbg_wait_ms = 0;   // host time spent enqueueing trials / waiting for their scalars (PTAM_DEBUG_STALL)
@@ -1034,26 +1047,41 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     double ht_first = 0;
     (void)hipMemsetAsync(ba->d.dbg + TL_BASE, 0, 8, ba->ctx->stream);
 #endif
-    if (ba->comm && ba->world > 1) {
-        // every rank must walk the same sequence of collectives: a rank without measurements would leave the loop below
-        // at once and the others would wait for it for ever.  One tiny all-reduce up front makes the refusal unanimous.
+    if (sharded) {
+        // every rank must walk the same sequence of collectives: a rank without measurements, or one whose prepare failed
+        // (a point with more than BA_CHUNK cameras, a duplicate measurement, an allocation failure — all of them local to a
+        // shard), would return at once and the others would wait for it for ever.  One tiny all-reduce up front makes the
+        // refusal unanimous and carries the first abort sample.
         // The same exchange settles the block bandwidth of the camera system: every rank marks the bandwidth its own
         // points need (one-hot, the collective only sums), the widest one wins — S is the sum of all ranks' parts.
-        const int nblk_x = d.npad / SOLVE_NB;
-        const bool band_fits = nblk_x + 2 <= 512;   // d_xchg holds 512 doubles
-        std::vector<double> mine(band_fits ? 2 + nblk_x : 2, 0.0), all(mine.size(), 0.0);
-        mine[0] = d.M == 0 ? 1.0 : 0.0;
+        // (the layout of this vector only depends on the cameras, which every rank holds, never on the outcome of prepare)
+        int n_free = 0;
+        for (uint8_t x : ba->cam_fixed) n_free += x ? 0 : 1;
+        const int nblk_x = (6 * n_free + SOLVE_NB - 1) / SOLVE_NB;
+        const bool band_fits = nblk_x + 4 <= 512;   // d_xchg holds 512 doubles
+        std::vector<double> mine(band_fits ? 4 + nblk_x : 4, 0.0), all(mine.size(), 0.0);
+        mine[0] = (!rc_prepare && d.M == 0) ? 1.0 : 0.0;
         mine[1] = (double)d.M;
-        if (band_fits && nblk_x > 0) mine[2 + std::min(ba->band_local, nblk_x - 1)] = 1.0;
+        mine[2] = rc_prepare ? 1.0 : 0.0;
+        mine[3] = abort_local() ? 1.0 : 0.0;
+        if (!rc_prepare && band_fits && nblk_x > 0) mine[4 + std::min(ba->band_local, nblk_x - 1)] = 1.0;
+        if (!ba->d_xchg) HIP_TRY(hipMalloc((void**)&ba->d_xchg, 4096));   // (a failed prepare has not allocated it)
         HIP_TRY(hipMemcpyAsync(ba->d_xchg, mine.data(), mine.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         rc = ba_allreduce(ba, ba->d_xchg, mine.size());
-        if (rc) return rc;
+        if (rc) return rc_prepare ? rc_prepare : rc;
         HIP_TRY(hipMemcpyAsync(all.data(), ba->d_xchg, all.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ptam_stream_wait(ctx->stream));
-        ba->d.band = nblk_x;
+        if (all[2] > 0.5) {
+            if (rc_prepare) return rc_prepare;   // (this rank's own error message stands)
+            ptam_set_error("sharded bundle: %d of %d ranks could not prepare their shard; nothing was computed on any rank",
+                           (int)(all[2] + 0.5), ba->world);
+            return PTAM_E_STATE;
+        }
+        abort_all = all[3] > 0.5;
+        ba->d.band = std::max(0, nblk_x - 1);
         if (band_fits)
             for (int b = nblk_x - 1; b >= 0; b--)
-                if (all[2 + b] > 0.5) {
+                if (all[4 + b] > 0.5) {
                     ba->d.band = b;
                     break;
                 }
@@ -1065,7 +1093,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     }
     const bool empty = d.M == 0;
     // speculative step prologue (ba_enqueue_speculative): single device, not while per-kernel events are being taken
-    const bool spec = !(ba->comm && ba->world > 1) && !ba->prof && d.n_chunks > 0 && !getenv("PTAM_NO_SPECULATION");
+    const bool spec = !sharded && !ba->prof && d.n_chunks > 0 && !getenv("PTAM_NO_SPECULATION");
     bool spec_ready = false;   // pass 1 .. V*^-1 of the coming step are already running behind the device-side flag
     while (!empty && !ba->converged && !hit_max && !aborted()) {
         // ---- Do_LM_Step :209-551 ----
@@ -1088,7 +1116,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
             if (ba->converged || hit_max || aborted()) break;
             BA_DBG("trial %d lambda %g", counter, lambda);
             const auto q0 = std::chrono::steady_clock::now();
-            rc = ba_trial(ba, lambda, skip_vinv, counter + 1 >= ba->opts.max_iterations ? 1 : 0);
+            rc = ba_trial(ba, lambda, skip_vinv, counter + 1 >= ba->opts.max_iterations ? 1 : 0, abort_local() ? 1 : 0);
             {
                 const double qms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - q0).count();
                 dbg_enq_ms += qms;
@@ -1142,6 +1170,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
                 }
             }
             ran_any = true;
+            if (sharded) abort_all = abort_all || sc.abort_any != 0;
             new_err = sc.new_err;
             const double sumsq = sc.sumsq_cam + sc.sumsq_pt;
             if (sumsq < ba->opts.update_sq_conv_limit) ba->converged = true;   // :488-490
@@ -1386,6 +1415,41 @@ int ptam_ba_bench_jacobian(ptam_ba* ba, int reps, double* avg_ms, double* algori
     if (algorithmic_bytes)   // 8 idx + 24 found/s + 1 state + 144 W per measurement,
                              // 96 B/camera pose read, 24 read + 72 write per point, 216 B/free camera
         *algorithmic_bytes = (double)d.M * (8 + 24 + 1 + 144) + (double)d.C * 96 + (double)d.P * (24 + 72) + (double)d.F * 216;
+    return PTAM_OK;
+}
+
+// K7 with its inputs and outputs COLD in the 256 MB Infinity Cache: `n` prepared bundles of the same context (copies of one
+// problem) are launched round-robin, back to back, inside ONE event bracket — the method of ptam_ba_bench_jacobian, but
+// between two launches on the same bundle lie the n - 1 other working sets.  The caller picks n so that
+// (n - 1) x (bytes one launch touches) exceeds the cache by a wide margin; then every launch streams from / to HBM.
+int ptam_ba_bench_jacobian_rotating(ptam_ba** bas, int n, int reps, double* avg_ms) {
+    ARG_TRY(bas && n > 0 && reps > 0 && avg_ms);
+    ptam_ctx* ctx = bas[0]->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (int i = 0; i < n; i++) {
+        ARG_TRY(bas[i] && bas[i]->ctx == ctx);
+        int rc = ptam_ba_prepare(bas[i]);
+        if (rc) return rc;
+        ARG_TRY(bas[i]->d.M > 0);
+        rc = ba_pass1_sigma(bas[i]);
+        if (rc) return rc;
+    }
+    for (int r = 0; r < 2; r++)
+        for (int i = 0; i < n; i++) launch_k7(bas[i]);
+    HIP_TRY(ptam_stream_wait(ctx->stream));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, ctx->stream));
+    for (int r = 0; r < reps; r++)
+        for (int i = 0; i < n; i++) launch_k7(bas[i]);
+    HIP_TRY(hipEventRecord(e1, ctx->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms_total = 0;
+    HIP_TRY(hipEventElapsedTime(&ms_total, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *avg_ms = (double)ms_total / ((double)reps * n);
     return PTAM_OK;
 }
 

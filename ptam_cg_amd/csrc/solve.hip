@@ -88,9 +88,9 @@ struct StepLds {
 __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
     if (k == 0) { TL_MARK(d, 9) }
     __shared__ StepLds s;
-    const int npad = d.npad, nblk = npad / NB, rem = min(nblk - k - 1, d.band);   // (rows below the band hold zeros in column k)
+    const int npad = d.npad, nblk = npad / NB, band = se_band(d), rem = min(nblk - k - 1, band);   // (below the band column k holds zeros: not stored)
     double* __restrict__ S = d.SE;
-    double* __restrict__ E = d.SE + (size_t)npad * npad;
+    double* __restrict__ E = se_E(d);
     const int tid = threadIdx.x;
     const int r = tid / STRIPS, g = tid % STRIPS;   // row, column residue (columns g + 8*jj)
     int role, bi = 0, bj = 0;
@@ -116,12 +116,12 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
     for (int jj = 0; jj < CPT; jj++) {
         const int q = g + STRIPS * jj;
         aj[jj] = 0.0;
-        akk[jj] = S[(size_t)(k * NB + r) * npad + k * NB + q];
+        akk[jj] = S[se_blk(k, k, band) + r * NB + q];
         if (role == 0)   // the identity rides along as the panel block: its X is Lkk^-T
             ai[jj] = (q == r) ? 1.0 : 0.0;
         else
-            ai[jj] = S[(size_t)(bi * NB + r) * npad + k * NB + q];
-        if (two) aj[jj] = S[(size_t)(bj * NB + r) * npad + k * NB + q];
+            ai[jj] = S[se_blk(bi, k, band) + r * NB + q];
+        if (two) aj[jj] = S[se_blk(bj, k, band) + r * NB + q];
     }
     double br = (g == STRIPS - 1) ? E[k * NB + r] : 0.0;   // thread (r, 7) carries b_r
     // operands of the closing read-modify-writes, fetched now so that the step does not end on a load
@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
     if (role == 2) {
 #pragma unroll
         for (int v = 0; v < 4; v++)
-            sij[v] = S[(size_t)(bi * NB + 16 * qi + (mlane >> 4) + 4 * v) * npad + bj * NB + 16 * qj + (mlane & 15)];
+            sij[v] = S[se_blk(bi, bj, band) + (16 * qi + (mlane >> 4) + 4 * v) * NB + 16 * qj + (mlane & 15)];
     }
     const double e_old = (role == 1 && g == STRIPS - 1) ? E[bi * NB + r] : 0.0;
 #ifdef K7_TIMING
@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
     if (role == 0) {
         // diagonal block of the factor buffer: Lkk^-T (upper triangular, unit diagonal) for the backward pass
 #pragma unroll
-        for (int jj = 0; jj < CPT; jj++) d.L[(size_t)(k * NB + r) * npad + k * NB + g + STRIPS * jj] = ai[jj];
+        for (int jj = 0; jj < CPT; jj++) d.L[se_blk(k, k, band) + r * NB + g + STRIPS * jj] = ai[jj];
         if (tid < NB) {
             d.Dg[k * NB + tid] = s.Dv[tid];
             d.y[k * NB + tid] = s.z[tid];
@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
         for (int jj = 0; jj < CPT; jj++) {
             const int q = g + STRIPS * jj;
             const double l = ai[jj] * id4[jj];
-            d.L[(size_t)(bi * NB + r) * npad + k * NB + q] = l;
+            d.L[se_blk(bi, k, band) + r * NB + q] = l;
             sum += l * s.z[q];
         }
         sum += dpp_row_shr_f64<1>(sum);   // the 8 threads of a row are 8 consecutive lanes of a DPP row: lane 7 collects
@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
 #pragma unroll
         for (int v = 0; v < 4; v++) {
             const int row = 16 * qi + (lane >> 4) + 4 * v, col = 16 * qj + (lane & 15);
-            S[(size_t)(bi * NB + row) * npad + bj * NB + col] = sij[v] - acc[v];
+            S[se_blk(bi, bj, band) + row * NB + col] = sij[v] - acc[v];
         }
     }
 #ifdef K7_TIMING
@@ -341,30 +341,35 @@ __global__ void __launch_bounds__(TPB) ldlt_step_kernel(BaDev d, int k) {
 __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur) {
     TL_MARK(d, 10)
     extern __shared__ __attribute__((aligned(16))) double bw_lds[];
-    const int npad = d.npad, nblk = npad / NB;
+    const int npad = d.npad, nblk = npad / NB, band = se_band(d);
     double* xs = bw_lds;         // npad: the solution
-    double* pend = xs + npad;    // npad: sum_{blocks below} L^T x
-    double* wv = pend + npad;    // npad: D^-1 z
+    double* pend = xs + npad;    // 4 x npad: sum_{blocks below} L^T x, one plane per row slice (summed in fixed order by the
+                                 // reader: every rank of a sharded bundle must arrive at bit-identical poses — LDS atomics did not)
+    double* wv = pend + 4 * npad;    // npad: D^-1 z
     const int tid = threadIdx.x;
     const int c = tid % NB, rr = tid / NB;
     for (int i = tid; i < npad; i += 1024) {
-        pend[i] = 0.0;
+        pend[i] = pend[npad + i] = pend[2 * npad + i] = pend[3 * npad + i] = 0.0;
         wv[i] = d.y[i] / d.Dg[i];
     }
-    double wnext = d.L[(size_t)((nblk - 1) * NB + rr) * npad + (nblk - 1) * NB + c];   // Lkk^-T element (rr, c)
+    double wnext = d.L[se_blk(nblk - 1, nblk - 1, band) + rr * NB + c];   // Lkk^-T element (rr, c)
     for (int k = nblk - 1; k >= 0; k--) {
         const double w = wnext;
-        if (k > 0) wnext = d.L[(size_t)((k - 1) * NB + rr) * npad + (k - 1) * NB + c];   // prefetch the next block
+        if (k > 0) wnext = d.L[se_blk(k - 1, k - 1, band) + rr * NB + c];   // prefetch the next block
         // first round of this block's update operands (independent of x_k): in flight during the mat-vec
         // columns of the blocks above that row block k reaches: all of them, or — S banded — the last `band` blocks
-        const int jlo = max(0, k - d.band) * NB, ncol = k * NB - jlo;
+        const int jlo = max(0, k - band) * NB, ncol = k * NB - jlo;
+        // block row k of L: its blocks left of the diagonal are contiguous, column j of row q sits at
+        const double* Lrow = d.L + se_blk(k, max(0, k - band), band);
+        auto l_at = [&](int q, int j) { return Lrow[(size_t)((j - jlo) / NB) * (NB * NB) + q * NB + ((j - jlo) % NB)]; };
         const bool upd = tid < ncol * 4;
         const int j0 = jlo + (upd ? tid % ncol : 0), sl0 = upd ? tid / ncol : 0;
         double lreg[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) lreg[q] = upd ? d.L[(size_t)(k * NB + sl0 * 8 + q) * npad + j0] : 0.0;
+        for (int q = 0; q < 8; q++) lreg[q] = upd ? l_at(sl0 * 8 + q, j0) : 0.0;
         __syncthreads();   // (A) pending sums of the previous block are complete
-        double p = (c >= rr) ? w * (wv[k * NB + c] - pend[k * NB + c]) : 0.0;   // upper triangular
+        const int kc = k * NB + c;
+        double p = (c >= rr) ? w * (wv[kc] - ((pend[kc] + pend[npad + kc]) + (pend[2 * npad + kc] + pend[3 * npad + kc]))) : 0.0;   // upper triangular
         // 32-lane sum on the VALU (DPP row shifts, then lane 15 of rows 0 / 2 into rows 1 / 3): five ds_bpermute
         // round trips sat on the block's critical path
         p += dpp_row_shr_f64<1>(p);
@@ -379,14 +384,14 @@ __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur) {
             double a = 0;
 #pragma unroll
             for (int q = 0; q < 8; q++) a += lreg[q] * xs[k * NB + sl0 * 8 + q];
-            atomicAdd(&pend[j0], a);   // LDS; four addends per column
+            pend[sl0 * npad + j0] += a;   // (thread (slice, column) is the only writer of its slot in this round)
         }
         for (int idx = tid + 1024; idx < ncol * 4; idx += 1024) {
             const int j = jlo + idx % ncol, sl = idx / ncol;
             double a = 0;
 #pragma unroll
-            for (int q = 0; q < 8; q++) a += d.L[(size_t)(k * NB + sl * 8 + q) * npad + j] * xs[k * NB + sl * 8 + q];
-            atomicAdd(&pend[j], a);
+            for (int q = 0; q < 8; q++) a += l_at(sl * 8 + q, j) * xs[k * NB + sl * 8 + q];
+            pend[sl * npad + j] += a;
         }
     }
     __syncthreads();
@@ -428,11 +433,11 @@ int ba_solve_init() {
 int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
     const int nblk = d.npad / NB;
     for (int k = 0; k < nblk; k++) {
-        const int rem = std::min(nblk - k - 1, d.band);
+        const int rem = std::min(nblk - k - 1, se_band(d));
         const int nwg = 1 + rem + rem * (rem + 1) / 2;
         hipLaunchKernelGGL(ldlt_step_kernel, dim3(nwg), dim3(TPB), 0, ctx->stream, d, k);
     }
-    const size_t bw_bytes = (size_t)3 * d.npad * sizeof(double);
+    const size_t bw_bytes = (size_t)6 * d.npad * sizeof(double);
     hipLaunchKernelGGL(ldlt_backward_kernel, dim3(1), dim3(1024), bw_bytes, ctx->stream, d, cur);
     HIP_TRY(hipGetLastError());
     return PTAM_OK;

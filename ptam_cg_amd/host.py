@@ -459,6 +459,14 @@ class Bundle:
         self.ctx._check(self.lib.ba_bench_jacobian(self.h, reps, C.byref(ms), C.byref(by)), "ba_bench_jacobian")
         return ms.value, by.value
 
+    @staticmethod
+    def bench_jacobian_rotating(bundles, reps):
+        """K7 round-robin over copies of one problem (Infinity-Cache-cold launches) -> average ms per launch"""
+        arr = (C.c_void_p * len(bundles))(*[b.h for b in bundles])
+        ms = C.c_double()
+        bundles[0].ctx._check(bundles[0].lib.ba_bench_jacobian_rotating(arr, len(bundles), reps, C.byref(ms)), "ba_bench_jacobian_rotating")
+        return ms.value
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.ba_destroy(self.h)

@@ -49,7 +49,7 @@ def merge_outliers(local_outliers, global_point_ids, all_gather):
     """(local point, camera) pairs -> global ids, concatenated in rank order."""
     loc = np.asarray(local_outliers, dtype=np.int64).reshape(-1, 2)
     mine = np.column_stack([global_point_ids[loc[:, 0]], loc[:, 1]]) if len(loc) else np.zeros((0, 2), np.int64)
-    return np.concatenate(all_gather(mine)) if True else mine
+    return np.concatenate(all_gather(mine))
 
 
 def torch_allreduce_hook(ctx=None, device_ptr=False, group=None):

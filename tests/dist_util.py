@@ -21,7 +21,7 @@ def free_port():
     return p
 
 
-def run_sharded(which, world, case, timeout=300, extra_env=None):
+def run_sharded(which, world, case, timeout=300, extra_env=None, opts=None, drop=None, abort=None):
     """launch `world` worker processes (gloo on 127.0.0.1); returns rank 0's result dict"""
     out = tempfile.mktemp(suffix=".pkl")
     port = str(free_port())
@@ -29,6 +29,12 @@ def run_sharded(which, world, case, timeout=300, extra_env=None):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
                    PTAM_DIST_CASE=repr(case), OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if opts is not None:
+            env["PTAM_DIST_OPTS"] = repr(opts)
+        if drop is not None:
+            env["PTAM_DIST_DROP"] = repr(drop)
+        if abort is not None:
+            env["PTAM_DIST_ABORT"] = repr(abort)
         env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), which, out],
                                       env=env, cwd=ROOT))
@@ -45,11 +51,11 @@ def run_sharded(which, world, case, timeout=300, extra_env=None):
     return res
 
 
-def check_sharded_equals_single(sharded, single_lib, case, rel=1e-8):
+def check_sharded_equals_single(sharded, single_lib, case, rel=1e-8, **opts):
     """the N-shard run must reproduce the one-process run trial by trial (sums are re-associated
     across shards, hence a tolerance instead of bit equality)"""
     prob = synth.make_ba_problem(**case)
-    one = util.run_ba(single_lib, prob)
+    one = util.run_ba(single_lib, prob, **opts)
     ts, to = sharded["trials"], one["trials"]
     assert len(ts) == len(to), (len(ts), len(to))
     assert np.array_equal(ts["lambda"], to["lambda"]) and np.array_equal(ts["accepted"], to["accepted"])

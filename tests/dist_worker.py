@@ -25,13 +25,37 @@ def main():
         from ptam_cg_amd._lib import load
         lib = load()
     kw = eval(os.environ.get("PTAM_DIST_CASE", "dict(n_cams=10, n_pts=160, seed=5)"))
+    opts = eval(os.environ.get("PTAM_DIST_OPTS", "dict()"))                   # host.Bundle options (max_iterations ...)
+    drop = eval(os.environ.get("PTAM_DIST_DROP", "None"))                      # (point modulus, residue, first camera dropped)
+    abort_at = eval(os.environ.get("PTAM_DIST_ABORT", "None"))                 # (rank, all-reduce calls before the flag goes up)
     prob = synth.make_ba_problem(**kw)
+    if drop is not None:     # thin out some points' measurements: lets ONE shard break a per-point limit
+        mod, res, cam0 = drop
+        keep = ~((prob["pt_idx"] % mod == res) & (prob["cam_idx"] >= cam0))
+        for k in ("cam_idx", "pt_idx", "found", "sigma_sq"):
+            prob[k] = prob[k][keep]
     mine = shard_problem(prob, rank, world)
     ctx = host.Context(lib=lib)
-    ba = synth.load_into(host.Bundle(ctx), mine)
-    ba.set_comm(rank, world, torch_allreduce_hook(ctx, device_ptr=(which == "hip")))
+    ba = synth.load_into(host.Bundle(ctx, **opts), mine)
+    inner = torch_allreduce_hook(ctx, device_ptr=(which == "hip"))
+    abort = np.zeros(1, dtype=np.uint8)
+    calls = [0]
+    if abort_at is not None and abort_at[0] == rank:
+        from ptam_cg_amd import _abi
+        if abort_at[1] == 0:
+            abort[0] = 1
+
+        def counting(user, ptr, count, stream):   # the flag of THIS rank only goes up in the middle of the run
+            calls[0] += 1
+            if calls[0] >= abort_at[1]:
+                abort[0] = 1
+            return inner(user, ptr, count, stream)
+        hook = _abi.ALLREDUCE_FN(counting)
+    else:
+        hook = inner
+    ba.set_comm(rank, world, hook)
     try:
-        acc = ba.Compute()
+        acc = ba.Compute(abort)
     except host.PtamError as e:          # (every rank raises together: the refusal is decided by a collective)
         errs = [None] * world
         dist.all_gather_object(errs, str(e))
@@ -42,6 +66,8 @@ def main():
         dist.destroy_process_group()
         return
     poses, pts = ba.get_all()
+    n_trials_all = [None] * world
+    dist.all_gather_object(n_trials_all, (len(ba.trials()), acc))
 
     def all_gather(obj):
         out = [None] * world
@@ -54,7 +80,7 @@ def main():
     if rank == 0:
         with open(out_path, "wb") as f:
             pickle.dump(dict(accepted=acc, converged=ba.Converged(), trials=ba.trials(), poses=poses, points=full_pts,
-                             outliers=outl, poses_all=all_poses), f)
+                             outliers=outl, poses_all=all_poses, trials_accepted_all=n_trials_all), f)
     dist.barrier()
     dist.destroy_process_group()
 

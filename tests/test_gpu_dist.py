@@ -20,6 +20,37 @@ def test_sharded_hip_matches_single_process_oracle(oracle, world, case):
     dist_util.check_sharded_equals_single(res, oracle, case, rel=1e-6)
 
 
+def test_sharded_config5_shape_three_ranks(oracle):
+    """BASELINE.json configs[4] at more than half its size — 200 keyframes x 26 000 points, 16-camera covisibility window
+    (M ~ 0.42 M), camera system 1194 x 1194 with a 4-block band — sharded over three processes on the one GPU: the looping
+    K7 form, the banded LDL^T and the band-only exchange of S|E, trial by trial against the single-process oracle"""
+    case = dict(n_cams=200, n_pts=26000, seed=0x5EED0006, window=16)
+    res = dist_util.run_sharded("hip", 3, case, opts=dict(max_iterations=3), timeout=900)
+    dist_util.check_sharded_equals_single(res, oracle, case, rel=1e-6, max_iterations=3)
+    assert len(res["trials"]) == 3
+
+
+def test_abort_raised_on_one_rank_stops_every_rank_at_the_same_trial():
+    """the abort byte is rank-local, the trials are collective.  Rank 1 alone raises it (before Compute(), and
+    after its 12th all-reduce): every rank must leave the LM loops at the same trial, none may hang"""
+    case = dict(n_cams=10, n_pts=160, seed=5)
+    res = dist_util.run_sharded("hip", 2, case, abort=(1, 0), timeout=120)
+    assert res["trials_accepted_all"] == [(0, 0), (0, 0)]
+    res = dist_util.run_sharded("hip", 2, case, abort=(1, 12), timeout=120)
+    (n0, a0), (n1, a1) = res["trials_accepted_all"]
+    assert n0 == n1 and a0 == a1 and 0 < n0 < 20
+    for p in res["poses_all"]:
+        assert (p == res["poses"]).all()
+
+
+def test_prepare_error_on_one_rank_is_returned_by_every_rank():
+    """rank 0's shard holds points seen by 300 cameras (the limit is 256 per point), rank 1's shard is fine.
+    Rank 1 must not enter the first all-reduce alone: both return an error, rank 0 its own, rank 1 the collective one"""
+    res = dist_util.run_sharded("hip", 2, dict(n_cams=300, n_pts=6, seed=3), drop=(2, 1, 250), timeout=180)
+    assert "error" in res and len(res["error"]) == 2
+    assert "limit" in res["error"][0] and "could not prepare" in res["error"][1]
+
+
 def test_sharded_select_with_ties_and_slot_overflow(oracle):
     """every point replicated 24 times: bit-identical errors in runs of 24.  With 6-key exchange slots the
     last stage of the sharded select overflows, the host repeats the step on the gather-everything path,

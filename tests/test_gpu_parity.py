@@ -274,16 +274,21 @@ BA_BIG_CASES = {
     "headline_50x5000": dict(n_cams=50, n_pts=5000, seed=synth.SEED_BA_HEADLINE),                 # one chunk per wave
     "loop256_60x7000": dict(n_cams=60, n_pts=7000, seed=11),                                      # looping K7, 256 threads
     "loop512_200x26000_w16": dict(n_cams=200, n_pts=26000, seed=synth.SEED_BA_GLOBAL, window=16),   # LDS-bound: 512 threads
+    # BASELINE.json configs[4] at its full size on ONE device (M ~ 0.8 M, camera system 1194 x 1194, band 4 blocks);
+    # three trials: the oracle's dense 1194^3/3 factorisation and its C x P scans take seconds each
+    "config5_200x50000_w16": dict(n_cams=200, n_pts=50000, seed=synth.SEED_BA_GLOBAL, window=16),
 }
+BA_BIG_TRIALS = {"config5_200x50000_w16": 3}
 
 
 @pytest.mark.parametrize("case", list(BA_BIG_CASES))
 def test_bundle_full_size_trial_by_trial(hip, oracle, case):
     prob = synth.make_ba_problem(**BA_BIG_CASES[case])
-    rh = util.run_ba(hip, prob, max_iterations=4)
-    ro = util.run_ba(oracle, prob, max_iterations=4)
+    k = BA_BIG_TRIALS.get(case, 4)
+    rh = util.run_ba(hip, prob, max_iterations=k)
+    ro = util.run_ba(oracle, prob, max_iterations=k)
     util.assert_ba_equal(rh, ro, rel=1e-6)
-    assert len(rh["trials"]) == 4 and rh["accepted"] > 0
+    assert len(rh["trials"]) == k and rh["accepted"] > 0
     # size-independent properties: every accepted trial lowers the robust error, rejected ones do not move the state
     t = rh["trials"]
     assert all(x["err_new"] < x["err_old"] for x in t if x["accepted"])
