@@ -177,10 +177,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch   # before libptam_hip.so: one shared HIP runtime (see ptam_cg_amd/_lib.py)
     import torch.distributed as dist
+    # PTAM_BENCH_ONE_GPU=1 (development only): all ranks share device 0 and exchange through gloo with host staging, so that
+    # the N > 1 code path of this file can be exercised on a one-GPU box; its numbers mean nothing.
+    one_gpu = world > 1 and os.environ.get("PTAM_BENCH_ONE_GPU") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            local_rank = 0
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     from ptam_cg_amd import _abi, host, synth
     from ptam_cg_amd.sharding import shard_problem
     from ptam_cg_amd._lib import load
@@ -207,7 +214,10 @@ def main():
     prob = shard_problem(prob_full, rank, world)
 
     comm = hook = None
-    if world > 1:
+    if one_gpu:
+        from ptam_cg_amd.sharding import torch_allreduce_hook
+        hook, comm = torch_allreduce_hook(ctx, device_ptr=True), ctypes.c_void_p()
+    elif world > 1:
         ident = (ctypes.c_uint8 * 128)()
         if rank == 0:
             ctx._check(hip.rccl_unique_id(ident), "rccl_unique_id")
@@ -289,7 +299,7 @@ def main():
 
     dt, trials, (n_cams, n_free, n_points, n_meas), spin = timed_compute(prob, args.steps, args.warmup)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -394,7 +404,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
-        if comm is not None:
+        if comm is not None and not one_gpu:
             hip.rccl_destroy(comm)
         dist.barrier()
         dist.destroy_process_group()
