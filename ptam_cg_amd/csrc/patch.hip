@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "keyframe.h"
+#include "track_internal.h"
 
 // fp64 primitives that are never contracted into FMAs (hipcc's __dmul_rn / __dadd_rn / __dsub_rn are plain operators
 // under -ffp-contract=fast and WOULD be fused): each rounds on its own, like the reference's x86-64 build
@@ -51,11 +52,17 @@ __device__ __forceinline__ int wave_zmssd(const uint8_t* __restrict__ im, int w,
     return zmssd_finish(tsum, isum, isumsq, tsumsq, cross);
 }
 
+// d_range (nullable): {first, end} query indices in device memory — the resident TrackMap chain decides on the device
+// which slots a stage searches
 __global__ void __launch_bounds__(256) zmssd_search_kernel(KfLevels L, int n, const ptam_patch_query* __restrict__ queries,
                                                            const uint8_t* __restrict__ templates,
-                                                           ptam_patch_result* __restrict__ results) {
+                                                           ptam_patch_result* __restrict__ results, const int* __restrict__ d_range) {
     const int lane = threadIdx.x & 63;
-    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (d_range) {
+        qi += d_range[0];
+        n = min(n, d_range[1]);
+    }
     if (qi >= n) return;
     const ptam_patch_query q = queries[qi];
     ptam_patch_result res;
@@ -186,13 +193,29 @@ __device__ __forceinline__ void ldlt3_inverse(double A[9], double out[9]) {   //
     }
 }
 
+// Chain form (pq / pr given, queries == null): the query is the coarse search's own — level of pq[qi], position pr[qi].pos,
+// only where pr[qi].found (src/Tracker.cc:897-905) — with chain_its iterations; d_range as in zmssd_search_kernel.
 __global__ void __launch_bounds__(256) subpix_kernel(KfLevels L, int n, const ptam_subpix_query* __restrict__ queries,
                                                      const uint8_t* __restrict__ templates,
-                                                     ptam_subpix_result* __restrict__ results) {
+                                                     ptam_subpix_result* __restrict__ results, const int* __restrict__ d_range,
+                                                     const ptam_patch_query* __restrict__ pq, const ptam_patch_result* __restrict__ pr,
+                                                     int chain_its) {
     const int lane = threadIdx.x & 63;
-    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (d_range) {
+        qi += d_range[0];
+        n = min(n, d_range[1]);
+    }
     if (qi >= n) return;
-    const ptam_subpix_query q = queries[qi];
+    ptam_subpix_query q;
+    if (pq) {
+        const bool go = pq[qi].level >= 0 && pr[qi].found;
+        q.level = go ? pq[qi].level : -1;
+        q.max_its = chain_its;
+        q.coarse_pos[0] = pr[qi].pos[0];
+        q.coarse_pos[1] = pr[qi].pos[1];
+    } else
+        q = queries[qi];
     ptam_subpix_result res;
     res.converged = 0;
     res.iterations = 0;
@@ -266,21 +289,20 @@ __global__ void __launch_bounds__(256) subpix_kernel(KfLevels L, int n, const pt
 // =================================================================================================
 // MakeTemplateCoarseCont (src/PatchFinder.cc:98-127): CVD::transform of the source patch + template sums
 // =================================================================================================
-struct TemplateJob {          // device-side form of ptam_template_query (keyframe handle resolved to its level image)
-    const uint8_t* im;
-    int w, h;
-    int search_level;
-    int cx, cy;
-    double wi[4];
-};
+// (TemplateJob, the device-side form of ptam_template_query, lives in track_internal.h)
 
 // One wave per template, lane = output pixel (i = lane / 8 row, j = lane % 8 column).  The source position is
 // NOT evaluated in closed form: the reference walks p += across / += carriage_return pixel by pixel, and the
 // lane replays that exact sequence of fp64 additions (<= 70 of them) so the sampled positions are bit-identical.
 // Every product and sum goes through the nc_* primitives below: no FMA contraction.
 __global__ void __launch_bounds__(256) make_templates_kernel(int n, const TemplateJob* __restrict__ jobs, uint8_t* __restrict__ tmpl,
-                                                             ptam_template_result* __restrict__ res) {
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+                                                             ptam_template_result* __restrict__ res, const int* __restrict__ d_range) {
+    int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (d_range) {
+        q += d_range[0];
+        n = min(n, d_range[1]);
+    }
     if (q >= n) return;
     const TemplateJob jb = jobs[q];
     ptam_template_result r;
@@ -440,6 +462,30 @@ __global__ void __launch_bounds__(256) epipolar_search_kernel(KfLevels S, KfLeve
     if (lane == 0) results[qi] = res;
 }
 
+// ---- launch helpers of the resident TrackMap chain (track_internal.h) ------------------------------------------
+int patch_launch_templates_dev(ptam_ctx* ctx, int n_cap, const TemplateJob* d_jobs, uint8_t* d_tmpl, ptam_template_result* d_res,
+                               const int* d_range) {
+    if (n_cap <= 0) return PTAM_OK;
+    hipLaunchKernelGGL(make_templates_kernel, dim3((n_cap + 3) / 4), dim3(256), 0, ctx->stream, n_cap, d_jobs, d_tmpl, d_res, d_range);
+    HIP_TRY(hipGetLastError());
+    return PTAM_OK;
+}
+int patch_launch_search_dev(ptam_ctx* ctx, const ptam_kf* kf, int n_cap, const ptam_patch_query* d_q, const uint8_t* d_tmpl,
+                            ptam_patch_result* d_r, const int* d_range) {
+    if (n_cap <= 0) return PTAM_OK;
+    hipLaunchKernelGGL(zmssd_search_kernel, dim3((n_cap + 3) / 4), dim3(256), 0, ctx->stream, kf->L, n_cap, d_q, d_tmpl, d_r, d_range);
+    HIP_TRY(hipGetLastError());
+    return PTAM_OK;
+}
+int patch_launch_subpix_dev(ptam_ctx* ctx, const ptam_kf* kf, int n_cap, const ptam_patch_query* d_q, const ptam_patch_result* d_pr,
+                            const uint8_t* d_tmpl, ptam_subpix_result* d_sr, const int* d_range, int max_its) {
+    if (n_cap <= 0) return PTAM_OK;
+    hipLaunchKernelGGL(subpix_kernel, dim3((n_cap + 3) / 4), dim3(256), 0, ctx->stream, kf->L, n_cap, (const ptam_subpix_query*)nullptr,
+                       d_tmpl, d_sr, d_range, d_q, d_pr, max_its);
+    HIP_TRY(hipGetLastError());
+    return PTAM_OK;
+}
+
 extern "C" {
 
 int ptam_subpix_batch(ptam_ctx* ctx, const ptam_kf* kf, int n, const ptam_subpix_query* queries, const uint8_t* templates,
@@ -457,7 +503,8 @@ int ptam_subpix_batch(ptam_ctx* ctx, const ptam_kf* kf, int n, const ptam_subpix
     uint8_t* d_t = (uint8_t*)s + bq + br;
     HIP_TRY(hipMemcpyAsync(d_q, queries, bq, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(d_t, templates, bt, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(subpix_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, kf->L, n, d_q, d_t, d_r);
+    hipLaunchKernelGGL(subpix_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, kf->L, n, (const ptam_subpix_query*)d_q, (const uint8_t*)d_t, d_r,
+                       (const int*)nullptr, (const ptam_patch_query*)nullptr, (const ptam_patch_result*)nullptr, 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(results, d_r, br, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ptam_stream_wait(ctx->stream));
@@ -470,7 +517,7 @@ int ptam_find_patch_coarse_batch_dev(ptam_ctx* ctx, const ptam_kf* kf, int n, co
     if (n == 0) return PTAM_OK;
     ARG_TRY(d_q && d_t && d_r);
     HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(zmssd_search_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, kf->L, n, d_q, d_t, d_r);
+    hipLaunchKernelGGL(zmssd_search_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, kf->L, n, d_q, d_t, d_r, (const int*)nullptr);
     HIP_TRY(hipGetLastError());
     return PTAM_OK;
 }
@@ -551,7 +598,7 @@ int ptam_make_templates_batch(ptam_ctx* ctx, int n, const ptam_template_query* q
     ptam_template_result* d_r = (ptam_template_result*)((char*)s + bj);
     uint8_t* d_t = (uint8_t*)s + bj + br;
     HIP_TRY(hipMemcpyAsync(d_j, jobs.data(), bj, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(make_templates_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, n, (const TemplateJob*)d_j, d_t, d_r);
+    hipLaunchKernelGGL(make_templates_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, n, (const TemplateJob*)d_j, d_t, d_r, (const int*)nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(templates_out, d_t, bt, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(results, d_r, br, hipMemcpyDeviceToHost, ctx->stream));

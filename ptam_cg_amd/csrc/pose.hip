@@ -10,6 +10,7 @@
 #include <atomic>
 
 #include "common.h"
+#include "track_internal.h"
 
 struct PoseState {
     double cam[3];
@@ -272,9 +273,11 @@ __global__ void __launch_bounds__(GN_THREADS) pose_gn_kernel(DevCam cam, int n, 
                                                              const ptam_projection* __restrict__ entry,
                                                              double* __restrict__ pose_io, ptam_gn_opts opts,
                                                              PoseState* __restrict__ st, int* __restrict__ flags,
-                                                             double* __restrict__ updates, const int* __restrict__ n_dev, PoseIn pin) {
+                                                             double* __restrict__ updates, const int* __restrict__ n_dev, PoseIn pin,
+                                                             PoseChainIo io, int size_guard) {
     __shared__ GnShared sh;
     const int tid = threadIdx.x;
+    if (size_guard == 2 && *n_dev <= GS_LIMIT) return;   // the resident chain enqueues both kernels: the list length picks one
     if (n_dev) n = min(n, max(*n_dev, 0));   // counted variant: the measurement list was compacted on the device
     if (tid < 12) sh.pose[tid] = pin.use ? pin.v[tid] : pose_io[tid];
     __syncthreads();
@@ -352,6 +355,43 @@ __global__ void __launch_bounds__(GN_THREADS) pose_gn_kernel(DevCam cam, int n, 
         __syncthreads();
     }
     if (tid < 12) pose_io[tid] = sh.pose[tid];
+    // resident chain: the measurements' TrackerData state goes back to the per-point table, scene depth sums
+    if (io.td_base)
+        for (int i = tid; i < n; i += GN_THREADS) {
+            ptam_projection* o = (ptam_projection*)((char*)io.td_base + (size_t)io.td_index[i] * io.td_stride);
+#pragma unroll
+            for (int k = 0; k < 3; k++) o->cam[k] = st[i].cam[k];
+            o->image[0] = st[i].img[0];
+            o->image[1] = st[i].img[1];
+#pragma unroll
+            for (int k = 0; k < 4; k++) o->derivs[k] = st[i].D[k];
+        }
+    if (io.depth_out) {
+        double z1 = 0, z2 = 0;
+        for (int i = tid; i < n; i += GN_THREADS) {
+            const double z = st[i].cam[2];
+            z1 += z;
+            z2 += z * z;
+        }
+        z1 = wave_sum_f64(z1);
+        z2 = wave_sum_f64(z2);
+        __syncthreads();
+        if ((tid & 63) == 0) {
+            sh.red[tid >> 6][0] = z1;
+            sh.red[tid >> 6][1] = z2;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double a = 0, b = 0;
+            for (int w = 0; w < GN_WAVES; w++) {
+                a += sh.red[w][0];
+                b += sh.red[w][1];
+            }
+            io.depth_out[0] = a;
+            io.depth_out[1] = b;
+            io.depth_out[2] = (double)n;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -557,9 +597,10 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
                                                                    double* __restrict__ pose_io, ptam_gn_opts opts,
                                                                    int* __restrict__ flags, double* __restrict__ updates,
                                                                    ulonglong2* __restrict__ host_slots, unsigned long long seq,
-                                                                   const int* __restrict__ n_dev, PoseIn pin) {
+                                                                   const int* __restrict__ n_dev, PoseIn pin, PoseChainIo io, int size_guard) {
     __shared__ GnSmallShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (size_guard == 1 && *n_dev > GS_LIMIT) return;   // (the general kernel, enqueued behind this one, takes the long list)
     if (n_dev) n = min(n, max(*n_dev, 0));   // counted variant: the measurement list was compacted on the device
     if (tid < 12) sh.pose[tid] = pin.use ? pin.v[tid] : pose_io[tid];
     if (tid < 6) sh.mu[tid] = 0;
@@ -772,6 +813,49 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
         for (int i = 0; i < 6; i++) updates[6 * 20 + i] = (double)ph[i];
 #endif
     if (tid < 12) pose_io[tid] = sh.pose[tid];
+    // resident chain: the measurements' TrackerData state goes back to the per-point table, scene depth sums
+    if (io.td_base) {
+#pragma unroll
+        for (int q = 0; q < GS_MPT; q++) {
+            const int i = tid + q * GS_THREADS;
+            if (i < n) {
+                ptam_projection* o = (ptam_projection*)((char*)io.td_base + (size_t)io.td_index[i] * io.td_stride);
+#pragma unroll
+                for (int k = 0; k < 3; k++) o->cam[k] = t[q].cam3[k];
+                o->image[0] = t[q].img[0];
+                o->image[1] = t[q].img[1];
+#pragma unroll
+                for (int k = 0; k < 4; k++) o->derivs[k] = t[q].D[k];
+            }
+        }
+    }
+    if (io.depth_out) {
+        double z1 = 0, z2 = 0;
+#pragma unroll
+        for (int q = 0; q < GS_MPT; q++) {
+            const double z = (tid + q * GS_THREADS < n) ? t[q].cam3[2] : 0.0;
+            z1 += z;
+            z2 += z * z;
+        }
+        z1 = wave_sum_f64(z1);
+        z2 = wave_sum_f64(z2);
+        __syncthreads();
+        if (lane == 0) {
+            sh.red[wid][0] = z1;
+            sh.red[wid][1] = z2;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double a = 0, b = 0;
+            for (int w = 0; w < GS_WAVES; w++) {
+                a += sh.red[w][0];
+                b += sh.red[w][1];
+            }
+            io.depth_out[0] = a;
+            io.depth_out[1] = b;
+            io.depth_out[2] = (double)n;
+        }
+    }
     // the refined pose also goes straight into host-mapped memory as (word, sequence) pairs the host spins on: the call
     // returns one PCIe write after the last iteration instead of a D2H copy plus a stream synchronisation later
     if (host_slots && tid < 12) host_slots[tid] = make_ulonglong2((unsigned long long)__double_as_longlong(sh.pose[tid]), seq);

@@ -4,6 +4,7 @@
 // step into the current view.  One thread per map point; the per-level PVS sizes (avPVS[l].size())
 // are counted with one atomic per wave and level.  
 #include "common.h"
+#include "track_internal.h"
 
 __global__ void __launch_bounds__(256) track_pvs_kernel(DevCam cam, int n, const ptam_pvs_point* __restrict__ pts,
                                                         const double* __restrict__ pose, ptam_pvs_result* __restrict__ out,
@@ -72,6 +73,13 @@ __global__ void __launch_bounds__(256) track_pvs_kernel(DevCam cam, int n, const
             if (lane == 0 && m) atomicAdd(&counts[l], __popcll(m));
         }
     }
+}
+
+int pvs_launch_dev(ptam_ctx* ctx, int n, const ptam_pvs_point* d_pts, const double* d_pose, ptam_pvs_result* d_out) {
+    if (n <= 0) return PTAM_OK;
+    hipLaunchKernelGGL(track_pvs_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->cam, n, d_pts, d_pose, d_out, (int*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return PTAM_OK;
 }
 
 extern "C" int ptam_track_pvs(ptam_ctx* ctx, int n, const ptam_pvs_point* points, const double pose[12],

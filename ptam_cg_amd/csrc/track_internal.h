@@ -1,0 +1,39 @@
+// track_internal.h — launch helpers the resident TrackMap chain (trackmap.hip) uses from the other translation units.
+// Every helper only enqueues on the context's stream; slot ranges and counts live in DEVICE memory (d_range = {begin, end},
+// d_n), because which patches are searched and how many are found is decided on the device (no host round trip inside a
+// tracked frame).
+#pragma once
+#include "common.h"
+#include "keyframe.h"
+
+struct TemplateJob {          // device-side form of ptam_template_query (keyframe handle resolved to its level image)
+    const uint8_t* im;
+    int w, h;
+    int search_level;
+    int cx, cy;
+    double wi[4];
+};
+
+// patch.hip
+int patch_launch_templates_dev(ptam_ctx* ctx, int n_cap, const TemplateJob* d_jobs, uint8_t* d_tmpl, ptam_template_result* d_res,
+                               const int* d_range);
+int patch_launch_search_dev(ptam_ctx* ctx, const ptam_kf* kf, int n_cap, const ptam_patch_query* d_q, const uint8_t* d_tmpl,
+                            ptam_patch_result* d_r, const int* d_range);
+// sub-pixel refinement of the patches the coarse search found (queries taken from the search's own queries / results)
+int patch_launch_subpix_dev(ptam_ctx* ctx, const ptam_kf* kf, int n_cap, const ptam_patch_query* d_q, const ptam_patch_result* d_pr,
+                            const uint8_t* d_tmpl, ptam_subpix_result* d_sr, const int* d_range, int max_its);
+// pvs.hip
+int pvs_launch_dev(ptam_ctx* ctx, int n, const ptam_pvs_point* d_pts, const double* d_pose, ptam_pvs_result* d_out);
+
+// pose.hip: the ten-iteration loop on a measurement list whose length sits in device memory, with the extras of the chain
+struct PoseChainIo {
+    // TrackerData state of the measurements when the loop ends (v3Cam, v2Image, m2CamDerivs as left by the last
+    // ProjectAndDerivs / LinearUpdate), scattered to td_base + td_index[i] * td_stride bytes (ptam_projection each); null: no
+    void* td_base;
+    const int* td_index;
+    int td_stride;
+    // scene depth statistics over the measurements (src/Tracker.cc:680-690): {sum z, sum z^2, count}; null: no
+    double* depth_out;
+};
+int pose_launch_chain(ptam_ctx* ctx, int n_cap, const int* d_n, const ptam_pose_meas* d_meas, const ptam_projection* d_entry,
+                      double* d_pose_inout, const ptam_gn_opts* opts, int32_t* d_outlier_flags, const PoseChainIo& io);
