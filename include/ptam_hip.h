@@ -224,6 +224,12 @@ typedef struct {
 int ptam_project_points(ptam_ctx* ctx, int n, const double* world_xyz, const double pose[12],
                         ptam_projection* out);
 
+/* TrackerData::Project (include/Tracker.h:70-85) on EXISTING TrackerData, as TrackMap re-projects the points it is about to
+ * search after the coarse pose update (src/Tracker.cc:573-574, :606-608): cam always, image once the camera model is reached
+ * (a point that bails out earlier keeps its previous v2Image), derivs untouched (ProjectAndDerivs refreshes them only for
+ * found points, include/Tracker.h:89-94), in_image = bInImage. */
+int ptam_reproject_points(ptam_ctx* ctx, int n, const double* world_xyz, const double pose[12], ptam_projection* inout);
+
 /* ---- Tracker::TrackMap potentially-visible-set loop (src/Tracker.cc:453-478) with
  *      PatchFinder::CalcSearchLevelAndWarpMatrix (src/PatchFinder.cc:52-84)   */
 typedef struct {
@@ -271,6 +277,13 @@ int ptam_pose_gn(ptam_ctx* ctx, int n, const ptam_pose_meas* meas, const ptam_pr
                  double pose_inout[12], const ptam_gn_opts* opts,
                  int32_t* outlier_flags, double* updates_out);
 
+/* The same, also returning the measurements' TrackerData state when the loop ends (cam = v3Cam, image = v2Image, derivs =
+ * m2CamDerivs as the last ProjectAndDerivs / LinearUpdate left them; in_image unspecified): what a FOLLOWING loop starts
+ * from, because its iteration 0 does not re-project (src/Tracker.cc:617) — the coarse loop's points in the fine loop. */
+int ptam_pose_gn_state(ptam_ctx* ctx, int n, const ptam_pose_meas* meas, const ptam_projection* entry,
+                       double pose_inout[12], const ptam_gn_opts* opts, int32_t* outlier_flags, double* updates_out,
+                       ptam_projection* state_out);
+
 /* device-resident variant: every pointer is a device pointer (d_entry, d_outlier_flags, d_updates nullable; d_updates
  * holds 32*6 doubles), asynchronous on the context's stream — the measurements of a tracked frame are produced on
  * the device (patch search / sub-pixel results), so the frame needs no upload and only the 96-byte pose comes back.
@@ -300,6 +313,61 @@ int ptam_pose_gn_dev_counted(ptam_ctx* ctx, int n_cap, const int32_t* d_n, const
 int ptam_gather_pose_meas_dev(ptam_ctx* ctx, int n, const ptam_patch_query* d_queries, const ptam_patch_result* d_results,
                               const ptam_subpix_result* d_subpix, const void* d_world, int world_stride_bytes,
                               ptam_pose_meas* d_meas_out, int32_t* d_src_index, int32_t* d_count, int32_t* d_level_found);
+
+/* ---- Tracker::TrackMap (src/Tracker.cc:442-696) as ONE device-resident chain ------------------------------------------
+ *      PVS loop -> choice of the coarse / top-level / fine search sets -> coarse SearchForPoints (range 30, sub-pixel) ->
+ *      ten coarse pose iterations -> re-projection + SearchForPoints of the other sets -> ten fine pose iterations ->
+ *      measurement and scene-depth bookkeeping.  List lengths, the mbDidCoarse decision and the fine search range are taken
+ *      on the device; the call enqueues everything at once and returns when the result block has arrived (host-mapped
+ *      memory, no copy).  The map (world positions, pixel vectors, patch sources) stays resident between frames. */
+typedef struct ptam_tracker ptam_tracker;
+typedef struct {
+    int32_t try_coarse;         /* bTryCoarse after the caller's heuristics (src/Tracker.cc:505-516: DisableCoarse, velocity,
+                                   just-recovered — then the caller also doubles coarse_max / coarse_range) */
+    uint32_t coarse_min;        /* Tracker.CoarseMin 20        :492 */
+    uint32_t coarse_max;        /* Tracker.CoarseMax 60        :493 */
+    uint32_t coarse_range;      /* Tracker.CoarseRange 30      :494 */
+    int32_t coarse_subpix_its;  /* Tracker.CoarseSubPixIts 8   :495 */
+    int32_t max_patches;        /* Tracker.MaxPatchesPerFrame 1000  :593 */
+    int32_t estimator;          /* Tracker.MEstimator */
+    int32_t pad_;
+} ptam_trackmap_opts;
+void ptam_trackmap_opts_default(ptam_trackmap_opts* o);
+typedef struct {
+    double pose[12];            /* mse3CamFromWorld after the fine stage */
+    int32_t did_coarse;         /* mbDidCoarse */
+    int32_t n_pvs[4];           /* avPVS[l].size() after the PVS loop */
+    int32_t attempted[4];       /* manMeasAttempted */
+    int32_t found[4];           /* manMeasFound */
+    int32_t n_coarse, n_top, n_fine;   /* sizes of the coarse set, of the remaining top-level set and of the fine set */
+    int32_t n_meas;             /* found entries of vIterationSet = measurements of the fine pose loop */
+    int32_t depth_n;            /* number of found points in the two sums below */
+    double depth_sum, depth_sum_sq;   /* sums of v3Cam[2] and its square over the found points (:680-690) */
+} ptam_trackmap_result;
+/* one entry of vIterationSet, in its order (coarse set, top-level set, fine set) */
+typedef struct {
+    int32_t point;              /* map point index */
+    int32_t level;              /* nSearchLevel (-1: bad template, not searched) */
+    int32_t found;              /* bFound */
+    int32_t did_subpix;         /* bDidSubPix */
+    int32_t outlier;            /* Weight() == 0 on the fine loop's last iteration (:640, CalcPoseUpdate bMarkOutliers) */
+    int32_t pad_;
+    double v2_found[2];         /* v2Found, level-0 pixels (valid iff found) */
+} ptam_trackmap_meas;
+int ptam_tracker_create(ptam_ctx* ctx, int max_points, ptam_tracker** out);
+int ptam_tracker_destroy(ptam_tracker* t);
+/* the map: world position + pixel vectors per point, and its patch source (src_kf, src_level, center_x / center_y of
+ * ptam_template_query; the other fields are ignored).  The source keyframes must stay alive while the tracker uses them. */
+int ptam_tracker_set_map(ptam_tracker* t, int n, const ptam_pvs_point* points, const ptam_template_query* sources);
+/* The frame's random orders, each a permutation of 0..n-1 (asynchronous upload): level l's PVS list is taken in the order
+ * its members appear in shuffle_levels (replaces std::random_shuffle of avPVS[l], :483-484), the chop of the fine set to
+ * MaxPatchesPerFrame in the order of shuffle_fine (:597-600).  Identity until set. */
+int ptam_tracker_set_shuffle(ptam_tracker* t, const int32_t* shuffle_levels, const int32_t* shuffle_fine);
+int ptam_track_map(ptam_tracker* t, const ptam_kf* current, const double pose_in[12], const ptam_trackmap_opts* opts,
+                   ptam_trackmap_result* out);
+/* vIterationSet of the last frame (what :667-676 turns into mCurrentKF.mMeasurements): *n = its length; out (nullable)
+ * receives up to cap entries. */
+int ptam_tracker_read_iteration_set(ptam_tracker* t, ptam_trackmap_meas* out, int cap, int* n);
 
 /* One Tracker::CalcPoseUpdate (src/Tracker.cc:928-1005) on caller-provided Jacobians. */
 typedef struct {

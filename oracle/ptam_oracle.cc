@@ -1598,8 +1598,9 @@ void ptamo_gn_opts_default(ptam_gn_opts* o) {
 }
 
 // src/Tracker.cc:613-643 (fine stage) / :552-568 (coarse stage) driven by opts
-int ptamo_pose_gn(ptamo_ctx* c, int n, const ptam_pose_meas* meas, const ptam_projection* entry,
-                  double pose[12], const ptam_gn_opts* opts, int32_t* outlier_flags, double* updates_out) {
+static int pose_gn_impl(ptamo_ctx* c, int n, const ptam_pose_meas* meas, const ptam_projection* entry,
+                        double pose[12], const ptam_gn_opts* opts, int32_t* outlier_flags, double* updates_out,
+                        ptam_projection* state_out) {
     ATANCamera cam(c->c.cam);
     SE3 T = se3_from12(pose);
     std::vector<TrackerData> vTD(n);
@@ -1654,6 +1655,40 @@ int ptamo_pose_gn(ptamo_ctx* c, int n, const ptam_pose_meas* meas, const ptam_pr
         if (updates_out) std::memcpy(updates_out + 6 * iter, mu, sizeof mu);
     }
     se3_to12(T, pose);
+    if (state_out)   // the TrackerData a following loop starts from (its iteration 0 does not re-project, src/Tracker.cc:617)
+        for (int i = 0; i < n; i++) {
+            std::memset(&state_out[i], 0, sizeof state_out[i]);
+            std::memcpy(state_out[i].cam, vTD[i].v3Cam, sizeof vTD[i].v3Cam);
+            std::memcpy(state_out[i].image, vTD[i].v2Image, sizeof vTD[i].v2Image);
+            std::memcpy(state_out[i].derivs, vTD[i].m2CamDerivs, sizeof vTD[i].m2CamDerivs);
+        }
+    return PTAM_OK;
+}
+int ptamo_pose_gn(ptamo_ctx* c, int n, const ptam_pose_meas* meas, const ptam_projection* entry,
+                  double pose[12], const ptam_gn_opts* opts, int32_t* outlier_flags, double* updates_out) {
+    return pose_gn_impl(c, n, meas, entry, pose, opts, outlier_flags, updates_out, nullptr);
+}
+int ptamo_pose_gn_state(ptamo_ctx* c, int n, const ptam_pose_meas* meas, const ptam_projection* entry,
+                        double pose[12], const ptam_gn_opts* opts, int32_t* outlier_flags, double* updates_out,
+                        ptam_projection* state_out) {
+    return pose_gn_impl(c, n, meas, entry, pose, opts, outlier_flags, updates_out, state_out);
+}
+
+// TrackerData::Project (include/Tracker.h:70-85) on EXISTING TrackerData: v3Cam always, v2Image only when the camera model
+// is reached, m2CamDerivs never (ProjectAndDerivs refreshes them only if bFound, :89-94 — false for every point TrackMap
+// re-projects before a search, src/Tracker.cc:470,573,607)
+int ptamo_reproject_points(ptamo_ctx* c, int n, const double* world, const double pose[12], ptam_projection* inout) {
+    ATANCamera cam(c->c.cam);
+    const SE3 T = se3_from12(pose);
+    for (int i = 0; i < n; i++) {
+        TrackerData td;
+        std::memcpy(td.world, world + 3 * i, sizeof td.world);
+        std::memcpy(td.v2Image, inout[i].image, sizeof td.v2Image);
+        td.Project(T, cam);
+        std::memcpy(inout[i].cam, td.v3Cam, sizeof td.v3Cam);
+        std::memcpy(inout[i].image, td.v2Image, sizeof td.v2Image);
+        inout[i].in_image = td.bInImage;
+    }
     return PTAM_OK;
 }
 

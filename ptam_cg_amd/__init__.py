@@ -4,4 +4,4 @@ Product = ptam_cg_amd/csrc (HIP kernels + C ABI of include/ptam_hip.h, built as 
 this package is the thin host-side mirror of the reference's class surface used by tests and bench.
 """
 from . import _abi  # noqa: F401
-from .host import (Bundle, Context, KeyFrame, PatchFinder, PtamError, DEFAULT_CAMERA)  # noqa: F401
+from .host import (Bundle, Context, KeyFrame, PatchFinder, PtamError, Tracker, DEFAULT_CAMERA)  # noqa: F401

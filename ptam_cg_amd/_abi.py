@@ -162,6 +162,15 @@ PROTOTYPES = {
     "ba_kernel_time": (_i, [_vp, _i, _pd, C.POINTER(_i)]),
     "ba_prepare": (_i, [_vp]),
     "ba_bench_jacobian": (_i, [_vp, _i, _pd, _pd]),
+    "reproject_points": (_i, [_vp, _i, _vp, _pd, _vp]),
+    "pose_gn_state": (_i, [_vp, _i, _vp, _vp, _pd, _vp, _vp, _vp, _vp]),
+    "trackmap_opts_default": (None, [_vp]),
+    "tracker_create": (_i, [_vp, _i, _ppv]),
+    "tracker_destroy": (_i, [_vp]),
+    "tracker_set_map": (_i, [_vp, _i, _vp, _vp]),
+    "tracker_set_shuffle": (_i, [_vp, _vp, _vp]),
+    "track_map": (_i, [_vp, _vp, _pd, _vp, _vp]),
+    "tracker_read_iteration_set": (_i, [_vp, _vp, _i, C.POINTER(_i)]),
     "ba_bench_jacobian_rotating": (_i, [_vp, _i, _i, _pd]),
     "ba_set_comm": (_i, [_vp, _i, _i, ALLREDUCE_FN, _vp]),
     "rccl_unique_id": (_i, [_vp]),

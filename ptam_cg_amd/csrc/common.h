@@ -79,6 +79,7 @@ void pose_preload_kernels();
 void patch_preload_kernels();
 void kf_preload_kernels();
 void pvs_preload_kernels();
+void trackmap_preload_kernels();
 int ctx_scratch(ptam_ctx* ctx, size_t bytes, void** out);     // device scratch >= bytes
 int ctx_pinned(ptam_ctx* ctx, size_t bytes, void** out);      // pinned host staging >= bytes
 

@@ -165,6 +165,31 @@ __global__ void project_points_kernel(DevCam cam, int n, const double* __restric
     out[i] = p;
 }
 
+// TrackerData::Project on existing state (include/Tracker.h:70-85): v3Cam always, v2Image once the camera model is reached,
+// m2CamDerivs untouched (ProjectAndDerivs only refreshes them for found points, :89-94)
+__global__ void reproject_points_kernel(DevCam cam, int n, const double* __restrict__ world, const double* __restrict__ pose,
+                                        ptam_projection* __restrict__ io) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = pose[k];
+    ptam_projection p = io[i];
+    p.in_image = 0;
+    se3_apply(T, world[3 * i], world[3 * i + 1], world[3 * i + 2], p.cam[0], p.cam[1], p.cam[2]);
+    if (!(p.cam[2] < 0.001)) {
+        const double x = p.cam[0] / p.cam[2], y = p.cam[1] / p.cam[2];
+        if (!(x * x + y * y > cam.largest_radius * cam.largest_radius)) {
+            double u, v, r, f;
+            cam_project(cam, x, y, u, v, r, f);
+            p.image[0] = u;
+            p.image[1] = v;
+            if (!(r > cam.max_r) && !(u < 0 || v < 0 || u > cam.width || v > cam.height)) p.in_image = 1;
+        }
+    }
+    io[i] = p;
+}
+
 extern "C" {
 
 const char* ptam_last_error(void) { return g_err; }
@@ -198,6 +223,8 @@ int ptam_ctx_create(const ptam_cam_params* cam, int device, ptam_ctx** out) {
         return PTAM_E_HIP;
     }
     ptam_preload((const void*)project_points_kernel);
+    ptam_preload((const void*)reproject_points_kernel);
+    trackmap_preload_kernels();
     ba_preload_kernels();
     solve_preload_kernels();
     pose_preload_kernels();
@@ -303,6 +330,27 @@ int ptam_project_points(ptam_ctx* ctx, int n, const double* world_xyz, const dou
                        d_world, d_pose, d_out);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, d_out, ob, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ptam_stream_wait(ctx->stream));
+    return PTAM_OK;
+}
+
+int ptam_reproject_points(ptam_ctx* ctx, int n, const double* world_xyz, const double pose[12], ptam_projection* inout) {
+    ARG_TRY(ctx && n >= 0 && pose && (n == 0 || (world_xyz && inout)));
+    if (n == 0) return PTAM_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t wb = (size_t)n * 24, ob = (size_t)n * sizeof(ptam_projection);
+    void* scratch;
+    int rc = ctx_scratch(ctx, wb + 128 + ob, &scratch);
+    if (rc) return rc;
+    double* d_world = (double*)scratch;
+    double* d_pose = (double*)((char*)scratch + wb);
+    ptam_projection* d_io = (ptam_projection*)((char*)scratch + wb + 128);
+    HIP_TRY(hipMemcpyAsync(d_world, world_xyz, wb, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_pose, pose, 96, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_io, inout, ob, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(reproject_points_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->cam, n, d_world, d_pose, d_io);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(inout, d_io, ob, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ptam_stream_wait(ctx->stream));
     return PTAM_OK;
 }

@@ -24,6 +24,7 @@ struct PoseState {
 };
 
 #define GN_THREADS 1024
+#define GS_LIMIT 1024   // measurements the register-resident kernel (pose_gn_small_kernel) holds
 #define GN_WAVES (GN_THREADS / 64)
 
 struct GnShared {
@@ -358,7 +359,7 @@ __global__ void __launch_bounds__(GN_THREADS) pose_gn_kernel(DevCam cam, int n, 
     // resident chain: the measurements' TrackerData state goes back to the per-point table, scene depth sums
     if (io.td_base)
         for (int i = tid; i < n; i += GN_THREADS) {
-            ptam_projection* o = (ptam_projection*)((char*)io.td_base + (size_t)io.td_index[i] * io.td_stride);
+            ptam_projection* o = (ptam_projection*)((char*)io.td_base + (size_t)(io.td_index ? io.td_index[i] : i) * io.td_stride);
 #pragma unroll
             for (int k = 0; k < 3; k++) o->cam[k] = st[i].cam[k];
             o->image[0] = st[i].img[0];
@@ -402,6 +403,7 @@ __global__ void __launch_bounds__(GN_THREADS) pose_gn_kernel(DevCam cam, int n, 
 #define GS_THREADS 256
 #define GS_WAVES (GS_THREADS / 64)
 #define GS_MPT 4   // measurements per thread: n <= 1024
+static_assert(GS_THREADS * GS_MPT == GS_LIMIT, "GS_LIMIT");
 #define GS_BINS 2048   // 11-bit digits of the order-statistic select
 #define GS_TR_PITCH (8 * 33 + 1)   // 8 slices of 32 threads, padded so that slices and rows fall into different banks
 
@@ -819,7 +821,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
         for (int q = 0; q < GS_MPT; q++) {
             const int i = tid + q * GS_THREADS;
             if (i < n) {
-                ptam_projection* o = (ptam_projection*)((char*)io.td_base + (size_t)io.td_index[i] * io.td_stride);
+                ptam_projection* o = (ptam_projection*)((char*)io.td_base + (size_t)(io.td_index ? io.td_index[i] : i) * io.td_stride);
 #pragma unroll
                 for (int k = 0; k < 3; k++) o->cam[k] = t[q].cam3[k];
                 o->image[0] = t[q].img[0];
@@ -901,8 +903,9 @@ void ptam_gn_opts_default(ptam_gn_opts* o) {
     o->prior = 100.0;            // :974
 }
 
-int ptam_pose_gn(ptam_ctx* ctx, int n, const ptam_pose_meas* meas, const ptam_projection* entry,
-                 double pose_inout[12], const ptam_gn_opts* opts, int32_t* outlier_flags, double* updates_out) {
+static int pose_gn_host(ptam_ctx* ctx, int n, const ptam_pose_meas* meas, const ptam_projection* entry,
+                        double pose_inout[12], const ptam_gn_opts* opts, int32_t* outlier_flags, double* updates_out,
+                        ptam_projection* state_out) {
     ARG_TRY(ctx && n >= 0 && pose_inout);
     ptam_gn_opts o;
     if (opts)
@@ -920,9 +923,17 @@ int ptam_pose_gn(ptam_ctx* ctx, int n, const ptam_pose_meas* meas, const ptam_pr
     const size_t bm = (size_t)n * sizeof(ptam_pose_meas), be = entry ? (size_t)n * sizeof(ptam_projection) : 0,
                  bs = (size_t)n * sizeof(PoseState), bf = (size_t)n * 4, bu = (size_t)6 * 32 * 8;
     const size_t b_in = bm + be + 96;   // [measurements | entry state | pose]: ONE upload
+    const size_t b_so = state_out ? (size_t)n * sizeof(ptam_projection) : 0;
     void* s;
-    int rc = ctx_scratch(ctx, b_in + bs + bf + bu + 64, &s);
+    int rc = ctx_scratch(ctx, b_in + bs + bf + bu + b_so + 128, &s);
     if (rc) return rc;
+    PoseChainIo io{};
+    if (state_out) {   // the measurements' TrackerData state at loop exit (entry state of a following loop, src/Tracker.cc:617)
+        io.td_base = (char*)s + ((b_in + bs + bf + bu + 63) & ~(size_t)63);
+        io.td_index = nullptr;
+        io.td_stride = (int)sizeof(ptam_projection);
+        HIP_TRY(hipMemsetAsync(io.td_base, 0, b_so, ctx->stream));
+    }
     char* p = (char*)s;
     ptam_pose_meas* d_m = (ptam_pose_meas*)p;
     ptam_projection* d_e = entry ? (ptam_projection*)(p + bm) : nullptr;
@@ -953,12 +964,12 @@ int ptam_pose_gn(ptam_ctx* ctx, int n, const ptam_pose_meas* meas, const ptam_pr
     const unsigned long long seq = ++ctx->pose_seq;
     if (small)
         hipLaunchKernelGGL(pose_gn_small_kernel, dim3(1), dim3(GS_THREADS), 0, ctx->stream, ctx->cam, n, d_m, d_e, d_pose, o, d_f,
-                           d_u, (ulonglong2*)((char*)ctx->d_pinned + o_slots), seq, (const int*)nullptr, PoseIn{});
+                           d_u, (ulonglong2*)((char*)ctx->d_pinned + o_slots), seq, (const int*)nullptr, PoseIn{}, io, 0);
     else
         hipLaunchKernelGGL(pose_gn_kernel, dim3(1), dim3(GN_THREADS), 0, ctx->stream, ctx->cam, n, d_m, d_e, d_pose, o,
-                           d_s, d_f, d_u, (const int*)nullptr, PoseIn{});
+                           d_s, d_f, d_u, (const int*)nullptr, PoseIn{}, io, 0);
     HIP_TRY(hipGetLastError());
-    const bool extras = outlier_flags || updates_out;
+    const bool extras = outlier_flags || updates_out || state_out;
     if (outlier_flags) HIP_TRY(hipMemcpyAsync(hf, d_f, bf, hipMemcpyDeviceToHost, ctx->stream));
     if (updates_out) HIP_TRY(hipMemcpyAsync(hu, d_u, b_upd, hipMemcpyDeviceToHost, ctx->stream));
     if (small && !extras) {
@@ -994,7 +1005,19 @@ int ptam_pose_gn(ptam_ctx* ctx, int n, const ptam_pose_meas* meas, const ptam_pr
         std::memcpy(pose_inout, hp + o_slots, 96);
     if (outlier_flags) std::memcpy(outlier_flags, hf, bf);
     if (updates_out) std::memcpy(updates_out, hu, b_upd);
+    if (state_out) HIP_TRY(hipMemcpy(state_out, io.td_base, b_so, hipMemcpyDeviceToHost));   // (tests and the shim's staged path only)
     return PTAM_OK;
+}
+
+int ptam_pose_gn(ptam_ctx* ctx, int n, const ptam_pose_meas* meas, const ptam_projection* entry,
+                 double pose_inout[12], const ptam_gn_opts* opts, int32_t* outlier_flags, double* updates_out) {
+    return pose_gn_host(ctx, n, meas, entry, pose_inout, opts, outlier_flags, updates_out, nullptr);
+}
+int ptam_pose_gn_state(ptam_ctx* ctx, int n, const ptam_pose_meas* meas, const ptam_projection* entry,
+                       double pose_inout[12], const ptam_gn_opts* opts, int32_t* outlier_flags, double* updates_out,
+                       ptam_projection* state_out) {
+    ARG_TRY(n == 0 || state_out);
+    return pose_gn_host(ctx, n, meas, entry, pose_inout, opts, outlier_flags, updates_out, state_out);
 }
 
 static int pose_gn_dev_impl(ptam_ctx* ctx, int n, const int32_t* d_n, const ptam_pose_meas* d_meas, const ptam_projection* d_entry,
@@ -1037,10 +1060,10 @@ static int pose_gn_dev_impl(ptam_ctx* ctx, int n, const int32_t* d_n, const ptam
     }
     if (small)
         hipLaunchKernelGGL(pose_gn_small_kernel, dim3(1), dim3(GS_THREADS), 0, ctx->stream, ctx->cam, n, d_meas, d_entry,
-                           d_pose_inout, o, d_outlier_flags, d_u, d_slots, seq, (const int*)d_n, pin);
+                           d_pose_inout, o, d_outlier_flags, d_u, d_slots, seq, (const int*)d_n, pin, PoseChainIo{}, 0);
     else
         hipLaunchKernelGGL(pose_gn_kernel, dim3(1), dim3(GN_THREADS), 0, ctx->stream, ctx->cam, n, d_meas, d_entry, d_pose_inout, o,
-                           d_s, d_outlier_flags, d_u, (const int*)d_n, pin);
+                           d_s, d_outlier_flags, d_u, (const int*)d_n, pin, PoseChainIo{}, 0);
     HIP_TRY(hipGetLastError());
     if (!pose_host_out) return PTAM_OK;
     if (!small) {
@@ -1070,6 +1093,30 @@ static int pose_gn_dev_impl(ptam_ctx* ctx, int n, const int32_t* d_n, const ptam
     }
     return PTAM_OK;
 }
+
+}   // extern "C"
+
+// resident TrackMap chain: the list length sits in device memory and may exceed what the register-resident kernel holds,
+// so BOTH kernels are enqueued and the length picks the one that runs (the other leaves at once)
+int pose_launch_chain(ptam_ctx* ctx, int n_cap, const int* d_n, const ptam_pose_meas* d_meas, const ptam_projection* d_entry,
+                      double* d_pose_inout, const ptam_gn_opts* opts, int32_t* d_outlier_flags, const PoseChainIo& io) {
+    ARG_TRY(ctx && n_cap >= 1 && d_n && d_meas && d_pose_inout && opts);
+    const bool may_be_long = n_cap > GS_LIMIT;
+    const size_t bs = may_be_long ? (size_t)n_cap * sizeof(PoseState) : 0, bu = (size_t)6 * 32 * 8;
+    void* s;
+    int rc = ctx_scratch(ctx, bs + bu + 64, &s);
+    if (rc) return rc;
+    double* d_u = (double*)((char*)s + bs);
+    hipLaunchKernelGGL(pose_gn_small_kernel, dim3(1), dim3(GS_THREADS), 0, ctx->stream, ctx->cam, std::min(n_cap, GS_LIMIT), d_meas, d_entry,
+                       d_pose_inout, *opts, d_outlier_flags, d_u, (ulonglong2*)nullptr, 0ull, d_n, PoseIn{}, io, may_be_long ? 1 : 0);
+    if (may_be_long)
+        hipLaunchKernelGGL(pose_gn_kernel, dim3(1), dim3(GN_THREADS), 0, ctx->stream, ctx->cam, n_cap, d_meas, d_entry, d_pose_inout, *opts,
+                           (PoseState*)s, d_outlier_flags, d_u, d_n, PoseIn{}, io, 2);
+    HIP_TRY(hipGetLastError());
+    return PTAM_OK;
+}
+
+extern "C" {
 
 int ptam_pose_gn_dev(ptam_ctx* ctx, int n, const ptam_pose_meas* d_meas, const ptam_projection* d_entry, double* d_pose_inout,
                      const ptam_gn_opts* opts, int32_t* d_outlier_flags, double* d_updates) {

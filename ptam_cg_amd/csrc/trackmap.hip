@@ -1,0 +1,673 @@
+// trackmap.hip — Tracker::TrackMap (src/Tracker.cc:442-696) as ONE device-resident chain.
+//
+// The reference's frame is  PVS loop (:453-478)  ->  choice of the coarse / top-level / fine search sets (:480-611)  ->
+// SearchForPoints on the coarse set, range 30, 8 sub-pixel iterations (:549)  ->  ten coarse pose iterations (:554-568)  ->
+// SearchForPoints on the remaining top-level points (sub-pixel) and on the fine set (:572-610)  ->  ten fine pose
+// iterations (:613-643)  ->  measurement / scene-depth bookkeeping (:660-696).  Which sets are searched, whether the coarse
+// stage counts (nFound >= CoarseMin), the fine search range (5 or 10) and every list length are decided from data that only
+// exists on the device, so the whole chain is enqueued at once: list lengths, slot ranges and the stage flags live in a
+// small control block (TmCtl) that the kernels read; nothing comes back to the host before the final result.
+//
+// std::random_shuffle (:483-484, :598) is replaced by caller-provided permutations of the map-point ids: level l's
+// list is taken in the order its members appear in `shuffle_levels` (the order a uniform permutation induces on a subset is
+// itself uniform), the chop of the fine set likewise with `shuffle_fine`.
+//
+// Per map point the chain keeps the reference's TrackerData (v3Cam, v2Image, m2CamDerivs) in the PVS result table and
+// carries it from stage to stage exactly as the reference does: the fine loop's iteration 0 does not re-project
+// (:617), so a point found in the coarse stage enters it with the state the coarse loop left, a point of the later sets
+// with its re-projection at the post-coarse pose and the camera derivatives of the PVS pass (ProjectAndDerivs only
+// refreshes them for found points, include/Tracker.h:89-94).
+#include <atomic>
+
+#include "track_internal.h"
+
+struct TmSrc {   // MapPoint::pPatchSourceKF / nSourceLevel / irCenter, resolved to the level image
+    const uint8_t* im;
+    int w, h;
+    int cx, cy;
+};
+
+struct TmCtl {
+    int n_lvl[4];           // avPVS[l].size() after the PVS loop
+    int nC, nH, nF, n_slots;
+    int do_coarse;          // the coarse search runs (:519)
+    int did_coarse;         // mbDidCoarse (:551)
+    int n_found_coarse;     // nFound of the coarse SearchForPoints
+    int n_meas_coarse;      // measurements of the coarse pose loop (0 unless did_coarse)
+    int n_meas;             // found entries of vIterationSet
+    int fine_range;         // nFineRange (:572)
+    int attempted[4], found[4];   // manMeasAttempted / manMeasFound
+    int range_all[2], range_c[2], range_hf[2], range_h[2];   // slot ranges {first, end} of the stages
+    int pad_[2];
+    double depth[3];        // sum z, sum z^2, count over the found points (:680-690)
+};
+
+struct TmDev {
+    int n, cap;
+    ptam_pvs_point* pts;
+    TmSrc* src;
+    int* perm_a;
+    int* perm_b;
+    ptam_pvs_result* pvs;     // proj = the point's TrackerData state
+    int* lvl_list;            // [4][cap]
+    uint8_t* isfc;            // [cap] member of the fine candidate set
+    int* list;                // [cap] search slots: coarse | top level | fine
+    TemplateJob* jobs;
+    uint8_t* tmpl;
+    ptam_template_result* tres;
+    ptam_patch_query* q;
+    ptam_patch_result* r;
+    ptam_subpix_result* sr;
+    int* slot_found;
+    int* slot_subpix;
+    double2* slot_v2;
+    ptam_pose_meas* meas;
+    ptam_projection* entry;
+    int* midx;                // measurement -> map point
+    int* mslot;               // measurement -> slot
+    int* outlier;             // per measurement (fine loop, iteration 9)
+    TmCtl* ctl;
+    double* pose;
+};
+
+// exclusive block scan of four counters at once (1024 threads): returns this thread's four offsets, totals in tot[]
+__device__ __forceinline__ void block_scan4(const int v[4], int off[4], int tot[4], int (*wsum)[16]) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    int incl[4];
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        int x = v[l];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        incl[l] = x;
+        if (lane == 63) wsum[l][wid] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        int base = 0, total = 0;
+        for (int w = 0; w < 16; w++) {
+            const int s = wsum[l][w];
+            if (w < wid) base += s;
+            total += s;
+        }
+        off[l] = base + incl[l] - v[l];
+        tot[l] = total;
+    }
+    __syncthreads();
+}
+
+__global__ void tm_set_pose_kernel(double* pose, TmCtl* ctl, double p0, double p1, double p2, double p3, double p4, double p5,
+                                   double p6, double p7, double p8, double p9, double p10, double p11) {
+    pose[0] = p0, pose[1] = p1, pose[2] = p2, pose[3] = p3, pose[4] = p4, pose[5] = p5;
+    pose[6] = p6, pose[7] = p7, pose[8] = p8, pose[9] = p9, pose[10] = p10, pose[11] = p11;
+}
+
+// The choice of the search sets, src/Tracker.cc:480-611.  One workgroup.
+__global__ void __launch_bounds__(1024) tm_select_kernel(TmDev d, ptam_trackmap_opts o) {
+    __shared__ int wsum[4][16];
+    const int tid = threadIdx.x, n = d.n, cap = d.cap;
+    const int chunk = (n + 1023) / 1024, p0 = min(n, tid * chunk), p1 = min(n, p0 + chunk);
+    // level lists in the order the shuffle permutation visits their members
+    int cnt[4] = {0, 0, 0, 0};
+    for (int p = p0; p < p1; p++) {
+        const int id = d.perm_a[p];
+        const int l = d.pvs[id].level;
+        d.isfc[id] = 0;
+        if (l >= 0) cnt[l]++;
+    }
+    int off[4], tot[4];
+    block_scan4(cnt, off, tot, wsum);
+    for (int p = p0; p < p1; p++) {
+        const int id = d.perm_a[p];
+        const int l = d.pvs[id].level;
+        if (l >= 0) d.lvl_list[l * cap + off[l]++] = id;
+    }
+    __syncthreads();
+    const int n3 = tot[3], n2 = tot[2], n1 = tot[1], n0 = tot[0];
+    const int cmax = (int)o.coarse_max;
+    // coarse set (:519-546)
+    const int do_coarse = o.try_coarse && ((unsigned)(n3 + n2) > o.coarse_min);
+    int t3 = 0, t2 = 0, nC3 = 0, nC2 = 0;
+    if (do_coarse) {
+        t3 = min(n3, cmax);   // all of level 3, or CoarseMax of it; either way they leave avPVS[3]
+        nC3 = t3;
+        if (nC3 < cmax) {
+            const int need = cmax - nC3;
+            if (n2 <= need) {
+                // :538 ASSIGNS avPVS[LEVELS-2] to vNextToSearch: the level-3 picks made above are dropped from the frame
+                // (they are neither searched nor left in the PVS).  Kept as the reference does it.
+                nC3 = 0;
+                nC2 = n2;
+                t2 = n2;
+            } else {
+                nC2 = need;
+                t2 = need;
+            }
+        }
+    }
+    const int nC = nC3 + nC2, nH = n3 - t3;
+    const int nFC = (n2 - t2) + n1 + n0;
+    const int n_use = max(0, o.max_patches - (nC + nH));   // :594-596
+    const bool chop = nFC > n_use;
+    const int nF = chop ? n_use : nFC;
+    const int* L3 = d.lvl_list + 3 * cap;
+    const int* L2 = d.lvl_list + 2 * cap;
+    const int* L1 = d.lvl_list + 1 * cap;
+    const int* L0 = d.lvl_list;
+    for (int s = tid; s < nC; s += 1024) d.list[s] = s < nC3 ? L3[s] : L2[s - nC3];
+    for (int s = tid; s < nH; s += 1024) d.list[nC + s] = L3[t3 + s];
+    // fine candidates in the order of :588-590: levels 2, 1, 0
+    for (int s = tid; s < nFC; s += 1024) {
+        const int a = n2 - t2;
+        const int id = s < a ? L2[t2 + s] : (s < a + n1 ? L1[s - a] : L0[s - a - n1]);
+        if (chop)
+            d.isfc[id] = 1;
+        else
+            d.list[nC + nH + s] = id;
+    }
+    if (chop) {
+        // random_shuffle + resize (:597-600): the first n_use members in the order of the second permutation
+        __syncthreads();
+        int c4[4] = {0, 0, 0, 0};
+        for (int p = p0; p < p1; p++) c4[0] += d.isfc[d.perm_b[p]];
+        int o4[4], t4[4];
+        block_scan4(c4, o4, t4, wsum);
+        int k = o4[0];
+        for (int p = p0; p < p1; p++) {
+            const int id = d.perm_b[p];
+            if (d.isfc[id]) {
+                if (k < n_use) d.list[nC + nH + k] = id;
+                k++;
+            }
+        }
+    }
+    if (tid == 0) {
+        TmCtl& c = *d.ctl;
+        c.n_lvl[0] = n0, c.n_lvl[1] = n1, c.n_lvl[2] = n2, c.n_lvl[3] = n3;
+        c.nC = nC, c.nH = nH, c.nF = nF, c.n_slots = nC + nH + nF;
+        c.do_coarse = do_coarse;
+        c.did_coarse = 0;
+        c.n_found_coarse = c.n_meas_coarse = c.n_meas = 0;
+        c.fine_range = 10;
+        for (int l = 0; l < 4; l++) c.attempted[l] = c.found[l] = 0;
+        c.range_all[0] = 0, c.range_all[1] = nC + nH + nF;
+        c.range_c[0] = 0, c.range_c[1] = nC;
+        c.range_hf[0] = nC, c.range_hf[1] = nC + nH + nF;
+        c.range_h[0] = nC, c.range_h[1] = nC + nH;
+        c.depth[0] = c.depth[1] = c.depth[2] = 0;
+    }
+}
+
+// template jobs of every slot: MakeTemplateCoarseCont only needs what the PVS pass left (search level, warp)
+__global__ void __launch_bounds__(256) tm_prep_kernel(TmDev d) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= d.ctl->n_slots) return;
+    const int id = d.list[s];
+    const TmSrc sr = d.src[id];
+    const ptam_pvs_result& pv = d.pvs[id];
+    TemplateJob j;
+    j.im = sr.im;
+    j.w = sr.w;
+    j.h = sr.h;
+    j.search_level = pv.level;
+    j.cx = sr.cx;
+    j.cy = sr.cy;
+#pragma unroll
+    for (int k = 0; k < 4; k++) j.wi[k] = pv.warp_inverse[k];
+    d.jobs[s] = j;
+}
+
+// The head of SearchForPoints (src/Tracker.cc:873-881) for a stage's slots: a bad template drops the point, otherwise the
+// search query is ir(v2Image) at the point's search level.  stage 0: the coarse set; stage 1: top-level and fine sets, after
+// TrackerData::Project at the current pose (:573-574 always, :606-608 if the coarse stage counted).
+__global__ void __launch_bounds__(256) tm_query_kernel(DevCam cam, TmDev d, int stage, unsigned coarse_range) {
+    const TmCtl& c = *d.ctl;
+    const int first = stage == 0 ? c.range_c[0] : c.range_hf[0], end = stage == 0 ? c.range_c[1] : c.range_hf[1];
+    const int s = first + blockIdx.x * 256 + threadIdx.x;
+    if (s >= end) return;
+    const int id = d.list[s];
+    ptam_projection& td = d.pvs[id].proj;
+    if (stage == 1 && (s < c.range_h[1] || c.did_coarse)) {
+        // TrackerData::Project include/Tracker.h:70-85 (bFound is false here: the derivatives stay, :89-94)
+        const ptam_pvs_point& p = d.pts[id];
+        double X, Y, Z;
+        se3_apply(d.pose, p.world[0], p.world[1], p.world[2], X, Y, Z);
+        td.cam[0] = X, td.cam[1] = Y, td.cam[2] = Z;
+        int in_image = 0;
+        if (!(Z < 0.001)) {
+            const double x = X / Z, y = Y / Z;
+            if (!(x * x + y * y > cam.largest_radius * cam.largest_radius)) {
+                double u, v, rr, f;
+                cam_project(cam, x, y, u, v, rr, f);
+                td.image[0] = u;
+                td.image[1] = v;
+                if (!(rr > cam.max_r) && !(u < 0 || v < 0 || u > cam.width || v > cam.height)) in_image = 1;
+            }
+        }
+        td.in_image = in_image;
+    }
+    ptam_patch_query q;
+    q.x = (int)td.image[0];   // ir(): truncation
+    q.y = (int)td.image[1];
+    q.range = stage == 0 ? coarse_range : (unsigned)c.fine_range;
+    q.level = d.jobs[s].search_level;
+    if (d.tres[s].bad) {
+        q.level = -1;   // Finder.TemplateBad(): not attempted, not searched (:876-879)
+        td.in_image = 0;
+    } else
+        atomicAdd(&d.ctl->attempted[q.level], 1);
+    d.q[s] = q;
+}
+
+// The tail of SearchForPoints (:883-909) and the measurement list of the pose loop that follows.  One workgroup.
+//   stage 0: status of the coarse slots, nFound, mbDidCoarse, the coarse loop's measurements;
+//   stage 1: status of the other slots, then vIterationSet's found entries in order (coarse, top level, fine).
+__global__ void __launch_bounds__(1024) tm_gather_kernel(TmDev d, int stage, int coarse_its, unsigned coarse_min) {
+    __shared__ int wsum[4][16];
+    TmCtl& c = *d.ctl;
+    const int tid = threadIdx.x;
+    const int st_first = stage == 0 ? 0 : c.nC, st_end = stage == 0 ? c.nC : c.n_slots;
+    int lf[4] = {0, 0, 0, 0};
+    for (int s = st_first + tid; s < st_end; s += 1024) {
+        const ptam_patch_query q = d.q[s];
+        const int its = stage == 0 ? coarse_its : (s < c.range_h[1] ? 8 : 0);
+        int found = q.level >= 0 && d.r[s].found;
+        int sub = 0;
+        double2 v2 = make_double2(0, 0);
+        if (found) {
+            if (its > 0) {
+                sub = 1;
+                const ptam_subpix_result sr = d.sr[s];
+                found = sr.converged;   // :898-904
+                v2 = make_double2(sr.pos[0], sr.pos[1]);
+            } else
+                v2 = make_double2(d.r[s].pos[0], d.r[s].pos[1]);
+        }
+        d.slot_found[s] = found;
+        d.slot_subpix[s] = sub;
+        d.slot_v2[s] = v2;
+        if (found) lf[q.level]++;
+    }
+    // per-level found counts of this stage (integers: order-free)
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        const int t = wave_sum_i32(lf[l]);
+        if ((tid & 63) == 0 && t) atomicAdd(&c.found[l], t);
+    }
+    __syncthreads();
+    // stable compaction of the found slots
+    const int g_end = stage == 0 ? c.nC : c.n_slots;
+    const int chunk = (g_end + 1023) / 1024, s0 = min(g_end, tid * chunk), s1 = min(g_end, s0 + chunk);
+    int cnt[4] = {0, 0, 0, 0};
+    for (int s = s0; s < s1; s++) cnt[0] += d.slot_found[s];
+    int off[4], tot[4];
+    block_scan4(cnt, off, tot, wsum);
+    int k = off[0];
+    for (int s = s0; s < s1; s++)
+        if (d.slot_found[s]) {
+            const int id = d.list[s];
+            ptam_pose_meas m;
+            const ptam_pvs_point& p = d.pts[id];
+            m.world[0] = p.world[0], m.world[1] = p.world[1], m.world[2] = p.world[2];
+            const double2 v2 = d.slot_v2[s];
+            m.found[0] = v2.x;
+            m.found[1] = v2.y;
+            m.sqrt_inv_noise = 1.0 / (double)(1 << d.q[s].level);   // :889
+            d.meas[k] = m;
+            d.entry[k] = d.pvs[id].proj;
+            d.midx[k] = id;
+            d.mslot[k] = s;
+            k++;
+        }
+    if (tid == 0) {
+        if (stage == 0) {
+            c.n_found_coarse = tot[0];
+            c.did_coarse = c.do_coarse && (unsigned)tot[0] >= coarse_min;   // :550-551
+            c.n_meas_coarse = c.did_coarse ? tot[0] : 0;
+            c.fine_range = c.did_coarse ? 5 : 10;                           // :572
+        } else
+            c.n_meas = tot[0];
+    }
+}
+
+struct TmMailbox {
+    ptam_trackmap_result res;
+    unsigned long long seq;
+};
+__global__ void tm_finish_kernel(TmDev d, TmMailbox* out, unsigned long long seq) {
+    const TmCtl& c = *d.ctl;
+    ptam_trackmap_result r;
+    for (int k = 0; k < 12; k++) r.pose[k] = d.pose[k];
+    r.did_coarse = c.did_coarse;
+    for (int l = 0; l < 4; l++) {
+        r.n_pvs[l] = c.n_lvl[l];
+        r.attempted[l] = c.attempted[l];
+        r.found[l] = c.found[l];
+    }
+    r.n_coarse = c.nC;
+    r.n_top = c.nH;
+    r.n_fine = c.nF;
+    r.n_meas = c.n_meas;
+    r.depth_n = (int)c.depth[2];
+    r.depth_sum = c.depth[0];
+    r.depth_sum_sq = c.depth[1];
+    out->res = r;
+    __threadfence_system();
+    *(volatile unsigned long long*)&out->seq = seq;
+}
+
+// =================================================================================================
+struct ptam_tracker {
+    ptam_ctx* ctx;
+    TmDev d;
+    void* block;
+    TmMailbox* mbox;       // host-mapped
+    TmMailbox* mbox_dev;
+    unsigned long long seq;
+    int have_shuffle;
+};
+
+static int tm_pin_copy(ptam_ctx* ctx, void* dst, const void* src, size_t bytes) {   // pageable host -> device through the pinned staging
+    void* pin;
+    int rc = ctx_pinned(ctx, bytes + 64, &pin);
+    if (rc) return rc;
+    std::memcpy(pin, src, bytes);
+    HIP_TRY(hipMemcpyAsync(dst, pin, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ptam_stream_wait(ctx->stream));   // (the staging buffer is shared)
+    return PTAM_OK;
+}
+
+extern "C" {
+
+void ptam_trackmap_opts_default(ptam_trackmap_opts* o) {
+    if (!o) return;
+    o->try_coarse = 1;
+    o->coarse_min = 20;          // Tracker.CoarseMin          src/Tracker.cc:492
+    o->coarse_max = 60;          // Tracker.CoarseMax          :493
+    o->coarse_range = 30;        // Tracker.CoarseRange        :494
+    o->coarse_subpix_its = 8;    // Tracker.CoarseSubPixIts    :495
+    o->max_patches = 1000;       // Tracker.MaxPatchesPerFrame :593
+    o->estimator = PTAM_EST_TUKEY;
+    o->pad_ = 0;
+}
+
+int ptam_tracker_create(ptam_ctx* ctx, int max_points, ptam_tracker** out) {
+    ARG_TRY(ctx && out && max_points >= 1);
+    HIP_TRY(hipSetDevice(ctx->device));
+    ptam_tracker* t = new ptam_tracker();
+    std::memset(t, 0, sizeof *t);
+    t->ctx = ctx;
+    const size_t cap = (size_t)max_points;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    const size_t o_pts = take(cap * sizeof(ptam_pvs_point)), o_src = take(cap * sizeof(TmSrc)), o_pa = take(cap * 4), o_pb = take(cap * 4),
+                 o_pvs = take(cap * sizeof(ptam_pvs_result)), o_ll = take(cap * 16), o_fc = take(cap), o_list = take(cap * 4),
+                 o_jobs = take(cap * sizeof(TemplateJob)), o_tm = take(cap * 64), o_tr = take(cap * sizeof(ptam_template_result)),
+                 o_q = take(cap * sizeof(ptam_patch_query)), o_r = take(cap * sizeof(ptam_patch_result)),
+                 o_sr = take(cap * sizeof(ptam_subpix_result)), o_sf = take(cap * 4), o_ss = take(cap * 4), o_sv = take(cap * 16),
+                 o_me = take(cap * sizeof(ptam_pose_meas)), o_en = take(cap * sizeof(ptam_projection)), o_mi = take(cap * 4),
+                 o_ms = take(cap * 4), o_ou = take(cap * 4), o_ctl = take(sizeof(TmCtl)), o_pose = take(96);
+    if (hipMalloc(&t->block, off) != hipSuccess) {
+        delete t;
+        ptam_set_error("hipMalloc(%zu) failed", off);
+        return PTAM_E_HIP;
+    }
+    (void)hipMemsetAsync(t->block, 0, off, ctx->stream);
+    char* b = (char*)t->block;
+    TmDev& d = t->d;
+    d.n = 0;
+    d.cap = max_points;
+    d.pts = (ptam_pvs_point*)(b + o_pts);
+    d.src = (TmSrc*)(b + o_src);
+    d.perm_a = (int*)(b + o_pa);
+    d.perm_b = (int*)(b + o_pb);
+    d.pvs = (ptam_pvs_result*)(b + o_pvs);
+    d.lvl_list = (int*)(b + o_ll);
+    d.isfc = (uint8_t*)(b + o_fc);
+    d.list = (int*)(b + o_list);
+    d.jobs = (TemplateJob*)(b + o_jobs);
+    d.tmpl = (uint8_t*)(b + o_tm);
+    d.tres = (ptam_template_result*)(b + o_tr);
+    d.q = (ptam_patch_query*)(b + o_q);
+    d.r = (ptam_patch_result*)(b + o_r);
+    d.sr = (ptam_subpix_result*)(b + o_sr);
+    d.slot_found = (int*)(b + o_sf);
+    d.slot_subpix = (int*)(b + o_ss);
+    d.slot_v2 = (double2*)(b + o_sv);
+    d.meas = (ptam_pose_meas*)(b + o_me);
+    d.entry = (ptam_projection*)(b + o_en);
+    d.midx = (int*)(b + o_mi);
+    d.mslot = (int*)(b + o_ms);
+    d.outlier = (int*)(b + o_ou);
+    d.ctl = (TmCtl*)(b + o_ctl);
+    d.pose = (double*)(b + o_pose);
+    void* h = nullptr;
+    if (hipHostMalloc(&h, sizeof(TmMailbox), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+        hipFree(t->block);
+        delete t;
+        ptam_set_error("hipHostMalloc failed");
+        return PTAM_E_HIP;
+    }
+    std::memset(h, 0, sizeof(TmMailbox));
+    void* dv = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dv, h, 0));
+    t->mbox = (TmMailbox*)h;
+    t->mbox_dev = (TmMailbox*)dv;
+    // identity shuffles until the caller sets its own
+    std::vector<int> idp((size_t)max_points);
+    for (int i = 0; i < max_points; i++) idp[(size_t)i] = i;
+    HIP_TRY(hipMemcpy(d.perm_a, idp.data(), cap * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d.perm_b, idp.data(), cap * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ptam_stream_wait(ctx->stream));
+    *out = t;
+    return PTAM_OK;
+}
+
+int ptam_tracker_destroy(ptam_tracker* t) {
+    if (!t) return PTAM_OK;
+    hipSetDevice(t->ctx->device);
+    ptam_stream_wait(t->ctx->stream);
+    if (t->block) hipFree(t->block);
+    if (t->mbox) hipHostFree(t->mbox);
+    delete t;
+    return PTAM_OK;
+}
+
+int ptam_tracker_set_map(ptam_tracker* t, int n, const ptam_pvs_point* pts, const ptam_template_query* src) {
+    ARG_TRY(t && n >= 0 && n <= t->d.cap && (n == 0 || (pts && src)));
+    ptam_ctx* ctx = t->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<TmSrc> s((size_t)n);
+    for (int i = 0; i < n; i++) {
+        const ptam_template_query& q = src[i];
+        ARG_TRY(q.src_kf && q.src_level >= 0 && q.src_level < PTAM_LEVELS && q.src_kf->device == ctx->device);
+        s[(size_t)i].im = q.src_kf->L.im[q.src_level];
+        s[(size_t)i].w = q.src_kf->L.w[q.src_level];
+        s[(size_t)i].h = q.src_kf->L.h[q.src_level];
+        s[(size_t)i].cx = q.center_x;
+        s[(size_t)i].cy = q.center_y;
+    }
+    HIP_TRY(ptam_stream_wait(ctx->stream));
+    if (n > 0) {
+        HIP_TRY(hipMemcpy(t->d.pts, pts, (size_t)n * sizeof(ptam_pvs_point), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(t->d.src, s.data(), (size_t)n * sizeof(TmSrc), hipMemcpyHostToDevice));
+    }
+    if (n != t->d.n) {   // the shuffles are permutations of 0..n-1: back to the identity until the caller sets them again
+        std::vector<int> idp((size_t)std::max(n, 1));
+        for (int i = 0; i < n; i++) idp[(size_t)i] = i;
+        if (n > 0) {
+            HIP_TRY(hipMemcpy(t->d.perm_a, idp.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(t->d.perm_b, idp.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        }
+    }
+    t->d.n = n;
+    return PTAM_OK;
+}
+
+int ptam_tracker_set_shuffle(ptam_tracker* t, const int32_t* shuffle_levels, const int32_t* shuffle_fine) {
+    ARG_TRY(t && shuffle_levels && shuffle_fine);
+    const int n = t->d.n;
+    if (n == 0) return PTAM_OK;
+    // permutations of 0..n-1 (anything else would index outside the map on the device)
+    std::vector<uint8_t> seen((size_t)n);
+    for (int pass = 0; pass < 2; pass++) {
+        const int32_t* p = pass ? shuffle_fine : shuffle_levels;
+        std::fill(seen.begin(), seen.end(), 0);
+        for (int i = 0; i < n; i++) {
+            ARG_TRY(p[i] >= 0 && p[i] < n && !seen[(size_t)p[i]]);
+            seen[(size_t)p[i]] = 1;
+        }
+    }
+    HIP_TRY(hipSetDevice(t->ctx->device));
+    void* pin;
+    int rc = ctx_pinned(t->ctx, (size_t)n * 8 + 64, &pin);
+    if (rc) return rc;
+    HIP_TRY(ptam_stream_wait(t->ctx->stream));   // (shared staging buffer; the previous frame has been read by now anyway)
+    std::memcpy(pin, shuffle_levels, (size_t)n * 4);
+    std::memcpy((char*)pin + (size_t)n * 4, shuffle_fine, (size_t)n * 4);
+    HIP_TRY(hipMemcpyAsync(t->d.perm_a, pin, (size_t)n * 4, hipMemcpyHostToDevice, t->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(t->d.perm_b, (char*)pin + (size_t)n * 4, (size_t)n * 4, hipMemcpyHostToDevice, t->ctx->stream));
+    return PTAM_OK;
+}
+
+int ptam_track_map(ptam_tracker* t, const ptam_kf* cur, const double pose_in[12], const ptam_trackmap_opts* opts,
+                   ptam_trackmap_result* out) {
+    ARG_TRY(t && cur && pose_in && out);
+    ptam_ctx* ctx = t->ctx;
+    ARG_TRY(cur->device == ctx->device);
+    ptam_trackmap_opts o;
+    if (opts)
+        o = *opts;
+    else
+        ptam_trackmap_opts_default(&o);
+    ARG_TRY(o.max_patches >= 0 && o.coarse_subpix_its >= 0 && o.coarse_subpix_its <= 64);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const TmDev& d = t->d;
+    const int n = d.n;
+    hipStream_t st = ctx->stream;
+    const double* p = pose_in;
+    hipLaunchKernelGGL(tm_set_pose_kernel, dim3(1), dim3(1), 0, st, d.pose, d.ctl, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9],
+                       p[10], p[11]);
+    int rc = pvs_launch_dev(ctx, n, d.pts, d.pose, d.pvs);                              // :453-478
+    if (rc) return rc;
+    hipLaunchKernelGGL(tm_select_kernel, dim3(1), dim3(1024), 0, st, d, o);             // :480-611
+    const int g256 = std::max(1, (n + 255) / 256);
+    hipLaunchKernelGGL(tm_prep_kernel, dim3(g256), dim3(256), 0, st, d);
+    rc = patch_launch_templates_dev(ctx, n, d.jobs, d.tmpl, d.tres, d.ctl->range_all);   // MakeTemplateCoarseCont :873
+    if (rc) return rc;
+    // ---- coarse stage :519-569 ----
+    const int ncc = std::max(1, std::min(n, (int)o.coarse_max));
+    hipLaunchKernelGGL(tm_query_kernel, dim3((ncc + 255) / 256), dim3(256), 0, st, ctx->cam, d, 0, o.coarse_range);
+    rc = patch_launch_search_dev(ctx, cur, ncc, d.q, d.tmpl, d.r, d.ctl->range_c);
+    if (rc) return rc;
+    if (o.coarse_subpix_its > 0) {
+        rc = patch_launch_subpix_dev(ctx, cur, ncc, d.q, d.r, d.tmpl, d.sr, d.ctl->range_c, o.coarse_subpix_its);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(tm_gather_kernel, dim3(1), dim3(1024), 0, st, d, 0, o.coarse_subpix_its, o.coarse_min);
+    {
+        ptam_gn_opts g;
+        ptam_gn_opts_default(&g);
+        g.nonlinear_mask = 0x3ff;       // every coarse iteration re-projects (:556-562)
+        g.override_sigma_sq = 1.0;      // :565
+        g.mark_outliers_iter = -1;      // CalcPoseUpdate(vIterationSet, dOverrideSigma): bMarkOutliers defaults to false
+        g.estimator = o.estimator;
+        PoseChainIo io{};
+        io.td_base = &d.pvs[0].proj;
+        io.td_index = d.midx;
+        io.td_stride = (int)sizeof(ptam_pvs_result);
+        rc = pose_launch_chain(ctx, ncc, &d.ctl->n_meas_coarse, d.meas, d.entry, d.pose, &g, nullptr, io);
+        if (rc) return rc;
+    }
+    // ---- fine stage :571-643 ----
+    hipLaunchKernelGGL(tm_query_kernel, dim3(g256), dim3(256), 0, st, ctx->cam, d, 1, 0u);
+    rc = patch_launch_search_dev(ctx, cur, n, d.q, d.tmpl, d.r, d.ctl->range_hf);
+    if (rc) return rc;
+    rc = patch_launch_subpix_dev(ctx, cur, n, d.q, d.r, d.tmpl, d.sr, d.ctl->range_h, 8);   // :576
+    if (rc) return rc;
+    hipLaunchKernelGGL(tm_gather_kernel, dim3(1), dim3(1024), 0, st, d, 1, o.coarse_subpix_its, o.coarse_min);
+    {
+        ptam_gn_opts g;
+        ptam_gn_opts_default(&g);       // fine schedule :613-643
+        g.estimator = o.estimator;
+        PoseChainIo io{};
+        io.depth_out = d.ctl->depth;
+        rc = pose_launch_chain(ctx, std::max(n, 1), &d.ctl->n_meas, d.meas, d.entry, d.pose, &g, d.outlier, io);
+        if (rc) return rc;
+    }
+    const unsigned long long seq = ++t->seq;
+    hipLaunchKernelGGL(tm_finish_kernel, dim3(1), dim3(1), 0, st, d, t->mbox_dev, seq);
+    HIP_TRY(hipGetLastError());
+    unsigned spins = 0;
+    while (*(volatile unsigned long long*)&t->mbox->seq != seq) {
+        if (++spins == 100000) {
+            spins = 0;
+            const hipError_t q = hipStreamQuery(st);
+            if (q != hipSuccess && q != hipErrorNotReady) {
+                ptam_set_error("track_map: stream failed: %s", hipGetErrorString(q));
+                return PTAM_E_HIP;
+            }
+            if (q == hipSuccess && *(volatile unsigned long long*)&t->mbox->seq != seq) return PTAM_E_HIP;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    std::memcpy(out, (const void*)&t->mbox->res, sizeof *out);
+    return PTAM_OK;
+}
+
+int ptam_tracker_read_iteration_set(ptam_tracker* t, ptam_trackmap_meas* out, int cap, int* n_out) {
+    ARG_TRY(t && n_out);
+    ptam_ctx* ctx = t->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(ptam_stream_wait(ctx->stream));
+    TmCtl c;
+    HIP_TRY(hipMemcpy(&c, t->d.ctl, sizeof c, hipMemcpyDeviceToHost));
+    const int ns = c.n_slots;
+    *n_out = ns;
+    if (!out || ns == 0) return PTAM_OK;
+    std::vector<int> list((size_t)ns), sf((size_t)ns), ss((size_t)ns), ms((size_t)std::max(c.n_meas, 1)), ou((size_t)std::max(c.n_meas, 1));
+    std::vector<ptam_patch_query> q((size_t)ns);
+    std::vector<double2> v2((size_t)ns);
+    HIP_TRY(hipMemcpy(list.data(), t->d.list, (size_t)ns * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(sf.data(), t->d.slot_found, (size_t)ns * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ss.data(), t->d.slot_subpix, (size_t)ns * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(q.data(), t->d.q, (size_t)ns * sizeof(ptam_patch_query), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(v2.data(), t->d.slot_v2, (size_t)ns * 16, hipMemcpyDeviceToHost));
+    if (c.n_meas > 0) {
+        HIP_TRY(hipMemcpy(ms.data(), t->d.mslot, (size_t)c.n_meas * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(ou.data(), t->d.outlier, (size_t)c.n_meas * 4, hipMemcpyDeviceToHost));
+    }
+    for (int s = 0; s < ns && s < cap; s++) {
+        ptam_trackmap_meas& m = out[s];
+        m.point = list[(size_t)s];
+        m.level = q[(size_t)s].level;
+        m.found = sf[(size_t)s];
+        m.did_subpix = ss[(size_t)s];
+        m.outlier = 0;
+        m.pad_ = 0;
+        m.v2_found[0] = v2[(size_t)s].x;
+        m.v2_found[1] = v2[(size_t)s].y;
+    }
+    for (int k = 0; k < c.n_meas; k++)
+        if (ms[(size_t)k] < cap) out[ms[(size_t)k]].outlier = ou[(size_t)k];
+    return PTAM_OK;
+}
+
+}   // extern "C"
+
+void trackmap_preload_kernels() {
+    ptam_preload((const void*)tm_set_pose_kernel);
+    ptam_preload((const void*)tm_select_kernel);
+    ptam_preload((const void*)tm_prep_kernel);
+    ptam_preload((const void*)tm_query_kernel);
+    ptam_preload((const void*)tm_gather_kernel);
+    ptam_preload((const void*)tm_finish_kernel);
+}

@@ -36,6 +36,14 @@ PVS_POINT_DT = np.dtype([("world", "<f8", (3,)), ("pixel_right_w", "<f8", (3,)),
 PVS_RESULT_DT = np.dtype([("proj", PROJECTION_DT), ("warp_inverse", "<f8", (4,)), ("level", "<i4"), ("pad_", "<i4")])
 BA_TRIAL_DT = np.dtype([("lambda", "<f8"), ("sigma_sq", "<f8"), ("err_old", "<f8"), ("err_new", "<f8"),
                         ("sum_sq_update", "<f8"), ("n_bad", "<i4"), ("accepted", "<i4")])
+TRACKMAP_OPTS_DT = np.dtype([("try_coarse", "<i4"), ("coarse_min", "<u4"), ("coarse_max", "<u4"), ("coarse_range", "<u4"),
+                             ("coarse_subpix_its", "<i4"), ("max_patches", "<i4"), ("estimator", "<i4"), ("pad_", "<i4")])
+TRACKMAP_RESULT_DT = np.dtype([("pose", "<f8", (12,)), ("did_coarse", "<i4"), ("n_pvs", "<i4", (4,)), ("attempted", "<i4", (4,)),
+                               ("found", "<i4", (4,)), ("n_coarse", "<i4"), ("n_top", "<i4"), ("n_fine", "<i4"), ("n_meas", "<i4"),
+                               ("depth_n", "<i4"), ("depth_sum", "<f8"), ("depth_sum_sq", "<f8")])
+TRACKMAP_MEAS_DT = np.dtype([("point", "<i4"), ("level", "<i4"), ("found", "<i4"), ("did_subpix", "<i4"), ("outlier", "<i4"),
+                             ("pad_", "<i4"), ("v2_found", "<f8", (2,))])
+assert TRACKMAP_RESULT_DT.itemsize == 96 + 4 * 18 + 16 and TRACKMAP_MEAS_DT.itemsize == 40
 assert PATCH_RESULT_DT.itemsize == C.sizeof(PatchResult)
 assert PROJECTION_DT.itemsize == C.sizeof(Projection)
 assert POSE_MEAS_DT.itemsize == C.sizeof(PoseMeas)
@@ -140,6 +148,30 @@ class Context:
         self._check(self.lib.pose_gn(self.h, n, _ptr(meas), _ptr(entry), _pd(pose), C.byref(opts),
                                      _ptr(flags), _ptr(updates)), "pose_gn")
         return pose, flags, updates
+
+    def pose_gn_state(self, world, found, sqrt_inv_noise, pose, opts=None, entry=None):
+        """pose_gn that also returns the measurements' TrackerData state at loop exit (ptam_pose_gn_state)"""
+        n = len(world)
+        meas = np.zeros(n, dtype=POSE_MEAS_DT)
+        meas["world"], meas["found"], meas["sqrt_inv_noise"] = world, found, sqrt_inv_noise
+        pose = np.array(pose, dtype=np.float64).reshape(12).copy()
+        opts = opts or self.gn_opts()
+        flags = np.zeros(n, dtype=np.int32)
+        updates = np.zeros((opts.iterations, 6))
+        state = np.zeros(n, dtype=PROJECTION_DT)
+        if entry is not None:
+            entry = np.ascontiguousarray(entry, dtype=PROJECTION_DT)
+        self._check(self.lib.pose_gn_state(self.h, n, _ptr(meas), _ptr(entry), _pd(pose), C.byref(opts), _ptr(flags),
+                                           _ptr(updates), _ptr(state)), "pose_gn_state")
+        return pose, flags, updates, state
+
+    def reproject_points(self, world, pose, state):
+        """TrackerData::Project on existing state (ptam_reproject_points) -> updated copy of `state`"""
+        world = np.ascontiguousarray(world, dtype=np.float64).reshape(-1, 3)
+        pose = np.ascontiguousarray(pose, dtype=np.float64).reshape(12)
+        st = np.ascontiguousarray(state, dtype=PROJECTION_DT).copy()
+        self._check(self.lib.reproject_points(self.h, len(world), _ptr(world), _pd(pose), _ptr(st)), "reproject_points")
+        return st
 
     # -- Tracker::CalcPoseUpdate (src/Tracker.cc:928-1005) --
     def calc_pose_update(self, found, image, sqrt_inv_noise, jac, override_sigma_sq=0.0,
@@ -304,6 +336,63 @@ class DevBuf:
         if self.p:
             self.ctx.lib.dev_free(self.ctx.h, self.p)
             self.p = None
+
+
+class Tracker:
+    """Tracker::TrackMap (src/Tracker.cc:442-696) as one device-resident chain (ptam_tracker_* / ptam_track_map): the map
+    stays on the device, a frame is one call."""
+
+    def __init__(self, ctx, max_points):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.h = C.c_void_p()
+        ctx._check(self.lib.tracker_create(ctx.h, int(max_points), C.byref(self.h)), "tracker_create")
+        self._keep = []
+
+    def set_map(self, world, pixel_right_w, pixel_down_w, src_kfs, src_levels, centers):
+        n = len(world)
+        pts = np.zeros(n, dtype=PVS_POINT_DT)
+        pts["world"], pts["pixel_right_w"], pts["pixel_down_w"] = world, pixel_right_w, pixel_down_w
+        q = np.zeros(n, dtype=TEMPLATE_QUERY_DT)
+        kfs = [src_kfs] * n if isinstance(src_kfs, KeyFrame) else list(src_kfs)
+        self._keep = kfs
+        q["src_kf"] = [k.h.value if hasattr(k.h, "value") else int(k.h) for k in kfs]
+        q["src_level"] = src_levels
+        c = np.asarray(centers, dtype=np.int32).reshape(n, 2)
+        q["center_x"], q["center_y"] = c[:, 0], c[:, 1]
+        self.ctx._check(self.lib.tracker_set_map(self.h, n, _ptr(pts), _ptr(q)), "tracker_set_map")
+        self.n = n
+
+    def set_shuffle(self, shuffle_levels, shuffle_fine):
+        a = np.ascontiguousarray(shuffle_levels, dtype=np.int32)
+        b = np.ascontiguousarray(shuffle_fine, dtype=np.int32)
+        self.ctx._check(self.lib.tracker_set_shuffle(self.h, _ptr(a), _ptr(b)), "tracker_set_shuffle")
+
+    def opts(self, **kw):
+        o = np.zeros(1, dtype=TRACKMAP_OPTS_DT)
+        self.lib.trackmap_opts_default(_ptr(o))
+        for k, v in kw.items():
+            o[k] = v
+        return o
+
+    def TrackMap(self, kf, pose, opts=None):
+        """-> structured scalar (TRACKMAP_RESULT_DT)"""
+        pose = np.ascontiguousarray(pose, dtype=np.float64).reshape(12)
+        res = np.zeros(1, dtype=TRACKMAP_RESULT_DT)
+        self.ctx._check(self.lib.track_map(self.h, kf.h, _pd(pose), _ptr(opts) if opts is not None else None, _ptr(res)), "track_map")
+        return res[0]
+
+    def iteration_set(self):
+        n = C.c_int()
+        self.ctx._check(self.lib.tracker_read_iteration_set(self.h, None, 0, C.byref(n)), "tracker_read_iteration_set")
+        out = np.zeros(n.value, dtype=TRACKMAP_MEAS_DT)
+        if n.value:
+            self.ctx._check(self.lib.tracker_read_iteration_set(self.h, _ptr(out), n.value, C.byref(n)), "tracker_read_iteration_set")
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tracker_destroy(self.h)
+            self.h = None
 
 
 class FrameTracker:

@@ -206,6 +206,63 @@ def make_pvs_case(n=4000, seed=0x5EED0007, camera=DEFAULT_CAMERA, size=(640, 480
     return {"world": world, "pixel_right_w": right, "pixel_down_w": down, "pose": cur_pose}
 
 
+def make_trackmap_case(levels_a, counts=(800, 300, 80, 40), seed=0x5EED000A, camera=DEFAULT_CAMERA, size=(640, 480),
+                       shift=(3, -2), height=1.5, pose_noise=(0.004, 0.004), n_junk=24):
+    """A map for Tracker::TrackMap against the synthetic frame pair: the source keyframe (frame A) looks straight down at the
+    plane z = 0 from `height`; every map point is the back-projection of a FAST corner of frame A at its pyramid level
+    (`counts` corners of levels 0..3), with the world-frame one-pixel-right / -down vectors of that level
+    (MapPoint::RefreshPixelVectors, src/Map.cc:40-65).  The current frame (frame B = A shifted by `shift` pixels) corresponds
+    to a camera translation parallel to the plane; `pose_in` is that pose perturbed by N(0, pose_noise) (m, rad) — the
+    motion model's prediction.  A few junk points (behind the camera, outside the view, absurd pixel vectors) ride along.
+    levels_a: KeyFrame.level(l) of frame A for l = 0..3."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    cam = AtanCam(camera, size)
+    src_pose = np.concatenate([np.diag([1.0, -1.0, -1.0]).reshape(9), [0, 0, height]])
+    R, t = src_pose[:9].reshape(3, 3), src_pose[9:]
+
+    def back_project(px0):                      # level-0 pixel -> world point on the plane
+        xy = cam.unproject(px0)
+        camc = np.column_stack([xy * height, np.full(len(xy), height)])
+        return (camc - t) @ R                   # R^T (c - t)
+
+    world, right, down, lev, cen = [], [], [], [], []
+    for l, n_l in enumerate(counts):
+        c = levels_a[l]["corners"]
+        hh, ww = levels_a[l]["im"].shape
+        m = 14
+        c = c[(c[:, 0] >= m) & (c[:, 1] >= m) & (c[:, 0] < ww - m) & (c[:, 1] < hh - m)]
+        c = c[rng.permutation(len(c))[:n_l]]
+        s_ = float(1 << l)
+        p0 = (c + 0.5) * s_ - 0.5               # LevelZeroPos
+        w0 = back_project(p0)
+        world.append(w0)
+        right.append(back_project(p0 + [s_, 0.0]) - w0)
+        down.append(back_project(p0 + [0.0, s_]) - w0)
+        lev.append(np.full(len(c), l, np.int32))
+        cen.append(c.astype(np.int32))
+    world, right, down = np.vstack(world), np.vstack(right), np.vstack(down)
+    lev, cen = np.concatenate(lev), np.vstack(cen)
+    # junk: behind the camera / far outside / degenerate warps
+    j = n_junk
+    jw = np.column_stack([rng.uniform(-6, 6, j), rng.uniform(-6, 6, j), rng.uniform(-1, 4, j)])
+    jr = rng.normal(0, 1, (j, 3)) * rng.choice([1e-6, 1e-3, 1.0], j)[:, None]
+    jd = rng.normal(0, 1, (j, 3)) * rng.choice([1e-6, 1e-3, 1.0], j)[:, None]
+    world, right, down = np.vstack([world, jw]), np.vstack([right, jr]), np.vstack([down, jd])
+    lev = np.concatenate([lev, rng.integers(0, 4, j).astype(np.int32)])
+    cen = np.vstack([cen, np.column_stack([rng.integers(14, 60, j), rng.integers(14, 40, j)]).astype(np.int32)])
+    perm = rng.permutation(len(world))          # map order is not level order
+    world, right, down, lev, cen = world[perm], right[perm], down[perm], lev[perm], cen[perm]
+    # current pose: the scene moves by `shift` pixels in the image
+    tcam = np.array([shift[0] * height / cam.focal[0], shift[1] * height / cam.focal[1], 0.0])
+    cur_pose = se3_mul(np.concatenate([np.eye(3).reshape(9), tcam]), src_pose)
+    xi = np.concatenate([rng.normal(0, pose_noise[0], 3), rng.normal(0, pose_noise[1], 3)])
+    pose_in = se3_mul(se3_exp(xi), cur_pose)
+    n = len(world)
+    return {"world": world, "pixel_right_w": right, "pixel_down_w": down, "src_level": lev, "center": cen,
+            "src_pose": src_pose, "cur_pose": cur_pose, "pose_in": pose_in,
+            "shuffle_levels": rng.permutation(n).astype(np.int32), "shuffle_fine": rng.permutation(n).astype(np.int32)}
+
+
 def make_template_cases(size, n=600, seed=0x5EED0008):
     """Inputs of PatchFinder::MakeTemplateCoarseCont against a keyframe of level-0 size `size` (w, h): source level
     (50/25/15/10 mix), patch centre at that level (mostly interior, some hugging the border so that the walk
