@@ -125,17 +125,96 @@ def tracking_bench(hip, host, synth, frames=250):
     ref = pose.copy()
     chk(hip.pose_gn(ctx.h, n, meas.ctypes.data, None, ref.ctypes.data_as(C.POINTER(C.c_double)), C.byref(opts), None, None), "pose")
     assert np.array_equal(ref, pose_out), "device-resident pose solve differs from the host entry"
+    # ---- the resident TrackMap chain (ptam_track_map, src/Tracker.cc:442-696): one dependent pipeline per frame —
+    # pyramid + FAST of the new frame, PVS over the map, set choice, warped templates, coarse search (range 30) + sub-pixel,
+    # ten coarse pose iterations, re-projection, fine search (+ sub-pixel on the top level), gather, ten fine pose iterations.
+    # The pose solves consume what the searches of the same frame found.
+    chain = trackmap_bench(hip, host, synth, ctx, kfa, b, d_im, frames)
     for p in (d_im, d_q, d_t, d_r):
         hip.dev_free(ctx.h, p)
     for bfr in (d_w, d_gm, d_gi, d_gc, d_pm, d_pn, d_pp):
         bfr.free()
-    return {"tracked_fps": 1.0 / stage["frame"], "frame_us": stage["frame"] * 1e6,
+    return {"tracked_fps": chain["fps"], "frame_us": chain["frame_us"], "frame_chain": chain,
+            "fine_stage_only_fps": 1.0 / stage["frame"], "fine_stage_only_frame_us": stage["frame"] * 1e6,
             "keyframe_us": stage["keyframe"] * 1e6, "keyframe_plus_patch_us": stage["patch"] * 1e6,
             "pose_gn_us": stage["pose_dev"] * 1e6, "pose_gn_host_buffers_us": stage["pose"] * 1e6,
             "frame_host_staged_pose_us": stage["frame_staged"] * 1e6,
             "gather_us": stage["gather"] * 1e6,
             "frame_us_min_max_of_5_blocks": [spread["frame"][0] * 1e6, spread["frame"][1] * 1e6], "patches_per_frame": int(len(q)), "pose_meas": int(n),
-            "note": "frame = pyramid + FAST + 1000-patch ZMSSD search + measurement gather + 10-iteration pose solve, device resident"}
+            "note": "tracked_fps / frame_us = the resident TrackMap chain (frame_chain); fine_stage_only_* = round 1's frame: pyramid + FAST + "
+                    "1000-patch search + gather + one 10-iteration pose solve fed from a separate pose case"}
+
+
+def trackmap_bench(hip, host, synth, ctx, kfa, frame_b, d_im, frames):
+    import threading
+    C = ctypes
+    case = synth.make_trackmap_case([kfa.level(l) for l in range(4)])
+
+    def make(ctx_, kfa_):
+        tr = host.Tracker(ctx_, len(case["world"]))
+        tr.set_map(case["world"], case["pixel_right_w"], case["pixel_down_w"], kfa_, case["src_level"], case["center"])
+        return tr
+
+    tr = make(ctx, kfa)
+    kfb = host.KeyFrame(ctx)
+    opts = tr.opts()
+    pose = np.ascontiguousarray(case["pose_in"])
+    res = None
+
+    def frame(ctx_, kf_, tr_, d_im_):
+        ctx_._check(hip.make_keyframe_lite_dev(ctx_.h, kf_.h, d_im_), "kf")
+        tr_.set_shuffle(case["shuffle_levels"], case["shuffle_fine"])     # the frame's random orders travel with it
+        return tr_.TrackMap(kf_, pose, opts)
+
+    for _ in range(30):
+        res = frame(ctx, kfb, tr, d_im)
+    blocks = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for _ in range(frames // 5):
+            res = frame(ctx, kfb, tr, d_im)
+        blocks.append((time.perf_counter() - t0) / (frames // 5))
+    blocks.sort()
+    out = {"fps": 1.0 / blocks[2], "frame_us": blocks[2] * 1e6, "frame_us_min_max_of_5_blocks": [blocks[0] * 1e6, blocks[-1] * 1e6],
+           "map_points": int(len(case["world"])), "did_coarse": int(res["did_coarse"]), "n_coarse": int(res["n_coarse"]),
+           "n_top": int(res["n_top"]), "n_fine": int(res["n_fine"]), "patches_searched": int(sum(res["attempted"])),
+           "patches_found": int(res["n_meas"]),
+           "pose_err_in_out": [float(np.abs(case["pose_in"] - case["cur_pose"]).max()), float(np.abs(res["pose"] - case["cur_pose"]).max())]}
+    tr.close()
+    # replicas (frames scale as independent units): k contexts, each with its own stream, map and keyframes,
+    # driven by k host threads; aggregate frames/s
+    conc = {}
+    for k in (1, 8, 32):
+        workers = []
+        for _ in range(k):
+            cx = host.Context(lib=hip)
+            ka = host.KeyFrame(cx).MakeKeyFrame_Lite(synth.make_frame_pair()[0])
+            di = host.DevBuf(cx, frame_b)
+            workers.append((cx, ka, host.KeyFrame(cx), make(cx, ka), di))
+        nf = max(20, 400 // k)
+
+        def run(w):
+            cx, _, kb, t_, di = w
+            for _ in range(nf):
+                frame(cx, kb, t_, di.p)
+
+        for w in workers:
+            frame(w[0], w[2], w[3], w[4].p)
+        th = [threading.Thread(target=run, args=(w,)) for w in workers]
+        t0 = time.perf_counter()
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        conc[str(k)] = k * nf / (time.perf_counter() - t0)
+        for cx, ka, kb, t_, di in workers:
+            t_.close()
+            di.free()
+            kb.close()
+            ka.close()
+            cx.close()
+    out["aggregate_fps_by_concurrent_contexts"] = conc
+    return out
 
 
 def cpu_model():

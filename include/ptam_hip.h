@@ -247,6 +247,23 @@ typedef struct {
 int ptam_track_pvs(ptam_ctx* ctx, int n, const ptam_pvs_point* points, const double pose[12],
                    ptam_pvs_result* results, int32_t counts[4]);
 
+/* ---- MapMaker::ReFind_Common (src/MapMaker.cc:943-1020) for a batch of map points against ONE keyframe — the loop of
+ *      ReFindInSingleKeyFrame (:1027-1042), and per keyframe of ReFindNewlyMade / ReFindFromFailureQueue  (SURVEY §8f rank 4).
+ *      Per point: projection into the keyframe with the visibility tests of :950-975, camera derivatives,
+ *      CalcSearchLevelAndWarpMatrix (its verdict is not looked at by the reference: the template is made at the level the
+ *      loop stopped at and only CVD::transform's outside count decides TemplateBad, :979-986), FindPatchCoarse with range 4
+ *      (:988), and for level > 0 the sub-pixel refinement whose convergence flag the reference ignores (:1000-1006).
+ *      The set bookkeeping (sMeasurementKFs / sNeverRetryKFs tests of :947-948, inserts) stays with the caller. */
+typedef struct {
+    int32_t found;          /* return value: a measurement {level, root_pos, sub_pix, SRC_REFIND} is to be added */
+    int32_t level;          /* m.nLevel = Finder.GetLevel(); -1 when the point never reached the PatchFinder */
+    int32_t sub_pix;        /* m.bSubPix */
+    int32_t never_retry;    /* the point-keyframe pair goes into sNeverRetryKFs (every failure path of the reference) */
+    double root_pos[2];     /* m.v2RootPos, level-0 pixels (valid iff found) */
+} ptam_refind_result;
+int ptam_refind_batch(ptam_ctx* ctx, const ptam_kf* kf, const double kf_pose[12], int n, const ptam_pvs_point* points,
+                      const ptam_template_query* sources /* src_kf, src_level, center_x / center_y */, ptam_refind_result* out);
+
 /* ---- Tracker pose Gauss-Newton (src/Tracker.cc:613-643 driver, :928-1005 CalcPoseUpdate,
  *      include/Tracker.h:125-142 CalcJacobian/LinearUpdate) ---------------------------------------- */
 typedef struct {

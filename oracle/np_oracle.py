@@ -473,6 +473,45 @@ def track_pvs(cam, pose, world, pixel_right_w, pixel_down_w):
                 counts=counts)
 
 
+def refind(cam, levels_k, pose_k, world, pixel_right_w, pixel_down_w, src_images, centers):
+    """MapMaker::ReFind_Common (src/MapMaker.cc:943-1020) for a batch of points against one keyframe, composed from the
+    pieces above: projection + visibility tests, CalcSearchLevelAndWarpMatrix (whose -1 verdict the reference does not look
+    at: the template is made at the level the loop stopped at), MakeTemplateCoarseCont, FindPatchCoarse with range 4,
+    sub-pixel refinement for level > 0 (convergence ignored).  src_images[i]: the source level image of point i.
+    -> list of dict(found, level, sub_pix, never_retry, root_pos)"""
+    pr = project_points(cam, pose_k, world)
+    R = pose_k[:9].reshape(3, 3)
+    out = []
+    for i in range(len(world)):
+        r = dict(found=0, level=-1, sub_pix=0, never_retry=1, root_pos=np.zeros(2))
+        out.append(r)
+        if not pr["in_image"][i]:
+            continue
+        Xc = pr["cam"][i:i + 1]
+        M = np.stack([pixel_right_w[i:i + 1] @ R.T, pixel_down_w[i:i + 1] @ R.T], axis=1)
+        W = np.einsum("nab,nkb->nak", pr["derivs"][i:i + 1], motion_to_plane(Xc, M))[0]
+        det = W[0, 0] * W[1, 1] - W[0, 1] * W[1, 0]
+        level = 0
+        while det > 3 and level < LEVELS - 1:
+            level += 1
+            det *= 0.25
+        tmpl, tr = make_template_coarse_cont(src_images[i], int(centers[i][0]), int(centers[i][1]), level, W.reshape(4))
+        r["level"] = level
+        if tr["bad"]:
+            continue
+        q = dict(x=int(pr["image"][i][0]), y=int(pr["image"][i][1]), level=level, range=4)
+        res = find_patch_coarse(levels_k, q, tmpl)
+        if not res["found"]:
+            continue
+        r["found"], r["never_retry"] = 1, 0
+        if level > 0:
+            sp = subpix(levels_k, res["pos"], level, tmpl, 8)
+            r["root_pos"], r["sub_pix"] = np.array(sp["pos"], float), 1
+        else:
+            r["root_pos"] = np.array(res["pos"], float)
+    return out
+
+
 def calc_pose_update(found, image, s, J, override=0.0, est="Tukey", prior=100.0):
     """-> (mu, weight_zero_mask)   J: (N,2,6)"""
     if len(found) == 0:

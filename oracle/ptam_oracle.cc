@@ -1587,6 +1587,94 @@ int ptamo_track_pvs(ptamo_ctx* c, int n, const ptam_pvs_point* pts, const double
     return PTAM_OK;
 }
 
+// MapMaker::ReFind_Common src/MapMaker.cc:943-1020 for a batch of map points against ONE keyframe (what
+// ReFindInSingleKeyFrame :1027-1042 loops over).  Per point, statement by statement; the set bookkeeping (sMeasurementKFs,
+// sNeverRetryKFs) is the caller's: `never_retry` says the point went into sNeverRetryKFs.  The static PatchFinder of the
+// reference keeps its last template between calls (:100-111); a batch never repeats a point, so every template is made anew.
+int ptamo_refind_batch(ptamo_ctx* c, const ptamo_kf* k, const double kf_pose[12], int n, const ptam_pvs_point* pts,
+                       const ptam_template_query* src, ptam_refind_result* out) {
+    ATANCamera cam(c->c.cam);
+    const SE3 T = se3_from12(kf_pose);
+    for (int i = 0; i < n; i++) {
+        ptam_refind_result& r = out[i];
+        std::memset(&r, 0, sizeof r);
+        r.level = -1;
+        r.never_retry = 1;
+        double v3Cam[3];
+        se3_apply(T, pts[i].world, v3Cam);                                        // :950
+        if (v3Cam[2] < 0.001) continue;                                            // :951-955
+        const double v2ImPlane[2] = {v3Cam[0] / v3Cam[2], v3Cam[1] / v3Cam[2]};
+        if (v2ImPlane[0] * v2ImPlane[0] + v2ImPlane[1] * v2ImPlane[1] > cam.largest_radius * cam.largest_radius) continue;   // :957-961
+        double v2Image[2];
+        cam.Project(v2ImPlane, v2Image);                                           // :963
+        if (cam.invalid) continue;                                                 // :964-968
+        if (v2Image[0] < 0 || v2Image[1] < 0 || v2Image[0] > cam.size[0] || v2Image[1] > cam.size[1]) continue;   // :970-975
+        double D[4];
+        cam.GetProjectionDerivs(D);                                                // :978
+        // Finder.CalcSearchLevelAndWarpMatrix(p, k.se3CfromW, m2CamDerivs)  :979 — its return value is NOT looked at: a warp
+        // it calls inappropriate (-1) still gets its template made at the level the loop stopped at (src/PatchFinder.cc:52-84)
+        const double dOneOverCameraZ = 1.0 / v3Cam[2];
+        double mr[3], md[3];
+        for (int q = 0; q < 3; q++) {
+            mr[q] = T.R[q * 3] * pts[i].pixel_right_w[0] + T.R[q * 3 + 1] * pts[i].pixel_right_w[1] + T.R[q * 3 + 2] * pts[i].pixel_right_w[2];
+            md[q] = T.R[q * 3] * pts[i].pixel_down_w[0] + T.R[q * 3 + 1] * pts[i].pixel_down_w[1] + T.R[q * 3 + 2] * pts[i].pixel_down_w[2];
+        }
+        double W[4];
+        {
+            const double ax = (mr[0] - v3Cam[0] * mr[2] * dOneOverCameraZ) * dOneOverCameraZ;
+            const double ay = (mr[1] - v3Cam[1] * mr[2] * dOneOverCameraZ) * dOneOverCameraZ;
+            W[0] = D[0] * ax + D[1] * ay;
+            W[2] = D[2] * ax + D[3] * ay;
+            const double bx = (md[0] - v3Cam[0] * md[2] * dOneOverCameraZ) * dOneOverCameraZ;
+            const double by = (md[1] - v3Cam[1] * md[2] * dOneOverCameraZ) * dOneOverCameraZ;
+            W[1] = D[0] * bx + D[1] * by;
+            W[3] = D[2] * bx + D[3] * by;
+        }
+        double dDet = W[0] * W[3] - W[1] * W[2];
+        int level = 0;
+        while (dDet > 3 && level < PTAM_LEVELS - 1) {
+            level++;
+            dDet *= 0.25;
+        }
+        // Finder.MakeTemplateCoarseCont(p)  :980 ; mbTemplateBad = (bool)nOutside overwrites the verdict above
+        const ptamo_kf* sk = reinterpret_cast<const ptamo_kf*>(src[i].src_kf);
+        if (!sk || src[i].src_level < 0 || src[i].src_level >= PTAM_LEVELS) return PTAM_E_ARG;
+        uint8_t tmpl[64];
+        ptam_template_result tr;
+        std::memset(&tr, 0, sizeof tr);
+        make_template_coarse_cont(sk->kf.lev[src[i].src_level], src[i].center_x, src[i].center_y, level, W, tmpl, tr);
+        r.level = level;
+        if (tr.bad) continue;                                                      // :982-986
+        ptam_patch_query q;
+        q.x = (int)v2Image[0];                                                     // ir(v2Image) :988
+        q.y = (int)v2Image[1];
+        q.level = level;
+        q.range = 4;
+        ptam_patch_result pr;
+        find_patch_coarse(k->kf, q, tmpl, pr);
+        if (!pr.found) continue;                                                   // :989-993
+        r.never_retry = 0;
+        r.found = 1;
+        if (level > 0) {                                                           // :1000-1006 (convergence is not looked at)
+            ptam_subpix_query sq;
+            sq.coarse_pos[0] = pr.pos[0];
+            sq.coarse_pos[1] = pr.pos[1];
+            sq.level = level;
+            sq.max_its = 8;
+            ptam_subpix_result sr;
+            subpix_refine(k->kf, sq, tmpl, sr);
+            r.root_pos[0] = sr.pos[0];
+            r.root_pos[1] = sr.pos[1];
+            r.sub_pix = 1;
+        } else {                                                                   // :1007-1011
+            r.root_pos[0] = pr.pos[0];
+            r.root_pos[1] = pr.pos[1];
+            r.sub_pix = 0;
+        }
+    }
+    return PTAM_OK;
+}
+
 void ptamo_gn_opts_default(ptam_gn_opts* o) {
     o->iterations = 10;
     o->nonlinear_mask = 0x211;

@@ -334,6 +334,105 @@ __global__ void __launch_bounds__(1024) tm_gather_kernel(TmDev d, int stage, int
     }
 }
 
+// ---- MapMaker::ReFind_Common (src/MapMaker.cc:943-1020), batched over the map points of one keyframe ----
+// stage 1: projection + visibility tests (:950-975), derivatives, CalcSearchLevelAndWarpMatrix (:979, verdict unused),
+// the template job at the level its loop stopped at, and the search query ir(v2Image), range 4 (:988)
+__global__ void __launch_bounds__(256) refind_prep_kernel(DevCam cam, int n, const ptam_pvs_point* __restrict__ pts,
+                                                          const TmSrc* __restrict__ src, const double* __restrict__ pose,
+                                                          TemplateJob* __restrict__ jobs, ptam_patch_query* __restrict__ q) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = pose[k];
+    const ptam_pvs_point p = pts[i];
+    TemplateJob j;
+    j.im = nullptr;
+    j.w = j.h = 0;
+    j.search_level = -1;
+    j.cx = j.cy = 0;
+    j.wi[0] = j.wi[1] = j.wi[2] = j.wi[3] = 0;
+    ptam_patch_query qq;
+    qq.x = qq.y = 0;
+    qq.level = -1;
+    qq.range = 4;
+    double X, Y, Z;
+    se3_apply(T, p.world[0], p.world[1], p.world[2], X, Y, Z);
+    if (!(Z < 0.001)) {
+        const double x = X / Z, y = Y / Z;
+        if (!(x * x + y * y > cam.largest_radius * cam.largest_radius)) {
+            double u, v, rr, f;
+            cam_project(cam, x, y, u, v, rr, f);
+            if (!(rr > cam.max_r) && !(u < 0 || v < 0 || u > cam.width || v > cam.height)) {
+                double D[4];
+                cam_derivs(cam, x, y, rr, f, D);
+                const double iz = 1.0 / Z;
+                double mr[3], md[3];
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    mr[a] = T[a * 3] * p.pixel_right_w[0] + T[a * 3 + 1] * p.pixel_right_w[1] + T[a * 3 + 2] * p.pixel_right_w[2];
+                    md[a] = T[a * 3] * p.pixel_down_w[0] + T[a * 3 + 1] * p.pixel_down_w[1] + T[a * 3 + 2] * p.pixel_down_w[2];
+                }
+                const double ax = (mr[0] - X * mr[2] * iz) * iz, ay = (mr[1] - Y * mr[2] * iz) * iz;
+                const double bx = (md[0] - X * md[2] * iz) * iz, by = (md[1] - Y * md[2] * iz) * iz;
+                j.wi[0] = D[0] * ax + D[1] * ay;
+                j.wi[2] = D[2] * ax + D[3] * ay;
+                j.wi[1] = D[0] * bx + D[1] * by;
+                j.wi[3] = D[2] * bx + D[3] * by;
+                double det = j.wi[0] * j.wi[3] - j.wi[1] * j.wi[2];
+                int l = 0;
+                while (det > 3 && l < PTAM_LEVELS - 1) {
+                    l++;
+                    det *= 0.25;
+                }
+                const TmSrc sr = src[i];
+                j.im = sr.im;
+                j.w = sr.w;
+                j.h = sr.h;
+                j.cx = sr.cx;
+                j.cy = sr.cy;
+                j.search_level = l;
+                qq.x = (int)u;   // ir(): truncation
+                qq.y = (int)v;
+                qq.level = l;
+            }
+        }
+    }
+    jobs[i] = j;
+    q[i] = qq;
+}
+// stage 2: Finder.TemplateBad() (:982-986) takes the point out of the search
+__global__ void __launch_bounds__(256) refind_mask_kernel(int n, const ptam_template_result* __restrict__ tres, ptam_patch_query* __restrict__ q) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && q[i].level >= 0 && tres[i].bad) q[i].level = -2 - q[i].level;   // (remembers the level for the report)
+}
+// stage 3: the measurement (:995-1011)
+__global__ void __launch_bounds__(256) refind_finish_kernel(int n, const ptam_patch_query* __restrict__ q, const ptam_patch_result* __restrict__ r,
+                                                            const ptam_subpix_result* __restrict__ sr, ptam_refind_result* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    ptam_refind_result o;
+    const int lv = q[i].level;
+    o.found = 0;
+    o.level = lv >= 0 ? lv : (lv <= -2 ? -2 - lv : -1);
+    o.sub_pix = 0;
+    o.never_retry = 1;
+    o.root_pos[0] = o.root_pos[1] = 0;
+    if (lv >= 0 && r[i].found) {
+        o.found = 1;
+        o.never_retry = 0;
+        if (lv > 0) {   // sub-pixel position whether or not the iteration converged (:1000-1006)
+            o.sub_pix = 1;
+            o.root_pos[0] = sr[i].pos[0];
+            o.root_pos[1] = sr[i].pos[1];
+        } else {
+            o.root_pos[0] = r[i].pos[0];
+            o.root_pos[1] = r[i].pos[1];
+        }
+    }
+    out[i] = o;
+}
+
 struct TmMailbox {
     ptam_trackmap_result res;
     unsigned long long seq;
@@ -661,9 +760,72 @@ int ptam_tracker_read_iteration_set(ptam_tracker* t, ptam_trackmap_meas* out, in
     return PTAM_OK;
 }
 
+int ptam_refind_batch(ptam_ctx* ctx, const ptam_kf* kf, const double kf_pose[12], int n, const ptam_pvs_point* points,
+                      const ptam_template_query* sources, ptam_refind_result* out) {
+    ARG_TRY(ctx && kf && kf_pose && n >= 0);
+    if (n == 0) return PTAM_OK;
+    ARG_TRY(points && sources && out);
+    ARG_TRY(kf->device == ctx->device);
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<TmSrc> hs((size_t)n);
+    for (int i = 0; i < n; i++) {
+        const ptam_template_query& q = sources[i];
+        ARG_TRY(q.src_kf && q.src_level >= 0 && q.src_level < PTAM_LEVELS && q.src_kf->device == ctx->device);
+        hs[(size_t)i].im = q.src_kf->L.im[q.src_level];
+        hs[(size_t)i].w = q.src_kf->L.w[q.src_level];
+        hs[(size_t)i].h = q.src_kf->L.h[q.src_level];
+        hs[(size_t)i].cx = q.center_x;
+        hs[(size_t)i].cy = q.center_y;
+    }
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    const size_t N = (size_t)n;
+    const size_t o_pts = take(N * sizeof(ptam_pvs_point)), o_src = take(N * sizeof(TmSrc)), o_pose = take(96),
+                 o_jobs = take(N * sizeof(TemplateJob)), o_tm = take(N * 64), o_tr = take(N * sizeof(ptam_template_result)),
+                 o_q = take(N * sizeof(ptam_patch_query)), o_r = take(N * sizeof(ptam_patch_result)),
+                 o_sr = take(N * sizeof(ptam_subpix_result)), o_out = take(N * sizeof(ptam_refind_result));
+    void* s;
+    int rc = ctx_scratch(ctx, off, &s);
+    if (rc) return rc;
+    char* b = (char*)s;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(b + o_pts, points, N * sizeof(ptam_pvs_point), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b + o_src, hs.data(), N * sizeof(TmSrc), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b + o_pose, kf_pose, 96, hipMemcpyHostToDevice, st));
+    const int g = (n + 255) / 256;
+    TemplateJob* d_jobs = (TemplateJob*)(b + o_jobs);
+    ptam_patch_query* d_q = (ptam_patch_query*)(b + o_q);
+    ptam_patch_result* d_r = (ptam_patch_result*)(b + o_r);
+    ptam_subpix_result* d_sr = (ptam_subpix_result*)(b + o_sr);
+    ptam_template_result* d_tr = (ptam_template_result*)(b + o_tr);
+    uint8_t* d_tm = (uint8_t*)(b + o_tm);
+    hipLaunchKernelGGL(refind_prep_kernel, dim3(g), dim3(256), 0, st, ctx->cam, n, (const ptam_pvs_point*)(b + o_pts), (const TmSrc*)(b + o_src),
+                       (const double*)(b + o_pose), d_jobs, d_q);
+    rc = patch_launch_templates_dev(ctx, n, d_jobs, d_tm, d_tr, nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(refind_mask_kernel, dim3(g), dim3(256), 0, st, n, (const ptam_template_result*)d_tr, d_q);
+    rc = patch_launch_search_dev(ctx, kf, n, d_q, d_tm, d_r, nullptr);
+    if (rc) return rc;
+    rc = patch_launch_subpix_dev(ctx, kf, n, d_q, d_r, d_tm, d_sr, nullptr, 8);
+    if (rc) return rc;
+    hipLaunchKernelGGL(refind_finish_kernel, dim3(g), dim3(256), 0, st, n, (const ptam_patch_query*)d_q, (const ptam_patch_result*)d_r,
+                       (const ptam_subpix_result*)d_sr, (ptam_refind_result*)(b + o_out));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, b + o_out, N * sizeof(ptam_refind_result), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ptam_stream_wait(st));   // (also keeps hs[] alive until its pageable copy has been staged)
+    return PTAM_OK;
+}
+
 }   // extern "C"
 
 void trackmap_preload_kernels() {
+    ptam_preload((const void*)refind_prep_kernel);
+    ptam_preload((const void*)refind_mask_kernel);
+    ptam_preload((const void*)refind_finish_kernel);
     ptam_preload((const void*)tm_set_pose_kernel);
     ptam_preload((const void*)tm_select_kernel);
     ptam_preload((const void*)tm_prep_kernel);

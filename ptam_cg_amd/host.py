@@ -36,6 +36,7 @@ PVS_POINT_DT = np.dtype([("world", "<f8", (3,)), ("pixel_right_w", "<f8", (3,)),
 PVS_RESULT_DT = np.dtype([("proj", PROJECTION_DT), ("warp_inverse", "<f8", (4,)), ("level", "<i4"), ("pad_", "<i4")])
 BA_TRIAL_DT = np.dtype([("lambda", "<f8"), ("sigma_sq", "<f8"), ("err_old", "<f8"), ("err_new", "<f8"),
                         ("sum_sq_update", "<f8"), ("n_bad", "<i4"), ("accepted", "<i4")])
+REFIND_RESULT_DT = np.dtype([("found", "<i4"), ("level", "<i4"), ("sub_pix", "<i4"), ("never_retry", "<i4"), ("root_pos", "<f8", (2,))])
 TRACKMAP_OPTS_DT = np.dtype([("try_coarse", "<i4"), ("coarse_min", "<u4"), ("coarse_max", "<u4"), ("coarse_range", "<u4"),
                              ("coarse_subpix_its", "<i4"), ("max_patches", "<i4"), ("estimator", "<i4"), ("pad_", "<i4")])
 TRACKMAP_RESULT_DT = np.dtype([("pose", "<f8", (12,)), ("did_coarse", "<i4"), ("n_pvs", "<i4", (4,)), ("attempted", "<i4", (4,)),
@@ -292,6 +293,22 @@ class PatchFinder:
         res = np.zeros(n, dtype=TEMPLATE_RESULT_DT)
         self.ctx._check(self.lib.make_templates_batch(self.ctx.h, n, _ptr(q), _ptr(tm), _ptr(res)), "make_templates_batch")
         return tm, res
+
+    def ReFind(self, kf, kf_pose, world, pixel_right_w, pixel_down_w, src_kfs, src_levels, centers):
+        """MapMaker::ReFind_Common for a batch of map points against one keyframe (src/MapMaker.cc:943-1020)"""
+        n = len(world)
+        pts = np.zeros(n, dtype=PVS_POINT_DT)
+        pts["world"], pts["pixel_right_w"], pts["pixel_down_w"] = world, pixel_right_w, pixel_down_w
+        q = np.zeros(n, dtype=TEMPLATE_QUERY_DT)
+        kfs = [src_kfs] * n if isinstance(src_kfs, KeyFrame) else list(src_kfs)
+        q["src_kf"] = [k.h.value if hasattr(k.h, "value") else int(k.h) for k in kfs]
+        q["src_level"] = src_levels
+        c = np.asarray(centers, dtype=np.int32).reshape(n, 2)
+        q["center_x"], q["center_y"] = c[:, 0], c[:, 1]
+        pose = np.ascontiguousarray(kf_pose, dtype=np.float64).reshape(12)
+        out = np.zeros(n, dtype=REFIND_RESULT_DT)
+        self.ctx._check(self.lib.refind_batch(self.ctx.h, kf.h, _pd(pose), n, _ptr(pts), _ptr(q), _ptr(out)), "refind_batch")
+        return out
 
     def EpipolarSearch(self, src_kf, target_kf, level, queries):
         """the corner scan of MapMaker::AddPointEpipolar (src/MapMaker.cc:598-637) for a batch of candidates"""

@@ -91,6 +91,16 @@ def main():
                         iterations=np.array([r["iterations"] for r in sp], np.int32), pos=np.array([r["pos"] for r in sp]),
                         mean_diff=np.array([r["mean_diff"] for r in sp]))
     print("subpix converged", sum(r["converged"] for r in sp), "of", len(sp))
+    # --- MapMaker::ReFind_Common against frame B of the small pair: map points back-projected from frame A's corners ---
+    rc = synth.make_trackmap_case(la, counts=(160, 60, 12, 0), size=(a.shape[1], a.shape[0]), height=1.5, n_junk=16, seed=0x5EED000B)
+    rr = npo.refind(ncam, lb, rc["cur_pose"], rc["world"], rc["pixel_right_w"], rc["pixel_down_w"],
+                    [la[int(l)]["im"] for l in rc["src_level"]], rc["center"])
+    np.savez_compressed(os.path.join(OUT, "refind_160x128.npz"), im_a=a, im_b=b, pose=rc["cur_pose"], world=rc["world"],
+                        pixel_right_w=rc["pixel_right_w"], pixel_down_w=rc["pixel_down_w"], src_level=rc["src_level"],
+                        center=rc["center"], found=np.array([x["found"] for x in rr], np.int32),
+                        level=np.array([x["level"] for x in rr], np.int32), sub_pix=np.array([x["sub_pix"] for x in rr], np.int32),
+                        never_retry=np.array([x["never_retry"] for x in rr], np.int32), root_pos=np.array([x["root_pos"] for x in rr]))
+    print("refind found", sum(x["found"] for x in rr), "of", len(rr), "levels", np.bincount(np.array([x["level"] for x in rr]) + 1))
     # --- pose Gauss-Newton (fine and coarse schedules) ---
     cam = npo.Camera(CAM, (640, 480))
     # --- PVS loop ---

@@ -43,3 +43,7 @@ def test_pvs(hip):
 
 def test_keyframe_rest(hip):
     G.check_keyframe_rest(hip)
+
+
+def test_refind(hip):
+    G.check_refind(hip)

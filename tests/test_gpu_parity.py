@@ -522,3 +522,23 @@ def test_keyframe_rest_matches_oracle(hip, oracle, case):
         assert np.allclose(out[0][l]["st_scores"], out[1][l]["st_scores"], rtol=1e-12, atol=1e-12)
         assert np.array_equal(out[0][l]["candidates"], out[1][l]["candidates"])
     assert len(out[0][0]["candidates"]) > 0
+
+
+def test_refind_common_matches_oracle(hip, oracle):
+    """MapMaker::ReFind_Common (src/MapMaker.cc:943-1020) batched over the map points of one keyframe: 1244 points of the
+    TrackMap scenario (junk points behind the camera / outside the view / with degenerate pixel vectors included) searched
+    in frame B at its true pose and at a pose a few pixels off (range 4 is tight: many then fail and go to never-retry)"""
+    from tests import golden_util as G
+    out = {}
+    for name, lib in (("hip", hip), ("oracle", oracle)):
+        ctx = host.Context(lib=lib)
+        a, b = synth.make_frame_pair()
+        kfa = host.KeyFrame(ctx).MakeKeyFrame_Lite(a)
+        kfb = host.KeyFrame(ctx).MakeKeyFrame_Lite(b)
+        case = synth.make_trackmap_case([kfa.level(l) for l in range(4)])
+        pf = host.PatchFinder(ctx)
+        out[name] = [pf.ReFind(kfb, pose, case["world"], case["pixel_right_w"], case["pixel_down_w"], kfa, case["src_level"], case["center"])
+                     for pose in (case["cur_pose"], case["pose_in"])]
+    for rh, ro in zip(out["hip"], out["oracle"]):
+        G.assert_refind_equal(rh, ro["found"], ro["level"], ro["sub_pix"], ro["never_retry"], ro["root_pos"])
+    assert out["oracle"][0]["found"].sum() > 1000 and out["oracle"][1]["found"].sum() < out["oracle"][0]["found"].sum()

@@ -41,3 +41,7 @@ def test_pvs(oracle):
 
 def test_keyframe_rest(oracle):
     G.check_keyframe_rest(oracle)
+
+
+def test_refind(oracle):
+    G.check_refind(oracle)
