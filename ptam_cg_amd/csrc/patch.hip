@@ -56,7 +56,8 @@ __device__ __forceinline__ int wave_zmssd(const uint8_t* __restrict__ im, int w,
 // which slots a stage searches
 __global__ void __launch_bounds__(256) zmssd_search_kernel(KfLevels L, int n, const ptam_patch_query* __restrict__ queries,
                                                            const uint8_t* __restrict__ templates,
-                                                           ptam_patch_result* __restrict__ results, const int* __restrict__ d_range) {
+                                                           ptam_patch_result* __restrict__ results, const int* __restrict__ d_range,
+                                                           const ptam_template_result* __restrict__ tres) {
     const int lane = threadIdx.x & 63;
     int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (d_range) {
@@ -73,6 +74,7 @@ __global__ void __launch_bounds__(256) zmssd_search_kernel(KfLevels L, int n, co
     res.pad_ = 0;
     res.pos[0] = res.pos[1] = 0;
     bool search = q.level >= 0 && q.level < PTAM_LEVELS;
+    if (tres && tres[qi].bad) search = false;   // Finder.TemplateBad(): the point is dropped before the search (src/Tracker.cc:876-879)
     int w = 0, h = 0, px = 0, py = 0, nLeft = 0, nRight = 0, i0 = 0, i1 = 0;
     unsigned nRange = 0;
     const uint8_t* im = nullptr;
@@ -471,9 +473,9 @@ int patch_launch_templates_dev(ptam_ctx* ctx, int n_cap, const TemplateJob* d_jo
     return PTAM_OK;
 }
 int patch_launch_search_dev(ptam_ctx* ctx, const ptam_kf* kf, int n_cap, const ptam_patch_query* d_q, const uint8_t* d_tmpl,
-                            ptam_patch_result* d_r, const int* d_range) {
+                            ptam_patch_result* d_r, const int* d_range, const ptam_template_result* d_tres) {
     if (n_cap <= 0) return PTAM_OK;
-    hipLaunchKernelGGL(zmssd_search_kernel, dim3((n_cap + 3) / 4), dim3(256), 0, ctx->stream, kf->L, n_cap, d_q, d_tmpl, d_r, d_range);
+    hipLaunchKernelGGL(zmssd_search_kernel, dim3((n_cap + 3) / 4), dim3(256), 0, ctx->stream, kf->L, n_cap, d_q, d_tmpl, d_r, d_range, d_tres);
     HIP_TRY(hipGetLastError());
     return PTAM_OK;
 }
@@ -517,7 +519,8 @@ int ptam_find_patch_coarse_batch_dev(ptam_ctx* ctx, const ptam_kf* kf, int n, co
     if (n == 0) return PTAM_OK;
     ARG_TRY(d_q && d_t && d_r);
     HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(zmssd_search_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, kf->L, n, d_q, d_t, d_r, (const int*)nullptr);
+    hipLaunchKernelGGL(zmssd_search_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, kf->L, n, d_q, d_t, d_r, (const int*)nullptr,
+                       (const ptam_template_result*)nullptr);
     HIP_TRY(hipGetLastError());
     return PTAM_OK;
 }

@@ -391,7 +391,19 @@ __global__ void __launch_bounds__(GN_THREADS) pose_gn_kernel(DevCam cam, int n, 
             io.depth_out[0] = a;
             io.depth_out[1] = b;
             io.depth_out[2] = (double)n;
+            if (io.result_depth) {
+                io.result_depth[0] = a;
+                io.result_depth[1] = b;
+                io.result_depth[2] = (double)n;
+            }
         }
+    }
+    if (io.result_seq) {   // the frame's last kernel: pose, then the sequence word the host spins on (host-mapped memory)
+        __syncthreads();
+        if (threadIdx.x < 12) io.result_pose[threadIdx.x] = sh.pose[threadIdx.x];
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) *(volatile unsigned long long*)io.result_seq = io.seq;
     }
 }
 
@@ -856,7 +868,19 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
             io.depth_out[0] = a;
             io.depth_out[1] = b;
             io.depth_out[2] = (double)n;
+            if (io.result_depth) {
+                io.result_depth[0] = a;
+                io.result_depth[1] = b;
+                io.result_depth[2] = (double)n;
+            }
         }
+    }
+    if (io.result_seq) {   // the frame's last kernel: pose, then the sequence word the host spins on (host-mapped memory)
+        __syncthreads();
+        if (threadIdx.x < 12) io.result_pose[threadIdx.x] = sh.pose[threadIdx.x];
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) *(volatile unsigned long long*)io.result_seq = io.seq;
     }
     // the refined pose also goes straight into host-mapped memory as (word, sequence) pairs the host spins on: the call
     // returns one PCIe write after the last iteration instead of a D2H copy plus a stream synchronisation later

@@ -6,16 +6,19 @@
 #include "common.h"
 #include "track_internal.h"
 
+// pv.use: the pose travels as a kernel argument (the resident TrackMap chain: the motion model's prediction needs no copy of
+// its own) and block 0 also leaves it in pose_out for the kernels that follow
 __global__ void __launch_bounds__(256) track_pvs_kernel(DevCam cam, int n, const ptam_pvs_point* __restrict__ pts,
                                                         const double* __restrict__ pose, ptam_pvs_result* __restrict__ out,
-                                                        int* __restrict__ counts) {
+                                                        int* __restrict__ counts, PoseArg pv, double* __restrict__ pose_out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int level = -1;
+    if (pv.use && pose_out && blockIdx.x == 0 && threadIdx.x < 12) pose_out[threadIdx.x] = pv.v[threadIdx.x];
     if (i < n) {
         double T[12];
 #pragma unroll
-        for (int k = 0; k < 12; k++) T[k] = pose[k];
+        for (int k = 0; k < 12; k++) T[k] = pv.use ? pv.v[k] : pose[k];
         const ptam_pvs_point p = pts[i];
         ptam_pvs_result r;
         r.proj.image[0] = r.proj.image[1] = 0;
@@ -75,9 +78,15 @@ __global__ void __launch_bounds__(256) track_pvs_kernel(DevCam cam, int n, const
     }
 }
 
-int pvs_launch_dev(ptam_ctx* ctx, int n, const ptam_pvs_point* d_pts, const double* d_pose, ptam_pvs_result* d_out) {
+int pvs_launch_dev(ptam_ctx* ctx, int n, const ptam_pvs_point* d_pts, double* d_pose, const double* host_pose, ptam_pvs_result* d_out) {
     if (n <= 0) return PTAM_OK;
-    hipLaunchKernelGGL(track_pvs_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->cam, n, d_pts, d_pose, d_out, (int*)nullptr);
+    PoseArg pv{};
+    if (host_pose) {
+        std::memcpy(pv.v, host_pose, 96);
+        pv.use = 1;
+    }
+    hipLaunchKernelGGL(track_pvs_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->cam, n, d_pts, (const double*)d_pose, d_out,
+                       (int*)nullptr, pv, d_pose);
     HIP_TRY(hipGetLastError());
     return PTAM_OK;
 }
@@ -100,7 +109,8 @@ extern "C" int ptam_track_pvs(ptam_ctx* ctx, int n, const ptam_pvs_point* points
     HIP_TRY(hipMemcpyAsync(d_p, points, bp, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(d_pose, pose, 96, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemsetAsync(d_c, 0, 16, ctx->stream));
-    hipLaunchKernelGGL(track_pvs_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->cam, n, d_p, d_pose, d_r, d_c);
+    hipLaunchKernelGGL(track_pvs_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->cam, n, d_p, (const double*)d_pose, d_r, d_c, PoseArg{},
+                       (double*)nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(results, d_r, br, hipMemcpyDeviceToHost, ctx->stream));
     if (counts) HIP_TRY(hipMemcpyAsync(counts, d_c, 16, hipMemcpyDeviceToHost, ctx->stream));

@@ -17,13 +17,19 @@ struct TemplateJob {          // device-side form of ptam_template_query (keyfra
 // patch.hip
 int patch_launch_templates_dev(ptam_ctx* ctx, int n_cap, const TemplateJob* d_jobs, uint8_t* d_tmpl, ptam_template_result* d_res,
                                const int* d_range);
+// d_tres (nullable): a query whose template came out bad (Finder.TemplateBad(), src/Tracker.cc:876) is not searched
 int patch_launch_search_dev(ptam_ctx* ctx, const ptam_kf* kf, int n_cap, const ptam_patch_query* d_q, const uint8_t* d_tmpl,
-                            ptam_patch_result* d_r, const int* d_range);
+                            ptam_patch_result* d_r, const int* d_range, const ptam_template_result* d_tres);
 // sub-pixel refinement of the patches the coarse search found (queries taken from the search's own queries / results)
 int patch_launch_subpix_dev(ptam_ctx* ctx, const ptam_kf* kf, int n_cap, const ptam_patch_query* d_q, const ptam_patch_result* d_pr,
                             const uint8_t* d_tmpl, ptam_subpix_result* d_sr, const int* d_range, int max_its);
 // pvs.hip
-int pvs_launch_dev(ptam_ctx* ctx, int n, const ptam_pvs_point* d_pts, const double* d_pose, ptam_pvs_result* d_out);
+struct PoseArg {   // a pose handed over by value
+    double v[12];
+    int use;
+};
+// host_pose (nullable): the pose as a kernel argument, also written to d_pose; otherwise d_pose is read
+int pvs_launch_dev(ptam_ctx* ctx, int n, const ptam_pvs_point* d_pts, double* d_pose, const double* host_pose, ptam_pvs_result* d_out);
 
 // pose.hip: the ten-iteration loop on a measurement list whose length sits in device memory, with the extras of the chain
 struct PoseChainIo {
@@ -34,6 +40,12 @@ struct PoseChainIo {
     int td_stride;
     // scene depth statistics over the measurements (src/Tracker.cc:680-690): {sum z, sum z^2, count}; null: no
     double* depth_out;
+    // the frame's result block in host-mapped memory: the loop's last act is to publish the pose (12 doubles at
+    // result_pose), the depth sums (3 doubles at result_depth) and then the sequence word the host spins on; null: no
+    double* result_pose;
+    double* result_depth;
+    unsigned long long* result_seq;
+    unsigned long long seq;
 };
 int pose_launch_chain(ptam_ctx* ctx, int n_cap, const int* d_n, const ptam_pose_meas* d_meas, const ptam_projection* d_entry,
                       double* d_pose_inout, const ptam_gn_opts* opts, int32_t* d_outlier_flags, const PoseChainIo& io);

@@ -100,12 +100,6 @@ __device__ __forceinline__ void block_scan4(const int v[4], int off[4], int tot[
     __syncthreads();
 }
 
-__global__ void tm_set_pose_kernel(double* pose, TmCtl* ctl, double p0, double p1, double p2, double p3, double p4, double p5,
-                                   double p6, double p7, double p8, double p9, double p10, double p11) {
-    pose[0] = p0, pose[1] = p1, pose[2] = p2, pose[3] = p3, pose[4] = p4, pose[5] = p5;
-    pose[6] = p6, pose[7] = p7, pose[8] = p8, pose[9] = p9, pose[10] = p10, pose[11] = p11;
-}
-
 // The choice of the search sets, src/Tracker.cc:480-611.  One workgroup.
 __global__ void __launch_bounds__(1024) tm_select_kernel(TmDev d, ptam_trackmap_opts o) {
     __shared__ int wsum[4][16];
@@ -185,6 +179,33 @@ __global__ void __launch_bounds__(1024) tm_select_kernel(TmDev d, ptam_trackmap_
             }
         }
     }
+    // template jobs of every slot (MakeTemplateCoarseCont only needs what the PVS pass left: search level, warp) and the
+    // coarse set's search queries ir(v2Image) (:881) — the lists were written by this workgroup: visible after the barrier
+    __syncthreads();
+    const int n_slots = nC + nH + nF;
+    for (int sl = tid; sl < n_slots; sl += 1024) {
+        const int id = d.list[sl];
+        const TmSrc sr = d.src[id];
+        const ptam_pvs_result& pv = d.pvs[id];
+        TemplateJob j;
+        j.im = sr.im;
+        j.w = sr.w;
+        j.h = sr.h;
+        j.search_level = pv.level;
+        j.cx = sr.cx;
+        j.cy = sr.cy;
+#pragma unroll
+        for (int kq = 0; kq < 4; kq++) j.wi[kq] = pv.warp_inverse[kq];
+        d.jobs[sl] = j;
+        if (sl < nC) {
+            ptam_patch_query q;
+            q.x = (int)pv.proj.image[0];   // ir(): truncation
+            q.y = (int)pv.proj.image[1];
+            q.level = pv.level;
+            q.range = o.coarse_range;
+            d.q[sl] = q;
+        }
+    }
     if (tid == 0) {
         TmCtl& c = *d.ctl;
         c.n_lvl[0] = n0, c.n_lvl[1] = n1, c.n_lvl[2] = n2, c.n_lvl[3] = n3;
@@ -202,36 +223,17 @@ __global__ void __launch_bounds__(1024) tm_select_kernel(TmDev d, ptam_trackmap_
     }
 }
 
-// template jobs of every slot: MakeTemplateCoarseCont only needs what the PVS pass left (search level, warp)
-__global__ void __launch_bounds__(256) tm_prep_kernel(TmDev d) {
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= d.ctl->n_slots) return;
-    const int id = d.list[s];
-    const TmSrc sr = d.src[id];
-    const ptam_pvs_result& pv = d.pvs[id];
-    TemplateJob j;
-    j.im = sr.im;
-    j.w = sr.w;
-    j.h = sr.h;
-    j.search_level = pv.level;
-    j.cx = sr.cx;
-    j.cy = sr.cy;
-#pragma unroll
-    for (int k = 0; k < 4; k++) j.wi[k] = pv.warp_inverse[k];
-    d.jobs[s] = j;
-}
-
-// The head of SearchForPoints (src/Tracker.cc:873-881) for a stage's slots: a bad template drops the point, otherwise the
-// search query is ir(v2Image) at the point's search level.  stage 0: the coarse set; stage 1: top-level and fine sets, after
-// TrackerData::Project at the current pose (:573-574 always, :606-608 if the coarse stage counted).
-__global__ void __launch_bounds__(256) tm_query_kernel(DevCam cam, TmDev d, int stage, unsigned coarse_range) {
+// The head of SearchForPoints (src/Tracker.cc:873-881) for the top-level and fine sets: TrackerData::Project at the current
+// pose (:573-574 always, :606-608 if the coarse stage counted), then the search query ir(v2Image) at the point's level.
+// (A bad template drops the point: the search kernel and the gather look at the template result themselves.)
+__global__ void __launch_bounds__(256) tm_query_kernel(DevCam cam, TmDev d) {
     const TmCtl& c = *d.ctl;
-    const int first = stage == 0 ? c.range_c[0] : c.range_hf[0], end = stage == 0 ? c.range_c[1] : c.range_hf[1];
-    const int s = first + blockIdx.x * 256 + threadIdx.x;
-    if (s >= end) return;
+    const int s = c.range_hf[0] + blockIdx.x * 256 + threadIdx.x;
+    if (s >= c.range_hf[1]) return;
     const int id = d.list[s];
     ptam_projection& td = d.pvs[id].proj;
-    if (stage == 1 && (s < c.range_h[1] || c.did_coarse)) {
+    double u = td.image[0], v = td.image[1];
+    if (s < c.range_h[1] || c.did_coarse) {
         // TrackerData::Project include/Tracker.h:70-85 (bFound is false here: the derivatives stay, :89-94)
         const ptam_pvs_point& p = d.pts[id];
         double X, Y, Z;
@@ -241,7 +243,7 @@ __global__ void __launch_bounds__(256) tm_query_kernel(DevCam cam, TmDev d, int 
         if (!(Z < 0.001)) {
             const double x = X / Z, y = Y / Z;
             if (!(x * x + y * y > cam.largest_radius * cam.largest_radius)) {
-                double u, v, rr, f;
+                double rr, f;
                 cam_project(cam, x, y, u, v, rr, f);
                 td.image[0] = u;
                 td.image[1] = v;
@@ -251,61 +253,77 @@ __global__ void __launch_bounds__(256) tm_query_kernel(DevCam cam, TmDev d, int 
         td.in_image = in_image;
     }
     ptam_patch_query q;
-    q.x = (int)td.image[0];   // ir(): truncation
-    q.y = (int)td.image[1];
-    q.range = stage == 0 ? coarse_range : (unsigned)c.fine_range;
+    q.x = (int)u;   // ir(): truncation
+    q.y = (int)v;
+    q.range = (unsigned)c.fine_range;
     q.level = d.jobs[s].search_level;
-    if (d.tres[s].bad) {
-        q.level = -1;   // Finder.TemplateBad(): not attempted, not searched (:876-879)
-        td.in_image = 0;
-    } else
-        atomicAdd(&d.ctl->attempted[q.level], 1);
     d.q[s] = q;
 }
 
 // The tail of SearchForPoints (:883-909) and the measurement list of the pose loop that follows.  One workgroup.
 //   stage 0: status of the coarse slots, nFound, mbDidCoarse, the coarse loop's measurements;
 //   stage 1: status of the other slots, then vIterationSet's found entries in order (coarse, top level, fine).
-__global__ void __launch_bounds__(1024) tm_gather_kernel(TmDev d, int stage, int coarse_its, unsigned coarse_min) {
+struct TmMailbox {
+    ptam_trackmap_result res;
+    double depth3[3];
+    unsigned long long seq;
+};
+__global__ void __launch_bounds__(1024) tm_gather_kernel(TmDev d, int stage, int coarse_its, unsigned coarse_min, TmMailbox* mbox) {
     __shared__ int wsum[4][16];
+    __shared__ int lsum[8][16];
     TmCtl& c = *d.ctl;
-    const int tid = threadIdx.x;
-    const int st_first = stage == 0 ? 0 : c.nC, st_end = stage == 0 ? c.nC : c.n_slots;
-    int lf[4] = {0, 0, 0, 0};
-    for (int s = st_first + tid; s < st_end; s += 1024) {
-        const ptam_patch_query q = d.q[s];
-        const int its = stage == 0 ? coarse_its : (s < c.range_h[1] ? 8 : 0);
-        int found = q.level >= 0 && d.r[s].found;
-        int sub = 0;
-        double2 v2 = make_double2(0, 0);
-        if (found) {
-            if (its > 0) {
-                sub = 1;
-                const ptam_subpix_result sr = d.sr[s];
-                found = sr.converged;   // :898-904
-                v2 = make_double2(sr.pos[0], sr.pos[1]);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // every thread owns a run of consecutive slots for both phases (status, then compaction): what it found out about its
+    // slots stays in registers
+    constexpr int RUN = 4;
+    const int g_end = stage == 0 ? c.nC : c.n_slots;            // slots compacted by this stage
+    const int st_first = stage == 0 ? 0 : c.nC;                 // slots whose status this stage decides
+    const int chunk = (g_end + 1023) / 1024, s0 = min(g_end, tid * chunk), s1 = min(g_end, s0 + chunk);
+    int lf[4] = {0, 0, 0, 0}, la[4] = {0, 0, 0, 0};
+    int cnt[4] = {0, 0, 0, 0};
+    for (int sb = s0; sb < s1; sb += RUN) {
+#pragma unroll
+        for (int u = 0; u < RUN; u++) {
+            const int s = sb + u;
+            if (s >= s1) break;
+            if (s >= st_first) {
+                const ptam_patch_query q = d.q[s];
+                const bool bad = d.tres[s].bad != 0;
+                const int its = stage == 0 ? coarse_its : (s < c.range_h[1] ? 8 : 0);
+                const bool att = q.level >= 0 && !bad;           // manMeasAttempted (:880)
+                int found = att && d.r[s].found;
+                int sub = 0;
+                double2 v2 = make_double2(0, 0);
+                if (found) {
+                    if (its > 0) {
+                        sub = 1;
+                        const ptam_subpix_result sr = d.sr[s];
+                        found = sr.converged;   // :898-904
+                        v2 = make_double2(sr.pos[0], sr.pos[1]);
+                    } else
+                        v2 = make_double2(d.r[s].pos[0], d.r[s].pos[1]);
+                }
+                d.slot_found[s] = found;
+                d.slot_subpix[s] = sub;
+                d.slot_v2[s] = v2;
+                if (att) la[q.level]++;
+                if (found) lf[q.level]++;
+                cnt[0] += found;
             } else
-                v2 = make_double2(d.r[s].pos[0], d.r[s].pos[1]);
+                cnt[0] += d.slot_found[s];   // (coarse slots in the final pass: decided by stage 0)
         }
-        d.slot_found[s] = found;
-        d.slot_subpix[s] = sub;
-        d.slot_v2[s] = v2;
-        if (found) lf[q.level]++;
     }
-    // per-level found counts of this stage (integers: order-free)
+    // per-level attempted / found counts of this stage (integers: order-free)
 #pragma unroll
     for (int l = 0; l < 4; l++) {
-        const int t = wave_sum_i32(lf[l]);
-        if ((tid & 63) == 0 && t) atomicAdd(&c.found[l], t);
+        const int tf = wave_sum_i32(lf[l]), ta = wave_sum_i32(la[l]);
+        if (lane == 63) {
+            lsum[l][wid] = tf;
+            lsum[4 + l][wid] = ta;
+        }
     }
-    __syncthreads();
-    // stable compaction of the found slots
-    const int g_end = stage == 0 ? c.nC : c.n_slots;
-    const int chunk = (g_end + 1023) / 1024, s0 = min(g_end, tid * chunk), s1 = min(g_end, s0 + chunk);
-    int cnt[4] = {0, 0, 0, 0};
-    for (int s = s0; s < s1; s++) cnt[0] += d.slot_found[s];
     int off[4], tot[4];
-    block_scan4(cnt, off, tot, wsum);
+    block_scan4(cnt, off, tot, wsum);   // (its barriers also publish lsum and the slot_* arrays of this workgroup)
     int k = off[0];
     for (int s = s0; s < s1; s++)
         if (d.slot_found[s]) {
@@ -324,13 +342,39 @@ __global__ void __launch_bounds__(1024) tm_gather_kernel(TmDev d, int stage, int
             k++;
         }
     if (tid == 0) {
+        int f4[4], a4[4];
+        for (int l = 0; l < 4; l++) {
+            int tf = 0, ta = 0;
+            for (int w = 0; w < 16; w++) {
+                tf += lsum[l][w];
+                ta += lsum[4 + l][w];
+            }
+            f4[l] = c.found[l] + tf;
+            a4[l] = c.attempted[l] + ta;
+            c.found[l] = f4[l];
+            c.attempted[l] = a4[l];
+        }
         if (stage == 0) {
             c.n_found_coarse = tot[0];
             c.did_coarse = c.do_coarse && (unsigned)tot[0] >= coarse_min;   // :550-551
             c.n_meas_coarse = c.did_coarse ? tot[0] : 0;
             c.fine_range = c.did_coarse ? 5 : 10;                           // :572
-        } else
+        } else {
             c.n_meas = tot[0];
+            // everything of the frame's result but the pose and the depth sums (the fine pose loop publishes those, then
+            // the sequence word)
+            ptam_trackmap_result& r = mbox->res;
+            r.did_coarse = c.did_coarse;
+            for (int l = 0; l < 4; l++) {
+                r.n_pvs[l] = c.n_lvl[l];
+                r.attempted[l] = a4[l];
+                r.found[l] = f4[l];
+            }
+            r.n_coarse = c.nC;
+            r.n_top = c.nH;
+            r.n_fine = c.nF;
+            r.n_meas = tot[0];
+        }
     }
 }
 
@@ -431,32 +475,6 @@ __global__ void __launch_bounds__(256) refind_finish_kernel(int n, const ptam_pa
         }
     }
     out[i] = o;
-}
-
-struct TmMailbox {
-    ptam_trackmap_result res;
-    unsigned long long seq;
-};
-__global__ void tm_finish_kernel(TmDev d, TmMailbox* out, unsigned long long seq) {
-    const TmCtl& c = *d.ctl;
-    ptam_trackmap_result r;
-    for (int k = 0; k < 12; k++) r.pose[k] = d.pose[k];
-    r.did_coarse = c.did_coarse;
-    for (int l = 0; l < 4; l++) {
-        r.n_pvs[l] = c.n_lvl[l];
-        r.attempted[l] = c.attempted[l];
-        r.found[l] = c.found[l];
-    }
-    r.n_coarse = c.nC;
-    r.n_top = c.nH;
-    r.n_fine = c.nF;
-    r.n_meas = c.n_meas;
-    r.depth_n = (int)c.depth[2];
-    r.depth_sum = c.depth[0];
-    r.depth_sum_sq = c.depth[1];
-    out->res = r;
-    __threadfence_system();
-    *(volatile unsigned long long*)&out->seq = seq;
 }
 
 // =================================================================================================
@@ -652,26 +670,21 @@ int ptam_track_map(ptam_tracker* t, const ptam_kf* cur, const double pose_in[12]
     const TmDev& d = t->d;
     const int n = d.n;
     hipStream_t st = ctx->stream;
-    const double* p = pose_in;
-    hipLaunchKernelGGL(tm_set_pose_kernel, dim3(1), dim3(1), 0, st, d.pose, d.ctl, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9],
-                       p[10], p[11]);
-    int rc = pvs_launch_dev(ctx, n, d.pts, d.pose, d.pvs);                              // :453-478
+    int rc = pvs_launch_dev(ctx, n, d.pts, d.pose, pose_in, d.pvs);                     // :453-478 (the pose rides in as an argument)
     if (rc) return rc;
-    hipLaunchKernelGGL(tm_select_kernel, dim3(1), dim3(1024), 0, st, d, o);             // :480-611
+    hipLaunchKernelGGL(tm_select_kernel, dim3(1), dim3(1024), 0, st, d, o);             // :480-611 + template jobs + coarse queries
     const int g256 = std::max(1, (n + 255) / 256);
-    hipLaunchKernelGGL(tm_prep_kernel, dim3(g256), dim3(256), 0, st, d);
     rc = patch_launch_templates_dev(ctx, n, d.jobs, d.tmpl, d.tres, d.ctl->range_all);   // MakeTemplateCoarseCont :873
     if (rc) return rc;
     // ---- coarse stage :519-569 ----
     const int ncc = std::max(1, std::min(n, (int)o.coarse_max));
-    hipLaunchKernelGGL(tm_query_kernel, dim3((ncc + 255) / 256), dim3(256), 0, st, ctx->cam, d, 0, o.coarse_range);
-    rc = patch_launch_search_dev(ctx, cur, ncc, d.q, d.tmpl, d.r, d.ctl->range_c);
+    rc = patch_launch_search_dev(ctx, cur, ncc, d.q, d.tmpl, d.r, d.ctl->range_c, d.tres);
     if (rc) return rc;
     if (o.coarse_subpix_its > 0) {
         rc = patch_launch_subpix_dev(ctx, cur, ncc, d.q, d.r, d.tmpl, d.sr, d.ctl->range_c, o.coarse_subpix_its);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(tm_gather_kernel, dim3(1), dim3(1024), 0, st, d, 0, o.coarse_subpix_its, o.coarse_min);
+    hipLaunchKernelGGL(tm_gather_kernel, dim3(1), dim3(1024), 0, st, d, 0, o.coarse_subpix_its, o.coarse_min, t->mbox_dev);
     {
         ptam_gn_opts g;
         ptam_gn_opts_default(&g);
@@ -687,23 +700,26 @@ int ptam_track_map(ptam_tracker* t, const ptam_kf* cur, const double pose_in[12]
         if (rc) return rc;
     }
     // ---- fine stage :571-643 ----
-    hipLaunchKernelGGL(tm_query_kernel, dim3(g256), dim3(256), 0, st, ctx->cam, d, 1, 0u);
-    rc = patch_launch_search_dev(ctx, cur, n, d.q, d.tmpl, d.r, d.ctl->range_hf);
+    hipLaunchKernelGGL(tm_query_kernel, dim3(g256), dim3(256), 0, st, ctx->cam, d);
+    rc = patch_launch_search_dev(ctx, cur, n, d.q, d.tmpl, d.r, d.ctl->range_hf, d.tres);
     if (rc) return rc;
     rc = patch_launch_subpix_dev(ctx, cur, n, d.q, d.r, d.tmpl, d.sr, d.ctl->range_h, 8);   // :576
     if (rc) return rc;
-    hipLaunchKernelGGL(tm_gather_kernel, dim3(1), dim3(1024), 0, st, d, 1, o.coarse_subpix_its, o.coarse_min);
+    hipLaunchKernelGGL(tm_gather_kernel, dim3(1), dim3(1024), 0, st, d, 1, o.coarse_subpix_its, o.coarse_min, t->mbox_dev);
+    const unsigned long long seq = ++t->seq;
     {
         ptam_gn_opts g;
         ptam_gn_opts_default(&g);       // fine schedule :613-643
         g.estimator = o.estimator;
         PoseChainIo io{};
         io.depth_out = d.ctl->depth;
+        io.result_pose = t->mbox_dev->res.pose;      // the loop's last act: pose + depth sums + sequence word into the mailbox
+        io.result_depth = t->mbox_dev->depth3;
+        io.result_seq = &t->mbox_dev->seq;
+        io.seq = seq;
         rc = pose_launch_chain(ctx, std::max(n, 1), &d.ctl->n_meas, d.meas, d.entry, d.pose, &g, d.outlier, io);
         if (rc) return rc;
     }
-    const unsigned long long seq = ++t->seq;
-    hipLaunchKernelGGL(tm_finish_kernel, dim3(1), dim3(1), 0, st, d, t->mbox_dev, seq);
     HIP_TRY(hipGetLastError());
     unsigned spins = 0;
     while (*(volatile unsigned long long*)&t->mbox->seq != seq) {
@@ -719,6 +735,9 @@ int ptam_track_map(ptam_tracker* t, const ptam_kf* cur, const double pose_in[12]
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     std::memcpy(out, (const void*)&t->mbox->res, sizeof *out);
+    out->depth_sum = t->mbox->depth3[0];
+    out->depth_sum_sq = t->mbox->depth3[1];
+    out->depth_n = (int)t->mbox->depth3[2];
     return PTAM_OK;
 }
 
@@ -734,12 +753,14 @@ int ptam_tracker_read_iteration_set(ptam_tracker* t, ptam_trackmap_meas* out, in
     if (!out || ns == 0) return PTAM_OK;
     std::vector<int> list((size_t)ns), sf((size_t)ns), ss((size_t)ns), ms((size_t)std::max(c.n_meas, 1)), ou((size_t)std::max(c.n_meas, 1));
     std::vector<ptam_patch_query> q((size_t)ns);
+    std::vector<ptam_template_result> tr((size_t)ns);
     std::vector<double2> v2((size_t)ns);
     HIP_TRY(hipMemcpy(list.data(), t->d.list, (size_t)ns * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(sf.data(), t->d.slot_found, (size_t)ns * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(ss.data(), t->d.slot_subpix, (size_t)ns * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(q.data(), t->d.q, (size_t)ns * sizeof(ptam_patch_query), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(v2.data(), t->d.slot_v2, (size_t)ns * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tr.data(), t->d.tres, (size_t)ns * sizeof(ptam_template_result), hipMemcpyDeviceToHost));
     if (c.n_meas > 0) {
         HIP_TRY(hipMemcpy(ms.data(), t->d.mslot, (size_t)c.n_meas * 4, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(ou.data(), t->d.outlier, (size_t)c.n_meas * 4, hipMemcpyDeviceToHost));
@@ -747,7 +768,7 @@ int ptam_tracker_read_iteration_set(ptam_tracker* t, ptam_trackmap_meas* out, in
     for (int s = 0; s < ns && s < cap; s++) {
         ptam_trackmap_meas& m = out[s];
         m.point = list[(size_t)s];
-        m.level = q[(size_t)s].level;
+        m.level = tr[(size_t)s].bad ? -1 : q[(size_t)s].level;   // (a bad template: the point was dropped before the search)
         m.found = sf[(size_t)s];
         m.did_subpix = ss[(size_t)s];
         m.outlier = 0;
@@ -808,7 +829,7 @@ int ptam_refind_batch(ptam_ctx* ctx, const ptam_kf* kf, const double kf_pose[12]
     rc = patch_launch_templates_dev(ctx, n, d_jobs, d_tm, d_tr, nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(refind_mask_kernel, dim3(g), dim3(256), 0, st, n, (const ptam_template_result*)d_tr, d_q);
-    rc = patch_launch_search_dev(ctx, kf, n, d_q, d_tm, d_r, nullptr);
+    rc = patch_launch_search_dev(ctx, kf, n, d_q, d_tm, d_r, nullptr, nullptr);
     if (rc) return rc;
     rc = patch_launch_subpix_dev(ctx, kf, n, d_q, d_r, d_tm, d_sr, nullptr, 8);
     if (rc) return rc;
@@ -826,10 +847,7 @@ void trackmap_preload_kernels() {
     ptam_preload((const void*)refind_prep_kernel);
     ptam_preload((const void*)refind_mask_kernel);
     ptam_preload((const void*)refind_finish_kernel);
-    ptam_preload((const void*)tm_set_pose_kernel);
     ptam_preload((const void*)tm_select_kernel);
-    ptam_preload((const void*)tm_prep_kernel);
     ptam_preload((const void*)tm_query_kernel);
     ptam_preload((const void*)tm_gather_kernel);
-    ptam_preload((const void*)tm_finish_kernel);
 }
