@@ -115,6 +115,39 @@ int main() {
         ptam_dev_free(ctx.handle(), dt);
         ptam_dev_free(ctx.handle(), dw);
     }
+    // the resident TrackMap chain and the batched ReFind_Common on a toy map: the level-0 corners of this keyframe
+    // back-projected (pinhole, Z = 1) as map points seen from the identity pose, their patch source being the keyframe itself
+    {
+        double cc[8];
+        check(ptam_ctx_camera_constants(ctx.handle(), cc), "camera_constants");   // focal x/y, centre x/y, ...
+        std::vector<ptam_pvs_point> pts;
+        std::vector<ptam_template_query> src;
+        for (auto& c : L0.vCorners) {
+            if (!(c.x >= 20 && c.y >= 20 && c.x < 140 && c.y < 100)) continue;
+            const double x = (c.x - cc[2]) / cc[0], y = (c.y - cc[3]) / cc[1];
+            const double r = std::sqrt(x * x + y * y);
+            if (r > 0.12) continue;   // (near the centre the FOV model is close to a pinhole: the projection lands on the corner)
+            ptam_pvs_point p{};
+            p.world[0] = x, p.world[1] = y, p.world[2] = 1.0;
+            p.pixel_right_w[0] = 1.0 / cc[0];
+            p.pixel_down_w[1] = 1.0 / cc[1];
+            pts.push_back(p);
+            ptam_template_query q{};
+            q.src_kf = kf.handle();
+            q.src_level = 0;
+            q.center_x = c.x, q.center_y = c.y;
+            src.push_back(q);
+        }
+        MapTracker mt(ctx, (int)pts.size() + 1);
+        mt.SetMap(pts, src);
+        const ptam_trackmap_result tr = mt.TrackMap(kf, SE3::Identity());
+        int n_found = 0;
+        for (auto& m : mt.IterationSet()) n_found += m.found;
+        const auto rf = ReFindInKeyFrame(ctx, kf, SE3::Identity(), pts, src);
+        int n_refound = 0;
+        for (auto& r : rf) n_refound += r.found;
+        std::printf("TRACKMAP %zu %d %d %d %d %d\n", pts.size(), tr.n_pvs[0], tr.attempted[0], tr.n_meas, n_found, n_refound);
+    }
     // a toy bundle: 3 cameras on a line looking down +z, 12 points on a grid, exact measurements of a
     // pinhole-ish projection perturbed deterministically
     Context c640({1.0803, 1.43987, 0.519983, 0.548655, 0.244943}, {640, 480});

@@ -357,6 +357,61 @@ private:
     void *res_ = nullptr, *meas_ = nullptr, *src_ = nullptr, *flags_ = nullptr, *count_ = nullptr, *pose_ = nullptr;
 };
 
+// Tracker::TrackMap (src/Tracker.cc:442-696) as one device-resident chain: the map (world positions, pixel vectors, patch
+// sources) lives on the device between frames; a frame is one call that returns the refined pose, mbDidCoarse, the
+// per-level manMeasAttempted / manMeasFound counters and the scene-depth sums.  The caller keeps what is host logic in the
+// reference: the bTryCoarse heuristics (:505-516), the motion model, the tracking-quality assessment, and the two random
+// orders per frame (SetShuffle: permutations of the map indices that replace std::random_shuffle, :483-484 and :598).
+class MapTracker {
+public:
+    MapTracker(Context& c, int nMaxPoints) : c_(c) { check(ptam_tracker_create(c.handle(), nMaxPoints, &h_), "ptam_tracker_create"); }
+    ~MapTracker() { ptam_tracker_destroy(h_); }
+    MapTracker(const MapTracker&) = delete;
+    MapTracker& operator=(const MapTracker&) = delete;
+    // vSources[i]: src_kf / src_level / center_x / center_y of map point i (MapPoint::pPatchSourceKF, nSourceLevel, irCenter)
+    void SetMap(const std::vector<ptam_pvs_point>& vMapPoints, const std::vector<ptam_template_query>& vSources) {
+        check(ptam_tracker_set_map(h_, (int)vMapPoints.size(), vMapPoints.data(), vSources.data()), "ptam_tracker_set_map");
+    }
+    void SetShuffle(const std::vector<int32_t>& vLevels, const std::vector<int32_t>& vFine) {
+        check(ptam_tracker_set_shuffle(h_, vLevels.data(), vFine.data()), "ptam_tracker_set_shuffle");
+    }
+    ptam_trackmap_result TrackMap(KeyFrame& kfCurrent, const SE3& se3Predicted, const ptam_trackmap_opts* pOpts = nullptr) {
+        double in[12];
+        se3Predicted.to12(in);
+        ptam_trackmap_result r;
+        check(ptam_track_map(h_, kfCurrent.handle(), in, pOpts, &r), "ptam_track_map");
+        return r;
+    }
+    // vIterationSet of the last frame: what :667-676 turns into mCurrentKF.mMeasurements and what routes the outlier flags
+    // back to MapPoint::nMEstimatorOutlierCount
+    std::vector<ptam_trackmap_meas> IterationSet() {
+        int n = 0;
+        check(ptam_tracker_read_iteration_set(h_, nullptr, 0, &n), "ptam_tracker_read_iteration_set");
+        std::vector<ptam_trackmap_meas> v((size_t)n);
+        if (n > 0) check(ptam_tracker_read_iteration_set(h_, v.data(), n, &n), "ptam_tracker_read_iteration_set");
+        return v;
+    }
+
+private:
+    Context& c_;
+    ptam_tracker* h_ = nullptr;
+};
+
+// MapMaker::ReFind_Common (src/MapMaker.cc:943-1020) over the candidate points of one keyframe (the loop body of
+// ReFindInSingleKeyFrame :1027-1042): out[i].found -> add Measurement{nLevel = level, v2RootPos = root_pos, bSubPix =
+// sub_pix, Source = SRC_REFIND} and insert into sMeasurementKFs; out[i].never_retry -> insert into sNeverRetryKFs.
+// The caller filters the points exactly as :947-948 does (already measured / never retry) before the call.
+inline std::vector<ptam_refind_result> ReFindInKeyFrame(Context& c, KeyFrame& k, const SE3& se3CfromW,
+                                                        const std::vector<ptam_pvs_point>& vPoints,
+                                                        const std::vector<ptam_template_query>& vSources) {
+    double pose[12];
+    se3CfromW.to12(pose);
+    std::vector<ptam_refind_result> out(vPoints.size());
+    check(ptam_refind_batch(c.handle(), k.handle(), pose, (int)vPoints.size(), vPoints.data(), vSources.data(), out.data()),
+          "ptam_refind_batch");
+    return out;
+}
+
 // class Bundle (include/Bundle.h:106-152)
 class Bundle {
 public:
@@ -379,9 +434,16 @@ public:
     void AddMeas(int nCam, int nPoint, const Vec<2>& v2Pos, double dSigmaSquared) {   // :113
         check(ptam_ba_add_meas(h_, nCam, nPoint, v2Pos.data(), dSigmaSquared), "ptam_ba_add_meas");
     }
-    int Compute(bool* pbAbortSignal) {   // :114 ; returns mnAccepted or -1
+    // :114 ; returns mnAccepted (>= 0).  The reference's own -1 is dead code (Do_LM_Step returns true unconditionally,
+    // src/Bundle.cc:550), so a negative value only leaves this shim for inputs the device path refuses: a point measured by
+    // more than 256 cameras (PTAM_E_LIMIT) or a duplicated (camera, point) measurement (PTAM_E_ARG).  MapMaker treats a
+    // negative return as "ditch the map" (src/MapMaker.cc:887-892) — harsh, but it keeps its thread alive, where an
+    // exception thrown out of Compute() would not.  HIP / communicator failures still throw.
+    int Compute(bool* pbAbortSignal) {
         int acc = 0;
-        check(ptam_ba_compute(h_, reinterpret_cast<const volatile unsigned char*>(pbAbortSignal), &acc), "ptam_ba_compute");
+        const int rc = ptam_ba_compute(h_, reinterpret_cast<const volatile unsigned char*>(pbAbortSignal), &acc);
+        if (rc == PTAM_E_LIMIT || rc == PTAM_E_ARG) return -1;
+        check(rc, "ptam_ba_compute");
         return acc;
     }
     bool Converged() const { return ptam_ba_converged(h_) != 0; }   // :115

@@ -62,6 +62,10 @@ def test_shim_demo_matches_oracle(oracle, tmp_path):
     # the resident frame tracker: same measurement list, same pose (bit for bit) and outlier count as the host-vector path
     r = [int(v) for v in next(x for x in lines if x[0] == "RESIDENT")[1:]]
     assert r[0] > 20 and r[1] == r[2] and r[1] > 10 and r[3] == 1 and r[4] == r[5]
+    # resident TrackMap + batched ReFind_Common over the toy map: every point is in the PVS at level 0, nearly all are found
+    # again in their own source image, and the iteration set agrees with the result block
+    t = [int(v) for v in next(x for x in lines if x[0] == "TRACKMAP")[1:]]
+    assert t[0] >= 5 and t[1] == t[0] and t[2] == t[0] and t[3] == t[4] and t[3] >= 0.8 * t[0] and t[5] >= 0.8 * t[0]
     # bundle: replicate the toy problem through the oracle
     ctx = host.Context(lib=oracle)
     ba = host.Bundle(ctx)
