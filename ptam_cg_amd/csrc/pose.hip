@@ -459,10 +459,11 @@ __device__ __forceinline__ int small_key_bin(unsigned long long key) {
     return t < 0 ? 0 : (t > GS_BINS - 1 ? GS_BINS - 1 : t);
 }
 // rank the keys for which `mine` holds among themselves (cnt <= 64 of them): returns the k-th smallest
-__device__ double small_select_finish(GnSmallShared& sh, const unsigned long long key[GS_MPT], const bool mine[GS_MPT], int cnt, int k) {
+template <int MPT>
+__device__ double small_select_finish(GnSmallShared& sh, const unsigned long long key[MPT], const bool mine[MPT], int cnt, int k) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 #pragma unroll
-    for (int q = 0; q < GS_MPT; q++)
+    for (int q = 0; q < MPT; q++)
         if (mine[q]) sh.cand[atomicAdd(&sh.n_cand, 1)] = key[q];
     __syncthreads();
     if (wid == 0) {
@@ -513,12 +514,53 @@ __device__ void small_select_scan(GnSmallShared& sh, int k, bool clear) {
     }
     __syncthreads();
 }
+// MPT == 1 and n <= 128 (the coarse set): no histogram — every key is ranked against the others by broadcast reads
+template <int MPT>
 __device__ double small_select_kth(GnSmallShared& sh, int n, int k) {
-    const int tid = threadIdx.x;
-    unsigned long long key[GS_MPT];
-    bool mine[GS_MPT];
+    if (MPT == 1 && n <= 128) {
+        // One key per thread slot (slots past n hold +inf).  With n <= 64 (<= 128) only the first wave (two) holds
+        // keys, so the list is cut in four (two) parts and thread (part, i) ranks key i against its part; the partial
+        // ranks meet in LDS.  Sixteen independent broadcast reads per round; "less" and "equal" are counted separately —
+        // the index tie-break costs as much as the comparison, ties are rare, and only a key that has an equal walks the
+        // list again.
+        const int tid = threadIdx.x;
+        const int parts = n <= 64 ? 4 : 2, per = GS_THREADS / parts;
+        const int i = tid % per, part = tid / per;
+        const int len = ((n + parts - 1) / parts + 15) & ~15, j_begin = part * len, j_end = min(j_begin + len, GS_THREADS);
+        const unsigned long long me = (unsigned long long)__double_as_longlong(sh.keys[i]);
+        int rank = 0, n_eq = 0;
+        for (int j0 = j_begin; j0 < j_end; j0 += 16) {
+            unsigned long long o[16];
 #pragma unroll
-    for (int q = 0; q < GS_MPT; q++) {
+            for (int u = 0; u < 16; u++) o[u] = (unsigned long long)__double_as_longlong(sh.keys[j0 + u]);
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                rank += o[u] < me ? 1 : 0;
+                n_eq += o[u] == me ? 1 : 0;
+            }
+        }
+        {   // (the histogram is unused on this path — n is fixed for the launch — and serves as the meeting place)
+            if (tid < per) sh.hist[tid] = 0, sh.hist[GS_THREADS + tid] = 0;
+            __syncthreads();
+            atomicAdd(&sh.hist[i], (unsigned)rank);
+            atomicAdd(&sh.hist[GS_THREADS + i], (unsigned)n_eq);
+            __syncthreads();
+            rank = (int)sh.hist[i];
+            n_eq = (int)sh.hist[GS_THREADS + i];
+        }
+        if (tid < n && n_eq > 1)
+            for (int j = 0; j < tid; j++) rank += (unsigned long long)__double_as_longlong(sh.keys[j]) == me ? 1 : 0;
+        if (tid < n && rank == k) sh.cand[63] = me;   // exactly one thread (ties broken by index)
+        __syncthreads();
+        const double r = __longlong_as_double((long long)sh.cand[63]);
+        __syncthreads();   // (read before the next iteration's keys / the next winner overwrite it)
+        return r;
+    }
+    const int tid = threadIdx.x;
+    unsigned long long key[MPT];
+    bool mine[MPT];
+#pragma unroll
+    for (int q = 0; q < MPT; q++) {
         const int i = tid + q * GS_THREADS;
         key[q] = i < n ? (unsigned long long)__double_as_longlong(sh.keys[i]) : ~0ull;
         if (i < n) atomicAdd(&sh.hist[small_key_bin(key[q])], 1u);
@@ -529,8 +571,8 @@ __device__ double small_select_kth(GnSmallShared& sh, int n, int k) {
         const int bin = sh.sel_digit, cnt = sh.sel_cnt;
         if (bin != 0 && bin != GS_BINS - 1 && cnt <= 64) {
 #pragma unroll
-            for (int q = 0; q < GS_MPT; q++) mine[q] = tid + q * GS_THREADS < n && small_key_bin(key[q]) == bin;
-            return small_select_finish(sh, key, mine, cnt, sh.sel_k);
+            for (int q = 0; q < MPT; q++) mine[q] = tid + q * GS_THREADS < n && small_key_bin(key[q]) == bin;
+            return small_select_finish<MPT>(sh, key, mine, cnt, sh.sel_k);
         }
     }
     // general path
@@ -541,7 +583,7 @@ __device__ double small_select_kth(GnSmallShared& sh, int n, int k) {
         const unsigned mask = (1u << bits) - 1u;
         __syncthreads();   // (the previous round's reads of sel_* are done; hist is zero)
 #pragma unroll
-        for (int q = 0; q < GS_MPT; q++)
+        for (int q = 0; q < MPT; q++)
             if (tid + q * GS_THREADS < n && (top == 64 || (key[q] >> top) == (prefix >> top)))
                 atomicAdd(&sh.hist[(unsigned)(key[q] >> shift) & mask], 1u);
         __syncthreads();
@@ -552,8 +594,8 @@ __device__ double small_select_kth(GnSmallShared& sh, int n, int k) {
         const int cnt = sh.sel_cnt;
         if (top > 0 && cnt <= 64) {
 #pragma unroll
-            for (int q = 0; q < GS_MPT; q++) mine[q] = tid + q * GS_THREADS < n && (key[q] >> top) == (prefix >> top);
-            return small_select_finish(sh, key, mine, cnt, k);
+            for (int q = 0; q < MPT; q++) mine[q] = tid + q * GS_THREADS < n && (key[q] >> top) == (prefix >> top);
+            return small_select_finish<MPT>(sh, key, mine, cnt, k);
         }
     }
     return __longlong_as_double((long long)prefix);
@@ -606,6 +648,7 @@ __device__ __forceinline__ void small_project(const DevCam& cam, const double* p
 // Fast path, n <= 1024: 256 threads x 4 measurements held in registers (one wave per SIMD, the four
 // independent measurements of a thread give the fp64 pipeline its ILP), e^2 keys of the order
 // statistic in LDS, wave sums by DPP, same arithmetic and reduction order as the general kernel.
+template <int MPT>
 __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, int n, const ptam_pose_meas* __restrict__ meas,
                                                                    const ptam_projection* __restrict__ entry,
                                                                    double* __restrict__ pose_io, ptam_gn_opts opts,
@@ -614,14 +657,14 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
                                                                    const int* __restrict__ n_dev, PoseIn pin, PoseChainIo io, int size_guard) {
     __shared__ GnSmallShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (size_guard == 1 && *n_dev > GS_LIMIT) return;   // (the general kernel, enqueued behind this one, takes the long list)
+    if (size_guard == 1 && *n_dev > GS_THREADS * MPT) return;   // (the general kernel, enqueued behind this one, takes the long list)
     if (n_dev) n = min(n, max(*n_dev, 0));   // counted variant: the measurement list was compacted on the device
     if (tid < 12) sh.pose[tid] = pin.use ? pin.v[tid] : pose_io[tid];
     if (tid < 6) sh.mu[tid] = 0;
     for (int b = tid; b < GS_BINS; b += GS_THREADS) sh.hist[b] = 0;   // small_select_kth keeps it zero between calls
-    SmallMeas t[GS_MPT];
+    SmallMeas t[MPT];
 #pragma unroll
-    for (int q = 0; q < GS_MPT; q++) {
+    for (int q = 0; q < MPT; q++) {
         const int i = tid + q * GS_THREADS;
         t[q].found = 0;
         t[q].cam3[0] = t[q].cam3[1] = 0;
@@ -642,7 +685,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < GS_MPT; q++) {
+    for (int q = 0; q < MPT; q++) {
         const int i = tid + q * GS_THREADS;
         if (i < n) {
             t[q].found = 1;
@@ -675,7 +718,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
 #endif
         const bool nonlinear = (opts.nonlinear_mask >> iter) & 1u;
         const double ov = iter > opts.override_after ? opts.override_sigma_sq : 0.0;
-        double ex[GS_MPT], ey[GS_MPT], e2[GS_MPT];
+        double ex[MPT], ey[MPT], e2[MPT];
         int cnt = 0;
         // The four measurements of a thread are kept in straight-line code (selects instead of per-measurement branches):
         // with one wave per SIMD the only latency hiding there is comes from interleaving their dependence chains, and
@@ -683,7 +726,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
         // (zero Jacobian, zero noise scale) and are masked out of the keys, the count and the weights.
         if (iter != 0 && nonlinear) {
 #pragma unroll
-            for (int q = 0; q < GS_MPT; q++)
+            for (int q = 0; q < MPT; q++)
                 if (t[q].found) {
                     bool in_image;
                     small_project(cam, sh.pose, t[q], in_image);
@@ -694,7 +737,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
 #pragma unroll
             for (int m = 0; m < 6; m++) mu[m] = sh.mu[m];
 #pragma unroll
-            for (int q = 0; q < GS_MPT; q++) {
+            for (int q = 0; q < MPT; q++) {
                 double a = 0, b = 0;
 #pragma unroll
                 for (int m = 0; m < 6; m++) {
@@ -706,7 +749,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
             }
         }
 #pragma unroll
-        for (int q = 0; q < GS_MPT; q++) {
+        for (int q = 0; q < MPT; q++) {
             // CalcPoseUpdate :946-954
             ex[q] = t[q].sn * (t[q].fnd[0] - t[q].img[0]);
             ey[q] = t[q].sn * (t[q].fnd[1] - t[q].img[1]);
@@ -726,7 +769,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
             if (ov > 0)
                 sigma_sq = ov;
             else {
-                const double med = small_select_kth(sh, n, nf / 2);
+                const double med = small_select_kth<MPT>(sh, n, nf / 2);
                 sigma_sq = est_sigma_sq_from_median(opts.estimator, med, (unsigned long long)nf);
             }
             PH(1)
@@ -736,7 +779,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
 #pragma unroll
             for (int k = 0; k < 27; k++) acc[k] = 0;
 #pragma unroll
-            for (int q = 0; q < GS_MPT; q++) {
+            for (int q = 0; q < MPT; q++) {
                 // weight 0 (an outlier, or no measurement in this slot): every product below is an exact zero
                 double wgt;   // Weight() of include/Tools.h:128-228 with e^2 / sigma^2 as a product
                 if (opts.estimator == PTAM_EST_TUKEY) {
@@ -830,7 +873,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
     // resident chain: the measurements' TrackerData state goes back to the per-point table, scene depth sums
     if (io.td_base) {
 #pragma unroll
-        for (int q = 0; q < GS_MPT; q++) {
+        for (int q = 0; q < MPT; q++) {
             const int i = tid + q * GS_THREADS;
             if (i < n) {
                 ptam_projection* o = (ptam_projection*)((char*)io.td_base + (size_t)(io.td_index ? io.td_index[i] : i) * io.td_stride);
@@ -846,7 +889,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
     if (io.depth_out) {
         double z1 = 0, z2 = 0;
 #pragma unroll
-        for (int q = 0; q < GS_MPT; q++) {
+        for (int q = 0; q < MPT; q++) {
             const double z = (tid + q * GS_THREADS < n) ? t[q].cam3[2] : 0.0;
             z1 += z;
             z2 += z * z;
@@ -987,8 +1030,9 @@ static int pose_gn_host(ptam_ctx* ctx, int n, const ptam_pose_meas* meas, const 
     HIP_TRY(hipMemcpyAsync(d_m, hp, b_in, hipMemcpyHostToDevice, ctx->stream));
     const unsigned long long seq = ++ctx->pose_seq;
     if (small)
-        hipLaunchKernelGGL(pose_gn_small_kernel, dim3(1), dim3(GS_THREADS), 0, ctx->stream, ctx->cam, n, d_m, d_e, d_pose, o, d_f,
-                           d_u, (ulonglong2*)((char*)ctx->d_pinned + o_slots), seq, (const int*)nullptr, PoseIn{}, io, 0);
+        hipLaunchKernelGGL(n <= GS_THREADS ? pose_gn_small_kernel<1> : pose_gn_small_kernel<4>, dim3(1), dim3(GS_THREADS), 0, ctx->stream,
+                           ctx->cam, n, d_m, d_e, d_pose, o, d_f, d_u, (ulonglong2*)((char*)ctx->d_pinned + o_slots), seq,
+                           (const int*)nullptr, PoseIn{}, io, 0);
     else
         hipLaunchKernelGGL(pose_gn_kernel, dim3(1), dim3(GN_THREADS), 0, ctx->stream, ctx->cam, n, d_m, d_e, d_pose, o,
                            d_s, d_f, d_u, (const int*)nullptr, PoseIn{}, io, 0);
@@ -1083,8 +1127,9 @@ static int pose_gn_dev_impl(ptam_ctx* ctx, int n, const int32_t* d_n, const ptam
         seq = ++ctx->pose_seq;
     }
     if (small)
-        hipLaunchKernelGGL(pose_gn_small_kernel, dim3(1), dim3(GS_THREADS), 0, ctx->stream, ctx->cam, n, d_meas, d_entry,
-                           d_pose_inout, o, d_outlier_flags, d_u, d_slots, seq, (const int*)d_n, pin, PoseChainIo{}, 0);
+        hipLaunchKernelGGL(n <= GS_THREADS ? pose_gn_small_kernel<1> : pose_gn_small_kernel<4>, dim3(1), dim3(GS_THREADS), 0, ctx->stream,
+                           ctx->cam, n, d_meas, d_entry, d_pose_inout, o, d_outlier_flags, d_u, d_slots, seq, (const int*)d_n, pin,
+                           PoseChainIo{}, 0);
     else
         hipLaunchKernelGGL(pose_gn_kernel, dim3(1), dim3(GN_THREADS), 0, ctx->stream, ctx->cam, n, d_meas, d_entry, d_pose_inout, o,
                            d_s, d_outlier_flags, d_u, (const int*)d_n, pin, PoseChainIo{}, 0);
@@ -1131,8 +1176,11 @@ int pose_launch_chain(ptam_ctx* ctx, int n_cap, const int* d_n, const ptam_pose_
     int rc = ctx_scratch(ctx, bs + bu + 64, &s);
     if (rc) return rc;
     double* d_u = (double*)((char*)s + bs);
-    hipLaunchKernelGGL(pose_gn_small_kernel, dim3(1), dim3(GS_THREADS), 0, ctx->stream, ctx->cam, std::min(n_cap, GS_LIMIT), d_meas, d_entry,
-                       d_pose_inout, *opts, d_outlier_flags, d_u, (ulonglong2*)nullptr, 0ull, d_n, PoseIn{}, io, may_be_long ? 1 : 0);
+    // (a list that cannot exceed 256 entries — the coarse set — runs with one measurement per thread: a quarter of the
+    //  straight-line work per iteration and a ranking select without a histogram)
+    hipLaunchKernelGGL(n_cap <= GS_THREADS ? pose_gn_small_kernel<1> : pose_gn_small_kernel<4>, dim3(1), dim3(GS_THREADS), 0, ctx->stream,
+                       ctx->cam, std::min(n_cap, GS_LIMIT), d_meas, d_entry, d_pose_inout, *opts, d_outlier_flags, d_u, (ulonglong2*)nullptr,
+                       0ull, d_n, PoseIn{}, io, may_be_long ? 1 : 0);
     if (may_be_long)
         hipLaunchKernelGGL(pose_gn_kernel, dim3(1), dim3(GN_THREADS), 0, ctx->stream, ctx->cam, n_cap, d_meas, d_entry, d_pose_inout, *opts,
                            (PoseState*)s, d_outlier_flags, d_u, d_n, PoseIn{}, io, 2);
@@ -1266,7 +1314,8 @@ int ptam_calc_pose_update(ptam_ctx* ctx, int n, const ptam_pose_update_meas* mea
 // loading the code object / resolving the function — 10-28 ms in the middle of the first frame or the first adjustment
 void pose_preload_kernels() {
     ptam_preload((const void*)pose_gn_kernel);
-    ptam_preload((const void*)pose_gn_small_kernel);
+    ptam_preload((const void*)pose_gn_small_kernel<1>);
+    ptam_preload((const void*)pose_gn_small_kernel<4>);
     ptam_preload((const void*)calc_pose_update_kernel);
     ptam_preload((const void*)gather_pose_meas_kernel);
 }

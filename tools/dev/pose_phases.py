@@ -5,10 +5,10 @@ import numpy as np, torch  # noqa
 from ptam_cg_amd import host, synth
 from ptam_cg_amd._lib import load
 hip = load(); ctx = host.Context(lib=hip)
-pc = synth.make_pose_case(); n = len(pc["world"])
+pc = synth.make_pose_case(n=int(sys.argv[1]) if len(sys.argv) > 1 else 1000); n = len(pc["world"])
 meas = np.zeros(n, dtype=host.POSE_MEAS_DT); meas["world"], meas["found"], meas["sqrt_inv_noise"] = pc["world"], pc["found"], pc["sqrt_inv_noise"]
 d_m, d_p, d_u = host.DevBuf(ctx, meas), host.DevBuf(ctx, pc["init_pose"].copy()), host.DevBuf(ctx, 32 * 6 * 8)
-opts = ctx.gn_opts()
+opts = ctx.gn_opts(nonlinear_mask=0x3ff, override_sigma_sq=1.0, mark_outliers_iter=-1) if len(sys.argv) > 2 else ctx.gn_opts()
 for _ in range(3):
     d_p.upload(pc["init_pose"].copy())
     ctx._check(hip.pose_gn_dev(ctx.h, n, d_m.p, None, d_p.p, C.byref(opts), None, d_u.p), "pose")
