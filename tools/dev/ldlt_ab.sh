@@ -1,6 +1,8 @@
 python -m pytest tests/test_gpu_parity.py -x -q -k "bundle" 2>&1 | tail -2
-for m in block wave; do
-  PTAM_LDLT=$m python bench.py --no-tracking --no-cpu-baseline 2>/dev/null | python -c "
+python -m pytest tests/test_gpu_dist.py -x -q -k "config5" 2>&1 | tail -1
+for m in 1 0; do
+  if [ $m = 1 ]; then export PTAM_LDLT_ONE_ENDED=1; else unset PTAM_LDLT_ONE_ENDED; fi
+  python bench.py --no-tracking --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); g=d['global_ba_single_gpu']
-print('$m', 'headline value %.0f ms/step %.4f solve %.1f us | config5 value %.0f solve %.1f us' % (d['value'], d['ms_per_step'], d['kernel_ms_per_trial']['solve']*1e3, g['value'], g['kernel_ms_per_trial']['solve']*1e3))"
+print('one_ended=$m', 'headline value %.0f solve %.1f us | config5 value %.0f ms/step %.4f solve %.1f us' % (d['value'], d['kernel_ms_per_trial']['solve']*1e3, g['value'], g['ms_per_step'], g['kernel_ms_per_trial']['solve']*1e3))"
 done
