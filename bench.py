@@ -368,6 +368,18 @@ def main():
         stay = int(((tr["err_new"] == tr["err_old"]) & (tr["accepted"] == 0)).sum())
         return {"accepted": acc, "rejected": int(len(tr) - acc - stay), "stay": stay}
 
+    def schur_roofline(problem, kms):
+        """the Schur complement's useful fp64 work — per point with n free cameras n(n+1)/2 blocks of (6x3)(3x3)... = 216 flop
+        each (src/Bundle.cc:374-446) — over the measured K8 time (tile kernel + reduce, HIP events), against the chip's fp64
+        peak (MI355X_MICROARCH.md gives no fp64 row: 78.6 TFLOP/s vector = matrix, AMD's datasheet figure)"""
+        free = problem["fixed"][problem["cam_idx"]] == 0
+        _, npc = np.unique(problem["pt_idx"][free], return_counts=True)
+        flops = float((npc.astype(np.float64) * (npc + 1) / 2 * 216).sum())
+        t = kms.get("schur", 0.0) * 1e-3
+        return {"kernel": "schur_tile_mfma_kernel + schur_reduce_kernel", "bound": "mfma (fp64)", "useful_flop_per_trial": flops,
+                "us_per_trial": t * 1e6, "achieved": flops / t / 1e12 if t > 0 else None, "peak": 78.6, "unit": "TFLOP/s",
+                "frac": flops / t / 78.6e12 if t > 0 else None}
+
     def kernel_breakdown(problem, steps, sharded=True):
         kb = new_bundle(steps, problem, sharded)
         kb.set_profiling(True)
@@ -458,6 +470,7 @@ def main():
                                              f"{(n_rot - 1) * alg_bytes / 1e6:.0f} MB of other working sets pass between two launches "
                                              f"on the same copy (Infinity Cache 256 MB + L2 32 MB)"})
         out["kernel_ms_per_trial"] = kernel_breakdown(prob, args.steps)
+        out["schur_roofline"] = schur_roofline(prob, out["kernel_ms_per_trial"])
         # ---- BASELINE configs[4] on ONE device: the N = 1 point of the strong-scaling curve that `--gpus N` measures ----
         if not is_global and not args.no_global:
             big = synth.make_ba_problem(GLOBAL_BA["cams"], GLOBAL_BA["points"], synth.SEED_BA_GLOBAL, window=GLOBAL_BA["window"])
@@ -465,6 +478,7 @@ def main():
             gb = {"workload": workload_name(**GLOBAL_BA), "value": args.steps / dtg, "unit": "LM iterations/s",
                   "ms_per_step": 1e3 * dtg / args.steps, "steps": args.steps, "measurements": int(cg[3]),
                   "trial_mix": trial_mix(trg), "kernel_ms_per_trial": kernel_breakdown(big, args.steps)}
+            gb["schur_roofline"] = schur_roofline(big, gb["kernel_ms_per_trial"])
             bb = synth.load_into(host.Bundle(ctx), big)
             bb.bench_jacobian(300)
             bms, bby = bb.bench_jacobian(50)

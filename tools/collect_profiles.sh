@@ -13,4 +13,21 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -
 cp $OUT/trace/ba_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 bash $R/tools/profile_k7.sh ${TAG}_headline 50 5000 20 > $OUT/pmc_headline.txt 2>&1
 bash $R/tools/profile_k7.sh ${TAG}_config5 200 50000 20 16 > $OUT/pmc_config5.txt 2>&1
+# PMC passes of the Schur tile kernel and the LDL^T step (MFMA / VALU / LDS / wait counters) over a short BA run
+for pass in "sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS" \
+            "sq2 SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU GRBM_GUI_ACTIVE"; do
+  set -- $pass; name=$1; shift
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_ba -o $name -- python $R/bench.py --no-cpu-baseline --no-tracking --no-global --steps 10 --warmup 1 > $OUT/pmc_ba_$name.log 2>&1 || echo "pass $name failed"
+done
+python3 - <<PY | tee $OUT/pmc_schur_ldlt.txt
+import csv, glob, collections
+for f in sorted(glob.glob("$OUT/pmc_ba/*counter_collection.csv")):
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        if not any(x in k for x in ("schur_tile", "ldlt_step", "ldlt_backward")): continue
+        a = agg[(k, r["Counter_Name"])]; a[0] += float(r["Counter_Value"]); a[1] += 1
+    for (k, c), (v, n) in sorted(agg.items()):
+        print(f"{k[:28]:28s} {c:26s} per-launch {v / max(n,1):.4g}  (launches {n})")
+PY
 tail -3 $OUT/pmc_headline.txt; head -c 600 $OUT/bench.json
