@@ -30,4 +30,9 @@ for f in sorted(glob.glob("$OUT/pmc_ba/*counter_collection.csv")):
     for (k, c), (v, n) in sorted(agg.items()):
         print(f"{k[:28]:28s} {c:26s} per-launch {v / max(n,1):.4g}  (launches {n})")
 PY
+# gpurun merges at most 64 MiB back: keep the summaries, drop the raw per-dispatch tables
+rm -rf $OUT/pmc_ba $OUT/trace
+for dd in $R/gpurun_out/pmc_${TAG}_headline $R/gpurun_out/pmc_${TAG}_config5; do
+  find $dd -name '*_kernel_trace.csv' -delete; find $dd -name '*_counter_collection.csv' -delete; find $dd -name '*_agent_info.csv' -delete
+done
 tail -3 $OUT/pmc_headline.txt; head -c 600 $OUT/bench.json
