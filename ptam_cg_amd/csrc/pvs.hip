@@ -79,14 +79,14 @@ __global__ void __launch_bounds__(256) track_pvs_kernel(DevCam cam, int n, const
 }
 
 int pvs_launch_dev(ptam_ctx* ctx, int n, const ptam_pvs_point* d_pts, double* d_pose, const double* host_pose, ptam_pvs_result* d_out) {
-    if (n <= 0) return PTAM_OK;
+    if (n <= 0 && !host_pose) return PTAM_OK;   // (an empty map still has to leave the pose for the kernels that follow)
     PoseArg pv{};
     if (host_pose) {
         std::memcpy(pv.v, host_pose, 96);
         pv.use = 1;
     }
-    hipLaunchKernelGGL(track_pvs_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->cam, n, d_pts, (const double*)d_pose, d_out,
-                       (int*)nullptr, pv, d_pose);
+    hipLaunchKernelGGL(track_pvs_kernel, dim3(std::max(1, (n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->cam, std::max(n, 0), d_pts,
+                       (const double*)d_pose, d_out, (int*)nullptr, pv, d_pose);
     HIP_TRY(hipGetLastError());
     return PTAM_OK;
 }

@@ -100,3 +100,27 @@ def test_track_map_matches_composed_oracle(hip, oracle, name):
         err_in = np.abs(case["pose_in"] - case["cur_pose"]).max()
         err_out = np.abs(res["pose"] - case["cur_pose"]).max()
         assert err_out < err_in
+
+
+def test_track_map_degenerate_maps(hip):
+    """an empty map, a map none of whose points is visible, and a map of two points: the chain must return the prediction
+    unchanged (CalcPoseUpdate of an empty set is a zero update, src/Tracker.cc:955-956) and empty sets, not hang or fault"""
+    ctx, kfa, kfb, case = _setup(hip, (40, 20, 10, 5))
+    tr = host.Tracker(ctx, 64)
+    pose = case["pose_in"]
+    # empty
+    tr.set_map(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3)), kfa, np.zeros(0, np.int32), np.zeros((0, 2), np.int32))
+    r = tr.TrackMap(kfb, pose)
+    assert np.array_equal(r["pose"], pose) and r["n_meas"] == 0 and list(r["n_pvs"]) == [0, 0, 0, 0] and len(tr.iteration_set()) == 0
+    # nothing visible: every point behind the camera
+    w = case["world"][:30].copy()
+    w[:, 2] += 50.0
+    tr.set_map(w, case["pixel_right_w"][:30], case["pixel_down_w"][:30], kfa, case["src_level"][:30], case["center"][:30])
+    r = tr.TrackMap(kfb, pose)
+    assert np.array_equal(r["pose"], pose) and r["n_meas"] == 0 and sum(r["n_pvs"]) == 0
+    # two points
+    tr.set_map(case["world"][:2], case["pixel_right_w"][:2], case["pixel_down_w"][:2], kfa, case["src_level"][:2], case["center"][:2])
+    tr.set_shuffle(np.array([1, 0], np.int32), np.array([0, 1], np.int32))
+    r = tr.TrackMap(kfb, pose)
+    assert np.isfinite(r["pose"]).all() and r["n_meas"] <= 2 and len(tr.iteration_set()) == sum(r["n_pvs"])
+    tr.close()
