@@ -485,18 +485,7 @@ struct ptam_tracker {
     TmMailbox* mbox;       // host-mapped
     TmMailbox* mbox_dev;
     unsigned long long seq;
-    int have_shuffle;
 };
-
-static int tm_pin_copy(ptam_ctx* ctx, void* dst, const void* src, size_t bytes) {   // pageable host -> device through the pinned staging
-    void* pin;
-    int rc = ctx_pinned(ctx, bytes + 64, &pin);
-    if (rc) return rc;
-    std::memcpy(pin, src, bytes);
-    HIP_TRY(hipMemcpyAsync(dst, pin, bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ptam_stream_wait(ctx->stream));   // (the staging buffer is shared)
-    return PTAM_OK;
-}
 
 extern "C" {
 
