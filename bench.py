@@ -441,10 +441,10 @@ def main():
             n_lead += 1
         if n_lead >= 2:
             dta, tra, _, _ = timed_compute(prob, n_lead, args.warmup)
-            if int(tra["accepted"].sum()) == n_lead:
-                out["accepted_trial_us"] = 1e6 * dta / n_lead
-                out["accepted_trial_note"] = (f"one Compute() of {n_lead} trials, all accepted (includes the first step's full "
-                                              f"projection pass and the read-back at the end of Compute())")
+            out["accepted_trial_us"] = 1e6 * dta / n_lead
+            out["accepted_trial_note"] = (f"one Compute() of {n_lead} trials, {int(tra['accepted'].sum())} of them accepted (includes the "
+                                          f"first step's full projection pass and the read-back at the end of Compute(); near the "
+                                          f"noise floor the last trials of the run may come out rejected in one run and accepted in the next)")
         # ---- roofline leg: K7 alone, HIP events on the library's stream -------------------------
         pb = new_bundle(args.steps)
         pb.bench_jacobian(1000)   # (untimed: the bundle was just built, the chip idled meanwhile — see the spin-up above)
