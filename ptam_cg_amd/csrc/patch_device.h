@@ -1,0 +1,296 @@
+// patch_device.h — the per-wave routines of the patch pipeline (one wave = one 8x8 patch, lane = pixel), shared by the batch
+// kernels of patch.hip and the fused search kernel of the resident TrackMap chain (trackmap.hip).
+#pragma once
+#include "common.h"
+#include "keyframe.h"
+#include "track_internal.h"
+
+// fp64 primitives that are never contracted into FMAs (hipcc's __dmul_rn / __dadd_rn / __dsub_rn are plain operators
+// under -ffp-contract=fast and WOULD be fused): each rounds on its own, like the reference's x86-64 build
+__device__ __forceinline__ double nc_mul(double a, double b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ double nc_add(double a, double b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ double nc_sub(double a, double b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ float nc_mulf(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float nc_addf(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+
+// integer zero-mean SSD; the /64 is a C division truncating toward zero (numerator <= 0)
+__device__ __forceinline__ int zmssd_finish(int SA, int SB, int isumsq, int tsumsq, int cross) {
+    return ((2 * SA * SB - SA * SA - SB * SB) / 64 + isumsq + tsumsq - 2 * cross);
+}
+
+// score the window centred on (cx,cy) of one level against the wave's template (T = this lane's pixel)
+__device__ __forceinline__ int wave_zmssd(const uint8_t* __restrict__ im, int w, int h, int cx, int cy, int T,
+                                          int tsum, int tsumsq, int lane) {
+    if (!(cx >= 4 && cy >= 4 && cx < w - 4 && cy < h - 4)) return PTAM_MAX_SSD + 1;
+    const int I = im[(size_t)(cy - 4 + (lane >> 3)) * w + (cx - 4 + (lane & 7))];
+    const int isum = wave_sum_i32(I);
+    const int isumsq = wave_sum_i32(I * I);
+    const int cross = wave_sum_i32(I * T);
+    return zmssd_finish(tsum, isum, isumsq, tsumsq, cross);
+}
+
+// PatchFinder::FindPatchCoarse (src/PatchFinder.cc:160-211) by one wave: lane = pixel of the 8x8 window, T = this lane's
+// template pixel.  enabled = false: the query is not searched (bad template).
+__device__ __forceinline__ void wave_find_patch_coarse(const KfLevels& L, const ptam_patch_query& q, bool enabled, int T, int lane,
+                                                       ptam_patch_result& res) {
+    res.found = 0;
+    res.best_ssd = PTAM_MAX_SSD + 1;
+    res.best_x = res.best_y = -1;
+    res.n_scored = 0;
+    res.pad_ = 0;
+    res.pos[0] = res.pos[1] = 0;
+    bool search = q.level >= 0 && q.level < PTAM_LEVELS;
+    if (!enabled) search = false;   // Finder.TemplateBad(): the point is dropped before the search (src/Tracker.cc:876-879)
+    int w = 0, h = 0, px = 0, py = 0, nLeft = 0, nRight = 0, i0 = 0, i1 = 0;
+    unsigned nRange = 0;
+    const uint8_t* im = nullptr;
+    const ptam_int2* corners = nullptr;
+    if (search) {
+        const int lev = q.level;
+        w = L.w[lev];
+        h = L.h[lev];
+        im = L.im[lev];
+        corners = L.corners[lev];
+        const int scale = 1 << lev;
+        px = q.x / scale;   // ImageRef / int: C division
+        py = q.y / scale;
+        nRange = (q.range + scale - 1) / scale;
+        int nTop = (int)((unsigned)py - nRange);
+        const int nBottomPlusOne = (int)((unsigned)py + nRange + 1u);
+        nLeft = (int)((unsigned)px - nRange);
+        nRight = (int)((unsigned)px + nRange);
+        if (nTop < 0) nTop = 0;
+        if (nTop >= h || nBottomPlusOne <= 0)
+            search = false;
+        else {
+            i0 = L.rowlut[lev][nTop];
+            i1 = nBottomPlusOne >= h ? L.ncorners[lev] : L.rowlut[lev][nBottomPlusOne];
+        }
+    }
+    if (search) {
+        const int tsum = wave_sum_i32(T), tsumsq = wave_sum_i32(T * T);
+        int best = PTAM_MAX_SSD + 1, bx = -1, by = -1, nsc = 0;
+        for (int base = i0; base < i1; base += 64) {
+            const int idx = base + lane;
+            ptam_int2 c = {0, 0};
+            bool pass = false;
+            if (idx < i1) {
+                c = corners[idx];
+                const int dx = px - c.x, dy = py - c.y;
+                pass = !(c.x < nLeft || c.x > nRight) && !((unsigned)(dx * dx + dy * dy) > nRange * nRange);
+            }
+            unsigned long long m = __ballot(pass);
+            while (m) {
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int cx = __shfl(c.x, b, 64), cy = __shfl(c.y, b, 64);
+                const int ssd = wave_zmssd(im, w, h, cx, cy, T, tsum, tsumsq, lane);
+                nsc++;
+                if (ssd < best) {
+                    best = ssd;
+                    bx = cx;
+                    by = cy;
+                }
+            }
+        }
+        res.best_ssd = best;
+        res.best_x = bx;
+        res.best_y = by;
+        res.n_scored = nsc;
+        if (best < PTAM_MAX_SSD) {
+            const int scale = 1 << q.level;
+            res.found = 1;
+            res.pos[0] = (bx + 0.5) * scale - 0.5;   // Level::LevelZeroPos include/KeyFrame.h:91-94
+            res.pos[1] = (by + 0.5) * scale - 0.5;
+        }
+    }
+}
+
+__device__ __forceinline__ void ldlt3_inverse(double A[9], double out[9]) {   // TooN Cholesky<3>::get_inverse
+    for (int col = 0; col < 3; col++) {
+        double inv_diag = 1;
+        for (int row = col; row < 3; row++) {
+            double val = A[row * 3 + col];
+            for (int c2 = 0; c2 < col; c2++) val -= A[c2 * 3 + col] * A[row * 3 + c2];
+            if (row == col) {
+                A[row * 3 + col] = val;
+                inv_diag = 1 / val;
+            } else {
+                A[col * 3 + row] = val;
+                A[row * 3 + col] = val * inv_diag;
+            }
+        }
+    }
+    for (int c = 0; c < 3; c++) {
+        double y[3], x[3];
+        for (int i = 0; i < 3; i++) {
+            double val = (i == c) ? 1.0 : 0.0;
+            for (int j = 0; j < i; j++) val -= A[i * 3 + j] * y[j];
+            y[i] = val;
+        }
+        for (int i = 0; i < 3; i++) y[i] /= A[i * 3 + i];
+        for (int i = 2; i >= 0; i--) {
+            double val = y[i];
+            for (int j = i + 1; j < 3; j++) val -= A[j * 3 + i] * x[j];
+            x[i] = val;
+        }
+        for (int r = 0; r < 3; r++) out[r * 3 + c] = x[r];
+    }
+}
+
+// PatchFinder::MakeSubPixTemplate + IterateSubPixToConvergence (src/PatchFinder.cc:219-318) by one wave, T = this lane's
+// template pixel
+__device__ __forceinline__ void wave_subpix(const KfLevels& L, const ptam_subpix_query& q, int T, int lane, ptam_subpix_result& res) {
+    res.converged = 0;
+    res.iterations = 0;
+    res.pos[0] = q.coarse_pos[0];
+    res.pos[1] = q.coarse_pos[1];
+    res.mean_diff = 0.0;
+    if (q.level >= 0 && q.level < PTAM_LEVELS) {
+        const int w = L.w[q.level], h = L.h[q.level];
+        const uint8_t* __restrict__ im = L.im[q.level];
+        const int px = lane & 7, py = lane >> 3;
+        const bool inner = px >= 1 && px <= 6 && py >= 1 && py <= 6;
+        // MakeSubPixTemplate :219-240
+        const int Txp = __shfl(T, (lane + 1) & 63, 64), Txm = __shfl(T, (lane - 1) & 63, 64);
+        const int Typ = __shfl(T, (lane + 8) & 63, 64), Tym = __shfl(T, (lane - 8) & 63, 64);
+        const double gx = inner ? 0.5 * (Txp - Txm) : 0.0, gy = inner ? 0.5 * (Typ - Tym) : 0.0;
+        const double one = inner ? 1.0 : 0.0;
+        double H[9];
+        H[0] = wave_sum_f64(gx * gx);
+        H[1] = H[3] = wave_sum_f64(gx * gy);
+        H[2] = H[6] = wave_sum_f64(gx * one);
+        H[4] = wave_sum_f64(gy * gy);
+        H[5] = H[7] = wave_sum_f64(gy * one);
+        H[8] = wave_sum_f64(one);
+        double Hinv[9];
+        ldlt3_inverse(H, Hinv);
+        const double jx = (double)(float)gx, jy = (double)(float)gy;   // mimJacs holds floats
+        double pos0 = q.coarse_pos[0], pos1 = q.coarse_pos[1], mean_diff = 0.0;
+        const int scale = 1 << q.level;
+        for (int it = 0; it < q.max_its; it++) {
+            res.iterations = it + 1;
+            // IterateSubPix :271-318
+            const double cx = (pos0 + 0.5) / scale - 0.5, cy = (pos1 + 0.5) / scale - 0.5;   // LevelNPos
+            const int rx = (int)(cx > 0.0 ? cx + 0.5 : cx - 0.5), ry = (int)(cy > 0.0 ? cy + 0.5 : cy - 0.5);   // ir_rounded
+            if (!(rx >= 5 && ry >= 5 && rx < w - 5 && ry < h - 5)) break;
+            const double bx = cx - 4, by = cy - 4;
+            const double dX = bx - floor(bx), dY = by - floor(by);
+            const float fTL = (float)((1.0 - dX) * (1.0 - dY)), fTR = (float)(dX * (1.0 - dY));
+            const float fBL = (float)((1.0 - dX) * dY), fBR = (float)(dX * dY);
+            const int ibx = (int)bx, iby = (int)by;   // ::ir() truncation
+            double d0 = 0, d1 = 0, d2 = 0;
+            if (inner) {
+                const uint8_t* p = im + (size_t)(iby + py) * w + ibx + px;
+                const float fPixel = nc_addf(nc_addf(nc_addf(nc_mulf(fTL, (float)p[0]), nc_mulf(fTR, (float)p[1])),
+                                                     nc_mulf(fBL, (float)p[w])),
+                                             nc_mulf(fBR, (float)p[w + 1]));
+                const double dDiff = (double)fPixel - (double)T + mean_diff;
+                d0 = dDiff * jx;
+                d1 = dDiff * jy;
+                d2 = dDiff;
+            }
+            const double a0 = wave_sum_f64(d0), a1 = wave_sum_f64(d1), a2 = wave_sum_f64(d2);
+            const double u0 = Hinv[0] * a0 + Hinv[1] * a1 + Hinv[2] * a2;
+            const double u1 = Hinv[3] * a0 + Hinv[4] * a1 + Hinv[5] * a2;
+            const double u2 = Hinv[6] * a0 + Hinv[7] * a1 + Hinv[8] * a2;
+            pos0 -= u0 * scale;
+            pos1 -= u1 * scale;
+            mean_diff -= u2;
+            if (u0 * u0 + u1 * u1 < 0.03 * 0.03) {
+                res.converged = 1;
+                break;
+            }
+        }
+        res.pos[0] = pos0;
+        res.pos[1] = pos1;
+        res.mean_diff = mean_diff;
+    }
+}
+
+// PatchFinder::MakeTemplateCoarseCont (src/PatchFinder.cc:98-127) by one wave: lane = output pixel (i = lane / 8 row,
+// j = lane % 8 column); returns this lane's template pixel and fills r (identical in every lane).  The source position is
+// NOT evaluated in closed form: the reference walks p += across / += carriage_return pixel by pixel, and the lane replays
+// that exact sequence of fp64 additions (<= 70 of them) so the sampled positions are bit-identical.  Every product and sum
+// goes through the nc_* primitives: no FMA contraction.
+__device__ __forceinline__ int wave_make_template(const TemplateJob& jb, int lane, ptam_template_result& r) {
+    r.bad = 1;
+    r.n_outside = 0;
+    r.sum = r.sum_sq = 0;
+    r.m2[0] = r.m2[1] = r.m2[2] = r.m2[3] = 0;
+    if (jb.search_level < 0 || jb.im == nullptr) return 0;
+    // m2 = M2Inverse(mm2WarpInverse) * LevelScale(mnSearchLevel)   (include/Tools.h:54-65)
+    const double det = nc_sub(nc_mul(jb.wi[0], jb.wi[3]), nc_mul(jb.wi[2], jb.wi[1]));
+    const double inv = 1.0 / det;
+    const double sc = (double)(1 << jb.search_level);
+    const double m00 = nc_mul(nc_mul(jb.wi[3], inv), sc), m11 = nc_mul(nc_mul(jb.wi[0], inv), sc);
+    const double m10 = nc_mul(nc_mul(-jb.wi[2], inv), sc), m01 = nc_mul(nc_mul(-jb.wi[1], inv), sc);
+    // CVD::transform(in, out, M, inOrig = vec(irCenter), outOrig = (4,4))
+    const int w = 8, h = 8;
+    const double ax = m00, ay = m10;   // across = M.T()[0]
+    const double dx = m01, dy = m11;   // down   = M.T()[1]
+    const double p0x = nc_sub((double)jb.cx, nc_add(nc_mul(m00, 4.0), nc_mul(m01, 4.0)));
+    const double p0y = nc_sub((double)jb.cy, nc_add(nc_mul(m10, 4.0), nc_mul(m11, 4.0)));
+    double min_x = p0x, min_y = p0y, max_x = p0x, max_y = p0y;
+    if (ax < 0) min_x = nc_add(min_x, nc_mul(w, ax)); else max_x = nc_add(max_x, nc_mul(w, ax));
+    if (dx < 0) min_x = nc_add(min_x, nc_mul(h, dx)); else max_x = nc_add(max_x, nc_mul(h, dx));
+    if (ay < 0) min_y = nc_add(min_y, nc_mul(w, ay)); else max_y = nc_add(max_y, nc_mul(w, ay));
+    if (dy < 0) min_y = nc_add(min_y, nc_mul(h, dy)); else max_y = nc_add(max_y, nc_mul(h, dy));
+    const double crx = nc_sub(dx, nc_mul(w, ax)), cry = nc_sub(dy, nc_mul(w, ay));   // carriage_return
+    const bool all_inside = min_x >= 0 && min_y >= 0 && max_x < jb.w - 1 && max_y < jb.h - 1;
+    // replay the walk up to my pixel
+    const int i = lane >> 3, j = lane & 7;
+    double px = p0x, py = p0y;
+    for (int rr = 0; rr < 7; rr++)
+        if (rr < i) {
+#pragma unroll
+            for (int cc = 0; cc < 8; cc++) {
+                px = nc_add(px, ax);
+                py = nc_add(py, ay);
+            }
+            px = nc_add(px, crx);
+            py = nc_add(py, cry);
+        }
+    for (int cc = 0; cc < 7; cc++)
+        if (cc < j) {
+            px = nc_add(px, ax);
+            py = nc_add(py, ay);
+        }
+    int v = 0, outside = 0;
+    if (all_inside || (0 <= px && 0 <= py && px < (double)(jb.w - 1) && py < (double)(jb.h - 1))) {
+        // CVD::sample
+        const int lx = (int)px, ly = (int)py;
+        const double x = nc_sub(px, (double)lx), y = nc_sub(py, (double)ly);
+        const uint8_t* row0 = jb.im + (size_t)ly * jb.w + lx;
+        const double a = row0[0], b = row0[1], c = row0[jb.w], d = row0[jb.w + 1];
+        const double omx = nc_sub(1.0, x), omy = nc_sub(1.0, y);
+        const double top = nc_add(nc_mul(omx, a), nc_mul(x, b));
+        const double bot = nc_add(nc_mul(omx, c), nc_mul(x, d));
+        const double val = nc_add(nc_mul(omy, top), nc_mul(y, bot));
+        v = (int)(unsigned char)val;   // scalar_convert<byte, byte, double>: static_cast
+    } else {
+        outside = 1;   // defaultValue = byte()
+    }
+    const int n_out = wave_sum_i32(outside), s1 = wave_sum_i32(v), s2 = wave_sum_i32(v * v);
+    r.n_outside = n_out;
+    r.bad = n_out != 0;
+    r.sum = s1;      // MakeTemplateSums src/PatchFinder.cc:326-... : sum and sum of squares of all 64 pixels
+    r.sum_sq = s2;
+    r.m2[0] = m00, r.m2[1] = m01, r.m2[2] = m10, r.m2[3] = m11;
+    return v;
+}
