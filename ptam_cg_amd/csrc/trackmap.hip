@@ -20,6 +20,7 @@
 #include <atomic>
 
 #include "track_internal.h"
+#include "patch_device.h"
 
 struct TmSrc {   // MapPoint::pPatchSourceKF / nSourceLevel / irCenter, resolved to the level image
     const uint8_t* im;
@@ -52,8 +53,6 @@ struct TmDev {
     int* lvl_list;            // [4][cap]
     uint8_t* isfc;            // [cap] member of the fine candidate set
     int* list;                // [cap] search slots: coarse | top level | fine
-    TemplateJob* jobs;
-    uint8_t* tmpl;
     ptam_template_result* tres;
     ptam_patch_query* q;
     ptam_patch_result* r;
@@ -179,33 +178,6 @@ __global__ void __launch_bounds__(1024) tm_select_kernel(TmDev d, ptam_trackmap_
             }
         }
     }
-    // template jobs of every slot (MakeTemplateCoarseCont only needs what the PVS pass left: search level, warp) and the
-    // coarse set's search queries ir(v2Image) (:881) — the lists were written by this workgroup: visible after the barrier
-    __syncthreads();
-    const int n_slots = nC + nH + nF;
-    for (int sl = tid; sl < n_slots; sl += 1024) {
-        const int id = d.list[sl];
-        const TmSrc sr = d.src[id];
-        const ptam_pvs_result& pv = d.pvs[id];
-        TemplateJob j;
-        j.im = sr.im;
-        j.w = sr.w;
-        j.h = sr.h;
-        j.search_level = pv.level;
-        j.cx = sr.cx;
-        j.cy = sr.cy;
-#pragma unroll
-        for (int kq = 0; kq < 4; kq++) j.wi[kq] = pv.warp_inverse[kq];
-        d.jobs[sl] = j;
-        if (sl < nC) {
-            ptam_patch_query q;
-            q.x = (int)pv.proj.image[0];   // ir(): truncation
-            q.y = (int)pv.proj.image[1];
-            q.level = pv.level;
-            q.range = o.coarse_range;
-            d.q[sl] = q;
-        }
-    }
     if (tid == 0) {
         TmCtl& c = *d.ctl;
         c.n_lvl[0] = n0, c.n_lvl[1] = n1, c.n_lvl[2] = n2, c.n_lvl[3] = n3;
@@ -223,41 +195,78 @@ __global__ void __launch_bounds__(1024) tm_select_kernel(TmDev d, ptam_trackmap_
     }
 }
 
-// The head of SearchForPoints (src/Tracker.cc:873-881) for the top-level and fine sets: TrackerData::Project at the current
-// pose (:573-574 always, :606-608 if the coarse stage counted), then the search query ir(v2Image) at the point's level.
-// (A bad template drops the point: the search kernel and the gather look at the template result themselves.)
-__global__ void __launch_bounds__(256) tm_query_kernel(DevCam cam, TmDev d) {
+// Tracker::SearchForPoints (src/Tracker.cc:867-912) for the slots of a stage, ONE WAVE PER SLOT, everything a patch needs
+// in one pass of that wave: [stage 1: TrackerData::Project at the current pose — :573-574 always for the top-level set,
+// :606-608 for the fine set if the coarse stage counted; bFound is false here, so the derivatives stay, include/Tracker.h:89-94]
+// -> MakeTemplateCoarseCont (:873; the template never leaves the wave's registers) -> FindPatchCoarse at ir(v2Image) (:881)
+// -> MakeSubPixTemplate + IterateSubPixToConvergence where the stage asks for it (:896-906: the coarse set with
+// CoarseSubPixIts, the top-level set with 8, the fine set not at all).  Every lane computes the same scalars (wave-uniform
+// control flow); lane 0 stores.  stage 0: the coarse set; stage 1: top-level and fine sets.
+__global__ void __launch_bounds__(256) tm_search_kernel(DevCam cam, KfLevels L, TmDev d, int stage, unsigned coarse_range, int coarse_its) {
     const TmCtl& c = *d.ctl;
-    const int s = c.range_hf[0] + blockIdx.x * 256 + threadIdx.x;
-    if (s >= c.range_hf[1]) return;
+    const int first = stage == 0 ? c.range_c[0] : c.range_hf[0], end = stage == 0 ? c.range_c[1] : c.range_hf[1];
+    const int s = first + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= end) return;
     const int id = d.list[s];
-    ptam_projection& td = d.pvs[id].proj;
-    double u = td.image[0], v = td.image[1];
-    if (s < c.range_h[1] || c.did_coarse) {
-        // TrackerData::Project include/Tracker.h:70-85 (bFound is false here: the derivatives stay, :89-94)
+    ptam_pvs_result& pv = d.pvs[id];
+    double u = pv.proj.image[0], v = pv.proj.image[1];
+    if (stage == 1 && (s < c.range_h[1] || c.did_coarse)) {
         const ptam_pvs_point& p = d.pts[id];
         double X, Y, Z;
         se3_apply(d.pose, p.world[0], p.world[1], p.world[2], X, Y, Z);
-        td.cam[0] = X, td.cam[1] = Y, td.cam[2] = Z;
         int in_image = 0;
+        bool reached = false;
         if (!(Z < 0.001)) {
             const double x = X / Z, y = Y / Z;
             if (!(x * x + y * y > cam.largest_radius * cam.largest_radius)) {
                 double rr, f;
                 cam_project(cam, x, y, u, v, rr, f);
-                td.image[0] = u;
-                td.image[1] = v;
+                reached = true;
                 if (!(rr > cam.max_r) && !(u < 0 || v < 0 || u > cam.width || v > cam.height)) in_image = 1;
             }
         }
-        td.in_image = in_image;
+        if (lane == 0) {
+            pv.proj.cam[0] = X, pv.proj.cam[1] = Y, pv.proj.cam[2] = Z;
+            if (reached) pv.proj.image[0] = u, pv.proj.image[1] = v;
+            pv.proj.in_image = in_image;
+        }
     }
     ptam_patch_query q;
     q.x = (int)u;   // ir(): truncation
     q.y = (int)v;
-    q.range = (unsigned)c.fine_range;
-    q.level = d.jobs[s].search_level;
-    d.q[s] = q;
+    q.level = pv.level;
+    q.range = stage == 0 ? coarse_range : (unsigned)c.fine_range;
+    const TmSrc sr = d.src[id];
+    TemplateJob jb;
+    jb.im = sr.im;
+    jb.w = sr.w;
+    jb.h = sr.h;
+    jb.search_level = pv.level;
+    jb.cx = sr.cx;
+    jb.cy = sr.cy;
+#pragma unroll
+    for (int k = 0; k < 4; k++) jb.wi[k] = pv.warp_inverse[k];
+    ptam_template_result tr;
+    const int T = wave_make_template(jb, lane, tr);
+    ptam_patch_result res;
+    wave_find_patch_coarse(L, q, !tr.bad, T, lane, res);
+    if (lane == 0) {
+        d.tres[s] = tr;
+        d.q[s] = q;
+        d.r[s] = res;
+        if (tr.bad) pv.proj.in_image = 0;   // TD.bInImage = false (:877)
+    }
+    const int its = stage == 0 ? coarse_its : (s < c.range_h[1] ? 8 : 0);
+    if (its > 0) {
+        ptam_subpix_query sq;
+        sq.level = (q.level >= 0 && !tr.bad && res.found) ? q.level : -1;
+        sq.max_its = its;
+        sq.coarse_pos[0] = res.pos[0];
+        sq.coarse_pos[1] = res.pos[1];
+        ptam_subpix_result sres;
+        wave_subpix(L, sq, T, lane, sres);
+        if (lane == 0) d.sr[s] = sres;
+    }
 }
 
 // The tail of SearchForPoints (:883-909) and the measurement list of the pose loop that follows.  One workgroup.
@@ -516,7 +525,7 @@ int ptam_tracker_create(ptam_ctx* ctx, int max_points, ptam_tracker** out) {
     };
     const size_t o_pts = take(cap * sizeof(ptam_pvs_point)), o_src = take(cap * sizeof(TmSrc)), o_pa = take(cap * 4), o_pb = take(cap * 4),
                  o_pvs = take(cap * sizeof(ptam_pvs_result)), o_ll = take(cap * 16), o_fc = take(cap), o_list = take(cap * 4),
-                 o_jobs = take(cap * sizeof(TemplateJob)), o_tm = take(cap * 64), o_tr = take(cap * sizeof(ptam_template_result)),
+                 o_tr = take(cap * sizeof(ptam_template_result)),
                  o_q = take(cap * sizeof(ptam_patch_query)), o_r = take(cap * sizeof(ptam_patch_result)),
                  o_sr = take(cap * sizeof(ptam_subpix_result)), o_sf = take(cap * 4), o_ss = take(cap * 4), o_sv = take(cap * 16),
                  o_me = take(cap * sizeof(ptam_pose_meas)), o_en = take(cap * sizeof(ptam_projection)), o_mi = take(cap * 4),
@@ -539,8 +548,6 @@ int ptam_tracker_create(ptam_ctx* ctx, int max_points, ptam_tracker** out) {
     d.lvl_list = (int*)(b + o_ll);
     d.isfc = (uint8_t*)(b + o_fc);
     d.list = (int*)(b + o_list);
-    d.jobs = (TemplateJob*)(b + o_jobs);
-    d.tmpl = (uint8_t*)(b + o_tm);
     d.tres = (ptam_template_result*)(b + o_tr);
     d.q = (ptam_patch_query*)(b + o_q);
     d.r = (ptam_patch_result*)(b + o_r);
@@ -661,18 +668,10 @@ int ptam_track_map(ptam_tracker* t, const ptam_kf* cur, const double pose_in[12]
     hipStream_t st = ctx->stream;
     int rc = pvs_launch_dev(ctx, n, d.pts, d.pose, pose_in, d.pvs);                     // :453-478 (the pose rides in as an argument)
     if (rc) return rc;
-    hipLaunchKernelGGL(tm_select_kernel, dim3(1), dim3(1024), 0, st, d, o);             // :480-611 + template jobs + coarse queries
-    const int g256 = std::max(1, (n + 255) / 256);
-    rc = patch_launch_templates_dev(ctx, n, d.jobs, d.tmpl, d.tres, d.ctl->range_all);   // MakeTemplateCoarseCont :873
-    if (rc) return rc;
+    hipLaunchKernelGGL(tm_select_kernel, dim3(1), dim3(1024), 0, st, d, o);             // :480-611
     // ---- coarse stage :519-569 ----
     const int ncc = std::max(1, std::min(n, (int)o.coarse_max));
-    rc = patch_launch_search_dev(ctx, cur, ncc, d.q, d.tmpl, d.r, d.ctl->range_c, d.tres);
-    if (rc) return rc;
-    if (o.coarse_subpix_its > 0) {
-        rc = patch_launch_subpix_dev(ctx, cur, ncc, d.q, d.r, d.tmpl, d.sr, d.ctl->range_c, o.coarse_subpix_its);
-        if (rc) return rc;
-    }
+    hipLaunchKernelGGL(tm_search_kernel, dim3((ncc + 3) / 4), dim3(256), 0, st, ctx->cam, cur->L, d, 0, o.coarse_range, o.coarse_subpix_its);
     hipLaunchKernelGGL(tm_gather_kernel, dim3(1), dim3(1024), 0, st, d, 0, o.coarse_subpix_its, o.coarse_min, t->mbox_dev);
     {
         ptam_gn_opts g;
@@ -689,11 +688,7 @@ int ptam_track_map(ptam_tracker* t, const ptam_kf* cur, const double pose_in[12]
         if (rc) return rc;
     }
     // ---- fine stage :571-643 ----
-    hipLaunchKernelGGL(tm_query_kernel, dim3(g256), dim3(256), 0, st, ctx->cam, d);
-    rc = patch_launch_search_dev(ctx, cur, n, d.q, d.tmpl, d.r, d.ctl->range_hf, d.tres);
-    if (rc) return rc;
-    rc = patch_launch_subpix_dev(ctx, cur, n, d.q, d.r, d.tmpl, d.sr, d.ctl->range_h, 8);   // :576
-    if (rc) return rc;
+    hipLaunchKernelGGL(tm_search_kernel, dim3(std::max(1, (n + 3) / 4)), dim3(256), 0, st, ctx->cam, cur->L, d, 1, 0u, 0);
     hipLaunchKernelGGL(tm_gather_kernel, dim3(1), dim3(1024), 0, st, d, 1, o.coarse_subpix_its, o.coarse_min, t->mbox_dev);
     const unsigned long long seq = ++t->seq;
     {
@@ -837,6 +832,6 @@ void trackmap_preload_kernels() {
     ptam_preload((const void*)refind_mask_kernel);
     ptam_preload((const void*)refind_finish_kernel);
     ptam_preload((const void*)tm_select_kernel);
-    ptam_preload((const void*)tm_query_kernel);
+    ptam_preload((const void*)tm_search_kernel);
     ptam_preload((const void*)tm_gather_kernel);
 }
