@@ -382,6 +382,10 @@ int ptam_tracker_set_map(ptam_tracker* t, int n, const ptam_pvs_point* points, c
 int ptam_tracker_set_shuffle(ptam_tracker* t, const int32_t* shuffle_levels, const int32_t* shuffle_fine);
 int ptam_track_map(ptam_tracker* t, const ptam_kf* current, const double pose_in[12], const ptam_trackmap_opts* opts,
                    ptam_trackmap_result* out);
+/* A whole tracked frame in one call: KeyFrame::MakeKeyFrame_Lite (src/KeyFrame.cc:18-54) of the device-resident image
+ * d_frame (stride == width) into `current`, then TrackMap against it: one entry, one queue, one wait. */
+int ptam_track_map_frame(ptam_tracker* t, ptam_kf* current, const uint8_t* d_frame, const double pose_in[12],
+                         const ptam_trackmap_opts* opts, ptam_trackmap_result* out);
 /* vIterationSet of the last frame (what :667-676 turns into mCurrentKF.mMeasurements): *n = its length; out (nullable)
  * receives up to cap entries. */
 int ptam_tracker_read_iteration_set(ptam_tracker* t, ptam_trackmap_meas* out, int cap, int* n);

@@ -6,6 +6,7 @@
 //                            -> corner list + row LUT (the LUT IS the exclusive row prefix)
 #include "common.h"
 #include "keyframe.h"
+#include "track_internal.h"
 
 // ------------------------------------------------------------------------------------------------
 // K1: halfSample cascade.  Thread = one 8x8 block of L0 -> 4x4 of L1, 2x2 of L2, 1 of L3.
@@ -357,7 +358,7 @@ static int kf_alloc(ptam_ctx* ctx, int w, int h, ptam_kf** out) {
     return PTAM_OK;
 }
 
-static int kf_run(ptam_ctx* ctx, ptam_kf* kf, const uint8_t* d_src) {
+static int kf_run(ptam_ctx* ctx, ptam_kf* kf, const uint8_t* d_src, hipStream_t stream) {
     for (int l = 0; l < PTAM_LEVELS; l++) kf->implane_valid[l] = 0;   // new corners: the in-plane cache is stale
     PyrArgs a;
     a.src = d_src;
@@ -369,16 +370,19 @@ static int kf_run(ptam_ctx* ctx, ptam_kf* kf, const uint8_t* d_src) {
     const int nbx = (a.w[0] + 7) / 8, nby = (a.h[0] + 7) / 8;
     dim3 blk(64, 4), grd((nbx + 63) / 64, (nby + 3) / 4);
     if (ctx->halfsample == PTAM_HALFSAMPLE_T)
-        hipLaunchKernelGGL(pyramid_kernel<PTAM_HALFSAMPLE_T>, grd, blk, 0, ctx->stream, a);
+        hipLaunchKernelGGL(pyramid_kernel<PTAM_HALFSAMPLE_T>, grd, blk, 0, stream, a);
     else
-        hipLaunchKernelGGL(pyramid_kernel<PTAM_HALFSAMPLE_R>, grd, blk, 0, ctx->stream, a);
-    hipLaunchKernelGGL(fast_detect_kernel, dim3(kf->n_blocks), dim3(256), 0, ctx->stream, kf->L);
-    hipLaunchKernelGGL(fast_compact_kernel, dim3(PTAM_LEVELS), dim3(1024), 0, ctx->stream, kf->L, 0);
+        hipLaunchKernelGGL(pyramid_kernel<PTAM_HALFSAMPLE_R>, grd, blk, 0, stream, a);
+    hipLaunchKernelGGL(fast_detect_kernel, dim3(kf->n_blocks), dim3(256), 0, stream, kf->L);
+    hipLaunchKernelGGL(fast_compact_kernel, dim3(PTAM_LEVELS), dim3(1024), 0, stream, kf->L, 0);
     HIP_TRY(hipGetLastError());
     kf->counts_valid = 0;
     kf->rest_valid = 0;
     return PTAM_OK;
 }
+
+// MakeKeyFrame_Lite of a device-resident frame on a stream of the caller's choosing (track_internal.h)
+int kf_make_lite_on(ptam_ctx* ctx, ptam_kf* kf, const uint8_t* d_im, hipStream_t stream) { return kf_run(ctx, kf, d_im, stream); }
 
 int kf_fetch_counts(ptam_ctx* ctx, const ptam_kf* kf_c) {
     ptam_kf* kf = const_cast<ptam_kf*>(kf_c);
@@ -414,13 +418,13 @@ int ptam_make_keyframe_lite(ptam_ctx* ctx, ptam_kf* kf, const uint8_t* im, int s
     // copy(im, aLevels[0].im)  src/KeyFrame.cc:20-21 — straight into the keyframe's level 0
     HIP_TRY(hipMemcpy2DAsync(kf->L.im[0], kf->L.w[0], im, stride, kf->L.w[0], kf->L.h[0], hipMemcpyHostToDevice,
                              ctx->stream));
-    return kf_run(ctx, kf, kf->L.im[0]);
+    return kf_run(ctx, kf, kf->L.im[0], ctx->stream);
 }
 
 int ptam_make_keyframe_lite_dev(ptam_ctx* ctx, ptam_kf* kf, const uint8_t* d_im) {
     ARG_TRY(ctx && kf && d_im);
     HIP_TRY(hipSetDevice(ctx->device));
-    return kf_run(ctx, kf, d_im);   // the pyramid kernel also copies src -> level 0
+    return kf_run(ctx, kf, d_im, ctx->stream);   // the pyramid kernel also copies src -> level 0
 }
 
 int ptam_make_keyframe_rest(ptam_ctx* ctx, ptam_kf* kf) {

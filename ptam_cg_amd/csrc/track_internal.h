@@ -23,6 +23,8 @@ int patch_launch_search_dev(ptam_ctx* ctx, const ptam_kf* kf, int n_cap, const p
 // sub-pixel refinement of the patches the coarse search found (queries taken from the search's own queries / results)
 int patch_launch_subpix_dev(ptam_ctx* ctx, const ptam_kf* kf, int n_cap, const ptam_patch_query* d_q, const ptam_patch_result* d_pr,
                             const uint8_t* d_tmpl, ptam_subpix_result* d_sr, const int* d_range, int max_its);
+// keyframe.hip: KeyFrame::MakeKeyFrame_Lite of a device-resident frame, enqueued on `stream`
+int kf_make_lite_on(ptam_ctx* ctx, ptam_kf* kf, const uint8_t* d_im, hipStream_t stream);
 // pvs.hip
 struct PoseArg {   // a pose handed over by value
     double v[12];

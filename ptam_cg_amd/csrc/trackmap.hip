@@ -651,8 +651,11 @@ int ptam_tracker_set_shuffle(ptam_tracker* t, const int32_t* shuffle_levels, con
     return PTAM_OK;
 }
 
-int ptam_track_map(ptam_tracker* t, const ptam_kf* cur, const double pose_in[12], const ptam_trackmap_opts* opts,
-                   ptam_trackmap_result* out) {
+// d_new_frame (nullable): the current keyframe is made first — KeyFrame::MakeKeyFrame_Lite of this device-resident image, in
+// the same queue.  (Measured and dropped: the keyframe kernels on a second queue beside the PVS pass and the set choice, which
+// do not look at the image — the two cross-queue event waits cost more than the 13 us of overlap: 207-218 vs 193-200 us.)
+static int track_map_impl(ptam_tracker* t, ptam_kf* cur, const uint8_t* d_new_frame, const double pose_in[12],
+                          const ptam_trackmap_opts* opts, ptam_trackmap_result* out) {
     ARG_TRY(t && cur && pose_in && out);
     ptam_ctx* ctx = t->ctx;
     ARG_TRY(cur->device == ctx->device);
@@ -666,7 +669,12 @@ int ptam_track_map(ptam_tracker* t, const ptam_kf* cur, const double pose_in[12]
     const TmDev& d = t->d;
     const int n = d.n;
     hipStream_t st = ctx->stream;
-    int rc = pvs_launch_dev(ctx, n, d.pts, d.pose, pose_in, d.pvs);                     // :453-478 (the pose rides in as an argument)
+    int rc = PTAM_OK;
+    if (d_new_frame) {
+        rc = kf_make_lite_on(ctx, cur, d_new_frame, st);                 // src/KeyFrame.cc:18-54
+        if (rc) return rc;
+    }
+    rc = pvs_launch_dev(ctx, n, d.pts, d.pose, pose_in, d.pvs);                         // :453-478 (the pose rides in as an argument)
     if (rc) return rc;
     hipLaunchKernelGGL(tm_select_kernel, dim3(1), dim3(1024), 0, st, d, o);             // :480-611
     // ---- coarse stage :519-569 ----
@@ -723,6 +731,17 @@ int ptam_track_map(ptam_tracker* t, const ptam_kf* cur, const double pose_in[12]
     out->depth_sum_sq = t->mbox->depth3[1];
     out->depth_n = (int)t->mbox->depth3[2];
     return PTAM_OK;
+}
+
+int ptam_track_map(ptam_tracker* t, const ptam_kf* cur, const double pose_in[12], const ptam_trackmap_opts* opts,
+                   ptam_trackmap_result* out) {
+    return track_map_impl(t, const_cast<ptam_kf*>(cur), nullptr, pose_in, opts, out);
+}
+
+int ptam_track_map_frame(ptam_tracker* t, ptam_kf* cur, const uint8_t* d_frame, const double pose_in[12],
+                         const ptam_trackmap_opts* opts, ptam_trackmap_result* out) {
+    ARG_TRY(d_frame);
+    return track_map_impl(t, cur, d_frame, pose_in, opts, out);
 }
 
 int ptam_tracker_read_iteration_set(ptam_tracker* t, ptam_trackmap_meas* out, int cap, int* n_out) {

@@ -398,6 +398,15 @@ class Tracker:
         self.ctx._check(self.lib.track_map(self.h, kf.h, _pd(pose), _ptr(opts) if opts is not None else None, _ptr(res)), "track_map")
         return res[0]
 
+    def TrackFrame(self, kf, d_frame, pose, opts=None):
+        """MakeKeyFrame_Lite of the device-resident frame (DevBuf or raw pointer) into `kf` + TrackMap in one call"""
+        pose = np.ascontiguousarray(pose, dtype=np.float64).reshape(12)
+        res = np.zeros(1, dtype=TRACKMAP_RESULT_DT)
+        dp = d_frame.p if isinstance(d_frame, DevBuf) else d_frame
+        self.ctx._check(self.lib.track_map_frame(self.h, kf.h, dp, _pd(pose), _ptr(opts) if opts is not None else None, _ptr(res)),
+                        "track_map_frame")
+        return res[0]
+
     def iteration_set(self):
         n = C.c_int()
         self.ctx._check(self.lib.tracker_read_iteration_set(self.h, None, 0, C.byref(n)), "tracker_read_iteration_set")

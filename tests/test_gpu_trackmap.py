@@ -124,3 +124,33 @@ def test_track_map_degenerate_maps(hip):
     r = tr.TrackMap(kfb, pose)
     assert np.isfinite(r["pose"]).all() and r["n_meas"] <= 2 and len(tr.iteration_set()) == sum(r["n_pvs"])
     tr.close()
+
+
+def test_track_frame_equals_keyframe_then_track_map(hip):
+    """ptam_track_map_frame (keyframe of the new image + TrackMap, one call) == MakeKeyFrame_Lite followed by
+    ptam_track_map, bit for bit — also when the keyframe object is re-used frame after frame with different images"""
+    ctx, kfa, kfb, case = _setup(hip, (800, 300, 80, 40))
+    a, b = synth.make_frame_pair()
+    frames = [b, a, b, np.roll(b, 2, axis=1), b]
+    tr = host.Tracker(ctx, len(case["world"]))
+    tr.set_map(case["world"], case["pixel_right_w"], case["pixel_down_w"], kfa, case["src_level"], case["center"])
+    want = []
+    for im in frames:
+        kf = host.KeyFrame(ctx).MakeKeyFrame_Lite(im)
+        tr.set_shuffle(case["shuffle_levels"], case["shuffle_fine"])
+        r = tr.TrackMap(kf, case["pose_in"])
+        want.append((r.copy(), tr.iteration_set().copy(), [kf.level(l)["corners"].copy() for l in range(4)]))
+    kfc = host.KeyFrame(ctx)
+    bufs = [host.DevBuf(ctx, im) for im in frames]
+    got = []
+    for d in bufs:                                  # back to back, no synchronisation of the caller's in between
+        tr.set_shuffle(case["shuffle_levels"], case["shuffle_fine"])
+        r = tr.TrackFrame(kfc, d, case["pose_in"])
+        got.append((r.copy(), tr.iteration_set().copy(), [kfc.level(l)["corners"].copy() for l in range(4)]))
+    for (r0, it0, c0), (r1, it1, c1) in zip(want, got):
+        assert r0.tobytes() == r1.tobytes()
+        assert it0.tobytes() == it1.tobytes()
+        for x, y in zip(c0, c1):
+            assert np.array_equal(x, y)
+    assert want[0][0]["n_meas"] != want[1][0]["n_meas"] or not np.array_equal(want[0][0]["pose"], want[1][0]["pose"])
+    tr.close()

@@ -11,6 +11,7 @@ from ptam_cg_amd import host, synth  # noqa: E402
 from ptam_cg_amd._lib import load  # noqa: E402
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+fused = len(sys.argv) > 2 and sys.argv[2] == "frame"       # ptam_track_map_frame (keyframe + TrackMap in one call)
 hip = load()
 ctx = host.Context(lib=hip)
 a, b = synth.make_frame_pair()
@@ -24,8 +25,11 @@ opts = tr.opts()
 for it in range(2):
     t0 = time.perf_counter()
     for _ in range(frames):
-        ctx._check(hip.make_keyframe_lite_dev(ctx.h, kfb.h, d_im.p), "kf")
         tr.set_shuffle(case["shuffle_levels"], case["shuffle_fine"])
-        res = tr.TrackMap(kfb, case["pose_in"], opts)
+        if fused:
+            res = tr.TrackFrame(kfb, d_im, case["pose_in"], opts)
+        else:
+            ctx._check(hip.make_keyframe_lite_dev(ctx.h, kfb.h, d_im.p), "kf")
+            res = tr.TrackMap(kfb, case["pose_in"], opts)
     dt = (time.perf_counter() - t0) / frames
-print(f"TrackMap chain: {dt*1e6:.1f} us/frame, {1/dt:.0f} fps, found {res['n_meas']} of {sum(res['attempted'])}, did_coarse {res['did_coarse']}")
+print(f"TrackMap chain ({'one call' if fused else 'two calls'}): {dt*1e6:.1f} us/frame, {1/dt:.0f} fps, found {res['n_meas']} of {sum(res['attempted'])}, did_coarse {res['did_coarse']}")
