@@ -7,7 +7,10 @@
 //   64 consecutive elements:
 //     m_cam[M] i32 | m_pt[M] i32 | m_found[M] double2 | m_s[M] f64 | m_state[M] u8 | m_orig[M] i32
 //     m_e2[M]                       squared error of pass 1
-//     W[9][M] double2               W_ij = A^T B (6x3 row-major, 18 doubles) as 9 planes of double2
+//     W[3][M+1][6]                  W_ij = A^T B (6x3) COORDINATE-MAJOR: plane c holds, per measurement, column c of the
+//                                   block (the six camera parameters) as 6 consecutive doubles — the k-major operand
+//                                   layout of the Schur product (k = point coordinate, row = camera parameter), so an
+//                                   MFMA fragment is a plain global load; slot M of every plane is a zero block
 //   points:  pt[2][P][3] (current / trial), V[P][6] (lower 00,10,11,20,21,22), epsB[P][3],
 //            Vinv[P][9]
 //   cameras: pose[2][C][12] (current / trial), Usplit[16][F][27] (U lower triangle 21 + epsA 6)
@@ -33,10 +36,12 @@ struct BaChunk {
 
 // one (camera-tile pair, point) work item of the Schur build
 struct SchurEntry {
-    int pt;         // point id
-    int ma;         // first measurement of the point inside tile a
-    int mb;         // first measurement of the point inside tile b
-    int na_nb;      // na | nb << 16   (measurement counts, fixed cameras included)
+    int pt;            // point id
+    int ma;            // first measurement of the point inside tile a (a free camera's)
+    int mb;            // first measurement of the point inside tile b
+    int pad;
+    unsigned offa[2];  // byte s: offset from ma of the measurement by the tile's camera slot s (0..7), 0xff = the point
+    unsigned offb[2];  //         is not measured by that camera (fixed cameras in between have no slot)
 };
 struct SchurWG {
     int pair;       // tile pair index a*(a+1)/2 + b
@@ -97,7 +102,7 @@ struct BaDev {
     double* m_e2;
     double* m_e2t;          // squared errors of the last trial state (adopted as pass 1 when the trial is accepted)
     uint8_t* m_zbad_t;      // its z <= 0 flags
-    double2* W;
+    double* W;              // [3][M + 1][6], see above
     // accumulators
     double* Usplit;         // [16][F*27] : per camera 21 lower-triangle U sums + 6 epsA sums, in 16
                             // fixed-order row splits of the accumulate grid (consumers add the 16)
@@ -125,6 +130,9 @@ struct BaDev {
     BaScalars* sc;
     long long* dbg;         // 16 cycle stamps (only written by -DK7_TIMING builds)
 };
+
+// ---- W planes ----
+__host__ __device__ __forceinline__ size_t w_plane(const BaDev& d) { return (size_t)(d.M + 1) * 6; }   // doubles per coordinate plane
 
 // ---- block-banded packed storage of S and L (lower triangle, 32x32 blocks inside the band) ----
 __host__ __device__ __forceinline__ size_t se_blocks_before_row(int bi, int band) {

@@ -19,6 +19,7 @@
 // The lambda-trial control flow, convergence test and abort polling stay on the host, one readback of
 // a 64-byte scalar block per trial.
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <climits>
 #include <atomic>
@@ -211,11 +212,13 @@ static int ba_prepare_impl(ptam_ba* ba) {
     const int n_pairs = n_tiles * (n_tiles + 1) / 2;
     std::vector<std::vector<SchurEntry>> per_pair(n_pairs);
     {
-        std::vector<int> t_first(n_tiles), t_cnt(n_tiles), touched;
+        std::vector<int> t_first(n_tiles), touched;
+        std::vector<std::array<unsigned, 2>> t_off(n_tiles);
         for (int p = 0; p < P; p++) {
             touched.clear();
-            // measurement sub-range of each tile inside the point's row (camera ids ascending ->
-            // free indices ascending; fixed cameras may sit in between and are skipped in-kernel)
+            // per tile the point touches: its first measurement by a camera of the tile and, per camera slot, the offset
+            // of that camera's measurement from it (camera ids ascending -> free indices ascending; fixed cameras may sit
+            // in between and have no slot)
             int last_tile = -1;
             for (int i = rowptr[p]; i < rowptr[p + 1]; i++) {
                 const int f = cam_free[ba->m_cam[order[i]]];
@@ -224,9 +227,16 @@ static int ba_prepare_impl(ptam_ba* ba) {
                 if (t != last_tile) {
                     touched.push_back(t);
                     t_first[t] = i;
+                    t_off[t] = {0xffffffffu, 0xffffffffu};
                     last_tile = t;
                 }
-                t_cnt[t] = i - t_first[t] + 1;
+                const int off = i - t_first[t], slot = f - t * SCHUR_TC;
+                if (off >= 255) {
+                    ptam_set_error("point %d: more than 254 measurements by fixed cameras inside one camera tile", p);
+                    return PTAM_E_LIMIT;
+                }
+                t_off[t][slot >> 2] &= ~(0xffu << (8 * (slot & 3)));
+                t_off[t][slot >> 2] |= (unsigned)off << (8 * (slot & 3));
             }
             for (size_t ia = 0; ia < touched.size(); ia++)
                 for (size_t ib = 0; ib <= ia; ib++) {
@@ -235,7 +245,9 @@ static int ba_prepare_impl(ptam_ba* ba) {
                     e.pt = p;
                     e.ma = t_first[a];
                     e.mb = t_first[b];
-                    e.na_nb = t_cnt[a] | (t_cnt[b] << 16);
+                    e.pad = 0;
+                    e.offa[0] = t_off[a][0], e.offa[1] = t_off[a][1];
+                    e.offb[0] = t_off[b][0], e.offb[1] = t_off[b][1];
                     per_pair[a * (a + 1) / 2 + b].push_back(e);
                 }
         }
@@ -275,7 +287,9 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.n_schur_wg = (int)s_wgs.size();
     d.n_schur_entries = (int)s_entries.size();
     // persistent grid of the accumulate kernel: bounded by LDS residency, 2 x 256 CUs by default
-    ba->smem_acc = ((((size_t)F * 27 + 1) & ~(size_t)1) + (ba->use_wave ? (size_t)C * 12 + 2 : (size_t)BA_CHUNK * 8)) * sizeof(double);
+    // (wave variant: + one 3 KB W transposition buffer per wave, K7_WT_DOUBLES)
+    const size_t smem_base = ((((size_t)F * 27 + 1) & ~(size_t)1) + (ba->use_wave ? (size_t)C * 12 + 2 : (size_t)BA_CHUNK * 8)) * sizeof(double);
+    auto k7_smem = [&](int threads) { return smem_base + (ba->use_wave ? (size_t)(threads / 64) * K7_WT_DOUBLES * sizeof(double) : 0); };
     // wave variant, two shapes:
     //  - few chunks (every 64-measurement chunk can be resident at once: <= 24 waves per CU):
     //    straight-line kernel, ONE chunk per wave, 512-thread workgroups (64 VGPRs);
@@ -296,11 +310,11 @@ static int ba_prepare_impl(ptam_ba* ba) {
     };
     auto k7_occupancy = [&](int threads, int* per_cu) -> int {
         const void* k7 = k7_fn(threads);
-        if (ba->smem_acc > 64 * 1024) {
-            const hipError_t e = hipFuncSetAttribute(k7, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ba->smem_acc);
+        if (k7_smem(threads) > 64 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(k7, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k7_smem(threads));
             if (e != hipSuccess) return PTAM_E_HIP;
         }
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k7, threads, ba->smem_acc) == hipSuccess ? PTAM_OK : PTAM_E_HIP;
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k7, threads, k7_smem(threads)) == hipSuccess ? PTAM_OK : PTAM_E_HIP;
     };
     int per_cu = 0;
     if (int rc = k7_occupancy(ba->k7_threads, &per_cu)) return rc;
@@ -326,6 +340,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
         }
         if (const char* e = getenv("PTAM_K7_WG_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));
     }
+    ba->smem_acc = k7_smem(ba->k7_threads);
     if (ba->use_wave) {
         // every wave gets the same number of consecutive 64-measurement chunks
         // one 64-measurement chunk per wave (straight-line kernel body: 68 VGPRs instead of ~160 for the
@@ -354,7 +369,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
                  o_Vinv = cv.take(Pz * 72), o_rowptr = cv.take((Pz + 1) * 4),
                  o_cut = cv.take(ba->use_wave ? (size_t)((M + 63) / 64) * 2 * 72 : 8);
     const size_t o_mcam = cv.take(Mz * 4), o_mpt = cv.take(Mz * 4), o_mfound = cv.take(Mz * 16), o_ms = cv.take(Mz * 8),
-                 o_morig = cv.take(Mz * 4), o_mfidx = cv.take(Mz * 4), o_mstate = cv.take(Mz), o_me2 = cv.take(Mz * 8), o_me2t = cv.take(Mz * 8), o_zbad = cv.take(Mz), o_W = cv.take(Mz * 144);
+                 o_morig = cv.take(Mz * 4), o_mfidx = cv.take(Mz * 4), o_mstate = cv.take(Mz), o_me2 = cv.take(Mz * 8), o_me2t = cv.take(Mz * 8), o_zbad = cv.take(Mz), o_W = cv.take((Mz + 1) * 144);
     const size_t o_U = cv.take(Fz * 27 * 8 * 16), o_Upart = cv.take((size_t)d.grid_acc * Fz * 27 * 8);
     const size_t n_part = std::max(d.n_chunks, d.grid_acc);
     const size_t o_errp = cv.take(n_part * 16 + 16), o_badp = cv.take((size_t)d.grid_acc * 4 + 16);
@@ -399,7 +414,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.m_e2 = (double*)(base + o_me2);
     d.m_e2t = (double*)(base + o_me2t);
     d.m_zbad_t = (uint8_t*)(base + o_zbad);
-    d.W = (double2*)(base + o_W);
+    d.W = (double*)(base + o_W);   // (slot M of every plane stays zero: the block is cleared below and nobody writes it)
     d.Usplit = (double*)(base + o_U);
     d.Upart = (double*)(base + o_Upart);
     d.err_part = (double*)(base + o_errp);
@@ -474,8 +489,6 @@ static int ba_prepare_impl(ptam_ba* ba) {
         const int rc_s = ba_solve_init();
         if (rc_s) return rc_s;
     }
-    HIP_TRY(hipFuncSetAttribute((const void*)schur_tile_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(2 * sizeof(SchurStageM))));
     HIP_TRY(hipMalloc((void**)&ba->d_xchg, 4096));
 
     ba->cur = 0;
@@ -682,7 +695,7 @@ static int ba_trial(ptam_ba* ba, double lambda, bool skip_vinv, int last_allowed
     if (d.F > 0) {
         prof_begin(ba, PTAM_K_SCHUR);
         if (d.n_schur_wg > 0)
-            hipLaunchKernelGGL(schur_tile_mfma_kernel, dim3(d.n_schur_wg), dim3(256), 2 * sizeof(SchurStageM), ctx->stream, d);
+            hipLaunchKernelGGL(schur_tile_mfma_kernel, dim3(d.n_schur_wg), dim3(256), 0, ctx->stream, d);
         hipLaunchKernelGGL(schur_reduce_kernel, dim3(d.n_pairs, SRED_SLICES), dim3(256), 0, ctx->stream, d, lambda,
                            (ba->world > 1 && ba->rank != 0) ? 0 : 1);
         prof_end(ba, PTAM_K_SCHUR);
