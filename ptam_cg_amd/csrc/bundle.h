@@ -43,9 +43,10 @@ struct SchurEntry {
     unsigned offa[2];  // byte s: offset from ma of the measurement by the tile's camera slot s (0..7), 0xff = the point
     unsigned offb[2];  //         is not measured by that camera (fixed cameras in between have no slot)
 };
-struct SchurWG {
+struct SchurWG {    // one segment of a workgroup of the tile kernel
     int pair;       // tile pair index a*(a+1)/2 + b
     int e_begin, e_end;
+    int slot;       // its partial tile in s_part (contiguous per pair)
 };
 
 // device scalars shared between kernels and read back once per trial
@@ -116,9 +117,10 @@ struct BaDev {
     double* cand;           // [M]
     // Schur
     SchurEntry* s_entries;
-    SchurWG* s_wgs;
+    SchurWG* s_segs;        // segments, a workgroup's one after another
+    int* s_wg_seg;          // [n_schur_wg + 1] first segment of each workgroup (block 8 i + x = i-th workgroup of XCD x)
     int* s_pair_wg_begin;   // [n_pairs+1] first WG of each pair
-    double* s_part;         // [n_schur_wg][48*48 + 48]
+    double* s_part;         // [partial-tile slots][48*48 + 48]
     // camera system
     double* SE;             // S then E
     double* L;

@@ -252,25 +252,117 @@ static int ba_prepare_impl(ptam_ba* ba) {
                 }
         }
     }
+    // Workgroups of the tile kernel: XCD-aware, cost-balanced, a workgroup = a few SEGMENTS (pair, entry range).
+    // Block b runs on XCD b % 8 (observed placement, MI355X_MICROARCH.md), each XCD has its own 4 MB L2, and every W block
+    // is read once per tile pair its tile takes part in.  The points are cut into 8 ranges of equal cost; XCD x multiplies
+    // ALL tile pairs over range x, so that its L2 holds one eighth of W (4.5 MB at 50 x 5000) and the pairs sharing a tile
+    // find its lines there (round-robin slices of the pairs: 41 % L2 hits; this: 83 %).  Inside an XCD the work — the
+    // chunks of all pairs, one after another — is cut into 64 pieces of equal cost (2 resident workgroups per CU), so a
+    // piece may end one pair and begin the next: the workgroup then leaves one partial tile per segment.
+    // Partial tiles keep one slot per segment, contiguous per pair (fixed-order sum in schur_reduce_kernel).
     std::vector<SchurEntry> s_entries;
-    std::vector<SchurWG> s_wgs;
+    std::vector<SchurWG> s_segs;
+    std::vector<int> s_wg_seg;
     std::vector<int> pair_wg_begin(n_pairs + 1, 0);
     {
-        size_t total = 0;
-        for (auto& v : per_pair) total += v.size();
-        // ~2 resident workgroups per CU x 256 CUs in ONE round; whole LDS batches per workgroup.  Entries are dealt out
-        // evenly although pairs with a partial last tile multiply fewer fragments: weighting by MFMA count measured
-        // SLOWER (103 vs 83 us) — the staging of an entry costs more than its fragments
-        int per_wg = (int)std::min<size_t>(2048, std::max<size_t>(64, total / 500 + 1));
-        per_wg = (per_wg + SCHUR_BATCH - 1) / SCHUR_BATCH * SCHUR_BATCH;
-        for (int pr = 0; pr < n_pairs; pr++) {
-            pair_wg_begin[pr] = (int)s_wgs.size();
-            const int base = (int)s_entries.size();
-            s_entries.insert(s_entries.end(), per_pair[pr].begin(), per_pair[pr].end());
-            const int cnt = (int)per_pair[pr].size();
-            for (int o = 0; o < cnt; o += per_wg) s_wgs.push_back(SchurWG{pr, base + o, base + std::min(cnt, o + per_wg)});
+        int NX = 8;   // point ranges (1 or 8)
+        if (const char* e = getenv("PTAM_SCHUR_NX")) NX = atoi(e) == 8 ? 8 : 1;   // A/B runs (tools/dev/schur_ab.sh)
+        bool span = true;   // a workgroup may end one pair and begin the next
+        if (const char* e = getenv("PTAM_SCHUR_SPAN")) span = atoi(e) != 0;
+        const int SLOTS = 512 / NX, MIN_SEG = 16;
+        // 16x16 fragments the kernel multiplies per entry of a pair (row mappings of ba_schur.inc: 1-2 cameras in a tile = 1
+        // fragment, 3-5 = 2, 6-8 = 3; a full diagonal pair skips two of its nine)
+        auto frags = [&](int t) { const int n = std::min(SCHUR_TC, F - t * SCHUR_TC); return n <= 2 ? 1 : (n <= 5 ? 2 : 3); };
+        std::vector<int> pair_cost(n_pairs, 1);
+        // cost of an entry = fragments + 8: the loads of an iteration (the same for every pair) weigh about as much as eight
+        // fragments' MFMAs (A/B of 0 = entries only / fragments + 3 / + 8 / max(5, fragments): 75 / 72 / 69 / 75 us at 50 x 5000)
+        int cost_model = 8;
+        if (const char* e = getenv("PTAM_SCHUR_COST")) cost_model = atoi(e);   // A/B runs
+        if (cost_model)
+            for (int a = 0, pr = 0; a < n_tiles; a++)
+                for (int b = 0; b <= a; b++, pr++) {
+                    const int f = a == b ? (frags(a) == 3 ? 7 : frags(a) * frags(a)) : frags(a) * frags(b);
+                    pair_cost[pr] = cost_model == 1 ? std::max(5, f) : f + cost_model;
+                }
+        // point ranges of equal cost
+        std::vector<double> pt_cost(P + 1, 0.0);
+        for (int pr = 0; pr < n_pairs; pr++)
+            for (const SchurEntry& e : per_pair[pr]) pt_cost[e.pt + 1] += pair_cost[pr];
+        for (int p = 0; p < P; p++) pt_cost[p + 1] += pt_cost[p];
+        int bound[9];
+        bound[0] = 0;
+        for (int x = 1; x < NX; x++)
+            bound[x] = (int)(std::lower_bound(pt_cost.begin(), pt_cost.end(), pt_cost[P] * x / NX) - pt_cost.begin());
+        bound[NX] = P;
+        std::vector<std::vector<std::vector<int>>> wgs_x(NX);    // per XCD: workgroups = lists of segment indices
+        std::vector<std::vector<int>> segs_of_pair(n_pairs);
+        for (int x = 0; x < NX; x++) {
+            std::vector<int> lo(n_pairs), hi(n_pairs);
+            double cost_x = 0;
+            size_t ent_x = 0;
+            for (int pr = 0; pr < n_pairs; pr++) {
+                auto& v = per_pair[pr];
+                auto cmp = [](const SchurEntry& e, int p) { return e.pt < p; };
+                lo[pr] = (int)(std::lower_bound(v.begin(), v.end(), bound[x], cmp) - v.begin());
+                hi[pr] = (int)(std::lower_bound(v.begin(), v.end(), bound[x + 1], cmp) - v.begin());
+                cost_x += (double)(hi[pr] - lo[pr]) * pair_cost[pr];
+                ent_x += (size_t)(hi[pr] - lo[pr]);
+            }
+            if (ent_x == 0) continue;
+            const int n_wg = (int)std::max<size_t>(1, std::min<size_t>(SLOTS, ent_x / (4 * MIN_SEG)));
+            const double target = cost_x / n_wg * 1.005;
+            std::vector<int> cur;
+            double cur_cost = 0;
+            auto close = [&]() {
+                if (!cur.empty()) wgs_x[x].push_back(cur);
+                cur.clear();
+                cur_cost = 0;
+            };
+            for (int pr = 0; pr < n_pairs; pr++) {
+                const int c = pair_cost[pr];
+                const int base = (int)s_entries.size() - lo[pr];   // position of the pair's entry i in s_entries: base + i
+                s_entries.insert(s_entries.end(), per_pair[pr].begin() + lo[pr], per_pair[pr].begin() + hi[pr]);
+                int pos = lo[pr];
+                while (pos < hi[pr]) {
+                    const int left = hi[pr] - pos;
+                    int take = (int)((target - cur_cost) / c) / 4 * 4;
+                    if (take < MIN_SEG && !cur.empty() && left > take) {   // a sliver at the end of a full workgroup: start the next one
+                        close();
+                        continue;
+                    }
+                    take = std::max(take, MIN_SEG);
+                    if (left - take < MIN_SEG) take = left;                // ... or at the end of the pair's chunk: take it along
+                    segs_of_pair[pr].push_back((int)s_segs.size());
+                    cur.push_back((int)s_segs.size());
+                    s_segs.push_back(SchurWG{pr, base + pos, base + pos + take, -1});
+                    cur_cost += (double)take * c;
+                    pos += take;
+                    if (cur_cost >= target * 0.98) close();
+                }
+                if (!span) close();
+            }
+            close();
         }
-        pair_wg_begin[n_pairs] = (int)s_wgs.size();
+        // partial-tile slots: contiguous per pair
+        int slot = 0;
+        for (int pr = 0; pr < n_pairs; pr++) {
+            pair_wg_begin[pr] = slot;
+            for (int sg : segs_of_pair[pr]) s_segs[sg].slot = slot++;
+        }
+        pair_wg_begin[n_pairs] = slot;
+        // blocks: 8 i + x = the i-th workgroup of XCD x (short lists are padded with empty workgroups); a workgroup's segments
+        // are consecutive in s_segs by construction
+        size_t longest = 0;
+        for (auto& v : wgs_x) longest = std::max(longest, v.size());
+        std::vector<SchurWG> ordered;
+        for (size_t i = 0; i < longest; i++)
+            for (int x = 0; x < NX; x++) {
+                s_wg_seg.push_back((int)ordered.size());
+                if (i < wgs_x[x].size())
+                    for (int sg : wgs_x[x][i]) ordered.push_back(s_segs[sg]);
+            }
+        s_wg_seg.push_back((int)ordered.size());
+        s_segs.swap(ordered);
     }
 
     d.C = C;
@@ -284,7 +376,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     ba->use_wave = !wchunks.empty();
     d.n_tiles = n_tiles;
     d.n_pairs = n_pairs;
-    d.n_schur_wg = (int)s_wgs.size();
+    d.n_schur_wg = (int)s_wg_seg.size() - 1;
     d.n_schur_entries = (int)s_entries.size();
     // persistent grid of the accumulate kernel: bounded by LDS residency, 2 x 256 CUs by default
     // (wave variant: + one 3 KB W transposition buffer per wave, K7_WT_DOUBLES)
@@ -377,9 +469,9 @@ static int ba_prepare_impl(ptam_ba* ba) {
     const size_t o_wchunks = cv.take(std::max<size_t>(1, wchunks.size()) * sizeof(BaChunk));
     const size_t o_hist = cv.take(2 * HIST_BINS * 4), o_cand = cv.take(Mz * 8);
     const size_t o_sent = cv.take(std::max<size_t>(1, s_entries.size()) * sizeof(SchurEntry)),
-                 o_swg = cv.take(std::max<size_t>(1, s_wgs.size()) * sizeof(SchurWG)),
+                 o_swg = cv.take(std::max<size_t>(1, s_segs.size()) * sizeof(SchurWG)), o_swgseg = cv.take(s_wg_seg.size() * 4),
                  o_spw = cv.take((size_t)(n_pairs + 1) * 4),
-                 o_spart = cv.take(std::max<size_t>(1, s_wgs.size()) * SCHUR_TILE_ELEMS * 8);
+                 o_spart = cv.take(std::max<size_t>(1, s_segs.size()) * SCHUR_TILE_ELEMS * 8);
     const size_t npad = std::max(d.npad, SOLVE_NB);
     // S and L block-banded (bundle.h: se_blk); sized for the full lower triangle, because a sharded bundle only learns the
     // bandwidth in force (the widest over all ranks) in Compute()'s first exchange
@@ -424,7 +516,8 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.hist = (unsigned*)(base + o_hist);
     d.cand = (double*)(base + o_cand);
     d.s_entries = (SchurEntry*)(base + o_sent);
-    d.s_wgs = (SchurWG*)(base + o_swg);
+    d.s_segs = (SchurWG*)(base + o_swg);
+    d.s_wg_seg = (int*)(base + o_swgseg);
     d.s_pair_wg_begin = (int*)(base + o_spw);
     d.s_part = (double*)(base + o_spart);
     d.SE = (double*)(base + o_SE);
@@ -481,7 +574,8 @@ static int ba_prepare_impl(ptam_ba* ba) {
     UP(d.chunks, chunks.data(), chunks.size() * sizeof(BaChunk));
     UP(d.wchunks, wchunks.data(), wchunks.size() * sizeof(BaChunk));
     UP(d.s_entries, s_entries.data(), s_entries.size() * sizeof(SchurEntry));
-    UP(d.s_wgs, s_wgs.data(), s_wgs.size() * sizeof(SchurWG));
+    UP(d.s_segs, s_segs.data(), s_segs.size() * sizeof(SchurWG));
+    UP(d.s_wg_seg, s_wg_seg.data(), s_wg_seg.size() * 4);
     UP(d.s_pair_wg_begin, pair_wg_begin.data(), pair_wg_begin.size() * 4);
 #undef UP
     HIP_TRY(ptam_stream_wait(ctx->stream));   // host staging vectors die here
