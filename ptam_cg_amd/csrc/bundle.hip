@@ -269,7 +269,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
         if (const char* e = getenv("PTAM_SCHUR_NX")) NX = atoi(e) == 8 ? 8 : 1;   // A/B runs (tools/dev/schur_ab.sh)
         bool span = true;   // a workgroup may end one pair and begin the next
         if (const char* e = getenv("PTAM_SCHUR_SPAN")) span = atoi(e) != 0;
-        const int SLOTS = 512 / NX, MIN_SEG = 16;
+        const int SLOTS = 256 * SCHUR_WG_PER_CU / NX, MIN_SEG = 16;
         // 16x16 fragments the kernel multiplies per entry of a pair (row mappings of ba_schur.inc: 1-2 cameras in a tile = 1
         // fragment, 3-5 = 2, 6-8 = 3; a full diagonal pair skips two of its nine)
         auto frags = [&](int t) { const int n = std::min(SCHUR_TC, F - t * SCHUR_TC); return n <= 2 ? 1 : (n <= 5 ? 2 : 3); };

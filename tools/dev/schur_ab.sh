@@ -1,13 +1,10 @@
 #!/bin/bash
-# A/B of the Schur tile kernel: work-split settings (and ablation builds under tools/_exp/, if present), one GPU call
+# A/B of the Schur tile kernel: the product build vs the experimental builds under tools/_exp/ (tools/dev/build_variant.sh), one GPU call
 cd ${GRAFT_REPO_ROOT:-.}
 run() { echo "== $1"; shift; env "$@" bash tools/dev/kstats.sh ab "schur_tile" | sed 's/^/   /'; }
-run "default" A=1
-run "nx8" PTAM_SCHUR_NX=8
-run "nx8 cost=frags+3" PTAM_SCHUR_NX=8 PTAM_SCHUR_COST=3
-run "nx8 cost=frags+8" PTAM_SCHUR_NX=8 PTAM_SCHUR_COST=8
-run "default again" A=1
-run "nx8 again" PTAM_SCHUR_NX=8
-for v in nomfma noload; do
+for rep in 1 2; do
+run "product" A=1
+for v in $(ls tools/_exp 2>/dev/null); do
   [ -f tools/_exp/$v/libptam_hip.so ] && run "$v" PTAM_HIP_LIB=$PWD/tools/_exp/$v/libptam_hip.so
+done
 done
