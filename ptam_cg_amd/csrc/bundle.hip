@@ -412,19 +412,22 @@ static int ba_prepare_impl(ptam_ba* ba) {
     if (int rc = k7_occupancy(ba->k7_threads, &per_cu)) return rc;
     if (ba->k7_loop) {
         // many cameras: the LDS partials (F*27 + C*12 doubles per workgroup) bound the workgroups per CU,
-        // so the wider workgroup keeps more waves resident
-        int per_cu512 = 0;
-        if (int rc = k7_occupancy(512, &per_cu512)) return rc;
-        if (per_cu512 * 8 > per_cu * 4) {
-            ba->k7_threads = 512;
-            per_cu = per_cu512;
+        // so a wider workgroup keeps more waves resident (200 cameras: 62 KB + 3 KB per wave -> ONE workgroup per CU
+        // whatever its width, and only the 1024-thread one fills the four waves per SIMD the loop needs)
+        for (int t : {512, 1024}) {
+            int per_cu_t = 0;
+            if (int rc = k7_occupancy(t, &per_cu_t)) return rc;
+            if (per_cu_t * t > per_cu * ba->k7_threads) {
+                ba->k7_threads = t;
+                per_cu = per_cu_t;
+            }
         }
     }
     per_cu = std::max(1, std::min(per_cu, 8));
     if (ba->use_wave && ba->k7_loop) {
         if (const char* e = getenv("PTAM_K7_THREADS")) {
             const int t = atoi(e);
-            if (t == 256 || t == 512) {
+            if (t == 256 || t == 512 || t == 1024) {
                 ba->k7_threads = t;
                 if (int rc = k7_occupancy(t, &per_cu)) return rc;
                 per_cu = std::max(1, std::min(per_cu, 8));
@@ -1599,5 +1602,6 @@ void ba_preload_kernels() {
         ptam_preload(k7_wave_fn(512, false, est ? PTAM_EST_CAUCHY : PTAM_EST_TUKEY));
         ptam_preload(k7_wave_fn(256, true, est ? PTAM_EST_CAUCHY : PTAM_EST_TUKEY));
         ptam_preload(k7_wave_fn(512, true, est ? PTAM_EST_CAUCHY : PTAM_EST_TUKEY));
+        ptam_preload(k7_wave_fn(1024, true, est ? PTAM_EST_CAUCHY : PTAM_EST_TUKEY));
     }
 }
