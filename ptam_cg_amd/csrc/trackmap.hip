@@ -58,6 +58,7 @@ struct TmDev {
     ptam_patch_result* r;
     ptam_subpix_result* sr;
     int* slot_found;
+    int* slot_stat;           // per slot: found | attempted << 1 | level << 2, written by the search kernel
     int* slot_subpix;
     double2* slot_v2;
     ptam_pose_meas* meas;
@@ -257,15 +258,35 @@ __global__ void __launch_bounds__(256) tm_search_kernel(DevCam cam, KfLevels L, 
         if (tr.bad) pv.proj.in_image = 0;   // TD.bInImage = false (:877)
     }
     const int its = stage == 0 ? coarse_its : (s < c.range_h[1] ? 8 : 0);
+    ptam_subpix_result sres;
+    sres.converged = 0;
+    sres.pos[0] = sres.pos[1] = 0;
     if (its > 0) {
         ptam_subpix_query sq;
         sq.level = (q.level >= 0 && !tr.bad && res.found) ? q.level : -1;
         sq.max_its = its;
         sq.coarse_pos[0] = res.pos[0];
         sq.coarse_pos[1] = res.pos[1];
-        ptam_subpix_result sres;
         wave_subpix(L, sq, T, lane, sres);
         if (lane == 0) d.sr[s] = sres;
+    }
+    // the slot's outcome (the tail of SearchForPoints, :880-906), for the gather pass: one packed word + the position
+    if (lane == 0) {
+        const bool att = q.level >= 0 && !tr.bad;   // manMeasAttempted (:880)
+        int found = att && res.found, sub = 0;
+        double2 v2 = make_double2(0, 0);
+        if (found) {
+            if (its > 0) {
+                sub = 1;
+                found = sres.converged;   // :898-904
+                v2 = make_double2(sres.pos[0], sres.pos[1]);
+            } else
+                v2 = make_double2(res.pos[0], res.pos[1]);
+        }
+        d.slot_found[s] = found;
+        d.slot_subpix[s] = sub;
+        d.slot_v2[s] = v2;
+        d.slot_stat[s] = found | ((int)att << 1) | ((q.level & 3) << 2);
     }
 }
 
@@ -277,79 +298,12 @@ struct TmMailbox {
     double depth3[3];
     unsigned long long seq;
 };
-__global__ void __launch_bounds__(1024) tm_gather_kernel(TmDev d, int stage, int coarse_its, unsigned coarse_min, TmMailbox* mbox) {
-    __shared__ int wsum[4][16];
-    __shared__ int lsum[8][16];
-    TmCtl& c = *d.ctl;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    // every thread owns a run of consecutive slots for both phases (status, then compaction): what it found out about its
-    // slots stays in registers
-    constexpr int RUN = 4;
-    const int g_end = stage == 0 ? c.nC : c.n_slots;            // slots compacted by this stage
-    const int st_first = stage == 0 ? 0 : c.nC;                 // slots whose status this stage decides
-    const int chunk = (g_end + 1023) / 1024, s0 = min(g_end, tid * chunk), s1 = min(g_end, s0 + chunk);
-    int lf[4] = {0, 0, 0, 0}, la[4] = {0, 0, 0, 0};
-    int cnt[4] = {0, 0, 0, 0};
-    for (int sb = s0; sb < s1; sb += RUN) {
-#pragma unroll
-        for (int u = 0; u < RUN; u++) {
-            const int s = sb + u;
-            if (s >= s1) break;
-            if (s >= st_first) {
-                const ptam_patch_query q = d.q[s];
-                const bool bad = d.tres[s].bad != 0;
-                const int its = stage == 0 ? coarse_its : (s < c.range_h[1] ? 8 : 0);
-                const bool att = q.level >= 0 && !bad;           // manMeasAttempted (:880)
-                int found = att && d.r[s].found;
-                int sub = 0;
-                double2 v2 = make_double2(0, 0);
-                if (found) {
-                    if (its > 0) {
-                        sub = 1;
-                        const ptam_subpix_result sr = d.sr[s];
-                        found = sr.converged;   // :898-904
-                        v2 = make_double2(sr.pos[0], sr.pos[1]);
-                    } else
-                        v2 = make_double2(d.r[s].pos[0], d.r[s].pos[1]);
-                }
-                d.slot_found[s] = found;
-                d.slot_subpix[s] = sub;
-                d.slot_v2[s] = v2;
-                if (att) la[q.level]++;
-                if (found) lf[q.level]++;
-                cnt[0] += found;
-            } else
-                cnt[0] += d.slot_found[s];   // (coarse slots in the final pass: decided by stage 0)
-        }
-    }
-    // per-level attempted / found counts of this stage (integers: order-free)
-#pragma unroll
-    for (int l = 0; l < 4; l++) {
-        const int tf = wave_sum_i32(lf[l]), ta = wave_sum_i32(la[l]);
-        if (lane == 63) {
-            lsum[l][wid] = tf;
-            lsum[4 + l][wid] = ta;
-        }
-    }
-    int off[4], tot[4];
-    block_scan4(cnt, off, tot, wsum);   // (its barriers also publish lsum and the slot_* arrays of this workgroup)
-    int k = off[0];
-    for (int s = s0; s < s1; s++)
-        if (d.slot_found[s]) {
-            const int id = d.list[s];
-            ptam_pose_meas m;
-            const ptam_pvs_point& p = d.pts[id];
-            m.world[0] = p.world[0], m.world[1] = p.world[1], m.world[2] = p.world[2];
-            const double2 v2 = d.slot_v2[s];
-            m.found[0] = v2.x;
-            m.found[1] = v2.y;
-            m.sqrt_inv_noise = 1.0 / (double)(1 << d.q[s].level);   // :889
-            d.meas[k] = m;
-            d.entry[k] = d.pvs[id].proj;
-            d.midx[k] = id;
-            d.mslot[k] = s;
-            k++;
-        }
+// the last act of a gather pass: thread 0 books the per-level counts and the stage's outcome (coarse: mbDidCoarse and the
+// fine range; fine: everything of the frame's result but the pose and the depth sums)
+__device__ __forceinline__ void tm_gather_finish(const TmDev& d, TmCtl& c, int stage, unsigned coarse_min, TmMailbox* mbox, int total,
+                                                 int (*lsum)[16]) {
+    const int tid = threadIdx.x;
+    int tot[1] = {total};
     if (tid == 0) {
         int f4[4], a4[4];
         for (int l = 0; l < 4; l++) {
@@ -385,6 +339,73 @@ __global__ void __launch_bounds__(1024) tm_gather_kernel(TmDev d, int stage, int
             r.n_meas = tot[0];
         }
     }
+}
+
+// One WAVE per 64 slots, as many workgroups as the capacity needs (a single 1024-thread workgroup spent 12-20 us copying
+// ~250-byte records per slot through ONE CU).  The search kernel has left a packed status word per slot, so every wave
+// counts the found slots in front of its own by itself (at most 1024 coalesced words) — no scan across workgroups, no
+// barrier; workgroup 0 also counts everything and books the stage's outcome.
+#define TM_GATHER_THREADS 64
+__global__ void __launch_bounds__(TM_GATHER_THREADS) tm_gather_kernel(TmDev d, int stage, int coarse_its, unsigned coarse_min, TmMailbox* mbox) {
+    __shared__ int lsum[8][16];
+    TmCtl& c = *d.ctl;
+    const int lane = threadIdx.x;
+    const int g_end = stage == 0 ? c.nC : c.n_slots;            // slots compacted by this stage
+    const int st_first = stage == 0 ? 0 : c.nC;                 // slots whose status this stage decided
+    const int s0 = blockIdx.x * TM_GATHER_THREADS;
+    if (s0 >= g_end && blockIdx.x != 0) return;
+    // my slot: everything that does not depend on another load leaves at once
+    const int s = s0 + lane;
+    const bool valid = s < g_end;
+    const int sc = valid ? s : 0;
+    const int st = valid ? d.slot_stat[sc] : 0;
+    const int id = g_end > 0 ? d.list[sc] : 0;
+    const double2 v2 = d.slot_v2[sc];
+    // found slots in front of my workgroup's first (workgroup 0: also the totals and the per-level counts of this stage)
+    const int upto = blockIdx.x == 0 ? g_end : s0;
+    int before = 0, total = 0, lf[4] = {0, 0, 0, 0}, la[4] = {0, 0, 0, 0};
+    for (int j = lane; j < upto; j += TM_GATHER_THREADS) {
+        const int w = d.slot_stat[j];
+        total += w & 1;
+        if (j < s0) before += w & 1;
+        if (blockIdx.x == 0 && j >= st_first) {
+            const int l = (w >> 2) & 3;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                lf[q] += (l == q) & (w & 1);
+                la[q] += (l == q) & ((w >> 1) & 1);
+            }
+        }
+    }
+    before = wave_sum_i32(before);
+    const int found = valid ? (st & 1) : 0;
+    const int k = __builtin_amdgcn_readlane(before, 63) + wave_incl_scan_i32(found) - found;
+    if (found) {
+        const ptam_pvs_point& p = d.pts[id];
+        ptam_pose_meas m;
+        m.world[0] = p.world[0], m.world[1] = p.world[1], m.world[2] = p.world[2];
+        m.found[0] = v2.x;
+        m.found[1] = v2.y;
+        m.sqrt_inv_noise = 1.0 / (double)(1 << ((st >> 2) & 3));   // :889
+        d.meas[k] = m;
+        d.entry[k] = d.pvs[id].proj;
+        d.midx[k] = id;
+        d.mslot[k] = s;
+    }
+    if (blockIdx.x != 0) return;
+    total = wave_sum_i32(total);
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        const int tf = wave_sum_i32(lf[l]), ta = wave_sum_i32(la[l]);
+        if (lane == 63) {
+            lsum[l][0] = tf;
+            lsum[4 + l][0] = ta;
+#pragma unroll
+            for (int w = 1; w < 16; w++) lsum[l][w] = lsum[4 + l][w] = 0;
+        }
+    }
+    __syncthreads();
+    tm_gather_finish(d, c, stage, coarse_min, mbox, __builtin_amdgcn_readlane(total, 63), lsum);
 }
 
 // ---- MapMaker::ReFind_Common (src/MapMaker.cc:943-1020), batched over the map points of one keyframe ----
@@ -527,7 +548,7 @@ int ptam_tracker_create(ptam_ctx* ctx, int max_points, ptam_tracker** out) {
                  o_pvs = take(cap * sizeof(ptam_pvs_result)), o_ll = take(cap * 16), o_fc = take(cap), o_list = take(cap * 4),
                  o_tr = take(cap * sizeof(ptam_template_result)),
                  o_q = take(cap * sizeof(ptam_patch_query)), o_r = take(cap * sizeof(ptam_patch_result)),
-                 o_sr = take(cap * sizeof(ptam_subpix_result)), o_sf = take(cap * 4), o_ss = take(cap * 4), o_sv = take(cap * 16),
+                 o_sr = take(cap * sizeof(ptam_subpix_result)), o_sf = take(cap * 4), o_st = take(cap * 4), o_ss = take(cap * 4), o_sv = take(cap * 16),
                  o_me = take(cap * sizeof(ptam_pose_meas)), o_en = take(cap * sizeof(ptam_projection)), o_mi = take(cap * 4),
                  o_ms = take(cap * 4), o_ou = take(cap * 4), o_ctl = take(sizeof(TmCtl)), o_pose = take(96);
     if (hipMalloc(&t->block, off) != hipSuccess) {
@@ -553,6 +574,7 @@ int ptam_tracker_create(ptam_ctx* ctx, int max_points, ptam_tracker** out) {
     d.r = (ptam_patch_result*)(b + o_r);
     d.sr = (ptam_subpix_result*)(b + o_sr);
     d.slot_found = (int*)(b + o_sf);
+    d.slot_stat = (int*)(b + o_st);
     d.slot_subpix = (int*)(b + o_ss);
     d.slot_v2 = (double2*)(b + o_sv);
     d.meas = (ptam_pose_meas*)(b + o_me);
@@ -680,7 +702,7 @@ static int track_map_impl(ptam_tracker* t, ptam_kf* cur, const uint8_t* d_new_fr
     // ---- coarse stage :519-569 ----
     const int ncc = std::max(1, std::min(n, (int)o.coarse_max));
     hipLaunchKernelGGL(tm_search_kernel, dim3((ncc + 3) / 4), dim3(256), 0, st, ctx->cam, cur->L, d, 0, o.coarse_range, o.coarse_subpix_its);
-    hipLaunchKernelGGL(tm_gather_kernel, dim3(1), dim3(1024), 0, st, d, 0, o.coarse_subpix_its, o.coarse_min, t->mbox_dev);
+    hipLaunchKernelGGL(tm_gather_kernel, dim3(std::max(1, (ncc + TM_GATHER_THREADS - 1) / TM_GATHER_THREADS)), dim3(TM_GATHER_THREADS), 0, st, d, 0, o.coarse_subpix_its, o.coarse_min, t->mbox_dev);
     {
         ptam_gn_opts g;
         ptam_gn_opts_default(&g);
@@ -697,7 +719,7 @@ static int track_map_impl(ptam_tracker* t, ptam_kf* cur, const uint8_t* d_new_fr
     }
     // ---- fine stage :571-643 ----
     hipLaunchKernelGGL(tm_search_kernel, dim3(std::max(1, (n + 3) / 4)), dim3(256), 0, st, ctx->cam, cur->L, d, 1, 0u, 0);
-    hipLaunchKernelGGL(tm_gather_kernel, dim3(1), dim3(1024), 0, st, d, 1, o.coarse_subpix_its, o.coarse_min, t->mbox_dev);
+    hipLaunchKernelGGL(tm_gather_kernel, dim3(std::max(1, (n + TM_GATHER_THREADS - 1) / TM_GATHER_THREADS)), dim3(TM_GATHER_THREADS), 0, st, d, 1, o.coarse_subpix_its, o.coarse_min, t->mbox_dev);
     const unsigned long long seq = ++t->seq;
     {
         ptam_gn_opts g;
