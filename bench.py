@@ -162,9 +162,8 @@ def trackmap_bench(hip, host, synth, ctx, kfa, frame_b, d_im, frames):
     res = None
 
     def frame(ctx_, kf_, tr_, d_im_):
-        ctx_._check(hip.make_keyframe_lite_dev(ctx_.h, kf_.h, d_im_), "kf")
         tr_.set_shuffle(case["shuffle_levels"], case["shuffle_fine"])     # the frame's random orders travel with it
-        return tr_.TrackMap(kf_, pose, opts)
+        return tr_.TrackFrame(kf_, d_im_, pose, opts)                      # ptam_track_map_frame: keyframe of the new image + TrackMap
 
     for _ in range(30):
         res = frame(ctx, kfb, tr, d_im)

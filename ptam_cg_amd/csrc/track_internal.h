@@ -25,6 +25,10 @@ int patch_launch_subpix_dev(ptam_ctx* ctx, const ptam_kf* kf, int n_cap, const p
                             const uint8_t* d_tmpl, ptam_subpix_result* d_sr, const int* d_range, int max_its);
 // keyframe.hip: KeyFrame::MakeKeyFrame_Lite of a device-resident frame, enqueued on `stream`
 int kf_make_lite_on(ptam_ctx* ctx, ptam_kf* kf, const uint8_t* d_im, hipStream_t stream);
+// the same in pieces, for a caller that fuses the pyramid and the compaction into launches of its own (keyframe_device.h)
+struct PyrArgs;
+void kf_lite_begin(ptam_kf* kf, const uint8_t* d_src, PyrArgs* a_out, int* gx, int* gy);
+void kf_launch_detect(ptam_kf* kf, hipStream_t stream);
 // pvs.hip
 struct PoseArg {   // a pose handed over by value
     double v[12];

@@ -21,6 +21,8 @@
 
 #include "track_internal.h"
 #include "patch_device.h"
+#include "keyframe_device.h"
+#include "pvs_device.h"
 
 struct TmSrc {   // MapPoint::pPatchSourceKF / nSourceLevel / irCenter, resolved to the level image
     const uint8_t* im;
@@ -101,7 +103,7 @@ __device__ __forceinline__ void block_scan4(const int v[4], int off[4], int tot[
 }
 
 // The choice of the search sets, src/Tracker.cc:480-611.  One workgroup.
-__global__ void __launch_bounds__(1024) tm_select_kernel(TmDev d, ptam_trackmap_opts o) {
+__device__ __forceinline__ void tm_select_body(const TmDev& d, const ptam_trackmap_opts& o) {   // a 1024-thread workgroup
     __shared__ int wsum[4][16];
     const int tid = threadIdx.x, n = d.n, cap = d.cap;
     const int chunk = (n + 1023) / 1024, p0 = min(n, tid * chunk), p1 = min(n, p0 + chunk);
@@ -195,6 +197,31 @@ __global__ void __launch_bounds__(1024) tm_select_kernel(TmDev d, ptam_trackmap_
         c.depth[0] = c.depth[1] = c.depth[2] = 0;
     }
 }
+
+__global__ void __launch_bounds__(1024) tm_select_kernel(TmDev d, ptam_trackmap_opts o) { tm_select_body(d, o); }
+
+// ---- horizontal fusion for a frame that arrives with its image (ptam_track_map_frame) ----
+// The PVS pass and the set choice do not look at the image, the pyramid and the corner compaction do not look at the map:
+// run on separate queues the two cross-queue waits cost more than the overlap (measured, see track_map_impl), but as
+// workgroups of ONE launch they overlap for free — every kernel of this chain leaves most of the chip idle.
+//   launch 1: pyramid (its 2-D grid linearised) | PVS pass        launch 2: FAST detect
+//   launch 3: set choice (workgroup 0) | raster-ordered corner compaction (one workgroup per level)
+template <int VARIANT>
+__global__ void __launch_bounds__(256) tm_pyr_pvs_kernel(PyrArgs a, int gx, int n_pyr, DevCam cam, int n, const ptam_pvs_point* __restrict__ pts,
+                                                         ptam_pvs_result* __restrict__ out, PoseArg pv, double* __restrict__ pose_out) {
+    const int b = blockIdx.x;
+    if (b < n_pyr)
+        pyramid_body<VARIANT>(a, (b % gx) * 64 + (threadIdx.x & 63), (b / gx) * 4 + (threadIdx.x >> 6));
+    else
+        track_pvs_body(cam, n, pts, pose_out, out, nullptr, pv, pose_out, b - n_pyr);
+}
+__global__ void __launch_bounds__(1024) tm_compact_select_kernel(KfLevels L, TmDev d, ptam_trackmap_opts o) {
+    if (blockIdx.x == 0)
+        tm_select_body(d, o);
+    else
+        fast_compact_body(L, blockIdx.x - 1, 0);
+}
+
 
 // Tracker::SearchForPoints (src/Tracker.cc:867-912) for the slots of a stage, ONE WAVE PER SLOT, everything a patch needs
 // in one pass of that wave: [stage 1: TrackerData::Project at the current pose — :573-574 always for the top-level set,
@@ -693,12 +720,28 @@ static int track_map_impl(ptam_tracker* t, ptam_kf* cur, const uint8_t* d_new_fr
     hipStream_t st = ctx->stream;
     int rc = PTAM_OK;
     if (d_new_frame) {
-        rc = kf_make_lite_on(ctx, cur, d_new_frame, st);                 // src/KeyFrame.cc:18-54
+        // KeyFrame::MakeKeyFrame_Lite (src/KeyFrame.cc:18-54) of the new image, the PVS pass (:453-478, the pose rides in as an
+        // argument) and the set choice (:480-611) in three launches
+        PyrArgs pa;
+        int gx, gy;
+        kf_lite_begin(cur, d_new_frame, &pa, &gx, &gy);
+        PoseArg pv{};
+        std::memcpy(pv.v, pose_in, 96);
+        pv.use = 1;
+        const int n_pyr = gx * gy, n_pvs = std::max(1, (n + 255) / 256);
+        if (ctx->halfsample == PTAM_HALFSAMPLE_T)
+            hipLaunchKernelGGL(tm_pyr_pvs_kernel<PTAM_HALFSAMPLE_T>, dim3(n_pyr + n_pvs), dim3(256), 0, st, pa, gx, n_pyr, ctx->cam, std::max(n, 0),
+                               (const ptam_pvs_point*)d.pts, d.pvs, pv, d.pose);
+        else
+            hipLaunchKernelGGL(tm_pyr_pvs_kernel<PTAM_HALFSAMPLE_R>, dim3(n_pyr + n_pvs), dim3(256), 0, st, pa, gx, n_pyr, ctx->cam, std::max(n, 0),
+                               (const ptam_pvs_point*)d.pts, d.pvs, pv, d.pose);
+        kf_launch_detect(cur, st);
+        hipLaunchKernelGGL(tm_compact_select_kernel, dim3(1 + PTAM_LEVELS), dim3(1024), 0, st, cur->L, d, o);
+    } else {
+        rc = pvs_launch_dev(ctx, n, d.pts, d.pose, pose_in, d.pvs);                         // :453-478 (the pose rides in as an argument)
         if (rc) return rc;
+        hipLaunchKernelGGL(tm_select_kernel, dim3(1), dim3(1024), 0, st, d, o);             // :480-611
     }
-    rc = pvs_launch_dev(ctx, n, d.pts, d.pose, pose_in, d.pvs);                         // :453-478 (the pose rides in as an argument)
-    if (rc) return rc;
-    hipLaunchKernelGGL(tm_select_kernel, dim3(1), dim3(1024), 0, st, d, o);             // :480-611
     // ---- coarse stage :519-569 ----
     const int ncc = std::max(1, std::min(n, (int)o.coarse_max));
     hipLaunchKernelGGL(tm_search_kernel, dim3((ncc + 3) / 4), dim3(256), 0, st, ctx->cam, cur->L, d, 0, o.coarse_range, o.coarse_subpix_its);
@@ -873,6 +916,9 @@ void trackmap_preload_kernels() {
     ptam_preload((const void*)refind_mask_kernel);
     ptam_preload((const void*)refind_finish_kernel);
     ptam_preload((const void*)tm_select_kernel);
+    ptam_preload((const void*)tm_pyr_pvs_kernel<PTAM_HALFSAMPLE_R>);
+    ptam_preload((const void*)tm_pyr_pvs_kernel<PTAM_HALFSAMPLE_T>);
+    ptam_preload((const void*)tm_compact_select_kernel);
     ptam_preload((const void*)tm_search_kernel);
     ptam_preload((const void*)tm_gather_kernel);
 }
