@@ -384,13 +384,14 @@ static int ba_prepare_impl(ptam_ba* ba) {
     auto k7_smem = [&](int threads) { return smem_base + (ba->use_wave ? (size_t)(threads / 64) * K7_WT_DOUBLES * sizeof(double) : 0); };
     // wave variant, two shapes:
     //  - few chunks (every 64-measurement chunk can be resident at once: <= 24 waves per CU):
-    //    straight-line kernel, ONE chunk per wave, 512-thread workgroups (64 VGPRs);
+    //    straight-line kernel, ONE chunk per wave, 1024-thread workgroups (79 VGPRs);
     //  - many chunks: persistent 256-thread workgroups looping over `per_wave` consecutive chunks,
     //    which amortises the LDS prologue and the camera-partial flush.
     const int n64_all = (M + 63) / 64;
     ba->k7_loop = ba->use_wave && n64_all > 256 * 24;
     if (const char* e = getenv("PTAM_K7_LOOP")) ba->k7_loop = ba->use_wave && atoi(e) != 0;   // shape sweeps (tools/k7_only.py)
-    ba->k7_threads = !ba->use_wave ? BA_CHUNK : (ba->k7_loop ? 256 : 512);
+    ba->k7_threads = !ba->use_wave ? BA_CHUNK : (ba->k7_loop ? 256 : 1024);   // (one chunk per wave: 1024-thread workgroups halve the
+                                                                                 //  camera-partial flush — 12.0 vs 12.3 us at 50 x 5000)
     int n_cu = 256;
     {
         hipDeviceProp_t prop;
@@ -434,6 +435,15 @@ static int ba_prepare_impl(ptam_ba* ba) {
             }
         }
         if (const char* e = getenv("PTAM_K7_WG_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));
+    }
+    if (ba->use_wave && !ba->k7_loop) {
+        if (const char* e = getenv("PTAM_K7_THREADS1")) {   // (A/B of the one-chunk-per-wave shape: 512 / 1024-thread workgroups)
+            const int t = atoi(e);
+            if (t == 512 || t == 1024) {
+                ba->k7_threads = t;
+                if (int rc = k7_occupancy(t, &per_cu)) return rc;
+            }
+        }
     }
     ba->smem_acc = k7_smem(ba->k7_threads);
     if (ba->use_wave) {
@@ -1600,6 +1610,7 @@ void ba_preload_kernels() {
     ptam_preload((const void*)place_keys_kernel);
     for (int est = 0; est < 2; est++) {
         ptam_preload(k7_wave_fn(512, false, est ? PTAM_EST_CAUCHY : PTAM_EST_TUKEY));
+        ptam_preload(k7_wave_fn(1024, false, est ? PTAM_EST_CAUCHY : PTAM_EST_TUKEY));
         ptam_preload(k7_wave_fn(256, true, est ? PTAM_EST_CAUCHY : PTAM_EST_TUKEY));
         ptam_preload(k7_wave_fn(512, true, est ? PTAM_EST_CAUCHY : PTAM_EST_TUKEY));
         ptam_preload(k7_wave_fn(1024, true, est ? PTAM_EST_CAUCHY : PTAM_EST_TUKEY));
