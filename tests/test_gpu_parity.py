@@ -336,6 +336,19 @@ def test_bundle_random_shapes(hip, oracle, case):
     util.assert_ba_equal(util.run_ba(hip, prob, estimator=est), util.run_ba(oracle, prob, estimator=est), rel=1e-6)
 
 
+@pytest.mark.parametrize("n_cams,fixed", [(30, (0, 3, 4, 11, 17)), (21, (0, 9, 10, 20)), (13, (2,)), (27, (0, 1, 8, 16, 24, 26))],
+                         ids=lambda v: str(v).replace(" ", ""))
+def test_bundle_fixed_cameras_anywhere(hip, oracle, n_cams, fixed):
+    """fixed cameras scattered through the camera order (the reference fixes whichever keyframes lie outside the
+    adjusted set, src/MapMaker.cc:791-824): their measurements sit BETWEEN those of a Schur tile's free cameras, so the
+    per-entry camera-slot tables of K8 must skip them; the free-camera counts 25 / 17 / 12 / 21 leave last tiles of
+    1 / 1 / 4 / 5 cameras (fragment modes 1, 1, 2, 2 of ba_schur.inc) beside full ones"""
+    prob = synth.make_ba_problem(n_cams, 260, 77 + n_cams, window=None if n_cams < 25 else 14)
+    prob["fixed"][:] = 0
+    prob["fixed"][list(fixed)] = 1
+    util.assert_ba_equal(util.run_ba(hip, prob), util.run_ba(oracle, prob), rel=1e-6)
+
+
 @pytest.mark.parametrize("est", [_abi.EST_CAUCHY, _abi.EST_HUBER])
 def test_bundle_other_estimators(hip, oracle, est):
     prob = synth.make_ba_problem(10, 150, 9)
