@@ -1360,8 +1360,10 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
         HIP_TRY(hipMemcpy(h, d.dbg, sizeof h, hipMemcpyDeviceToHost));
         std::printf("LDLT step2 wg0: loop %lld tail %lld | last wg (role %lld): loop %lld tail %lld\n", h[1] - h[0], h[2] - h[1], h[7],
                     h[5] - h[4], h[6] - h[5]);
-        std::printf("SCHUR wg100 cycles: total %lld fetch %lld compute %lld wait-for-loads %lld store %lld barrier %lld rounds %lld\n", h[10], h[11],
-                    h[12], h[9], h[13], h[14], h[15]);
+        long long q[8];
+        HIP_TRY(hipMemcpy(q, d.dbg + 32, sizeof q, hipMemcpyDeviceToHost));
+        std::printf("LDLT step2 wg0 iteration 3 (cycles): micro factor %lld | my rows %lld | next panel columns %lld | publish %lld | barrier %lld | "
+                    "operand reads issued %lld | off-chain updates %lld\n", q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], q[6] - q[5], q[7] - q[6]);
     }
 #endif
     // ---- read back results: one pinned staging buffer, one synchronisation (pageable destinations cost ~100 us each) ----
