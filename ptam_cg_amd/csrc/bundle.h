@@ -127,6 +127,7 @@ struct BaDev {
     double* Dg;
     double* y;              // forward-substituted rhs
     double* da;             // [npad] camera update
+    double* sumsq2;         // [2] |da|^2 in two parts (the two workgroups of the backward substitution; consumers add them)
     // outliers
     int* outliers;          // [M] original indices, in purge order
     BaScalars* sc;

@@ -490,7 +490,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     // bandwidth in force (the widest over all ranks) in Compute()'s first exchange
     const size_t se_full = se_size((int)(npad / SOLVE_NB), (int)(npad / SOLVE_NB) - 1);
     const size_t o_SE = cv.take((se_full + npad + 8) * 8), o_L = cv.take(se_full * 8), o_Dg = cv.take(npad * 8),
-                 o_y = cv.take(npad * 8), o_da = cv.take(npad * 8);
+                 o_y = cv.take(npad * 8), o_da = cv.take(npad * 8), o_sq2 = cv.take(16);
     const size_t o_out = cv.take(Mz * 4), o_sc = cv.take(sizeof(BaScalars)), o_dbg = cv.take(65536);
     ba->block_bytes = cv.off;
     if (!ctx_cache_take(ctx->dev_cache, ba->block_bytes, &ba->block, &ba->block_cap)) {   // (a released bundle's block, if it fits)
@@ -538,6 +538,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.Dg = (double*)(base + o_Dg);
     d.y = (double*)(base + o_y);
     d.da = (double*)(base + o_da);
+    d.sumsq2 = (double*)(base + o_sq2);
     d.outliers = (int*)(base + o_out);
     d.sc = (BaScalars*)(base + o_sc);
     d.dbg = (long long*)(base + o_dbg);

@@ -131,8 +131,13 @@ __global__ void __launch_bounds__(TPB) ldlt_step_twin_kernel(BaDev d, int k_top,
 // the upward chain's blocks from b_start up to the end — block k of that chain couples to the `band` blocks above it, whose
 // solution is known by then (left-looking: a (band * 32)-column mat-vec with the stored multiplier blocks, then the 32x32
 // triangular one), in the chain's mirrored coordinates.
+// TWO workgroups when the elimination was two-ended: the chains are independent given the middle's solution, so workgroup 0
+// substitutes the middle and the downward chain's blocks, workgroup 1 the middle AGAIN (2 * band blocks, bit-identical) and
+// then the upward chain's blocks — 22 sequential block steps each instead of 38 in a row at 200 keyframes / window 16.
+// Each writes its part of da, the trial poses of the cameras whose rows it knows, and its part of |da|^2 (d.sumsq2).
 __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur, int b_start) {
     TL_MARK(d, 10)
+    const int chain = blockIdx.x;   // 0: middle + downward chain (or everything, one-ended); 1: middle + upward chain
     extern __shared__ __attribute__((aligned(16))) double bw_lds[];
     const int npad = d.npad, nblk = npad / NB, band = se_band(d);
     double* xs = bw_lds;         // npad: the solution
@@ -145,10 +150,12 @@ __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur, i
         pend[i] = pend[npad + i] = pend[2 * npad + i] = pend[3 * npad + i] = 0.0;
         wv[i] = d.y[i] / d.Dg[i];
     }
+    const int t_end = nblk - b_start;                 // blocks of each chain (0: one-ended elimination)
+    const int k_stop = chain == 0 ? 0 : t_end;        // workgroup 1 stops above the middle
     double wnext = d.L[se_blk(b_start - 1, b_start - 1, band) + rr * NB + c];   // Lkk^-T element (rr, c)
-    for (int k = b_start - 1; k >= 0; k--) {
+    for (int k = b_start - 1; k >= k_stop; k--) {
         const double w = wnext;
-        if (k > 0) wnext = d.L[se_blk(k - 1, k - 1, band) + rr * NB + c];   // prefetch the next block
+        if (k > k_stop) wnext = d.L[se_blk(k - 1, k - 1, band) + rr * NB + c];   // prefetch the next block
         // first round of this block's update operands (independent of x_k): in flight during the mat-vec
         // columns of the blocks above that row block k reaches: all of them, or — S banded — the last `band` blocks
         const int jlo = max(0, k - band) * NB, ncol = k * NB - jlo;
@@ -188,7 +195,7 @@ __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur, i
         }
     }
     __syncthreads();
-    for (int k = b_start; k < nblk; k++) {
+    for (int k = b_start; k < nblk && chain == 1; k++) {
         const int jb = max(0, k - band), nj = k - jb;
         const double w = d.L[se_blk(k, k, band) + rr * NB + c];   // Lkk^-T element (rr, c), mirrored coordinates
         // thread (q = rr, lane c): row q of the stored blocks (k, jb .. k-1) against the known solution of those blocks
@@ -212,13 +219,19 @@ __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur, i
         if (c == NB - 1) xs[k * NB + (NB - 1 - rr)] = p;   // back to natural coordinates
         __syncthreads();
     }
-    for (int i = tid; i < npad; i += 1024) d.da[i] = xs[i];
+    // my part of the solution: rows [r_lo, r_hi)
+    const bool two = t_end > 0;
+    const int r_lo = chain == 0 ? 0 : b_start * NB, r_hi = (two && chain == 0) ? b_start * NB : npad;
+    for (int i = r_lo + tid; i < r_hi; i += 1024) d.da[i] = xs[i];
     // trial poses  exp(da_j) * se3CfW  (src/Bundle.cc:496-501) and |da|^2, straight from LDS: saves the
-    // separate pose-update launch
+    // separate pose-update launch.  A camera whose six rows reach into the upward chain's blocks belongs to workgroup 1
+    // (which knows the middle as well), every other one — the fixed ones included — to workgroup 0.
     for (int c2 = tid; c2 < d.C; c2 += 1024) {
+        const int f = d.cam_free[c2];
+        const bool mine = (two && f >= 0 && 6 * f + 5 >= b_start * NB) ? chain == 1 : chain == 0;
+        if (!mine) continue;
         const double* T = d.pose[cur] + 12 * c2;
         double* Tn = d.pose[cur ^ 1] + 12 * c2;
-        const int f = d.cam_free[c2];
         double Tl[12], o[12];
 #pragma unroll
         for (int i = 0; i < 12; i++) Tl[i] = T[i];
@@ -236,9 +249,12 @@ __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur, i
     }
     if (tid < 64) {
         double sq = 0;
-        for (int i = tid; i < d.n; i += 64) sq += xs[i] * xs[i];
+        for (int i = r_lo + tid; i < min(r_hi, d.n); i += 64) sq += xs[i] * xs[i];
         sq = wave_sum_f64(sq);
-        if (tid == 0) d.sc->sumsq_cam = sq;
+        if (tid == 0) {
+            d.sumsq2[chain] = sq;   // (finalize_new_kernel adds the two)
+            if (!two) d.sumsq2[1] = 0.0;
+        }
     }
 }
 
@@ -269,7 +285,7 @@ int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
         hipLaunchKernelGGL(ldlt_step_kernel, dim3(nwg), dim3(TPB), 0, ctx->stream, d, k, b_start);
     }
     const size_t bw_bytes = (size_t)6 * d.npad * sizeof(double);
-    hipLaunchKernelGGL(ldlt_backward_kernel, dim3(1), dim3(1024), bw_bytes, ctx->stream, d, cur, b_start);
+    hipLaunchKernelGGL(ldlt_backward_kernel, dim3(t_end > 0 ? 2 : 1), dim3(1024), bw_bytes, ctx->stream, d, cur, b_start);
     HIP_TRY(hipGetLastError());
     return PTAM_OK;
 }
