@@ -267,6 +267,13 @@ static int ba_prepare_impl(ptam_ba* ba) {
     {
         int NX = 8;   // point ranges (1 or 8)
         if (const char* e = getenv("PTAM_SCHUR_NX")) NX = atoi(e) == 8 ? 8 : 1;   // A/B runs (tools/dev/schur_ab.sh)
+        bool sort_pattern = true;
+        if (const char* e = getenv("PTAM_SCHUR_SORT")) sort_pattern = atoi(e) != 0;   // A/B runs
+        auto set01 = [](const unsigned o[2]) { return (o[0] != 0xffffffffu) || ((o[1] & 0xffffu) != 0xffffu); };   // slots 0..5
+        auto set2 = [](const unsigned o[2]) { return (o[1] >> 8) != 0xffffffu; };                                    // slots 5..7
+        auto pattern_of = [&](const SchurEntry& e) {
+            return (int)set01(e.offa) | ((int)set2(e.offa) << 1) | ((int)set01(e.offb) << 2) | ((int)set2(e.offb) << 3);
+        };
         bool span = true;   // a workgroup may end one pair and begin the next
         if (const char* e = getenv("PTAM_SCHUR_SPAN")) span = atoi(e) != 0;
         const int SLOTS = 256 * SCHUR_WG_PER_CU / NX, MIN_SEG = 16;
@@ -322,6 +329,10 @@ static int ba_prepare_impl(ptam_ba* ba) {
                 const int c = pair_cost[pr];
                 const int base = (int)s_entries.size() - lo[pr];   // position of the pair's entry i in s_entries: base + i
                 s_entries.insert(s_entries.end(), per_pair[pr].begin() + lo[pr], per_pair[pr].begin() + hi[pr]);
+                if (sort_pattern)   // entries of one fragment pattern next to each other: the kernel skips a fragment set only
+                                    // when none of the FOUR points of a group has a camera in it
+                    std::stable_sort(s_entries.end() - (hi[pr] - lo[pr]), s_entries.end(),
+                                     [&](const SchurEntry& u, const SchurEntry& v) { return pattern_of(u) < pattern_of(v); });
                 int pos = lo[pr];
                 while (pos < hi[pr]) {
                     const int left = hi[pr] - pos;
