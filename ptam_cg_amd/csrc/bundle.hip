@@ -277,24 +277,33 @@ static int ba_prepare_impl(ptam_ba* ba) {
         bool span = true;   // a workgroup may end one pair and begin the next
         if (const char* e = getenv("PTAM_SCHUR_SPAN")) span = atoi(e) != 0;
         const int SLOTS = 256 * SCHUR_WG_PER_CU / NX, MIN_SEG = 16;
-        // 16x16 fragments the kernel multiplies per entry of a pair (row mappings of ba_schur.inc: 1-2 cameras in a tile = 1
-        // fragment, 3-5 = 2, 6-8 = 3; a full diagonal pair skips two of its nine)
+        // 16x16 fragments per tile (row mappings of ba_schur.inc: 1-2 cameras in a tile = 1 fragment, 3-5 = 2, 6-8 = 3)
         auto frags = [&](int t) { const int n = std::min(SCHUR_TC, F - t * SCHUR_TC); return n <= 2 ? 1 : (n <= 5 ? 2 : 3); };
-        std::vector<int> pair_cost(n_pairs, 1);
-        // cost of an entry = fragments + 8: the loads of an iteration (the same for every pair) weigh about as much as eight
-        // fragments' MFMAs (A/B of 0 = entries only / fragments + 3 / + 8 / max(5, fragments): 75 / 72 / 69 / 75 us at 50 x 5000)
+        // cost of an entry = fragments multiplied + 8: the loads of an iteration (the same for every entry) weigh about as much
+        // as eight fragments' MFMAs (A/B of 0 = entries only / fragments + 3 / + 8 / max(5, fragments): 75 / 72 / 69 / 75 us at 50 x 5000)
         int cost_model = 8;
         if (const char* e = getenv("PTAM_SCHUR_COST")) cost_model = atoi(e);   // A/B runs
-        if (cost_model)
-            for (int a = 0, pr = 0; a < n_tiles; a++)
-                for (int b = 0; b <= a; b++, pr++) {
-                    const int f = a == b ? (frags(a) == 3 ? 7 : frags(a) * frags(a)) : frags(a) * frags(b);
-                    pair_cost[pr] = cost_model == 1 ? std::max(5, f) : f + cost_model;
-                }
+        // cost of one entry: the 16x16 fragments its pattern multiplies (+ cost_model for its loads)
+        std::vector<int> pair_a(n_pairs), pair_b(n_pairs);
+        for (int a = 0, pr = 0; a < n_tiles; a++)
+            for (int b = 0; b <= a; b++, pr++) pair_a[pr] = a, pair_b[pr] = b;
+        auto entry_cost = [&](int pr, const SchurEntry& e) {
+            if (!cost_model) return 1;
+            const int ma = frags(pair_a[pr]), mb = frags(pair_b[pr]);
+            const int a01 = set01(e.offa) ? std::min(ma, 2) : 0, a2 = (ma == 3 && set2(e.offa)) ? 1 : 0;
+            int f;
+            if (pair_a[pr] == pair_b[pr])
+                f = a01 * a01 + a2 * a01 + a2;
+            else {
+                const int b01 = set01(e.offb) ? std::min(mb, 2) : 0, b2 = (mb == 3 && set2(e.offb)) ? 1 : 0;
+                f = (a01 + a2) * (b01 + b2);
+            }
+            return cost_model == 1 ? std::max(5, f) : f + cost_model;
+        };
         // point ranges of equal cost
         std::vector<double> pt_cost(P + 1, 0.0);
         for (int pr = 0; pr < n_pairs; pr++)
-            for (const SchurEntry& e : per_pair[pr]) pt_cost[e.pt + 1] += pair_cost[pr];
+            for (const SchurEntry& e : per_pair[pr]) pt_cost[e.pt + 1] += entry_cost(pr, e);
         for (int p = 0; p < P; p++) pt_cost[p + 1] += pt_cost[p];
         int bound[9];
         bound[0] = 0;
@@ -312,7 +321,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
                 auto cmp = [](const SchurEntry& e, int p) { return e.pt < p; };
                 lo[pr] = (int)(std::lower_bound(v.begin(), v.end(), bound[x], cmp) - v.begin());
                 hi[pr] = (int)(std::lower_bound(v.begin(), v.end(), bound[x + 1], cmp) - v.begin());
-                cost_x += (double)(hi[pr] - lo[pr]) * pair_cost[pr];
+                for (int i = lo[pr]; i < hi[pr]; i++) cost_x += entry_cost(pr, v[i]);
                 ent_x += (size_t)(hi[pr] - lo[pr]);
             }
             if (ent_x == 0) continue;
@@ -326,27 +335,32 @@ static int ba_prepare_impl(ptam_ba* ba) {
                 cur_cost = 0;
             };
             for (int pr = 0; pr < n_pairs; pr++) {
-                const int c = pair_cost[pr];
                 const int base = (int)s_entries.size() - lo[pr];   // position of the pair's entry i in s_entries: base + i
                 s_entries.insert(s_entries.end(), per_pair[pr].begin() + lo[pr], per_pair[pr].begin() + hi[pr]);
                 if (sort_pattern)   // entries of one fragment pattern next to each other: the kernel skips a fragment set only
                                     // when none of the FOUR points of a group has a camera in it
                     std::stable_sort(s_entries.end() - (hi[pr] - lo[pr]), s_entries.end(),
                                      [&](const SchurEntry& u, const SchurEntry& v) { return pattern_of(u) < pattern_of(v); });
+                std::vector<double> pre((size_t)(hi[pr] - lo[pr]) + 1, 0.0);   // prefix costs of the chunk's (sorted) entries
+                for (int i = lo[pr]; i < hi[pr]; i++) pre[(size_t)(i - lo[pr]) + 1] = pre[(size_t)(i - lo[pr])] + entry_cost(pr, s_entries[(size_t)(base + i)]);
                 int pos = lo[pr];
                 while (pos < hi[pr]) {
                     const int left = hi[pr] - pos;
-                    int take = (int)((target - cur_cost) / c) / 4 * 4;
+                    // as many whole 4-entry groups as the workgroup's remaining budget pays for
+                    const double room = target - cur_cost, p0 = pre[(size_t)(pos - lo[pr])];
+                    int take = (int)(std::upper_bound(pre.begin() + (pos - lo[pr]), pre.end(), p0 + room) - (pre.begin() + (pos - lo[pr]))) - 1;
+                    take = std::max(0, take) / 4 * 4;
                     if (take < MIN_SEG && !cur.empty() && left > take) {   // a sliver at the end of a full workgroup: start the next one
                         close();
                         continue;
                     }
                     take = std::max(take, MIN_SEG);
                     if (left - take < MIN_SEG) take = left;                // ... or at the end of the pair's chunk: take it along
+                    take = std::min(take, left);
                     segs_of_pair[pr].push_back((int)s_segs.size());
                     cur.push_back((int)s_segs.size());
                     s_segs.push_back(SchurWG{pr, base + pos, base + pos + take, -1});
-                    cur_cost += (double)take * c;
+                    cur_cost += pre[(size_t)(pos - lo[pr] + take)] - p0;
                     pos += take;
                     if (cur_cost >= target * 0.98) close();
                 }
