@@ -32,6 +32,17 @@ for f in sorted(glob.glob("$OUT/pmc_ba/*counter_collection.csv")):
     for (k, c), (v, n) in sorted(agg.items()):
         print(f"{k[:28]:28s} {c:26s} per-launch {v / max(n,1):.4g}  (launches {n})")
 PY
+# the keyed traffic record bench.py reads (profiles/k7_pmc_traffic.json): written next to the summaries, copy it into profiles/
+python3 - <<PY
+import json
+rec = {}
+for key, dd in (("bundle_50kf_x_5000pts_dense", "$R/gpurun_out/pmc_${TAG}_headline"), ("bundle_200kf_x_50000pts_window16", "$R/gpurun_out/pmc_${TAG}_config5")):
+    try:
+        rec[key] = json.load(open(dd + "/traffic.json"))
+    except OSError:
+        pass
+json.dump(rec, open("$OUT/k7_pmc_traffic.json", "w"), indent=1)
+PY
 # gpurun merges at most 64 MiB back: keep the summaries, drop the raw per-dispatch tables
 rm -rf $OUT/pmc_ba $OUT/trace
 for dd in $R/gpurun_out/pmc_${TAG}_headline $R/gpurun_out/pmc_${TAG}_config5; do
