@@ -84,6 +84,15 @@ __device__ __forceinline__ void wave_find_patch_coarse(const KfLevels& L, const 
     }
     if (search) {
         const int tsum = wave_sum_i32(T), tsumsq = wave_sum_i32(T * T);
+        // Candidates are scored FOUR at a time: 16 lanes per candidate, 4 consecutive pixels per lane (one 32-bit load),
+        // the three sums by v_dot4_u32_u8 and four DPP row steps — ~45 instructions per four candidates instead of ~80 per
+        // candidate with a lane per pixel and three whole-wave sums (integer arithmetic: the same numbers, bit for bit).
+        // My four template pixels, packed like the image word: row sub / 2, columns 4 (sub % 2) .. + 3
+        const int sub = lane & 15, grp = lane >> 4;
+        const int tb = (sub >> 1) * 8 + (sub & 1) * 4;
+        const unsigned T4 = (unsigned)__shfl(T, tb, 64) | ((unsigned)__shfl(T, tb + 1, 64) << 8) | ((unsigned)__shfl(T, tb + 2, 64) << 16) |
+                            ((unsigned)__shfl(T, tb + 3, 64) << 24);
+        typedef unsigned u32_unaligned __attribute__((aligned(1)));
         int best = PTAM_MAX_SSD + 1, bx = -1, by = -1, nsc = 0;
         for (int base = i0; base < i1; base += 64) {
             const int idx = base + lane;
@@ -96,16 +105,41 @@ __device__ __forceinline__ void wave_find_patch_coarse(const KfLevels& L, const 
             }
             unsigned long long m = __ballot(pass);
             while (m) {
-                const int b = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const int cx = __shfl(c.x, b, 64), cy = __shfl(c.y, b, 64);
-                const int ssd = wave_zmssd(im, w, h, cx, cy, T, tsum, tsumsq, lane);
-                nsc++;
-                if (ssd < best) {
-                    best = ssd;
-                    bx = cx;
-                    by = cy;
-                }
+                int cx[4] = {0, 0, 0, 0}, cy[4] = {0, 0, 0, 0}, n = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (m) {   // (wave-uniform)
+                        const int b = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        cx[k] = __builtin_amdgcn_readlane(c.x, b);
+                        cy[k] = __builtin_amdgcn_readlane(c.y, b);
+                        n = k + 1;
+                    }
+                const int mx = grp == 0 ? cx[0] : grp == 1 ? cx[1] : grp == 2 ? cx[2] : cx[3];
+                const int my = grp == 0 ? cy[0] : grp == 1 ? cy[1] : grp == 2 ? cy[2] : cy[3];
+                const bool inb = grp < n && mx >= 4 && my >= 4 && mx < w - 4 && my < h - 4;
+                unsigned I4 = 0;
+                if (inb) I4 = *(const u32_unaligned*)(im + (size_t)(my - 4 + (sub >> 1)) * w + (mx - 4 + 4 * (sub & 1)));
+                int s1 = (int)__builtin_amdgcn_udot4(I4, 0x01010101u, 0u, false);
+                int s2 = (int)__builtin_amdgcn_udot4(I4, I4, 0u, false);
+                int s3 = (int)__builtin_amdgcn_udot4(I4, T4, 0u, false);
+                s1 += dpp_row_shr0_i32<1>(s1), s2 += dpp_row_shr0_i32<1>(s2), s3 += dpp_row_shr0_i32<1>(s3);
+                s1 += dpp_row_shr0_i32<2>(s1), s2 += dpp_row_shr0_i32<2>(s2), s3 += dpp_row_shr0_i32<2>(s3);
+                s1 += dpp_row_shr0_i32<4>(s1), s2 += dpp_row_shr0_i32<4>(s2), s3 += dpp_row_shr0_i32<4>(s3);
+                s1 += dpp_row_shr0_i32<8>(s1), s2 += dpp_row_shr0_i32<8>(s2), s3 += dpp_row_shr0_i32<8>(s3);
+                // (lane 15 of each 16-lane row holds its candidate's sums)
+                const int ssd_l = inb ? zmssd_finish(tsum, s1, s2, tsumsq, s3) : PTAM_MAX_SSD + 1;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (k < n) {   // in corner order: the first strict minimum wins
+                        const int ssd = __builtin_amdgcn_readlane(ssd_l, 16 * k + 15);
+                        nsc++;
+                        if (ssd < best) {
+                            best = ssd;
+                            bx = cx[k];
+                            by = cy[k];
+                        }
+                    }
             }
         }
         res.best_ssd = best;
