@@ -157,6 +157,7 @@ __global__ void __launch_bounds__(256) epipolar_search_kernel(KfLevels S, KfLeve
     }
     const int Tp = S.im[lev][(size_t)(q.level_y - 4 + (lane >> 3)) * sw + (q.level_x - 4 + (lane & 7))];
     const int tsum = wave_sum_i32(Tp), tsumsq = wave_sum_i32(Tp * Tp);
+    const unsigned T4 = wave_pack_template4(Tp, lane);
     const int tw = T.w[lev], th = T.h[lev];
     const uint8_t* im = T.im[lev];
     const ptam_int2* corners = T.corners[lev];
@@ -174,16 +175,28 @@ __global__ void __launch_bounds__(256) epipolar_search_kernel(KfLevels S, KfLeve
             c = corners[idx];
         }
         unsigned long long m = __ballot(pass);
-        while (m) {
-            const int b = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int cx = __shfl(c.x, b, 64), cy = __shfl(c.y, b, 64);
-            const int ssd = wave_zmssd(im, tw, th, cx, cy, Tp, tsum, tsumsq, lane);
-            nsc++;
-            if (ssd < best) {
-                best = ssd;
-                bi = base + b;
-            }
+        while (m) {   // four candidates per pass (wave_zmssd4), judged in corner order
+            int cx[4] = {0, 0, 0, 0}, cy[4] = {0, 0, 0, 0}, bb[4] = {0, 0, 0, 0}, nn = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (m) {   // (wave-uniform)
+                    bb[k] = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    cx[k] = __builtin_amdgcn_readlane(c.x, bb[k]);
+                    cy[k] = __builtin_amdgcn_readlane(c.y, bb[k]);
+                    nn = k + 1;
+                }
+            const int ssd_l = wave_zmssd4(im, tw, th, cx, cy, nn, T4, tsum, tsumsq, lane);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (k < nn) {
+                    const int ssd = __builtin_amdgcn_readlane(ssd_l, 16 * k + 15);
+                    nsc++;
+                    if (ssd < best) {
+                        best = ssd;
+                        bi = base + bb[k];
+                    }
+                }
         }
     }
     res.best = bi;

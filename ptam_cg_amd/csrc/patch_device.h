@@ -44,6 +44,35 @@ __device__ __forceinline__ int wave_zmssd(const uint8_t* __restrict__ im, int w,
     return zmssd_finish(tsum, isum, isumsq, tsumsq, cross);
 }
 
+// Four candidates per pass: 16 lanes per candidate, 4 consecutive window pixels per lane (one 32-bit load), the three sums
+// by v_dot4_u32_u8 against the lane's packed template pixels and four DPP row steps — ~45 instructions per four candidates
+// instead of ~80 per candidate with a lane per pixel and three whole-wave sums (integer arithmetic: the same numbers, bit
+// for bit).  wave_pack_template4: my four template pixels, packed like the image word (row sub / 2, columns 4 (sub % 2) .. + 3,
+// sub = lane % 16).  wave_zmssd4: lane 16 k + 15 returns candidate k's score (PTAM_MAX_SSD + 1 outside the border, like wave_zmssd).
+__device__ __forceinline__ unsigned wave_pack_template4(int T, int lane) {
+    const int sub = lane & 15, tb = (sub >> 1) * 8 + (sub & 1) * 4;
+    return (unsigned)__shfl(T, tb, 64) | ((unsigned)__shfl(T, tb + 1, 64) << 8) | ((unsigned)__shfl(T, tb + 2, 64) << 16) |
+           ((unsigned)__shfl(T, tb + 3, 64) << 24);
+}
+__device__ __forceinline__ int wave_zmssd4(const uint8_t* __restrict__ im, int w, int h, const int cx[4], const int cy[4], int n,
+                                           unsigned T4, int tsum, int tsumsq, int lane) {
+    typedef unsigned u32_unaligned __attribute__((aligned(1)));
+    const int sub = lane & 15, grp = lane >> 4;
+    const int mx = grp == 0 ? cx[0] : grp == 1 ? cx[1] : grp == 2 ? cx[2] : cx[3];
+    const int my = grp == 0 ? cy[0] : grp == 1 ? cy[1] : grp == 2 ? cy[2] : cy[3];
+    const bool inb = grp < n && mx >= 4 && my >= 4 && mx < w - 4 && my < h - 4;
+    unsigned I4 = 0;
+    if (inb) I4 = *(const u32_unaligned*)(im + (size_t)(my - 4 + (sub >> 1)) * w + (mx - 4 + 4 * (sub & 1)));
+    int s1 = (int)__builtin_amdgcn_udot4(I4, 0x01010101u, 0u, false);
+    int s2 = (int)__builtin_amdgcn_udot4(I4, I4, 0u, false);
+    int s3 = (int)__builtin_amdgcn_udot4(I4, T4, 0u, false);
+    s1 += dpp_row_shr0_i32<1>(s1), s2 += dpp_row_shr0_i32<1>(s2), s3 += dpp_row_shr0_i32<1>(s3);
+    s1 += dpp_row_shr0_i32<2>(s1), s2 += dpp_row_shr0_i32<2>(s2), s3 += dpp_row_shr0_i32<2>(s3);
+    s1 += dpp_row_shr0_i32<4>(s1), s2 += dpp_row_shr0_i32<4>(s2), s3 += dpp_row_shr0_i32<4>(s3);
+    s1 += dpp_row_shr0_i32<8>(s1), s2 += dpp_row_shr0_i32<8>(s2), s3 += dpp_row_shr0_i32<8>(s3);
+    return inb ? zmssd_finish(tsum, s1, s2, tsumsq, s3) : PTAM_MAX_SSD + 1;   // (lane 15 of each 16-lane row holds its candidate's)
+}
+
 // PatchFinder::FindPatchCoarse (src/PatchFinder.cc:160-211) by one wave: lane = pixel of the 8x8 window, T = this lane's
 // template pixel.  enabled = false: the query is not searched (bad template).
 __device__ __forceinline__ void wave_find_patch_coarse(const KfLevels& L, const ptam_patch_query& q, bool enabled, int T, int lane,
@@ -84,15 +113,7 @@ __device__ __forceinline__ void wave_find_patch_coarse(const KfLevels& L, const 
     }
     if (search) {
         const int tsum = wave_sum_i32(T), tsumsq = wave_sum_i32(T * T);
-        // Candidates are scored FOUR at a time: 16 lanes per candidate, 4 consecutive pixels per lane (one 32-bit load),
-        // the three sums by v_dot4_u32_u8 and four DPP row steps — ~45 instructions per four candidates instead of ~80 per
-        // candidate with a lane per pixel and three whole-wave sums (integer arithmetic: the same numbers, bit for bit).
-        // My four template pixels, packed like the image word: row sub / 2, columns 4 (sub % 2) .. + 3
-        const int sub = lane & 15, grp = lane >> 4;
-        const int tb = (sub >> 1) * 8 + (sub & 1) * 4;
-        const unsigned T4 = (unsigned)__shfl(T, tb, 64) | ((unsigned)__shfl(T, tb + 1, 64) << 8) | ((unsigned)__shfl(T, tb + 2, 64) << 16) |
-                            ((unsigned)__shfl(T, tb + 3, 64) << 24);
-        typedef unsigned u32_unaligned __attribute__((aligned(1)));
+        const unsigned T4 = wave_pack_template4(T, lane);   // candidates are scored four at a time (wave_zmssd4)
         int best = PTAM_MAX_SSD + 1, bx = -1, by = -1, nsc = 0;
         for (int base = i0; base < i1; base += 64) {
             const int idx = base + lane;
@@ -115,20 +136,7 @@ __device__ __forceinline__ void wave_find_patch_coarse(const KfLevels& L, const 
                         cy[k] = __builtin_amdgcn_readlane(c.y, b);
                         n = k + 1;
                     }
-                const int mx = grp == 0 ? cx[0] : grp == 1 ? cx[1] : grp == 2 ? cx[2] : cx[3];
-                const int my = grp == 0 ? cy[0] : grp == 1 ? cy[1] : grp == 2 ? cy[2] : cy[3];
-                const bool inb = grp < n && mx >= 4 && my >= 4 && mx < w - 4 && my < h - 4;
-                unsigned I4 = 0;
-                if (inb) I4 = *(const u32_unaligned*)(im + (size_t)(my - 4 + (sub >> 1)) * w + (mx - 4 + 4 * (sub & 1)));
-                int s1 = (int)__builtin_amdgcn_udot4(I4, 0x01010101u, 0u, false);
-                int s2 = (int)__builtin_amdgcn_udot4(I4, I4, 0u, false);
-                int s3 = (int)__builtin_amdgcn_udot4(I4, T4, 0u, false);
-                s1 += dpp_row_shr0_i32<1>(s1), s2 += dpp_row_shr0_i32<1>(s2), s3 += dpp_row_shr0_i32<1>(s3);
-                s1 += dpp_row_shr0_i32<2>(s1), s2 += dpp_row_shr0_i32<2>(s2), s3 += dpp_row_shr0_i32<2>(s3);
-                s1 += dpp_row_shr0_i32<4>(s1), s2 += dpp_row_shr0_i32<4>(s2), s3 += dpp_row_shr0_i32<4>(s3);
-                s1 += dpp_row_shr0_i32<8>(s1), s2 += dpp_row_shr0_i32<8>(s2), s3 += dpp_row_shr0_i32<8>(s3);
-                // (lane 15 of each 16-lane row holds its candidate's sums)
-                const int ssd_l = inb ? zmssd_finish(tsum, s1, s2, tsumsq, s3) : PTAM_MAX_SSD + 1;
+                const int ssd_l = wave_zmssd4(im, w, h, cx, cy, n, T4, tsum, tsumsq, lane);
 #pragma unroll
                 for (int k = 0; k < 4; k++)
                     if (k < n) {   // in corner order: the first strict minimum wins
