@@ -78,12 +78,7 @@ __device__ __forceinline__ void block_scan4(const int v[4], int off[4], int tot[
     int incl[4];
 #pragma unroll
     for (int l = 0; l < 4; l++) {
-        int x = v[l];
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int y = __shfl_up(x, d, 64);
-            if (lane >= d) x += y;
-        }
+        const int x = wave_incl_scan_i32(v[l]);   // (DPP: a __shfl_up ladder is six LDS round trips per counter)
         incl[l] = x;
         if (lane == 63) wsum[l][wid] = x;
     }
@@ -102,25 +97,54 @@ __device__ __forceinline__ void block_scan4(const int v[4], int off[4], int tot[
     __syncthreads();
 }
 
-// The choice of the search sets, src/Tracker.cc:480-611.  One workgroup.
+// The choice of the search sets, src/Tracker.cc:480-611.  One workgroup.  The level lists and the fine-candidate flags live
+// in LDS when the map has at most TM_SEL_LDS points (global scratch otherwise): a list written to global memory and read
+// back by another thread of the workgroup costs two round trips per pass, and this kernel is a chain of such passes.
+#define TM_SEL_LDS 2048
 __device__ __forceinline__ void tm_select_body(const TmDev& d, const ptam_trackmap_opts& o) {   // a 1024-thread workgroup
     __shared__ int wsum[4][16];
+    __shared__ int ls_list[4][TM_SEL_LDS];
+    __shared__ uint8_t ls_isfc[TM_SEL_LDS];
     const int tid = threadIdx.x, n = d.n, cap = d.cap;
+    const bool lds = n <= TM_SEL_LDS;
     const int chunk = (n + 1023) / 1024, p0 = min(n, tid * chunk), p1 = min(n, p0 + chunk);
+    // both permutations' entries of my run and the levels of the first one's points leave together
+    constexpr int RUNMAX = 2;   // (runs longer than this — maps of more than 2048 points — reload inside the loops)
+    int ida[RUNMAX] = {0, 0}, idb[RUNMAX] = {0, 0}, lva[RUNMAX] = {-1, -1};
+#pragma unroll
+    for (int j = 0; j < RUNMAX; j++)
+        if (p0 + j < p1) {
+            ida[j] = d.perm_a[p0 + j];
+            idb[j] = d.perm_b[p0 + j];
+        }
+#pragma unroll
+    for (int j = 0; j < RUNMAX; j++)
+        if (p0 + j < p1) lva[j] = d.pvs[ida[j]].level;
+    auto id_a = [&](int p) { return p - p0 < RUNMAX ? (p - p0 == 0 ? ida[0] : ida[1]) : d.perm_a[p]; };
+    auto id_b = [&](int p) { return p - p0 < RUNMAX ? (p - p0 == 0 ? idb[0] : idb[1]) : d.perm_b[p]; };
+    auto lv_a = [&](int p, int id) { return p - p0 < RUNMAX ? (p - p0 == 0 ? lva[0] : lva[1]) : d.pvs[id].level; };
+    auto set_fc = [&](int id, int v) { if (lds) ls_isfc[id] = (uint8_t)v; else d.isfc[id] = (uint8_t)v; };
+    auto get_fc = [&](int id) { return lds ? (int)ls_isfc[id] : (int)d.isfc[id]; };
+    auto LL = [&](int l, int i) -> int { return lds ? ls_list[l][i] : d.lvl_list[l * cap + i]; };
     // level lists in the order the shuffle permutation visits their members
     int cnt[4] = {0, 0, 0, 0};
     for (int p = p0; p < p1; p++) {
-        const int id = d.perm_a[p];
-        const int l = d.pvs[id].level;
-        d.isfc[id] = 0;
+        const int id = id_a(p);
+        const int l = lv_a(p, id);
+        set_fc(id, 0);
         if (l >= 0) cnt[l]++;
     }
     int off[4], tot[4];
     block_scan4(cnt, off, tot, wsum);
     for (int p = p0; p < p1; p++) {
-        const int id = d.perm_a[p];
-        const int l = d.pvs[id].level;
-        if (l >= 0) d.lvl_list[l * cap + off[l]++] = id;
+        const int id = id_a(p);
+        const int l = lv_a(p, id);
+        if (l >= 0) {
+            if (lds)
+                ls_list[l][off[l]++] = id;
+            else
+                d.lvl_list[l * cap + off[l]++] = id;
+        }
     }
     __syncthreads();
     const int n3 = tot[3], n2 = tot[2], n1 = tot[1], n0 = tot[0];
@@ -150,18 +174,14 @@ __device__ __forceinline__ void tm_select_body(const TmDev& d, const ptam_trackm
     const int n_use = max(0, o.max_patches - (nC + nH));   // :594-596
     const bool chop = nFC > n_use;
     const int nF = chop ? n_use : nFC;
-    const int* L3 = d.lvl_list + 3 * cap;
-    const int* L2 = d.lvl_list + 2 * cap;
-    const int* L1 = d.lvl_list + 1 * cap;
-    const int* L0 = d.lvl_list;
-    for (int s = tid; s < nC; s += 1024) d.list[s] = s < nC3 ? L3[s] : L2[s - nC3];
-    for (int s = tid; s < nH; s += 1024) d.list[nC + s] = L3[t3 + s];
+    for (int s = tid; s < nC; s += 1024) d.list[s] = s < nC3 ? LL(3, s) : LL(2, s - nC3);
+    for (int s = tid; s < nH; s += 1024) d.list[nC + s] = LL(3, t3 + s);
     // fine candidates in the order of :588-590: levels 2, 1, 0
     for (int s = tid; s < nFC; s += 1024) {
         const int a = n2 - t2;
-        const int id = s < a ? L2[t2 + s] : (s < a + n1 ? L1[s - a] : L0[s - a - n1]);
+        const int id = s < a ? LL(2, t2 + s) : (s < a + n1 ? LL(1, s - a) : LL(0, s - a - n1));
         if (chop)
-            d.isfc[id] = 1;
+            set_fc(id, 1);
         else
             d.list[nC + nH + s] = id;
     }
@@ -169,13 +189,13 @@ __device__ __forceinline__ void tm_select_body(const TmDev& d, const ptam_trackm
         // random_shuffle + resize (:597-600): the first n_use members in the order of the second permutation
         __syncthreads();
         int c4[4] = {0, 0, 0, 0};
-        for (int p = p0; p < p1; p++) c4[0] += d.isfc[d.perm_b[p]];
+        for (int p = p0; p < p1; p++) c4[0] += get_fc(id_b(p));
         int o4[4], t4[4];
         block_scan4(c4, o4, t4, wsum);
         int k = o4[0];
         for (int p = p0; p < p1; p++) {
-            const int id = d.perm_b[p];
-            if (d.isfc[id]) {
+            const int id = id_b(p);
+            if (get_fc(id)) {
                 if (k < n_use) d.list[nC + nH + k] = id;
                 k++;
             }
