@@ -386,6 +386,13 @@ int ptam_track_map(ptam_tracker* t, const ptam_kf* current, const double pose_in
  * d_frame (stride == width) into `current`, then TrackMap against it: one entry, one queue, one wait. */
 int ptam_track_map_frame(ptam_tracker* t, ptam_kf* current, const uint8_t* d_frame, const double pose_in[12],
                          const ptam_trackmap_opts* opts, ptam_trackmap_result* out);
+/* Measurement helper, not part of the reference's surface: n independent trackers (each with its own context, map and
+ * keyframes) driven by n host threads inside the library, frames_each frames per thread — per frame ptam_tracker_set_shuffle
+ * then ptam_track_map_frame, as the tracker thread of src/Tracker.cc:442-696 would issue them.  *seconds_out = wall time
+ * from the common start to the last return (bench.py: aggregate frames/s of replicas on one device). */
+int ptam_bench_track_frames(int n, ptam_tracker* const* trackers, ptam_kf* const* current, const uint8_t* const* d_frames,
+                            const double pose_in[12], const ptam_trackmap_opts* opts, const int32_t* shuffle_levels,
+                            const int32_t* shuffle_fine, int frames_each, double* seconds_out);
 /* vIterationSet of the last frame (what :667-676 turns into mCurrentKF.mMeasurements): *n = its length; out (nullable)
  * receives up to cap entries. */
 int ptam_tracker_read_iteration_set(ptam_tracker* t, ptam_trackmap_meas* out, int cap, int* n);

@@ -172,6 +172,7 @@ PROTOTYPES = {
     "tracker_set_shuffle": (_i, [_vp, _vp, _vp]),
     "track_map": (_i, [_vp, _vp, _pd, _vp, _vp]),
     "track_map_frame": (_i, [_vp, _vp, _vp, _pd, _vp, _vp]),
+    "bench_track_frames": (_i, [_i, _vp, _vp, _vp, _pd, _vp, _vp, _vp, _i, _pd]),
     "tracker_read_iteration_set": (_i, [_vp, _vp, _i, C.POINTER(_i)]),
     "ba_bench_jacobian_rotating": (_i, [_vp, _i, _i, _pd]),
     "ba_set_comm": (_i, [_vp, _i, _i, ALLREDUCE_FN, _vp]),

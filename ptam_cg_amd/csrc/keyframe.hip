@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) fast_detect_kernel(KfLevels L) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2b: one block per level (body: keyframe_device.h).
+// K2b: ceil(entries / 1024) workgroups per level, independent of each other (body: keyframe_device.h).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) fast_compact_kernel(KfLevels L, int rest) { fast_compact_body(L, blockIdx.x, rest); }
 
@@ -262,7 +262,7 @@ static int kf_run(ptam_ctx* ctx, ptam_kf* kf, const uint8_t* d_src, hipStream_t 
     else
         hipLaunchKernelGGL(pyramid_kernel<PTAM_HALFSAMPLE_R>, grd, blk, 0, stream, a);
     hipLaunchKernelGGL(fast_detect_kernel, dim3(kf->n_blocks), dim3(256), 0, stream, kf->L);
-    hipLaunchKernelGGL(fast_compact_kernel, dim3(PTAM_LEVELS), dim3(1024), 0, stream, kf->L, 0);
+    hipLaunchKernelGGL(fast_compact_kernel, dim3(fast_compact_blocks(kf->L)), dim3(1024), 0, stream, kf->L, 0);
     HIP_TRY(hipGetLastError());
     kf->counts_valid = 0;
     kf->rest_valid = 0;
@@ -329,7 +329,7 @@ int ptam_make_keyframe_rest(ptam_ctx* ctx, ptam_kf* kf) {
         const int n = kf->n_corners[l];
         if (n > 0) hipLaunchKernelGGL(fast_nonmax_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, kf->L, l);
     }
-    hipLaunchKernelGGL(fast_compact_kernel, dim3(PTAM_LEVELS), dim3(1024), 0, ctx->stream, kf->L, 1);
+    hipLaunchKernelGGL(fast_compact_kernel, dim3(fast_compact_blocks(kf->L)), dim3(1024), 0, ctx->stream, kf->L, 1);
     for (int l = 0; l < PTAM_LEVELS; l++) {
         const int n = kf->n_corners[l];   // upper bound of the maximal corners; the kernel checks nmax
         if (n > 0) hipLaunchKernelGGL(shi_tomasi_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, kf->L, l);

@@ -97,48 +97,57 @@ __device__ __forceinline__ void pyramid_body(const PyrArgs& a, int bx, int by) {
 
 
 // ------------------------------------------------------------------------------------------------
-// K2b: one block per level.  Entries e = y*ntx + tx in raster order; thread t owns a contiguous
-// chunk of entries, so an exclusive scan of per-thread popcounts gives raster-ordered offsets.
+// K2b: raster-ordered corner lists + row LUTs from the (row, tile) bit masks.  Entries e = y*ntx + tx in raster order, ONE
+// entry per thread, ceil(E / 1024) workgroups per level (640x480: 5 + 2 + 1 + 1).  A workgroup needs the number of corners
+// in front of its slice: it counts them itself — the masks of the whole level are 38 KB at most, a preceding slice is one
+// more 8-byte load per thread, issued together with the thread's own — so the workgroups of a level never talk to each
+// other (no look-back chain, no second launch), and the block-wide exclusive scan of the slice gives the offsets.
 // rowlut[y] = offset of entry (y, 0) = index of the first corner with row >= y (src/KeyFrame.cc:46-52).
+// (The first version ran ONE workgroup per level with five consecutive entries per thread: 6.6 us for 640x480.)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fast_compact_body(const KfLevels& L, int lev, int rest) {   // a 1024-thread workgroup
-    __shared__ int wsum[16];
-    __shared__ int total_s;
-    const int h = L.h[lev], ntx = L.ntx[lev];
-    const int E = h * ntx;
-    const int per = (E + 1023) / 1024;
-    const int e0 = threadIdx.x * per, e1 = min(E, e0 + per);
-    const unsigned long long* __restrict__ mask = rest ? L.mmask[lev] : L.mask[lev];
-    int cnt = 0;
-    for (int e = e0; e < e1; e++) cnt += __popcll(mask[e]);
-    // block exclusive scan
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int incl = wave_incl_scan_i32(cnt);
-    if (lane == 63) wsum[wid] = incl;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int i = 0; i < 16; i++) {
-            const int v = wsum[i];
-            wsum[i] = run;
-            run += v;
-        }
-        total_s = run;
+__host__ __device__ __forceinline__ int fast_compact_blocks(const KfLevels& L) {
+    int n = 0;
+    for (int l = 0; l < PTAM_LEVELS; l++) n += (L.h[l] * L.ntx[l] + 1023) / 1024;
+    return n;
+}
+__device__ __forceinline__ void fast_compact_body(const KfLevels& L, int blk, int rest) {   // a 1024-thread workgroup
+    __shared__ int wsum[16], wbase[16];
+    int lev = 0, b = blk;
+    for (; lev < PTAM_LEVELS - 1; lev++) {
+        const int nb = (L.h[lev] * L.ntx[lev] + 1023) / 1024;
+        if (b < nb) break;
+        b -= nb;
     }
+    const int ntx = L.ntx[lev], E = L.h[lev] * ntx;
+    const unsigned long long* __restrict__ mask = rest ? L.mmask[lev] : L.mask[lev];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int e = b * 1024 + tid;
+    unsigned long long m = e < E ? mask[e] : 0ull;
+    int before = 0;
+    for (int k = 0; k < b; k++) before += __popcll(mask[k * 1024 + tid]);
+    const int cnt = __popcll(m);
+    const int incl = wave_incl_scan_i32(cnt);
+    before = wave_sum_i32(before);
+    if (lane == 63) wsum[wid] = incl;
+    if (lane == 0) wbase[wid] = before;
     __syncthreads();
-    int off = wsum[wid] + incl - cnt;
+    int base = 0, off = 0, slice = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        base += wbase[i];
+        off += i < wid ? wsum[i] : 0;
+        slice += wsum[i];
+    }
+    off += base + incl - cnt;
     ptam_int2* __restrict__ out = rest ? L.mcorners[lev] : L.corners[lev];
-    int* __restrict__ lut = rest ? nullptr : L.rowlut[lev];
-    for (int e = e0; e < e1; e++) {
+    if (e < E) {
         const int y = e / ntx, tx = e - y * ntx;
-        if (tx == 0 && lut) lut[y] = off;
-        unsigned long long m = mask[e];
+        if (tx == 0 && !rest) L.rowlut[lev][y] = off;
         while (m) {
             const int bit = __ffsll((long long)m) - 1;
             m &= m - 1;
             out[off++] = ptam_int2{tx * FAST_TW + bit, y};
         }
     }
-    if (threadIdx.x == 0) (rest ? L.nmax : L.ncorners)[lev] = total_s;
+    if (tid == 0 && (b + 1) * 1024 >= E) (rest ? L.nmax : L.ncorners)[lev] = base + slice;
 }
-

@@ -18,6 +18,8 @@
 // with its re-projection at the post-coarse pose and the camera derivatives of the PVS pass (ProjectAndDerivs only
 // refreshes them for found points, include/Tracker.h:89-94).
 #include <atomic>
+#include <chrono>
+#include <thread>
 
 #include "track_internal.h"
 #include "patch_device.h"
@@ -225,7 +227,7 @@ __global__ void __launch_bounds__(1024) tm_select_kernel(TmDev d, ptam_trackmap_
 // run on separate queues the two cross-queue waits cost more than the overlap (measured, see track_map_impl), but as
 // workgroups of ONE launch they overlap for free — every kernel of this chain leaves most of the chip idle.
 //   launch 1: pyramid (its 2-D grid linearised) | PVS pass        launch 2: FAST detect
-//   launch 3: set choice (workgroup 0) | raster-ordered corner compaction (one workgroup per level)
+//   launch 3: set choice (workgroup 0) | raster-ordered corner compaction (9 independent workgroups at 640x480)
 template <int VARIANT>
 __global__ void __launch_bounds__(256) tm_pyr_pvs_kernel(PyrArgs a, int gx, int n_pyr, DevCam cam, int n, const ptam_pvs_point* __restrict__ pts,
                                                          ptam_pvs_result* __restrict__ out, PoseArg pv, double* __restrict__ pose_out) {
@@ -756,7 +758,7 @@ static int track_map_impl(ptam_tracker* t, ptam_kf* cur, const uint8_t* d_new_fr
             hipLaunchKernelGGL(tm_pyr_pvs_kernel<PTAM_HALFSAMPLE_R>, dim3(n_pyr + n_pvs), dim3(256), 0, st, pa, gx, n_pyr, ctx->cam, std::max(n, 0),
                                (const ptam_pvs_point*)d.pts, d.pvs, pv, d.pose);
         kf_launch_detect(cur, st);
-        hipLaunchKernelGGL(tm_compact_select_kernel, dim3(1 + PTAM_LEVELS), dim3(1024), 0, st, cur->L, d, o);
+        hipLaunchKernelGGL(tm_compact_select_kernel, dim3(1 + fast_compact_blocks(cur->L)), dim3(1024), 0, st, cur->L, d, o);
     } else {
         rc = pvs_launch_dev(ctx, n, d.pts, d.pose, pose_in, d.pvs);                         // :453-478 (the pose rides in as an argument)
         if (rc) return rc;
@@ -926,6 +928,52 @@ int ptam_refind_batch(ptam_ctx* ctx, const ptam_kf* kf, const double kf_pose[12]
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, b + o_out, N * sizeof(ptam_refind_result), hipMemcpyDeviceToHost, st));
     HIP_TRY(ptam_stream_wait(st));   // (also keeps hs[] alive until its pageable copy has been staged)
+    return PTAM_OK;
+}
+
+// Measurement helper (like ptam_ba_bench_jacobian): the "replicas" axis of the tracking path driven natively.
+// n independent trackers — each with its own context (stream, scratch, mailbox), map and keyframes — are run by n host
+// threads, frames_each frames per thread: per frame the two permutations are handed over (ptam_tracker_set_shuffle) and
+// ptam_track_map_frame is called exactly as the reference's tracker thread would.  The threads start together; *seconds_out
+// is the wall time from that start to the last thread's return, n * frames_each frames in all.
+int ptam_bench_track_frames(int n, ptam_tracker* const* trackers, ptam_kf* const* current, const uint8_t* const* d_frames,
+                            const double pose_in[12], const ptam_trackmap_opts* opts, const int32_t* shuffle_levels,
+                            const int32_t* shuffle_fine, int frames_each, double* seconds_out) {
+    ARG_TRY(n >= 1 && n <= 1024 && trackers && current && d_frames && pose_in && shuffle_levels && shuffle_fine && frames_each >= 1 && seconds_out);
+    for (int i = 0; i < n; i++) ARG_TRY(trackers[i] && current[i] && d_frames[i]);
+    std::atomic<int> ready{0}, failed{0};
+    std::atomic<bool> go{false};
+    std::vector<std::string> errs((size_t)n);
+    std::vector<std::thread> th;
+    th.reserve((size_t)n);
+    for (int i = 0; i < n; i++)
+        th.emplace_back([&, i]() {
+            ptam_trackmap_result res;
+            ready.fetch_add(1);
+            while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+            for (int f = 0; f < frames_each; f++) {
+                int rc = ptam_tracker_set_shuffle(trackers[i], shuffle_levels, shuffle_fine);
+                if (!rc) rc = ptam_track_map_frame(trackers[i], current[i], d_frames[i], pose_in, opts, &res);
+                if (rc) {
+                    errs[(size_t)i] = ptam_last_error();
+                    failed.store(rc);
+                    return;
+                }
+            }
+        });
+    while (ready.load() < n) std::this_thread::yield();
+    const auto t0 = std::chrono::steady_clock::now();
+    go.store(true, std::memory_order_release);
+    for (auto& t : th) t.join();
+    *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (failed.load()) {
+        for (const auto& e : errs)
+            if (!e.empty()) {
+                ptam_set_error("ptam_bench_track_frames: a worker failed: %s", e.c_str());
+                break;
+            }
+        return failed.load();
+    }
     return PTAM_OK;
 }
 
