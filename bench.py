@@ -400,11 +400,17 @@ def main():
                 "frac": flops / t / 78.6e12 if t > 0 else None}
 
     def kernel_breakdown(problem, steps, sharded=True):
-        kb = new_bundle(steps, problem, sharded)
-        kb.set_profiling(True)
-        kb.Compute()
-        out = {k: (ms / n) for k, (ms, n) in kb.kernel_times().items() if n > 0}
-        kb.close()
+        # two profiled runs, per kernel the smaller average: now and then one event bracket of a run catches a stall of
+        # several milliseconds (seen in the solve bracket: 0.4 - 0.8 ms "per trial" instead of 0.1)
+        out = {}
+        for _ in range(2):
+            kb = new_bundle(steps, problem, sharded)
+            kb.set_profiling(True)
+            kb.Compute()
+            for k, (ms, n) in kb.kernel_times().items():
+                if n > 0:
+                    out[k] = min(out.get(k, float("inf")), ms / n)
+            kb.close()
         return out
 
     dt, trials, (n_cams, n_free, n_points, n_meas), spin = timed_compute(prob, args.steps, args.warmup)
