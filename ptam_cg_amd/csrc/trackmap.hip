@@ -564,6 +564,12 @@ struct ptam_tracker {
     TmMailbox* mbox;       // host-mapped
     TmMailbox* mbox_dev;
     unsigned long long seq;
+    // the frame's two permutations in host-mapped memory (maps of at most TM_SEL_LDS points: the set-choice kernel reads every
+    // entry exactly once, at its start) — no upload, i.e. two copy kernels and their boundaries less per frame (~10 us);
+    // d.perm_a / d.perm_b point either here or at the device arrays
+    int* perm_host;        // [2][cap], host address
+    int* perm_host_dev;    // device address of the same memory
+    int *perm_dev_a, *perm_dev_b;
 };
 
 extern "C" {
@@ -645,6 +651,22 @@ int ptam_tracker_create(ptam_ctx* ctx, int max_points, ptam_tracker** out) {
     HIP_TRY(hipHostGetDevicePointer(&dv, h, 0));
     t->mbox = (TmMailbox*)h;
     t->mbox_dev = (TmMailbox*)dv;
+    t->perm_dev_a = d.perm_a;
+    t->perm_dev_b = d.perm_b;
+    {
+        void *hp = nullptr, *dp = nullptr;
+        if (hipHostMalloc(&hp, cap * 8, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+            if (hp) hipHostFree(hp);
+            hipHostFree(h);
+            hipFree(t->block);
+            delete t;
+            ptam_set_error("hipHostMalloc failed");
+            return PTAM_E_HIP;
+        }
+        t->perm_host = (int*)hp;
+        t->perm_host_dev = (int*)dp;
+    }
     // identity shuffles until the caller sets its own
     std::vector<int> idp((size_t)max_points);
     for (int i = 0; i < max_points; i++) idp[(size_t)i] = i;
@@ -661,6 +683,7 @@ int ptam_tracker_destroy(ptam_tracker* t) {
     ptam_stream_wait(t->ctx->stream);
     if (t->block) hipFree(t->block);
     if (t->mbox) hipHostFree(t->mbox);
+    if (t->perm_host) hipHostFree(t->perm_host);
     delete t;
     return PTAM_OK;
 }
@@ -687,6 +710,8 @@ int ptam_tracker_set_map(ptam_tracker* t, int n, const ptam_pvs_point* pts, cons
     if (n != t->d.n) {   // the shuffles are permutations of 0..n-1: back to the identity until the caller sets them again
         std::vector<int> idp((size_t)std::max(n, 1));
         for (int i = 0; i < n; i++) idp[(size_t)i] = i;
+        t->d.perm_a = t->perm_dev_a;
+        t->d.perm_b = t->perm_dev_b;
         if (n > 0) {
             HIP_TRY(hipMemcpy(t->d.perm_a, idp.data(), (size_t)n * 4, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(t->d.perm_b, idp.data(), (size_t)n * 4, hipMemcpyHostToDevice));
@@ -711,6 +736,18 @@ int ptam_tracker_set_shuffle(ptam_tracker* t, const int32_t* shuffle_levels, con
         }
     }
     HIP_TRY(hipSetDevice(t->ctx->device));
+    if (n <= TM_SEL_LDS) {
+        // host-mapped: the kernel of the coming frame reads the entries straight from here.  The previous frame's set choice
+        // is certainly done once that frame's result has arrived; otherwise wait for the queue.
+        if (t->mbox->seq != t->seq) HIP_TRY(ptam_stream_wait(t->ctx->stream));
+        std::memcpy(t->perm_host, shuffle_levels, (size_t)n * 4);
+        std::memcpy(t->perm_host + t->d.cap, shuffle_fine, (size_t)n * 4);
+        t->d.perm_a = t->perm_host_dev;
+        t->d.perm_b = t->perm_host_dev + t->d.cap;
+        return PTAM_OK;
+    }
+    t->d.perm_a = t->perm_dev_a;
+    t->d.perm_b = t->perm_dev_b;
     void* pin;
     int rc = ctx_pinned(t->ctx, (size_t)n * 8 + 64, &pin);
     if (rc) return rc;

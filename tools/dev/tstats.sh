@@ -5,7 +5,7 @@ TAG=${1:-ts}
 OUT=$R/gpurun_out/ts_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o tm -- python $R/tools/dev/trackmap_only.py > $OUT/log.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o tm -- python $R/tools/dev/trackmap_only.py ${FRAMES:-300} ${MODE:-frame} > $OUT/log.txt 2>&1
 python3 - <<PY
 import csv
 for r in csv.DictReader(open("$OUT/tm_kernel_stats.csv")):
