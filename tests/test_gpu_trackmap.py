@@ -154,3 +154,47 @@ def test_track_frame_equals_keyframe_then_track_map(hip):
             assert np.array_equal(x, y)
     assert want[0][0]["n_meas"] != want[1][0]["n_meas"] or not np.array_equal(want[0][0]["pose"], want[1][0]["pose"])
     tr.close()
+
+
+def test_native_replicas_track_the_same_frame(hip):
+    """ptam_bench_track_frames: k contexts driven by k host threads inside the library (per frame set_shuffle +
+    ptam_track_map_frame) leave every tracker with the pose a single ptam_track_map_frame call gives — the permutations
+    travel through host-mapped memory on this path (maps of at most 2048 points), so a non-trivial shuffle is part of it."""
+    import ctypes as C
+    ctx0 = host.Context(lib=hip)
+    a, b = synth.make_frame_pair()
+    kfa0 = host.KeyFrame(ctx0).MakeKeyFrame_Lite(a)
+    case = synth.make_trackmap_case([kfa0.level(l) for l in range(4)], counts=(400, 200, 60, 30))
+    ws = []
+    for _ in range(3):
+        cx = host.Context(lib=hip)
+        ka = host.KeyFrame(cx).MakeKeyFrame_Lite(a)
+        tr = host.Tracker(cx, len(case["world"]))
+        tr.set_map(case["world"], case["pixel_right_w"], case["pixel_down_w"], ka, case["src_level"], case["center"])
+        ws.append((cx, ka, host.KeyFrame(cx), tr, host.DevBuf(cx, b)))
+    cx, ka, kb, tr, di = ws[0]
+    opts = tr.opts()
+    tr.set_shuffle(case["shuffle_levels"], case["shuffle_fine"])
+    want = tr.TrackFrame(kb, di, case["pose_in"], opts)
+    # the same frame with the identity shuffle picks other sets: the permutations do arrive
+    ident = np.arange(len(case["world"]), dtype=np.int32)
+    tr.set_shuffle(ident, ident)
+    other = tr.TrackFrame(kb, di, case["pose_in"], opts)
+    assert not np.array_equal(other["pose"], want["pose"]) or other["n_meas"] != want["n_meas"]
+    raw = lambda h: h.value if hasattr(h, "value") else int(h)
+    k = len(ws)
+    trs = (C.c_void_p * k)(*[raw(w[3].h) for w in ws])
+    kfs = (C.c_void_p * k)(*[raw(w[2].h) for w in ws])
+    dis = (C.c_void_p * k)(*[raw(w[4].p) for w in ws])
+    sl = np.ascontiguousarray(case["shuffle_levels"], dtype=np.int32)
+    sf = np.ascontiguousarray(case["shuffle_fine"], dtype=np.int32)
+    pose = np.ascontiguousarray(case["pose_in"], dtype=np.float64)
+    secs = C.c_double()
+    ctx0._check(hip.bench_track_frames(k, trs, kfs, dis, pose.ctypes.data_as(C.POINTER(C.c_double)), opts.ctypes.data_as(C.c_void_p),
+                                       sl.ctypes.data_as(C.c_void_p), sf.ctypes.data_as(C.c_void_p), 5, C.byref(secs)), "bench_track_frames")
+    assert secs.value > 0
+    for cx, ka, kb, tr, di in ws:
+        # the trackers' last frame == the single call (the resident state does not leak from frame to frame)
+        again = tr.TrackFrame(kb, di, case["pose_in"], opts)   # (shuffle as the native driver left it)
+        assert np.array_equal(again["pose"], want["pose"]) and again["n_meas"] == want["n_meas"]
+        tr.close()
