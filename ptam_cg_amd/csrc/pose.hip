@@ -412,25 +412,29 @@ __global__ void __launch_bounds__(GN_THREADS) pose_gn_kernel(DevCam cam, int n, 
 // keys of the order statistic in LDS, wave sums by DPP (no LDS round trips), same arithmetic and
 // the same fixed reduction order as the general kernel above.
 // ------------------------------------------------------------------------------------------------
-#define GS_THREADS 256
-#define GS_WAVES (GS_THREADS / 64)
-#define GS_MPT 4   // measurements per thread: n <= 1024
+#define GS_THREADS 256   // the workgroup of the 1024- and 256-measurement instantiations
+#define GS_MPT 4         // measurements per thread of the largest one: n <= 1024
 static_assert(GS_THREADS * GS_MPT == GS_LIMIT, "GS_LIMIT");
+#define GS_WAVE_LIMIT 64 // lists of at most 64 measurements (the coarse set: Tracker.CoarseMax = 60) run as ONE wave — see pose_gn_small_kernel
 #define GS_BINS 2048   // 11-bit digits of the order-statistic select
-#define GS_TR_PITCH (8 * 33 + 1)   // 8 slices of 32 threads, padded so that slices and rows fall into different banks
 
+// THREADS x MPT measurements; THREADS = 256, or 64 (MPT = 1): a single wave, whose barriers cost nothing
+template <int THREADS, int MPT>
 struct GnSmallShared {
+    static constexpr int WAVES = THREADS / 64;
+    static constexpr int SLICES = THREADS / 32;            // 32-thread slices of the workgroup
+    static constexpr int TR_PITCH = SLICES * 33 + 1;       // padded so that slices and rows fall into different banks
     double pose[12];
     double mu[6];
-    double red[GS_WAVES][27];
-    double keys[GS_THREADS * GS_MPT];
+    double red[WAVES][27];
+    double keys[THREADS * MPT];
     unsigned hist[GS_BINS];
     int sel_digit, sel_k, sel_cnt;
-    int wcount[GS_WAVES];
-    int scan[GS_WAVES];
+    int wcount[WAVES];
+    int scan[WAVES];
     unsigned long long cand[64];
     int n_cand;
-    double tr[27][GS_TR_PITCH];   // transposed per-thread partials of the 27 sums (row = sum, column = thread)
+    double tr[27][TR_PITCH];   // transposed per-thread partials of the 27 sums (row = sum, column = thread)
 };
 
 // wave sum by DPP: row shifts 1,2,4,8 then row broadcasts; the total lands in lane 63
@@ -459,8 +463,8 @@ __device__ __forceinline__ int small_key_bin(unsigned long long key) {
     return t < 0 ? 0 : (t > GS_BINS - 1 ? GS_BINS - 1 : t);
 }
 // rank the keys for which `mine` holds among themselves (cnt <= 64 of them): returns the k-th smallest
-template <int MPT>
-__device__ double small_select_finish(GnSmallShared& sh, const unsigned long long key[MPT], const bool mine[MPT], int cnt, int k) {
+template <int MPT, int THREADS>
+__device__ double small_select_finish(GnSmallShared<THREADS, MPT>& sh, const unsigned long long key[MPT], const bool mine[MPT], int cnt, int k) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 #pragma unroll
     for (int q = 0; q < MPT; q++)
@@ -480,9 +484,10 @@ __device__ double small_select_finish(GnSmallShared& sh, const unsigned long lon
 }
 // block-wide scan of sh.hist (GS_BINS / GS_THREADS bins per thread); the owner of rank k publishes bin / residual rank /
 // count and resets the candidate counter.  clear: zero the bins while reading them.
-__device__ void small_select_scan(GnSmallShared& sh, int k, bool clear) {
+template <int MPT, int THREADS>
+__device__ void small_select_scan(GnSmallShared<THREADS, MPT>& sh, int k, bool clear) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    constexpr int BPT = GS_BINS / GS_THREADS;
+    constexpr int BPT = GS_BINS / THREADS, GS_WAVES = THREADS / 64;
     unsigned c[BPT];
     int s = 0;
 #pragma unroll
@@ -515,8 +520,8 @@ __device__ void small_select_scan(GnSmallShared& sh, int k, bool clear) {
     __syncthreads();
 }
 // MPT == 1 and n <= 128 (the coarse set): no histogram — every key is ranked against the others by broadcast reads
-template <int MPT>
-__device__ double small_select_kth(GnSmallShared& sh, int n, int k) {
+template <int MPT, int THREADS>
+__device__ double small_select_kth(GnSmallShared<THREADS, MPT>& sh, int n, int k) {
     if (MPT == 1 && n <= 128) {
         // One key per thread slot (slots past n hold +inf).  With n <= 64 (<= 128) only the first wave (two) holds
         // keys, so the list is cut in four (two) parts and thread (part, i) ranks key i against its part; the partial
@@ -524,9 +529,10 @@ __device__ double small_select_kth(GnSmallShared& sh, int n, int k) {
         // the index tie-break costs as much as the comparison, ties are rare, and only a key that has an equal walks the
         // list again.
         const int tid = threadIdx.x;
-        const int parts = n <= 64 ? 4 : 2, per = GS_THREADS / parts;
+        // (one wave, THREADS == 64: every lane ranks its key against the whole list, nothing to meet)
+        const int parts = THREADS == 64 ? 1 : (n <= 64 ? 4 : 2), per = THREADS / parts;
         const int i = tid % per, part = tid / per;
-        const int len = ((n + parts - 1) / parts + 15) & ~15, j_begin = part * len, j_end = min(j_begin + len, GS_THREADS);
+        const int len = ((n + parts - 1) / parts + 15) & ~15, j_begin = part * len, j_end = min(j_begin + len, THREADS);
         const unsigned long long me = (unsigned long long)__double_as_longlong(sh.keys[i]);
         int rank = 0, n_eq = 0;
         for (int j0 = j_begin; j0 < j_end; j0 += 16) {
@@ -539,14 +545,14 @@ __device__ double small_select_kth(GnSmallShared& sh, int n, int k) {
                 n_eq += o[u] == me ? 1 : 0;
             }
         }
-        {   // (the histogram is unused on this path — n is fixed for the launch — and serves as the meeting place)
-            if (tid < per) sh.hist[tid] = 0, sh.hist[GS_THREADS + tid] = 0;
+        if (parts > 1) {   // (the histogram is unused on this path — n is fixed for the launch — and serves as the meeting place)
+            if (tid < per) sh.hist[tid] = 0, sh.hist[THREADS + tid] = 0;
             __syncthreads();
             atomicAdd(&sh.hist[i], (unsigned)rank);
-            atomicAdd(&sh.hist[GS_THREADS + i], (unsigned)n_eq);
+            atomicAdd(&sh.hist[THREADS + i], (unsigned)n_eq);
             __syncthreads();
             rank = (int)sh.hist[i];
-            n_eq = (int)sh.hist[GS_THREADS + i];
+            n_eq = (int)sh.hist[THREADS + i];
         }
         if (tid < n && n_eq > 1)
             for (int j = 0; j < tid; j++) rank += (unsigned long long)__double_as_longlong(sh.keys[j]) == me ? 1 : 0;
@@ -561,18 +567,18 @@ __device__ double small_select_kth(GnSmallShared& sh, int n, int k) {
     bool mine[MPT];
 #pragma unroll
     for (int q = 0; q < MPT; q++) {
-        const int i = tid + q * GS_THREADS;
+        const int i = tid + q * THREADS;
         key[q] = i < n ? (unsigned long long)__double_as_longlong(sh.keys[i]) : ~0ull;
         if (i < n) atomicAdd(&sh.hist[small_key_bin(key[q])], 1u);
     }
     __syncthreads();
-    small_select_scan(sh, k, true);
+    small_select_scan<MPT, THREADS>(sh, k, true);
     {
         const int bin = sh.sel_digit, cnt = sh.sel_cnt;
         if (bin != 0 && bin != GS_BINS - 1 && cnt <= 64) {
 #pragma unroll
-            for (int q = 0; q < MPT; q++) mine[q] = tid + q * GS_THREADS < n && small_key_bin(key[q]) == bin;
-            return small_select_finish<MPT>(sh, key, mine, cnt, sh.sel_k);
+            for (int q = 0; q < MPT; q++) mine[q] = tid + q * THREADS < n && small_key_bin(key[q]) == bin;
+            return small_select_finish<MPT, THREADS>(sh, key, mine, cnt, sh.sel_k);
         }
     }
     // general path
@@ -584,18 +590,18 @@ __device__ double small_select_kth(GnSmallShared& sh, int n, int k) {
         __syncthreads();   // (the previous round's reads of sel_* are done; hist is zero)
 #pragma unroll
         for (int q = 0; q < MPT; q++)
-            if (tid + q * GS_THREADS < n && (top == 64 || (key[q] >> top) == (prefix >> top)))
+            if (tid + q * THREADS < n && (top == 64 || (key[q] >> top) == (prefix >> top)))
                 atomicAdd(&sh.hist[(unsigned)(key[q] >> shift) & mask], 1u);
         __syncthreads();
-        small_select_scan(sh, k, true);
+        small_select_scan<MPT, THREADS>(sh, k, true);
         prefix |= (unsigned long long)sh.sel_digit << shift;
         k = sh.sel_k;
         top = shift;
         const int cnt = sh.sel_cnt;
         if (top > 0 && cnt <= 64) {
 #pragma unroll
-            for (int q = 0; q < MPT; q++) mine[q] = tid + q * GS_THREADS < n && (key[q] >> top) == (prefix >> top);
-            return small_select_finish<MPT>(sh, key, mine, cnt, k);
+            for (int q = 0; q < MPT; q++) mine[q] = tid + q * THREADS < n && (key[q] >> top) == (prefix >> top);
+            return small_select_finish<MPT, THREADS>(sh, key, mine, cnt, k);
         }
     }
     return __longlong_as_double((long long)prefix);
@@ -648,24 +654,26 @@ __device__ __forceinline__ void small_project(const DevCam& cam, const double* p
 // Fast path, n <= 1024: 256 threads x 4 measurements held in registers (one wave per SIMD, the four
 // independent measurements of a thread give the fp64 pipeline its ILP), e^2 keys of the order
 // statistic in LDS, wave sums by DPP, same arithmetic and reduction order as the general kernel.
-template <int MPT>
-__global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, int n, const ptam_pose_meas* __restrict__ meas,
+template <int MPT, int THREADS>
+__global__ void __launch_bounds__(THREADS) pose_gn_small_kernel(DevCam cam, int n, const ptam_pose_meas* __restrict__ meas,
                                                                    const ptam_projection* __restrict__ entry,
                                                                    double* __restrict__ pose_io, ptam_gn_opts opts,
                                                                    int* __restrict__ flags, double* __restrict__ updates,
                                                                    ulonglong2* __restrict__ host_slots, unsigned long long seq,
                                                                    const int* __restrict__ n_dev, PoseIn pin, PoseChainIo io, int size_guard) {
-    __shared__ GnSmallShared sh;
+    typedef GnSmallShared<THREADS, MPT> Sh;
+    constexpr int GS_WAVES = Sh::WAVES, GS_SLICES = Sh::SLICES;
+    __shared__ Sh sh;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (size_guard == 1 && *n_dev > GS_THREADS * MPT) return;   // (the general kernel, enqueued behind this one, takes the long list)
+    if (size_guard == 1 && *n_dev > THREADS * MPT) return;   // (the general kernel, enqueued behind this one, takes the long list)
     if (n_dev) n = min(n, max(*n_dev, 0));   // counted variant: the measurement list was compacted on the device
     if (tid < 12) sh.pose[tid] = pin.use ? pin.v[tid] : pose_io[tid];
     if (tid < 6) sh.mu[tid] = 0;
-    for (int b = tid; b < GS_BINS; b += GS_THREADS) sh.hist[b] = 0;   // small_select_kth keeps it zero between calls
+    for (int b = tid; b < GS_BINS; b += THREADS) sh.hist[b] = 0;   // small_select_kth keeps it zero between calls
     SmallMeas t[MPT];
 #pragma unroll
     for (int q = 0; q < MPT; q++) {
-        const int i = tid + q * GS_THREADS;
+        const int i = tid + q * THREADS;
         t[q].found = 0;
         t[q].cam3[0] = t[q].cam3[1] = 0;
         t[q].cam3[2] = 1;
@@ -686,7 +694,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < MPT; q++) {
-        const int i = tid + q * GS_THREADS;
+        const int i = tid + q * THREADS;
         if (i < n) {
             t[q].found = 1;
             if (entry) {
@@ -755,7 +763,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
             ey[q] = t[q].sn * (t[q].fnd[1] - t[q].img[1]);
             e2[q] = ex[q] * ex[q] + ey[q] * ey[q];
             cnt += t[q].found;
-            if (!(ov > 0)) sh.keys[tid + q * GS_THREADS] = t[q].found ? e2[q] : __longlong_as_double(0x7ff0000000000000ll);
+            if (!(ov > 0)) sh.keys[tid + q * THREADS] = t[q].found ? e2[q] : __longlong_as_double(0x7ff0000000000000ll);
         }
         cnt = wave_sum_i32(cnt);
         if (lane == 0) sh.wcount[wid] = cnt;
@@ -769,7 +777,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
             if (ov > 0)
                 sigma_sq = ov;
             else {
-                const double med = small_select_kth<MPT>(sh, n, nf / 2);
+                const double med = small_select_kth<MPT, THREADS>(sh, n, nf / 2);
                 sigma_sq = est_sigma_sq_from_median(opts.estimator, med, (unsigned long long)nf);
             }
             PH(1)
@@ -808,7 +816,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
 #pragma unroll
                     for (int a = 0; a < 6; a++) acc[21 + a] += er[r] * Jw[a];
                 }
-                if (iter == opts.mark_outliers_iter && flags && t[q].found && wgt == 0.0) flags[tid + q * GS_THREADS] = 1;
+                if (iter == opts.mark_outliers_iter && flags && t[q].found && wgt == 0.0) flags[tid + q * THREADS] = 1;
             }
             // 27 sums over 256 threads through LDS: every thread drops its partials column-wise, then 27 x 8 threads
             // each add a 32-thread slice and the 8 slices of a sum meet by shuffles — ~100 instructions per thread
@@ -820,8 +828,8 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
         PH(2)
         __syncthreads();
         PH(3)
-        if (nf > 0 && tid < 27 * 8) {
-            const int k = tid >> 3, part = tid & 7;
+        if (nf > 0 && tid < 27 * GS_SLICES) {
+            const int k = tid / GS_SLICES, part = tid % GS_SLICES;
             const double* src = &sh.tr[k][part * 33];
             double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
@@ -832,10 +840,12 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
                 a3 += src[j + 3];
             }
             double v = (a0 + a1) + (a2 + a3);
-            v += dpp_row_shr_f64<1>(v);   // the 8 slices of a sum sit in 8 consecutive lanes of a DPP row: lane 7 collects
-            v += dpp_row_shr_f64<2>(v);
-            v += dpp_row_shr_f64<4>(v);
-            if (part == 7) sh.red[0][k] = v;
+            v += dpp_row_shr_f64<1>(v);   // the slices of a sum (8, or 2 in the one-wave form) sit in consecutive lanes of a DPP row: the last collects
+            if (GS_SLICES > 2) {
+                v += dpp_row_shr_f64<2>(v);
+                v += dpp_row_shr_f64<4>(v);
+            }
+            if (part == GS_SLICES - 1) sh.red[0][k] = v;
         }
         __syncthreads();
         PH(4)
@@ -874,7 +884,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
     if (io.td_base) {
 #pragma unroll
         for (int q = 0; q < MPT; q++) {
-            const int i = tid + q * GS_THREADS;
+            const int i = tid + q * THREADS;
             if (i < n) {
                 ptam_projection* o = (ptam_projection*)((char*)io.td_base + (size_t)(io.td_index ? io.td_index[i] : i) * io.td_stride);
 #pragma unroll
@@ -890,7 +900,7 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
         double z1 = 0, z2 = 0;
 #pragma unroll
         for (int q = 0; q < MPT; q++) {
-            const double z = (tid + q * GS_THREADS < n) ? t[q].cam3[2] : 0.0;
+            const double z = (tid + q * THREADS < n) ? t[q].cam3[2] : 0.0;
             z1 += z;
             z2 += z * z;
         }
@@ -928,6 +938,21 @@ __global__ void __launch_bounds__(GS_THREADS) pose_gn_small_kernel(DevCam cam, i
     // the refined pose also goes straight into host-mapped memory as (word, sequence) pairs the host spins on: the call
     // returns one PCIe write after the last iteration instead of a D2H copy plus a stream synchronisation later
     if (host_slots && tid < 12) host_slots[tid] = make_ulonglong2((unsigned long long)__double_as_longlong(sh.pose[tid]), seq);
+}
+
+// instantiation and workgroup size for a list of at most n_cap (<= GS_LIMIT) measurements: ONE wave for the coarse set's
+// sizes (<= 64: every barrier of the kernel is then a no-op and the 27 sums meet after a single DPP step), one measurement
+// per thread up to 256, four up to 1024
+typedef void (*pose_small_fn)(DevCam, int, const ptam_pose_meas*, const ptam_projection*, double*, ptam_gn_opts, int*, double*, ulonglong2*,
+                              unsigned long long, const int*, PoseIn, PoseChainIo, int);
+static pose_small_fn pose_small_pick(int n_cap, int* threads) {
+    static const bool no_wave = getenv("PTAM_POSE_NO_WAVE") != nullptr;   // (A/B runs)
+    if (n_cap <= GS_WAVE_LIMIT && !no_wave) {
+        *threads = GS_WAVE_LIMIT;
+        return pose_gn_small_kernel<1, GS_WAVE_LIMIT>;
+    }
+    *threads = GS_THREADS;
+    return n_cap <= GS_THREADS ? pose_gn_small_kernel<1, GS_THREADS> : pose_gn_small_kernel<GS_MPT, GS_THREADS>;
 }
 
 __global__ void __launch_bounds__(GN_THREADS) calc_pose_update_kernel(int n, const ptam_pose_update_meas* __restrict__ meas,
@@ -1029,10 +1054,13 @@ static int pose_gn_host(ptam_ctx* ctx, int n, const ptam_pose_meas* meas, const 
     for (int i = 0; i < 12; i++) slots[2 * i + 1] = 0;   // (the staging buffer is shared: no stale sequence numbers)
     HIP_TRY(hipMemcpyAsync(d_m, hp, b_in, hipMemcpyHostToDevice, ctx->stream));
     const unsigned long long seq = ++ctx->pose_seq;
-    if (small)
-        hipLaunchKernelGGL(n <= GS_THREADS ? pose_gn_small_kernel<1> : pose_gn_small_kernel<4>, dim3(1), dim3(GS_THREADS), 0, ctx->stream,
+    if (small) {
+        int thr;
+        const pose_small_fn fn = pose_small_pick(n, &thr);
+        hipLaunchKernelGGL(fn, dim3(1), dim3(thr), 0, ctx->stream,
                            ctx->cam, n, d_m, d_e, d_pose, o, d_f, d_u, (ulonglong2*)((char*)ctx->d_pinned + o_slots), seq,
                            (const int*)nullptr, PoseIn{}, io, 0);
+    }
     else
         hipLaunchKernelGGL(pose_gn_kernel, dim3(1), dim3(GN_THREADS), 0, ctx->stream, ctx->cam, n, d_m, d_e, d_pose, o,
                            d_s, d_f, d_u, (const int*)nullptr, PoseIn{}, io, 0);
@@ -1126,10 +1154,13 @@ static int pose_gn_dev_impl(ptam_ctx* ctx, int n, const int32_t* d_n, const ptam
         for (int i = 0; i < 12; i++) slots[2 * i + 1] = 0;
         seq = ++ctx->pose_seq;
     }
-    if (small)
-        hipLaunchKernelGGL(n <= GS_THREADS ? pose_gn_small_kernel<1> : pose_gn_small_kernel<4>, dim3(1), dim3(GS_THREADS), 0, ctx->stream,
+    if (small) {
+        int thr;
+        const pose_small_fn fn = pose_small_pick(n, &thr);
+        hipLaunchKernelGGL(fn, dim3(1), dim3(thr), 0, ctx->stream,
                            ctx->cam, n, d_meas, d_entry, d_pose_inout, o, d_outlier_flags, d_u, d_slots, seq, (const int*)d_n, pin,
                            PoseChainIo{}, 0);
+    }
     else
         hipLaunchKernelGGL(pose_gn_kernel, dim3(1), dim3(GN_THREADS), 0, ctx->stream, ctx->cam, n, d_meas, d_entry, d_pose_inout, o,
                            d_s, d_outlier_flags, d_u, (const int*)d_n, pin, PoseChainIo{}, 0);
@@ -1178,7 +1209,9 @@ int pose_launch_chain(ptam_ctx* ctx, int n_cap, const int* d_n, const ptam_pose_
     double* d_u = (double*)((char*)s + bs);
     // (a list that cannot exceed 256 entries — the coarse set — runs with one measurement per thread: a quarter of the
     //  straight-line work per iteration and a ranking select without a histogram)
-    hipLaunchKernelGGL(n_cap <= GS_THREADS ? pose_gn_small_kernel<1> : pose_gn_small_kernel<4>, dim3(1), dim3(GS_THREADS), 0, ctx->stream,
+    int thr;
+    const pose_small_fn fn = pose_small_pick(std::min(n_cap, GS_LIMIT), &thr);
+    hipLaunchKernelGGL(fn, dim3(1), dim3(thr), 0, ctx->stream,
                        ctx->cam, std::min(n_cap, GS_LIMIT), d_meas, d_entry, d_pose_inout, *opts, d_outlier_flags, d_u, (ulonglong2*)nullptr,
                        0ull, d_n, PoseIn{}, io, may_be_long ? 1 : 0);
     if (may_be_long)
@@ -1314,8 +1347,9 @@ int ptam_calc_pose_update(ptam_ctx* ctx, int n, const ptam_pose_update_meas* mea
 // loading the code object / resolving the function — 10-28 ms in the middle of the first frame or the first adjustment
 void pose_preload_kernels() {
     ptam_preload((const void*)pose_gn_kernel);
-    ptam_preload((const void*)pose_gn_small_kernel<1>);
-    ptam_preload((const void*)pose_gn_small_kernel<4>);
+    ptam_preload((const void*)pose_gn_small_kernel<1, GS_THREADS>);
+    ptam_preload((const void*)pose_gn_small_kernel<1, GS_WAVE_LIMIT>);
+    ptam_preload((const void*)pose_gn_small_kernel<GS_MPT, GS_THREADS>);
     ptam_preload((const void*)calc_pose_update_kernel);
     ptam_preload((const void*)gather_pose_meas_kernel);
 }
