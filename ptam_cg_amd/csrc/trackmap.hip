@@ -410,6 +410,11 @@ __global__ void __launch_bounds__(TM_GATHER_THREADS) tm_gather_kernel(TmDev d, i
     const int st = valid ? d.slot_stat[sc] : 0;
     const int id = g_end > 0 ? d.list[sc] : 0;
     const double2 v2 = d.slot_v2[sc];
+    // (the point and its TrackerData state are requested as soon as the id is there, found or not: behind the `found` test
+    //  they would be one more round trip at the end of the kernel)
+    const int idc = g_end > 0 ? id : 0;
+    const double w0 = d.pts[idc].world[0], w1 = d.pts[idc].world[1], w2 = d.pts[idc].world[2];
+    const ptam_projection pj = d.pvs[idc].proj;
     // found slots in front of my workgroup's first (workgroup 0: also the totals and the per-level counts of this stage)
     const int upto = blockIdx.x == 0 ? g_end : s0;
     int before = 0, total = 0, lf[4] = {0, 0, 0, 0}, la[4] = {0, 0, 0, 0};
@@ -430,14 +435,13 @@ __global__ void __launch_bounds__(TM_GATHER_THREADS) tm_gather_kernel(TmDev d, i
     const int found = valid ? (st & 1) : 0;
     const int k = __builtin_amdgcn_readlane(before, 63) + wave_incl_scan_i32(found) - found;
     if (found) {
-        const ptam_pvs_point& p = d.pts[id];
         ptam_pose_meas m;
-        m.world[0] = p.world[0], m.world[1] = p.world[1], m.world[2] = p.world[2];
+        m.world[0] = w0, m.world[1] = w1, m.world[2] = w2;
         m.found[0] = v2.x;
         m.found[1] = v2.y;
         m.sqrt_inv_noise = 1.0 / (double)(1 << ((st >> 2) & 3));   // :889
         d.meas[k] = m;
-        d.entry[k] = d.pvs[id].proj;
+        d.entry[k] = pj;
         d.midx[k] = id;
         d.mslot[k] = s;
     }
