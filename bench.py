@@ -273,6 +273,11 @@ def workload_name(cams, points, window):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON record: whatever libraries print there on the way (gloo's connection notes,
+    # RCCL's version banner) goes to stderr — file descriptor 1 is pointed at stderr until the record is written
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -523,7 +528,9 @@ def main():
             rel = abs(otr["err_new"][-1] - trials["err_new"][-1]) / abs(otr["err_new"][-1])
             out["parity_rel_err_final_trial"] = float(rel)
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
     if world > 1:
         if comm is not None and not one_gpu:
             hip.rccl_destroy(comm)
