@@ -48,11 +48,12 @@ def parse():
     ap.add_argument("--no-global", action="store_true", help="skip the single-GPU run of the 200 x 50000 global adjustment")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tracking", action="store_true")
+    ap.add_argument("--no-replicas", action="store_true", help="tracking: one context only (no k-thread replica runs; used under rocprofv3)")
     ap.add_argument("--jac-reps", type=int, default=200)
     return ap.parse_args()
 
 
-def tracking_bench(hip, host, synth, frames=250):
+def tracking_bench(hip, host, synth, frames=250, replicas=True):
     """tracked frames/s: K1+K2 (keyframe) + K3 (1000 patches) + K4 (pose GN, 10 iterations)."""
     C = ctypes
     ctx = host.Context(lib=hip)
@@ -133,7 +134,7 @@ def tracking_bench(hip, host, synth, frames=250):
     # pyramid + FAST of the new frame, PVS over the map, set choice, warped templates, coarse search (range 30) + sub-pixel,
     # ten coarse pose iterations, re-projection, fine search (+ sub-pixel on the top level), gather, ten fine pose iterations.
     # The pose solves consume what the searches of the same frame found.
-    chain = trackmap_bench(hip, host, synth, ctx, kfa, b, d_im, frames)
+    chain = trackmap_bench(hip, host, synth, ctx, kfa, b, d_im, frames, replicas)
     for p in (d_im, d_q, d_t, d_r):
         hip.dev_free(ctx.h, p)
     for bfr in (d_w, d_gm, d_gi, d_gc, d_pm, d_pn, d_pp):
@@ -152,7 +153,7 @@ def tracking_bench(hip, host, synth, frames=250):
                     "1000-patch search + gather + one 10-iteration pose solve fed from a separate pose case"}
 
 
-def trackmap_bench(hip, host, synth, ctx, kfa, frame_b, d_im, frames):
+def trackmap_bench(hip, host, synth, ctx, kfa, frame_b, d_im, frames, replicas=True):
     import threading
     C = ctypes
     case = synth.make_trackmap_case([kfa.level(l) for l in range(4)])
@@ -191,10 +192,10 @@ def trackmap_bench(hip, host, synth, ctx, kfa, frame_b, d_im, frames):
     # driven by k host threads INSIDE the library (ptam_bench_track_frames: per frame set_shuffle + ptam_track_map_frame, the
     # calls the reference's tracker thread would make); aggregate frames/s.  `python_threads` keeps the earlier figure whose
     # host side was k Python threads (interpreter-bound).
-    conc, conc_py = {}, {}
+    conc, conc_py, batched = {}, {}, {}
     sl = np.ascontiguousarray(case["shuffle_levels"], dtype=np.int32)
     sf = np.ascontiguousarray(case["shuffle_fine"], dtype=np.int32)
-    for k in (1, 4, 8, 16, 32, 64):
+    for k in ((1, 4, 8, 16, 32, 64) if replicas else (1,)):
         workers = []
         for _ in range(k):
             cx = host.Context(lib=hip)
@@ -213,6 +214,14 @@ def trackmap_bench(hip, host, synth, ctx, kfa, frame_b, d_im, frames):
             ctx._check(hip.bench_track_frames(k, trs, kfs, dis, pose.ctypes.data_as(C.POINTER(C.c_double)), opts.ctypes.data_as(C.c_void_p),
                                               sl.ctypes.data_as(C.c_void_p), sf.ctypes.data_as(C.c_void_p), nf, C.byref(secs)), "bench_track_frames")
         conc[str(k)] = k * nf / secs.value
+        if k in (4, 16, 64):
+            # the same k trackers as ONE chain of launches per round of frames (ptam_track_map_frames_batch): not bound by the
+            # process' four hardware queues
+            rounds = max(20, 1600 // k)
+            for rep in range(2):
+                ctx._check(hip.bench_track_batch(k, trs, kfs, dis, pose.ctypes.data_as(C.POINTER(C.c_double)), opts.ctypes.data_as(C.c_void_p),
+                                                 sl.ctypes.data_as(C.c_void_p), sf.ctypes.data_as(C.c_void_p), rounds, C.byref(secs)), "bench_track_batch")
+            batched[str(k)] = {"fps": k * rounds / secs.value, "batch_us": 1e6 * secs.value / rounds}
         if k in (1, 8, 32):
             nfp = max(20, 400 // k)
 
@@ -235,6 +244,7 @@ def trackmap_bench(hip, host, synth, ctx, kfa, frame_b, d_im, frames):
             ka.close()
             cx.close()
     out["aggregate_fps_python_threads"] = conc_py
+    out["batched_fps_by_frames_per_batch"] = batched
     out["aggregate_fps_by_concurrent_contexts"] = conc
     return out
 
@@ -521,7 +531,7 @@ def main():
             bb.close()
             out["global_ba_single_gpu"] = gb
         if not args.no_tracking:
-            out["tracking"] = tracking_bench(hip, host, synth)
+            out["tracking"] = tracking_bench(hip, host, synth, replicas=not args.no_replicas)
         if not args.no_cpu_baseline:
             out["cpu_baseline"], otr = cpu_baseline(args, host, synth, prob)
             # parity of the timed workload itself (oracle as checker, cheap: it already ran)

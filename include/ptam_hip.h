@@ -386,6 +386,16 @@ int ptam_track_map(ptam_tracker* t, const ptam_kf* current, const double pose_in
  * d_frame (stride == width) into `current`, then TrackMap against it: one entry, one queue, one wait. */
 int ptam_track_map_frame(ptam_tracker* t, ptam_kf* current, const uint8_t* d_frame, const double pose_in[12],
                          const ptam_trackmap_opts* opts, ptam_trackmap_result* out);
+/* nb frames of nb independent trackers (own context, map, keyframe, prediction each) as ONE chain of launches on the first
+ * tracker's queue: every kernel of the chain gets a second grid dimension, row i works on frame i.  Not part of the
+ * reference's surface (it tracks one camera); it exists because a process gets four hardware queues and a tracked frame
+ * occupies one for its whole dependent chain, so separate calls keep at most four frames in flight whatever the device has
+ * idle.  Frame i's result is what ptam_track_map_frame(trackers[i], current[i], d_frames[i], poses_in + 12 i, opts) gives
+ * (bit for bit when the batch's list capacities select the same pose-kernel instantiation as the single call: maps of equal
+ * size do).  The trackers must sit on one device in DIFFERENT contexts with the same camera model, image size and halfSample
+ * variant; set the frames' permutations beforehand (ptam_tracker_set_shuffle). */
+int ptam_track_map_frames_batch(int nb, ptam_tracker* const* trackers, ptam_kf* const* current, const uint8_t* const* d_frames,
+                                const double* poses_in, const ptam_trackmap_opts* opts, ptam_trackmap_result* out);
 /* Measurement helper, not part of the reference's surface: n independent trackers (each with its own context, map and
  * keyframes) driven by n host threads inside the library, frames_each frames per thread — per frame ptam_tracker_set_shuffle
  * then ptam_track_map_frame, as the tracker thread of src/Tracker.cc:442-696 would issue them.  *seconds_out = wall time
@@ -393,6 +403,11 @@ int ptam_track_map_frame(ptam_tracker* t, ptam_kf* current, const uint8_t* d_fra
 int ptam_bench_track_frames(int n, ptam_tracker* const* trackers, ptam_kf* const* current, const uint8_t* const* d_frames,
                             const double pose_in[12], const ptam_trackmap_opts* opts, const int32_t* shuffle_levels,
                             const int32_t* shuffle_fine, int frames_each, double* seconds_out);
+/* Measurement helper: `rounds` rounds of ptam_tracker_set_shuffle (every tracker) + ptam_track_map_frames_batch, one host thread;
+ * *seconds_out = wall time (bench.py: frames/s of nb cameras tracked as batches). */
+int ptam_bench_track_batch(int nb, ptam_tracker* const* trackers, ptam_kf* const* current, const uint8_t* const* d_frames,
+                           const double pose_in[12], const ptam_trackmap_opts* opts, const int32_t* shuffle_levels,
+                           const int32_t* shuffle_fine, int rounds, double* seconds_out);
 /* vIterationSet of the last frame (what :667-676 turns into mCurrentKF.mMeasurements): *n = its length; out (nullable)
  * receives up to cap entries. */
 int ptam_tracker_read_iteration_set(ptam_tracker* t, ptam_trackmap_meas* out, int cap, int* n);

@@ -30,14 +30,14 @@ __device__ __forceinline__ bool has_run10(unsigned m16) {
     return (c & (a >> 8) & 0xffffu) != 0;
 }
 
-__global__ void __launch_bounds__(256) fast_detect_kernel(KfLevels L) {
+__device__ __forceinline__ void fast_detect_body(const KfLevels& L, int bx) {   // a 256-thread workgroup
     __shared__ uint8_t tile[(FAST_TH + 6) * FAST_LW];
     // which level does this block belong to?
     int lev = 0;
 #pragma unroll
     for (int l = 1; l < PTAM_LEVELS; l++)
-        if ((int)blockIdx.x >= L.block_begin[l]) lev = l;
-    const int b = blockIdx.x - L.block_begin[lev];
+        if (bx >= L.block_begin[l]) lev = l;
+    const int b = bx - L.block_begin[lev];
     const int w = L.w[lev], h = L.h[lev], ntx = L.ntx[lev];
     const int tx = b % ntx, ty = b / ntx;
     const int x0 = tx * FAST_TW, y0 = ty * FAST_TH;
@@ -73,6 +73,16 @@ __global__ void __launch_bounds__(256) fast_detect_kernel(KfLevels L) {
     }
     const unsigned long long m = __ballot(corner);
     if (lx == 0 && y < h) L.mask[lev][(size_t)y * ntx + tx] = m;
+}
+
+__global__ void __launch_bounds__(256) fast_detect_kernel(KfLevels L) { fast_detect_body(L, blockIdx.x); }
+// the keyframes of a batch of frames (ptam_track_map_frames_batch): blockIdx.y picks the keyframe, `stride` bytes apart
+__global__ void __launch_bounds__(256) fast_detect_batch_kernel(const char* __restrict__ items, size_t stride, size_t off_levels, int n_blocks) {
+    const KfLevels& L = *(const KfLevels*)(items + (size_t)blockIdx.y * stride + off_levels);
+    if ((int)blockIdx.x < n_blocks) fast_detect_body(L, blockIdx.x);
+}
+void kf_launch_detect_batch(int nb, int n_blocks, const void* d_items, size_t stride, size_t off_levels, hipStream_t stream) {
+    hipLaunchKernelGGL(fast_detect_batch_kernel, dim3(n_blocks, nb), dim3(256), 0, stream, (const char*)d_items, stride, off_levels, n_blocks);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -421,6 +431,7 @@ int ptam_kf_read_level(ptam_ctx* ctx, const ptam_kf* kf, int level, uint8_t* px,
 void kf_preload_kernels() {
     ptam_preload((const void*)fast_detect_kernel);
     ptam_preload((const void*)fast_compact_kernel);
+    ptam_preload((const void*)fast_detect_batch_kernel);
     ptam_preload((const void*)fast_score_kernel);
     ptam_preload((const void*)fast_nonmax_kernel);
     ptam_preload((const void*)shi_tomasi_kernel);

@@ -270,12 +270,13 @@ struct PoseIn {
     int use;
 };
 
-__global__ void __launch_bounds__(GN_THREADS) pose_gn_kernel(DevCam cam, int n, const ptam_pose_meas* __restrict__ meas,
-                                                             const ptam_projection* __restrict__ entry,
-                                                             double* __restrict__ pose_io, ptam_gn_opts opts,
-                                                             PoseState* __restrict__ st, int* __restrict__ flags,
-                                                             double* __restrict__ updates, const int* __restrict__ n_dev, PoseIn pin,
-                                                             PoseChainIo io, int size_guard) {
+// (body of pose_gn_kernel / pose_gn_batch_kernel: a 1024-thread workgroup)
+__device__ __forceinline__ void pose_gn_body(const DevCam& cam, int n, const ptam_pose_meas* __restrict__ meas,
+                                             const ptam_projection* __restrict__ entry,
+                                             double* __restrict__ pose_io, const ptam_gn_opts& opts,
+                                             PoseState* __restrict__ st, int* __restrict__ flags,
+                                             double* __restrict__ updates, const int* __restrict__ n_dev, const PoseIn& pin,
+                                             const PoseChainIo& io, int size_guard) {
     __shared__ GnShared sh;
     const int tid = threadIdx.x;
     if (size_guard == 2 && *n_dev <= GS_LIMIT) return;   // the resident chain enqueues both kernels: the list length picks one
@@ -405,6 +406,23 @@ __global__ void __launch_bounds__(GN_THREADS) pose_gn_kernel(DevCam cam, int n, 
         __syncthreads();
         if (threadIdx.x == 0) *(volatile unsigned long long*)io.result_seq = io.seq;
     }
+}
+
+__global__ void __launch_bounds__(GN_THREADS) pose_gn_kernel(DevCam cam, int n, const ptam_pose_meas* __restrict__ meas,
+                                                             const ptam_projection* __restrict__ entry,
+                                                             double* __restrict__ pose_io, ptam_gn_opts opts,
+                                                             PoseState* __restrict__ st, int* __restrict__ flags,
+                                                             double* __restrict__ updates, const int* __restrict__ n_dev, PoseIn pin,
+                                                             PoseChainIo io, int size_guard) {
+    pose_gn_body(cam, n, meas, entry, pose_io, opts, st, flags, updates, n_dev, pin, io, size_guard);
+}
+// one workgroup per frame of a batch (ptam_track_map_frames_batch): the same body on the frame's own lists
+__global__ void __launch_bounds__(GN_THREADS) pose_gn_batch_kernel(DevCam cam, const PoseBatchItem* __restrict__ items, ptam_gn_opts opts,
+                                                                   int size_guard) {
+    const PoseBatchItem it = items[blockIdx.x];
+    PoseIn pin;
+    pin.use = 0;
+    pose_gn_body(cam, it.n_cap, it.meas, it.entry, it.pose_io, opts, (PoseState*)it.st, it.flags, it.updates, it.n_dev, pin, it.io, size_guard);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -655,12 +673,12 @@ __device__ __forceinline__ void small_project(const DevCam& cam, const double* p
 // independent measurements of a thread give the fp64 pipeline its ILP), e^2 keys of the order
 // statistic in LDS, wave sums by DPP, same arithmetic and reduction order as the general kernel.
 template <int MPT, int THREADS>
-__global__ void __launch_bounds__(THREADS) pose_gn_small_kernel(DevCam cam, int n, const ptam_pose_meas* __restrict__ meas,
-                                                                   const ptam_projection* __restrict__ entry,
-                                                                   double* __restrict__ pose_io, ptam_gn_opts opts,
-                                                                   int* __restrict__ flags, double* __restrict__ updates,
-                                                                   ulonglong2* __restrict__ host_slots, unsigned long long seq,
-                                                                   const int* __restrict__ n_dev, PoseIn pin, PoseChainIo io, int size_guard) {
+__device__ __forceinline__ void pose_gn_small_body(const DevCam& cam, int n, const ptam_pose_meas* __restrict__ meas,
+                                                   const ptam_projection* __restrict__ entry,
+                                                   double* __restrict__ pose_io, const ptam_gn_opts& opts,
+                                                   int* __restrict__ flags, double* __restrict__ updates,
+                                                   ulonglong2* __restrict__ host_slots, unsigned long long seq,
+                                                   const int* __restrict__ n_dev, const PoseIn& pin, const PoseChainIo& io, int size_guard) {
     typedef GnSmallShared<THREADS, MPT> Sh;
     constexpr int GS_WAVES = Sh::WAVES, GS_SLICES = Sh::SLICES;
     __shared__ Sh sh;
@@ -938,6 +956,25 @@ __global__ void __launch_bounds__(THREADS) pose_gn_small_kernel(DevCam cam, int 
     // the refined pose also goes straight into host-mapped memory as (word, sequence) pairs the host spins on: the call
     // returns one PCIe write after the last iteration instead of a D2H copy plus a stream synchronisation later
     if (host_slots && tid < 12) host_slots[tid] = make_ulonglong2((unsigned long long)__double_as_longlong(sh.pose[tid]), seq);
+}
+
+template <int MPT, int THREADS>
+__global__ void __launch_bounds__(THREADS) pose_gn_small_kernel(DevCam cam, int n, const ptam_pose_meas* __restrict__ meas,
+                                                                   const ptam_projection* __restrict__ entry,
+                                                                   double* __restrict__ pose_io, ptam_gn_opts opts,
+                                                                   int* __restrict__ flags, double* __restrict__ updates,
+                                                                   ulonglong2* __restrict__ host_slots, unsigned long long seq,
+                                                                   const int* __restrict__ n_dev, PoseIn pin, PoseChainIo io, int size_guard) {
+    pose_gn_small_body<MPT, THREADS>(cam, n, meas, entry, pose_io, opts, flags, updates, host_slots, seq, n_dev, pin, io, size_guard);
+}
+template <int MPT, int THREADS>
+__global__ void __launch_bounds__(THREADS) pose_gn_small_batch_kernel(DevCam cam, const PoseBatchItem* __restrict__ items, ptam_gn_opts opts,
+                                                                         int size_guard) {
+    const PoseBatchItem it = items[blockIdx.x];
+    PoseIn pin;
+    pin.use = 0;
+    pose_gn_small_body<MPT, THREADS>(cam, min(it.n_cap, THREADS * MPT), it.meas, it.entry, it.pose_io, opts, it.flags, it.updates, nullptr, 0ull,
+                                     it.n_dev, pin, it.io, size_guard);
 }
 
 // instantiation and workgroup size for a list of at most n_cap (<= GS_LIMIT) measurements: ONE wave for the coarse set's
@@ -1345,11 +1382,43 @@ int ptam_calc_pose_update(ptam_ctx* ctx, int n, const ptam_pose_update_meas* mea
 
 // every kernel of this file resolved once, when a context is created: the first launch of a kernel otherwise pays for
 // loading the code object / resolving the function — 10-28 ms in the middle of the first frame or the first adjustment
+// the same for nb frames at once: one workgroup per frame (d_items: nb PoseBatchItem in device memory); n_cap_max = the largest
+// capacity among them picks the instantiation
+int pose_launch_chain_batch(ptam_ctx* ctx, int nb, int n_cap_max, const PoseBatchItem* d_items, const ptam_gn_opts* opts) {
+    ARG_TRY(ctx && nb >= 1 && n_cap_max >= 1 && d_items && opts);
+    const bool may_be_long = n_cap_max > GS_LIMIT;
+    const int cap = std::min(n_cap_max, GS_LIMIT);
+    if (cap <= GS_WAVE_LIMIT)
+        hipLaunchKernelGGL((pose_gn_small_batch_kernel<1, GS_WAVE_LIMIT>), dim3(nb), dim3(GS_WAVE_LIMIT), 0, ctx->stream, ctx->cam, d_items, *opts, may_be_long ? 1 : 0);
+    else if (cap <= GS_THREADS)
+        hipLaunchKernelGGL((pose_gn_small_batch_kernel<1, GS_THREADS>), dim3(nb), dim3(GS_THREADS), 0, ctx->stream, ctx->cam, d_items, *opts, may_be_long ? 1 : 0);
+    else
+        hipLaunchKernelGGL((pose_gn_small_batch_kernel<GS_MPT, GS_THREADS>), dim3(nb), dim3(GS_THREADS), 0, ctx->stream, ctx->cam, d_items, *opts, may_be_long ? 1 : 0);
+    if (may_be_long) hipLaunchKernelGGL(pose_gn_batch_kernel, dim3(nb), dim3(GN_THREADS), 0, ctx->stream, ctx->cam, d_items, *opts, 2);
+    HIP_TRY(hipGetLastError());
+    return PTAM_OK;
+}
+// scratch of one frame's pose loops inside the context's scratch buffer (what pose_launch_chain takes for itself)
+int pose_chain_scratch(ptam_ctx* ctx, int n_cap, void** st_out, double** updates_out) {
+    const bool may_be_long = n_cap > GS_LIMIT;
+    const size_t bs = may_be_long ? (size_t)n_cap * sizeof(PoseState) : 0, bu = (size_t)6 * 32 * 8;
+    void* s;
+    const int rc = ctx_scratch(ctx, bs + bu + 64, &s);
+    if (rc) return rc;
+    *st_out = s;
+    *updates_out = (double*)((char*)s + bs);
+    return PTAM_OK;
+}
+
 void pose_preload_kernels() {
     ptam_preload((const void*)pose_gn_kernel);
     ptam_preload((const void*)pose_gn_small_kernel<1, GS_THREADS>);
     ptam_preload((const void*)pose_gn_small_kernel<1, GS_WAVE_LIMIT>);
     ptam_preload((const void*)pose_gn_small_kernel<GS_MPT, GS_THREADS>);
+    ptam_preload((const void*)pose_gn_small_batch_kernel<1, GS_WAVE_LIMIT>);
+    ptam_preload((const void*)pose_gn_small_batch_kernel<1, GS_THREADS>);
+    ptam_preload((const void*)pose_gn_small_batch_kernel<GS_MPT, GS_THREADS>);
+    ptam_preload((const void*)pose_gn_batch_kernel);
     ptam_preload((const void*)calc_pose_update_kernel);
     ptam_preload((const void*)gather_pose_meas_kernel);
 }

@@ -29,6 +29,8 @@ int kf_make_lite_on(ptam_ctx* ctx, ptam_kf* kf, const uint8_t* d_im, hipStream_t
 struct PyrArgs;
 void kf_lite_begin(ptam_kf* kf, const uint8_t* d_src, PyrArgs* a_out, int* gx, int* gy);
 void kf_launch_detect(ptam_kf* kf, hipStream_t stream);
+// FAST detection for nb keyframes of equal geometry in one launch: their KfLevels sit at d_items + i * stride + off_levels
+void kf_launch_detect_batch(int nb, int n_blocks, const void* d_items, size_t stride, size_t off_levels, hipStream_t stream);
 // pvs.hip
 struct PoseArg {   // a pose handed over by value
     double v[12];
@@ -53,5 +55,19 @@ struct PoseChainIo {
     unsigned long long* result_seq;
     unsigned long long seq;
 };
+// one frame of a batch (ptam_track_map_frames_batch): what pose_launch_chain takes as arguments, in device memory
+struct PoseBatchItem {
+    int n_cap;                      // capacity of the list (its length sits at n_dev)
+    const int* n_dev;
+    const ptam_pose_meas* meas;
+    const ptam_projection* entry;
+    double* pose_io;
+    int32_t* flags;                 // outlier flags (nullable)
+    double* updates;                // scratch: the iterations' updates
+    void* st;                       // scratch of the general kernel (lists of more than 1024 measurements)
+    PoseChainIo io;
+};
+int pose_launch_chain_batch(ptam_ctx* ctx, int nb, int n_cap_max, const PoseBatchItem* d_items, const ptam_gn_opts* opts);
+int pose_chain_scratch(ptam_ctx* ctx, int n_cap, void** st_out, double** updates_out);
 int pose_launch_chain(ptam_ctx* ctx, int n_cap, const int* d_n, const ptam_pose_meas* d_meas, const ptam_projection* d_entry,
                       double* d_pose_inout, const ptam_gn_opts* opts, int32_t* d_outlier_flags, const PoseChainIo& io);

@@ -252,10 +252,11 @@ __global__ void __launch_bounds__(1024) tm_compact_select_kernel(KfLevels L, TmD
 // -> MakeSubPixTemplate + IterateSubPixToConvergence where the stage asks for it (:896-906: the coarse set with
 // CoarseSubPixIts, the top-level set with 8, the fine set not at all).  Every lane computes the same scalars (wave-uniform
 // control flow); lane 0 stores.  stage 0: the coarse set; stage 1: top-level and fine sets.
-__global__ void __launch_bounds__(256) tm_search_kernel(DevCam cam, KfLevels L, TmDev d, int stage, unsigned coarse_range, int coarse_its) {
+__device__ __forceinline__ void tm_search_body(const DevCam& cam, const KfLevels& L, const TmDev& d, int stage, unsigned coarse_range,
+                                               int coarse_its, int bx) {   // a 256-thread workgroup: four slots
     const TmCtl& c = *d.ctl;
     const int first = stage == 0 ? c.range_c[0] : c.range_hf[0], end = stage == 0 ? c.range_c[1] : c.range_hf[1];
-    const int s = first + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int s = first + bx * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (s >= end) return;
     const int id = d.list[s];
     ptam_pvs_result& pv = d.pvs[id];
@@ -338,6 +339,9 @@ __global__ void __launch_bounds__(256) tm_search_kernel(DevCam cam, KfLevels L, 
         d.slot_stat[s] = found | ((int)att << 1) | ((q.level & 3) << 2);
     }
 }
+__global__ void __launch_bounds__(256) tm_search_kernel(DevCam cam, KfLevels L, TmDev d, int stage, unsigned coarse_range, int coarse_its) {
+    tm_search_body(cam, L, d, stage, coarse_range, coarse_its, blockIdx.x);
+}
 
 // The tail of SearchForPoints (:883-909) and the measurement list of the pose loop that follows.  One workgroup.
 //   stage 0: status of the coarse slots, nFound, mbDidCoarse, the coarse loop's measurements;
@@ -395,14 +399,14 @@ __device__ __forceinline__ void tm_gather_finish(const TmDev& d, TmCtl& c, int s
 // counts the found slots in front of its own by itself (at most 1024 coalesced words) — no scan across workgroups, no
 // barrier; workgroup 0 also counts everything and books the stage's outcome.
 #define TM_GATHER_THREADS 64
-__global__ void __launch_bounds__(TM_GATHER_THREADS) tm_gather_kernel(TmDev d, int stage, int coarse_its, unsigned coarse_min, TmMailbox* mbox) {
+__device__ __forceinline__ void tm_gather_body(const TmDev& d, int stage, int coarse_its, unsigned coarse_min, TmMailbox* mbox, int bx) {   // one wave
     __shared__ int lsum[8][16];
     TmCtl& c = *d.ctl;
     const int lane = threadIdx.x;
     const int g_end = stage == 0 ? c.nC : c.n_slots;            // slots compacted by this stage
     const int st_first = stage == 0 ? 0 : c.nC;                 // slots whose status this stage decided
-    const int s0 = blockIdx.x * TM_GATHER_THREADS;
-    if (s0 >= g_end && blockIdx.x != 0) return;
+    const int s0 = bx * TM_GATHER_THREADS;
+    if (s0 >= g_end && bx != 0) return;
     // my slot: everything that does not depend on another load leaves at once
     const int s = s0 + lane;
     const bool valid = s < g_end;
@@ -416,13 +420,13 @@ __global__ void __launch_bounds__(TM_GATHER_THREADS) tm_gather_kernel(TmDev d, i
     const double w0 = d.pts[idc].world[0], w1 = d.pts[idc].world[1], w2 = d.pts[idc].world[2];
     const ptam_projection pj = d.pvs[idc].proj;
     // found slots in front of my workgroup's first (workgroup 0: also the totals and the per-level counts of this stage)
-    const int upto = blockIdx.x == 0 ? g_end : s0;
+    const int upto = bx == 0 ? g_end : s0;
     int before = 0, total = 0, lf[4] = {0, 0, 0, 0}, la[4] = {0, 0, 0, 0};
     for (int j = lane; j < upto; j += TM_GATHER_THREADS) {
         const int w = d.slot_stat[j];
         total += w & 1;
         if (j < s0) before += w & 1;
-        if (blockIdx.x == 0 && j >= st_first) {
+        if (bx == 0 && j >= st_first) {
             const int l = (w >> 2) & 3;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -445,7 +449,7 @@ __global__ void __launch_bounds__(TM_GATHER_THREADS) tm_gather_kernel(TmDev d, i
         d.midx[k] = id;
         d.mslot[k] = s;
     }
-    if (blockIdx.x != 0) return;
+    if (bx != 0) return;
     total = wave_sum_i32(total);
 #pragma unroll
     for (int l = 0; l < 4; l++) {
@@ -459,6 +463,9 @@ __global__ void __launch_bounds__(TM_GATHER_THREADS) tm_gather_kernel(TmDev d, i
     }
     __syncthreads();
     tm_gather_finish(d, c, stage, coarse_min, mbox, __builtin_amdgcn_readlane(total, 63), lsum);
+}
+__global__ void __launch_bounds__(TM_GATHER_THREADS) tm_gather_kernel(TmDev d, int stage, int coarse_its, unsigned coarse_min, TmMailbox* mbox) {
+    tm_gather_body(d, stage, coarse_its, coarse_min, mbox, blockIdx.x);
 }
 
 // ---- MapMaker::ReFind_Common (src/MapMaker.cc:943-1020), batched over the map points of one keyframe ----
@@ -561,6 +568,47 @@ __global__ void __launch_bounds__(256) refind_finish_kernel(int n, const ptam_pa
 }
 
 // =================================================================================================
+// ---- a batch of frames in ONE chain of launches (ptam_track_map_frames_batch) ----
+// A process gets four hardware queues, and a tracked frame occupies its queue for the whole dependent chain (two
+// single-workgroup pose loops are 94 of its ~157 us): whatever the chip has idle, at most four frames of independent
+// trackers are in flight (20 k frames/s).  A batch runs the SAME chain once for nb trackers: every
+// launch gets a second grid dimension, workgroup row y works on frame y with that frame's arguments taken from a device
+// array — the kernels' bodies are the single-frame ones.
+struct TmBatchItem {
+    PyrArgs pa;
+    int n_pyr, n;          // pyramid workgroups (gx * gy), map points
+    KfLevels L;
+    TmDev d;
+    PoseArg pv;
+    TmMailbox* mbox;
+};
+template <int VARIANT>
+__global__ void __launch_bounds__(256) tm_pyr_pvs_batch_kernel(const TmBatchItem* __restrict__ items, int gx, DevCam cam) {
+    const TmBatchItem& it = items[blockIdx.y];
+    const int b = blockIdx.x;
+    if (b < it.n_pyr)
+        pyramid_body<VARIANT>(it.pa, (b % gx) * 64 + (threadIdx.x & 63), (b / gx) * 4 + (threadIdx.x >> 6));
+    else if ((b - it.n_pyr) * 256 < max(it.n, 1))
+        track_pvs_body(cam, it.n, it.d.pts, it.d.pose, it.d.pvs, nullptr, it.pv, it.d.pose, b - it.n_pyr);
+}
+__global__ void __launch_bounds__(1024) tm_compact_select_batch_kernel(const TmBatchItem* __restrict__ items, ptam_trackmap_opts o) {
+    const TmBatchItem& it = items[blockIdx.y];
+    if (blockIdx.x == 0)
+        tm_select_body(it.d, o);
+    else
+        fast_compact_body(it.L, blockIdx.x - 1, 0);
+}
+__global__ void __launch_bounds__(256) tm_search_batch_kernel(DevCam cam, const TmBatchItem* __restrict__ items, int stage, unsigned coarse_range,
+                                                              int coarse_its) {
+    const TmBatchItem& it = items[blockIdx.y];
+    tm_search_body(cam, it.L, it.d, stage, coarse_range, coarse_its, blockIdx.x);
+}
+__global__ void __launch_bounds__(TM_GATHER_THREADS) tm_gather_batch_kernel(const TmBatchItem* __restrict__ items, int stage, int coarse_its,
+                                                                            unsigned coarse_min) {
+    const TmBatchItem& it = items[blockIdx.y];
+    tm_gather_body(it.d, stage, coarse_its, coarse_min, it.mbox, blockIdx.x);
+}
+
 struct ptam_tracker {
     ptam_ctx* ctx;
     TmDev d;
@@ -574,6 +622,9 @@ struct ptam_tracker {
     int* perm_host;        // [2][cap], host address
     int* perm_host_dev;    // device address of the same memory
     int *perm_dev_a, *perm_dev_b;
+    // argument arrays of the batches this tracker leads (ptam_track_map_frames_batch): grown on demand
+    void* batch_dev;
+    size_t batch_cap;
 };
 
 extern "C" {
@@ -688,6 +739,7 @@ int ptam_tracker_destroy(ptam_tracker* t) {
     if (t->block) hipFree(t->block);
     if (t->mbox) hipHostFree(t->mbox);
     if (t->perm_host) hipHostFree(t->perm_host);
+    if (t->batch_dev) hipFree(t->batch_dev);
     delete t;
     return PTAM_OK;
 }
@@ -872,6 +924,164 @@ int ptam_track_map_frame(ptam_tracker* t, ptam_kf* cur, const uint8_t* d_frame, 
     return track_map_impl(t, cur, d_frame, pose_in, opts, out);
 }
 
+// nb frames of nb independent trackers — each with its own map, keyframe and motion-model prediction — as ONE chain of
+// launches on the first tracker's queue (see TmBatchItem).  Per frame the result is what ptam_track_map_frame gives (the same
+// kernel bodies on the same data).  All trackers must live on one device and share camera model, image geometry and
+// halfSample variant; opts apply to every frame.
+int ptam_track_map_frames_batch(int nb, ptam_tracker* const* ts, ptam_kf* const* curs, const uint8_t* const* d_frames, const double* poses_in,
+                                const ptam_trackmap_opts* opts, ptam_trackmap_result* outs) {
+    ARG_TRY(nb >= 1 && nb <= 4096 && ts && curs && d_frames && poses_in && outs);
+    for (int i = 0; i < nb; i++) ARG_TRY(ts[i] && curs[i] && d_frames[i]);
+    ptam_tracker* lead = ts[0];
+    ptam_ctx* ctx = lead->ctx;
+    ptam_trackmap_opts o;
+    if (opts)
+        o = *opts;
+    else
+        ptam_trackmap_opts_default(&o);
+    ARG_TRY(o.max_patches >= 0 && o.coarse_subpix_its >= 0 && o.coarse_subpix_its <= 64);
+    const KfLevels& L0 = curs[0]->L;
+    for (int i = 0; i < nb; i++) {
+        ARG_TRY(ts[i]->ctx->device == ctx->device && curs[i]->device == ctx->device);
+        ARG_TRY(ts[i]->ctx->halfsample == ctx->halfsample && std::memcmp(&ts[i]->ctx->cam, &ctx->cam, sizeof(DevCam)) == 0);
+        ARG_TRY(curs[i]->n_blocks == curs[0]->n_blocks);
+        for (int l = 0; l < PTAM_LEVELS; l++) ARG_TRY(curs[i]->L.w[l] == L0.w[l] && curs[i]->L.h[l] == L0.h[l]);
+        for (int j = 0; j < i; j++) ARG_TRY(ts[j] != ts[i] && curs[j] != curs[i] && ts[j]->ctx != ts[i]->ctx);   // (a context's scratch serves ONE frame)
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    // the other trackers' own queues: whatever they still hold (a map upload, the tail of their last frame) must be done
+    for (int i = 1; i < nb; i++)
+        if (ts[i]->ctx != ctx) HIP_TRY(ptam_stream_wait(ts[i]->ctx->stream));
+    // ---- the argument arrays: [nb TmBatchItem | nb PoseBatchItem (coarse) | nb PoseBatchItem (fine)] ----
+    const size_t b_items = (size_t)nb * sizeof(TmBatchItem), b_pose = (size_t)nb * sizeof(PoseBatchItem), b_all = b_items + 2 * b_pose;
+    void* pin;
+    int rc = ctx_pinned(ctx, b_all + 64, &pin);
+    if (rc) return rc;
+    if (lead->batch_cap < b_all) {
+        HIP_TRY(ptam_stream_wait(st));
+        if (lead->batch_dev) HIP_TRY(hipFree(lead->batch_dev));
+        lead->batch_dev = nullptr;
+        lead->batch_cap = 0;
+        HIP_TRY(hipMalloc(&lead->batch_dev, b_all * 2));
+        lead->batch_cap = b_all * 2;
+    }
+    TmBatchItem* h_it = (TmBatchItem*)pin;
+    PoseBatchItem* h_pc = (PoseBatchItem*)((char*)pin + b_items);
+    PoseBatchItem* h_pf = h_pc + nb;
+    const TmBatchItem* d_it = (const TmBatchItem*)lead->batch_dev;
+    const PoseBatchItem* d_pc = (const PoseBatchItem*)((const char*)lead->batch_dev + b_items);
+    const PoseBatchItem* d_pf = d_pc + nb;
+    int gx = 0, gy = 0, n_max = 0, ncc_max = 1;
+    std::vector<unsigned long long> seqs((size_t)nb);
+    for (int i = 0; i < nb; i++) {
+        ptam_tracker* t = ts[i];
+        TmBatchItem& it = h_it[i];
+        std::memset(&it, 0, sizeof it);
+        kf_lite_begin(curs[i], d_frames[i], &it.pa, &gx, &gy);
+        it.n_pyr = gx * gy;
+        it.n = t->d.n;
+        it.L = curs[i]->L;
+        it.d = t->d;
+        std::memcpy(it.pv.v, poses_in + 12 * (size_t)i, 96);
+        it.pv.use = 1;
+        it.mbox = t->mbox_dev;
+        const int n = t->d.n, ncc = std::max(1, std::min(n, (int)o.coarse_max));
+        n_max = std::max(n_max, n);
+        ncc_max = std::max(ncc_max, ncc);
+        void* sst;
+        double* su;
+        rc = pose_chain_scratch(t->ctx, std::max(n, 1), &sst, &su);   // (sized for the fine loop; the coarse one uses its start)
+        if (rc) return rc;
+        PoseBatchItem& pc = h_pc[i];
+        std::memset(&pc, 0, sizeof pc);
+        pc.n_cap = ncc;
+        pc.n_dev = &t->d.ctl->n_meas_coarse;
+        pc.meas = t->d.meas;
+        pc.entry = t->d.entry;
+        pc.pose_io = t->d.pose;
+        pc.flags = nullptr;
+        pc.updates = su;
+        pc.st = sst;
+        pc.io.td_base = &t->d.pvs[0].proj;
+        pc.io.td_index = t->d.midx;
+        pc.io.td_stride = (int)sizeof(ptam_pvs_result);
+        PoseBatchItem& pf = h_pf[i];
+        std::memset(&pf, 0, sizeof pf);
+        pf.n_cap = std::max(n, 1);
+        pf.n_dev = &t->d.ctl->n_meas;
+        pf.meas = t->d.meas;
+        pf.entry = t->d.entry;
+        pf.pose_io = t->d.pose;
+        pf.flags = t->d.outlier;
+        pf.updates = su;
+        pf.st = sst;
+        seqs[(size_t)i] = ++t->seq;
+        pf.io.depth_out = t->d.ctl->depth;
+        pf.io.result_pose = t->mbox_dev->res.pose;
+        pf.io.result_depth = t->mbox_dev->depth3;
+        pf.io.result_seq = &t->mbox_dev->seq;
+        pf.io.seq = seqs[(size_t)i];
+    }
+    HIP_TRY(hipMemcpyAsync(lead->batch_dev, pin, b_all, hipMemcpyHostToDevice, st));
+    const int n_pyr = gx * gy, n_pvs = std::max(1, (n_max + 255) / 256);
+    if (ctx->halfsample == PTAM_HALFSAMPLE_T)
+        hipLaunchKernelGGL(tm_pyr_pvs_batch_kernel<PTAM_HALFSAMPLE_T>, dim3(n_pyr + n_pvs, nb), dim3(256), 0, st, d_it, gx, ctx->cam);
+    else
+        hipLaunchKernelGGL(tm_pyr_pvs_batch_kernel<PTAM_HALFSAMPLE_R>, dim3(n_pyr + n_pvs, nb), dim3(256), 0, st, d_it, gx, ctx->cam);
+    kf_launch_detect_batch(nb, curs[0]->n_blocks, d_it, sizeof(TmBatchItem), offsetof(TmBatchItem, L), st);
+    hipLaunchKernelGGL(tm_compact_select_batch_kernel, dim3(1 + fast_compact_blocks(L0), nb), dim3(1024), 0, st, d_it, o);
+    // ---- coarse stage :519-569 ----
+    hipLaunchKernelGGL(tm_search_batch_kernel, dim3((ncc_max + 3) / 4, nb), dim3(256), 0, st, ctx->cam, d_it, 0, o.coarse_range, o.coarse_subpix_its);
+    hipLaunchKernelGGL(tm_gather_batch_kernel, dim3(std::max(1, (ncc_max + TM_GATHER_THREADS - 1) / TM_GATHER_THREADS), nb), dim3(TM_GATHER_THREADS), 0, st,
+                       d_it, 0, (int)o.coarse_subpix_its, o.coarse_min);
+    {
+        ptam_gn_opts g;
+        ptam_gn_opts_default(&g);
+        g.nonlinear_mask = 0x3ff;       // every coarse iteration re-projects (:556-562)
+        g.override_sigma_sq = 1.0;      // :565
+        g.mark_outliers_iter = -1;
+        g.estimator = o.estimator;
+        rc = pose_launch_chain_batch(ctx, nb, ncc_max, d_pc, &g);
+        if (rc) return rc;
+    }
+    // ---- fine stage :571-643 ----
+    hipLaunchKernelGGL(tm_search_batch_kernel, dim3(std::max(1, (n_max + 3) / 4), nb), dim3(256), 0, st, ctx->cam, d_it, 1, 0u, 0);
+    hipLaunchKernelGGL(tm_gather_batch_kernel, dim3(std::max(1, (n_max + TM_GATHER_THREADS - 1) / TM_GATHER_THREADS), nb), dim3(TM_GATHER_THREADS), 0, st,
+                       d_it, 1, (int)o.coarse_subpix_its, o.coarse_min);
+    {
+        ptam_gn_opts g;
+        ptam_gn_opts_default(&g);       // fine schedule :613-643
+        g.estimator = o.estimator;
+        rc = pose_launch_chain_batch(ctx, nb, std::max(n_max, 1), d_pf, &g);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipGetLastError());
+    for (int i = 0; i < nb; i++) {
+        ptam_tracker* t = ts[i];
+        const unsigned long long seq = seqs[(size_t)i];
+        unsigned spins = 0;
+        while (*(volatile unsigned long long*)&t->mbox->seq != seq) {
+            if (++spins == 100000) {
+                spins = 0;
+                const hipError_t q = hipStreamQuery(st);
+                if (q != hipSuccess && q != hipErrorNotReady) {
+                    ptam_set_error("track_map_frames_batch: stream failed: %s", hipGetErrorString(q));
+                    return PTAM_E_HIP;
+                }
+                if (q == hipSuccess && *(volatile unsigned long long*)&t->mbox->seq != seq) return PTAM_E_HIP;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        ptam_trackmap_result* out = outs + i;
+        std::memcpy(out, (const void*)&t->mbox->res, sizeof *out);
+        out->depth_sum = t->mbox->depth3[0];
+        out->depth_sum_sq = t->mbox->depth3[1];
+        out->depth_n = (int)t->mbox->depth3[2];
+    }
+    return PTAM_OK;
+}
+
 int ptam_tracker_read_iteration_set(ptam_tracker* t, ptam_trackmap_meas* out, int cap, int* n_out) {
     ARG_TRY(t && n_out);
     ptam_ctx* ctx = t->ctx;
@@ -1018,6 +1228,28 @@ int ptam_bench_track_frames(int n, ptam_tracker* const* trackers, ptam_kf* const
     return PTAM_OK;
 }
 
+// Measurement helper: `rounds` batches of nb frames (ptam_track_map_frames_batch), one host thread; per round every tracker
+// is handed its permutations first, as a caller tracking nb cameras would.  *seconds_out = wall time of the rounds.
+int ptam_bench_track_batch(int nb, ptam_tracker* const* trackers, ptam_kf* const* current, const uint8_t* const* d_frames,
+                           const double pose_in[12], const ptam_trackmap_opts* opts, const int32_t* shuffle_levels,
+                           const int32_t* shuffle_fine, int rounds, double* seconds_out) {
+    ARG_TRY(nb >= 1 && nb <= 4096 && trackers && current && d_frames && pose_in && shuffle_levels && shuffle_fine && rounds >= 1 && seconds_out);
+    std::vector<double> poses((size_t)nb * 12);
+    for (int i = 0; i < nb; i++) std::memcpy(&poses[(size_t)i * 12], pose_in, 96);
+    std::vector<ptam_trackmap_result> res((size_t)nb);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < rounds; r++) {
+        for (int i = 0; i < nb; i++) {
+            const int rc = ptam_tracker_set_shuffle(trackers[i], shuffle_levels, shuffle_fine);
+            if (rc) return rc;
+        }
+        const int rc = ptam_track_map_frames_batch(nb, trackers, current, d_frames, poses.data(), opts, res.data());
+        if (rc) return rc;
+    }
+    *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return PTAM_OK;
+}
+
 }   // extern "C"
 
 void trackmap_preload_kernels() {
@@ -1030,4 +1262,9 @@ void trackmap_preload_kernels() {
     ptam_preload((const void*)tm_compact_select_kernel);
     ptam_preload((const void*)tm_search_kernel);
     ptam_preload((const void*)tm_gather_kernel);
+    ptam_preload((const void*)tm_pyr_pvs_batch_kernel<PTAM_HALFSAMPLE_R>);
+    ptam_preload((const void*)tm_pyr_pvs_batch_kernel<PTAM_HALFSAMPLE_T>);
+    ptam_preload((const void*)tm_compact_select_batch_kernel);
+    ptam_preload((const void*)tm_search_batch_kernel);
+    ptam_preload((const void*)tm_gather_batch_kernel);
 }

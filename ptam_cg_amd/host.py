@@ -407,6 +407,21 @@ class Tracker:
                         "track_map_frame")
         return res[0]
 
+    @staticmethod
+    def TrackFramesBatch(trackers, kfs, d_frames, poses, opts=None):
+        """ptam_track_map_frames_batch: one chain of launches for len(trackers) frames -> array of TRACKMAP_RESULT_DT"""
+        k = len(trackers)
+        raw = lambda h: h.value if hasattr(h, "value") else int(h)
+        trs = (C.c_void_p * k)(*[raw(t.h) for t in trackers])
+        kf_ = (C.c_void_p * k)(*[raw(f.h) for f in kfs])
+        dis = (C.c_void_p * k)(*[raw(d.p if isinstance(d, DevBuf) else d) for d in d_frames])
+        poses = np.ascontiguousarray(np.asarray(poses, dtype=np.float64).reshape(k, 12))
+        res = np.zeros(k, dtype=TRACKMAP_RESULT_DT)
+        t0 = trackers[0]
+        t0.ctx._check(t0.lib.track_map_frames_batch(k, trs, kf_, dis, _pd(poses), _ptr(opts) if opts is not None else None, _ptr(res)),
+                      "track_map_frames_batch")
+        return res
+
     def iteration_set(self):
         n = C.c_int()
         self.ctx._check(self.lib.tracker_read_iteration_set(self.h, None, 0, C.byref(n)), "tracker_read_iteration_set")

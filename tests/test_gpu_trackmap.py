@@ -198,3 +198,48 @@ def test_native_replicas_track_the_same_frame(hip):
         again = tr.TrackFrame(kb, di, case["pose_in"], opts)   # (shuffle as the native driver left it)
         assert np.array_equal(again["pose"], want["pose"]) and again["n_meas"] == want["n_meas"]
         tr.close()
+
+
+def test_batch_of_frames_equals_single_calls(hip):
+    """ptam_track_map_frames_batch: nb trackers with DIFFERENT maps, frames and predictions in one chain of launches give, frame
+    by frame, exactly what ptam_track_map_frame gives (same kernel bodies; maps of equal size pick the same pose-kernel
+    instantiations) — pose, counts, depth sums and the iteration sets."""
+    import ctypes as C
+    a, b = synth.make_frame_pair()
+    ctx0 = host.Context(lib=hip)
+    kfa0 = host.KeyFrame(ctx0).MakeKeyFrame_Lite(a)
+    ws = []
+    for i in range(4):
+        case = synth.make_trackmap_case([kfa0.level(l) for l in range(4)], counts=(400, 200, 60, 30), seed=100 + i)
+        cx = host.Context(lib=hip)
+        ka = host.KeyFrame(cx).MakeKeyFrame_Lite(a)
+        tr = host.Tracker(cx, len(case["world"]))
+        tr.set_map(case["world"], case["pixel_right_w"], case["pixel_down_w"], ka, case["src_level"], case["center"])
+        frame = b if i % 2 == 0 else np.ascontiguousarray(b[::-1, ::-1])   # two of the frames show another image
+        ws.append((cx, ka, host.KeyFrame(cx), tr, host.DevBuf(cx, frame), case))
+    opts = ws[0][3].opts()
+    single, sets = [], []
+    for cx, ka, kb, tr, di, case in ws:
+        tr.set_shuffle(case["shuffle_levels"], case["shuffle_fine"])
+        single.append(tr.TrackFrame(kb, di, case["pose_in"], opts).copy())
+        sets.append(tr.iteration_set())
+    raw = lambda h: h.value if hasattr(h, "value") else int(h)
+    k = len(ws)
+    trs = (C.c_void_p * k)(*[raw(w[3].h) for w in ws])
+    kfs = (C.c_void_p * k)(*[raw(w[2].h) for w in ws])
+    dis = (C.c_void_p * k)(*[raw(w[4].p) for w in ws])
+    poses = np.ascontiguousarray(np.stack([np.asarray(w[5]["pose_in"], dtype=np.float64).reshape(12) for w in ws]))
+    res = np.zeros(k, dtype=host.TRACKMAP_RESULT_DT)
+    for rep in range(2):   # (twice: the resident state of a batch must not leak into the next one)
+        for cx, ka, kb, tr, di, case in ws:
+            tr.set_shuffle(case["shuffle_levels"], case["shuffle_fine"])
+        ctx0._check(hip.track_map_frames_batch(k, trs, kfs, dis, poses.ctypes.data_as(C.POINTER(C.c_double)), opts.ctypes.data_as(C.c_void_p),
+                                               res.ctypes.data_as(C.c_void_p)), "track_map_frames_batch")
+        for i, (cx, ka, kb, tr, di, case) in enumerate(ws):
+            for f in res.dtype.names:
+                assert np.array_equal(res[i][f], single[i][f]), (rep, i, f, res[i][f], single[i][f])
+            it = tr.iteration_set()
+            assert it.tobytes() == sets[i].tobytes(), (rep, i)
+    assert single[0]["n_meas"] > 100 and not np.array_equal(single[0]["pose"], single[1]["pose"])
+    for cx, ka, kb, tr, di, case in ws:
+        tr.close()

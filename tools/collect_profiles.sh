@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd $R && python bench.py > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 for attempt in 1 2; do   # (rocprofv3 segfaulted once in a tool thread while tracing this command; the second attempt passed)
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o ba -- python $R/bench.py --no-cpu-baseline > $OUT/trace.log 2>&1 && break
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o ba -- python $R/bench.py --no-cpu-baseline --no-replicas > $OUT/trace.log 2>&1 && break
 done
 cp $OUT/trace/ba_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 bash $R/tools/profile_k7.sh ${TAG}_headline 50 5000 20 > $OUT/pmc_headline.txt 2>&1
