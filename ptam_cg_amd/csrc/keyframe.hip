@@ -75,13 +75,76 @@ __device__ __forceinline__ void fast_detect_body(const KfLevels& L, int bx) {   
     if (lx == 0 && y < h) L.mask[lev][(size_t)y * ntx + tx] = m;
 }
 
+// The same test on a TALL tile, for launches that have workgroups to spare (a batch of frames): 64 x TH pixels per workgroup,
+// wave w takes rows w, w + 4, ...; the halo costs (TH + 6) / TH instead of 10 / 4, and the tile is staged as aligned 32-bit
+// words from column x0 - 4 (18 words per row) where the image width allows it.  Workgroups are numbered level by level,
+// ntx * ceil(h / TH) each.
+template <int TH>
+__device__ __forceinline__ void fast_detect_tall_body(const KfLevels& L, int bx) {   // a 256-thread workgroup
+    __shared__ __attribute__((aligned(4))) uint8_t tile[(TH + 6) * FAST_LW];
+    static_assert(FAST_LW == FAST_TW + 8 && TH % 4 == 0, "tile pitch = 18 words");
+    int lev = 0, b = bx;
+    for (; lev < PTAM_LEVELS - 1; lev++) {
+        const int nb = L.ntx[lev] * ((L.h[lev] + TH - 1) / TH);
+        if (b < nb) break;
+        b -= nb;
+    }
+    const int w = L.w[lev], h = L.h[lev], ntx = L.ntx[lev];
+    if (b >= ntx * ((h + TH - 1) / TH)) return;
+    const int tx = b % ntx, ty = b / ntx;
+    const int x0 = tx * FAST_TW, y0 = ty * TH;
+    const uint8_t* __restrict__ im = L.im[lev];
+    const bool words = (w & 3) == 0 && (((size_t)im) & 3) == 0;
+    for (int i = threadIdx.x; i < (TH + 6) * (FAST_LW / 4); i += 256) {
+        const int r = i / (FAST_LW / 4), cw = i - r * (FAST_LW / 4);
+        const int x = x0 - 4 + 4 * cw, y = y0 - 3 + r;
+        uint32_t v = 0;
+        if (y >= 0 && y < h) {
+            if (words && x >= 0 && x + 3 < w)
+                v = *reinterpret_cast<const uint32_t*>(im + (size_t)y * w + x);
+            else
+                for (int k = 0; k < 4; k++)
+                    if (x + k >= 0 && x + k < w) v |= (uint32_t)im[(size_t)y * w + x + k] << (8 * k);
+        }
+        *reinterpret_cast<uint32_t*>(&tile[r * FAST_LW + 4 * cw]) = v;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = x0 + lx, thr = L.thr[lev];
+#pragma unroll
+    for (int ry = 0; ry < TH / 4; ry++) {
+        const int ly = wv + 4 * ry, y = y0 + ly;
+        bool corner = false;
+        if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) {
+            const uint8_t* c = &tile[(ly + 3) * FAST_LW + lx + 4];
+            const int v = *c, hi = v + thr, lo = v - thr;
+            const int ring[16] = {c[3 * FAST_LW],      c[3 * FAST_LW + 1],  c[2 * FAST_LW + 2],  c[FAST_LW + 3],
+                                  c[3],                c[-FAST_LW + 3],     c[-2 * FAST_LW + 2], c[-3 * FAST_LW + 1],
+                                  c[-3 * FAST_LW],     c[-3 * FAST_LW - 1], c[-2 * FAST_LW - 2], c[-FAST_LW - 3],
+                                  c[-3],               c[FAST_LW - 3],      c[2 * FAST_LW - 2],  c[3 * FAST_LW - 1]};
+            unsigned br = 0, dk = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                br |= (unsigned)(ring[i] > hi) << i;
+                dk |= (unsigned)(ring[i] < lo) << i;
+            }
+            corner = has_run10(br) || has_run10(dk);
+        }
+        const unsigned long long m = __ballot(corner);
+        if (lx == 0 && y < h) L.mask[lev][(size_t)y * ntx + tx] = m;
+    }
+}
+#define FAST_BATCH_TH 16
 __global__ void __launch_bounds__(256) fast_detect_kernel(KfLevels L) { fast_detect_body(L, blockIdx.x); }
 // the keyframes of a batch of frames (ptam_track_map_frames_batch): blockIdx.y picks the keyframe, `stride` bytes apart
 __global__ void __launch_bounds__(256) fast_detect_batch_kernel(const char* __restrict__ items, size_t stride, size_t off_levels, int n_blocks) {
     const KfLevels& L = *(const KfLevels*)(items + (size_t)blockIdx.y * stride + off_levels);
-    if ((int)blockIdx.x < n_blocks) fast_detect_body(L, blockIdx.x);
+    (void)n_blocks;
+    fast_detect_tall_body<FAST_BATCH_TH>(L, blockIdx.x);
 }
-void kf_launch_detect_batch(int nb, int n_blocks, const void* d_items, size_t stride, size_t off_levels, hipStream_t stream) {
+void kf_launch_detect_batch(int nb, const KfLevels& L, const void* d_items, size_t stride, size_t off_levels, hipStream_t stream) {
+    int n_blocks = 0;
+    for (int l = 0; l < PTAM_LEVELS; l++) n_blocks += L.ntx[l] * ((L.h[l] + FAST_BATCH_TH - 1) / FAST_BATCH_TH);
     hipLaunchKernelGGL(fast_detect_batch_kernel, dim3(n_blocks, nb), dim3(256), 0, stream, (const char*)d_items, stride, off_levels, n_blocks);
 }
 

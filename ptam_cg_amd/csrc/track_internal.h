@@ -30,7 +30,7 @@ struct PyrArgs;
 void kf_lite_begin(ptam_kf* kf, const uint8_t* d_src, PyrArgs* a_out, int* gx, int* gy);
 void kf_launch_detect(ptam_kf* kf, hipStream_t stream);
 // FAST detection for nb keyframes of equal geometry in one launch: their KfLevels sit at d_items + i * stride + off_levels
-void kf_launch_detect_batch(int nb, int n_blocks, const void* d_items, size_t stride, size_t off_levels, hipStream_t stream);
+void kf_launch_detect_batch(int nb, const KfLevels& L, const void* d_items, size_t stride, size_t off_levels, hipStream_t stream);   // (L: the common geometry)
 // pvs.hip
 struct PoseArg {   // a pose handed over by value
     double v[12];

@@ -1029,7 +1029,7 @@ int ptam_track_map_frames_batch(int nb, ptam_tracker* const* ts, ptam_kf* const*
         hipLaunchKernelGGL(tm_pyr_pvs_batch_kernel<PTAM_HALFSAMPLE_T>, dim3(n_pyr + n_pvs, nb), dim3(256), 0, st, d_it, gx, ctx->cam);
     else
         hipLaunchKernelGGL(tm_pyr_pvs_batch_kernel<PTAM_HALFSAMPLE_R>, dim3(n_pyr + n_pvs, nb), dim3(256), 0, st, d_it, gx, ctx->cam);
-    kf_launch_detect_batch(nb, curs[0]->n_blocks, d_it, sizeof(TmBatchItem), offsetof(TmBatchItem, L), st);
+    kf_launch_detect_batch(nb, L0, d_it, sizeof(TmBatchItem), offsetof(TmBatchItem, L), st);
     hipLaunchKernelGGL(tm_compact_select_batch_kernel, dim3(1 + fast_compact_blocks(L0), nb), dim3(1024), 0, st, d_it, o);
     // ---- coarse stage :519-569 ----
     hipLaunchKernelGGL(tm_search_batch_kernel, dim3((ncc_max + 3) / 4, nb), dim3(256), 0, st, ctx->cam, d_it, 0, o.coarse_range, o.coarse_subpix_its);
