@@ -249,6 +249,45 @@ def trackmap_bench(hip, host, synth, ctx, kfa, frame_b, d_im, frames, replicas=T
     return out
 
 
+def tracking_replica_rank(hip, host, synth, ctx, k=64):
+    """this rank's share of the N-device tracking figure: frames/s of k cameras tracked as batches, and of one camera alone"""
+    C = ctypes
+    a, b = synth.make_frame_pair()
+    kfa0 = host.KeyFrame(ctx).MakeKeyFrame_Lite(a)
+    case = synth.make_trackmap_case([kfa0.level(l) for l in range(4)])
+    sl = np.ascontiguousarray(case["shuffle_levels"], dtype=np.int32)
+    sf = np.ascontiguousarray(case["shuffle_fine"], dtype=np.int32)
+    pose = np.ascontiguousarray(case["pose_in"], dtype=np.float64)
+    raw = lambda h: h.value if hasattr(h, "value") else int(h)
+    ws = []
+    for _ in range(k):
+        cx = host.Context(lib=hip, device=ctx.device)
+        ka = host.KeyFrame(cx).MakeKeyFrame_Lite(a)
+        tr = host.Tracker(cx, len(case["world"]))
+        tr.set_map(case["world"], case["pixel_right_w"], case["pixel_down_w"], ka, case["src_level"], case["center"])
+        ws.append((cx, ka, host.KeyFrame(cx), tr, host.DevBuf(cx, b)))
+    opts = ws[0][3].opts()
+    trs = (C.c_void_p * k)(*[raw(w[3].h) for w in ws])
+    kfs = (C.c_void_p * k)(*[raw(w[2].h) for w in ws])
+    dis = (C.c_void_p * k)(*[raw(w[4].p) for w in ws])
+    secs = C.c_double()
+    args_ = (pose.ctypes.data_as(C.POINTER(C.c_double)), opts.ctypes.data_as(C.c_void_p), sl.ctypes.data_as(C.c_void_p), sf.ctypes.data_as(C.c_void_p))
+    for rep in range(2):
+        ctx._check(hip.bench_track_batch(k, trs, kfs, dis, *args_, 40, C.byref(secs)), "bench_track_batch")
+    fps_b = k * 40 / secs.value
+    for rep in range(2):
+        ctx._check(hip.bench_track_frames(1, trs, kfs, dis, *args_, 400, C.byref(secs)), "bench_track_frames")
+    fps_1 = 400 / secs.value
+    for cx, ka, kb, tr, di in ws:
+        tr.close()
+        di.free()
+        kb.close()
+        ka.close()
+        cx.close()
+    kfa0.close()
+    return fps_b, fps_1
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -474,6 +513,23 @@ def main():
                                                "workload": wl, "trial_mix": trial_mix(tr1),
                                                "kernel_ms_per_trial": kernel_breakdown(prob_full, args.steps, sharded=False)}
             out["speedup_vs_single_gpu"] = out["value"] / out["single_gpu_same_workload"]["value"]
+        barrier()
+        # tracking on N devices: replicas only — every rank tracks its own 64 cameras as batches on its own
+        # device at the same time, no exchange; the total is the sum.  Kept out of the way of the BA record: a failure here
+        # only drops these keys.
+        if not args.no_tracking:
+            try:
+                fps64, fps1 = tracking_replica_rank(hip, host, synth, ctx)
+                tt = torch.tensor([fps64, fps1], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+                if rank == 0:
+                    out["tracking_replicas"] = {"devices": world, "frames_per_batch": 64, "batched_fps_total": float(tt[0].item()),
+                                                "single_camera_fps_sum": float(tt[1].item()),
+                                                "note": "one process per device, each tracking 64 independent cameras per "
+                                                        "ptam_track_map_frames_batch call (and one camera alone) concurrently; no data-path collective"}
+            except Exception as e:   # noqa: BLE001
+                if rank == 0:
+                    out["tracking_replicas"] = {"error": repr(e)}
         barrier()
     if world == 1:
         # ---- steady accepted-trial rate: a Compute() of exactly the leading accepted trials of this problem ----------

@@ -73,6 +73,7 @@ class Context:
             from ._lib import load
             lib = load()
         self.lib = lib
+        self.device = device
         self.size = tuple(size)
         self.cam = CamParams(*camera, size[0], size[1])
         h = C.c_void_p()
