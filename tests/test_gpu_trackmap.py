@@ -243,3 +243,31 @@ def test_batch_of_frames_equals_single_calls(hip):
     assert single[0]["n_meas"] > 100 and not np.array_equal(single[0]["pose"], single[1]["pose"])
     for cx, ka, kb, tr, di, case in ws:
         tr.close()
+
+
+@pytest.mark.parametrize("size", [(640, 480), (322, 243), (163, 121)], ids=lambda s: f"{s[0]}x{s[1]}")
+def test_batch_keyframes_and_degenerate_maps(hip, size):
+    """the batch's keyframe kernels (tall-tile FAST detection: aligned-word staging at widths that are multiples of four, the
+    byte path otherwise) leave every keyframe exactly as MakeKeyFrame_Lite does — images, corners, row LUTs of all four
+    levels — and frames whose map is empty or invisible come back with the prediction, beside a frame that tracks"""
+    w, h = size
+    a, b = synth.make_frame_pair()
+    rng = np.random.default_rng(7)
+    ims = [np.ascontiguousarray(a[:h, :w]), np.ascontiguousarray(b[:h, :w]), rng.integers(0, 256, (h, w)).astype(np.uint8)]
+    ws = []
+    for im in ims:
+        cx = host.Context(lib=hip, size=size)
+        tr = host.Tracker(cx, 32)
+        ka = host.KeyFrame(cx).MakeKeyFrame_Lite(ims[0])
+        tr.set_map(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3)), ka, np.zeros(0, np.int32), np.zeros((0, 2), np.int32))
+        ws.append((cx, ka, host.KeyFrame(cx), tr, host.DevBuf(cx, im)))
+    pose = np.concatenate([np.eye(3).reshape(9), [0.0, 0.0, 1.5]])
+    res = host.Tracker.TrackFramesBatch([x[3] for x in ws], [x[2] for x in ws], [x[4] for x in ws], [pose] * len(ws), ws[0][3].opts())
+    for (cx, ka, kb, tr, di), im, r in zip(ws, ims, res):
+        assert np.array_equal(r["pose"], pose) and r["n_meas"] == 0
+        want = host.KeyFrame(cx).MakeKeyFrame_Lite(im)
+        for l in range(4):
+            g, q = kb.level(l), want.level(l)
+            assert np.array_equal(g["im"], q["im"]) and np.array_equal(g["corners"], q["corners"]) and np.array_equal(g["rowlut"], q["rowlut"]), (size, l)
+        assert len(kb.level(0)["corners"]) > 0
+        tr.close()
