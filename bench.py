@@ -220,7 +220,7 @@ def trackmap_bench(hip, host, synth, ctx, kfa, frame_b, d_im, frames, replicas=T
             rounds = max(20, 1600 // k)
             for rep in range(2):
                 ctx._check(hip.bench_track_batch(k, trs, kfs, dis, pose.ctypes.data_as(C.POINTER(C.c_double)), opts.ctypes.data_as(C.c_void_p),
-                                                 sl.ctypes.data_as(C.c_void_p), sf.ctypes.data_as(C.c_void_p), rounds, C.byref(secs)), "bench_track_batch")
+                                                 sl.ctypes.data_as(C.c_void_p), sf.ctypes.data_as(C.c_void_p), rounds, 1, C.byref(secs)), "bench_track_batch")
             batched[str(k)] = {"fps": k * rounds / secs.value, "batch_us": 1e6 * secs.value / rounds}
         if k in (1, 8, 32):
             nfp = max(20, 400 // k)
@@ -273,7 +273,7 @@ def tracking_replica_rank(hip, host, synth, ctx, k=64):
     secs = C.c_double()
     args_ = (pose.ctypes.data_as(C.POINTER(C.c_double)), opts.ctypes.data_as(C.c_void_p), sl.ctypes.data_as(C.c_void_p), sf.ctypes.data_as(C.c_void_p))
     for rep in range(2):
-        ctx._check(hip.bench_track_batch(k, trs, kfs, dis, *args_, 40, C.byref(secs)), "bench_track_batch")
+        ctx._check(hip.bench_track_batch(k, trs, kfs, dis, *args_, 40, 1, C.byref(secs)), "bench_track_batch")
     fps_b = k * 40 / secs.value
     for rep in range(2):
         ctx._check(hip.bench_track_frames(1, trs, kfs, dis, *args_, 400, C.byref(secs)), "bench_track_frames")

@@ -403,11 +403,12 @@ int ptam_track_map_frames_batch(int nb, ptam_tracker* const* trackers, ptam_kf* 
 int ptam_bench_track_frames(int n, ptam_tracker* const* trackers, ptam_kf* const* current, const uint8_t* const* d_frames,
                             const double pose_in[12], const ptam_trackmap_opts* opts, const int32_t* shuffle_levels,
                             const int32_t* shuffle_fine, int frames_each, double* seconds_out);
-/* Measurement helper: `rounds` rounds of ptam_tracker_set_shuffle (every tracker) + ptam_track_map_frames_batch, one host thread;
- * *seconds_out = wall time (bench.py: frames/s of nb cameras tracked as batches). */
+/* Measurement helper: `rounds` rounds of ptam_tracker_set_shuffle (every tracker) + ptam_track_map_frames_batch.  groups == 1:
+ * one host thread, one batch of nb per round; groups > 1: the trackers dealt into that many groups, each batched by its own
+ * host thread on its own queue.  *seconds_out = wall time (bench.py: frames/s of nb cameras tracked as batches). */
 int ptam_bench_track_batch(int nb, ptam_tracker* const* trackers, ptam_kf* const* current, const uint8_t* const* d_frames,
                            const double pose_in[12], const ptam_trackmap_opts* opts, const int32_t* shuffle_levels,
-                           const int32_t* shuffle_fine, int rounds, double* seconds_out);
+                           const int32_t* shuffle_fine, int rounds, int groups, double* seconds_out);
 /* vIterationSet of the last frame (what :667-676 turns into mCurrentKF.mMeasurements): *n = its length; out (nullable)
  * receives up to cap entries. */
 int ptam_tracker_read_iteration_set(ptam_tracker* t, ptam_trackmap_meas* out, int cap, int* n);

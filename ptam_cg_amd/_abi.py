@@ -174,7 +174,7 @@ PROTOTYPES = {
     "track_map_frame": (_i, [_vp, _vp, _vp, _pd, _vp, _vp]),
     "bench_track_frames": (_i, [_i, _vp, _vp, _vp, _pd, _vp, _vp, _vp, _i, _pd]),
     "track_map_frames_batch": (_i, [_i, _vp, _vp, _vp, _pd, _vp, _vp]),
-    "bench_track_batch": (_i, [_i, _vp, _vp, _vp, _pd, _vp, _vp, _vp, _i, _pd]),
+    "bench_track_batch": (_i, [_i, _vp, _vp, _vp, _pd, _vp, _vp, _vp, _i, _i, _pd]),
     "tracker_read_iteration_set": (_i, [_vp, _vp, _i, C.POINTER(_i)]),
     "ba_bench_jacobian_rotating": (_i, [_vp, _i, _i, _pd]),
     "ba_set_comm": (_i, [_vp, _i, _i, ALLREDUCE_FN, _vp]),

@@ -1228,25 +1228,58 @@ int ptam_bench_track_frames(int n, ptam_tracker* const* trackers, ptam_kf* const
     return PTAM_OK;
 }
 
-// Measurement helper: `rounds` batches of nb frames (ptam_track_map_frames_batch), one host thread; per round every tracker
-// is handed its permutations first, as a caller tracking nb cameras would.  *seconds_out = wall time of the rounds.
+// Measurement helper: `rounds` rounds of nb frames as batches (ptam_track_map_frames_batch).  groups == 1: one host thread, one
+// batch of nb per round.  groups > 1: the trackers are dealt into that many groups, each driven by its own host thread on its
+// own queue (the group's first tracker leads), so that one group's single-workgroup pose loops run beside another group's
+// searches.  Per round every tracker is handed its permutations first, as a caller tracking nb cameras would.
+// *seconds_out = wall time from the common start to the last thread's return.
 int ptam_bench_track_batch(int nb, ptam_tracker* const* trackers, ptam_kf* const* current, const uint8_t* const* d_frames,
                            const double pose_in[12], const ptam_trackmap_opts* opts, const int32_t* shuffle_levels,
-                           const int32_t* shuffle_fine, int rounds, double* seconds_out) {
+                           const int32_t* shuffle_fine, int rounds, int groups, double* seconds_out) {
     ARG_TRY(nb >= 1 && nb <= 4096 && trackers && current && d_frames && pose_in && shuffle_levels && shuffle_fine && rounds >= 1 && seconds_out);
-    std::vector<double> poses((size_t)nb * 12);
-    for (int i = 0; i < nb; i++) std::memcpy(&poses[(size_t)i * 12], pose_in, 96);
-    std::vector<ptam_trackmap_result> res((size_t)nb);
-    const auto t0 = std::chrono::steady_clock::now();
-    for (int r = 0; r < rounds; r++) {
-        for (int i = 0; i < nb; i++) {
-            const int rc = ptam_tracker_set_shuffle(trackers[i], shuffle_levels, shuffle_fine);
-            if (rc) return rc;
+    ARG_TRY(groups >= 1 && groups <= nb);
+    std::atomic<int> ready{0}, failed{0};
+    std::atomic<bool> go{false};
+    std::vector<std::string> errs((size_t)groups);
+    auto work = [&](int g) {
+        const int per = (nb + groups - 1) / groups, i0 = g * per, i1 = std::min(nb, i0 + per), m = i1 - i0;
+        if (m <= 0) return;
+        std::vector<double> poses((size_t)m * 12);
+        for (int i = 0; i < m; i++) std::memcpy(&poses[(size_t)i * 12], pose_in, 96);
+        std::vector<ptam_trackmap_result> res((size_t)m);
+        ready.fetch_add(1);
+        while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+        for (int r = 0; r < rounds; r++) {
+            int rc = PTAM_OK;
+            for (int i = i0; i < i1 && !rc; i++) rc = ptam_tracker_set_shuffle(trackers[i], shuffle_levels, shuffle_fine);
+            if (!rc) rc = ptam_track_map_frames_batch(m, trackers + i0, current + i0, d_frames + i0, poses.data(), opts, res.data());
+            if (rc) {
+                errs[(size_t)g] = ptam_last_error();
+                failed.store(rc);
+                return;
+            }
         }
-        const int rc = ptam_track_map_frames_batch(nb, trackers, current, d_frames, poses.data(), opts, res.data());
-        if (rc) return rc;
-    }
+    };
+    std::vector<std::thread> th;
+    int n_threads = 0;
+    for (int g = 0; g < groups; g++)
+        if (g * ((nb + groups - 1) / groups) < nb) {
+            th.emplace_back(work, g);
+            n_threads++;
+        }
+    while (ready.load() < n_threads && !failed.load()) std::this_thread::yield();
+    const auto t0 = std::chrono::steady_clock::now();
+    go.store(true, std::memory_order_release);
+    for (auto& t : th) t.join();
     *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (failed.load()) {
+        for (const auto& e : errs)
+            if (!e.empty()) {
+                ptam_set_error("ptam_bench_track_batch: a group failed: %s", e.c_str());
+                break;
+            }
+        return failed.load();
+    }
     return PTAM_OK;
 }
 

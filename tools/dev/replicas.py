@@ -29,7 +29,9 @@ for k in ks:
     print(f"contexts {k:3d}: {k * nf / secs.value:9.0f} frames/s  ({secs.value / nf * 1e6:.0f} us per frame per context)", flush=True)
     if os.environ.get("BATCH"):
         rounds = max(20, 2000 // k)
-        for rep in range(2):
-            ctx0._check(hip.bench_track_batch(k, trs, kfs, dis, pose.ctypes.data_as(C.POINTER(C.c_double)), opts.ctypes.data_as(C.c_void_p),
-                                              sl.ctypes.data_as(C.c_void_p), sf.ctypes.data_as(C.c_void_p), rounds, C.byref(secs)), "bench_batch")
-        print(f"   batched {k:3d}: {k * rounds / secs.value:9.0f} frames/s  ({secs.value / rounds * 1e6:.0f} us per batch)", flush=True)
+        for groups in [int(g) for g in os.environ.get("NGROUPS", "1").split(",")]:
+            if groups > k: continue
+            for rep in range(2):
+                ctx0._check(hip.bench_track_batch(k, trs, kfs, dis, pose.ctypes.data_as(C.POINTER(C.c_double)), opts.ctypes.data_as(C.c_void_p),
+                                                  sl.ctypes.data_as(C.c_void_p), sf.ctypes.data_as(C.c_void_p), rounds, groups, C.byref(secs)), "bench_batch")
+            print(f"   batched {k:3d} in {groups} group(s): {k * rounds / secs.value:9.0f} frames/s  ({secs.value / rounds * 1e6:.0f} us per round)", flush=True)
