@@ -4,6 +4,7 @@
 //   g++ -O2 -std=c++17 -Iinclude examples/shim_demo.cc -Lptam_cg_amd/csrc -lptam_hip -Wl,-rpath,$PWD/ptam_cg_amd/csrc
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #include "ptam_shim.hpp"
@@ -147,6 +148,30 @@ int main() {
         int n_refound = 0;
         for (auto& r : rf) n_refound += r.found;
         std::printf("TRACKMAP %zu %d %d %d %d %d\n", pts.size(), tr.n_pvs[0], tr.attempted[0], tr.n_meas, n_found, n_refound);
+        // two cameras on the one device, one chain of launches for both frames (MapTracker::TrackFramesBatch): each tracker in
+        // a context of its own, the frames device-resident; frame by frame the result of the single call
+        Context ctxB({1.0803, 1.43987, 0.519983, 0.548655, 0.244943}, {160, 120});
+        KeyFrame kfB(ctxB);
+        kfB.MakeKeyFrame_Lite(im.data(), 160);
+        std::vector<ptam_template_query> srcB = src;
+        for (auto& q : srcB) q.src_kf = kfB.handle();
+        MapTracker mtB(ctxB, (int)pts.size() + 1);
+        mtB.SetMap(pts, srcB);
+        void *dA = nullptr, *dB = nullptr;
+        check(ptam_dev_alloc(ctx.handle(), im.size(), &dA), "ptam_dev_alloc");
+        check(ptam_dev_alloc(ctxB.handle(), im.size(), &dB), "ptam_dev_alloc");
+        check(ptam_dev_upload(ctx.handle(), dA, im.data(), im.size()), "ptam_dev_upload");
+        check(ptam_dev_upload(ctxB.handle(), dB, im.data(), im.size()), "ptam_dev_upload");
+        KeyFrame curA(ctx), curB(ctxB);
+        const ptam_trackmap_result one = mt.TrackFrame(curA, (const uint8_t*)dA, SE3::Identity());
+        const auto both = MapTracker::TrackFramesBatch({&mt, &mtB}, {&curA, &curB}, {(const uint8_t*)dA, (const uint8_t*)dB},
+                                                       {SE3::Identity(), SE3::Identity()});
+        int same = 1;
+        for (int i = 0; i < 2; i++)
+            same &= both[i].n_meas == one.n_meas && std::memcmp(both[i].pose, one.pose, sizeof one.pose) == 0;
+        std::printf("BATCH %d %d %d %d\n", one.n_meas, both[0].n_meas, both[1].n_meas, same);
+        ptam_dev_free(ctx.handle(), dA);
+        ptam_dev_free(ctxB.handle(), dB);
     }
     // a toy bundle: 3 cameras on a line looking down +z, 12 points on a grid, exact measurements of a
     // pinhole-ish projection perturbed deterministically

@@ -382,6 +382,34 @@ public:
         check(ptam_track_map(h_, kfCurrent.handle(), in, pOpts, &r), "ptam_track_map");
         return r;
     }
+    // The frame arrives with its image (device-resident, stride == width): MakeKeyFrame_Lite of it into kfCurrent + TrackMap
+    ptam_trackmap_result TrackFrame(KeyFrame& kfCurrent, const uint8_t* dFrame, const SE3& se3Predicted, const ptam_trackmap_opts* pOpts = nullptr) {
+        double in[12];
+        se3Predicted.to12(in);
+        ptam_trackmap_result r;
+        check(ptam_track_map_frame(h_, kfCurrent.handle(), dFrame, in, pOpts, &r), "ptam_track_map_frame");
+        return r;
+    }
+    // Several cameras (or agents) on one device: ONE chain of launches for all their frames, results as the single calls give
+    // them (ptam_track_map_frames_batch).  The trackers live in different Contexts with the same camera model and image size;
+    // SetShuffle each of them first.
+    static std::vector<ptam_trackmap_result> TrackFramesBatch(const std::vector<MapTracker*>& vTrackers, const std::vector<KeyFrame*>& vCurrent,
+                                                              const std::vector<const uint8_t*>& vdFrames, const std::vector<SE3>& vPredicted,
+                                                              const ptam_trackmap_opts* pOpts = nullptr) {
+        const size_t n = vTrackers.size();
+        if (n == 0 || vCurrent.size() != n || vdFrames.size() != n || vPredicted.size() != n) throw std::runtime_error("TrackFramesBatch: sizes differ");
+        std::vector<ptam_tracker*> t(n);
+        std::vector<ptam_kf*> k(n);
+        std::vector<double> poses(12 * n);
+        for (size_t i = 0; i < n; i++) {
+            t[i] = vTrackers[i]->h_;
+            k[i] = vCurrent[i]->handle();
+            vPredicted[i].to12(&poses[12 * i]);
+        }
+        std::vector<ptam_trackmap_result> r(n);
+        check(ptam_track_map_frames_batch((int)n, t.data(), k.data(), vdFrames.data(), poses.data(), pOpts, r.data()), "ptam_track_map_frames_batch");
+        return r;
+    }
     // vIterationSet of the last frame: what :667-676 turns into mCurrentKF.mMeasurements and what routes the outlier flags
     // back to MapPoint::nMEstimatorOutlierCount
     std::vector<ptam_trackmap_meas> IterationSet() {

@@ -66,6 +66,9 @@ def test_shim_demo_matches_oracle(oracle, tmp_path):
     # again in their own source image, and the iteration set agrees with the result block
     t = [int(v) for v in next(x for x in lines if x[0] == "TRACKMAP")[1:]]
     assert t[0] >= 5 and t[1] == t[0] and t[2] == t[0] and t[3] == t[4] and t[3] >= 0.8 * t[0] and t[5] >= 0.8 * t[0]
+    # two trackers in two contexts, one chain of launches: both frames come back exactly as the single call's
+    bt = [int(v) for v in next(x for x in lines if x[0] == "BATCH")[1:]]
+    assert bt[0] >= 0.8 * t[0] and bt[1] == bt[0] and bt[2] == bt[0] and bt[3] == 1
     # bundle: replicate the toy problem through the oracle
     ctx = host.Context(lib=oracle)
     ba = host.Bundle(ctx)
