@@ -466,6 +466,14 @@ __device__ __forceinline__ double wave_sum_f64_dpp(double v) {
     return v;
 }
 
+#ifdef K7_TIMING
+__device__ long long g_sel_ph[4];   // select sub-phases (timing build): histogram | scan | candidates + rank | -
+#define SEL_PH(i) { if (threadIdx.x == 0) { const long long n_ = (long long)__builtin_readcyclecounter(); g_sel_ph[i] += n_ - spt_; spt_ = n_; } }
+#define SEL_PH0 long long spt_ = (long long)__builtin_readcyclecounter();
+#else
+#define SEL_PH(i)
+#define SEL_PH0
+#endif
 // exact k-th smallest of sh.keys[0..n) (non-found entries hold +inf), bit patterns compared as unsigned
 // 64-bit integers.
 //  - fast path: ONE histogram over the top 16 bits (sign, exponent, 4 mantissa bits = 16 bins per binade) relative to
@@ -583,6 +591,7 @@ __device__ double small_select_kth(GnSmallShared<THREADS, MPT>& sh, int n, int k
     const int tid = threadIdx.x;
     unsigned long long key[MPT];
     bool mine[MPT];
+    SEL_PH0
 #pragma unroll
     for (int q = 0; q < MPT; q++) {
         const int i = tid + q * THREADS;
@@ -590,13 +599,17 @@ __device__ double small_select_kth(GnSmallShared<THREADS, MPT>& sh, int n, int k
         if (i < n) atomicAdd(&sh.hist[small_key_bin(key[q])], 1u);
     }
     __syncthreads();
+    SEL_PH(0)
     small_select_scan<MPT, THREADS>(sh, k, true);
+    SEL_PH(1)
     {
         const int bin = sh.sel_digit, cnt = sh.sel_cnt;
         if (bin != 0 && bin != GS_BINS - 1 && cnt <= 64) {
 #pragma unroll
             for (int q = 0; q < MPT; q++) mine[q] = tid + q * THREADS < n && small_key_bin(key[q]) == bin;
-            return small_select_finish<MPT, THREADS>(sh, key, mine, cnt, sh.sel_k);
+            const double r_ = small_select_finish<MPT, THREADS>(sh, key, mine, cnt, sh.sel_k);
+            SEL_PH(2)
+            return r_;
         }
     }
     // general path
@@ -896,6 +909,11 @@ __device__ __forceinline__ void pose_gn_small_body(const DevCam& cam, int n, con
 #ifdef K7_TIMING
     if (tid == 0 && updates)
         for (int i = 0; i < 6; i++) updates[6 * 20 + i] = (double)ph[i];
+    if (tid == 0 && updates)
+        for (int i = 0; i < 4; i++) {
+            updates[6 * 20 + 6 + i] = (double)g_sel_ph[i];
+            g_sel_ph[i] = 0;
+        }
 #endif
     if (tid < 12) pose_io[tid] = sh.pose[tid];
     // resident chain: the measurements' TrackerData state goes back to the per-point table, scene depth sums

@@ -16,3 +16,4 @@ for _ in range(3):
 u = d_u.download(np.float64, 32 * 6)
 names = ["errors+barrier", "select", "accumulate", "barrier", "reduce+barrier", "solve+barrier"]
 print({k: int(v) for k, v in zip(names, u[120:126])}, "total", int(u[120:126].sum()))
+print("select sub-phases (cycles over the run): histogram + barrier %d | bin scan %d | candidates + rank %d" % tuple(int(v) for v in u[126:129]))
