@@ -476,16 +476,23 @@ __device__ long long g_sel_ph[4];   // select sub-phases (timing build): histogr
 #endif
 // exact k-th smallest of sh.keys[0..n) (non-found entries hold +inf), bit patterns compared as unsigned
 // 64-bit integers.
-//  - fast path: ONE histogram over the top 16 bits (sign, exponent, 4 mantissa bits = 16 bins per binade) relative to
-//    2^-40, clamped to 2048 bins.  A thousand squared errors spread over ~10 binades leave a handful of keys in the
+//  - fast path: ONE histogram over the leading bits (sign, exponent, GS_KEY_MBITS mantissa bits) relative to the window's
+//    lower end, clamped to 2048 bins.  A thousand squared errors spread over ~10 binades leave a handful of keys in the
 //    selected bin; they are gathered and ranked by one wave.  sh.hist must be zero on entry and is left zero (the scan
 //    phase clears the bins it reads), so no zeroing pass and five barriers in all;
 //  - general path (selected bin clamped or holding more than 64 keys): MSB radix select with 11-bit digits, switching
 //    to the same finisher as soon as the selected digit holds at most 64 keys.
 // The 8-bit radix version needed 24 barriers per Gauss-Newton iteration and was ~45 % of the pose solve.
-#define GS_KEY_BASE ((1023 - 40) << 4)
+// (round 2c: 64 bins per binade over 2^-22 .. 2^10 instead of 16 over 2^-40 .. 2^88 — squared pixel errors live in that window,
+//  and the finisher ranks its keys one broadcast at a time: ~100 cycles per key of the selected bin, 3 k cycles per call with the
+//  ~30 keys a 16-per-binade bin holds around the median of a thousand)
+#ifndef GS_KEY_MBITS
+#define GS_KEY_MBITS 6
+#endif
+#define GS_KEY_LOW_EXP (GS_KEY_MBITS == 6 ? 22 : (GS_KEY_MBITS == 5 ? 40 : 40))   // window starts at 2^-LOW_EXP
+#define GS_KEY_BASE ((1023 - GS_KEY_LOW_EXP) << GS_KEY_MBITS)
 __device__ __forceinline__ int small_key_bin(unsigned long long key) {
-    const int t = (int)(key >> 48) - GS_KEY_BASE;
+    const int t = (int)(key >> (52 - GS_KEY_MBITS)) - GS_KEY_BASE;
     return t < 0 ? 0 : (t > GS_BINS - 1 ? GS_BINS - 1 : t);
 }
 // rank the keys for which `mine` holds among themselves (cnt <= 64 of them): returns the k-th smallest
