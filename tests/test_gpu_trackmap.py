@@ -271,3 +271,42 @@ def test_batch_keyframes_and_degenerate_maps(hip, size):
             assert np.array_equal(g["im"], q["im"]) and np.array_equal(g["corners"], q["corners"]) and np.array_equal(g["rowlut"], q["rowlut"]), (size, l)
         assert len(kb.level(0)["corners"]) > 0
         tr.close()
+
+
+def test_batch_with_maps_of_different_sizes(hip):
+    """a batch whose maps differ in size: grids are sized for the largest, every frame works on its own counts; the pose
+    kernels run in the instantiation the LARGEST list capacity selects, so a small map's sums are taken in another order
+    than in its single call — same sets, counts and flags, poses equal to rounding"""
+    a, b = synth.make_frame_pair()
+    ctx0 = host.Context(lib=hip)
+    kfa0 = host.KeyFrame(ctx0).MakeKeyFrame_Lite(a)
+    ws = []
+    for i, counts in enumerate([(800, 300, 80, 40), (80, 40, 20, 10), (300, 120, 30, 25)]):
+        case = synth.make_trackmap_case([kfa0.level(l) for l in range(4)], counts=counts, seed=200 + i)
+        cx = host.Context(lib=hip)
+        ka = host.KeyFrame(cx).MakeKeyFrame_Lite(a)
+        tr = host.Tracker(cx, len(case["world"]) + 3 * i)
+        tr.set_map(case["world"], case["pixel_right_w"], case["pixel_down_w"], ka, case["src_level"], case["center"])
+        ws.append((cx, ka, host.KeyFrame(cx), tr, host.DevBuf(cx, b), case))
+    opts = ws[0][3].opts()
+    single, sets = [], []
+    for cx, ka, kb, tr, di, case in ws:
+        tr.set_shuffle(case["shuffle_levels"], case["shuffle_fine"])
+        single.append(tr.TrackFrame(kb, di, case["pose_in"], opts).copy())
+        sets.append(tr.iteration_set())
+    for cx, ka, kb, tr, di, case in ws:
+        tr.set_shuffle(case["shuffle_levels"], case["shuffle_fine"])
+    res = host.Tracker.TrackFramesBatch([w[3] for w in ws], [w[2] for w in ws], [w[4] for w in ws], [w[5]["pose_in"] for w in ws], opts)
+    assert len({len(w[5]["world"]) for w in ws}) == 3
+    for i, (cx, ka, kb, tr, di, case) in enumerate(ws):
+        for f in res.dtype.names:
+            if f in ("pose", "depth_sum", "depth_sum_sq"):
+                assert np.allclose(res[i][f], single[i][f], rtol=1e-9, atol=1e-9), (i, f)
+            else:
+                assert np.array_equal(res[i][f], single[i][f]), (i, f, res[i][f], single[i][f])
+        it = tr.iteration_set()
+        for f in ("point", "level", "found", "did_subpix", "outlier"):
+            assert np.array_equal(it[f], sets[i][f]), (i, f)
+        assert np.allclose(it["v2_found"], sets[i]["v2_found"], rtol=0, atol=1e-9)
+        assert single[i]["n_meas"] > 20
+        tr.close()
