@@ -102,7 +102,10 @@ __device__ __forceinline__ void block_scan4(const int v[4], int off[4], int tot[
 // The choice of the search sets, src/Tracker.cc:480-611.  One workgroup.  The level lists and the fine-candidate flags live
 // in LDS when the map has at most TM_SEL_LDS points (global scratch otherwise): a list written to global memory and read
 // back by another thread of the workgroup costs two round trips per pass, and this kernel is a chain of such passes.
-#define TM_SEL_LDS 2048
+#ifndef TM_SEL_LDS
+#define TM_SEL_LDS 8192   // 4 x 32 KB level lists + 8 KB flags = 136 KB of the CU's 160 KB (2048 until round 2c: a 2 561-point map
+                          // cost 18 us more per frame than a 1 998-point one)
+#endif
 __device__ __forceinline__ void tm_select_body(const TmDev& d, const ptam_trackmap_opts& o) {   // a 1024-thread workgroup
     __shared__ int wsum[4][16];
     __shared__ int ls_list[4][TM_SEL_LDS];
@@ -111,43 +114,56 @@ __device__ __forceinline__ void tm_select_body(const TmDev& d, const ptam_trackm
     const bool lds = n <= TM_SEL_LDS;
     const int chunk = (n + 1023) / 1024, p0 = min(n, tid * chunk), p1 = min(n, p0 + chunk);
     // both permutations' entries of my run and the levels of the first one's points leave together
-    constexpr int RUNMAX = 2;   // (runs longer than this — maps of more than 2048 points — reload inside the loops)
-    int ida[RUNMAX] = {0, 0}, idb[RUNMAX] = {0, 0}, lva[RUNMAX] = {-1, -1};
+    constexpr int RUNMAX = TM_SEL_LDS / 1024;   // (longer runs — maps that do not fit the LDS lists — reload inside the loops)
+    int ida[RUNMAX], idb[RUNMAX], lva[RUNMAX];
 #pragma unroll
-    for (int j = 0; j < RUNMAX; j++)
-        if (p0 + j < p1) {
+    for (int j = 0; j < RUNMAX; j++) {
+        ida[j] = idb[j] = 0;
+        lva[j] = -1;
+        if (chunk <= RUNMAX && p0 + j < p1) {
             ida[j] = d.perm_a[p0 + j];
             idb[j] = d.perm_b[p0 + j];
         }
+    }
 #pragma unroll
     for (int j = 0; j < RUNMAX; j++)
-        if (p0 + j < p1) lva[j] = d.pvs[ida[j]].level;
-    auto id_a = [&](int p) { return p - p0 < RUNMAX ? (p - p0 == 0 ? ida[0] : ida[1]) : d.perm_a[p]; };
-    auto id_b = [&](int p) { return p - p0 < RUNMAX ? (p - p0 == 0 ? idb[0] : idb[1]) : d.perm_b[p]; };
-    auto lv_a = [&](int p, int id) { return p - p0 < RUNMAX ? (p - p0 == 0 ? lva[0] : lva[1]) : d.pvs[id].level; };
+        if (chunk <= RUNMAX && p0 + j < p1) lva[j] = d.pvs[ida[j]].level;
+    // f(id of the first permutation, its level, id of the second permutation) over my run, in order
+    auto for_run = [&](auto&& f) {
+        if (chunk <= RUNMAX) {
+#pragma unroll
+            for (int j = 0; j < RUNMAX; j++)
+                if (p0 + j < p1) f(ida[j], lva[j], idb[j]);
+        } else
+            for (int p = p0; p < p1; p++) {
+                const int ia = d.perm_a[p];
+                f(ia, (int)d.pvs[ia].level, d.perm_b[p]);
+            }
+    };
     auto set_fc = [&](int id, int v) { if (lds) ls_isfc[id] = (uint8_t)v; else d.isfc[id] = (uint8_t)v; };
     auto get_fc = [&](int id) { return lds ? (int)ls_isfc[id] : (int)d.isfc[id]; };
     auto LL = [&](int l, int i) -> int { return lds ? ls_list[l][i] : d.lvl_list[l * cap + i]; };
     // level lists in the order the shuffle permutation visits their members
     int cnt[4] = {0, 0, 0, 0};
-    for (int p = p0; p < p1; p++) {
-        const int id = id_a(p);
-        const int l = lv_a(p, id);
+    for_run([&](int id, int l, int) {
         set_fc(id, 0);
-        if (l >= 0) cnt[l]++;
-    }
+#pragma unroll
+        for (int q = 0; q < 4; q++) cnt[q] += (l == q) ? 1 : 0;
+    });
     int off[4], tot[4];
     block_scan4(cnt, off, tot, wsum);
-    for (int p = p0; p < p1; p++) {
-        const int id = id_a(p);
-        const int l = lv_a(p, id);
+    for_run([&](int id, int l, int) {
         if (l >= 0) {
+            int at = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (l == q) at = off[q]++;
             if (lds)
-                ls_list[l][off[l]++] = id;
+                ls_list[l][at] = id;
             else
-                d.lvl_list[l * cap + off[l]++] = id;
+                d.lvl_list[l * cap + at] = id;
         }
-    }
+    });
     __syncthreads();
     const int n3 = tot[3], n2 = tot[2], n1 = tot[1], n0 = tot[0];
     const int cmax = (int)o.coarse_max;
@@ -191,17 +207,16 @@ __device__ __forceinline__ void tm_select_body(const TmDev& d, const ptam_trackm
         // random_shuffle + resize (:597-600): the first n_use members in the order of the second permutation
         __syncthreads();
         int c4[4] = {0, 0, 0, 0};
-        for (int p = p0; p < p1; p++) c4[0] += get_fc(id_b(p));
+        for_run([&](int, int, int id) { c4[0] += get_fc(id); });
         int o4[4], t4[4];
         block_scan4(c4, o4, t4, wsum);
         int k = o4[0];
-        for (int p = p0; p < p1; p++) {
-            const int id = id_b(p);
+        for_run([&](int, int, int id) {
             if (get_fc(id)) {
                 if (k < n_use) d.list[nC + nH + k] = id;
                 k++;
             }
-        }
+        });
     }
     if (tid == 0) {
         TmCtl& c = *d.ctl;
@@ -616,8 +631,8 @@ struct ptam_tracker {
     TmMailbox* mbox;       // host-mapped
     TmMailbox* mbox_dev;
     unsigned long long seq;
-    // the frame's two permutations in host-mapped memory (maps of at most TM_SEL_LDS points: the set-choice kernel reads every
-    // entry exactly once, at its start) — no upload, i.e. two copy kernels and their boundaries less per frame (~10 us);
+    // the frame's two permutations in host-mapped memory (maps of at most TM_SEL_LDS = 8192 points: the set-choice kernel reads
+    // every entry exactly once, at its start) — no upload, i.e. two copy kernels and their boundaries less per frame (~10 us);
     // d.perm_a / d.perm_b point either here or at the device arrays
     int* perm_host;        // [2][cap], host address
     int* perm_host_dev;    // device address of the same memory

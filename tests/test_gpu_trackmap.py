@@ -159,7 +159,7 @@ def test_track_frame_equals_keyframe_then_track_map(hip):
 def test_native_replicas_track_the_same_frame(hip):
     """ptam_bench_track_frames: k contexts driven by k host threads inside the library (per frame set_shuffle +
     ptam_track_map_frame) leave every tracker with the pose a single ptam_track_map_frame call gives — the permutations
-    travel through host-mapped memory on this path (maps of at most 2048 points), so a non-trivial shuffle is part of it."""
+    travel through host-mapped memory on this path (maps of at most 8192 points), so a non-trivial shuffle is part of it."""
     import ctypes as C
     ctx0 = host.Context(lib=hip)
     a, b = synth.make_frame_pair()
@@ -310,3 +310,30 @@ def test_batch_with_maps_of_different_sizes(hip):
         assert np.allclose(it["v2_found"], sets[i]["v2_found"], rtol=0, atol=1e-9)
         assert single[i]["n_meas"] > 20
         tr.close()
+
+
+@pytest.mark.parametrize("tile", [1, 4], ids=["2561pts_lds_lists", "10244pts_global_lists"])
+def test_track_map_large_maps(hip, tile):
+    """maps beyond the one- and two-entries-per-thread runs of the set choice: 2 561 points (LDS level lists, three entries per
+    thread, host-mapped permutations) and the same map four times over = 10 244 points (more than the LDS lists hold: global
+    lists, device permutations, runs reloaded inside the loops) against the composition through the product's own stage calls —
+    the chain's control flow, list order and hand-over must reproduce it to the last bit"""
+    ctx, kfa, kfb, case = _setup(hip, (1000, 900, 700, 500))
+    if tile > 1:
+        rng = np.random.default_rng(5)
+        for k in ("world", "pixel_right_w", "pixel_down_w", "src_level", "center"):
+            case[k] = np.concatenate([case[k]] * tile)
+        n = len(case["world"])
+        case["shuffle_levels"] = rng.permutation(n).astype(np.int32)
+        case["shuffle_fine"] = rng.permutation(n).astype(np.int32)
+    n = len(case["world"])
+    assert (n > 8192) == (tile > 1) and n > 2048
+    tr = host.Tracker(ctx, n)
+    tr.set_map(case["world"], case["pixel_right_w"], case["pixel_down_w"], kfa, case["src_level"], case["center"])
+    tr.set_shuffle(case["shuffle_levels"], case["shuffle_fine"])
+    res = tr.TrackMap(kfb, case["pose_in"], tr.opts())
+    it = tr.iteration_set()
+    tr.close()
+    ref = trackmap_ref.track_map(ctx, kfb, kfa, case, case["pose_in"], case["shuffle_levels"], case["shuffle_fine"])
+    _check(res, it, ref, strict=True)
+    assert res["n_meas"] > 500 and sum(res["n_pvs"]) > 2400 * tile
