@@ -130,6 +130,15 @@ struct Carver {
 static void ba_finish_outliers(ptam_ba* ba);
 static int ba_prepare_impl(ptam_ba* ba) {
     ptam_ctx* ctx = ba->ctx;
+    // PTAM_DEBUG_PREPARE=1: host time of the phases of this function (sort | lists | Schur work lists | launch shape | alloc + clear | upload)
+    static const bool dbg_prep = getenv("PTAM_DEBUG_PREPARE") != nullptr;
+    auto pt0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!dbg_prep) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[ptam] prepare: %-18s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - pt0).count());
+        pt0 = t;
+    };
     ba_finish_outliers(ba);   // erased measurements of earlier Compute() calls leave the problem here
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(ptam_stream_wait(ctx->stream));
@@ -144,14 +153,35 @@ static int ba_prepare_impl(ptam_ba* ba) {
     for (int c = 0; c < C; c++)
         if (!ba->cam_fixed[c]) cam_free[c] = F++;
     // live measurements sorted point-major (point, camera); ties keep insertion order
+    // (a counting sort over the points, then each point's short run by camera: a comparison sort of the whole list was 1.8 ms
+    //  of a 10 ms prepare at 250 000 measurements)
     std::vector<int> order;
-    order.reserve(Mall);
-    for (int i = 0; i < Mall; i++)
-        if (!ba->m_dead[i]) order.push_back(i);
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-        if (ba->m_pt[x] != ba->m_pt[y]) return ba->m_pt[x] < ba->m_pt[y];
-        return ba->m_cam[x] < ba->m_cam[y];
-    });
+    {
+        std::vector<int> start(P + 1, 0);
+        int live = 0;
+        for (int i = 0; i < Mall; i++)
+            if (!ba->m_dead[i]) {
+                start[ba->m_pt[i] + 1]++;
+                live++;
+            }
+        for (int p = 0; p < P; p++) start[p + 1] += start[p];
+        order.resize((size_t)live);
+        std::vector<int> fill(start.begin(), start.end() - 1);
+        for (int i = 0; i < Mall; i++)
+            if (!ba->m_dead[i]) order[(size_t)fill[ba->m_pt[i]]++] = i;   // insertion order inside a point: stable
+        for (int p = 0; p < P; p++) {
+            int* b0 = order.data() + start[p];
+            int* b1 = order.data() + start[p + 1];
+            bool sorted = true;
+            for (int* q = b0; q + 1 < b1; q++)
+                if (ba->m_cam[q[0]] > ba->m_cam[q[1]]) {
+                    sorted = false;
+                    break;
+                }
+            if (!sorted) std::stable_sort(b0, b1, [&](int x, int y) { return ba->m_cam[x] < ba->m_cam[y]; });
+        }
+    }
+    lap("sort");
     const int M = (int)order.size();
     for (int i = 1; i < M; i++)
         if (ba->m_pt[order[i]] == ba->m_pt[order[i - 1]] && ba->m_cam[order[i]] == ba->m_cam[order[i - 1]]) {
@@ -207,6 +237,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
             wchunks.push_back(ch);
         }
     }
+    lap("rowptr + chunks");
     // Schur work lists
     const int n_tiles = (F + SCHUR_TC - 1) / SCHUR_TC;
     const int n_pairs = n_tiles * (n_tiles + 1) / 2;
@@ -252,6 +283,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
                 }
         }
     }
+    lap("schur entries");
     // Workgroups of the tile kernel: XCD-aware, cost-balanced, a workgroup = a few SEGMENTS (pair, entry range).
     // Block b runs on XCD b % 8 (observed placement, MI355X_MICROARCH.md), each XCD has its own 4 MB L2, and every W block
     // is read once per tile pair its tile takes part in.  The points are cut into 8 ranges of equal cost; XCD x multiplies
@@ -337,10 +369,19 @@ static int ba_prepare_impl(ptam_ba* ba) {
             for (int pr = 0; pr < n_pairs; pr++) {
                 const int base = (int)s_entries.size() - lo[pr];   // position of the pair's entry i in s_entries: base + i
                 s_entries.insert(s_entries.end(), per_pair[pr].begin() + lo[pr], per_pair[pr].begin() + hi[pr]);
-                if (sort_pattern)   // entries of one fragment pattern next to each other: the kernel skips a fragment set only
-                                    // when none of the FOUR points of a group has a camera in it
-                    std::stable_sort(s_entries.end() - (hi[pr] - lo[pr]), s_entries.end(),
-                                     [&](const SchurEntry& u, const SchurEntry& v) { return pattern_of(u) < pattern_of(v); });
+                if (sort_pattern && hi[pr] > lo[pr]) {   // entries of one fragment pattern next to each other: the kernel skips a
+                                                          // fragment set only when none of the FOUR points of a group has a camera in it
+                    auto e0 = s_entries.end() - (hi[pr] - lo[pr]);
+                    const int pat0 = pattern_of(*e0);
+                    bool uniform = true;   // (a dense problem: every entry has every camera — nothing to sort)
+                    for (auto it = e0 + 1; it != s_entries.end(); ++it)
+                        if (pattern_of(*it) != pat0) {
+                            uniform = false;
+                            break;
+                        }
+                    if (!uniform)
+                        std::stable_sort(e0, s_entries.end(), [&](const SchurEntry& u, const SchurEntry& v) { return pattern_of(u) < pattern_of(v); });
+                }
                 std::vector<double> pre((size_t)(hi[pr] - lo[pr]) + 1, 0.0);   // prefix costs of the chunk's (sorted) entries
                 for (int i = lo[pr]; i < hi[pr]; i++) pre[(size_t)(i - lo[pr]) + 1] = pre[(size_t)(i - lo[pr])] + entry_cost(pr, s_entries[(size_t)(base + i)]);
                 int pos = lo[pr];
@@ -390,6 +431,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
         s_segs.swap(ordered);
     }
 
+    lap("schur split");
     d.C = C;
     d.F = F;
     d.P = P;
@@ -491,6 +533,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     } else
         d.grid_acc = std::max(1, std::min(d.n_chunks, n_cu * per_cu));
 
+    lap("launch shape");
     // ---- carve one device allocation ------------------------------------------------------------
     Carver cv;
     const size_t Mz = std::max(M, 1), Pz = std::max(P, 1), Cz = std::max(C, 1), Fz = std::max(F, 1);
@@ -568,9 +611,21 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.sc = (BaScalars*)(base + o_sc);
     d.dbg = (long long*)(base + o_dbg);
 
+    lap("alloc + clear");
     // ---- upload -------------------------------------------------------------------------------------
-    std::vector<int> h_cam(Mz), h_pt(Mz), h_orig(Mz), h_fidx(Mz);
-    std::vector<double> h_found(2 * Mz), h_s(Mz);
+    // the per-measurement arrays are put together in the context's PINNED staging buffer: a copy out of pageable vectors is
+    // staged by the runtime piece by piece (2.5 ms of a 10 ms prepare at 250 000 measurements)
+    void* pin_m = nullptr;
+    {
+        const int rc_p = ctx_pinned(ctx, Mz * 40 + 256, &pin_m);
+        if (rc_p) return rc_p;
+    }
+    int* h_cam = (int*)pin_m;
+    int* h_pt = h_cam + Mz;
+    int* h_orig = h_pt + Mz;
+    int* h_fidx = h_orig + Mz;
+    double* h_found = (double*)(h_fidx + Mz);   // (16 Mz bytes in: 8-byte aligned)
+    double* h_s = h_found + 2 * Mz;
     for (int i = 0; i < M; i++) {
         const int o = order[i];
         h_cam[i] = ba->m_cam[o];
@@ -604,12 +659,12 @@ static int ba_prepare_impl(ptam_ba* ba) {
     UP(d.cam_free, cam_free.data(), (size_t)C * 4);
     UP(d.pt[0], ba->pts.data(), (size_t)P * 24);
     UP(d.rowptr, rowptr.data(), (size_t)(P + 1) * 4);
-    UP(d.m_cam, h_cam.data(), (size_t)M * 4);
-    UP(d.m_pt, h_pt.data(), (size_t)M * 4);
-    UP(d.m_found, h_found.data(), (size_t)M * 16);
-    UP(d.m_s, h_s.data(), (size_t)M * 8);
-    UP(d.m_orig, h_orig.data(), (size_t)M * 4);
-    UP(d.m_fidx, h_fidx.data(), (size_t)M * 4);
+    UP(d.m_cam, h_cam, (size_t)M * 4);
+    UP(d.m_pt, h_pt, (size_t)M * 4);
+    UP(d.m_found, h_found, (size_t)M * 16);
+    UP(d.m_s, h_s, (size_t)M * 8);
+    UP(d.m_orig, h_orig, (size_t)M * 4);
+    UP(d.m_fidx, h_fidx, (size_t)M * 4);
     UP(d.chunks, chunks.data(), chunks.size() * sizeof(BaChunk));
     UP(d.wchunks, wchunks.data(), wchunks.size() * sizeof(BaChunk));
     UP(d.s_entries, s_entries.data(), s_entries.size() * sizeof(SchurEntry));
@@ -617,12 +672,15 @@ static int ba_prepare_impl(ptam_ba* ba) {
     UP(d.s_wg_seg, s_wg_seg.data(), s_wg_seg.size() * 4);
     UP(d.s_pair_wg_begin, pair_wg_begin.data(), pair_wg_begin.size() * 4);
 #undef UP
+    lap("stage + enqueue");
     HIP_TRY(ptam_stream_wait(ctx->stream));   // host staging vectors die here
+    lap("upload wait");
     {
         const int rc_s = ba_solve_init();
         if (rc_s) return rc_s;
     }
     HIP_TRY(hipMalloc((void**)&ba->d_xchg, 4096));
+    lap("solve init + xchg");
 
     ba->cur = 0;
     ba->prepared = true;
