@@ -243,6 +243,9 @@ static int ba_prepare_impl(ptam_ba* ba) {
     const int n_pairs = n_tiles * (n_tiles + 1) / 2;
     std::vector<std::vector<SchurEntry>> per_pair(n_pairs);
     {
+        // (a point contributes at most one entry to a pair)
+        const size_t guess = n_pairs > 0 ? std::min<size_t>((size_t)P, 2 * (size_t)M / (size_t)n_pairs + 16) : 0;
+        for (auto& v : per_pair) v.reserve(guess);
         std::vector<int> t_first(n_tiles), touched;
         std::vector<std::array<unsigned, 2>> t_off(n_tiles);
         for (int p = 0; p < P; p++) {
@@ -333,15 +336,21 @@ static int ba_prepare_impl(ptam_ba* ba) {
             return cost_model == 1 ? std::max(5, f) : f + cost_model;
         };
         // point ranges of equal cost
+        // (an entry's cost is worked out once and kept in its padding word, which the device does not read)
         std::vector<double> pt_cost(P + 1, 0.0);
         for (int pr = 0; pr < n_pairs; pr++)
-            for (const SchurEntry& e : per_pair[pr]) pt_cost[e.pt + 1] += entry_cost(pr, e);
+            for (SchurEntry& e : per_pair[pr]) {
+                const int c_ = entry_cost(pr, e);
+                e.pad = c_ | (pattern_of(e) << 16);   // (cost: low half, fragment pattern: high half)
+                pt_cost[e.pt + 1] += c_;
+            }
         for (int p = 0; p < P; p++) pt_cost[p + 1] += pt_cost[p];
         int bound[9];
         bound[0] = 0;
         for (int x = 1; x < NX; x++)
             bound[x] = (int)(std::lower_bound(pt_cost.begin(), pt_cost.end(), pt_cost[P] * x / NX) - pt_cost.begin());
         bound[NX] = P;
+        std::vector<SchurEntry> sort_tmp;
         std::vector<std::vector<std::vector<int>>> wgs_x(NX);    // per XCD: workgroups = lists of segment indices
         std::vector<std::vector<int>> segs_of_pair(n_pairs);
         for (int x = 0; x < NX; x++) {
@@ -353,7 +362,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
                 auto cmp = [](const SchurEntry& e, int p) { return e.pt < p; };
                 lo[pr] = (int)(std::lower_bound(v.begin(), v.end(), bound[x], cmp) - v.begin());
                 hi[pr] = (int)(std::lower_bound(v.begin(), v.end(), bound[x + 1], cmp) - v.begin());
-                for (int i = lo[pr]; i < hi[pr]; i++) cost_x += entry_cost(pr, v[i]);
+                for (int i = lo[pr]; i < hi[pr]; i++) cost_x += v[i].pad & 0xffff;
                 ent_x += (size_t)(hi[pr] - lo[pr]);
             }
             if (ent_x == 0) continue;
@@ -371,19 +380,22 @@ static int ba_prepare_impl(ptam_ba* ba) {
                 s_entries.insert(s_entries.end(), per_pair[pr].begin() + lo[pr], per_pair[pr].begin() + hi[pr]);
                 if (sort_pattern && hi[pr] > lo[pr]) {   // entries of one fragment pattern next to each other: the kernel skips a
                                                           // fragment set only when none of the FOUR points of a group has a camera in it
-                    auto e0 = s_entries.end() - (hi[pr] - lo[pr]);
-                    const int pat0 = pattern_of(*e0);
-                    bool uniform = true;   // (a dense problem: every entry has every camera — nothing to sort)
-                    for (auto it = e0 + 1; it != s_entries.end(); ++it)
-                        if (pattern_of(*it) != pat0) {
-                            uniform = false;
-                            break;
-                        }
-                    if (!uniform)
-                        std::stable_sort(e0, s_entries.end(), [&](const SchurEntry& u, const SchurEntry& v) { return pattern_of(u) < pattern_of(v); });
+                    // stable counting sort over the 16 patterns (kept in the entries' padding word); a chunk whose entries share
+                    // one pattern — every chunk of a dense problem — stays as it is
+                    SchurEntry* e0 = s_entries.data() + (s_entries.size() - (size_t)(hi[pr] - lo[pr]));
+                    const int nn = hi[pr] - lo[pr];
+                    int cnt16[17] = {0};
+                    for (int i = 0; i < nn; i++) cnt16[((e0[i].pad >> 16) & 15) + 1]++;
+                    bool uniform = false;
+                    for (int q = 1; q <= 16; q++) uniform = uniform || cnt16[q] == nn;
+                    if (!uniform) {
+                        for (int q = 0; q < 16; q++) cnt16[q + 1] += cnt16[q];
+                        sort_tmp.assign(e0, e0 + nn);
+                        for (int i = 0; i < nn; i++) e0[cnt16[(sort_tmp[(size_t)i].pad >> 16) & 15]++] = sort_tmp[(size_t)i];
+                    }
                 }
                 std::vector<double> pre((size_t)(hi[pr] - lo[pr]) + 1, 0.0);   // prefix costs of the chunk's (sorted) entries
-                for (int i = lo[pr]; i < hi[pr]; i++) pre[(size_t)(i - lo[pr]) + 1] = pre[(size_t)(i - lo[pr])] + entry_cost(pr, s_entries[(size_t)(base + i)]);
+                for (int i = lo[pr]; i < hi[pr]; i++) pre[(size_t)(i - lo[pr]) + 1] = pre[(size_t)(i - lo[pr])] + (s_entries[(size_t)(base + i)].pad & 0xffff);
                 int pos = lo[pr];
                 while (pos < hi[pr]) {
                     const int left = hi[pr] - pos;
