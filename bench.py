@@ -383,11 +383,16 @@ def main():
         ctx._check(hip.rccl_create(ctx.h, ident, rank, world, ctypes.byref(comm)), "rccl_create")
         hook = ctypes.cast(hip.lib.ptam_rccl_allreduce_f64, _abi.ALLREDUCE_FN)
 
+    prepare_ms = []   # host + upload time of every ptam_ba_prepare of this run (never part of `value`)
+
     def new_bundle(max_it, problem=None, sharded=True):
         ba = synth.load_into(host.Bundle(ctx, max_iterations=max_it, update_sq_conv_limit=0.0), prob if problem is None else problem)
         if comm is not None and sharded:
             ba.set_comm(rank, world, hook, comm)
+        t0 = time.perf_counter()
         ba.prepare()     # sort + upload: inputs resident in HBM before any timed region
+        ctx.sync()
+        prepare_ms.append(1e3 * (time.perf_counter() - t0))
         return ba
 
     def barrier():
@@ -471,6 +476,7 @@ def main():
         return out
 
     dt, trials, (n_cams, n_free, n_points, n_meas), spin = timed_compute(prob, args.steps, args.warmup)
+    prepare_headline_ms = min(prepare_ms) if prepare_ms else None   # (the bundles of the timed workload; later legs append more)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -498,6 +504,7 @@ def main():
             "accepted_trials": int(trials["accepted"].sum()),
             "spinup_k7_us_first_last_blocks": [spin[0] * 1e3, spin[-1] * 1e3, len(spin)],
             "err_first_last": [float(trials["err_old"][0]), float(trials["err_new"][-1])],
+            "prepare_ms": prepare_headline_ms,   # sort + work lists + upload of one Bundle of this workload: outside the timed region
         }
     if world > 1:
         # per-kernel breakdown of the sharded run (HIP events, separate Compute; every rank takes part in its collectives)
