@@ -337,3 +337,42 @@ def test_track_map_large_maps(hip, tile):
     ref = trackmap_ref.track_map(ctx, kfb, kfa, case, case["pose_in"], case["shuffle_levels"], case["shuffle_fine"])
     _check(res, it, ref, strict=True)
     assert res["n_meas"] > 500 and sum(res["n_pvs"]) > 2400 * tile
+
+
+def test_tracker_and_mapmaker_threads_run_side_by_side(hip):
+    """the reference's two-thread loop: a tracker thread tracking frames while the mapmaker thread runs a bundle adjustment, each in
+    its own context on the same device — both get exactly what they get when run one after the other"""
+    import threading
+    from tests import util
+    ctx_t, kfa, kfb, case = _setup(hip, (800, 300, 80, 40))
+    a, b = synth.make_frame_pair()
+    tr = host.Tracker(ctx_t, len(case["world"]))
+    tr.set_map(case["world"], case["pixel_right_w"], case["pixel_down_w"], kfa, case["src_level"], case["center"])
+    d_im = host.DevBuf(ctx_t, b)
+    kf_cur = host.KeyFrame(ctx_t)
+    opts = tr.opts()
+
+    def track(n):
+        out = []
+        for _ in range(n):
+            tr.set_shuffle(case["shuffle_levels"], case["shuffle_fine"])
+            out.append(tr.TrackFrame(kf_cur, d_im, case["pose_in"], opts).copy())
+        return out
+
+    prob = synth.make_ba_problem(20, 3000, 5)
+    want_track = track(3)
+    want_ba = util.run_ba(hip, prob)
+    got = {}
+    th = [threading.Thread(target=lambda: got.__setitem__("track", track(60))),
+          threading.Thread(target=lambda: got.__setitem__("ba", [util.run_ba(hip, prob) for _ in range(3)]))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert len(got["track"]) == 60 and len(got["ba"]) == 3
+    for r in got["track"]:
+        assert np.array_equal(r["pose"], want_track[0]["pose"]) and r["n_meas"] == want_track[0]["n_meas"]
+    for r in got["ba"]:
+        util.assert_ba_equal(r, want_ba, rel=1e-9)
+        assert np.array_equal(r["outliers"], want_ba["outliers"])
+    tr.close()
