@@ -80,6 +80,7 @@ struct ptam_ba {
     int k7_threads = BA_CHUNK;
     bool k7_loop = false;
     std::vector<int> sorted_orig;   // sorted position -> insertion index
+    std::vector<int> pt_orig;       // device point id -> original point id (the points with a live measurement, ascending)
     // gather buffers (sharded mode)
     double* d_gather = nullptr;
     size_t gather_cap = 0;
@@ -145,7 +146,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     ba_free_device(ba);
     BaDev& d = ba->d;
     std::memset(&d, 0, sizeof d);
-    const int C = (int)ba->cam_fixed.size(), P = (int)(ba->pts.size() / 3);
+    const int C = (int)ba->cam_fixed.size(), P_all = (int)(ba->pts.size() / 3);
     const int Mall = (int)ba->m_cam.size();
     // free-camera indices in insertion order  (nStartRow, src/Bundle.cc:52-57)
     std::vector<int> cam_free(C, -1);
@@ -153,23 +154,24 @@ static int ba_prepare_impl(ptam_ba* ba) {
     for (int c = 0; c < C; c++)
         if (!ba->cam_fixed[c]) cam_free[c] = F++;
     // live measurements sorted point-major (point, camera); ties keep insertion order
+    std::vector<int> dense_of;   // original point id -> device point id (-1: no live measurement)
     // (a counting sort over the points, then each point's short run by camera: a comparison sort of the whole list was 1.8 ms
     //  of a 10 ms prepare at 250 000 measurements)
     std::vector<int> order;
     {
-        std::vector<int> start(P + 1, 0);
+        std::vector<int> start(P_all + 1, 0);
         int live = 0;
         for (int i = 0; i < Mall; i++)
             if (!ba->m_dead[i]) {
                 start[ba->m_pt[i] + 1]++;
                 live++;
             }
-        for (int p = 0; p < P; p++) start[p + 1] += start[p];
+        for (int p = 0; p < P_all; p++) start[p + 1] += start[p];
         order.resize((size_t)live);
         std::vector<int> fill(start.begin(), start.end() - 1);
         for (int i = 0; i < Mall; i++)
             if (!ba->m_dead[i]) order[(size_t)fill[ba->m_pt[i]]++] = i;   // insertion order inside a point: stable
-        for (int p = 0; p < P; p++) {
+        for (int p = 0; p < P_all; p++) {
             int* b0 = order.data() + start[p];
             int* b1 = order.data() + start[p + 1];
             bool sorted = true;
@@ -180,8 +182,20 @@ static int ba_prepare_impl(ptam_ba* ba) {
                 }
             if (!sorted) std::stable_sort(b0, b1, [&](int x, int y) { return ba->m_cam[x] < ba->m_cam[y]; });
         }
+        // The device sees only the points that HAVE a live measurement, numbered densely in their original order: the kernels
+        // walk the point-major list 64 measurements at a time and fetch "the chunk's points" as one run of consecutive ids,
+        // which a stretch of unobserved points (never measured, or every measurement purged earlier) would break.  An
+        // unobserved point takes no part in an adjustment and keeps its position (its V* is zero, src/Bundle.cc:341-359).
+        dense_of.assign((size_t)P_all, -1);
+        ba->pt_orig.clear();
+        for (int p = 0; p < P_all; p++)
+            if (start[p + 1] > start[p]) {
+                dense_of[(size_t)p] = (int)ba->pt_orig.size();
+                ba->pt_orig.push_back(p);
+            }
     }
     lap("sort");
+    const int P = (int)ba->pt_orig.size();
     const int M = (int)order.size();
     for (int i = 1; i < M; i++)
         if (ba->m_pt[order[i]] == ba->m_pt[order[i - 1]] && ba->m_cam[order[i]] == ba->m_cam[order[i - 1]]) {
@@ -190,7 +204,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
         }
     ba->sorted_orig = order;
     std::vector<int> rowptr(P + 1, 0);
-    for (int i = 0; i < M; i++) rowptr[ba->m_pt[order[i]] + 1]++;
+    for (int i = 0; i < M; i++) rowptr[dense_of[(size_t)ba->m_pt[order[i]]] + 1]++;
     for (int p = 0; p < P; p++) {
         if (rowptr[p + 1] > BA_CHUNK) {
             ptam_set_error("point %d has %d measurements; the limit is %d cameras per point", p, rowptr[p + 1], BA_CHUNK);
@@ -641,7 +655,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     for (int i = 0; i < M; i++) {
         const int o = order[i];
         h_cam[i] = ba->m_cam[o];
-        h_pt[i] = ba->m_pt[o];
+        h_pt[i] = dense_of[(size_t)ba->m_pt[o]];
         h_orig[i] = o;
         h_fidx[i] = cam_free[ba->m_cam[o]];
         h_found[2 * i] = ba->m_found[2 * o];
@@ -669,7 +683,10 @@ static int ba_prepare_impl(ptam_ba* ba) {
     if ((bytes) > 0) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream))
     UP(d.pose[0], ba->cam_pose.data(), (size_t)C * 96);
     UP(d.cam_free, cam_free.data(), (size_t)C * 4);
-    UP(d.pt[0], ba->pts.data(), (size_t)P * 24);
+    std::vector<double> h_pts((size_t)std::max(P, 1) * 3);
+    for (int q = 0; q < P; q++)
+        for (int k = 0; k < 3; k++) h_pts[(size_t)3 * q + k] = ba->pts[(size_t)3 * ba->pt_orig[(size_t)q] + k];
+    UP(d.pt[0], h_pts.data(), (size_t)P * 24);
     UP(d.rowptr, rowptr.data(), (size_t)(P + 1) * 4);
     UP(d.m_cam, h_cam, (size_t)M * 4);
     UP(d.m_pt, h_pt, (size_t)M * 4);
@@ -1492,7 +1509,8 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
         }
         std::atomic_thread_fence(std::memory_order_acquire);
         std::memcpy(ba->cam_pose.data(), hp, b_pose);
-        if (d.P > 0) std::memcpy(ba->pts.data(), hp + b_pose, b_pts);
+        for (int q = 0; q < d.P; q++)   // (device point q is original point pt_orig[q]; unobserved points keep their position)
+            std::memcpy(&ba->pts[(size_t)3 * ba->pt_orig[(size_t)q]], hp + b_pose + (size_t)q * 24, 24);
         if (n_out > 0) std::memcpy(out_idx.data(), hp + b_pose + b_pts, b_out);
     }
     // the outlier list (reference order: LM step, then insertion order) is put together when somebody asks for it

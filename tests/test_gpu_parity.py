@@ -562,3 +562,19 @@ def test_refind_common_matches_oracle(hip, oracle):
     for rh, ro in zip(out["hip"], out["oracle"]):
         G.assert_refind_equal(rh, ro["found"], ro["level"], ro["sub_pix"], ro["never_retry"], ro["root_pos"])
     assert out["oracle"][0]["found"].sum() > 1000 and out["oracle"][1]["found"].sum() < out["oracle"][0]["found"].sum()
+
+
+@pytest.mark.parametrize("cams,pts,lo,hi", [(10, 400, 20, 120), (6, 300, 5, 290), (8, 500, 3, 70), (12, 1000, 100, 101)],
+                         ids=lambda v: str(v))
+def test_bundle_points_without_measurements(hip, oracle, cams, pts, lo, hi):
+    """long stretches of points that nobody measures (never measured, or purged earlier) between observed ones: the device
+    numbers the observed points densely — the kernels fetch a chunk's points as one run of consecutive ids, which such a gap
+    used to break (wrong coordinates, silently) — and an unobserved point keeps its position (src/Bundle.cc:341-359)"""
+    p = synth.make_ba_problem(cams, pts, 21)
+    keep = ~((p["pt_idx"] >= lo) & (p["pt_idx"] < hi))
+    q = {k: (v[keep] if k in ("cam_idx", "pt_idx", "found", "sigma_sq") else v) for k, v in p.items()}
+    a, b = util.run_ba(hip, q, max_iterations=8), util.run_ba(oracle, q, max_iterations=8)
+    util.assert_ba_equal(a, b, rel=1e-6)
+    assert a["accepted"] > 0
+    assert np.array_equal(a["points"][lo:hi], q["points"][lo:hi])          # untouched
+    assert not np.array_equal(a["points"][hi:hi + 5], q["points"][hi:hi + 5])   # the others moved
