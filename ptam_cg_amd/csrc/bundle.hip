@@ -231,26 +231,13 @@ static int ba_prepare_impl(ptam_ba* ba) {
             chunks.push_back(ch);
         }
     }
-    // wave chunks (K7 wave variant): consecutive whole points, at most 64 measurements
-    std::vector<BaChunk> wchunks;
-    int max_row = 0;
-    for (int p = 0; p < P; p++) max_row = std::max(max_row, rowptr[p + 1] - rowptr[p]);
-    if (max_row <= 64) {
-        int p = 0;
-        while (p < P) {
-            BaChunk ch;
-            ch.pt_begin = p;
-            ch.m_begin = rowptr[p];
-            int cnt = 0;
-            while (p < P && cnt + (rowptr[p + 1] - rowptr[p]) <= 64) {
-                cnt += rowptr[p + 1] - rowptr[p];
-                p++;
-            }
-            ch.pt_end = p;
-            ch.m_end = rowptr[p];
-            wchunks.push_back(ch);
-        }
-    }
+    // K7's wave variant walks the point-major list 64 measurements at a time whatever the points' lengths: a point cut by a
+    // chunk edge — or covering whole chunks, when more than 64 cameras measure it — leaves one piece per chunk, which K8a adds in
+    // chunk order.  (Until round 2c the variant was only taken when no point had more than 64 measurements, and a 100-camera
+    // dense problem ran the block variant: 38.8 instead of ~10 us per K7 launch.)  PTAM_K7_BLOCK=1 forces the block variant.
+    std::vector<BaChunk> wchunks;   // (one dummy entry marks the variant; the kernel does not read it)
+    static const bool force_block = getenv("PTAM_K7_BLOCK") != nullptr;
+    if (M > 0 && !force_block) wchunks.push_back(BaChunk{0, P, 0, M});
     lap("rowptr + chunks");
     // Schur work lists
     const int n_tiles = (F + SCHUR_TC - 1) / SCHUR_TC;
@@ -473,8 +460,10 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.n_schur_entries = (int)s_entries.size();
     // persistent grid of the accumulate kernel: bounded by LDS residency, 2 x 256 CUs by default
     // (wave variant: + one 3 KB W transposition buffer per wave, K7_WT_DOUBLES)
-    const size_t smem_base = ((((size_t)F * 27 + 1) & ~(size_t)1) + (ba->use_wave ? (size_t)C * 12 + 2 : (size_t)BA_CHUNK * 8)) * sizeof(double);
-    auto k7_smem = [&](int threads) { return smem_base + (ba->use_wave ? (size_t)(threads / 64) * K7_WT_DOUBLES * sizeof(double) : 0); };
+    auto k7_smem = [&](int threads) {   // (follows ba->use_wave: the choice below may fall back to the block variant)
+        const size_t base = ((((size_t)F * 27 + 1) & ~(size_t)1) + (ba->use_wave ? (size_t)C * 12 + 2 : (size_t)BA_CHUNK * 8)) * sizeof(double);
+        return base + (ba->use_wave ? (size_t)(threads / 64) * K7_WT_DOUBLES * sizeof(double) : 0);
+    };
     // wave variant, two shapes:
     //  - few chunks (every 64-measurement chunk can be resident at once: <= 24 waves per CU):
     //    straight-line kernel, ONE chunk per wave, 1024-thread workgroups (79 VGPRs);
@@ -503,7 +492,33 @@ static int ba_prepare_impl(ptam_ba* ba) {
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k7, threads, k7_smem(threads)) == hipSuccess ? PTAM_OK : PTAM_E_HIP;
     };
     int per_cu = 0;
-    if (int rc = k7_occupancy(ba->k7_threads, &per_cu)) return rc;
+    {
+        // the workgroup's LDS — camera partials F * 216 B + poses C * 96 B + 3 KB per wave — must fit the CU's 160 KB: many
+        // cameras take narrower workgroups (fewer transposition buffers), then the block variant (no pose staging), and
+        // beyond ~600 free cameras nothing fits
+        const size_t lds_max = 160 * 1024;
+        if (ba->use_wave && k7_smem(ba->k7_threads) > lds_max) {
+            for (int t : {512, 256})
+                if (k7_smem(t) <= lds_max) {
+                    ba->k7_threads = t;
+                    break;
+                }
+            if (k7_smem(ba->k7_threads) > lds_max) {
+                ba->use_wave = false;
+                ba->k7_loop = false;
+                ba->k7_threads = BA_CHUNK;
+            }
+        }
+        if (k7_smem(ba->k7_threads) > lds_max) {
+            ptam_set_error("%d free cameras (%d in all): the accumulation kernel's camera partials (%zu KB) do not fit a CU's 160 KB of LDS",
+                           F, C, k7_smem(ba->k7_threads) / 1024);
+            return PTAM_E_LIMIT;
+        }
+    }
+    if (int rc = k7_occupancy(ba->k7_threads, &per_cu)) {
+        ptam_set_error("the accumulation kernel cannot be launched with %zu bytes of LDS (%d free cameras)", k7_smem(ba->k7_threads), F);
+        return rc;
+    }
     if (ba->k7_loop) {
         // many cameras: the LDS partials (F*27 + C*12 doubles per workgroup) bound the workgroups per CU,
         // so a wider workgroup keeps more waves resident (200 cameras: 62 KB + 3 KB per wave -> ONE workgroup per CU
