@@ -31,11 +31,12 @@
 #define NITER (NB / 4)
 static_assert(NB == 32, "the strip decomposition below is written for 32x32 blocks");
 
+// reciprocal of a pivot: v_rcp_f64 (2^-24.4 relative, tools/pipes/rcpacc) and ONE cubic step y (1 + e + e^2), e = 1 - d y —
+// three dependent FMAs instead of the four of two Newton steps, <= 1 ulp all the same; it sits on the chain of every pivot
 __device__ __forceinline__ double fast_rcp(double d) {
-    double x = __builtin_amdgcn_rcp(d);
-    x = fma(fma(-d, x, 1.0), x, x);
-    x = fma(fma(-d, x, 1.0), x, x);
-    return x;
+    const double y = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, y, 1.0);
+    return fma(y, fma(e, e, e), y);
 }
 
 // unit-lower 4x4 micro factor (l), pivots' reciprocals (i) of a symmetric 4x4 given by its lower triangle
@@ -77,6 +78,7 @@ __device__ __forceinline__ void micro_subst(const Micro& f, const double a[4], d
     x[3] = a[3] - x[0] * f.l30 - x[1] * f.l31 - x[2] * f.l32;
 }
 
+typedef double v4f64 __attribute__((ext_vector_type(4)));
 struct StepLds {
     double P[2][3][NB][4];   // the iteration's panel (raw strips of A_kk, A_i, A_j), double buffered
     double Pb[2][4];         // rhs entries of the pivot rows
@@ -121,6 +123,8 @@ __global__ void __launch_bounds__(TPB) ldlt_step_twin_kernel(BaDev d, int k_top,
 #include "ldlt_step_body.inc"
     }
 }
+
+#include "ldlt_small.inc"
 
 // w = D^-1 z ; L^T x = w, blocked backwards and right-looking.  One workgroup of 1024 threads:
 // thread (rr, c) = (tid / 32, tid % 32).  Per block k:  x_k = Lkk^-T (w_k - pending_k)  is a 32x32
@@ -260,6 +264,7 @@ __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur, i
 
 int ba_solve_init() {
     HIP_TRY(hipFuncSetAttribute((const void*)ldlt_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)ldlt_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return PTAM_OK;
 }
 
@@ -273,6 +278,13 @@ static int ldlt_twist_len(int nblk, int band) {
 
 int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
     const int nblk = d.npad / NB, band = se_band(d);
+    static const bool no_small = getenv("PTAM_LDLT_NO_SMALL") != nullptr;   // (A/B runs: launch-per-block-column form only)
+    // a small system in one workgroup and one launch: ldlt_small.inc
+    if (!no_small && nblk <= SM_NB) {
+        hipLaunchKernelGGL(ldlt_small_kernel, dim3(1), dim3(TPB), sizeof(SmallLds), ctx->stream, d, cur);
+        HIP_TRY(hipGetLastError());
+        return PTAM_OK;
+    }
     auto nwg_of = [](int rem) { return 1 + rem + rem * (rem + 1) / 2; };
     const int t_end = ldlt_twist_len(nblk, band), b_start = nblk - t_end;
     for (int st = 0; st < t_end; st++) {   // one step of each chain per launch
@@ -296,4 +308,5 @@ void solve_preload_kernels() {
     ptam_preload((const void*)ldlt_step_kernel);
     ptam_preload((const void*)ldlt_step_twin_kernel);
     ptam_preload((const void*)ldlt_backward_kernel);
+    ptam_preload((const void*)ldlt_small_kernel);
 }

@@ -1,0 +1,127 @@
+// tools/ldlt/ldlt_bench.hip — the camera solve (csrc/solve.hip) alone, on a synthetic banded SPD system:
+//   ldlt_bench [free cameras = 49] [band (blocks) = all] [repetitions = 200]
+// Builds S = G G^T + n I inside the block band (lower triangle, block-banded storage of csrc/bundle.h), a right-hand
+// side, runs ba_solve() `repetitions` times (S | E restored from a master copy before each), checks da against a host
+// LDL^T of the same system and prints the average wall time per solve (events around the whole loop, copies included — use
+// rocprofv3 --kernel-trace --stats on this binary for per-kernel durations; -DK7_TIMING builds print the kernels' stamps).
+// Not part of the product: it includes solve.hip textually so that instrumented variants need no library rebuild.
+#include <cstdarg>
+#include <cstdlib>
+#include <random>
+
+#include "../../ptam_cg_amd/csrc/solve.hip"
+
+void ptam_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    va_end(ap);
+    fputc('\n', stderr);
+}
+void ptam_preload(const void*) {}
+#define CK(x)                                                                          \
+    do {                                                                               \
+        hipError_t e_ = (x);                                                           \
+        if (e_ != hipSuccess) {                                                        \
+            fprintf(stderr, "%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); \
+            exit(1);                                                                   \
+        }                                                                              \
+    } while (0)
+
+int main(int argc, char** argv) {
+    const int F = argc > 1 ? atoi(argv[1]) : 49;
+    const int n = 6 * F, npad = (n + NB - 1) / NB * NB, nblk = npad / NB;
+    int band = argc > 2 ? atoi(argv[2]) : nblk - 1;
+    if (band > nblk - 1) band = nblk - 1;
+    const int reps = argc > 3 ? atoi(argv[3]) : 200;
+    // dense symmetric matrix with the block band, strongly diagonal
+    std::vector<double> A((size_t)npad * npad, 0.0), b(npad, 0.0);
+    std::mt19937_64 rng(12345);
+    std::uniform_real_distribution<double> u(-1.0, 1.0);
+    for (int i = 0; i < npad; i++)
+        for (int j = 0; j <= i; j++) {
+            double v = 0;
+            if (i >= n || j >= n)
+                v = i == j ? 1.0 : 0.0;   // identity padding
+            else if (i / NB - j / NB <= band)
+                v = i == j ? 2.0 * NB * (band + 1) + u(rng) : u(rng);
+            A[(size_t)i * npad + j] = A[(size_t)j * npad + i] = v;
+        }
+    for (int i = 0; i < n; i++) b[i] = u(rng);
+    // host reference: dense LDL^T
+    std::vector<double> Lh = A, x = b;
+    for (int j = 0; j < npad; j++) {
+        const double dj = Lh[(size_t)j * npad + j];
+        for (int i = j + 1; i < npad; i++) {   // a_iq -= a_ij a_qj / d_j, lower triangle, column j still undivided
+            const double aij = Lh[(size_t)i * npad + j];
+            if (aij == 0.0) continue;
+            for (int q = j + 1; q <= i; q++) Lh[(size_t)i * npad + q] -= aij * Lh[(size_t)q * npad + j] / dj;
+        }
+        for (int i = j + 1; i < npad; i++) Lh[(size_t)i * npad + j] /= dj;
+    }
+    for (int i = 0; i < npad; i++)
+        for (int j = 0; j < i; j++) x[i] -= Lh[(size_t)i * npad + j] * x[j];
+    for (int i = 0; i < npad; i++) x[i] /= Lh[(size_t)i * npad + i];
+    for (int i = npad - 1; i >= 0; i--)
+        for (int j = i + 1; j < npad; j++) x[i] -= Lh[(size_t)j * npad + i] * x[j];
+    // device layout
+    BaDev d;
+    memset(&d, 0, sizeof d);
+    d.n = n, d.npad = npad, d.band = band, d.C = 0, d.F = F;
+    const size_t ssz = se_size(nblk, band), tot = ssz + npad + 3;
+    std::vector<double> SE(tot, 0.0);
+    for (int bi = 0; bi < nblk; bi++)
+        for (int bj = std::max(0, bi - band); bj <= bi; bj++)
+            for (int r = 0; r < NB; r++)
+                for (int c = 0; c < NB; c++)
+                    SE[se_blk(bi, bj, band) + r * NB + c] = (bi == bj && c > r) ? 1e300 : A[(size_t)(bi * NB + r) * npad + bj * NB + c];
+    for (int i = 0; i < npad; i++) SE[ssz + i] = b[i];
+    double *master, *dbg;
+    CK(hipMalloc(&master, tot * 8));
+    CK(hipMalloc(&d.SE, tot * 8));
+    CK(hipMalloc(&d.L, ssz * 8));
+    CK(hipMalloc(&d.Dg, npad * 8));
+    CK(hipMalloc(&d.y, npad * 8));
+    CK(hipMalloc(&d.da, npad * 8));
+    CK(hipMalloc(&d.sumsq2, 16));
+    CK(hipMalloc(&d.cam_free, 16));
+    CK(hipMalloc(&dbg, 65536 * 8));
+    CK(hipMemset(dbg, 0, 65536 * 8));
+    d.dbg = (long long*)dbg;
+    CK(hipMemcpy(master, SE.data(), tot * 8, hipMemcpyHostToDevice));
+    ptam_ctx ctx;
+    memset(&ctx, 0, sizeof ctx);
+    CK(hipStreamCreate(&ctx.stream));
+    if (ba_solve_init() != PTAM_OK) return 1;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e30f, ms = 0;
+    for (int round = 0; round < 3; round++) {
+        CK(hipEventRecord(e0, ctx.stream));
+        for (int i = 0; i < reps; i++) {
+            CK(hipMemcpyAsync(d.SE, master, tot * 8, hipMemcpyDeviceToDevice, ctx.stream));
+            if (ba_solve(&ctx, d, 0) != PTAM_OK) return 1;
+        }
+        CK(hipEventRecord(e1, ctx.stream));
+        CK(hipStreamSynchronize(ctx.stream));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, ms);
+    }
+    std::vector<double> da(npad);
+    CK(hipMemcpy(da.data(), d.da, npad * 8, hipMemcpyDeviceToHost));
+    double err = 0, nrm = 0;
+    for (int i = 0; i < n; i++) err = std::max(err, fabs(da[i] - x[i])), nrm = std::max(nrm, fabs(x[i]));
+    printf("F %d n %d nblk %d band %d: %.2f us per solve (copy included), max |da - ref| = %.3e (|ref| max %.3e) %s\n", F, n, nblk, band,
+           1e3 * best / reps, err, nrm, err <= 1e-11 * nrm + 1e-300 ? "OK" : "MISMATCH");
+#ifdef K7_TIMING
+    {
+        std::vector<long long> st(512);
+        CK(hipMemcpy(st.data(), dbg, 512 * 8, hipMemcpyDeviceToHost));
+        printf("stamps (cycles between consecutive ones):");
+        for (int i = 1; i < 400 && st[32 + i]; i++) printf(" %lld", st[32 + i] - st[31 + i]);
+        printf("\n");
+    }
+#endif
+    return err <= 1e-11 * nrm ? 0 : 2;
+}
