@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--points", type=int, default=None, help="map points (default: 5000 at N = 1, 50000 at N > 1)")
     ap.add_argument("--window", type=int, default=None, help="covisibility window, 0 = dense (default: 0 at N = 1, 16 at N > 1)")
     ap.add_argument("--no-global", action="store_true", help="skip the single-GPU run of the 200 x 50000 global adjustment")
+    ap.add_argument("--no-local", action="store_true", help="skip the local bundle adjustment leg (BASELINE.json configs[3]: 20 keyframes x 3000 points)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tracking", action="store_true")
     ap.add_argument("--no-replicas", action="store_true", help="tracking: one context only (no k-thread replica runs; used under rocprofv3)")
@@ -314,6 +315,7 @@ def pmc_traffic(workload):
 
 
 GLOBAL_BA = dict(cams=200, points=50000, window=16)   # BASELINE.json configs[4]
+LOCAL_BA = dict(cams=20, points=3000)                  # BASELINE.json configs[3]
 
 
 def workload_name(cams, points, window):
@@ -593,6 +595,37 @@ def main():
                                  "algorithmic_bytes_per_launch": bby}
             bb.close()
             out["global_ba_single_gpu"] = gb
+        # ---- BASELINE configs[3]: PTAM's local adjustment (src/MapMaker.cc:788-829), 20 keyframes x 3000 points ----------
+        if not args.no_local and (args.cams, args.points) != (LOCAL_BA["cams"], LOCAL_BA["points"]):
+            try:
+                loc = synth.make_ba_problem(LOCAL_BA["cams"], LOCAL_BA["points"], synth.SEED_BA_LOCAL)
+                lsteps = 10   # (configs[3] is quoted at 10 LM iterations)
+                dtl, trl, cl, _ = timed_compute(loc, lsteps, args.warmup)
+                lb = {"workload": workload_name(LOCAL_BA["cams"], LOCAL_BA["points"], 0), "value": lsteps / dtl, "unit": "LM iterations/s",
+                      "ms_per_step": 1e3 * dtl / lsteps, "steps": lsteps, "keyframes_free": int(cl[1]), "measurements": int(cl[3]),
+                      "trial_mix": trial_mix(trl), "kernel_ms_per_trial": kernel_breakdown(loc, lsteps)}
+                n_lead_l = 0
+                for a in trl["accepted"]:
+                    if not a:
+                        break
+                    n_lead_l += 1
+                if n_lead_l >= 2:
+                    dta, _, _, _ = timed_compute(loc, n_lead_l, args.warmup)
+                    lb["accepted_trial_us"] = 1e6 * dta / n_lead_l
+                if not args.no_cpu_baseline:
+                    from tests.oracle_lib import load_oracle
+                    ob = synth.load_into(host.Bundle(host.Context(lib=load_oracle()), max_iterations=lsteps, update_sq_conv_limit=0.0), loc)
+                    t0 = time.perf_counter()
+                    ob.Compute()
+                    cdt = time.perf_counter() - t0
+                    otl = ob.trials()
+                    lb["cpu_baseline"] = {"value": len(otl) / cdt, "unit": "LM iterations/s", "cores": 1, "kind": "port",
+                                          "sample": f"the same problem, {len(otl)} lambda trials, oracle/ptam_oracle.cc, one thread"}
+                    lb["parity_rel_err_final_trial"] = float(abs(otl["err_new"][-1] - trl["err_new"][-1]) / abs(otl["err_new"][-1]))
+                    ob.close()
+                out["local_ba_config4"] = lb
+            except Exception as e:   # noqa: BLE001
+                out["local_ba_config4"] = {"error": repr(e)}
         # the legs below report beside the headline record; a failure in one of them must not cost the record itself
         if not args.no_tracking:
             try:

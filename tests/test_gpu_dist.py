@@ -84,3 +84,30 @@ def test_rccl_single_rank_allreduce(hip):
     assert np.array_equal(x, y)                     # sum over one rank = identity
     hip.dev_free(ctx.h, d)
     hip.rccl_destroy(comm)
+
+
+def test_bench_n2_path_prints_one_json_line():
+    """bench.py's N > 1 code (rank bookkeeping, MAX over ranks, the one-device run of the same problem in the
+    same line) must have executed before the driver's first multi-GPU run does it.  Two ranks under torch.distributed.run,
+    both on the one GPU (PTAM_BENCH_ONE_GPU=1: gloo with host staging instead of RCCL — the numbers mean nothing)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, PTAM_BENCH_ONE_GPU="1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(dist_util.free_port()), os.path.join(dist_util.ROOT, "bench.py"), "--gpus", "2", "--cams", "24",
+           "--points", "900", "--window", "8", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-tracking"]
+    r = subprocess.run(cmd, env=env, cwd=dist_util.ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]          # stdout = exactly the record
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 4 and rec["scaling"] == "strong" and rec["value"] > 0
+    assert rec["config"]["workload"] == "bundle_24kf_x_900pts_window8_strong_x2"
+    one = rec["single_gpu_same_workload"]
+    assert one["workload"] == "bundle_24kf_x_900pts_window8" and one["value"] > 0
+    assert abs(rec["speedup_vs_single_gpu"] - rec["value"] / one["value"]) < 1e-12
+    assert set(rec["kernel_ms_per_trial"]) >= {"jacobian", "schur", "solve"}
