@@ -640,6 +640,7 @@ struct ptam_tracker {
     // argument arrays of the batches this tracker leads (ptam_track_map_frames_batch): grown on demand
     void* batch_dev;
     size_t batch_cap;
+    hipStream_t last_stream;   // the queue that last ran this tracker (its own context's, or a batch's lead tracker's)
 };
 
 extern "C" {
@@ -676,11 +677,16 @@ int ptam_tracker_create(ptam_ctx* ctx, int max_points, ptam_tracker** out) {
                  o_sr = take(cap * sizeof(ptam_subpix_result)), o_sf = take(cap * 4), o_st = take(cap * 4), o_ss = take(cap * 4), o_sv = take(cap * 16),
                  o_me = take(cap * sizeof(ptam_pose_meas)), o_en = take(cap * sizeof(ptam_projection)), o_mi = take(cap * 4),
                  o_ms = take(cap * 4), o_ou = take(cap * 4), o_ctl = take(sizeof(TmCtl)), o_pose = take(96);
-    if (hipMalloc(&t->block, off) != hipSuccess) {
+    // every failure past this point leaves through ONE path that releases what exists so far
+    auto fail = [&](const char* what) {
+        ptam_set_error("ptam_tracker_create: %s failed", what);
+        if (t->perm_host) hipHostFree(t->perm_host);
+        if (t->mbox) hipHostFree(t->mbox);
+        if (t->block) hipFree(t->block);
         delete t;
-        ptam_set_error("hipMalloc(%zu) failed", off);
         return PTAM_E_HIP;
-    }
+    };
+    if (hipMalloc(&t->block, off) != hipSuccess) return fail("hipMalloc");
     (void)hipMemsetAsync(t->block, 0, off, ctx->stream);
     char* b = (char*)t->block;
     TmDev& d = t->d;
@@ -710,39 +716,28 @@ int ptam_tracker_create(ptam_ctx* ctx, int max_points, ptam_tracker** out) {
     d.ctl = (TmCtl*)(b + o_ctl);
     d.pose = (double*)(b + o_pose);
     void* h = nullptr;
-    if (hipHostMalloc(&h, sizeof(TmMailbox), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
-        hipFree(t->block);
-        delete t;
-        ptam_set_error("hipHostMalloc failed");
-        return PTAM_E_HIP;
-    }
+    if (hipHostMalloc(&h, sizeof(TmMailbox), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return fail("hipHostMalloc");
+    t->mbox = (TmMailbox*)h;
     std::memset(h, 0, sizeof(TmMailbox));
     void* dv = nullptr;
-    HIP_TRY(hipHostGetDevicePointer(&dv, h, 0));
-    t->mbox = (TmMailbox*)h;
+    if (hipHostGetDevicePointer(&dv, h, 0) != hipSuccess) return fail("hipHostGetDevicePointer");
     t->mbox_dev = (TmMailbox*)dv;
     t->perm_dev_a = d.perm_a;
     t->perm_dev_b = d.perm_b;
     {
         void *hp = nullptr, *dp = nullptr;
-        if (hipHostMalloc(&hp, cap * 8, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
-            hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
-            if (hp) hipHostFree(hp);
-            hipHostFree(h);
-            hipFree(t->block);
-            delete t;
-            ptam_set_error("hipHostMalloc failed");
-            return PTAM_E_HIP;
-        }
+        if (hipHostMalloc(&hp, cap * 8, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return fail("hipHostMalloc");
         t->perm_host = (int*)hp;
+        if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) return fail("hipHostGetDevicePointer");
         t->perm_host_dev = (int*)dp;
     }
     // identity shuffles until the caller sets its own
     std::vector<int> idp((size_t)max_points);
     for (int i = 0; i < max_points; i++) idp[(size_t)i] = i;
-    HIP_TRY(hipMemcpy(d.perm_a, idp.data(), cap * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d.perm_b, idp.data(), cap * 4, hipMemcpyHostToDevice));
-    HIP_TRY(ptam_stream_wait(ctx->stream));
+    if (hipMemcpy(d.perm_a, idp.data(), cap * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d.perm_b, idp.data(), cap * 4, hipMemcpyHostToDevice) != hipSuccess)
+        return fail("hipMemcpy");
+    if (ptam_stream_wait(ctx->stream) != hipSuccess) return fail("stream wait");
     *out = t;
     return PTAM_OK;
 }
@@ -810,7 +805,8 @@ int ptam_tracker_set_shuffle(ptam_tracker* t, const int32_t* shuffle_levels, con
     if (n <= TM_SEL_LDS) {
         // host-mapped: the kernel of the coming frame reads the entries straight from here.  The previous frame's set choice
         // is certainly done once that frame's result has arrived; otherwise wait for the queue.
-        if (t->mbox->seq != t->seq) HIP_TRY(ptam_stream_wait(t->ctx->stream));
+        // (a batch runs the tracker on the LEAD tracker's queue: that is the one to wait for)
+        if (t->mbox->seq != t->seq) HIP_TRY(ptam_stream_wait(t->last_stream ? t->last_stream : t->ctx->stream));
         std::memcpy(t->perm_host, shuffle_levels, (size_t)n * 4);
         std::memcpy(t->perm_host + t->d.cap, shuffle_fine, (size_t)n * 4);
         t->d.perm_a = t->perm_host_dev;
@@ -823,6 +819,7 @@ int ptam_tracker_set_shuffle(ptam_tracker* t, const int32_t* shuffle_levels, con
     int rc = ctx_pinned(t->ctx, (size_t)n * 8 + 64, &pin);
     if (rc) return rc;
     HIP_TRY(ptam_stream_wait(t->ctx->stream));   // (shared staging buffer; the previous frame has been read by now anyway)
+    if (t->last_stream && t->last_stream != t->ctx->stream) HIP_TRY(ptam_stream_wait(t->last_stream));
     std::memcpy(pin, shuffle_levels, (size_t)n * 4);
     std::memcpy((char*)pin + (size_t)n * 4, shuffle_fine, (size_t)n * 4);
     HIP_TRY(hipMemcpyAsync(t->d.perm_a, pin, (size_t)n * 4, hipMemcpyHostToDevice, t->ctx->stream));
@@ -844,6 +841,10 @@ static int track_map_impl(ptam_tracker* t, ptam_kf* cur, const uint8_t* d_new_fr
     else
         ptam_trackmap_opts_default(&o);
     ARG_TRY(o.max_patches >= 0 && o.coarse_subpix_its >= 0 && o.coarse_subpix_its <= 64);
+    // (coarse_max / coarse_min become ints on the device and size the coarse search grid: a value past INT_MAX / 2 turned the
+    //  set sizes negative and the set choice wrote outside its lists; the range is a pixel radius inside a 640-pixel image)
+    ARG_TRY(o.coarse_max <= (unsigned)INT_MAX / 2 && o.coarse_min <= (unsigned)INT_MAX / 2 && o.coarse_range <= 4096u);
+    ARG_TRY(o.estimator == PTAM_EST_TUKEY || o.estimator == PTAM_EST_CAUCHY || o.estimator == PTAM_EST_HUBER);
     HIP_TRY(hipSetDevice(ctx->device));
     const TmDev& d = t->d;
     const int n = d.n;
@@ -894,6 +895,7 @@ static int track_map_impl(ptam_tracker* t, ptam_kf* cur, const uint8_t* d_new_fr
     hipLaunchKernelGGL(tm_search_kernel, dim3(std::max(1, (n + 3) / 4)), dim3(256), 0, st, ctx->cam, cur->L, d, 1, 0u, 0);
     hipLaunchKernelGGL(tm_gather_kernel, dim3(std::max(1, (n + TM_GATHER_THREADS - 1) / TM_GATHER_THREADS)), dim3(TM_GATHER_THREADS), 0, st, d, 1, o.coarse_subpix_its, o.coarse_min, t->mbox_dev);
     const unsigned long long seq = ++t->seq;
+    t->last_stream = st;
     {
         ptam_gn_opts g;
         ptam_gn_opts_default(&g);       // fine schedule :613-643
@@ -955,6 +957,10 @@ int ptam_track_map_frames_batch(int nb, ptam_tracker* const* ts, ptam_kf* const*
     else
         ptam_trackmap_opts_default(&o);
     ARG_TRY(o.max_patches >= 0 && o.coarse_subpix_its >= 0 && o.coarse_subpix_its <= 64);
+    // (coarse_max / coarse_min become ints on the device and size the coarse search grid: a value past INT_MAX / 2 turned the
+    //  set sizes negative and the set choice wrote outside its lists; the range is a pixel radius inside a 640-pixel image)
+    ARG_TRY(o.coarse_max <= (unsigned)INT_MAX / 2 && o.coarse_min <= (unsigned)INT_MAX / 2 && o.coarse_range <= 4096u);
+    ARG_TRY(o.estimator == PTAM_EST_TUKEY || o.estimator == PTAM_EST_CAUCHY || o.estimator == PTAM_EST_HUBER);
     const KfLevels& L0 = curs[0]->L;
     for (int i = 0; i < nb; i++) {
         ARG_TRY(ts[i]->ctx->device == ctx->device && curs[i]->device == ctx->device);
@@ -1032,6 +1038,7 @@ int ptam_track_map_frames_batch(int nb, ptam_tracker* const* ts, ptam_kf* const*
         pf.updates = su;
         pf.st = sst;
         seqs[(size_t)i] = ++t->seq;
+        t->last_stream = st;
         pf.io.depth_out = t->d.ctl->depth;
         pf.io.result_pose = t->mbox_dev->res.pose;
         pf.io.result_depth = t->mbox_dev->depth3;

@@ -376,3 +376,19 @@ def test_tracker_and_mapmaker_threads_run_side_by_side(hip):
         util.assert_ba_equal(r, want_ba, rel=1e-9)
         assert np.array_equal(r["outliers"], want_ba["outliers"])
     tr.close()
+
+
+def test_trackmap_options_out_of_range_are_refused(hip):
+    """coarse_max is an unsigned option that becomes an int on the device; 2^31 made the set sizes negative and the
+    set choice write outside its lists.  Every out-of-range option must come back as an argument error, nothing enqueued."""
+    ctx, kfa, kfb, case = _setup(hip, (60, 30, 20, 10))
+    tr = host.Tracker(ctx, len(case["world"]))
+    tr.set_map(case["world"], case["pixel_right_w"], case["pixel_down_w"], kfa, case["src_level"], case["center"])
+    good = tr.TrackMap(kfb, case["pose_in"], tr.opts())
+    for bad in (dict(coarse_max=2 ** 31), dict(coarse_max=2 ** 32 - 1), dict(coarse_min=2 ** 31 + 5), dict(coarse_range=10 ** 6),
+                dict(estimator=7), dict(estimator=-1), dict(max_patches=-1), dict(coarse_subpix_its=65)):
+        with pytest.raises(RuntimeError, match="bad argument"):
+            tr.TrackMap(kfb, case["pose_in"], tr.opts(**bad))
+    again = tr.TrackMap(kfb, case["pose_in"], tr.opts())      # and the tracker is still usable
+    assert np.array_equal(good["pose"], again["pose"])
+    tr.close()
