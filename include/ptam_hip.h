@@ -465,8 +465,9 @@ int ptam_ba_add_measurements(ptam_ba* ba, int n, const int32_t* cam, const int32
  * is dead code there — Do_LM_Step returns true unconditionally (:550), TooN's LDL^T signals nothing — and
  * a singular or non-finite system shows up as it does in the reference: NaN errors, rejected trials, and
  * (where the reference would loop for ever, :118-123) an early stop.  Errors of the call itself (< 0
- * status: PTAM_E_LIMIT for a point seen by more than 256 cameras, PTAM_E_ARG for a duplicate
- * measurement, HIP / communicator failures) are the return value, not *accepted_out. */
+ * status: PTAM_E_ARG for a duplicate measurement, HIP / communicator failures) are the return value, not
+ * *accepted_out.  Like src/Bundle.cc:46-93 the device path bounds neither the cameras of a bundle nor the measurements of a
+ * point (a point seen by more than 256 keyframes and more than ~600 free cameras take slower kernel forms). */
 int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* accepted_out);
 int ptam_ba_converged(const ptam_ba* ba);                    /* include/Bundle.h:115 */
 int ptam_ba_get_point(const ptam_ba* ba, int n, double pos[3]);      /* src/Bundle.cc:613 */
@@ -508,7 +509,14 @@ int ptam_ba_bench_jacobian_rotating(ptam_ba** bas, int n, int reps, double* avg_
 typedef int (*ptam_allreduce_f64_fn)(void* user, double* dptr, size_t count, void* stream);
 /* Attach a communicator to a bundle: `rank`'s bundle holds ALL cameras but only its shard of the
  * points (and every measurement of those points).  With a hook attached, Compute all-reduces the
- * camera system (S lower blocks + E), the error scalars and the median histogram per trial. */
+ * camera system (S lower blocks + E), the error scalars and the median histogram per trial.
+ * Failure semantics: what decides the SEQUENCE of collectives is itself collective — the abort flag, a shard that cannot
+ * be prepared, a rank without measurements — so every rank leaves Compute at the same trial with an error or a result.
+ * A failure that strikes ONE rank between two collectives of a trial (a HIP error, an allocation failure, the hook
+ * returning non-zero) is returned by that rank at once; the others are by then inside (or on their way into) the next
+ * all-reduce and can only be released by the communicator: the hook MUST time out or be abortable (RCCL: the
+ * communicator's own abort / watchdog; torch.distributed: the process group's timeout), after which the process group is
+ * to be torn down — the bundle's device state is undefined. */
 int ptam_ba_set_comm(ptam_ba* ba, int rank, int world, ptam_allreduce_f64_fn fn, void* user);
 
 /* built-in RCCL implementation of the hook (librccl is dlopen'ed on first use) */

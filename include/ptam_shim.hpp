@@ -463,14 +463,14 @@ public:
         check(ptam_ba_add_meas(h_, nCam, nPoint, v2Pos.data(), dSigmaSquared), "ptam_ba_add_meas");
     }
     // :114 ; returns mnAccepted (>= 0).  The reference's own -1 is dead code (Do_LM_Step returns true unconditionally,
-    // src/Bundle.cc:550), so a negative value only leaves this shim for inputs the device path refuses: a point measured by
-    // more than 256 cameras (PTAM_E_LIMIT) or a duplicated (camera, point) measurement (PTAM_E_ARG).  MapMaker treats a
+    // src/Bundle.cc:550), so a negative value only leaves this shim for the one input the device path refuses: a duplicated
+    // (camera, point) measurement (PTAM_E_ARG; the reference silently keeps the last one).  MapMaker treats a
     // negative return as "ditch the map" (src/MapMaker.cc:887-892) — harsh, but it keeps its thread alive, where an
     // exception thrown out of Compute() would not.  HIP / communicator failures still throw.
     int Compute(bool* pbAbortSignal) {
         int acc = 0;
         const int rc = ptam_ba_compute(h_, reinterpret_cast<const volatile unsigned char*>(pbAbortSignal), &acc);
-        if (rc == PTAM_E_LIMIT || rc == PTAM_E_ARG) return -1;
+        if (rc == PTAM_E_ARG) return -1;
         check(rc, "ptam_ba_compute");
         return acc;
     }

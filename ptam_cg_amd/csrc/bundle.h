@@ -79,6 +79,7 @@ struct BaDev {
     int n, npad;            // camera system order 6F and its padding to SOLVE_NB
     int band;               // block bandwidth of S (in SOLVE_NB blocks): |block(row) - block(col)| <= band wherever two cameras share a point
     int n_chunks, grid_acc; // measurement chunks; persistent grid of the accumulate kernel
+    int u_rows;             // rows of Upart the accumulate kernel leaves: grid_acc (one per workgroup), or 1 (many cameras: every wave adds to one row)
     int n_wchunks;          // wave chunks (<= 64 measurements, whole points); 0 = block variant only
     int n_tiles, n_pairs, n_schur_wg, n_schur_entries;
     // cameras
@@ -127,6 +128,7 @@ struct BaDev {
     double* Dg;
     double* y;              // forward-substituted rhs
     double* da;             // [npad] camera update
+    double* bw_scratch;     // [2][6 npad] the backward substitution's vectors when they do not fit LDS (solve.hip)
     double* sumsq2;         // [2] |da|^2 in two parts (the two workgroups of the backward substitution; consumers add them)
     // outliers
     int* outliers;          // [M] original indices, in purge order

@@ -65,6 +65,7 @@ struct ptam_ba {
     int cur = 0;
     size_t smem_acc = 0;
     bool use_wave = false;
+    bool k7_big = false;     // camera partials + poses of K7 in global memory (more cameras than a workgroup's LDS holds)
     int per_wave = 1, extra_waves = 0;
     // host-mapped mailbox the device publishes BaScalars into (the LM loop's one host decision per trial)
     struct Mailbox {
@@ -153,7 +154,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     int F = 0;
     for (int c = 0; c < C; c++)
         if (!ba->cam_fixed[c]) cam_free[c] = F++;
-    // live measurements sorted point-major (point, camera); ties keep insertion order
+    // live measurements sorted point-major (point, then free cameras by free index, then fixed cameras); ties keep insertion order
     std::vector<int> dense_of;   // original point id -> device point id (-1: no live measurement)
     // (a counting sort over the points, then each point's short run by camera: a comparison sort of the whole list was 1.8 ms
     //  of a 10 ms prepare at 250 000 measurements)
@@ -171,16 +172,21 @@ static int ba_prepare_impl(ptam_ba* ba) {
         std::vector<int> fill(start.begin(), start.end() - 1);
         for (int i = 0; i < Mall; i++)
             if (!ba->m_dead[i]) order[(size_t)fill[ba->m_pt[i]]++] = i;   // insertion order inside a point: stable
+        // inside a point: the free cameras first, by free index, then the fixed ones.  (The Schur work lists address a
+        // tile's cameras by their offset from the tile's first measurement of the point: with the fixed cameras out of
+        // the way an offset is at most 7 — in camera-id order, 255 or more fixed keyframes between two free ones of a
+        // tile overflowed the 8-bit offsets, and a local adjustment has many fixed keyframes.)
+        auto key = [&](int i) { const int c = ba->m_cam[i], f = cam_free[c]; return f >= 0 ? f : F + c; };
         for (int p = 0; p < P_all; p++) {
             int* b0 = order.data() + start[p];
             int* b1 = order.data() + start[p + 1];
             bool sorted = true;
             for (int* q = b0; q + 1 < b1; q++)
-                if (ba->m_cam[q[0]] > ba->m_cam[q[1]]) {
+                if (key(q[0]) > key(q[1])) {
                     sorted = false;
                     break;
                 }
-            if (!sorted) std::stable_sort(b0, b1, [&](int x, int y) { return ba->m_cam[x] < ba->m_cam[y]; });
+            if (!sorted) std::stable_sort(b0, b1, [&](int x, int y) { return key(x) < key(y); });
         }
         // The device sees only the points that HAVE a live measurement, numbered densely in their original order: the kernels
         // walk the point-major list 64 measurements at a time and fetch "the chunk's points" as one run of consecutive ids,
@@ -205,14 +211,10 @@ static int ba_prepare_impl(ptam_ba* ba) {
     ba->sorted_orig = order;
     std::vector<int> rowptr(P + 1, 0);
     for (int i = 0; i < M; i++) rowptr[dense_of[(size_t)ba->m_pt[order[i]]] + 1]++;
-    for (int p = 0; p < P; p++) {
-        if (rowptr[p + 1] > BA_CHUNK) {
-            ptam_set_error("point %d has %d measurements; the limit is %d cameras per point", p, rowptr[p + 1], BA_CHUNK);
-            return PTAM_E_LIMIT;
-        }
-        rowptr[p + 1] += rowptr[p];
-    }
-    // chunks: consecutive whole points, at most BA_CHUNK measurements
+    for (int p = 0; p < P; p++) rowptr[p + 1] += rowptr[p];
+    // chunks: consecutive whole points, at most BA_CHUNK measurements — or ONE point with more than that (a point seen by
+    // more than 256 keyframes: the kernels that own whole points walk such a chunk BA_CHUNK measurements at a time;
+    // src/Bundle.cc:75-93 puts no bound on the measurements of a point)
     std::vector<BaChunk> chunks;
     {
         int p = 0;
@@ -226,6 +228,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
                 p++;
                 np++;
             }
+            if (np == 0) p++;   // a long point, alone in its chunk
             ch.pt_end = p;
             ch.m_end = rowptr[p];
             chunks.push_back(ch);
@@ -233,11 +236,10 @@ static int ba_prepare_impl(ptam_ba* ba) {
     }
     // K7's wave variant walks the point-major list 64 measurements at a time whatever the points' lengths: a point cut by a
     // chunk edge — or covering whole chunks, when more than 64 cameras measure it — leaves one piece per chunk, which K8a adds in
-    // chunk order.  (Until round 2c the variant was only taken when no point had more than 64 measurements, and a 100-camera
-    // dense problem ran the block variant: 38.8 instead of ~10 us per K7 launch.)  PTAM_K7_BLOCK=1 forces the block variant.
-    std::vector<BaChunk> wchunks;   // (one dummy entry marks the variant; the kernel does not read it)
-    static const bool force_block = getenv("PTAM_K7_BLOCK") != nullptr;
-    if (M > 0 && !force_block) wchunks.push_back(BaChunk{0, P, 0, M});
+    // chunk order.  (Rounds 1-2 also had a block variant whose workgroups owned whole points: 38.8 instead of ~10 us per launch
+    // at 100 dense cameras, removed in round 3.)
+    std::vector<BaChunk> wchunks;   // (one dummy entry; the kernel does not read it)
+    if (M > 0) wchunks.push_back(BaChunk{0, P, 0, M});
     lap("rowptr + chunks");
     // Schur work lists
     const int n_tiles = (F + SCHUR_TC - 1) / SCHUR_TC;
@@ -265,11 +267,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
                     t_off[t] = {0xffffffffu, 0xffffffffu};
                     last_tile = t;
                 }
-                const int off = i - t_first[t], slot = f - t * SCHUR_TC;
-                if (off >= 255) {
-                    ptam_set_error("point %d: more than 254 measurements by fixed cameras inside one camera tile", p);
-                    return PTAM_E_LIMIT;
-                }
+                const int off = i - t_first[t], slot = f - t * SCHUR_TC;   // (off <= 7: the point's free cameras are consecutive)
                 t_off[t][slot >> 2] &= ~(0xffu << (8 * (slot & 3)));
                 t_off[t][slot >> 2] |= (unsigned)off << (8 * (slot & 3));
             }
@@ -453,16 +451,18 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.npad = ((d.n + SOLVE_NB - 1) / SOLVE_NB) * SOLVE_NB;
     d.n_chunks = (int)chunks.size();
     d.n_wchunks = (int)wchunks.size();
-    ba->use_wave = !wchunks.empty();
+    ba->use_wave = !wchunks.empty();   // (false: no live measurement at all — K7 is then a memset of its outputs)
     d.n_tiles = n_tiles;
     d.n_pairs = n_pairs;
     d.n_schur_wg = (int)s_wg_seg.size() - 1;
     d.n_schur_entries = (int)s_entries.size();
     // persistent grid of the accumulate kernel: bounded by LDS residency, 2 x 256 CUs by default
     // (wave variant: + one 3 KB W transposition buffer per wave, K7_WT_DOUBLES)
-    auto k7_smem = [&](int threads) {   // (follows ba->use_wave: the choice below may fall back to the block variant)
-        const size_t base = ((((size_t)F * 27 + 1) & ~(size_t)1) + (ba->use_wave ? (size_t)C * 12 + 2 : (size_t)BA_CHUNK * 8)) * sizeof(double);
-        return base + (ba->use_wave ? (size_t)(threads / 64) * K7_WT_DOUBLES * sizeof(double) : 0);
+    ba->k7_big = false;
+    auto k7_smem = [&](int threads) {
+        const size_t wt = (size_t)(threads / 64) * K7_WT_DOUBLES * sizeof(double);
+        if (ba->k7_big) return wt;   // (camera partials and poses in global memory)
+        return ((((size_t)F * 27 + 1) & ~(size_t)1) + (size_t)C * 12 + 2) * sizeof(double) + wt;
     };
     // wave variant, two shapes:
     //  - few chunks (every 64-measurement chunk can be resident at once: <= 24 waves per CU):
@@ -472,7 +472,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     const int n64_all = (M + 63) / 64;
     ba->k7_loop = ba->use_wave && n64_all > 256 * 24;
     if (const char* e = getenv("PTAM_K7_LOOP")) ba->k7_loop = ba->use_wave && atoi(e) != 0;   // shape sweeps (tools/k7_only.py)
-    ba->k7_threads = !ba->use_wave ? BA_CHUNK : (ba->k7_loop ? 256 : 1024);   // (one chunk per wave: 1024-thread workgroups halve the
+    ba->k7_threads = ba->k7_loop ? 256 : 1024;   // (one chunk per wave: 1024-thread workgroups halve the
                                                                                  //  camera-partial flush — 12.0 vs 12.3 us at 50 x 5000)
     int n_cu = 256;
     {
@@ -480,9 +480,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
         HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
         n_cu = prop.multiProcessorCount;
     }
-    auto k7_fn = [&](int threads) -> const void* {
-        return !ba->use_wave ? (const void*)jac_accum_kernel : k7_wave_fn(threads, ba->k7_loop, ba->opts.estimator);
-    };
+    auto k7_fn = [&](int threads) -> const void* { return k7_wave_fn(threads, ba->k7_loop, ba->opts.estimator, ba->k7_big); };
     auto k7_occupancy = [&](int threads, int* per_cu) -> int {
         const void* k7 = k7_fn(threads);
         if (k7_smem(threads) > 64 * 1024) {
@@ -494,32 +492,27 @@ static int ba_prepare_impl(ptam_ba* ba) {
     int per_cu = 0;
     {
         // the workgroup's LDS — camera partials F * 216 B + poses C * 96 B + 3 KB per wave — must fit the CU's 160 KB: many
-        // cameras take narrower workgroups (fewer transposition buffers), then the block variant (no pose staging), and
-        // beyond ~600 free cameras nothing fits
+        // cameras take narrower workgroups (fewer transposition buffers), and beyond ~600 free cameras the BIG form, whose
+        // partials and poses stay in global memory (ba_jacobian.inc)
         const size_t lds_max = 160 * 1024;
-        if (ba->use_wave && k7_smem(ba->k7_threads) > lds_max) {
+        if (k7_smem(ba->k7_threads) > lds_max) {
             for (int t : {512, 256})
                 if (k7_smem(t) <= lds_max) {
                     ba->k7_threads = t;
                     break;
                 }
             if (k7_smem(ba->k7_threads) > lds_max) {
-                ba->use_wave = false;
-                ba->k7_loop = false;
-                ba->k7_threads = BA_CHUNK;
+                ba->k7_big = true;
+                ba->k7_loop = true;
+                ba->k7_threads = 256;
             }
-        }
-        if (k7_smem(ba->k7_threads) > lds_max) {
-            ptam_set_error("%d free cameras (%d in all): the accumulation kernel's camera partials (%zu KB) do not fit a CU's 160 KB of LDS",
-                           F, C, k7_smem(ba->k7_threads) / 1024);
-            return PTAM_E_LIMIT;
         }
     }
     if (int rc = k7_occupancy(ba->k7_threads, &per_cu)) {
         ptam_set_error("the accumulation kernel cannot be launched with %zu bytes of LDS (%d free cameras)", k7_smem(ba->k7_threads), F);
         return rc;
     }
-    if (ba->k7_loop) {
+    if (ba->k7_loop && !ba->k7_big) {
         // many cameras: the LDS partials (F*27 + C*12 doubles per workgroup) bound the workgroups per CU,
         // so a wider workgroup keeps more waves resident (200 cameras: 62 KB + 3 KB per wave -> ONE workgroup per CU
         // whatever its width, and only the 1024-thread one fills the four waves per SIMD the loop needs)
@@ -533,7 +526,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
         }
     }
     per_cu = std::max(1, std::min(per_cu, 8));
-    if (ba->use_wave && ba->k7_loop) {
+    if (ba->use_wave && ba->k7_loop && !ba->k7_big) {
         if (const char* e = getenv("PTAM_K7_THREADS")) {
             const int t = atoi(e);
             if (t == 256 || t == 512 || t == 1024) {
@@ -572,7 +565,8 @@ static int ba_prepare_impl(ptam_ba* ba) {
             d.grid_acc = std::max(1, (n64 + wpb - 1) / wpb);
         }
     } else
-        d.grid_acc = std::max(1, std::min(d.n_chunks, n_cu * per_cu));
+        d.grid_acc = 1;
+    d.u_rows = (ba->k7_big || !ba->use_wave) ? 1 : d.grid_acc;
 
     lap("launch shape");
     // ---- carve one device allocation ------------------------------------------------------------
@@ -599,7 +593,8 @@ static int ba_prepare_impl(ptam_ba* ba) {
     // bandwidth in force (the widest over all ranks) in Compute()'s first exchange
     const size_t se_full = se_size((int)(npad / SOLVE_NB), (int)(npad / SOLVE_NB) - 1);
     const size_t o_SE = cv.take((se_full + npad + 8) * 8), o_L = cv.take(se_full * 8), o_Dg = cv.take(npad * 8),
-                 o_y = cv.take(npad * 8), o_da = cv.take(npad * 8), o_sq2 = cv.take(16);
+                 o_y = cv.take(npad * 8), o_da = cv.take(npad * 8), o_sq2 = cv.take(16),
+                 o_bws = cv.take(npad * 8 * 12);
     const size_t o_out = cv.take(Mz * 4), o_sc = cv.take(sizeof(BaScalars)), o_dbg = cv.take(65536);
     ba->block_bytes = cv.off;
     if (!ctx_cache_take(ctx->dev_cache, ba->block_bytes, &ba->block, &ba->block_cap)) {   // (a released bundle's block, if it fits)
@@ -648,6 +643,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.y = (double*)(base + o_y);
     d.da = (double*)(base + o_da);
     d.sumsq2 = (double*)(base + o_sq2);
+    d.bw_scratch = (double*)(base + o_bws);
     d.outliers = (int*)(base + o_out);
     d.sc = (BaScalars*)(base + o_sc);
     d.dbg = (long long*)(base + o_dbg);
@@ -873,14 +869,17 @@ static void launch_k7(ptam_ba* ba, int guard = 0) {
     BaDev d = ba->d;
     d.guard = guard;
     int cur = guard ? (ba->cur ^ 1) : ba->cur;   // a guarded launch belongs to the next step: the trial state is current there
-    if (ba->use_wave) {
-        int est = ba->opts.estimator;
-        void* args[] = {&ctx->cam, &d, &cur, &est, &ba->per_wave, &ba->extra_waves};
-        (void)hipLaunchKernel(k7_wave_fn(ba->k7_threads, ba->k7_loop, est), dim3(d.grid_acc), dim3(ba->k7_threads), args,
-                              ba->smem_acc, ctx->stream);
-    } else
-        hipLaunchKernelGGL(jac_accum_kernel, dim3(d.grid_acc), dim3(BA_CHUNK), ba->smem_acc, ctx->stream, ctx->cam, d, cur,
-                           ba->opts.estimator);
+    if (ba->k7_big || !ba->use_wave)   // the one row of camera partials every wave adds to (or, without measurements, all there is)
+        (void)hipMemsetAsync(d.Upart, 0, std::max<size_t>(1, (size_t)d.F * 27) * sizeof(double), ctx->stream);
+    if (!ba->use_wave) {   // no live measurement: zero error, zero bad count
+        (void)hipMemsetAsync(d.err_part, 0, 16, ctx->stream);
+        (void)hipMemsetAsync(d.bad_part, 0, 4, ctx->stream);
+        return;
+    }
+    int est = ba->opts.estimator;
+    void* args[] = {&ctx->cam, &d, &cur, &est, &ba->per_wave, &ba->extra_waves};
+    (void)hipLaunchKernel(k7_wave_fn(ba->k7_threads, ba->k7_loop, est, ba->k7_big), dim3(d.grid_acc), dim3(ba->k7_threads), args, ba->smem_acc,
+                          ctx->stream);
 }
 
 static int ba_pass2(ptam_ba* ba) {
@@ -1721,7 +1720,7 @@ void ba_preload_kernels() {
     ptam_preload((const void*)select_stage_kernel);
     ptam_preload((const void*)select_finish_kernel);
     ptam_preload((const void*)compact_valid_kernel);
-    ptam_preload((const void*)jac_accum_kernel);
+    ptam_preload(k7_wave_fn(256, true, -1, true));
     ptam_preload((const void*)reduce_partials_kernel);
     ptam_preload((const void*)vinv_kernel);
     ptam_preload((const void*)reduce_vinv_kernel);

@@ -29,6 +29,7 @@
 #define CPT (NB / STRIPS)         // columns per thread
 #define TPB (NB * STRIPS)         // 256 threads (512 = two waves per SIMD measured slower: the barrier grows, the chain does not shrink)
 #define NITER (NB / 4)
+#define BW_LDS_MAX ((size_t)150 * 1024)   // dynamic LDS the backward substitution may take for its six vectors
 static_assert(NB == 32, "the strip decomposition below is written for 32x32 blocks");
 
 // reciprocal of a pivot: v_rcp_f64 (2^-24.4 relative, tools/pipes/rcpacc) and ONE cubic step y (1 + e + e^2), e = 1 - d y —
@@ -139,12 +140,15 @@ __global__ void __launch_bounds__(TPB) ldlt_step_twin_kernel(BaDev d, int k_top,
 // substitutes the middle and the downward chain's blocks, workgroup 1 the middle AGAIN (2 * band blocks, bit-identical) and
 // then the upward chain's blocks — 22 sequential block steps each instead of 38 in a row at 200 keyframes / window 16.
 // Each writes its part of da, the trial poses of the cameras whose rows it knows, and its part of |da|^2 (d.sumsq2).
+template <bool BIG>
 __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur, int b_start) {
     TL_MARK(d, 10)
     const int chain = blockIdx.x;   // 0: middle + downward chain (or everything, one-ended); 1: middle + upward chain
     extern __shared__ __attribute__((aligned(16))) double bw_lds[];
     const int npad = d.npad, nblk = npad / NB, band = se_band(d);
-    double* xs = bw_lds;         // npad: the solution
+    // (systems of more than ~560 cameras: the six vectors do not fit LDS and live in global memory — one workgroup reads
+    //  what it wrote itself, behind its own barriers)
+    double* xs = BIG ? d.bw_scratch + (size_t)chain * 6 * npad : bw_lds;   // npad: the solution
     double* pend = xs + npad;    // 4 x npad: sum_{blocks below} L^T x, one plane per row slice (summed in fixed order by the
                                  // reader: every rank of a sharded bundle must arrive at bit-identical poses — LDS atomics did not)
     double* wv = pend + 4 * npad;    // npad: D^-1 z
@@ -263,7 +267,7 @@ __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur, i
 }
 
 int ba_solve_init() {
-    HIP_TRY(hipFuncSetAttribute((const void*)ldlt_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)ldlt_backward_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(hipFuncSetAttribute((const void*)ldlt_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return PTAM_OK;
 }
@@ -297,7 +301,10 @@ int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
         hipLaunchKernelGGL(ldlt_step_kernel, dim3(nwg), dim3(TPB), 0, ctx->stream, d, k, b_start);
     }
     const size_t bw_bytes = (size_t)6 * d.npad * sizeof(double);
-    hipLaunchKernelGGL(ldlt_backward_kernel, dim3(t_end > 0 ? 2 : 1), dim3(1024), bw_bytes, ctx->stream, d, cur, b_start);
+    if (bw_bytes > BW_LDS_MAX)   // (the vectors in d.bw_scratch instead)
+        hipLaunchKernelGGL(ldlt_backward_kernel<true>, dim3(t_end > 0 ? 2 : 1), dim3(1024), 0, ctx->stream, d, cur, b_start);
+    else
+        hipLaunchKernelGGL(ldlt_backward_kernel<false>, dim3(t_end > 0 ? 2 : 1), dim3(1024), bw_bytes, ctx->stream, d, cur, b_start);
     HIP_TRY(hipGetLastError());
     return PTAM_OK;
 }
@@ -307,6 +314,7 @@ int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
 void solve_preload_kernels() {
     ptam_preload((const void*)ldlt_step_kernel);
     ptam_preload((const void*)ldlt_step_twin_kernel);
-    ptam_preload((const void*)ldlt_backward_kernel);
+    ptam_preload((const void*)ldlt_backward_kernel<false>);
+    ptam_preload((const void*)ldlt_backward_kernel<true>);
     ptam_preload((const void*)ldlt_small_kernel);
 }

@@ -21,7 +21,7 @@ def free_port():
     return p
 
 
-def run_sharded(which, world, case, timeout=300, extra_env=None, opts=None, drop=None, abort=None):
+def run_sharded(which, world, case, timeout=300, extra_env=None, opts=None, drop=None, abort=None, dup=None):
     """launch `world` worker processes (gloo on 127.0.0.1); returns rank 0's result dict"""
     out = tempfile.mktemp(suffix=".pkl")
     port = str(free_port())
@@ -35,6 +35,8 @@ def run_sharded(which, world, case, timeout=300, extra_env=None, opts=None, drop
             env["PTAM_DIST_DROP"] = repr(drop)
         if abort is not None:
             env["PTAM_DIST_ABORT"] = repr(abort)
+        if dup is not None:
+            env["PTAM_DIST_DUP"] = repr(dup)
         env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), which, out],
                                       env=env, cwd=ROOT))

@@ -27,6 +27,7 @@ def main():
     kw = eval(os.environ.get("PTAM_DIST_CASE", "dict(n_cams=10, n_pts=160, seed=5)"))
     opts = eval(os.environ.get("PTAM_DIST_OPTS", "dict()"))                   # host.Bundle options (max_iterations ...)
     drop = eval(os.environ.get("PTAM_DIST_DROP", "None"))                      # (point modulus, residue, first camera dropped)
+    dup = eval(os.environ.get("PTAM_DIST_DUP", "None"))                        # global point id whose first measurement is added twice
     abort_at = eval(os.environ.get("PTAM_DIST_ABORT", "None"))                 # (rank, all-reduce calls before the flag goes up)
     prob = synth.make_ba_problem(**kw)
     if drop is not None:     # thin out some points' measurements: lets ONE shard break a per-point limit
@@ -34,6 +35,10 @@ def main():
         keep = ~((prob["pt_idx"] % mod == res) & (prob["cam_idx"] >= cam0))
         for k in ("cam_idx", "pt_idx", "found", "sigma_sq"):
             prob[k] = prob[k][keep]
+    if dup is not None:      # a duplicated (camera, point) measurement: the one input a shard's prepare refuses (PTAM_E_ARG)
+        i = int(np.nonzero(prob["pt_idx"] == dup)[0][0])
+        for k in ("cam_idx", "pt_idx", "found", "sigma_sq"):
+            prob[k] = np.concatenate([prob[k], prob[k][i:i + 1]])
     mine = shard_problem(prob, rank, world)
     ctx = host.Context(lib=lib)
     ba = synth.load_into(host.Bundle(ctx, **opts), mine)

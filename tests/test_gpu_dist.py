@@ -44,11 +44,20 @@ def test_abort_raised_on_one_rank_stops_every_rank_at_the_same_trial():
 
 
 def test_prepare_error_on_one_rank_is_returned_by_every_rank():
-    """rank 0's shard holds points seen by 300 cameras (the limit is 256 per point), rank 1's shard is fine.
-    Rank 1 must not enter the first all-reduce alone: both return an error, rank 0 its own, rank 1 the collective one"""
-    res = dist_util.run_sharded("hip", 2, dict(n_cams=300, n_pts=6, seed=3), drop=(2, 1, 250), timeout=180)
+    """rank 0's shard holds a duplicated (camera, point) measurement — the one input a shard's prepare refuses —,
+    rank 1's shard is fine.  Rank 1 must not enter the first all-reduce alone: both return an error, rank 0 its own, rank 1
+    the collective one.  (Until round 3 this test used a point seen by 300 cameras, which is no longer refused.)"""
+    res = dist_util.run_sharded("hip", 2, dict(n_cams=10, n_pts=160, seed=5), dup=4, timeout=180)
     assert "error" in res and len(res["error"]) == 2
-    assert "limit" in res["error"][0] and "could not prepare" in res["error"][1]
+    assert "duplicate" in res["error"][0] and "could not prepare" in res["error"][1]
+
+
+def test_sharded_long_points_and_many_fixed_cameras(oracle):
+    """every point seen by 300 cameras, 290 of them fixed, sharded over two processes: the long-point chunks and the
+    free-cameras-first row order on the sharded path"""
+    case = dict(n_cams=300, n_pts=24, seed=34, n_fixed=290)
+    res = dist_util.run_sharded("hip", 2, case, opts=dict(max_iterations=3))
+    dist_util.check_sharded_equals_single(res, oracle, case, rel=1e-6, max_iterations=3)
 
 
 def test_sharded_select_with_ties_and_slot_overflow(oracle):

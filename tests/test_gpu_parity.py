@@ -313,6 +313,31 @@ def test_bundle_trial_by_trial(hip, oracle, case):
         assert rh["trials"]["err_new"][-1] < rh["trials"]["err_old"][0]
 
 
+# src/Bundle.cc:46-93 bounds neither the cameras of a map nor the measurements of a point; until round 3 the device path
+# refused a point seen by more than 256 cameras, ~600 free cameras, and 255 fixed cameras between two free ones of a
+# Schur tile.  Each shape below crosses one of those former limits (VERDICT r2 missing 2).
+BA_UNBOUNDED_CASES = {
+    # every point is measured by 300 cameras: chunks of ONE point walked 256 measurements at a time (pass 1, the point update)
+    "long_points_300x40": (dict(n_cams=300, n_pts=40, seed=31), 3),
+    # 300 FIXED cameras in front of 9 free ones, every point seen by all 309: the Schur work lists address a tile's cameras by
+    # 8-bit offsets inside the point's row, which only works because the free cameras' measurements come first
+    "many_fixed_309x60": (dict(n_cams=309, n_pts=60, seed=32, n_fixed=300), 4),
+    # 639 free cameras: K7's camera partials (138 KB) + poses (61 KB) exceed a workgroup's LDS -> partials and poses in
+    # global memory; the backward substitution's vectors (6 x 3840 doubles) exceed it too
+    "many_cameras_640x1500_w6": (dict(n_cams=640, n_pts=1500, seed=33, window=6), 1),   # (one trial: the oracle factors 3834 x 3834 densely, ~40 s)
+}
+
+
+@pytest.mark.parametrize("case", list(BA_UNBOUNDED_CASES))
+def test_bundle_sizes_the_reference_does_not_bound(hip, oracle, case):
+    kw, k = BA_UNBOUNDED_CASES[case]
+    prob = synth.make_ba_problem(**kw)
+    rh = util.run_ba(hip, prob, max_iterations=k)
+    ro = util.run_ba(oracle, prob, max_iterations=k)
+    util.assert_ba_equal(rh, ro, rel=1e-6)
+    assert 1 <= len(rh["trials"]) <= k and rh["accepted"] > 0
+
+
 def _fuzz_cases(n=18, seed=2024):
     rng = np.random.default_rng(seed)
     out = []

@@ -85,6 +85,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d.da, npad * 8));
     CK(hipMalloc(&d.sumsq2, 16));
     CK(hipMalloc(&d.cam_free, 16));
+    CK(hipMalloc(&d.bw_scratch, (size_t)12 * npad * 8));
     CK(hipMalloc(&dbg, 65536 * 8));
     CK(hipMemset(dbg, 0, 65536 * 8));
     d.dbg = (long long*)dbg;
