@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tracking", action="store_true")
     ap.add_argument("--no-replicas", action="store_true", help="tracking: one context only (no k-thread replica runs; used under rocprofv3)")
+    ap.add_argument("--deterministic", action="store_true", help="ptam_ba_opts.deterministic = 1 (camera sums in a fixed order): what the mode costs")
     ap.add_argument("--jac-reps", type=int, default=200)
     return ap.parse_args()
 
@@ -388,7 +389,8 @@ def main():
     prepare_ms = []   # host + upload time of every ptam_ba_prepare of this run (never part of `value`)
 
     def new_bundle(max_it, problem=None, sharded=True):
-        ba = synth.load_into(host.Bundle(ctx, max_iterations=max_it, update_sq_conv_limit=0.0), prob if problem is None else problem)
+        ba = synth.load_into(host.Bundle(ctx, max_iterations=max_it, update_sq_conv_limit=0.0, deterministic=1 if args.deterministic else 0),
+                             prob if problem is None else problem)
         if comm is not None and sharded:
             ba.set_comm(rank, world, hook, comm)
         t0 = time.perf_counter()
@@ -506,6 +508,7 @@ def main():
             "accepted_trials": int(trials["accepted"].sum()),
             "spinup_k7_us_first_last_blocks": [spin[0] * 1e3, spin[-1] * 1e3, len(spin)],
             "err_first_last": [float(trials["err_old"][0]), float(trials["err_new"][-1])],
+            "deterministic": bool(args.deterministic),
             "prepare_ms": prepare_headline_ms,   # sort + work lists + upload of one Bundle of this workload: outside the timed region
         }
     if world > 1:

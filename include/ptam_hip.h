@@ -431,6 +431,11 @@ typedef struct {
     double min_sigma;                /* Bundle.MinTukeySigma = 0.4          src/Bundle.cc:234 */
     int32_t estimator;               /* Bundle.MEstimator = Tukey           src/Bundle.cc:132 */
     int32_t verbose;                 /* Bundle.Cout                         src/Bundle.cc:42 */
+    int32_t deterministic;           /* not in the reference: 1 = camera sums of pass 2 (src/Bundle.cc:315-321) in a fixed order —
+                                        the accumulation kernel stores each measurement's weighted A (2x6) and epsilon, a
+                                        camera-major pass adds them up; two runs of the same problem are then bit-identical.
+                                        0 (default): LDS atomics, whose order differs from run to run in the last bits */
+    int32_t pad_;
 } ptam_ba_opts;
 void ptam_ba_opts_default(ptam_ba_opts* o);
 

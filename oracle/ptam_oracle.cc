@@ -1819,6 +1819,8 @@ void ptamo_ba_opts_default(ptam_ba_opts* o) {
     o->min_sigma = 0.4;
     o->estimator = PTAM_EST_TUKEY;
     o->verbose = 0;
+    o->deterministic = 0;   // (the CPU loops are sequential: nothing to choose)
+    o->pad_ = 0;
 }
 int ptamo_ba_create(ptamo_ctx* c, const ptam_ba_opts* opts, ptamo_ba** out) {
     ptam_ba_opts o;

@@ -86,7 +86,8 @@ class PoseUpdateMeas(C.Structure):
 
 class BaOpts(C.Structure):
     _fields_ = [("max_iterations", C.c_int32), ("update_sq_conv_limit", C.c_double),
-                ("min_sigma", C.c_double), ("estimator", C.c_int32), ("verbose", C.c_int32)]
+                ("min_sigma", C.c_double), ("estimator", C.c_int32), ("verbose", C.c_int32),
+                ("deterministic", C.c_int32), ("pad_", C.c_int32)]
 
 
 class BaTrial(C.Structure):

@@ -109,6 +109,11 @@ struct BaDev {
     double* Usplit;         // [16][F*27] : per camera 21 lower-triangle U sums + 6 epsA sums, in 16
                             // fixed-order row splits of the accumulate grid (consumers add the 16)
     double* Upart;          // [grid_acc][F*27]
+    // deterministic mode (ptam_ba_opts.deterministic): K7 stores per measurement its weighted camera Jacobian and residual,
+    // a camera-major pass (reduce_det_kernel) adds each camera's U and epsA in a fixed order into Upart row 0
+    double* Adet;           // [14][M]: planes A0[0..5], A1[0..5], ex, ey (zeros for fixed cameras / rejected measurements); null otherwise
+    int* cam_ptr;           // [tiles][F+1] per tile of DET_TILE consecutive measurements: where each free camera's entries of cam_meas begin
+    int* cam_meas;          // [measurements by free cameras] measurement ids sorted by (tile, camera, id)
     double* err_part;       // [max(n_chunks, grid_acc)][2]
     int* bad_part;          // [grid_acc]
     BaChunk* chunks;

@@ -65,6 +65,7 @@ struct ptam_ba {
     int cur = 0;
     size_t smem_acc = 0;
     bool use_wave = false;
+    bool det = false;        // ptam_ba_opts.deterministic: K7 stores A / epsilon per measurement, reduce_det_kernel sums per camera
     bool k7_big = false;     // camera partials + poses of K7 in global memory (more cameras than a workgroup's LDS holds)
     int per_wave = 1, extra_waves = 0;
     // host-mapped mailbox the device publishes BaScalars into (the LM loop's one host decision per trial)
@@ -459,9 +460,11 @@ static int ba_prepare_impl(ptam_ba* ba) {
     // persistent grid of the accumulate kernel: bounded by LDS residency, 2 x 256 CUs by default
     // (wave variant: + one 3 KB W transposition buffer per wave, K7_WT_DOUBLES)
     ba->k7_big = false;
+    ba->det = ba->opts.deterministic != 0 && M > 0;
     auto k7_smem = [&](int threads) {
         const size_t wt = (size_t)(threads / 64) * K7_WT_DOUBLES * sizeof(double);
         if (ba->k7_big) return wt;   // (camera partials and poses in global memory)
+        if (ba->det) return ((size_t)C * 12 + 2) * sizeof(double) + wt;   // (no camera partials at all)
         return ((((size_t)F * 27 + 1) & ~(size_t)1) + (size_t)C * 12 + 2) * sizeof(double) + wt;
     };
     // wave variant, two shapes:
@@ -480,7 +483,8 @@ static int ba_prepare_impl(ptam_ba* ba) {
         HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
         n_cu = prop.multiProcessorCount;
     }
-    auto k7_fn = [&](int threads) -> const void* { return k7_wave_fn(threads, ba->k7_loop, ba->opts.estimator, ba->k7_big); };
+    auto k7_fn = [&](int threads) -> const void* { return k7_wave_fn(threads, ba->k7_loop, ba->opts.estimator, ba->k7_big, ba->det); };
+
     auto k7_occupancy = [&](int threads, int* per_cu) -> int {
         const void* k7 = k7_fn(threads);
         if (k7_smem(threads) > 64 * 1024) {
@@ -507,12 +511,13 @@ static int ba_prepare_impl(ptam_ba* ba) {
                 ba->k7_threads = 256;
             }
         }
+        if (ba->det && !ba->k7_big && ba->k7_threads == 512) ba->k7_threads = ba->k7_loop ? 256 : 1024;   // (the deterministic instantiations)
     }
     if (int rc = k7_occupancy(ba->k7_threads, &per_cu)) {
         ptam_set_error("the accumulation kernel cannot be launched with %zu bytes of LDS (%d free cameras)", k7_smem(ba->k7_threads), F);
         return rc;
     }
-    if (ba->k7_loop && !ba->k7_big) {
+    if (ba->k7_loop && !ba->k7_big && !ba->det) {
         // many cameras: the LDS partials (F*27 + C*12 doubles per workgroup) bound the workgroups per CU,
         // so a wider workgroup keeps more waves resident (200 cameras: 62 KB + 3 KB per wave -> ONE workgroup per CU
         // whatever its width, and only the 1024-thread one fills the four waves per SIMD the loop needs)
@@ -566,7 +571,13 @@ static int ba_prepare_impl(ptam_ba* ba) {
         }
     } else
         d.grid_acc = 1;
-    d.u_rows = (ba->k7_big || !ba->use_wave) ? 1 : d.grid_acc;
+    const int n_dtiles = (M + DET_TILE - 1) / DET_TILE;
+    if (ba->det) {
+        static const hipError_t det_attr = hipFuncSetAttribute((const void*)reduce_det_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                               (int)((size_t)14 * (DET_TILE + 1) * sizeof(double)));
+        HIP_TRY(det_attr);
+    }
+    d.u_rows = ba->det ? n_dtiles : (ba->k7_big || !ba->use_wave) ? 1 : d.grid_acc;
 
     lap("launch shape");
     // ---- carve one device allocation ------------------------------------------------------------
@@ -578,7 +589,8 @@ static int ba_prepare_impl(ptam_ba* ba) {
                  o_cut = cv.take(ba->use_wave ? (size_t)((M + 63) / 64) * 2 * 72 : 8);
     const size_t o_mcam = cv.take(Mz * 4), o_mpt = cv.take(Mz * 4), o_mfound = cv.take(Mz * 16), o_ms = cv.take(Mz * 8),
                  o_morig = cv.take(Mz * 4), o_mfidx = cv.take(Mz * 4), o_mstate = cv.take(Mz), o_me2 = cv.take(Mz * 8), o_me2t = cv.take(Mz * 8), o_zbad = cv.take(Mz), o_W = cv.take((Mz + 1) * 144);
-    const size_t o_U = cv.take(Fz * 27 * 8 * 16), o_Upart = cv.take((size_t)d.grid_acc * Fz * 27 * 8);
+    const size_t o_U = cv.take(Fz * 27 * 8 * 16), o_Upart = cv.take((size_t)std::max(d.grid_acc, ba->det ? n_dtiles : 1) * Fz * 27 * 8);
+    const size_t o_adet = cv.take(ba->det ? Mz * 14 * 8 : 8), o_camptr = cv.take(ba->det ? (size_t)n_dtiles * (Fz + 1) * 4 : 8), o_cammeas = cv.take(ba->det ? Mz * 4 : 8);
     const size_t n_part = std::max(d.n_chunks, d.grid_acc);
     const size_t o_errp = cv.take(n_part * 16 + 16), o_badp = cv.take((size_t)d.grid_acc * 4 + 16);
     const size_t o_chunks = cv.take(std::max<size_t>(1, chunks.size()) * sizeof(BaChunk));
@@ -626,6 +638,9 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.W = (double*)(base + o_W);   // (slot M of every plane stays zero: the block is cleared below and nobody writes it)
     d.Usplit = (double*)(base + o_U);
     d.Upart = (double*)(base + o_Upart);
+    d.Adet = ba->det ? (double*)(base + o_adet) : nullptr;
+    d.cam_ptr = (int*)(base + o_camptr);
+    d.cam_meas = (int*)(base + o_cammeas);
     d.err_part = (double*)(base + o_errp);
     d.bad_part = (int*)(base + o_badp);
     d.chunks = (BaChunk*)(base + o_chunks);
@@ -692,6 +707,30 @@ static int ba_prepare_impl(ptam_ba* ba) {
     }
 #define UP(dst, src, bytes)                                                                        \
     if ((bytes) > 0) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream))
+    std::vector<int> cam_ptr, cam_meas;   // (outlive the asynchronous uploads below: the function waits for the queue at its end)
+    if (ba->det) {
+        // per tile of DET_TILE consecutive measurements: the measurements by free cameras, camera-major (counting sort:
+        // ascending measurement id inside a camera); cam_ptr rows index cam_meas globally
+        cam_ptr.assign((size_t)n_dtiles * (F + 1), 0);
+        cam_meas.reserve((size_t)M);
+        std::vector<int> cnt((size_t)F + 1);
+        for (int t = 0; t < n_dtiles; t++) {
+            const int m0 = t * DET_TILE, m1 = std::min(M, m0 + DET_TILE);
+            std::fill(cnt.begin(), cnt.end(), 0);
+            for (int i = m0; i < m1; i++)
+                if (h_fidx[i] >= 0) cnt[(size_t)h_fidx[i] + 1]++;
+            int* row = cam_ptr.data() + (size_t)t * (F + 1);
+            row[0] = (int)cam_meas.size();
+            for (int f = 0; f < F; f++) row[f + 1] = row[f] + cnt[(size_t)f + 1];
+            cam_meas.resize((size_t)row[F]);
+            std::vector<int> fill(row, row + F);
+            for (int i = m0; i < m1; i++)
+                if (h_fidx[i] >= 0) cam_meas[(size_t)fill[(size_t)h_fidx[i]]++] = i;
+        }
+        if (cam_meas.empty()) cam_meas.push_back(0);
+        UP(d.cam_ptr, cam_ptr.data(), cam_ptr.size() * 4);
+        UP(d.cam_meas, cam_meas.data(), cam_meas.size() * 4);
+    }
     UP(d.pose[0], ba->cam_pose.data(), (size_t)C * 96);
     UP(d.cam_free, cam_free.data(), (size_t)C * 4);
     std::vector<double> h_pts((size_t)std::max(P, 1) * 3);
@@ -869,7 +908,7 @@ static void launch_k7(ptam_ba* ba, int guard = 0) {
     BaDev d = ba->d;
     d.guard = guard;
     int cur = guard ? (ba->cur ^ 1) : ba->cur;   // a guarded launch belongs to the next step: the trial state is current there
-    if (ba->k7_big || !ba->use_wave)   // the one row of camera partials every wave adds to (or, without measurements, all there is)
+    if ((ba->k7_big && !ba->det) || !ba->use_wave)   // the one row of camera partials every wave adds to (or, without measurements, all there is)
         (void)hipMemsetAsync(d.Upart, 0, std::max<size_t>(1, (size_t)d.F * 27) * sizeof(double), ctx->stream);
     if (!ba->use_wave) {   // no live measurement: zero error, zero bad count
         (void)hipMemsetAsync(d.err_part, 0, 16, ctx->stream);
@@ -878,8 +917,10 @@ static void launch_k7(ptam_ba* ba, int guard = 0) {
     }
     int est = ba->opts.estimator;
     void* args[] = {&ctx->cam, &d, &cur, &est, &ba->per_wave, &ba->extra_waves};
-    (void)hipLaunchKernel(k7_wave_fn(ba->k7_threads, ba->k7_loop, est, ba->k7_big), dim3(d.grid_acc), dim3(ba->k7_threads), args, ba->smem_acc,
-                          ctx->stream);
+    (void)hipLaunchKernel(k7_wave_fn(ba->k7_threads, ba->k7_loop, est, ba->k7_big, ba->det), dim3(d.grid_acc), dim3(ba->k7_threads), args,
+                          ba->smem_acc, ctx->stream);
+    if (ba->det && d.F > 0)
+        hipLaunchKernelGGL(reduce_det_kernel, dim3(d.u_rows), dim3(256), (size_t)14 * (DET_TILE + 1) * sizeof(double), ctx->stream, d);
 }
 
 static int ba_pass2(ptam_ba* ba) {
@@ -1107,6 +1148,8 @@ void ptam_ba_opts_default(ptam_ba_opts* o) {
     o->min_sigma = 0.4;
     o->estimator = PTAM_EST_TUKEY;
     o->verbose = 0;
+    o->deterministic = 0;
+    o->pad_ = 0;
 }
 
 int ptam_ba_create(ptam_ctx* ctx, const ptam_ba_opts* opts, ptam_ba** out) {
@@ -1721,6 +1764,10 @@ void ba_preload_kernels() {
     ptam_preload((const void*)select_finish_kernel);
     ptam_preload((const void*)compact_valid_kernel);
     ptam_preload(k7_wave_fn(256, true, -1, true));
+    for (int est : {(int)PTAM_EST_TUKEY, (int)PTAM_EST_CAUCHY})
+        for (int lp = 0; lp < 2; lp++) ptam_preload(k7_wave_fn(lp ? 256 : 1024, lp != 0, est, false, true));
+    ptam_preload(k7_wave_fn(256, true, -1, true, true));
+    ptam_preload((const void*)reduce_det_kernel);
     ptam_preload((const void*)reduce_partials_kernel);
     ptam_preload((const void*)vinv_kernel);
     ptam_preload((const void*)reduce_vinv_kernel);

@@ -1,4 +1,5 @@
-"""Random bundle shapes, HIP vs oracle trial by trial.   usage: fuzz_ba.py [seed] [n] [--diag]
+"""Random bundle shapes, HIP vs oracle trial by trial.   usage: fuzz_ba.py [seed] [n] [--diag] [--deterministic]
+--deterministic runs the HIP side with ptam_ba_opts.deterministic = 1 (camera sums in a fixed order).
 --diag prints, for every mismatching case, the per-trial differences (is the discrete trajectory — lambda, accepted,
 n_bad — the same and only the floating-point values drift, or does it fork?)."""
 import sys, os
@@ -11,6 +12,7 @@ from tests import util
 hip, oracle = load(), load_oracle()
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 diag = "--diag" in sys.argv
+det = 1 if "--deterministic" in sys.argv else 0
 rng = np.random.default_rng(int(args[0]) if len(args) > 0 else 7)
 bad = 0
 for i in range(int(args[1]) if len(args) > 1 else 150):
@@ -23,7 +25,7 @@ for i in range(int(args[1]) if len(args) > 1 else 150):
     if len(prob["cam_idx"]) == 0: continue
     est = [_abi.EST_TUKEY, _abi.EST_CAUCHY, _abi.EST_HUBER][i % 3]
     mi = int(rng.choice([20, 20, 3, 7]))
-    a = util.run_ba(hip, prob, estimator=est, max_iterations=mi)
+    a = util.run_ba(hip, prob, estimator=est, max_iterations=mi, deterministic=det)
     b = util.run_ba(oracle, prob, estimator=est, max_iterations=mi)
     try:
         util.assert_ba_equal(a, b, rel=1e-6)
