@@ -57,7 +57,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_abi.PatchQuery) == 16 and ctypes.sizeof(_abi.PatchResult) == 40
     assert ctypes.sizeof(_abi.Projection) == 80 and ctypes.sizeof(_abi.PoseMeas) == 48
     assert ctypes.sizeof(_abi.PoseUpdateMeas) == 136 and ctypes.sizeof(_abi.BaTrial) == 48
-    assert ctypes.sizeof(_abi.CamParams) == 48 and ctypes.sizeof(_abi.GnOpts) == 40 and ctypes.sizeof(_abi.BaOpts) == 32
+    assert ctypes.sizeof(_abi.CamParams) == 48 and ctypes.sizeof(_abi.GnOpts) == 40 and ctypes.sizeof(_abi.BaOpts) == 40
 
 
 def test_product_never_touches_the_oracle():
