@@ -336,7 +336,11 @@ int ptam_gather_pose_meas_dev(ptam_ctx* ctx, int n, const ptam_patch_query* d_qu
  *      ten coarse pose iterations -> re-projection + SearchForPoints of the other sets -> ten fine pose iterations ->
  *      measurement and scene-depth bookkeeping.  List lengths, the mbDidCoarse decision and the fine search range are taken
  *      on the device; the call enqueues everything at once and returns when the result block has arrived (host-mapped
- *      memory, no copy).  The map (world positions, pixel vectors, patch sources) stays resident between frames. */
+ *      memory, no copy).  The map (world positions, pixel vectors, patch sources) stays resident between frames, and so
+ *      does every point's PatchFinder (TrackerData::Finder): MakeTemplateCoarseCont keeps a point's search template — and
+ *      its mbTemplateBad — from frame to frame while neither column of the warp moves by more than 0.07
+ *      (src/PatchFinder.cc:98-127), a warp rejected by CalcSearchLevelAndWarpMatrix leaves mbTemplateBad up until the next
+ *      re-make (:78-81).  ptam_tracker_set_map starts every finder afresh. */
 typedef struct ptam_tracker ptam_tracker;
 typedef struct {
     int32_t try_coarse;         /* bTryCoarse after the caller's heuristics (src/Tracker.cc:505-516: DisableCoarse, velocity,
@@ -359,6 +363,8 @@ typedef struct {
     int32_t n_coarse, n_top, n_fine;   /* sizes of the coarse set, of the remaining top-level set and of the fine set */
     int32_t n_meas;             /* found entries of vIterationSet = measurements of the fine pose loop */
     int32_t depth_n;            /* number of found points in the two sums below */
+    int32_t templates_reused;   /* searched patches whose PatchFinder kept last frame's template (src/PatchFinder.cc:103-111) */
+    int32_t pad_;
     double depth_sum, depth_sum_sq;   /* sums of v3Cam[2] and its square over the found points (:680-690) */
 } ptam_trackmap_result;
 /* one entry of vIterationSet, in its order (coarse set, top-level set, fine set) */

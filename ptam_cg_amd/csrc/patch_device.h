@@ -270,18 +270,23 @@ __device__ __forceinline__ void wave_subpix(const KfLevels& L, const ptam_subpix
 // NOT evaluated in closed form: the reference walks p += across / += carriage_return pixel by pixel, and the lane replays
 // that exact sequence of fp64 additions (<= 70 of them) so the sampled positions are bit-identical.  Every product and sum
 // goes through the nc_* primitives: no FMA contraction.
+// m2 = M2Inverse(mm2WarpInverse) * LevelScale(mnSearchLevel)   (include/Tools.h:54-65; src/PatchFinder.cc:101): {m00, m01, m10, m11}
+__device__ __forceinline__ void template_m2(const TemplateJob& jb, double m2[4]) {
+    const double det = nc_sub(nc_mul(jb.wi[0], jb.wi[3]), nc_mul(jb.wi[2], jb.wi[1]));
+    const double inv = 1.0 / det;
+    const double sc = (double)(1 << jb.search_level);
+    m2[0] = nc_mul(nc_mul(jb.wi[3], inv), sc), m2[3] = nc_mul(nc_mul(jb.wi[0], inv), sc);
+    m2[2] = nc_mul(nc_mul(-jb.wi[2], inv), sc), m2[1] = nc_mul(nc_mul(-jb.wi[1], inv), sc);
+}
 __device__ __forceinline__ int wave_make_template(const TemplateJob& jb, int lane, ptam_template_result& r) {
     r.bad = 1;
     r.n_outside = 0;
     r.sum = r.sum_sq = 0;
     r.m2[0] = r.m2[1] = r.m2[2] = r.m2[3] = 0;
     if (jb.search_level < 0 || jb.im == nullptr) return 0;
-    // m2 = M2Inverse(mm2WarpInverse) * LevelScale(mnSearchLevel)   (include/Tools.h:54-65)
-    const double det = nc_sub(nc_mul(jb.wi[0], jb.wi[3]), nc_mul(jb.wi[2], jb.wi[1]));
-    const double inv = 1.0 / det;
-    const double sc = (double)(1 << jb.search_level);
-    const double m00 = nc_mul(nc_mul(jb.wi[3], inv), sc), m11 = nc_mul(nc_mul(jb.wi[0], inv), sc);
-    const double m10 = nc_mul(nc_mul(-jb.wi[2], inv), sc), m01 = nc_mul(nc_mul(-jb.wi[1], inv), sc);
+    double m2_[4];
+    template_m2(jb, m2_);
+    const double m00 = m2_[0], m01 = m2_[1], m10 = m2_[2], m11 = m2_[3];
     // CVD::transform(in, out, M, inOrig = vec(irCenter), outOrig = (4,4))
     const int w = 8, h = 8;
     const double ax = m00, ay = m10;   // across = M.T()[0]

@@ -9,11 +9,13 @@
 
 __global__ void __launch_bounds__(256) track_pvs_kernel(DevCam cam, int n, const ptam_pvs_point* __restrict__ pts,
                                                         const double* __restrict__ pose, ptam_pvs_result* __restrict__ out,
-                                                        int* __restrict__ counts, PoseArg pv, double* __restrict__ pose_out) {
-    track_pvs_body(cam, n, pts, pose, out, counts, pv, pose_out, blockIdx.x);
+                                                        int* __restrict__ counts, PoseArg pv, double* __restrict__ pose_out,
+                                                        int* __restrict__ finder_bad, int finder_stride) {
+    track_pvs_body(cam, n, pts, pose, out, counts, pv, pose_out, blockIdx.x, finder_bad, finder_stride);
 }
 
-int pvs_launch_dev(ptam_ctx* ctx, int n, const ptam_pvs_point* d_pts, double* d_pose, const double* host_pose, ptam_pvs_result* d_out) {
+int pvs_launch_dev(ptam_ctx* ctx, int n, const ptam_pvs_point* d_pts, double* d_pose, const double* host_pose, ptam_pvs_result* d_out,
+                   int* d_finder_bad, int finder_stride) {
     if (n <= 0 && !host_pose) return PTAM_OK;   // (an empty map still has to leave the pose for the kernels that follow)
     PoseArg pv{};
     if (host_pose) {
@@ -21,7 +23,7 @@ int pvs_launch_dev(ptam_ctx* ctx, int n, const ptam_pvs_point* d_pts, double* d_
         pv.use = 1;
     }
     hipLaunchKernelGGL(track_pvs_kernel, dim3(std::max(1, (n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->cam, std::max(n, 0), d_pts,
-                       (const double*)d_pose, d_out, (int*)nullptr, pv, d_pose);
+                       (const double*)d_pose, d_out, (int*)nullptr, pv, d_pose, d_finder_bad, finder_stride);
     HIP_TRY(hipGetLastError());
     return PTAM_OK;
 }
@@ -45,7 +47,7 @@ extern "C" int ptam_track_pvs(ptam_ctx* ctx, int n, const ptam_pvs_point* points
     HIP_TRY(hipMemcpyAsync(d_pose, pose, 96, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemsetAsync(d_c, 0, 16, ctx->stream));
     hipLaunchKernelGGL(track_pvs_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->cam, n, d_p, (const double*)d_pose, d_r, d_c, PoseArg{},
-                       (double*)nullptr);
+                       (double*)nullptr, (int*)nullptr, 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(results, d_r, br, hipMemcpyDeviceToHost, ctx->stream));
     if (counts) HIP_TRY(hipMemcpyAsync(counts, d_c, 16, hipMemcpyDeviceToHost, ctx->stream));

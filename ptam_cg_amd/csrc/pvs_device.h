@@ -8,7 +8,8 @@
 // its own) and block 0 also leaves it in pose_out for the kernels that follow
 __device__ __forceinline__ void track_pvs_body(const DevCam& cam, int n, const ptam_pvs_point* __restrict__ pts,
                                                const double* __restrict__ pose, ptam_pvs_result* __restrict__ out,
-                                               int* __restrict__ counts, const PoseArg& pv, double* __restrict__ pose_out, int block) {
+                                               int* __restrict__ counts, const PoseArg& pv, double* __restrict__ pose_out, int block,
+                                               int* __restrict__ finder_bad = nullptr, int finder_stride = 0) {
     const int i = block * 256 + threadIdx.x;   // (a 256-thread workgroup)
     const int lane = threadIdx.x & 63;
     int level = -1;
@@ -63,6 +64,9 @@ __device__ __forceinline__ void track_pvs_body(const DevCam& cam, int n, const p
                 det *= 0.25;
             }
             level = (det > 3 || det < 0.25) ? -1 : l;
+            // the point's PatchFinder: a rejected warp sets mbTemplateBad (src/PatchFinder.cc:78-81), and the flag stays up until
+            // the finder next re-makes its template (:98-127) — the resident tracker keeps it per point
+            if (level < 0 && finder_bad) *(int*)((char*)finder_bad + (size_t)i * finder_stride) = 1;
         }
         r.level = level;
         out[i] = r;

@@ -37,7 +37,9 @@ struct PoseArg {   // a pose handed over by value
     int use;
 };
 // host_pose (nullable): the pose as a kernel argument, also written to d_pose; otherwise d_pose is read
-int pvs_launch_dev(ptam_ctx* ctx, int n, const ptam_pvs_point* d_pts, double* d_pose, const double* host_pose, ptam_pvs_result* d_out);
+// d_finder_bad (nullable): word i * finder_stride bytes further on is set when point i's warp is rejected (PatchFinder::mbTemplateBad)
+int pvs_launch_dev(ptam_ctx* ctx, int n, const ptam_pvs_point* d_pts, double* d_pose, const double* host_pose, ptam_pvs_result* d_out,
+                   int* d_finder_bad = nullptr, int finder_stride = 0);
 
 // pose.hip: the ten-iteration loop on a measurement list whose length sits in device memory, with the extras of the chain
 struct PoseChainIo {

@@ -43,8 +43,21 @@ struct TmCtl {
     int fine_range;         // nFineRange (:572)
     int attempted[4], found[4];   // manMeasAttempted / manMeasFound
     int range_all[2], range_c[2], range_hf[2], range_h[2];   // slot ranges {first, end} of the stages
-    int pad_[2];
+    int n_reused;           // searched patches whose PatchFinder kept its template (src/PatchFinder.cc:103-111)
+    int pad_[1];
     double depth[3];        // sum z, sum z^2, count over the found points (:680-690)
+};
+
+// The PatchFinder of a map point (TrackerData::Finder, include/Tracker.h:52), the part of its state that outlives a frame:
+// MakeTemplateCoarseCont (src/PatchFinder.cc:98-127) keeps the template — and mbTemplateBad with it — when the finder last
+// warped THIS point and neither column of the warp m2 has moved by more than 0.07 since.  (The finder is per point here, so
+// "the same map point" is "a template was made at all".)
+struct TmFinder {
+    double m2[4];           // mm2LastWarpMatrix {m00, m01, m10, m11}
+    int valid;              // mpLastTemplateMapPoint == &p
+    int bad;                // mbTemplateBad
+    int sum, sum_sq;        // MakeTemplateSums
+    uint8_t tpl[64];        // mimTemplate
 };
 
 struct TmDev {
@@ -72,6 +85,7 @@ struct TmDev {
     int* outlier;             // per measurement (fine loop, iteration 9)
     TmCtl* ctl;
     double* pose;
+    TmFinder* finder;         // [cap] per-point PatchFinder state
 };
 
 // exclusive block scan of four counters at once (1024 threads): returns this thread's four offsets, totals in tot[]
@@ -225,6 +239,7 @@ __device__ __forceinline__ void tm_select_body(const TmDev& d, const ptam_trackm
         c.do_coarse = do_coarse;
         c.did_coarse = 0;
         c.n_found_coarse = c.n_meas_coarse = c.n_meas = 0;
+        c.n_reused = 0;
         c.fine_range = 10;
         for (int l = 0; l < 4; l++) c.attempted[l] = c.found[l] = 0;
         c.range_all[0] = 0, c.range_all[1] = nC + nH + nF;
@@ -245,12 +260,13 @@ __global__ void __launch_bounds__(1024) tm_select_kernel(TmDev d, ptam_trackmap_
 //   launch 3: set choice (workgroup 0) | raster-ordered corner compaction (9 independent workgroups at 640x480)
 template <int VARIANT>
 __global__ void __launch_bounds__(256) tm_pyr_pvs_kernel(PyrArgs a, int gx, int n_pyr, DevCam cam, int n, const ptam_pvs_point* __restrict__ pts,
-                                                         ptam_pvs_result* __restrict__ out, PoseArg pv, double* __restrict__ pose_out) {
+                                                         ptam_pvs_result* __restrict__ out, PoseArg pv, double* __restrict__ pose_out,
+                                                         int* __restrict__ finder_bad) {
     const int b = blockIdx.x;
     if (b < n_pyr)
         pyramid_body<VARIANT>(a, (b % gx) * 64 + (threadIdx.x & 63), (b / gx) * 4 + (threadIdx.x >> 6));
     else
-        track_pvs_body(cam, n, pts, pose_out, out, nullptr, pv, pose_out, b - n_pyr);
+        track_pvs_body(cam, n, pts, pose_out, out, nullptr, pv, pose_out, b - n_pyr, finder_bad, (int)sizeof(TmFinder));
 }
 __global__ void __launch_bounds__(1024) tm_compact_select_kernel(KfLevels L, TmDev d, ptam_trackmap_opts o) {
     if (blockIdx.x == 0)
@@ -312,8 +328,37 @@ __device__ __forceinline__ void tm_search_body(const DevCam& cam, const KfLevels
     jb.cy = sr.cy;
 #pragma unroll
     for (int k = 0; k < 4; k++) jb.wi[k] = pv.warp_inverse[k];
+    // MakeTemplateCoarseCont (src/PatchFinder.cc:98-127): re-make the template unless this finder's last one was made with
+    // (nearly) this warp — then the template, its sums and mbTemplateBad stay as they are
     ptam_template_result tr;
-    const int T = wave_make_template(jb, lane, tr);
+    int T;
+    {
+        TmFinder& fs = d.finder[id];
+        double m2[4];
+        template_m2(jb, m2);
+        const double c0x = m2[0] - fs.m2[0], c0y = m2[2] - fs.m2[2], c1x = m2[1] - fs.m2[1], c1y = m2[3] - fs.m2[3];   // columns m2.T()[0], m2.T()[1]
+        const double lim = 0.07 * 0.07;
+        const bool refresh = !fs.valid || pv.level < 0 || c0x * c0x + c0y * c0y > lim || c1x * c1x + c1y * c1y > lim;
+        if (refresh) {
+            T = wave_make_template(jb, lane, tr);
+            fs.tpl[lane] = (uint8_t)T;
+            if (lane == 0 && pv.level >= 0) {
+                fs.m2[0] = tr.m2[0], fs.m2[1] = tr.m2[1], fs.m2[2] = tr.m2[2], fs.m2[3] = tr.m2[3];
+                fs.valid = 1;
+                fs.bad = tr.bad;
+                fs.sum = tr.sum;
+                fs.sum_sq = tr.sum_sq;
+            }
+        } else {
+            T = fs.tpl[lane];
+            tr.bad = fs.bad;
+            tr.n_outside = 0;
+            tr.sum = fs.sum;
+            tr.sum_sq = fs.sum_sq;
+            tr.m2[0] = fs.m2[0], tr.m2[1] = fs.m2[1], tr.m2[2] = fs.m2[2], tr.m2[3] = fs.m2[3];
+            if (lane == 0) atomicAdd(&d.ctl->n_reused, 1);
+        }
+    }
     ptam_patch_result res;
     wave_find_patch_coarse(L, q, !tr.bad, T, lane, res);
     if (lane == 0) {
@@ -395,6 +440,8 @@ __device__ __forceinline__ void tm_gather_finish(const TmDev& d, TmCtl& c, int s
             // everything of the frame's result but the pose and the depth sums (the fine pose loop publishes those, then
             // the sequence word)
             ptam_trackmap_result& r = mbox->res;
+            r.templates_reused = c.n_reused;
+            r.pad_ = 0;
             r.did_coarse = c.did_coarse;
             for (int l = 0; l < 4; l++) {
                 r.n_pvs[l] = c.n_lvl[l];
@@ -604,7 +651,7 @@ __global__ void __launch_bounds__(256) tm_pyr_pvs_batch_kernel(const TmBatchItem
     if (b < it.n_pyr)
         pyramid_body<VARIANT>(it.pa, (b % gx) * 64 + (threadIdx.x & 63), (b / gx) * 4 + (threadIdx.x >> 6));
     else if ((b - it.n_pyr) * 256 < max(it.n, 1))
-        track_pvs_body(cam, it.n, it.d.pts, it.d.pose, it.d.pvs, nullptr, it.pv, it.d.pose, b - it.n_pyr);
+        track_pvs_body(cam, it.n, it.d.pts, it.d.pose, it.d.pvs, nullptr, it.pv, it.d.pose, b - it.n_pyr, &it.d.finder->bad, (int)sizeof(TmFinder));
 }
 __global__ void __launch_bounds__(1024) tm_compact_select_batch_kernel(const TmBatchItem* __restrict__ items, ptam_trackmap_opts o) {
     const TmBatchItem& it = items[blockIdx.y];
@@ -676,7 +723,8 @@ int ptam_tracker_create(ptam_ctx* ctx, int max_points, ptam_tracker** out) {
                  o_q = take(cap * sizeof(ptam_patch_query)), o_r = take(cap * sizeof(ptam_patch_result)),
                  o_sr = take(cap * sizeof(ptam_subpix_result)), o_sf = take(cap * 4), o_st = take(cap * 4), o_ss = take(cap * 4), o_sv = take(cap * 16),
                  o_me = take(cap * sizeof(ptam_pose_meas)), o_en = take(cap * sizeof(ptam_projection)), o_mi = take(cap * 4),
-                 o_ms = take(cap * 4), o_ou = take(cap * 4), o_ctl = take(sizeof(TmCtl)), o_pose = take(96);
+                 o_ms = take(cap * 4), o_ou = take(cap * 4), o_ctl = take(sizeof(TmCtl)), o_pose = take(96),
+                 o_fs = take(cap * sizeof(TmFinder));
     // every failure past this point leaves through ONE path that releases what exists so far
     auto fail = [&](const char* what) {
         ptam_set_error("ptam_tracker_create: %s failed", what);
@@ -715,6 +763,7 @@ int ptam_tracker_create(ptam_ctx* ctx, int max_points, ptam_tracker** out) {
     d.outlier = (int*)(b + o_ou);
     d.ctl = (TmCtl*)(b + o_ctl);
     d.pose = (double*)(b + o_pose);
+    d.finder = (TmFinder*)(b + o_fs);   // (cleared with the block: no finder has made a template yet)
     void* h = nullptr;
     if (hipHostMalloc(&h, sizeof(TmMailbox), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return fail("hipHostMalloc");
     t->mbox = (TmMailbox*)h;
@@ -773,6 +822,8 @@ int ptam_tracker_set_map(ptam_tracker* t, int n, const ptam_pvs_point* pts, cons
         HIP_TRY(hipMemcpy(t->d.pts, pts, (size_t)n * sizeof(ptam_pvs_point), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(t->d.src, s.data(), (size_t)n * sizeof(TmSrc), hipMemcpyHostToDevice));
     }
+    // a new map: new TrackerData, new PatchFinders (include/Tracker.h:42-67) — no template has been made, none is bad
+    HIP_TRY(hipMemset(t->d.finder, 0, (size_t)t->d.cap * sizeof(TmFinder)));
     if (n != t->d.n) {   // the shuffles are permutations of 0..n-1: back to the identity until the caller sets them again
         std::vector<int> idp((size_t)std::max(n, 1));
         for (int i = 0; i < n; i++) idp[(size_t)i] = i;
@@ -862,14 +913,14 @@ static int track_map_impl(ptam_tracker* t, ptam_kf* cur, const uint8_t* d_new_fr
         const int n_pyr = gx * gy, n_pvs = std::max(1, (n + 255) / 256);
         if (ctx->halfsample == PTAM_HALFSAMPLE_T)
             hipLaunchKernelGGL(tm_pyr_pvs_kernel<PTAM_HALFSAMPLE_T>, dim3(n_pyr + n_pvs), dim3(256), 0, st, pa, gx, n_pyr, ctx->cam, std::max(n, 0),
-                               (const ptam_pvs_point*)d.pts, d.pvs, pv, d.pose);
+                               (const ptam_pvs_point*)d.pts, d.pvs, pv, d.pose, &d.finder->bad);
         else
             hipLaunchKernelGGL(tm_pyr_pvs_kernel<PTAM_HALFSAMPLE_R>, dim3(n_pyr + n_pvs), dim3(256), 0, st, pa, gx, n_pyr, ctx->cam, std::max(n, 0),
-                               (const ptam_pvs_point*)d.pts, d.pvs, pv, d.pose);
+                               (const ptam_pvs_point*)d.pts, d.pvs, pv, d.pose, &d.finder->bad);
         kf_launch_detect(cur, st);
         hipLaunchKernelGGL(tm_compact_select_kernel, dim3(1 + fast_compact_blocks(cur->L)), dim3(1024), 0, st, cur->L, d, o);
     } else {
-        rc = pvs_launch_dev(ctx, n, d.pts, d.pose, pose_in, d.pvs);                         // :453-478 (the pose rides in as an argument)
+        rc = pvs_launch_dev(ctx, n, d.pts, d.pose, pose_in, d.pvs, &d.finder->bad, (int)sizeof(TmFinder));                         // :453-478 (the pose rides in as an argument)
         if (rc) return rc;
         hipLaunchKernelGGL(tm_select_kernel, dim3(1), dim3(1024), 0, st, d, o);             // :480-611
     }

@@ -41,10 +41,10 @@ TRACKMAP_OPTS_DT = np.dtype([("try_coarse", "<i4"), ("coarse_min", "<u4"), ("coa
                              ("coarse_subpix_its", "<i4"), ("max_patches", "<i4"), ("estimator", "<i4"), ("pad_", "<i4")])
 TRACKMAP_RESULT_DT = np.dtype([("pose", "<f8", (12,)), ("did_coarse", "<i4"), ("n_pvs", "<i4", (4,)), ("attempted", "<i4", (4,)),
                                ("found", "<i4", (4,)), ("n_coarse", "<i4"), ("n_top", "<i4"), ("n_fine", "<i4"), ("n_meas", "<i4"),
-                               ("depth_n", "<i4"), ("depth_sum", "<f8"), ("depth_sum_sq", "<f8")])
+                               ("depth_n", "<i4"), ("templates_reused", "<i4"), ("pad_", "<i4"), ("depth_sum", "<f8"), ("depth_sum_sq", "<f8")])
 TRACKMAP_MEAS_DT = np.dtype([("point", "<i4"), ("level", "<i4"), ("found", "<i4"), ("did_subpix", "<i4"), ("outlier", "<i4"),
                              ("pad_", "<i4"), ("v2_found", "<f8", (2,))])
-assert TRACKMAP_RESULT_DT.itemsize == 96 + 4 * 18 + 16 and TRACKMAP_MEAS_DT.itemsize == 40
+assert TRACKMAP_RESULT_DT.itemsize == 96 + 4 * 20 + 16 and TRACKMAP_MEAS_DT.itemsize == 40
 assert PATCH_RESULT_DT.itemsize == C.sizeof(PatchResult)
 assert PROJECTION_DT.itemsize == C.sizeof(Projection)
 assert POSE_MEAS_DT.itemsize == C.sizeof(PoseMeas)

@@ -15,17 +15,41 @@ class _TD:
     __slots__ = ("idx", "state", "level", "warp_inverse", "found", "did_subpix", "v2_found", "searched_level")
 
 
-def search_for_points(ctx, pf, kf, case, src_kf, tds, rng_range, subpix_its, attempted, found_cnt):
-    """Tracker::SearchForPoints src/Tracker.cc:867-912 on a list of TrackerData (batched: every step for all of them)"""
+REFRESH_LIMIT = 0.07   # dRefreshLimit, src/PatchFinder.cc:107
+
+
+def search_for_points(ctx, pf, kf, case, src_kf, tds, rng_range, subpix_its, attempted, found_cnt, finders=None, stats=None):
+    """Tracker::SearchForPoints src/Tracker.cc:867-912 on a list of TrackerData (batched: every step for all of them).
+    finders (dict: map point -> the state of its PatchFinder that outlives a frame, TrackerData::Finder): when given,
+    MakeTemplateCoarseCont's reuse rule (src/PatchFinder.cc:98-127) applies — the library call below always warps a fresh
+    template, and the rule decides per point whether the finder takes it or keeps its old one (with the old mbTemplateBad)."""
     if not tds:
         return 0
     ids = np.array([t.idx for t in tds])
     lev = np.array([t.level for t in tds], dtype=np.int32)
     wi = np.array([t.warp_inverse for t in tds])
     tm, tres = pf.MakeTemplateCoarseCont(src_kf, case["src_level"][ids], case["center"][ids], lev, wi)    # :873
+    tm = np.array(tm, copy=True)
+    bad_of = [bool(b) for b in tres["bad"]]
+    if finders is not None:
+        for k, t in enumerate(tds):
+            st = finders.setdefault(t.idx, {"valid": False, "bad": False})
+            m2 = np.array(tres["m2"][k], dtype=np.float64)           # {m00, m01, m10, m11}: columns (m00, m10), (m01, m11)
+            refresh = not st["valid"]
+            if not refresh:
+                dlt = m2 - st["m2"]
+                refresh = dlt[0] ** 2 + dlt[2] ** 2 > REFRESH_LIMIT ** 2 or dlt[1] ** 2 + dlt[3] ** 2 > REFRESH_LIMIT ** 2
+            if refresh:
+                st.update(valid=True, m2=m2, tm=tm[k].copy(), bad=bad_of[k])
+            else:                                                     # the finder keeps template, sums and mbTemplateBad
+                tm[k] = st["tm"]
+                bad_of[k] = st["bad"]
+                if stats is not None:
+                    stats["reused"] += 1
+                    stats["stale_bad"] += int(st["bad"])
     q = np.zeros(len(tds), dtype=host.PATCH_QUERY_DT)
     for k, t in enumerate(tds):
-        bad = bool(tres["bad"][k])
+        bad = bad_of[k]
         t.searched_level = -1 if bad else t.level
         if bad:                                   # :874-878
             t.found = False
@@ -65,8 +89,11 @@ def search_for_points(ctx, pf, kf, case, src_kf, tds, rng_range, subpix_its, att
 
 
 def track_map(ctx, kf, src_kf, case, pose_in, shuffle_levels, shuffle_fine, try_coarse=True, coarse_min=20, coarse_max=60,
-              coarse_range=30, coarse_subpix_its=8, max_patches=1000, estimator=0):
+              coarse_range=30, coarse_subpix_its=8, max_patches=1000, estimator=0, finders=None):
+    """finders: None = every PatchFinder fresh (a tracker's first frame); a dict kept by the caller from frame to frame =
+    the per-point finder state of a tracker that goes on tracking the same map"""
     pf = host.PatchFinder(ctx)
+    stats = {"reused": 0, "stale_bad": 0}
     n = len(case["world"])
     pose = np.array(pose_in, dtype=np.float64).copy()
     attempted, found_cnt = [0] * LEVELS, [0] * LEVELS
@@ -75,6 +102,9 @@ def track_map(ctx, kf, src_kf, case, pose_in, shuffle_levels, shuffle_fine, try_
     tds = {}
     for i in range(n):
         if pvs["level"][i] < 0:
+            # CalcSearchLevelAndWarpMatrix returned -1 (only reached for points in the image, :456-470): mbTemplateBad = true
+            if finders is not None and pvs["proj"][i]["in_image"]:
+                finders.setdefault(i, {"valid": False, "bad": False})["bad"] = True
             continue
         t = _TD()
         t.idx, t.level, t.warp_inverse = i, int(pvs["level"][i]), pvs["warp_inverse"][i].copy()
@@ -101,7 +131,7 @@ def track_map(ctx, kf, src_kf, case, pose_in, shuffle_levels, shuffle_fine, try_
             else:
                 next_to_search = next_to_search + av[2][:more]
                 av[2] = av[2][more:]
-        n_found = search_for_points(ctx, pf, kf, case, src_kf, next_to_search, coarse_range, coarse_subpix_its, attempted, found_cnt)
+        n_found = search_for_points(ctx, pf, kf, case, src_kf, next_to_search, coarse_range, coarse_subpix_its, attempted, found_cnt, finders, stats)
         iteration_set = list(next_to_search)                                 # :550
         if n_found >= coarse_min:                                            # :551
             did_coarse = True
@@ -124,7 +154,7 @@ def track_map(ctx, kf, src_kf, case, pose_in, shuffle_levels, shuffle_fine, try_
 
     top = list(av[3])                                                        # :574-581
     reproject(top)
-    search_for_points(ctx, pf, kf, case, src_kf, top, fine_range, 8, attempted, found_cnt)
+    search_for_points(ctx, pf, kf, case, src_kf, top, fine_range, 8, attempted, found_cnt, finders, stats)
     iteration_set += top
     fine = [t for l in (2, 1, 0) for t in av[l]]                             # :586-590
     n_use = max(0, max_patches - len(iteration_set))                         # :593-596
@@ -133,7 +163,7 @@ def track_map(ctx, kf, src_kf, case, pose_in, shuffle_levels, shuffle_fine, try_
         fine = [tds[i] for i in shuffle_fine if i in member][:n_use]
     if did_coarse:                                                           # :603-605
         reproject(fine)
-    search_for_points(ctx, pf, kf, case, src_kf, fine, fine_range, 0, attempted, found_cnt)
+    search_for_points(ctx, pf, kf, case, src_kf, fine, fine_range, 0, attempted, found_cnt, finders, stats)
     iteration_set += fine
     # ---- fine pose loop :613-643 ----
     f = [t for t in iteration_set if t.found]
@@ -156,4 +186,5 @@ def track_map(ctx, kf, src_kf, case, pose_in, shuffle_levels, shuffle_fine, try_
             it[s]["outlier"] = outl[k]
             k += 1
     return {"pose": pose, "did_coarse": did_coarse, "n_pvs": n_pvs, "attempted": attempted, "found": found_cnt,
-            "n_coarse": n_coarse, "n_top": len(top), "n_fine": len(fine), "n_meas": len(f), "depth": depth, "iteration_set": it}
+            "n_coarse": n_coarse, "n_top": len(top), "n_fine": len(fine), "n_meas": len(f), "depth": depth, "iteration_set": it,
+            "templates_reused": stats["reused"], "stale_bad": stats["stale_bad"]}
