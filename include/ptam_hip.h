@@ -264,6 +264,31 @@ typedef struct {
 int ptam_refind_batch(ptam_ctx* ctx, const ptam_kf* kf, const double kf_pose[12], int n, const ptam_pvs_point* points,
                       const ptam_template_query* sources /* src_kf, src_level, center_x / center_y */, ptam_refind_result* out);
 
+/* ---- MapMaker::ReFind_Common as the reference CALLS it (src/MapMaker.cc:1046-1082): a list of (keyframe, point) pairs taken
+ *      in order through ONE PatchFinder — `static PatchFinder Finder` (:977) — whose MakeTemplateCoarseCont keeps the
+ *      template, its sums and mbTemplateBad when it last warped THIS map point and neither column of the warp has moved by
+ *      more than 0.07 since (src/PatchFinder.cc:98-127).  ReFindNewlyMade (:1046-1066) is one new point against every
+ *      keyframe in turn: consecutive keyframes with nearly the same pose search with the template of the first.  And a warp
+ *      CalcSearchLevelAndWarpMatrix rejects sets mbTemplateBad (:78-81), which a kept template does not clear — that pair
+ *      (and the kept ones after it) goes into sNeverRetryKFs although an earlier pair searched with the same template.
+ *      The finder object carries that state from call to call like the static does; pairs with `skip` set (:947-948: the
+ *      point is already measured in the keyframe, or never to be retried) return false without touching it. */
+typedef struct ptam_refinder ptam_refinder;
+int ptam_refinder_create(ptam_ctx* ctx, ptam_refinder** out);
+int ptam_refinder_destroy(ptam_refinder* f);
+typedef struct {
+    const ptam_kf* kf;            /* k */
+    double kf_pose[12];           /* k.se3CfromW */
+    ptam_pvs_point point;         /* p: world position and pixel vectors */
+    ptam_template_query source;   /* p: patch source (src_kf, src_level, center_x / center_y; the other fields are ignored) */
+    int64_t point_id;             /* identity of the MapPoint (the reference compares &p with mpLastTemplateMapPoint) */
+    int32_t skip;                 /* :947-948 */
+    int32_t pad_;
+} ptam_refind_pair;
+/* template_kept (nullable): 1 where the finder searched with the template it already had */
+int ptam_refind_pairs(ptam_ctx* ctx, ptam_refinder* finder, int n, const ptam_refind_pair* pairs, ptam_refind_result* out,
+                      int32_t* template_kept);
+
 /* ---- Tracker pose Gauss-Newton (src/Tracker.cc:613-643 driver, :928-1005 CalcPoseUpdate,
  *      include/Tracker.h:125-142 CalcJacobian/LinearUpdate) ---------------------------------------- */
 typedef struct {

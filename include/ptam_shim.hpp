@@ -440,6 +440,30 @@ inline std::vector<ptam_refind_result> ReFindInKeyFrame(Context& c, KeyFrame& k,
     return out;
 }
 
+// The `static PatchFinder Finder` of MapMaker::ReFind_Common (src/MapMaker.cc:977) and the loops that drive it pair by pair:
+// ReFindNewlyMade (:1046-1066: one new point against every keyframe in turn) and ReFindFromFailureQueue (:1070-1082: the
+// sorted (keyframe, point) pairs).  The caller lists the pairs in the reference's order — with `skip` set where :947-948
+// would return at once — and applies out[i] as for ReFindInKeyFrame above.  One ReFinder per MapMaker: its state (last
+// template, last warp, mbTemplateBad) carries from call to call exactly like the static's.
+class ReFinder {
+public:
+    explicit ReFinder(Context& c) : c_(c) { check(ptam_refinder_create(c.handle(), &h_), "ptam_refinder_create"); }
+    ~ReFinder() { ptam_refinder_destroy(h_); }
+    ReFinder(const ReFinder&) = delete;
+    ReFinder& operator=(const ReFinder&) = delete;
+    std::vector<ptam_refind_result> Find(const std::vector<ptam_refind_pair>& vPairs, std::vector<int32_t>* pvTemplateKept = nullptr) {
+        std::vector<ptam_refind_result> out(vPairs.size());
+        if (pvTemplateKept) pvTemplateKept->assign(vPairs.size(), 0);
+        check(ptam_refind_pairs(c_.handle(), h_, (int)vPairs.size(), vPairs.data(), out.data(), pvTemplateKept ? pvTemplateKept->data() : nullptr),
+              "ptam_refind_pairs");
+        return out;
+    }
+
+private:
+    Context& c_;
+    ptam_refinder* h_ = nullptr;
+};
+
 // class Bundle (include/Bundle.h:106-152)
 class Bundle {
 public:

@@ -512,6 +512,60 @@ def refind(cam, levels_k, pose_k, world, pixel_right_w, pixel_down_w, src_images
     return out
 
 
+def refind_pairs(cam, pairs, state):
+    """MapMaker::ReFind_Common as its callers run it (src/MapMaker.cc:1046-1082): (keyframe, point) pairs in order through ONE
+    PatchFinder — `static PatchFinder Finder`, :977 — whose state `state` (a dict the caller keeps) outlives the call:
+    MakeTemplateCoarseCont (src/PatchFinder.cc:98-127) keeps template and mbTemplateBad when it last warped this map point and
+    no column of the warp m2 moved by more than 0.07; CalcSearchLevelAndWarpMatrix sets mbTemplateBad when it rejects a warp
+    (:78-81).  pairs: dicts with levels_k, pose_k, world, pixel_right_w, pixel_down_w, src_image, center, point_id, skip.
+    -> list of dict(found, level, sub_pix, never_retry, root_pos, kept)"""
+    out = []
+    for pr_ in pairs:
+        r = dict(found=0, level=-1, sub_pix=0, never_retry=0, root_pos=np.zeros(2), kept=0)
+        out.append(r)
+        if pr_["skip"]:                                             # :947-948
+            continue
+        r["never_retry"] = 1
+        pose_k = pr_["pose_k"]
+        pr = project_points(cam, pose_k, pr_["world"][None, :])
+        if not pr["in_image"][0]:                                   # :950-975
+            continue
+        R = pose_k[:9].reshape(3, 3)
+        M = np.stack([pr_["pixel_right_w"][None, :] @ R.T, pr_["pixel_down_w"][None, :] @ R.T], axis=1)
+        W = np.einsum("nab,nkb->nak", pr["derivs"][0:1], motion_to_plane(pr["cam"][0:1], M))[0]
+        det = W[0, 0] * W[1, 1] - W[0, 1] * W[1, 0]
+        level = 0
+        while det > 3 and level < LEVELS - 1:
+            level += 1
+            det *= 0.25
+        if det > 3 or det < 0.25:                                   # src/PatchFinder.cc:78-81; the -1 is not looked at (:979)
+            state["bad"] = True
+        m2 = np.linalg.inv(W) * (1 << level)                        # :101   (rows; columns are m2.T()[i])
+        need = state.get("point") != pr_["point_id"]                 # :103
+        if not need:
+            d = m2 - state["m2"]
+            need = bool((d[:, 0] @ d[:, 0] > 0.07 ** 2) or (d[:, 1] @ d[:, 1] > 0.07 ** 2))   # :105-110
+        if need:
+            tmpl, tr = make_template_coarse_cont(pr_["src_image"], int(pr_["center"][0]), int(pr_["center"][1]), level, W.reshape(4))
+            state.update(point=pr_["point_id"], m2=m2, tmpl=tmpl, bad=bool(tr["bad"]))   # :112-123
+        else:
+            r["kept"] = 1
+        r["level"] = level
+        if state["bad"]:                                            # :982-986
+            continue
+        q = dict(x=int(pr["image"][0][0]), y=int(pr["image"][0][1]), level=level, range=4)
+        res = find_patch_coarse(pr_["levels_k"], q, state["tmpl"])
+        if not res["found"]:
+            continue
+        r["found"], r["never_retry"] = 1, 0
+        if level > 0:
+            sp = subpix(pr_["levels_k"], res["pos"], level, state["tmpl"], 8)
+            r["root_pos"], r["sub_pix"] = np.array(sp["pos"], float), 1
+        else:
+            r["root_pos"] = np.array(res["pos"], float)
+    return out
+
+
 def calc_pose_update(found, image, s, J, override=0.0, est="Tukey", prior=100.0):
     """-> (mu, weight_zero_mask)   J: (N,2,6)"""
     if len(found) == 0:

@@ -1675,6 +1675,129 @@ int ptamo_refind_batch(ptamo_ctx* c, const ptamo_kf* k, const double kf_pose[12]
     return PTAM_OK;
 }
 
+// The same through the reference's ONE finder (`static PatchFinder Finder`, src/MapMaker.cc:977), pair after pair in the
+// caller's order — ReFindNewlyMade :1046-1066, ReFindFromFailureQueue :1070-1082: the finder's state that outlives a call.
+struct ptamo_refinder {
+    bool has_last = false;         // mpLastTemplateMapPoint != NULL
+    long long last_point = 0;      // mpLastTemplateMapPoint
+    double last_m2[4] = {0, 0, 0, 0};   // mm2LastWarpMatrix {m00, m01, m10, m11}
+    uint8_t tmpl[64] = {0};        // mimTemplate
+    bool bad = false;              // mbTemplateBad
+};
+int ptamo_refinder_create(ptamo_ctx*, ptamo_refinder** out) {
+    if (!out) return PTAM_E_ARG;
+    *out = new ptamo_refinder();
+    return PTAM_OK;
+}
+int ptamo_refinder_destroy(ptamo_refinder* f) {
+    delete f;
+    return PTAM_OK;
+}
+int ptamo_refind_pairs(ptamo_ctx* c, ptamo_refinder* F, int n, const ptam_refind_pair* pairs, ptam_refind_result* out, int32_t* kept) {
+    if (!c || !F || n < 0 || (n > 0 && (!pairs || !out))) return PTAM_E_ARG;
+    ATANCamera cam(c->c.cam);
+    for (int i = 0; i < n; i++) {
+        const ptam_refind_pair& pr_ = pairs[i];
+        ptam_refind_result& r = out[i];
+        std::memset(&r, 0, sizeof r);
+        r.level = -1;
+        if (kept) kept[i] = 0;
+        if (pr_.skip) continue;                                                    // :947-948 (neither found nor newly "never retry")
+        r.never_retry = 1;
+        const ptamo_kf* k = reinterpret_cast<const ptamo_kf*>(pr_.kf);
+        if (!k) return PTAM_E_ARG;
+        const SE3 T = se3_from12(pr_.kf_pose);
+        const ptam_pvs_point& p = pr_.point;
+        double v3Cam[3];
+        se3_apply(T, p.world, v3Cam);                                              // :950
+        if (v3Cam[2] < 0.001) continue;                                            // :951-955
+        const double v2ImPlane[2] = {v3Cam[0] / v3Cam[2], v3Cam[1] / v3Cam[2]};
+        if (v2ImPlane[0] * v2ImPlane[0] + v2ImPlane[1] * v2ImPlane[1] > cam.largest_radius * cam.largest_radius) continue;   // :957-961
+        double v2Image[2];
+        cam.Project(v2ImPlane, v2Image);                                           // :963
+        if (cam.invalid) continue;                                                 // :964-968
+        if (v2Image[0] < 0 || v2Image[1] < 0 || v2Image[0] > cam.size[0] || v2Image[1] > cam.size[1]) continue;   // :970-975
+        double D[4];
+        cam.GetProjectionDerivs(D);                                                // :978
+        // Finder.CalcSearchLevelAndWarpMatrix(p, k.se3CfromW, m2CamDerivs)  :979, src/PatchFinder.cc:52-84
+        const double dOneOverCameraZ = 1.0 / v3Cam[2];
+        double mr[3], md[3];
+        for (int q = 0; q < 3; q++) {
+            mr[q] = T.R[q * 3] * p.pixel_right_w[0] + T.R[q * 3 + 1] * p.pixel_right_w[1] + T.R[q * 3 + 2] * p.pixel_right_w[2];
+            md[q] = T.R[q * 3] * p.pixel_down_w[0] + T.R[q * 3 + 1] * p.pixel_down_w[1] + T.R[q * 3 + 2] * p.pixel_down_w[2];
+        }
+        double W[4];
+        {
+            const double ax = (mr[0] - v3Cam[0] * mr[2] * dOneOverCameraZ) * dOneOverCameraZ;
+            const double ay = (mr[1] - v3Cam[1] * mr[2] * dOneOverCameraZ) * dOneOverCameraZ;
+            W[0] = D[0] * ax + D[1] * ay;
+            W[2] = D[2] * ax + D[3] * ay;
+            const double bx = (md[0] - v3Cam[0] * md[2] * dOneOverCameraZ) * dOneOverCameraZ;
+            const double by = (md[1] - v3Cam[1] * md[2] * dOneOverCameraZ) * dOneOverCameraZ;
+            W[1] = D[0] * bx + D[1] * by;
+            W[3] = D[2] * bx + D[3] * by;
+        }
+        double dDet = W[0] * W[3] - W[1] * W[2];
+        int level = 0;
+        while (dDet > 3 && level < PTAM_LEVELS - 1) {
+            level++;
+            dDet *= 0.25;
+        }
+        if (dDet > 3 || dDet < 0.25) F->bad = true;                                // src/PatchFinder.cc:78-81 (the -1 itself is ignored)
+        // Finder.MakeTemplateCoarseCont(p)  :980, src/PatchFinder.cc:98-127
+        const double det = W[0] * W[3] - W[2] * W[1];
+        const double inv = 1.0 / det;
+        const double sc = (double)(1 << level);
+        const double m2[4] = {W[3] * inv * sc, -W[1] * inv * sc, -W[2] * inv * sc, W[0] * inv * sc};   // {m00, m01, m10, m11}
+        bool need = !F->has_last || F->last_point != (long long)pr_.point_id;       // :103
+        for (int col = 0; !need && col < 2; col++) {                               // :105-110: columns m2.T()[col]
+            const double dx = m2[col] - F->last_m2[col], dy = m2[2 + col] - F->last_m2[2 + col];
+            if (dx * dx + dy * dy > 0.07 * 0.07) need = true;
+        }
+        if (need) {
+            const ptamo_kf* sk = reinterpret_cast<const ptamo_kf*>(pr_.source.src_kf);
+            if (!sk || pr_.source.src_level < 0 || pr_.source.src_level >= PTAM_LEVELS) return PTAM_E_ARG;
+            ptam_template_result tr;
+            std::memset(&tr, 0, sizeof tr);
+            make_template_coarse_cont(sk->kf.lev[pr_.source.src_level], pr_.source.center_x, pr_.source.center_y, level, W, F->tmpl, tr);
+            F->bad = tr.bad != 0;                                                  // :118
+            F->has_last = true;                                                    // :121-122
+            F->last_point = (long long)pr_.point_id;
+            for (int q = 0; q < 4; q++) F->last_m2[q] = m2[q];
+        } else if (kept)
+            kept[i] = 1;
+        r.level = level;
+        if (F->bad) continue;                                                      // :982-986
+        ptam_patch_query q;
+        q.x = (int)v2Image[0];                                                     // ir(v2Image) :988
+        q.y = (int)v2Image[1];
+        q.level = level;
+        q.range = 4;
+        ptam_patch_result pr;
+        find_patch_coarse(k->kf, q, F->tmpl, pr);
+        if (!pr.found) continue;                                                   // :989-993
+        r.never_retry = 0;
+        r.found = 1;
+        if (level > 0) {                                                           // :1000-1006 (convergence is not looked at)
+            ptam_subpix_query sq;
+            sq.coarse_pos[0] = pr.pos[0];
+            sq.coarse_pos[1] = pr.pos[1];
+            sq.level = level;
+            sq.max_its = 8;
+            ptam_subpix_result sr;
+            subpix_refine(k->kf, sq, F->tmpl, sr);
+            r.root_pos[0] = sr.pos[0];
+            r.root_pos[1] = sr.pos[1];
+            r.sub_pix = 1;
+        } else {                                                                   // :1007-1011
+            r.root_pos[0] = pr.pos[0];
+            r.root_pos[1] = pr.pos[1];
+            r.sub_pix = 0;
+        }
+    }
+    return PTAM_OK;
+}
+
 void ptamo_gn_opts_default(ptam_gn_opts* o) {
     o->iterations = 10;
     o->nonlinear_mask = 0x211;

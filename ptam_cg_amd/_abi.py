@@ -165,6 +165,9 @@ PROTOTYPES = {
     "ba_bench_jacobian": (_i, [_vp, _i, _pd, _pd]),
     "reproject_points": (_i, [_vp, _i, _vp, _pd, _vp]),
     "refind_batch": (_i, [_vp, _vp, _pd, _i, _vp, _vp, _vp]),
+    "refinder_create": (_i, [_vp, C.POINTER(_vp)]),
+    "refinder_destroy": (_i, [_vp]),
+    "refind_pairs": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "pose_gn_state": (_i, [_vp, _i, _vp, _vp, _pd, _vp, _vp, _vp, _vp]),
     "trackmap_opts_default": (None, [_vp]),
     "tracker_create": (_i, [_vp, _i, _ppv]),

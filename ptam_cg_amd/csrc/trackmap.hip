@@ -629,6 +629,243 @@ __global__ void __launch_bounds__(256) refind_finish_kernel(int n, const ptam_pa
     out[i] = o;
 }
 
+// ---- ReFind_Common over a list of (keyframe, point) pairs through ONE PatchFinder (src/MapMaker.cc:977, :1046-1082) ----
+// The finder's state makes the list a sequence: whether pair i re-makes the template depends on the last pair that did.
+// But only inside a RUN of consecutive pairs (of those that reach the finder) with the same map point: another point always
+// re-makes it (src/PatchFinder.cc:103).  So: (1) every pair's exits, level, warp and m2 in parallel; (2) one workgroup
+// compacts the reaching pairs and walks each run with one thread — which pair re-makes, which template a kept one uses,
+// whether a rejected warp has raised mbTemplateBad since; (3) the re-made templates; (4) one wave per pair searches with its
+// template; (5) the finder's state after the last pair.
+struct RpPair {
+    ptam_pvs_point pt;
+    TmSrc src;
+    double pose[12];
+    long long id;
+    int skip, kf;
+};
+struct RpFinder {   // the state of the reference's static PatchFinder that outlives a call
+    long long pt;          // mpLastTemplateMapPoint
+    double m2[4];          // mm2LastWarpMatrix {m00, m01, m10, m11}
+    int valid, bad;        // mpLastTemplateMapPoint != NULL, mbTemplateBad
+    uint8_t tpl[64];       // mimTemplate
+};
+struct RpDev {
+    int n;
+    const RpPair* pairs;
+    const KfLevels* Ls;
+    TemplateJob* jobs;
+    ptam_patch_query* q;
+    double* m2;            // [n][4]
+    int* reach;            // the pair gets as far as the finder
+    int* detbad;           // CalcSearchLevelAndWarpMatrix rejects the warp
+    int* R;                // reaching pairs, in order
+    int* nr;
+    int* refresh;          // the finder re-makes its template for this pair
+    int* srcp;             // pair whose template this pair searches with (-1: the template the finder brought along)
+    int* dacc;             // a warp was rejected since that template was made (this pair's included)
+    int* bad;              // Finder.TemplateBad() for this pair
+    uint8_t* tm;           // [n][64]
+    ptam_template_result* tres;
+    RpFinder* st;
+    ptam_refind_result* out;
+    int* kept;
+};
+__global__ void __launch_bounds__(256) rp_prep_kernel(DevCam cam, RpDev d) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.n) return;
+    const RpPair& pr = d.pairs[i];
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = pr.pose[k];
+    const ptam_pvs_point p = pr.pt;
+    TemplateJob j;
+    j.im = nullptr;
+    j.w = j.h = 0;
+    j.search_level = -1;
+    j.cx = j.cy = 0;
+    j.wi[0] = j.wi[1] = j.wi[2] = j.wi[3] = 0;
+    ptam_patch_query qq;
+    qq.x = qq.y = 0;
+    qq.level = -1;
+    qq.range = 4;
+    int reach = 0, detbad = 0;
+    double m2[4] = {0, 0, 0, 0};
+    double X, Y, Z;
+    se3_apply(T, p.world[0], p.world[1], p.world[2], X, Y, Z);
+    if (!pr.skip && !(Z < 0.001)) {                                                     // :947-955
+        const double x = X / Z, y = Y / Z;
+        if (!(x * x + y * y > cam.largest_radius * cam.largest_radius)) {               // :957-961
+            double u, v, rr, f;
+            cam_project(cam, x, y, u, v, rr, f);
+            if (!(rr > cam.max_r) && !(u < 0 || v < 0 || u > cam.width || v > cam.height)) {   // :963-975
+                double D[4];
+                cam_derivs(cam, x, y, rr, f, D);
+                const double iz = 1.0 / Z;
+                double mr[3], md[3];
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    mr[a] = T[a * 3] * p.pixel_right_w[0] + T[a * 3 + 1] * p.pixel_right_w[1] + T[a * 3 + 2] * p.pixel_right_w[2];
+                    md[a] = T[a * 3] * p.pixel_down_w[0] + T[a * 3 + 1] * p.pixel_down_w[1] + T[a * 3 + 2] * p.pixel_down_w[2];
+                }
+                const double ax = (mr[0] - X * mr[2] * iz) * iz, ay = (mr[1] - Y * mr[2] * iz) * iz;
+                const double bx = (md[0] - X * md[2] * iz) * iz, by = (md[1] - Y * md[2] * iz) * iz;
+                j.wi[0] = D[0] * ax + D[1] * ay;
+                j.wi[2] = D[2] * ax + D[3] * ay;
+                j.wi[1] = D[0] * bx + D[1] * by;
+                j.wi[3] = D[2] * bx + D[3] * by;
+                double det = j.wi[0] * j.wi[3] - j.wi[1] * j.wi[2];
+                int l = 0;
+                while (det > 3 && l < PTAM_LEVELS - 1) {
+                    l++;
+                    det *= 0.25;
+                }
+                detbad = (det > 3 || det < 0.25) ? 1 : 0;                               // src/PatchFinder.cc:78-81
+                j.im = pr.src.im;
+                j.w = pr.src.w;
+                j.h = pr.src.h;
+                j.cx = pr.src.cx;
+                j.cy = pr.src.cy;
+                j.search_level = l;
+                template_m2(j, m2);
+                qq.x = (int)u;   // ir(): truncation
+                qq.y = (int)v;
+                qq.level = l;
+                reach = 1;
+            }
+        }
+    }
+    d.jobs[i] = j;
+    d.q[i] = qq;
+    d.reach[i] = reach;
+    d.detbad[i] = detbad;
+#pragma unroll
+    for (int k = 0; k < 4; k++) d.m2[4 * i + k] = m2[k];
+}
+__global__ void __launch_bounds__(1024) rp_scan_kernel(RpDev d) {
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < d.n; b0 += 1024) {   // stable compaction of the reaching pairs
+        const int i = b0 + tid;
+        const int f = i < d.n ? d.reach[i] : 0;
+        const int incl = wave_incl_scan_i32(f);
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        int off = base_s, tot = 0;
+        for (int w = 0; w < 16; w++) {
+            if (w < wid) off += wsum[w];
+            tot += wsum[w];
+        }
+        if (f) d.R[off + incl - 1] = i;
+        __syncthreads();
+        if (tid == 0) base_s += tot;
+        __syncthreads();
+    }
+    const int nr = base_s;
+    if (tid == 0) *d.nr = nr;
+    __threadfence_block();
+    __syncthreads();
+    const RpFinder st = *d.st;
+    const double lim = 0.07 * 0.07;
+    for (int k = tid; k < nr; k += 1024) {
+        const int i0 = d.R[k];
+        const long long id = d.pairs[i0].id;
+        const bool head = k == 0 ? !(st.valid && st.pt == id) : d.pairs[d.R[k - 1]].id != id;
+        if (!head && k != 0) continue;   // (a run is walked by the thread of its first pair)
+        int cur = head ? i0 : -1, acc = 0;
+        double l0 = st.m2[0], l1 = st.m2[1], l2 = st.m2[2], l3 = st.m2[3];
+        for (int kk = k; kk < nr; kk++) {
+            const int i = d.R[kk];
+            if (kk > k && d.pairs[i].id != id) break;
+            const double* m = d.m2 + 4 * i;
+            bool refresh = kk == k && head;
+            if (!refresh) {
+                const double ax = m[0] - l0, ay = m[2] - l2, bx = m[1] - l1, by = m[3] - l3;   // columns m2.T()[0], m2.T()[1]
+                refresh = ax * ax + ay * ay > lim || bx * bx + by * by > lim;
+            }
+            if (refresh) {
+                cur = i;
+                l0 = m[0], l1 = m[1], l2 = m[2], l3 = m[3];
+                acc = 0;
+            } else
+                acc |= d.detbad[i];
+            d.refresh[i] = refresh;
+            d.srcp[i] = cur;
+            d.dacc[i] = acc;
+        }
+    }
+}
+__global__ void __launch_bounds__(256) rp_template_kernel(RpDev d) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= d.n || !d.reach[i] || !d.refresh[i]) return;
+    ptam_template_result tr;
+    const int T = wave_make_template(d.jobs[i], lane, tr);
+    d.tm[(size_t)i * 64 + lane] = (uint8_t)T;
+    if (lane == 0) d.tres[i] = tr;
+}
+__global__ void __launch_bounds__(256) rp_search_kernel(RpDev d) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= d.n) return;
+    ptam_refind_result o;
+    o.found = 0;
+    o.level = -1;
+    o.sub_pix = 0;
+    o.never_retry = d.pairs[i].skip ? 0 : 1;
+    o.root_pos[0] = o.root_pos[1] = 0;
+    int kept = 0;
+    if (d.reach[i]) {
+        const int src = d.srcp[i], refresh = d.refresh[i];
+        const int T = src >= 0 ? d.tm[(size_t)src * 64 + lane] : d.st->tpl[lane];
+        const int bad = refresh ? d.tres[i].bad : (((src >= 0 ? d.tres[src].bad : d.st->bad) != 0) || d.dacc[i]);
+        kept = !refresh;
+        const ptam_patch_query q = d.q[i];
+        o.level = q.level;
+        if (lane == 0) d.bad[i] = bad;
+        const KfLevels& L = d.Ls[d.pairs[i].kf];
+        ptam_patch_result res;
+        wave_find_patch_coarse(L, q, !bad, T, lane, res);                              // :982-988 (range 4)
+        if (!bad && res.found) {
+            o.found = 1;
+            o.never_retry = 0;
+            if (q.level > 0) {                                                          // :1000-1006 (convergence is not looked at)
+                ptam_subpix_query sq;
+                sq.level = q.level;
+                sq.max_its = 8;
+                sq.coarse_pos[0] = res.pos[0];
+                sq.coarse_pos[1] = res.pos[1];
+                ptam_subpix_result sres;
+                wave_subpix(L, sq, T, lane, sres);
+                o.sub_pix = 1;
+                o.root_pos[0] = sres.pos[0];
+                o.root_pos[1] = sres.pos[1];
+            } else {
+                o.root_pos[0] = res.pos[0];
+                o.root_pos[1] = res.pos[1];
+            }
+        }
+    }
+    if (lane == 0) {
+        d.out[i] = o;
+        d.kept[i] = kept;
+    }
+}
+__global__ void __launch_bounds__(64) rp_state_kernel(RpDev d) {
+    const int nr = *d.nr, lane = threadIdx.x;
+    if (nr == 0) return;
+    const int last = d.R[nr - 1], src = d.srcp[last];
+    if (src >= 0) {
+        d.st->tpl[lane] = d.tm[(size_t)src * 64 + lane];
+        if (lane == 0) {
+            d.st->pt = d.pairs[last].id;
+            for (int k = 0; k < 4; k++) d.st->m2[k] = d.m2[4 * src + k];
+            d.st->valid = 1;
+        }
+    }
+    if (lane == 0) d.st->bad = d.bad[last];
+}
+
 // =================================================================================================
 // ---- a batch of frames in ONE chain of launches (ptam_track_map_frames_batch) ----
 // A process gets four hardware queues, and a tracked frame occupies its queue for the whole dependent chain (two
@@ -1255,6 +1492,119 @@ int ptam_refind_batch(ptam_ctx* ctx, const ptam_kf* kf, const double kf_pose[12]
     return PTAM_OK;
 }
 
+struct ptam_refinder {
+    ptam_ctx* ctx;
+    RpFinder* st;   // device
+};
+int ptam_refinder_create(ptam_ctx* ctx, ptam_refinder** out) {
+    ARG_TRY(ctx && out);
+    HIP_TRY(hipSetDevice(ctx->device));
+    ptam_refinder* f = new ptam_refinder();
+    f->ctx = ctx;
+    if (hipMalloc((void**)&f->st, sizeof(RpFinder)) != hipSuccess || hipMemset(f->st, 0, sizeof(RpFinder)) != hipSuccess) {
+        if (f->st) hipFree(f->st);
+        delete f;
+        ptam_set_error("ptam_refinder_create: allocation failed");
+        return PTAM_E_HIP;
+    }
+    *out = f;
+    return PTAM_OK;
+}
+int ptam_refinder_destroy(ptam_refinder* f) {
+    if (!f) return PTAM_OK;
+    hipSetDevice(f->ctx->device);
+    ptam_stream_wait(f->ctx->stream);
+    hipFree(f->st);
+    delete f;
+    return PTAM_OK;
+}
+int ptam_refind_pairs(ptam_ctx* ctx, ptam_refinder* finder, int n, const ptam_refind_pair* pairs, ptam_refind_result* out,
+                      int32_t* template_kept) {
+    ARG_TRY(ctx && finder && finder->ctx->device == ctx->device && n >= 0);
+    if (n == 0) return PTAM_OK;
+    ARG_TRY(pairs && out);
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<RpPair> hp((size_t)n);
+    std::vector<KfLevels> hl;
+    std::vector<const ptam_kf*> seen;
+    for (int i = 0; i < n; i++) {
+        const ptam_refind_pair& p = pairs[i];
+        const ptam_template_query& q = p.source;
+        ARG_TRY(p.kf && p.kf->device == ctx->device);
+        ARG_TRY(q.src_kf && q.src_level >= 0 && q.src_level < PTAM_LEVELS && q.src_kf->device == ctx->device);
+        RpPair& r = hp[(size_t)i];
+        r.pt = p.point;
+        r.src.im = q.src_kf->L.im[q.src_level];
+        r.src.w = q.src_kf->L.w[q.src_level];
+        r.src.h = q.src_kf->L.h[q.src_level];
+        r.src.cx = q.center_x;
+        r.src.cy = q.center_y;
+        std::memcpy(r.pose, p.kf_pose, 96);
+        r.id = (long long)p.point_id;
+        r.skip = p.skip != 0;
+        int k = -1;   // (lists name few keyframes, mostly in runs: a linear search from the back finds the last one at once)
+        for (int s = (int)seen.size() - 1; s >= 0; s--)
+            if (seen[(size_t)s] == p.kf) {
+                k = s;
+                break;
+            }
+        if (k < 0) {
+            k = (int)seen.size();
+            seen.push_back(p.kf);
+            hl.push_back(p.kf->L);
+        }
+        r.kf = k;
+    }
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    const size_t N = (size_t)n;
+    const size_t o_pairs = take(N * sizeof(RpPair)), o_ls = take(hl.size() * sizeof(KfLevels)), o_jobs = take(N * sizeof(TemplateJob)),
+                 o_q = take(N * sizeof(ptam_patch_query)), o_m2 = take(N * 32), o_reach = take(N * 4), o_det = take(N * 4), o_R = take(N * 4),
+                 o_nr = take(4), o_ref = take(N * 4), o_src = take(N * 4), o_dacc = take(N * 4), o_bad = take(N * 4), o_tm = take(N * 64),
+                 o_tr = take(N * sizeof(ptam_template_result)), o_out = take(N * sizeof(ptam_refind_result)), o_kept = take(N * 4);
+    void* sc;
+    int rc = ctx_scratch(ctx, off, &sc);
+    if (rc) return rc;
+    char* b = (char*)sc;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(b + o_pairs, hp.data(), N * sizeof(RpPair), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b + o_ls, hl.data(), hl.size() * sizeof(KfLevels), hipMemcpyHostToDevice, st));
+    RpDev d;
+    d.n = n;
+    d.pairs = (const RpPair*)(b + o_pairs);
+    d.Ls = (const KfLevels*)(b + o_ls);
+    d.jobs = (TemplateJob*)(b + o_jobs);
+    d.q = (ptam_patch_query*)(b + o_q);
+    d.m2 = (double*)(b + o_m2);
+    d.reach = (int*)(b + o_reach);
+    d.detbad = (int*)(b + o_det);
+    d.R = (int*)(b + o_R);
+    d.nr = (int*)(b + o_nr);
+    d.refresh = (int*)(b + o_ref);
+    d.srcp = (int*)(b + o_src);
+    d.dacc = (int*)(b + o_dacc);
+    d.bad = (int*)(b + o_bad);
+    d.tm = (uint8_t*)(b + o_tm);
+    d.tres = (ptam_template_result*)(b + o_tr);
+    d.st = finder->st;
+    d.out = (ptam_refind_result*)(b + o_out);
+    d.kept = (int*)(b + o_kept);
+    hipLaunchKernelGGL(rp_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ctx->cam, d);
+    hipLaunchKernelGGL(rp_scan_kernel, dim3(1), dim3(1024), 0, st, d);
+    hipLaunchKernelGGL(rp_template_kernel, dim3((n + 3) / 4), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(rp_search_kernel, dim3((n + 3) / 4), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(rp_state_kernel, dim3(1), dim3(64), 0, st, d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d.out, N * sizeof(ptam_refind_result), hipMemcpyDeviceToHost, st));
+    if (template_kept) HIP_TRY(hipMemcpyAsync(template_kept, d.kept, N * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ptam_stream_wait(st));   // (also keeps the staging vectors alive until their pageable copies have been staged)
+    return PTAM_OK;
+}
+
 // Measurement helper (like ptam_ba_bench_jacobian): the "replicas" axis of the tracking path driven natively.
 // n independent trackers — each with its own context (stream, scratch, mailbox), map and keyframes — are run by n host
 // threads, frames_each frames per thread: per frame the two permutations are handed over (ptam_tracker_set_shuffle) and
@@ -1362,6 +1712,11 @@ void trackmap_preload_kernels() {
     ptam_preload((const void*)refind_prep_kernel);
     ptam_preload((const void*)refind_mask_kernel);
     ptam_preload((const void*)refind_finish_kernel);
+    ptam_preload((const void*)rp_prep_kernel);
+    ptam_preload((const void*)rp_scan_kernel);
+    ptam_preload((const void*)rp_template_kernel);
+    ptam_preload((const void*)rp_search_kernel);
+    ptam_preload((const void*)rp_state_kernel);
     ptam_preload((const void*)tm_select_kernel);
     ptam_preload((const void*)tm_pyr_pvs_kernel<PTAM_HALFSAMPLE_R>);
     ptam_preload((const void*)tm_pyr_pvs_kernel<PTAM_HALFSAMPLE_T>);

@@ -37,6 +37,9 @@ PVS_RESULT_DT = np.dtype([("proj", PROJECTION_DT), ("warp_inverse", "<f8", (4,))
 BA_TRIAL_DT = np.dtype([("lambda", "<f8"), ("sigma_sq", "<f8"), ("err_old", "<f8"), ("err_new", "<f8"),
                         ("sum_sq_update", "<f8"), ("n_bad", "<i4"), ("accepted", "<i4")])
 REFIND_RESULT_DT = np.dtype([("found", "<i4"), ("level", "<i4"), ("sub_pix", "<i4"), ("never_retry", "<i4"), ("root_pos", "<f8", (2,))])
+REFIND_PAIR_DT = np.dtype([("kf", "<u8"), ("kf_pose", "<f8", (12,)), ("point", PVS_POINT_DT), ("source", TEMPLATE_QUERY_DT),
+                           ("point_id", "<i8"), ("skip", "<i4"), ("pad_", "<i4")])
+assert REFIND_PAIR_DT.itemsize == 248
 TRACKMAP_OPTS_DT = np.dtype([("try_coarse", "<i4"), ("coarse_min", "<u4"), ("coarse_max", "<u4"), ("coarse_range", "<u4"),
                              ("coarse_subpix_its", "<i4"), ("max_patches", "<i4"), ("estimator", "<i4"), ("pad_", "<i4")])
 TRACKMAP_RESULT_DT = np.dtype([("pose", "<f8", (12,)), ("did_coarse", "<i4"), ("n_pvs", "<i4", (4,)), ("attempted", "<i4", (4,)),
@@ -354,6 +357,48 @@ class DevBuf:
         if self.p:
             self.ctx.lib.dev_free(self.ctx.h, self.p)
             self.p = None
+
+
+class ReFinder:
+    """MapMaker::ReFind_Common through ONE PatchFinder (`static PatchFinder Finder`, src/MapMaker.cc:977), pair after pair in
+    the caller's order (ReFindNewlyMade :1046-1066, ReFindFromFailureQueue :1070-1082): ptam_refinder_* / ptam_refind_pairs"""
+
+    def __init__(self, ctx):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.h = C.c_void_p()
+        ctx._check(self.lib.refinder_create(ctx.h, C.byref(self.h)), "refinder_create")
+
+    @staticmethod
+    def pairs(kfs, kf_poses, world, pixel_right_w, pixel_down_w, src_kfs, src_levels, centers, point_ids, skip=None):
+        """one record per (keyframe, point) pair, all arguments per pair"""
+        n = len(kfs)
+        raw = lambda k: k.h.value if hasattr(k.h, "value") else int(k.h)
+        p = np.zeros(n, dtype=REFIND_PAIR_DT)
+        p["kf"] = [raw(k) for k in kfs]
+        p["kf_pose"] = np.asarray(kf_poses, dtype=np.float64).reshape(n, 12)
+        p["point"]["world"], p["point"]["pixel_right_w"], p["point"]["pixel_down_w"] = world, pixel_right_w, pixel_down_w
+        src = [src_kfs] * n if isinstance(src_kfs, KeyFrame) else list(src_kfs)
+        p["source"]["src_kf"] = [raw(k) for k in src]
+        p["source"]["src_level"] = src_levels
+        c = np.asarray(centers, dtype=np.int32).reshape(n, 2)
+        p["source"]["center_x"], p["source"]["center_y"] = c[:, 0], c[:, 1]
+        p["point_id"] = point_ids
+        if skip is not None:
+            p["skip"] = skip
+        return p
+
+    def find(self, pairs):
+        """-> (results REFIND_RESULT_DT[n], template_kept int32[n])"""
+        pairs = np.ascontiguousarray(pairs, dtype=REFIND_PAIR_DT)
+        out = np.zeros(len(pairs), dtype=REFIND_RESULT_DT)
+        kept = np.zeros(len(pairs), dtype=np.int32)
+        self.ctx._check(self.lib.refind_pairs(self.ctx.h, self.h, len(pairs), _ptr(pairs), _ptr(out), _ptr(kept)), "refind_pairs")
+        return out, kept
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.refinder_destroy(self.h)
+            self.h = None
 
 
 class Tracker:

@@ -23,8 +23,76 @@ def small_pair():
     return np.ascontiguousarray(a[100:228, 200:360]), np.ascontiguousarray(b[100:228, 200:360])
 
 
+def moved(pose, dz=0.0, dx=0.0):
+    q = np.array(pose, dtype=np.float64).copy()
+    q[9] += dx
+    q[11] += dz
+    return q
+
+
+def refind_pairs_fixture(a, b):
+    """MapMaker::ReFind_Common as ReFindNewlyMade runs it (src/MapMaker.cc:1046-1066): one map point after another, each
+    against a row of keyframes — here frame B at eight poses: the true one, three nearly the same (the finder keeps its
+    template), one pushed towards the scene (re-made; some warps rejected), back again, and two more nearly the same.  The
+    first four points have their pixel vectors scaled so that the warp's determinant sits just above 0.25 at the first pose
+    and just below at the second: CalcSearchLevelAndWarpMatrix rejects it there while the template is kept, and the stale
+    mbTemplateBad sends that pair and the following kept ones into never-retry (src/PatchFinder.cc:78-81, 98-127).  A few
+    pairs carry the skip flag (:947-948).  Two calls, the finder's state carried from the first into the second (the last
+    point of the first call is the first of the second)."""
+    la, lb = npo.make_keyframe_lite(a), npo.make_keyframe_lite(b)
+    ncam = npo.Camera(CAM, (a.shape[1], a.shape[0]))
+    rc = synth.make_trackmap_case(la, counts=(160, 60, 12, 0), size=(a.shape[1], a.shape[0]), height=1.5, n_junk=16, seed=0x5EED000B)
+    base = np.array(rc["cur_pose"], dtype=np.float64)
+    z = float(np.median(rc["world"] @ base[6:9] + base[11]))
+    poses = [base, moved(base, dz=3e-4 * z), moved(base, dx=2e-4 * z), moved(base, dz=6e-4 * z), moved(base, dz=-0.3 * z),
+             moved(base, dz=3e-4 * z), moved(base, dx=-2e-4 * z), moved(base, dz=1e-4 * z)]
+    rng = np.random.default_rng(0x5EED000C)
+    pts = list(rng.choice(len(rc["world"]), size=28, replace=False))
+    prw, pdw = rc["pixel_right_w"].copy(), rc["pixel_down_w"].copy()
+    pr0 = npo.project_points(ncam, base, rc["world"])
+    n_edge = 0
+    for i in pts:          # the first four level-0 points in view: determinant 0.2501 at the true pose
+        if n_edge == 4 or not pr0["in_image"][i]:
+            continue
+        R = base[:9].reshape(3, 3)
+        M = np.stack([prw[i:i + 1] @ R.T, pdw[i:i + 1] @ R.T], axis=1)
+        W = np.einsum("nab,nkb->nak", pr0["derivs"][i:i + 1], npo.motion_to_plane(pr0["cam"][i:i + 1], M))[0]
+        det = W[0, 0] * W[1, 1] - W[0, 1] * W[1, 0]
+        if not (0.25 < det <= 3):
+            continue
+        s_ = np.sqrt(0.25005 / det)
+        prw[i] *= s_
+        pdw[i] *= s_
+        n_edge += 1
+    pairs = []
+    for i in pts:
+        for k, pose in enumerate(poses):
+            pairs.append(dict(levels_k=lb, pose_k=pose, world=rc["world"][i], pixel_right_w=prw[i], pixel_down_w=pdw[i],
+                              src_image=la[int(rc["src_level"][i])]["im"], center=rc["center"][i], point_id=int(i),
+                              skip=int(rng.random() < 0.06), src_level=int(rc["src_level"][i])))
+    split = 8 * 17 + 3          # the first call ends in the middle of a point's row
+    state = {}
+    rr = npo.refind_pairs(ncam, pairs[:split], state) + npo.refind_pairs(ncam, pairs[split:], state)
+    np.savez_compressed(os.path.join(OUT, "refind_pairs_160x128.npz"), im_a=a, im_b=b, split=split,
+                        pose=np.array([p["pose_k"] for p in pairs]), world=np.array([p["world"] for p in pairs]),
+                        pixel_right_w=np.array([p["pixel_right_w"] for p in pairs]), pixel_down_w=np.array([p["pixel_down_w"] for p in pairs]),
+                        src_level=np.array([p["src_level"] for p in pairs], np.int32), center=np.array([p["center"] for p in pairs], np.int32),
+                        point_id=np.array([p["point_id"] for p in pairs], np.int64), skip=np.array([p["skip"] for p in pairs], np.int32),
+                        found=np.array([x["found"] for x in rr], np.int32), level=np.array([x["level"] for x in rr], np.int32),
+                        sub_pix=np.array([x["sub_pix"] for x in rr], np.int32), never_retry=np.array([x["never_retry"] for x in rr], np.int32),
+                        root_pos=np.array([x["root_pos"] for x in rr]), kept=np.array([x["kept"] for x in rr], np.int32))
+    kept = np.array([x["kept"] for x in rr])
+    lvl = np.array([x["level"] for x in rr])
+    fnd = np.array([x["found"] for x in rr])
+    print("refind pairs:", len(rr), "pairs, reached the finder", int((lvl >= 0).sum()), "template kept", int(kept.sum()), "found", int(fnd.sum()),
+          "kept but not searched (stale mbTemplateBad or rejected warp)", int(((kept == 1) & (fnd == 0)).sum()))
+
+
 def main():
     a, b = small_pair()
+    if len(sys.argv) > 1 and sys.argv[1] == "refind_pairs":   # (only this fixture)
+        refind_pairs_fixture(a, b)
+        return
     # --- keyframe: both halfSample variants ---
     for v in ("R", "T"):
         lv = npo.make_keyframe_lite(a, v)
@@ -101,6 +169,7 @@ def main():
                         level=np.array([x["level"] for x in rr], np.int32), sub_pix=np.array([x["sub_pix"] for x in rr], np.int32),
                         never_retry=np.array([x["never_retry"] for x in rr], np.int32), root_pos=np.array([x["root_pos"] for x in rr]))
     print("refind found", sum(x["found"] for x in rr), "of", len(rr), "levels", np.bincount(np.array([x["level"] for x in rr]) + 1))
+    refind_pairs_fixture(a, b)
     # --- pose Gauss-Newton (fine and coarse schedules) ---
     cam = npo.Camera(CAM, (640, 480))
     # --- PVS loop ---

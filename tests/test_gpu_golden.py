@@ -47,3 +47,7 @@ def test_keyframe_rest(hip):
 
 def test_refind(hip):
     G.check_refind(hip)
+
+
+def test_refind_pairs(hip):
+    G.check_refind_pairs(hip)

@@ -617,6 +617,56 @@ def test_refind_common_matches_oracle(hip, oracle):
     assert out["oracle"][0]["found"].sum() > 1000 and out["oracle"][1]["found"].sum() < out["oracle"][0]["found"].sum()
 
 
+def test_refind_pairs_through_one_patchfinder_matches_oracle(hip, oracle):
+    """MapMaker::ReFind_Common in the reference's call patterns (src/MapMaker.cc:1046-1082; VERDICT r2 missing 3) through ONE
+    PatchFinder (:977) whose state outlives the calls: (1) ReFindNewlyMade — 60 new points, each against twelve keyframes in
+    turn (frame B at poses that are mostly a fraction of a millimetre apart, so the finder keeps its template, plus one
+    pushed towards the scene and one far off); (2) ReFindFromFailureQueue — (keyframe, point) pairs sorted by keyframe, a
+    different point every time: every template re-made; (3) the last point again against two keyframes: continues the
+    previous call's state."""
+    from tests import golden_util as G
+    res = {}
+    for name, lib in (("hip", hip), ("oracle", oracle)):
+        ctx = host.Context(lib=lib)
+        a, b = synth.make_frame_pair()
+        kfa = host.KeyFrame(ctx).MakeKeyFrame_Lite(a)
+        kfb = host.KeyFrame(ctx).MakeKeyFrame_Lite(b)
+        case = synth.make_trackmap_case([kfa.level(l) for l in range(4)])
+        base = np.array(case["cur_pose"], dtype=np.float64)
+        z = float(np.median(case["world"] @ base[6:9] + base[11]))
+
+        def moved(dz=0.0, dx=0.0):
+            q = base.copy()
+            q[9] += dx
+            q[11] += dz
+            return q
+        poses = [base, moved(dz=2e-4 * z), moved(dx=1e-4 * z), moved(dz=-0.25 * z), moved(dz=2e-4 * z), moved(dz=4e-4 * z), case["pose_in"],
+                 moved(dx=-1e-4 * z), base, moved(dz=1e-4 * z), moved(dz=0.4 * z), moved(dz=0.4002 * z)]
+        rng = np.random.default_rng(77)
+        pts = rng.choice(len(case["world"]), size=60, replace=False)
+        idx = np.repeat(pts, len(poses))
+        pp = np.tile(np.array(poses), (len(pts), 1))
+        args = lambda ix: (case["world"][ix], case["pixel_right_w"][ix], case["pixel_down_w"][ix], kfa, case["src_level"][ix], case["center"][ix], ix)
+        rf = host.ReFinder(ctx)
+        out = [rf.find(host.ReFinder.pairs([kfb] * len(idx), pp, *args(idx), skip=(rng.random(len(idx)) < 0.05).astype(np.int32)))]
+        # failure queue: sorted by keyframe, then point
+        q_pts = np.sort(rng.choice(len(case["world"]), size=150, replace=False))
+        q_kfs = [kfa] * 70 + [kfb] * 80
+        q_pose = np.array([case["pose_in"]] * 70 + [base] * 80)
+        out.append(rf.find(host.ReFinder.pairs(q_kfs, q_pose, *args(q_pts))))
+        last = q_pts[-1:]
+        out.append(rf.find(host.ReFinder.pairs([kfb, kfb], np.array([base, moved(dz=1e-4 * z)]), *args(np.repeat(last, 2)))))
+        res[name] = out
+    for (rh, kh), (ro, ko) in zip(res["hip"], res["oracle"]):
+        assert np.array_equal(kh, ko)
+        G.assert_refind_equal(rh, ro["found"], ro["level"], ro["sub_pix"], ro["never_retry"], ro["root_pos"])
+    k0 = res["oracle"][0][1]
+    assert 0.4 * len(k0) < k0.sum() < 0.9 * len(k0)             # most consecutive keyframes keep the template
+    assert res["oracle"][1][1].sum() == 0                        # a different point every time: never kept
+    assert list(res["oracle"][2][1]) == [1, 1]                   # the state came along from the previous call
+    assert res["oracle"][0][0]["found"].sum() > 200
+
+
 @pytest.mark.parametrize("cams,pts,lo,hi", [(10, 400, 20, 120), (6, 300, 5, 290), (8, 500, 3, 70), (12, 1000, 100, 101)],
                          ids=lambda v: str(v))
 def test_bundle_points_without_measurements(hip, oracle, cams, pts, lo, hi):

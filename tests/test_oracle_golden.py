@@ -45,3 +45,7 @@ def test_keyframe_rest(oracle):
 
 def test_refind(oracle):
     G.check_refind(oracle)
+
+
+def test_refind_pairs(oracle):
+    G.check_refind_pairs(oracle)
