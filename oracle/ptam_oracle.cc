@@ -1903,6 +1903,350 @@ int ptamo_reproject_points(ptamo_ctx* c, int n, const double* world, const doubl
     return PTAM_OK;
 }
 
+// ---- Tracker::TrackMap src/Tracker.cc:442-696, the whole frame, statement by statement — the twin of the product's resident
+// chain (ptam_tracker_* / ptam_track_map) behind the same entry points, so that tests and bench.py's cpu_baseline drive the
+// SAME chain through either library.  The map's TrackerData (include/Tracker.h:42-67) live in the tracker object: what
+// outlives a frame is every point's PatchFinder (template, sums, mbTemplateBad, last warp — src/PatchFinder.cc:98-127).
+// std::random_shuffle (:483-484, :597-600) is replaced, as in the product's interface, by two caller-provided permutations.
+struct ptamo_tracker {
+    ptamo_ctx* ctx = nullptr;
+    int cap = 0, n = 0;
+    std::vector<ptam_pvs_point> pts;
+    std::vector<ptam_template_query> src;
+    std::vector<int> sh_levels, sh_fine;
+    struct Finder {
+        bool valid = false, bad = false;
+        double m2[4] = {0, 0, 0, 0};
+        uint8_t tmpl[64] = {0};
+    };
+    std::vector<Finder> finder;
+    std::vector<ptam_trackmap_meas> iteration_set;
+};
+namespace {
+struct TmTD {   // TrackerData of one map point, the fields TrackMap touches
+    int idx = 0, level = 0, searched_level = 0;
+    double wi[4] = {0, 0, 0, 0};
+    ptam_projection st;
+    bool found = false, did_subpix = false;
+    double v2_found[2] = {0, 0};
+};
+}   // namespace
+void ptamo_trackmap_opts_default(ptam_trackmap_opts* o) {
+    if (!o) return;
+    o->try_coarse = 1;
+    o->coarse_min = 20;
+    o->coarse_max = 60;
+    o->coarse_range = 30;
+    o->coarse_subpix_its = 8;
+    o->max_patches = 1000;
+    o->estimator = PTAM_EST_TUKEY;
+    o->pad_ = 0;
+}
+int ptamo_tracker_create(ptamo_ctx* c, int max_points, ptamo_tracker** out) {
+    if (!c || !out || max_points < 1) return PTAM_E_ARG;
+    ptamo_tracker* t = new ptamo_tracker();
+    t->ctx = c;
+    t->cap = max_points;
+    *out = t;
+    return PTAM_OK;
+}
+int ptamo_tracker_destroy(ptamo_tracker* t) {
+    delete t;
+    return PTAM_OK;
+}
+int ptamo_tracker_set_map(ptamo_tracker* t, int n, const ptam_pvs_point* pts, const ptam_template_query* src) {
+    if (!t || n < 0 || n > t->cap || (n > 0 && (!pts || !src))) return PTAM_E_ARG;
+    t->pts.assign(pts, pts + n);
+    t->src.assign(src, src + n);
+    t->finder.assign((size_t)n, ptamo_tracker::Finder());   // new TrackerData, new PatchFinders
+    if (n != t->n) {
+        t->sh_levels.resize((size_t)n);
+        t->sh_fine.resize((size_t)n);
+        for (int i = 0; i < n; i++) t->sh_levels[(size_t)i] = t->sh_fine[(size_t)i] = i;
+    }
+    t->n = n;
+    return PTAM_OK;
+}
+int ptamo_tracker_set_shuffle(ptamo_tracker* t, const int32_t* a, const int32_t* b) {
+    if (!t || !a || !b) return PTAM_E_ARG;
+    t->sh_levels.assign(a, a + t->n);
+    t->sh_fine.assign(b, b + t->n);
+    return PTAM_OK;
+}
+static int pose_gn_impl(ptamo_ctx* c, int n, const ptam_pose_meas* meas, const ptam_projection* entry, double pose[12],
+                        const ptam_gn_opts* opts, int32_t* outlier_flags, double* updates_out, ptam_projection* state_out);
+// Tracker::SearchForPoints src/Tracker.cc:867-912
+static int tm_search_for_points(ptamo_tracker* t, const ptamo_kf* kf, std::vector<TmTD*>& set, unsigned range, int subpix_its,
+                                int attempted[4], int found_cnt[4], int* n_kept) {
+    int n_found = 0;
+    for (TmTD* td : set) {
+        ptamo_tracker::Finder& F = t->finder[(size_t)td->idx];
+        const ptam_template_query& sq_ = t->src[(size_t)td->idx];
+        // Finder.MakeTemplateCoarseCont(TD.Point)  :873, src/PatchFinder.cc:98-127
+        const double* W = td->wi;
+        const double det = W[0] * W[3] - W[2] * W[1];
+        const double inv = 1.0 / det;
+        const double sc = (double)(1 << td->level);
+        const double m2[4] = {W[3] * inv * sc, -W[1] * inv * sc, -W[2] * inv * sc, W[0] * inv * sc};   // {m00, m01, m10, m11}
+        bool need = !F.valid;
+        for (int col = 0; !need && col < 2; col++) {
+            const double dx = m2[col] - F.m2[col], dy = m2[2 + col] - F.m2[2 + col];
+            if (dx * dx + dy * dy > 0.07 * 0.07) need = true;
+        }
+        if (need) {
+            const ptamo_kf* sk = reinterpret_cast<const ptamo_kf*>(sq_.src_kf);
+            ptam_template_result tr;
+            std::memset(&tr, 0, sizeof tr);
+            make_template_coarse_cont(sk->kf.lev[sq_.src_level], sq_.center_x, sq_.center_y, td->level, W, F.tmpl, tr);
+            F.bad = tr.bad != 0;
+            F.valid = true;
+            for (int q = 0; q < 4; q++) F.m2[q] = m2[q];
+        } else
+            ++*n_kept;
+        td->searched_level = F.bad ? -1 : td->level;
+        if (F.bad) {                                                   // :874-878
+            td->st.in_image = 0;
+            td->found = false;
+            continue;
+        }
+        attempted[td->level]++;                                        // :880
+        ptam_patch_query q;
+        q.x = (int)td->st.image[0];                                    // ir(TD.v2Image) :882
+        q.y = (int)td->st.image[1];
+        q.level = td->level;
+        q.range = range;
+        ptam_patch_result pr;
+        find_patch_coarse(kf->kf, q, F.tmpl, pr);
+        if (!pr.found) {                                               // :884-887
+            td->found = false;
+            continue;
+        }
+        td->found = true;
+        found_cnt[td->level]++;
+        n_found++;
+        if (subpix_its > 0) {                                          // :896-906
+            td->did_subpix = true;
+            ptam_subpix_query sq;
+            sq.coarse_pos[0] = pr.pos[0];
+            sq.coarse_pos[1] = pr.pos[1];
+            sq.level = td->level;
+            sq.max_its = subpix_its;
+            ptam_subpix_result sr;
+            subpix_refine(kf->kf, sq, F.tmpl, sr);
+            if (!sr.converged) {
+                td->found = false;
+                found_cnt[td->level]--;
+                n_found--;
+                continue;
+            }
+            td->v2_found[0] = sr.pos[0];
+            td->v2_found[1] = sr.pos[1];
+        } else {
+            td->v2_found[0] = pr.pos[0];
+            td->v2_found[1] = pr.pos[1];
+            td->did_subpix = false;
+        }
+    }
+    return n_found;
+}
+int ptamo_track_map(ptamo_tracker* t, const ptamo_kf* kf, const double pose_in[12], const ptam_trackmap_opts* opts, ptam_trackmap_result* out) {
+    if (!t || !kf || !pose_in || !out) return PTAM_E_ARG;
+    ptam_trackmap_opts o;
+    if (opts)
+        o = *opts;
+    else
+        ptamo_trackmap_opts_default(&o);
+    ptamo_ctx* c = t->ctx;
+    ATANCamera cam(c->c.cam);
+    const int n = t->n;
+    double pose[12];
+    std::memcpy(pose, pose_in, sizeof pose);
+    int attempted[4] = {0, 0, 0, 0}, found_cnt[4] = {0, 0, 0, 0}, n_kept = 0;
+    // ---- PVS loop :453-478 ----
+    std::vector<ptam_pvs_result> pvs((size_t)std::max(n, 1));
+    ptamo_track_pvs(c, n, t->pts.data(), pose, pvs.data(), nullptr);
+    std::vector<TmTD> tds((size_t)n);
+    std::vector<char> in_pvs((size_t)n, 0);
+    for (int i = 0; i < n; i++) {
+        if (pvs[(size_t)i].level < 0) {
+            if (pvs[(size_t)i].proj.in_image) t->finder[(size_t)i].bad = true;   // CalcSearchLevelAndWarpMatrix's -1: mbTemplateBad = true
+            continue;
+        }
+        TmTD& td = tds[(size_t)i];
+        td.idx = i;
+        td.level = td.searched_level = pvs[(size_t)i].level;
+        std::memcpy(td.wi, pvs[(size_t)i].warp_inverse, sizeof td.wi);
+        td.st = pvs[(size_t)i].proj;
+        in_pvs[(size_t)i] = 1;
+    }
+    std::vector<TmTD*> av[4];   // avPVS[l], shuffled (:483-484) = in the order of the caller's permutation
+    for (int k = 0; k < n; k++) {
+        const int i = t->sh_levels[(size_t)k];
+        if (i >= 0 && i < n && in_pvs[(size_t)i]) av[tds[(size_t)i].level].push_back(&tds[(size_t)i]);
+    }
+    int n_pvs[4];
+    for (int l = 0; l < 4; l++) n_pvs[l] = (int)av[l].size();
+    std::vector<TmTD*> next, iteration_set;
+    bool did_coarse = false;
+    const size_t cmax = o.coarse_max;
+    if (o.try_coarse && av[3].size() + av[2].size() > o.coarse_min) {                  // :519
+        if (av[3].size() <= cmax) {                                                     // :523-530
+            next = av[3];
+            av[3].clear();
+        } else {
+            next.assign(av[3].begin(), av[3].begin() + (long)cmax);
+            av[3].erase(av[3].begin(), av[3].begin() + (long)cmax);
+        }
+        if (next.size() < cmax) {                                                       // :533-545
+            const size_t more = cmax - next.size();
+            if (av[2].size() <= more) {
+                next = av[2];                                                           // :538 (an assignment in the reference)
+                av[2].clear();
+            } else {
+                next.insert(next.end(), av[2].begin(), av[2].begin() + (long)more);
+                av[2].erase(av[2].begin(), av[2].begin() + (long)more);
+            }
+        }
+        const int n_found = tm_search_for_points(t, kf, next, o.coarse_range, o.coarse_subpix_its, attempted, found_cnt, &n_kept);
+        iteration_set = next;                                                           // :550
+        if ((unsigned)n_found >= o.coarse_min) {                                        // :551
+            did_coarse = true;
+            std::vector<TmTD*> f;
+            for (TmTD* td : iteration_set)
+                if (td->found) f.push_back(td);
+            std::vector<ptam_pose_meas> meas(f.size());
+            std::vector<ptam_projection> entry(f.size()), st(f.size());
+            for (size_t k = 0; k < f.size(); k++) {
+                std::memcpy(meas[k].world, t->pts[(size_t)f[k]->idx].world, sizeof meas[k].world);
+                meas[k].found[0] = f[k]->v2_found[0];
+                meas[k].found[1] = f[k]->v2_found[1];
+                meas[k].sqrt_inv_noise = 1.0 / (1 << f[k]->level);
+                entry[k] = f[k]->st;
+            }
+            ptam_gn_opts g;
+            ptamo_gn_opts_default(&g);
+            g.nonlinear_mask = 0x3ff;        // :552-568: ten iterations, every one non-linear
+            g.override_sigma_sq = 1.0;       // :565
+            g.mark_outliers_iter = -1;
+            g.estimator = o.estimator;
+            pose_gn_impl(c, (int)f.size(), meas.data(), entry.data(), pose, &g, nullptr, nullptr, st.data());
+            for (size_t k = 0; k < f.size(); k++) {   // the TrackerData the loop leaves behind
+                std::memcpy(f[k]->st.cam, st[k].cam, sizeof st[k].cam);
+                std::memcpy(f[k]->st.image, st[k].image, sizeof st[k].image);
+                std::memcpy(f[k]->st.derivs, st[k].derivs, sizeof st[k].derivs);
+            }
+        }
+    }
+    const int n_coarse = (int)iteration_set.size();
+    const unsigned fine_range = did_coarse ? 5 : 10;                                    // :572
+    const SE3 Tcur = se3_from12(pose);
+    auto reproject = [&](std::vector<TmTD*>& lst) {   // TrackerData::Project with bFound == false: the derivatives stay
+        const SE3 T = se3_from12(pose);
+        for (TmTD* td : lst) {
+            TrackerData x;
+            std::memcpy(x.world, t->pts[(size_t)td->idx].world, sizeof x.world);
+            std::memcpy(x.v2Image, td->st.image, sizeof x.v2Image);
+            x.Project(T, cam);
+            std::memcpy(td->st.cam, x.v3Cam, sizeof x.v3Cam);
+            std::memcpy(td->st.image, x.v2Image, sizeof x.v2Image);
+            td->st.in_image = x.bInImage;
+        }
+    };
+    (void)Tcur;
+    std::vector<TmTD*> top = av[3];                                                     // :574-581
+    reproject(top);
+    tm_search_for_points(t, kf, top, fine_range, 8, attempted, found_cnt, &n_kept);
+    iteration_set.insert(iteration_set.end(), top.begin(), top.end());
+    std::vector<TmTD*> fine;                                                            // :586-590
+    for (int l = 2; l >= 0; l--) fine.insert(fine.end(), av[l].begin(), av[l].end());
+    const int n_use = std::max(0, o.max_patches - (int)iteration_set.size());           // :593-596
+    if ((int)fine.size() > n_use) {                                                     // :597-600: shuffle, then chop
+        std::vector<char> member((size_t)n, 0);
+        for (TmTD* td : fine) member[(size_t)td->idx] = 1;
+        std::vector<TmTD*> chopped;
+        for (int k = 0; k < n && (int)chopped.size() < n_use; k++) {
+            const int i = t->sh_fine[(size_t)k];
+            if (i >= 0 && i < n && member[(size_t)i]) chopped.push_back(&tds[(size_t)i]);
+        }
+        fine.swap(chopped);
+    }
+    if (did_coarse) reproject(fine);                                                    // :603-605
+    tm_search_for_points(t, kf, fine, fine_range, 0, attempted, found_cnt, &n_kept);
+    iteration_set.insert(iteration_set.end(), fine.begin(), fine.end());
+    // ---- fine pose loop :613-643 ----
+    std::vector<TmTD*> f;
+    for (TmTD* td : iteration_set)
+        if (td->found) f.push_back(td);
+    std::vector<int32_t> outl(f.size(), 0);
+    double dsum = 0, dsq = 0;
+    if (!f.empty()) {
+        std::vector<ptam_pose_meas> meas(f.size());
+        std::vector<ptam_projection> entry(f.size()), st(f.size());
+        for (size_t k = 0; k < f.size(); k++) {
+            std::memcpy(meas[k].world, t->pts[(size_t)f[k]->idx].world, sizeof meas[k].world);
+            meas[k].found[0] = f[k]->v2_found[0];
+            meas[k].found[1] = f[k]->v2_found[1];
+            meas[k].sqrt_inv_noise = 1.0 / (1 << f[k]->level);
+            entry[k] = f[k]->st;
+        }
+        ptam_gn_opts g;
+        ptamo_gn_opts_default(&g);
+        g.estimator = o.estimator;
+        pose_gn_impl(c, (int)f.size(), meas.data(), entry.data(), pose, &g, outl.data(), nullptr, st.data());
+        for (size_t k = 0; k < f.size(); k++) {                                         // :680-690
+            dsum += st[k].cam[2];
+            dsq += st[k].cam[2] * st[k].cam[2];
+        }
+    }
+    t->iteration_set.assign(iteration_set.size(), ptam_trackmap_meas());
+    size_t kf_ = 0;
+    for (size_t s_ = 0; s_ < iteration_set.size(); s_++) {
+        const TmTD* td = iteration_set[s_];
+        ptam_trackmap_meas& m = t->iteration_set[s_];
+        std::memset(&m, 0, sizeof m);
+        m.point = td->idx;
+        m.level = td->searched_level;
+        m.found = td->found;
+        m.did_subpix = td->did_subpix;
+        if (td->found) {
+            m.v2_found[0] = td->v2_found[0];
+            m.v2_found[1] = td->v2_found[1];
+            m.outlier = outl[kf_++];
+        }
+    }
+    std::memset(out, 0, sizeof *out);
+    std::memcpy(out->pose, pose, sizeof pose);
+    out->did_coarse = did_coarse;
+    for (int l = 0; l < 4; l++) {
+        out->n_pvs[l] = n_pvs[l];
+        out->attempted[l] = attempted[l];
+        out->found[l] = found_cnt[l];
+    }
+    out->n_coarse = n_coarse;
+    out->n_top = (int)top.size();
+    out->n_fine = (int)fine.size();
+    out->n_meas = (int)f.size();
+    out->depth_n = (int)f.size();
+    out->templates_reused = n_kept;
+    out->depth_sum = dsum;
+    out->depth_sum_sq = dsq;
+    return PTAM_OK;
+}
+// (the product's frame pointer is a device address; here it is the host image, stride == width)
+int ptamo_track_map_frame(ptamo_tracker* t, ptamo_kf* cur, const uint8_t* frame, const double pose_in[12], const ptam_trackmap_opts* opts,
+                          ptam_trackmap_result* out) {
+    if (!t || !cur || !frame) return PTAM_E_ARG;
+    const int rc = ptamo_make_keyframe_lite(t->ctx, cur, frame, cur->w);
+    return rc ? rc : ptamo_track_map(t, cur, pose_in, opts, out);
+}
+int ptamo_tracker_read_iteration_set(ptamo_tracker* t, ptam_trackmap_meas* out, int cap, int* n) {
+    if (!t || !n) return PTAM_E_ARG;
+    *n = (int)t->iteration_set.size();
+    if (out)
+        for (int i = 0; i < *n && i < cap; i++) out[i] = t->iteration_set[(size_t)i];
+    return PTAM_OK;
+}
+
 int ptamo_calc_pose_update(ptamo_ctx*, int n, const ptam_pose_update_meas* meas, double override_sigma_sq,
                            int estimator, double prior, double mu_out[6], int32_t* flags) {
     std::vector<TrackerData> vTD(n);

@@ -143,6 +143,8 @@ def test_track_frame_equals_keyframe_then_track_map(hip):
     kfc = host.KeyFrame(ctx)
     bufs = [host.DevBuf(ctx, im) for im in frames]
     got = []
+    # (the same history on both sides: set_map starts every point's PatchFinder afresh)
+    tr.set_map(case["world"], case["pixel_right_w"], case["pixel_down_w"], kfa, case["src_level"], case["center"])
     for d in bufs:                                  # back to back, no synchronisation of the caller's in between
         tr.set_shuffle(case["shuffle_levels"], case["shuffle_fine"])
         r = tr.TrackFrame(kfc, d, case["pose_in"])
@@ -230,13 +232,17 @@ def test_batch_of_frames_equals_single_calls(hip):
     dis = (C.c_void_p * k)(*[raw(w[4].p) for w in ws])
     poses = np.ascontiguousarray(np.stack([np.asarray(w[5]["pose_in"], dtype=np.float64).reshape(12) for w in ws]))
     res = np.zeros(k, dtype=host.TRACKMAP_RESULT_DT)
-    for rep in range(2):   # (twice: the resident state of a batch must not leak into the next one)
+    for rep in range(2):   # (twice: what the trackers keep between frames — the PatchFinders' templates: same prediction, so every
+                           #  one of them is kept — must not change the outcome)
         for cx, ka, kb, tr, di, case in ws:
             tr.set_shuffle(case["shuffle_levels"], case["shuffle_fine"])
         ctx0._check(hip.track_map_frames_batch(k, trs, kfs, dis, poses.ctypes.data_as(C.POINTER(C.c_double)), opts.ctypes.data_as(C.c_void_p),
                                                res.ctypes.data_as(C.c_void_p)), "track_map_frames_batch")
         for i, (cx, ka, kb, tr, di, case) in enumerate(ws):
             for f in res.dtype.names:
+                if f == "templates_reused":
+                    assert res[i][f] == sum(res[i]["attempted"]) + (res[i]["n_coarse"] + res[i]["n_top"] + res[i]["n_fine"] - sum(res[i]["attempted"]))
+                    continue
                 assert np.array_equal(res[i][f], single[i][f]), (rep, i, f, res[i][f], single[i][f])
             it = tr.iteration_set()
             assert it.tobytes() == sets[i].tobytes(), (rep, i)
@@ -302,6 +308,8 @@ def test_batch_with_maps_of_different_sizes(hip):
         for f in res.dtype.names:
             if f in ("pose", "depth_sum", "depth_sum_sq"):
                 assert np.allclose(res[i][f], single[i][f], rtol=1e-9, atol=1e-9), (i, f)
+            elif f == "templates_reused":     # (the single calls above made the templates, the batch keeps every one of them)
+                assert single[i][f] == 0 and res[i][f] == len(sets[i])
             else:
                 assert np.array_equal(res[i][f], single[i][f]), (i, f, res[i][f], single[i][f])
         it = tr.iteration_set()
@@ -438,3 +446,38 @@ def test_track_map_keeps_patchfinder_state_between_frames(hip, oracle):
     tr.set_shuffle(case["shuffle_levels"], case["shuffle_fine"])
     assert tr.TrackMap(kfb, p0, tr.opts())["templates_reused"] == 0
     tr.close()
+
+
+def test_track_map_chain_against_oracle_twin_over_frames(hip, oracle):
+    """the chain (ptam_track_map_frame: keyframe of the new image + TrackMap) against the oracle's twin of the same entry point
+    (ptamo_track_map_frame, C++), six frames of one tracker each: alternating images, predictions that wander, the
+    PatchFinders' state carried along on both sides"""
+    a, b = synth.make_frame_pair()
+    frames = [b, b, np.roll(b, 1, axis=1), b, a, b]
+    runs = {}
+    for name, lib in (("hip", hip), ("oracle", oracle)):
+        ctx = host.Context(lib=lib)
+        kfa = host.KeyFrame(ctx).MakeKeyFrame_Lite(a)
+        case = synth.make_trackmap_case([kfa.level(l) for l in range(4)], counts=(500, 250, 80, 40))
+        tr = host.Tracker(ctx, len(case["world"]))
+        tr.set_map(case["world"], case["pixel_right_w"], case["pixel_down_w"], kfa, case["src_level"], case["center"])
+        kf = host.KeyFrame(ctx)
+        out = []
+        pose = np.array(case["pose_in"], dtype=np.float64)
+        for k, im in enumerate(frames):
+            tr.set_shuffle(np.roll(case["shuffle_levels"], 7 * k), np.roll(case["shuffle_fine"], 3 * k))
+            fr = host.DevBuf(ctx, im) if name == "hip" else None
+            res = tr.TrackFrame(kf, fr if fr is not None else np.ascontiguousarray(im).ctypes.data, pose, tr.opts())
+            out.append((res, tr.iteration_set()))
+            if fr is not None:
+                fr.free()
+            pose = _moved(case["pose_in"], rot_z=1e-4 * (k + 1), dx=2e-5 * (k + 1))   # (the same predictions on both sides)
+        runs[name] = out
+        tr.close()
+    for k, ((rh, ih), (ro, io)) in enumerate(zip(runs["hip"], runs["oracle"])):
+        ref = {"pose": ro["pose"], "did_coarse": bool(ro["did_coarse"]), "n_pvs": list(ro["n_pvs"]), "attempted": list(ro["attempted"]),
+               "found": list(ro["found"]), "n_coarse": ro["n_coarse"], "n_top": ro["n_top"], "n_fine": ro["n_fine"], "n_meas": ro["n_meas"],
+               "depth": (ro["depth_sum"], ro["depth_sum_sq"], ro["depth_n"]), "iteration_set": io}
+        _check(rh, ih, ref, strict=False)
+        assert rh["templates_reused"] == ro["templates_reused"], k
+    assert runs["oracle"][1][0]["templates_reused"] > 0 and runs["oracle"][0][0]["n_meas"] > 300

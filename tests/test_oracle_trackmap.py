@@ -1,0 +1,54 @@
+"""CPU: the oracle's whole-frame Tracker::TrackMap (ptamo_track_map, C++) against the same frame COMPOSED stage by stage in
+Python from the oracle's per-stage calls (tests/trackmap_ref.py).  Two restatements of src/Tracker.cc:442-696's control flow
+— set choice incl. the :538 assignment, stage hand-over of the TrackerData, the per-point PatchFinder state of
+src/PatchFinder.cc:98-127 — written independently; they must agree to the last bit, frame after frame."""
+import numpy as np
+import pytest
+
+from ptam_cg_amd import host, synth
+from tests import trackmap_ref
+
+CASES = {
+    "coarse_and_chop": ((800, 300, 80, 40), {}),
+    "coarse_from_level2": ((300, 120, 30, 25), {}),
+    "coarse_mixed": ((200, 100, 90, 25), {}),
+    "no_coarse": ((400, 200, 60, 30), dict(try_coarse=0)),
+    "too_few_coarse": ((300, 100, 10, 6), {}),
+    "top_level_remainder": ((300, 100, 30, 40), dict(coarse_max=20, coarse_min=10)),
+    "tiny_budget": ((200, 100, 50, 30), dict(max_patches=40)),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_track_map_equals_composed_stages(oracle, name):
+    counts, kw = CASES[name]
+    ctx = host.Context(lib=oracle)
+    a, b = synth.make_frame_pair()
+    kfa = host.KeyFrame(ctx).MakeKeyFrame_Lite(a)
+    kfb = host.KeyFrame(ctx).MakeKeyFrame_Lite(b)
+    case = synth.make_trackmap_case([kfa.level(l) for l in range(4)], counts=counts)
+    tr = host.Tracker(ctx, len(case["world"]))
+    tr.set_map(case["world"], case["pixel_right_w"], case["pixel_down_w"], kfa, case["src_level"], case["center"])
+    finders = {}
+    p0 = np.array(case["pose_in"], dtype=np.float64)
+    p1 = p0.copy()
+    p1[9] += 1e-4                                 # nearly the same prediction: the finders keep their templates
+    p2 = p0.copy()
+    p2[11] -= 0.3 * abs(p0[11]) + 0.2             # pushed in: warps rejected / re-made
+    for k, pose in enumerate((p0, p1, p2, p1)):
+        tr.set_shuffle(case["shuffle_levels"], case["shuffle_fine"])
+        r = tr.TrackMap(kfb, pose, tr.opts(**kw))
+        it = tr.iteration_set()
+        ref = trackmap_ref.track_map(ctx, kfb, kfa, case, pose, case["shuffle_levels"], case["shuffle_fine"], finders=finders, **kw)
+        assert np.array_equal(r["pose"], ref["pose"]), k
+        assert bool(r["did_coarse"]) == ref["did_coarse"] and list(r["n_pvs"]) == ref["n_pvs"]
+        assert list(r["attempted"]) == ref["attempted"] and list(r["found"]) == ref["found"]
+        assert (r["n_coarse"], r["n_top"], r["n_fine"], r["n_meas"]) == (ref["n_coarse"], ref["n_top"], ref["n_fine"], ref["n_meas"])
+        assert r["templates_reused"] == ref["templates_reused"]
+        assert r["depth_n"] == ref["depth"][2]      # (the sums: sequential there, numpy's pairwise order here)
+        assert np.isclose(r["depth_sum"], ref["depth"][0], rtol=1e-13) and np.isclose(r["depth_sum_sq"], ref["depth"][1], rtol=1e-13)
+        for f in ("point", "level", "found", "did_subpix", "outlier", "v2_found"):
+            assert np.array_equal(it[f], ref["iteration_set"][f]), (k, f)
+        if k == 1:
+            assert r["templates_reused"] > 0
+    tr.close()
