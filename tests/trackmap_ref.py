@@ -89,16 +89,20 @@ def search_for_points(ctx, pf, kf, case, src_kf, tds, rng_range, subpix_its, att
 
 
 def track_map(ctx, kf, src_kf, case, pose_in, shuffle_levels, shuffle_fine, try_coarse=True, coarse_min=20, coarse_max=60,
-              coarse_range=30, coarse_subpix_its=8, max_patches=1000, estimator=0, finders=None):
+              coarse_range=30, coarse_subpix_its=8, max_patches=1000, estimator=0, finders=None, pvs_ctx=None):
     """finders: None = every PatchFinder fresh (a tracker's first frame); a dict kept by the caller from frame to frame =
-    the per-point finder state of a tracker that goes on tracking the same map"""
+    the per-point finder state of a tracker that goes on tracking the same map.
+    pvs_ctx: a context of ANOTHER library whose PVS pass (projection, derivatives, warp matrices) is taken instead of this
+    one's — the warped templates are truncated to bytes (src/PatchFinder.cc:116), so they are discontinuous in the warp
+    matrix, and two libraries whose atan differs in the last bit disagree in a grey level of ~1 % of them; with the warp
+    matrices shared every later stage can be compared exactly"""
     pf = host.PatchFinder(ctx)
     stats = {"reused": 0, "stale_bad": 0}
     n = len(case["world"])
     pose = np.array(pose_in, dtype=np.float64).copy()
     attempted, found_cnt = [0] * LEVELS, [0] * LEVELS
     # ---- PVS loop :453-478 ----
-    pvs, _ = ctx.track_pvs(case["world"], case["pixel_right_w"], case["pixel_down_w"], pose)
+    pvs, _ = (pvs_ctx or ctx).track_pvs(case["world"], case["pixel_right_w"], case["pixel_down_w"], pose)
     tds = {}
     for i in range(n):
         if pvs["level"][i] < 0:
