@@ -291,6 +291,10 @@ __device__ __forceinline__ void tm_search_body(const DevCam& cam, const KfLevels
     if (s >= end) return;
     const int id = d.list[s];
     ptam_pvs_result& pv = d.pvs[id];
+    // the point's PatchFinder state, requested with the point's TrackerData (one round trip, not one more behind the decision)
+    TmFinder& fs = d.finder[id];
+    const double fm0 = fs.m2[0], fm1 = fs.m2[1], fm2 = fs.m2[2], fm3 = fs.m2[3];
+    const int f_valid = fs.valid, f_bad = fs.bad, f_sum = fs.sum, f_sum_sq = fs.sum_sq, f_tpl = fs.tpl[lane];
     double u = pv.proj.image[0], v = pv.proj.image[1];
     if (stage == 1 && (s < c.range_h[1] || c.did_coarse)) {
         const ptam_pvs_point& p = d.pts[id];
@@ -331,14 +335,13 @@ __device__ __forceinline__ void tm_search_body(const DevCam& cam, const KfLevels
     // MakeTemplateCoarseCont (src/PatchFinder.cc:98-127): re-make the template unless this finder's last one was made with
     // (nearly) this warp — then the template, its sums and mbTemplateBad stay as they are
     ptam_template_result tr;
-    int T;
+    int T, kept = 0;
     {
-        TmFinder& fs = d.finder[id];
         double m2[4];
         template_m2(jb, m2);
-        const double c0x = m2[0] - fs.m2[0], c0y = m2[2] - fs.m2[2], c1x = m2[1] - fs.m2[1], c1y = m2[3] - fs.m2[3];   // columns m2.T()[0], m2.T()[1]
+        const double c0x = m2[0] - fm0, c0y = m2[2] - fm2, c1x = m2[1] - fm1, c1y = m2[3] - fm3;   // columns m2.T()[0], m2.T()[1]
         const double lim = 0.07 * 0.07;
-        const bool refresh = !fs.valid || pv.level < 0 || c0x * c0x + c0y * c0y > lim || c1x * c1x + c1y * c1y > lim;
+        const bool refresh = !f_valid || pv.level < 0 || c0x * c0x + c0y * c0y > lim || c1x * c1x + c1y * c1y > lim;
         if (refresh) {
             T = wave_make_template(jb, lane, tr);
             fs.tpl[lane] = (uint8_t)T;
@@ -350,13 +353,13 @@ __device__ __forceinline__ void tm_search_body(const DevCam& cam, const KfLevels
                 fs.sum_sq = tr.sum_sq;
             }
         } else {
-            T = fs.tpl[lane];
-            tr.bad = fs.bad;
+            T = f_tpl;
+            tr.bad = f_bad;
             tr.n_outside = 0;
-            tr.sum = fs.sum;
-            tr.sum_sq = fs.sum_sq;
-            tr.m2[0] = fs.m2[0], tr.m2[1] = fs.m2[1], tr.m2[2] = fs.m2[2], tr.m2[3] = fs.m2[3];
-            if (lane == 0) atomicAdd(&d.ctl->n_reused, 1);
+            tr.sum = f_sum;
+            tr.sum_sq = f_sum_sq;
+            tr.m2[0] = fm0, tr.m2[1] = fm1, tr.m2[2] = fm2, tr.m2[3] = fm3;
+            kept = 1;   // (counted by the gather pass from the slot's status word: a thousand atomics on one counter cost 5 us)
         }
     }
     ptam_patch_result res;
@@ -396,7 +399,7 @@ __device__ __forceinline__ void tm_search_body(const DevCam& cam, const KfLevels
         d.slot_found[s] = found;
         d.slot_subpix[s] = sub;
         d.slot_v2[s] = v2;
-        d.slot_stat[s] = found | ((int)att << 1) | ((q.level & 3) << 2);
+        d.slot_stat[s] = found | ((int)att << 1) | ((q.level & 3) << 2) | (kept << 4);
     }
 }
 __global__ void __launch_bounds__(256) tm_search_kernel(DevCam cam, KfLevels L, TmDev d, int stage, unsigned coarse_range, int coarse_its) {
@@ -414,10 +417,12 @@ struct TmMailbox {
 // the last act of a gather pass: thread 0 books the per-level counts and the stage's outcome (coarse: mbDidCoarse and the
 // fine range; fine: everything of the frame's result but the pose and the depth sums)
 __device__ __forceinline__ void tm_gather_finish(const TmDev& d, TmCtl& c, int stage, unsigned coarse_min, TmMailbox* mbox, int total,
-                                                 int (*lsum)[16]) {
+                                                 int (*lsum)[16], int n_kept) {
     const int tid = threadIdx.x;
     int tot[1] = {total};
     if (tid == 0) {
+        const int n_reused = c.n_reused + n_kept;   // searched patches of the stages so far whose finder kept its template
+        c.n_reused = n_reused;
         int f4[4], a4[4];
         for (int l = 0; l < 4; l++) {
             int tf = 0, ta = 0;
@@ -440,7 +445,7 @@ __device__ __forceinline__ void tm_gather_finish(const TmDev& d, TmCtl& c, int s
             // everything of the frame's result but the pose and the depth sums (the fine pose loop publishes those, then
             // the sequence word)
             ptam_trackmap_result& r = mbox->res;
-            r.templates_reused = c.n_reused;
+            r.templates_reused = n_reused;
             r.pad_ = 0;
             r.did_coarse = c.did_coarse;
             for (int l = 0; l < 4; l++) {
@@ -483,13 +488,14 @@ __device__ __forceinline__ void tm_gather_body(const TmDev& d, int stage, int co
     const ptam_projection pj = d.pvs[idc].proj;
     // found slots in front of my workgroup's first (workgroup 0: also the totals and the per-level counts of this stage)
     const int upto = bx == 0 ? g_end : s0;
-    int before = 0, total = 0, lf[4] = {0, 0, 0, 0}, la[4] = {0, 0, 0, 0};
+    int before = 0, total = 0, lf[4] = {0, 0, 0, 0}, la[4] = {0, 0, 0, 0}, nk = 0;
     for (int j = lane; j < upto; j += TM_GATHER_THREADS) {
         const int w = d.slot_stat[j];
         total += w & 1;
         if (j < s0) before += w & 1;
         if (bx == 0 && j >= st_first) {
             const int l = (w >> 2) & 3;
+            nk += (w >> 4) & 1;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 lf[q] += (l == q) & (w & 1);
@@ -513,6 +519,7 @@ __device__ __forceinline__ void tm_gather_body(const TmDev& d, int stage, int co
     }
     if (bx != 0) return;
     total = wave_sum_i32(total);
+    nk = wave_sum_i32(nk);
 #pragma unroll
     for (int l = 0; l < 4; l++) {
         const int tf = wave_sum_i32(lf[l]), ta = wave_sum_i32(la[l]);
@@ -524,7 +531,7 @@ __device__ __forceinline__ void tm_gather_body(const TmDev& d, int stage, int co
         }
     }
     __syncthreads();
-    tm_gather_finish(d, c, stage, coarse_min, mbox, __builtin_amdgcn_readlane(total, 63), lsum);
+    tm_gather_finish(d, c, stage, coarse_min, mbox, __builtin_amdgcn_readlane(total, 63), lsum, __builtin_amdgcn_readlane(nk, 63));
 }
 __global__ void __launch_bounds__(TM_GATHER_THREADS) tm_gather_kernel(TmDev d, int stage, int coarse_its, unsigned coarse_min, TmMailbox* mbox) {
     tm_gather_body(d, stage, coarse_its, coarse_min, mbox, blockIdx.x);
