@@ -71,6 +71,7 @@ struct BaScalars {
     int spec_stay;          //                or: the step is over WITHOUT an accepted trial (new == current error) and the
                             //                next one starts from the unchanged state with the unchanged lambda
     int abort_any;          // sharded: some rank's abort flag was up when this trial was enqueued (summed with the trial's scalars)
+    int solve_fault;        // the persistent factorisation gave up waiting for one of its workgroups (ldlt_chain.inc): the solve is void
 };
 
 struct BaDev {
@@ -133,6 +134,8 @@ struct BaDev {
     double* Dg;
     double* y;              // forward-substituted rhs
     double* da;             // [npad] camera update
+    unsigned* sflags;       // flag words of the persistent factorisation (ldlt_chain.inc); [0]: a spin gave up
+    unsigned solve_seq;     // its sequence number: a flag is up when it holds the current solve's number (the host increments it)
     double* bw_scratch;     // [2][6 npad] the backward substitution's vectors when they do not fit LDS (solve.hip)
     double* sumsq2;         // [2] |da|^2 in two parts (the two workgroups of the backward substitution; consumers add them)
     // outliers
@@ -163,6 +166,7 @@ __host__ __device__ __forceinline__ double* se_E(const BaDev& d) { return d.SE +
 
 // solve.hip
 int ba_solve(ptam_ctx* ctx, BaDev& d, int cur);   // also writes the trial poses pose[cur^1] and |da|^2
+size_t ba_solve_flag_bytes(int nblk);   // bytes of BaDev::sflags for a system of nblk blocks
 int ba_solve_init();   // raises the dynamic-LDS limits of the solve kernels (once per process/device)
 
 // -DK7_TIMING builds only (tools/): device-side timeline, one (kernel id, 100 MHz time stamp) pair per launch

@@ -606,7 +606,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     const size_t se_full = se_size((int)(npad / SOLVE_NB), (int)(npad / SOLVE_NB) - 1);
     const size_t o_SE = cv.take((se_full + npad + 8) * 8), o_L = cv.take(se_full * 8), o_Dg = cv.take(npad * 8),
                  o_y = cv.take(npad * 8), o_da = cv.take(npad * 8), o_sq2 = cv.take(16),
-                 o_bws = cv.take(npad * 8 * 12);
+                 o_bws = cv.take(npad * 8 * 12), o_sflags = cv.take(ba_solve_flag_bytes((int)(npad / SOLVE_NB)));
     const size_t o_out = cv.take(Mz * 4), o_sc = cv.take(sizeof(BaScalars)), o_dbg = cv.take(65536);
     ba->block_bytes = cv.off;
     if (!ctx_cache_take(ctx->dev_cache, ba->block_bytes, &ba->block, &ba->block_cap)) {   // (a released bundle's block, if it fits)
@@ -659,6 +659,8 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.da = (double*)(base + o_da);
     d.sumsq2 = (double*)(base + o_sq2);
     d.bw_scratch = (double*)(base + o_bws);
+    d.sflags = (unsigned*)(base + o_sflags);   // (cleared with the block: sequence numbers start at 1)
+    d.solve_seq = 0;
     d.outliers = (int*)(base + o_out);
     d.sc = (BaScalars*)(base + o_sc);
     d.dbg = (long long*)(base + o_dbg);
@@ -1458,6 +1460,12 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
                     nan_stop = true;
                     break;
                 }
+            }
+            if (sc.solve_fault) {
+                // (a workgroup of the persistent factorisation waited ~0.1 s for another one and gave up — it cannot happen
+                //  while all of them are resident, which a launch of a dozen workgroups on an otherwise idle XCD is)
+                ptam_set_error("bundle adjustment: the persistent camera solve timed out (set PTAM_LDLT_NO_CHAIN=1 to use the launch-per-block form)");
+                return PTAM_E_HIP;
             }
             ran_any = true;
             if (sharded) abort_all = abort_all || sc.abort_any != 0;

@@ -126,6 +126,7 @@ __global__ void __launch_bounds__(TPB) ldlt_step_twin_kernel(BaDev d, int k_top,
 }
 
 #include "ldlt_small.inc"
+#include "ldlt_chain.inc"
 
 // w = D^-1 z ; L^T x = w, blocked backwards and right-looking.  One workgroup of 1024 threads:
 // thread (rr, c) = (tid / 32, tid % 32).  Per block k:  x_k = Lkk^-T (w_k - pending_k)  is a 32x32
@@ -154,6 +155,8 @@ __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur, i
     double* wv = pend + 4 * npad;    // npad: D^-1 z
     const int tid = threadIdx.x;
     const int c = tid % NB, rr = tid / NB;
+    // (the persistent factorisation's error word: a spin gave up during THIS solve — the host stops the adjustment)
+    if (tid == 0 && chain == 0 && d.sflags && d.solve_seq != 0 && d.sflags[0] == d.solve_seq) d.sc->solve_fault = 1;
     for (int i = tid; i < npad; i += 1024) {
         pend[i] = pend[npad + i] = pend[2 * npad + i] = pend[3 * npad + i] = 0.0;
         wv[i] = d.y[i] / d.Dg[i];
@@ -269,6 +272,7 @@ __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur, i
 int ba_solve_init() {
     HIP_TRY(hipFuncSetAttribute((const void*)ldlt_backward_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(hipFuncSetAttribute((const void*)ldlt_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)ldlt_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return PTAM_OK;
 }
 
@@ -280,6 +284,8 @@ static int ldlt_twist_len(int nblk, int band) {
     return (nblk - 2 * band) / 2;
 }
 
+size_t ba_solve_flag_bytes(int nblk) { return ch_flag_words(nblk, nblk) * sizeof(unsigned); }
+
 int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
     const int nblk = d.npad / NB, band = se_band(d);
     static const bool no_small = getenv("PTAM_LDLT_NO_SMALL") != nullptr;   // (A/B runs: launch-per-block-column form only)
@@ -288,6 +294,22 @@ int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
         hipLaunchKernelGGL(ldlt_small_kernel, dim3(1), dim3(TPB), sizeof(SmallLds), ctx->stream, d, cur);
         HIP_TRY(hipGetLastError());
         return PTAM_OK;
+    }
+    {
+        // one persistent launch (ldlt_chain.inc) when a row worker's in-band tiles fit its LDS and the rows are few enough for
+        // one workgroup each to keep up with the chain: measured against the launch-per-block-column form below (tools/ldlt, us
+        // per solve) 81 / 98 at 10 blocks, 108 / 119 at 12; from 13 blocks on a worker's tiles no longer fit
+        static const bool no_chain = getenv("PTAM_LDLT_NO_CHAIN") != nullptr;   // (A/B runs)
+        const size_t lds = ch_lds_bytes(band);
+        if (!no_chain && d.sflags && nblk <= CH_MAX_NB && lds <= CH_LDS_MAX) {
+            d.solve_seq++;
+            if (d.solve_seq >= (1u << 27)) d.solve_seq = 1;   // (flags carry it shifted by up to 4 bits; flags of 2^27 solves ago are no concern)
+            hipLaunchKernelGGL(ldlt_chain_kernel, dim3(8 * ch_roles(nblk)), dim3(TPB), lds, ctx->stream, d);
+            const size_t bw = (size_t)6 * d.npad * sizeof(double);
+            hipLaunchKernelGGL(ldlt_backward_kernel<false>, dim3(1), dim3(1024), bw, ctx->stream, d, cur, nblk);
+            HIP_TRY(hipGetLastError());
+            return PTAM_OK;
+        }
     }
     auto nwg_of = [](int rem) { return 1 + rem + rem * (rem + 1) / 2; };
     const int t_end = ldlt_twist_len(nblk, band), b_start = nblk - t_end;
@@ -317,4 +339,5 @@ void solve_preload_kernels() {
     ptam_preload((const void*)ldlt_backward_kernel<false>);
     ptam_preload((const void*)ldlt_backward_kernel<true>);
     ptam_preload((const void*)ldlt_small_kernel);
+    ptam_preload((const void*)ldlt_chain_kernel);
 }

@@ -86,6 +86,8 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d.sumsq2, 16));
     CK(hipMalloc(&d.cam_free, 16));
     CK(hipMalloc(&d.bw_scratch, (size_t)12 * npad * 8));
+    CK(hipMalloc(&d.sflags, ba_solve_flag_bytes(nblk)));
+    CK(hipMemset(d.sflags, 0, ba_solve_flag_bytes(nblk)));
     CK(hipMalloc(&dbg, 65536 * 8));
     CK(hipMemset(dbg, 0, 65536 * 8));
     d.dbg = (long long*)dbg;
@@ -116,7 +118,41 @@ int main(int argc, char** argv) {
     printf("F %d n %d nblk %d band %d: %.2f us per solve (copy included), max |da - ref| = %.3e (|ref| max %.3e) %s\n", F, n, nblk, band,
            1e3 * best / reps, err, nrm, err <= 1e-11 * nrm + 1e-300 ? "OK" : "MISMATCH");
 #ifdef K7_TIMING
-    {
+    if (getenv("PTAM_LDLT_CHAIN")) {
+        std::vector<long long> st(512);
+        CK(hipMemcpy(st.data(), dbg, 512 * 8, hipMemcpyDeviceToHost));
+        {
+            std::vector<unsigned> fl(ch_flag_words(nblk, band));
+            CK(hipMemcpy(fl.data(), d.sflags, fl.size() * 4, hipMemcpyDeviceToHost));
+            printf("error word %u | F[0] %u (seq %u, plain stores %u) | XCC ids:", fl[0], fl[1], fl[1] >> 1, fl[1] & 1);
+            for (int i = 0; i < ch_roles(nblk); i++) printf(" %u", fl[1 + 2 * nblk + i] & 0xf);
+            printf("\n");
+        }
+        printf("chain stamps per step (cycles): factor | stores + wait for the row | row step, flags | (step total)\n");
+        for (int k = 0; k + 1 < nblk && k < 12; k++) {
+            const long long* q = &st[32 + 4 * k];
+            printf("  step %2d: %6lld %6lld %6lld   (%lld)\n", k, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[0]);
+        }
+        printf("iteration at which the next row's flag was seen (0: never inside the loop):");
+        for (int k = 0; k + 1 < nblk && k < 16; k++) printf(" %lld/%lld", st[440 + k] ? st[440 + k] - 100 : 0, st[456 + k] ? st[456 + k] - 100 : 0);
+        printf("\n");
+        {
+            std::vector<long long> rt(4 * 16);
+            CK(hipMemcpy(rt.data(), dbg + 600, rt.size() * 8, hipMemcpyDeviceToHost));
+            printf("per k (10 ns units, relative to the start of the chain's loop k): F[k] raised | worker k+2 saw it | worker k+2 raised RF | (loop k+1 starts)\n");
+            for (int k = 0; k + 2 < nblk && k < 15; k++)
+                printf("  k %2d: %5lld %5lld %5lld (%lld)\n", k, rt[4 * k] - rt[4 * k + 3], rt[4 * k + 1] - rt[4 * k + 3], rt[4 * k + 2] - rt[4 * k + 3],
+                       rt[4 * k + 7] - rt[4 * k + 3]);
+        }
+        {
+            std::vector<long long> rt(4 * 16), r0(4);
+            CK(hipMemcpy(rt.data(), dbg + 700, rt.size() * 8, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(r0.data(), dbg + 600, 32, hipMemcpyDeviceToHost));
+            printf("last row's worker, per m (10 ns units since the chain's start): saw F[m] | L stored, XF up | two tiles updated | step done\n");
+            for (int m = 0; m + 2 < nblk && m < 15; m++)
+                printf("  m %2d: %6lld %6lld %6lld %6lld\n", m, rt[4 * m] - r0[3], rt[4 * m + 1] - r0[3], rt[4 * m + 2] - r0[3], rt[4 * m + 3] - r0[3]);
+        }
+    } else {
         std::vector<long long> st(512);
         CK(hipMemcpy(st.data(), dbg, 512 * 8, hipMemcpyDeviceToHost));
         printf("stamps (cycles between consecutive ones):");
