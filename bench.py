@@ -144,7 +144,7 @@ def tracking_bench(hip, host, synth, frames=250, replicas=True):
     # the headline tracking figure: one dependent chain per frame through the C ABI, driven by a native host thread
     # (ptam_bench_track_frames, one context); frame_chain["fps"] is the same loop driven from Python (ctypes + interpreter per call)
     native1 = chain["aggregate_fps_by_concurrent_contexts"]["1"]
-    return {"tracked_fps": native1, "frame_us": 1e6 / native1, "frame_chain": chain,
+    return {"tracked_fps": native1, "frame_us": 1e6 / native1, "frame_chain": chain, "kernels": tracking_kernel_record(),
             "fine_stage_only_fps": 1.0 / stage["frame"], "fine_stage_only_frame_us": stage["frame"] * 1e6,
             "keyframe_us": stage["keyframe"] * 1e6, "keyframe_plus_patch_us": stage["patch"] * 1e6,
             "pose_gn_us": stage["pose_dev"] * 1e6, "pose_gn_host_buffers_us": stage["pose"] * 1e6,
@@ -153,6 +153,29 @@ def tracking_bench(hip, host, synth, frames=250, replicas=True):
             "frame_us_min_max_of_5_blocks": [spread["frame"][0] * 1e6, spread["frame"][1] * 1e6], "patches_per_frame": int(len(q)), "pose_meas": int(n),
             "note": "tracked_fps / frame_us = the resident TrackMap chain, one context, native host thread (frame_chain: the same driven from Python, and k contexts); fine_stage_only_* = round 1's frame: pyramid + FAST + "
                     "1000-patch search + gather + one 10-iteration pose solve fed from a separate pose case"}
+
+
+def tracking_kernel_record():
+    """the tracked frame kernel by kernel: the committed rocprofv3 summary of the same chain (profiles/tracking_kernels.json,
+    written by tools/collect_profiles.sh), with the algorithmic bytes of the two image kernels.  Every kernel of the frame is a
+    few microseconds of a dependent chain on an otherwise idle chip: they are latency-bound, none is near a roofline, and the
+    frame is their sum plus one host round trip."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "tracking_kernels.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    px = 640 * 480
+    alg = {"tm_pyr_pvs_kernel": px + px // 4 + px // 16 + px // 64,         # level 0 read; levels 1-3 written
+           "fast_detect_kernel": px + px // 4 + px // 16 + px // 64}        # the four levels read once
+    for name, k in rec.get("kernels", {}).items():
+        for key, nbytes in alg.items():
+            if key in name and k.get("avg_us"):
+                k["algorithmic_bytes"] = nbytes
+                k["achieved_GBps"] = round(nbytes / k["avg_us"] / 1e3, 1)
+    rec["file"] = "profiles/tracking_kernels.json"
+    return rec
 
 
 def trackmap_bench(hip, host, synth, ctx, kfa, frame_b, d_im, frames, replicas=True):

@@ -27,7 +27,7 @@ for f in sorted(glob.glob("$OUT/pmc_ba/*counter_collection.csv")):
     agg = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
-        if not any(x in k for x in ("schur_tile", "ldlt_step", "ldlt_backward")): continue
+        if not any(x in k for x in ("schur_tile", "ldlt_step", "ldlt_backward", "ldlt_chain", "ldlt_small")): continue
         a = agg[(k, r["Counter_Name"])]; a[0] += float(r["Counter_Value"]); a[1] += 1
     for (k, c), (v, n) in sorted(agg.items()):
         print(f"{k[:28]:28s} {c:26s} per-launch {v / max(n,1):.4g}  (launches {n})")
@@ -43,6 +43,33 @@ for key, dd in (("bundle_50kf_x_5000pts_dense", "$R/gpurun_out/pmc_${TAG}_headli
         pass
 json.dump(rec, open("$OUT/k7_pmc_traffic.json", "w"), indent=1)
 PY
+# the tracked frame, kernel by kernel: rocprofv3 stats of tools/dev/trackmap_only.py (one ptam_track_map_frame per frame),
+# per-frame launch counts and average durations -> tracking_kernels.json (bench.py embeds the committed copy in `tracking`)
+cd /tmp
+FR=300
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ttrace -o tm -- python $R/tools/dev/trackmap_only.py $FR frame > $OUT/tracking_trace.log 2>&1
+cp $OUT/ttrace/tm_kernel_stats.csv $OUT/tracking_kernel_stats.csv 2>/dev/null
+python3 - <<PY
+import csv, json
+frames = 2 * $FR   # (trackmap_only.py runs the loop twice)
+rec = {"source": "rocprofv3 --kernel-trace --stats -- python tools/dev/trackmap_only.py $FR frame", "frames": frames, "kernels": {}}
+tot = 0.0
+try:
+    for r in csv.DictReader(open("$OUT/tracking_kernel_stats.csv")):
+        n = r["Name"].split("(")[0]
+        if "rocclr" in n or int(r["Calls"]) < frames // 2: continue   # (set-up kernels: keyframe of the map, uploads)
+        per = int(r["Calls"]) / frames
+        rec["kernels"][n] = {"launches_per_frame": round(per, 2), "avg_us": round(float(r["AverageNs"]) / 1e3, 2),
+                             "us_per_frame": round(per * float(r["AverageNs"]) / 1e3, 2)}
+        tot += per * float(r["AverageNs"]) / 1e3
+    rec["kernel_us_per_frame"] = round(tot, 1)
+except OSError as e:
+    rec["error"] = repr(e)
+json.dump(rec, open("$OUT/tracking_kernels.json", "w"), indent=1)
+print(json.dumps(rec)[:600])
+PY
+rm -rf $OUT/ttrace
+cd $R
 # gpurun merges at most 64 MiB back: keep the summaries, drop the raw per-dispatch tables
 rm -rf $OUT/pmc_ba $OUT/trace
 for dd in $R/gpurun_out/pmc_${TAG}_headline $R/gpurun_out/pmc_${TAG}_config5; do

@@ -1,10 +1,11 @@
 #!/bin/bash
 # kernel timeline (all queues) of a few lambda trials of the bench problem: start offset, duration, gap to the previous kernel
-# of the same queue.  usage: tools/dev/ba_timeline.sh [first kernel index] [count]   (environment passes through)
+# of the same queue.  usage: tools/dev/ba_timeline.sh [first kernel index] [count]   (environment passes through;
+# BA_TIMELINE_ARGS="--cams 20 --points 3000" for another shape)
 R=${GRAFT_REPO_ROOT:-.}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/bt
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/bt -o bt -- python $R/bench.py --no-cpu-baseline --no-tracking --no-global --steps 10 --jac-reps 1 > /tmp/bt.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/bt -o bt -- python $R/bench.py --no-cpu-baseline --no-tracking --no-global --no-local --steps 10 --jac-reps 1 $BA_TIMELINE_ARGS > /tmp/bt.log 2>&1
 python3 - "$@" <<PY
 import csv, glob, sys
 f = glob.glob("/tmp/bt/**/bt_kernel_trace.csv", recursive=True)[0]
