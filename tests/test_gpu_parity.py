@@ -265,6 +265,11 @@ BA_CASES = {
     "two_fixed": dict(n_cams=12, n_pts=120, seed=4, n_fixed=2),
     "config4_20x3000": dict(n_cams=20, n_pts=3000, seed=synth.SEED_BA_LOCAL),
     "wide_80x60": dict(n_cams=80, n_pts=60, seed=6),          # > 64 measurements per point: block variant of K7
+    # the camera solve as ONE persistent launch (ldlt_chain.inc: 6 .. 12 block rows): the smallest system that takes it, a banded
+    # one whose row workers hold only part of their row, and the largest (12 blocks: the last rows' workers lag behind the chain)
+    "chain_33x500": dict(n_cams=33, n_pts=500, seed=41),
+    "chain_58x700_w20": dict(n_cams=58, n_pts=700, seed=42, window=20),
+    "chain_64x900": dict(n_cams=64, n_pts=900, seed=43),
     # long banded trajectories: camera system of 23 / 35 blocks with a 2- / 3-block band -> two-ended LDL^T (solve.hip)
     "twisted_120x1500_w8": dict(n_cams=120, n_pts=1500, seed=21, window=8),
     "twisted_181x2500_w12_f3": dict(n_cams=181, n_pts=2500, seed=22, window=12, n_fixed=3),
