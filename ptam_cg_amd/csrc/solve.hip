@@ -289,16 +289,19 @@ size_t ba_solve_flag_bytes(int nblk) { return ch_flag_words(nblk, nblk) * sizeof
 int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
     const int nblk = d.npad / NB, band = se_band(d);
     static const bool no_small = getenv("PTAM_LDLT_NO_SMALL") != nullptr;   // (A/B runs: launch-per-block-column form only)
-    // a small system in one workgroup and one launch: ldlt_small.inc
-    if (!no_small && nblk <= SM_NB) {
+    // one or two block rows in one workgroup and one launch: ldlt_small.inc.  (It holds up to SM_NB = 5 block rows and was the
+    // form of every system up to that size until the persistent launch's row workers learnt to keep up with the chain; now,
+    // us per solve, small / persistent: 10.3 / 10.7 at 1 block row, 16.8 / 16.5 at 2, 25.7 / 23.8 at 3, 36.1 / 30.6 at 4,
+    // 48.7 / 37.7 at 5 — the single workgroup does the row updates one after the other.)
+    if (!no_small && nblk <= SM_USE_NB) {
         hipLaunchKernelGGL(ldlt_small_kernel, dim3(1), dim3(TPB), sizeof(SmallLds), ctx->stream, d, cur);
         HIP_TRY(hipGetLastError());
         return PTAM_OK;
     }
     {
-        // one persistent launch (ldlt_chain.inc) when a row worker's in-band tiles fit its LDS and the rows are few enough for
-        // one workgroup each to keep up with the chain: measured against the launch-per-block-column form below (tools/ldlt, us
-        // per solve) 81 / 98 at 10 blocks, 108 / 119 at 12; from 13 blocks on a worker's tiles no longer fit
+        // one persistent launch (ldlt_chain.inc) when a row worker's in-band tiles fit its LDS: measured against the
+        // launch-per-block-column form below (tools/ldlt, us per solve) 49 / 67 at 7 block rows, 71 / 98 at 10, 86 / 119 at 12,
+        // 96 / 133 at 13; from 14 dense block rows on a worker's tiles no longer fit
         static const bool no_chain = getenv("PTAM_LDLT_NO_CHAIN") != nullptr;   // (A/B runs)
         const size_t lds = ch_lds_bytes(band);
         if (!no_chain && d.sflags && nblk <= CH_MAX_NB && lds <= CH_LDS_MAX) {

@@ -118,7 +118,7 @@ int main(int argc, char** argv) {
     printf("F %d n %d nblk %d band %d: %.2f us per solve (copy included), max |da - ref| = %.3e (|ref| max %.3e) %s\n", F, n, nblk, band,
            1e3 * best / reps, err, nrm, err <= 1e-11 * nrm + 1e-300 ? "OK" : "MISMATCH");
 #ifdef K7_TIMING
-    if (getenv("PTAM_LDLT_CHAIN")) {
+    if (!getenv("PTAM_LDLT_NO_CHAIN") && nblk > SM_USE_NB && nblk <= CH_MAX_NB) {
         std::vector<long long> st(512);
         CK(hipMemcpy(st.data(), dbg, 512 * 8, hipMemcpyDeviceToHost));
         {
