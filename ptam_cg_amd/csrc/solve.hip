@@ -307,7 +307,7 @@ int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
         if (!no_chain && d.sflags && nblk <= CH_MAX_NB && lds <= CH_LDS_MAX) {
             d.solve_seq++;
             if (d.solve_seq >= (1u << 27)) d.solve_seq = 1;   // (flags carry it shifted by up to 4 bits; flags of 2^27 solves ago are no concern)
-            hipLaunchKernelGGL(ldlt_chain_kernel, dim3(8 * ch_roles(nblk)), dim3(TPB), lds, ctx->stream, d);
+            hipLaunchKernelGGL(ldlt_chain_kernel, dim3(8 * ch_roles(nblk)), dim3(TPB), lds, ctx->stream, d, 0, nblk);
             const size_t bw = (size_t)6 * d.npad * sizeof(double);
             hipLaunchKernelGGL(ldlt_backward_kernel<false>, dim3(1), dim3(1024), bw, ctx->stream, d, cur, nblk);
             HIP_TRY(hipGetLastError());
@@ -321,9 +321,22 @@ int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
         const int nt = nwg_of(std::min(nblk - kt - 1, band)), nb = nwg_of(std::min(kb, band));
         hipLaunchKernelGGL(ldlt_step_twin_kernel, dim3(nt + nb), dim3(TPB), 0, ctx->stream, d, kt, kb, nt);
     }
-    for (int k = t_end; k < b_start; k++) {   // the middle (everything, without a second chain)
-        const int nwg = nwg_of(std::min(b_start - k - 1, band));
-        hipLaunchKernelGGL(ldlt_step_kernel, dim3(nwg), dim3(TPB), 0, ctx->stream, d, k, b_start);
+    {
+        // the middle (everything, without a second chain): one persistent launch over its block rows where that form applies
+        // (ldlt_chain.inc: 5.6 us per block row against 8.3 per launch), one launch per block column otherwise
+        static const bool no_chain = getenv("PTAM_LDLT_NO_CHAIN") != nullptr;
+        const int n_mid = b_start - t_end;
+        const size_t lds = ch_lds_bytes(band);
+        if (t_end > 0 && !no_chain && d.sflags && n_mid >= 3 && n_mid <= CH_MAX_NB && lds <= CH_LDS_MAX) {
+            d.solve_seq++;
+            if (d.solve_seq >= (1u << 27)) d.solve_seq = 1;
+            hipLaunchKernelGGL(ldlt_chain_kernel, dim3(8 * ch_roles(n_mid)), dim3(TPB), lds, ctx->stream, d, t_end, b_start);
+        } else {
+            for (int k = t_end; k < b_start; k++) {
+                const int nwg = nwg_of(std::min(b_start - k - 1, band));
+                hipLaunchKernelGGL(ldlt_step_kernel, dim3(nwg), dim3(TPB), 0, ctx->stream, d, k, b_start);
+            }
+        }
     }
     const size_t bw_bytes = (size_t)6 * d.npad * sizeof(double);
     if (bw_bytes > BW_LDS_MAX)   // (the vectors in d.bw_scratch instead)
