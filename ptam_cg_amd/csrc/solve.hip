@@ -298,13 +298,17 @@ int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
         HIP_TRY(hipGetLastError());
         return PTAM_OK;
     }
+    auto nwg_of = [](int rem) { return 1 + rem + rem * (rem + 1) / 2; };
+    const int t_end = ldlt_twist_len(nblk, band), b_start = nblk - t_end;
     {
-        // one persistent launch (ldlt_chain.inc) when a row worker's in-band tiles fit its LDS: measured against the
+        // not banded enough for two chains (below): one persistent launch (ldlt_chain.inc) when a row worker's in-band tiles fit its
+        // LDS and the block rows — a workgroup each — fit one XCD: measured against the
         // launch-per-block-column form below (tools/ldlt, us per solve) 49 / 67 at 7 block rows, 71 / 98 at 10, 86 / 119 at 12,
-        // 96 / 133 at 13; from 14 dense block rows on a worker's tiles no longer fit
+        // 96 / 133 at 13 (dense: from 14 block rows on a worker's tiles no longer fit), 105 / 149 at 15 rows of band 5,
+        // 202 / 287 at 28 of band 9.  (Where two chains apply they win: 137 against 152 at 23 rows of band 2.)
         static const bool no_chain = getenv("PTAM_LDLT_NO_CHAIN") != nullptr;   // (A/B runs)
         const size_t lds = ch_lds_bytes(band);
-        if (!no_chain && d.sflags && nblk <= CH_MAX_NB && lds <= CH_LDS_MAX) {
+        if (t_end == 0 && !no_chain && d.sflags && nblk <= CH_MAX_NB && lds <= CH_LDS_MAX) {
             d.solve_seq++;
             if (d.solve_seq >= (1u << 27)) d.solve_seq = 1;   // (flags carry it shifted by up to 4 bits; flags of 2^27 solves ago are no concern)
             hipLaunchKernelGGL(ldlt_chain_kernel, dim3(8 * ch_roles(nblk)), dim3(TPB), lds, ctx->stream, d, 0, nblk);
@@ -314,8 +318,6 @@ int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
             return PTAM_OK;
         }
     }
-    auto nwg_of = [](int rem) { return 1 + rem + rem * (rem + 1) / 2; };
-    const int t_end = ldlt_twist_len(nblk, band), b_start = nblk - t_end;
     for (int st = 0; st < t_end; st++) {   // one step of each chain per launch
         const int kt = st, kb = nblk - 1 - st;
         const int nt = nwg_of(std::min(nblk - kt - 1, band)), nb = nwg_of(std::min(kb, band));
