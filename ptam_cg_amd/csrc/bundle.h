@@ -134,6 +134,8 @@ struct BaDev {
     double* Dg;
     double* y;              // forward-substituted rhs
     double* da;             // [npad] camera update
+    double *SE2, *L2, *Dg2, *y2;   // the second chain of a two-ended persistent elimination: the system's bottom end in mirrored coordinates (ldlt_chain.inc)
+    unsigned* sflags2;      //   and its flag words
     unsigned* sflags;       // flag words of the persistent factorisation (ldlt_chain.inc); [0]: a spin gave up
     unsigned solve_seq;     // its sequence number: a flag is up when it holds the current solve's number (the host increments it)
     double* bw_scratch;     // [2][6 npad] the backward substitution's vectors when they do not fit LDS (solve.hip)

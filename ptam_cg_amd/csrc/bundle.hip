@@ -606,7 +606,9 @@ static int ba_prepare_impl(ptam_ba* ba) {
     const size_t se_full = se_size((int)(npad / SOLVE_NB), (int)(npad / SOLVE_NB) - 1);
     const size_t o_SE = cv.take((se_full + npad + 8) * 8), o_L = cv.take(se_full * 8), o_Dg = cv.take(npad * 8),
                  o_y = cv.take(npad * 8), o_da = cv.take(npad * 8), o_sq2 = cv.take(16),
-                 o_bws = cv.take(npad * 8 * 12), o_sflags = cv.take(ba_solve_flag_bytes((int)(npad / SOLVE_NB)));
+                 o_bws = cv.take(npad * 8 * 12), o_sflags = cv.take(ba_solve_flag_bytes((int)(npad / SOLVE_NB))),
+                 o_sflags2 = cv.take(ba_solve_flag_bytes((int)(npad / SOLVE_NB))), o_SE2 = cv.take((se_full + npad + 8) * 8),
+                 o_L2 = cv.take(se_full * 8), o_Dg2 = cv.take(npad * 8), o_y2 = cv.take(npad * 8);
     const size_t o_out = cv.take(Mz * 4), o_sc = cv.take(sizeof(BaScalars)), o_dbg = cv.take(65536);
     ba->block_bytes = cv.off;
     if (!ctx_cache_take(ctx->dev_cache, ba->block_bytes, &ba->block, &ba->block_cap)) {   // (a released bundle's block, if it fits)
@@ -660,6 +662,11 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.sumsq2 = (double*)(base + o_sq2);
     d.bw_scratch = (double*)(base + o_bws);
     d.sflags = (unsigned*)(base + o_sflags);   // (cleared with the block: sequence numbers start at 1)
+    d.sflags2 = (unsigned*)(base + o_sflags2);
+    d.SE2 = (double*)(base + o_SE2);
+    d.L2 = (double*)(base + o_L2);
+    d.Dg2 = (double*)(base + o_Dg2);
+    d.y2 = (double*)(base + o_y2);
     d.solve_seq = 0;
     d.outliers = (int*)(base + o_out);
     d.sc = (BaScalars*)(base + o_sc);

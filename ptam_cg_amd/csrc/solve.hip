@@ -286,6 +286,10 @@ static int ldlt_twist_len(int nblk, int band) {
 
 size_t ba_solve_flag_bytes(int nblk) { return ch_flag_words(nblk, nblk) * sizeof(unsigned); }
 
+static ChainArgs chain_args_natural(const BaDev& d, int k0, int k1, int kr) {
+    return ChainArgs{d.SE, se_E(d), d.L, d.Dg, d.y, d.sflags, k0, k1, kr, d.n};
+}
+
 int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
     const int nblk = d.npad / NB, band = se_band(d);
     static const bool no_small = getenv("PTAM_LDLT_NO_SMALL") != nullptr;   // (A/B runs: launch-per-block-column form only)
@@ -311,14 +315,32 @@ int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
         if (t_end == 0 && !no_chain && d.sflags && nblk <= CH_MAX_NB && lds <= CH_LDS_MAX) {
             d.solve_seq++;
             if (d.solve_seq >= (1u << 27)) d.solve_seq = 1;   // (flags carry it shifted by up to 4 bits; flags of 2^27 solves ago are no concern)
-            hipLaunchKernelGGL(ldlt_chain_kernel, dim3(8 * ch_roles(nblk)), dim3(TPB), lds, ctx->stream, d, 0, nblk);
+            {
+                const ChainArgs a = chain_args_natural(d, 0, nblk, nblk);
+                hipLaunchKernelGGL(ldlt_chain_kernel, dim3(8 * ch_roles(nblk)), dim3(TPB), lds, ctx->stream, d, a, a, 1);
+            }
             const size_t bw = (size_t)6 * d.npad * sizeof(double);
             hipLaunchKernelGGL(ldlt_backward_kernel<false>, dim3(1), dim3(1024), bw, ctx->stream, d, cur, nblk);
             HIP_TRY(hipGetLastError());
             return PTAM_OK;
         }
     }
-    for (int st = 0; st < t_end; st++) {   // one step of each chain per launch
+    // Two chains: as TWO persistent chains of one launch — the downward one on S itself (blocks 0, 8, 16 ... of the launch: XCD
+    // 0), the upward one on a mirrored copy of the system's bottom end (blocks 1, 9, 17 ...: XCD 1; ldlt_chain.inc, "the bottom
+    // end") — where each chain's block rows fit one XCD; as one launch per step of both chains otherwise.
+    static const bool no_chain2 = getenv("PTAM_LDLT_NO_CHAIN") != nullptr || getenv("PTAM_LDLT_TWIN_LAUNCHES") != nullptr;   // (A/B runs)
+    const int kr2 = std::min(b_start, t_end + band);   // (each chain's rows: its columns and the `band` block rows they reach)
+    const bool two_persistent = t_end >= 2 && !no_chain2 && d.sflags && d.SE2 && kr2 <= CH_MAX_NB && ch_lds_bytes(band) <= CH_LDS_MAX;
+    if (two_persistent) {
+        d.solve_seq++;
+        if (d.solve_seq >= (1u << 27)) d.solve_seq = 1;
+        hipLaunchKernelGGL(ldlt_mirror_in_kernel, dim3(kr2 * (band + 1)), dim3(TPB), 0, ctx->stream, d, kr2);
+        const ChainArgs a0 = chain_args_natural(d, 0, t_end, kr2);
+        const ChainArgs a1{d.SE2, d.SE2 + se_size(nblk, band), d.L2, d.Dg2, d.y2, d.sflags2, 0, t_end, kr2, d.npad};   // (mirrored: the padding comes first, nothing to skip)
+        hipLaunchKernelGGL(ldlt_chain_kernel, dim3(8 * ch_roles(kr2)), dim3(TPB), ch_lds_bytes(band), ctx->stream, d, a0, a1, 2);
+        hipLaunchKernelGGL(ldlt_mirror_out_kernel, dim3(kr2 * (band + 1)), dim3(TPB), 0, ctx->stream, d, t_end, kr2);
+    }
+    for (int st = 0; st < (two_persistent ? 0 : t_end); st++) {   // one step of each chain per launch
         const int kt = st, kb = nblk - 1 - st;
         const int nt = nwg_of(std::min(nblk - kt - 1, band)), nb = nwg_of(std::min(kb, band));
         hipLaunchKernelGGL(ldlt_step_twin_kernel, dim3(nt + nb), dim3(TPB), 0, ctx->stream, d, kt, kb, nt);
@@ -332,7 +354,10 @@ int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
         if (t_end > 0 && !no_chain && d.sflags && n_mid >= 3 && n_mid <= CH_MAX_NB && lds <= CH_LDS_MAX) {
             d.solve_seq++;
             if (d.solve_seq >= (1u << 27)) d.solve_seq = 1;
-            hipLaunchKernelGGL(ldlt_chain_kernel, dim3(8 * ch_roles(n_mid)), dim3(TPB), lds, ctx->stream, d, t_end, b_start);
+            {
+                const ChainArgs a = chain_args_natural(d, t_end, b_start, b_start);
+                hipLaunchKernelGGL(ldlt_chain_kernel, dim3(8 * ch_roles(n_mid)), dim3(TPB), lds, ctx->stream, d, a, a, 1);
+            }
         } else {
             for (int k = t_end; k < b_start; k++) {
                 const int nwg = nwg_of(std::min(b_start - k - 1, band));
@@ -358,4 +383,6 @@ void solve_preload_kernels() {
     ptam_preload((const void*)ldlt_backward_kernel<true>);
     ptam_preload((const void*)ldlt_small_kernel);
     ptam_preload((const void*)ldlt_chain_kernel);
+    ptam_preload((const void*)ldlt_mirror_in_kernel);
+    ptam_preload((const void*)ldlt_mirror_out_kernel);
 }

@@ -87,6 +87,12 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d.cam_free, 16));
     CK(hipMalloc(&d.bw_scratch, (size_t)12 * npad * 8));
     CK(hipMalloc(&d.sflags, ba_solve_flag_bytes(nblk)));
+    CK(hipMalloc(&d.sflags2, ba_solve_flag_bytes(nblk)));
+    CK(hipMemset(d.sflags2, 0, ba_solve_flag_bytes(nblk)));
+    CK(hipMalloc(&d.SE2, tot * 8));
+    CK(hipMalloc(&d.L2, ssz * 8));
+    CK(hipMalloc(&d.Dg2, npad * 8));
+    CK(hipMalloc(&d.y2, npad * 8));
     CK(hipMemset(d.sflags, 0, ba_solve_flag_bytes(nblk)));
     CK(hipMalloc(&dbg, 65536 * 8));
     CK(hipMemset(dbg, 0, 65536 * 8));
