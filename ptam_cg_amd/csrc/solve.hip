@@ -280,7 +280,7 @@ int ba_solve_init() {
 // The two chains must never update the same tile: the middle keeps at least 2 * band blocks.
 static int ldlt_twist_len(int nblk, int band) {
     static const bool off = getenv("PTAM_LDLT_ONE_ENDED") != nullptr;   // (A/B runs)
-    if (off || band < 1 || nblk < 4 * band + 4) return 0;
+    if (off || band < 1 || nblk < 2 * band + 8) return 0;   // (at least four block columns per chain: below that the mirrored copy and the third launch cost what the shorter chain saves)
     return (nblk - 2 * band) / 2;
 }
 
