@@ -124,7 +124,7 @@ int main(int argc, char** argv) {
     printf("F %d n %d nblk %d band %d: %.2f us per solve (copy included), max |da - ref| = %.3e (|ref| max %.3e) %s\n", F, n, nblk, band,
            1e3 * best / reps, err, nrm, err <= 1e-11 * nrm + 1e-300 ? "OK" : "MISMATCH");
 #ifdef K7_TIMING
-    if (!getenv("PTAM_LDLT_NO_CHAIN") && nblk > SM_USE_NB && nblk <= CH_MAX_NB) {
+    if (!getenv("PTAM_LDLT_NO_CHAIN") && nblk > SM_USE_NB) {
         std::vector<long long> st(512);
         CK(hipMemcpy(st.data(), dbg, 512 * 8, hipMemcpyDeviceToHost));
         {
@@ -132,6 +132,13 @@ int main(int argc, char** argv) {
             CK(hipMemcpy(fl.data(), d.sflags, fl.size() * 4, hipMemcpyDeviceToHost));
             printf("error word %u | F[0] %u (seq %u, plain stores %u) | XCC ids:", fl[0], fl[1], fl[1] >> 1, fl[1] & 1);
             for (int i = 0; i < ch_roles(nblk); i++) printf(" %u", fl[1 + 2 * nblk + i] & 0xf);
+            printf("\n");
+        }
+        {
+            std::vector<unsigned> fl(ch_flag_words(nblk, band));
+            CK(hipMemcpy(fl.data(), d.sflags2, fl.size() * 4, hipMemcpyDeviceToHost));
+            printf("second chain: F[0] %u (seq %u, plain stores %u) | XCC ids:", fl[1], fl[1] >> 1, fl[1] & 1);
+            for (int i = 0; i < 24; i++) printf(" %u", fl[1 + 2 * nblk + i] & 0xf);
             printf("\n");
         }
         printf("chain stamps per step (cycles): factor | stores + wait for the row | row step, flags | (step total)\n");
