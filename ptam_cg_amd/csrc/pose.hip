@@ -430,8 +430,10 @@ __global__ void __launch_bounds__(GN_THREADS) pose_gn_batch_kernel(DevCam cam, c
 // keys of the order statistic in LDS, wave sums by DPP (no LDS round trips), same arithmetic and
 // the same fixed reduction order as the general kernel above.
 // ------------------------------------------------------------------------------------------------
+#ifndef GS_THREADS
 #define GS_THREADS 256   // the workgroup of the 1024- and 256-measurement instantiations
 #define GS_MPT 4         // measurements per thread of the largest one: n <= 1024
+#endif
 static_assert(GS_THREADS * GS_MPT == GS_LIMIT, "GS_LIMIT");
 #define GS_WAVE_LIMIT 64 // lists of at most 64 measurements (the coarse set: Tracker.CoarseMax = 60) run as ONE wave — see pose_gn_small_kernel
 #define GS_BINS 2048   // 11-bit digits of the order-statistic select
@@ -883,6 +885,7 @@ __device__ __forceinline__ void pose_gn_small_body(const DevCam& cam, int n, con
                 v += dpp_row_shr_f64<2>(v);
                 v += dpp_row_shr_f64<4>(v);
             }
+            if (GS_SLICES > 8) v += dpp_row_shr_f64<8>(v);
             if (part == GS_SLICES - 1) sh.red[0][k] = v;
         }
         __syncthreads();

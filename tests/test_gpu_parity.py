@@ -270,6 +270,10 @@ BA_CASES = {
     "chain_33x500": dict(n_cams=33, n_pts=500, seed=41),
     "chain_58x700_w20": dict(n_cams=58, n_pts=700, seed=42, window=20),
     "chain_64x900": dict(n_cams=64, n_pts=900, seed=43),
+    # 19 block rows with a band of ~9: too many for a dense worker's LDS, not banded enough for two chains -> one persistent chain
+    # whose row workers hold only their band; and 24 block rows of band ~5: two persistent chains with four columns each
+    "chain_100x900_w40": dict(n_cams=100, n_pts=900, seed=44, window=40),
+    "twisted_128x1200_w24_chains": dict(n_cams=128, n_pts=1200, seed=45, window=24),
     # long banded trajectories: camera system of 23 / 35 blocks with a 2- / 3-block band -> two-ended LDL^T (solve.hip)
     "twisted_120x1500_w8": dict(n_cams=120, n_pts=1500, seed=21, window=8),
     "twisted_181x2500_w12_f3": dict(n_cams=181, n_pts=2500, seed=22, window=12, n_fixed=3),
