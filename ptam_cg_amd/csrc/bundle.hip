@@ -809,6 +809,13 @@ static int ba_allreduce(ptam_ba* ba, double* dptr, size_t count) {
 }
 
 // pass 1 + sigma^2
+static int ba_sel_blocks() {   // workgroup cap of select_compact_kernel (each scans the first-level histogram for itself)
+    static const int n = [] {
+        const char* e = getenv("PTAM_SEL_BLOCKS");
+        return e ? std::max(1, atoi(e)) : 256;
+    }();
+    return n;
+}
 static int ba_pass1_sigma(ptam_ba* ba) {
     ptam_ctx* ctx = ba->ctx;
     BaDev& d = ba->d;
@@ -828,7 +835,7 @@ static int ba_pass1_sigma(ptam_ba* ba) {
     prof_end(ba, PTAM_K_PROJECT);
     prof_begin(ba, PTAM_K_SELECT);
     if (!sharded) {
-        hipLaunchKernelGGL(select_compact_kernel, dim3(std::max(1, std::min((d.M + 1023) / 1024, 256))), dim3(256), 0,
+        hipLaunchKernelGGL(select_compact_kernel, dim3(std::max(1, std::min((d.M + 1023) / 1024, ba_sel_blocks()))), dim3(256), 0,
                            ctx->stream, d, (const double*)d.m_e2, (long long)d.M, (const uint8_t*)d.m_state);
     } else if (!ba->slow_select) {
         if (!ba->d_sel) {   // sized by the world the communicator was set for (ptam_ba_set_comm drops it on a change)
@@ -849,7 +856,7 @@ static int ba_pass1_sigma(ptam_ba* ba) {
         };
         int rc = reduce_hist(d.hist);
         if (rc) return rc;
-        hipLaunchKernelGGL(select_compact_kernel, dim3(std::max(1, std::min((d.M + 1023) / 1024, 256))), dim3(256), 0,
+        hipLaunchKernelGGL(select_compact_kernel, dim3(std::max(1, std::min((d.M + 1023) / 1024, ba_sel_blocks()))), dim3(256), 0,
                            ctx->stream, d, (const double*)d.m_e2, (long long)d.M, (const uint8_t*)d.m_state);
         rc = reduce_hist(d.hist + HIST_BINS);
         if (rc) return rc;
@@ -1049,7 +1056,7 @@ static int ba_enqueue_speculative(ptam_ba* ba, double lambda_next, double lambda
     const double min_s2 = ba->opts.min_sigma * ba->opts.min_sigma;
     d.guard = 1;
     hipLaunchKernelGGL(purge_pass1_kernel, dim3(std::max(1, std::min((d.M + 256 * P1_U - 1) / (256 * P1_U), ba_p1_blocks()))), dim3(256), 0, ctx->stream, d);
-    hipLaunchKernelGGL(select_compact_kernel, dim3(std::max(1, std::min((d.M + 1023) / 1024, 256))), dim3(256), 0, ctx->stream, d,
+    hipLaunchKernelGGL(select_compact_kernel, dim3(std::max(1, std::min((d.M + 1023) / 1024, ba_sel_blocks()))), dim3(256), 0, ctx->stream, d,
                        (const double*)d.m_e2, (long long)d.M, (const uint8_t*)d.m_state);
     hipLaunchKernelGGL(select_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, d, ba->opts.estimator, min_s2);
     launch_k7(ba, 1);
