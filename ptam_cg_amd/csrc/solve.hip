@@ -1,7 +1,17 @@
 // solve.hip — K9: dense SPD camera system  S * da = E  (src/Bundle.cc:457-458,
 // `Cholesky<>(mS).backsub(vE)`: TooN's unpivoted LDL^T reading the lower triangle).
 //
-// Blocked right-looking LDL^T, block size 32, ONE launch per block column k.  Every workgroup of
+// Blocked LDL^T, block size 32, in the block band of S.  Which form runs (ba_solve, bottom of this file):
+//   1 - 2 block rows                 ldlt_small_kernel: everything in one workgroup (ldlt_small.inc);
+//   3 .. 13 dense, <= 28 banded      ONE persistent launch: a chain workgroup through the pivot blocks, a workgroup per block
+//                                    row, one for the right-hand side, hand-offs by flags on one XCD (ldlt_chain.inc);
+//   banded, nblk >= 2 band + 8       eliminated from BOTH ends: two such chains in one launch (the upward one on a mirrored
+//                                    copy of the bottom end, on a second XCD), then the middle part as a third;
+//   anything else (and A/B runs)     one launch per block column — the form described next (ldlt_step_body.inc; for a
+//                                    two-ended elimination one launch per step of both chains, ldlt_step_twin_kernel);
+// then ldlt_backward_kernel: D^-1 and the backward substitution, trial poses, |da|^2.
+//
+// The launch-per-block-column form: right-looking, ONE launch per block column k.  Every workgroup of
 // step k re-factors the 32x32 diagonal block (cheap; avoids an extra launch + hand-off) and, in the
 // SAME loop, carries along
 //   - its panel blocks  X = A_ik * Lkk^-T  (so L_ik = X * D^-1),
