@@ -174,21 +174,38 @@ __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur, i
     const int t_end = nblk - b_start;                 // blocks of each chain (0: one-ended elimination)
     const int k_stop = chain == 0 ? 0 : t_end;        // workgroup 1 stops above the middle
     double wnext = d.L[se_blk(b_start - 1, b_start - 1, band) + rr * NB + c];   // Lkk^-T element (rr, c)
+#ifdef K7_TIMING
+#define BW_STAMP(i) if (tid == 0 && chain == 0) d.dbg[1000 + 8 * k + (i)] = (long long)__builtin_readcyclecounter();
+#else
+#define BW_STAMP(i)
+#endif
+    // work item of the updates = (tile, slice of 8 rows, column): thread -> (tid >> 7, (tid >> 5) & 3, tid & 31), eight tiles of
+    // L(k, .) per round.  (No division by a run-time count anywhere: `tid % ncol`, `tid / ncol` — two integer divisions per
+    // thread and block — were 400 of a block's 3 300 cycles, on the chain.)  What stands between two blocks now is the
+    // requests themselves: 16 waves x 9 loads x 512 B are ~1 000 cycles of the CU's one memory pipeline at 10 block rows, and
+    // the waves wait for queue space wherever the requests are placed (issued during the previous block's mat-vec they made
+    // THAT 900 cycles longer: measured, no gain).
+    const int ucol = tid & (NB - 1), sl0 = (tid >> 5) & 3, ut0 = tid >> 7;
+    auto fetch_l = [&](int k, double (&l)[8]) {
+        const int jb0 = max(0, k - band);
+        const double* src = d.L + se_blk(k, jb0, band) + (size_t)ut0 * (NB * NB) + (sl0 * 8) * NB + ucol;
+        const bool on = ut0 < k - jb0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) l[q] = on ? src[q * NB] : 0.0;
+    };
     for (int k = b_start - 1; k >= k_stop; k--) {
         const double w = wnext;
         if (k > k_stop) wnext = d.L[se_blk(k - 1, k - 1, band) + rr * NB + c];   // prefetch the next block
-        // first round of this block's update operands (independent of x_k): in flight during the mat-vec
-        // columns of the blocks above that row block k reaches: all of them, or — S banded — the last `band` blocks
-        const int jlo = max(0, k - band) * NB, ncol = k * NB - jlo;
-        // block row k of L: its blocks left of the diagonal are contiguous, column j of row q sits at
-        const double* Lrow = d.L + se_blk(k, max(0, k - band), band);
-        auto l_at = [&](int q, int j) { return Lrow[(size_t)((j - jlo) / NB) * (NB * NB) + q * NB + ((j - jlo) % NB)]; };
-        const bool upd = tid < ncol * 4;
-        const int j0 = jlo + (upd ? tid % ncol : 0), sl0 = upd ? tid / ncol : 0;
         double lreg[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) lreg[q] = upd ? l_at(sl0 * 8 + q, j0) : 0.0;
+        fetch_l(k, lreg);   // this block's update operands (independent of x_k): in flight during the mat-vec
+        // columns of the blocks above that row block k reaches: all of them, or — S banded — the last `band` blocks
+        const int jb0 = max(0, k - band), nbk = k - jb0, jlo = jb0 * NB;   // nbk tiles L(k, jb0 .. k-1), contiguous in block row k of L
+        const double* Lrow = d.L + se_blk(k, jb0, band);
+        const bool upd = ut0 < nbk;
+        const int j0 = jlo + ut0 * NB + ucol;
+        BW_STAMP(0)
         __syncthreads();   // (A) pending sums of the previous block are complete
+        BW_STAMP(1)
         const int kc = k * NB + c;
         double p = (c >= rr) ? w * (wv[kc] - ((pend[kc] + pend[npad + kc]) + (pend[2 * npad + kc] + pend[3 * npad + kc]))) : 0.0;   // upper triangular
         // 32-lane sum on the VALU (DPP row shifts, then lane 15 of rows 0 / 2 into rows 1 / 3): five ds_bpermute
@@ -199,7 +216,9 @@ __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur, i
         p += dpp_row_shr_f64<8>(p);
         p += dpp_bcast_f64<0x142, 0xA>(p);
         if (c == NB - 1) xs[k * NB + rr] = p;
+        BW_STAMP(2)
         __syncthreads();   // (B) x_k visible
+        BW_STAMP(3)
         // pending sums of the blocks above: column j, rows of block k in four slices of 8
         if (upd) {
             double a = 0;
@@ -207,13 +226,13 @@ __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur, i
             for (int q = 0; q < 8; q++) a += lreg[q] * xs[k * NB + sl0 * 8 + q];
             pend[sl0 * npad + j0] += a;   // (thread (slice, column) is the only writer of its slot in this round)
         }
-        for (int idx = tid + 1024; idx < ncol * 4; idx += 1024) {
-            const int j = jlo + idx % ncol, sl = idx / ncol;
+        for (int ut = ut0 + 8; ut < nbk; ut += 8) {   // (more than eight tiles in the block row)
             double a = 0;
 #pragma unroll
-            for (int q = 0; q < 8; q++) a += l_at(sl * 8 + q, j) * xs[k * NB + sl * 8 + q];
-            pend[sl * npad + j] += a;
+            for (int q = 0; q < 8; q++) a += Lrow[(size_t)ut * (NB * NB) + (sl0 * 8 + q) * NB + ucol] * xs[k * NB + sl0 * 8 + q];
+            pend[sl0 * npad + jlo + ut * NB + ucol] += a;
         }
+        BW_STAMP(4)
     }
     __syncthreads();
     for (int k = b_start; k < nblk && chain == 1; k++) {
