@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur, i
     const int tid = threadIdx.x;
     const int c = tid % NB, rr = tid / NB;
     // (the persistent factorisation's error word: a spin gave up during THIS solve — the host stops the adjustment)
-    if (tid == 0 && chain == 0 && d.sflags && d.solve_seq != 0 && d.sflags[0] == d.solve_seq) d.sc->solve_fault = 1;
+    if (tid == 0 && chain == 0 && d.sflags && d.sflags[0] != 0) d.sc->solve_fault = 1;   // (sticky: any launch of any solve of this bundle; a solve may be three launches with three sequence numbers)
     for (int i = tid; i < npad; i += 1024) {
         pend[i] = pend[npad + i] = pend[2 * npad + i] = pend[3 * npad + i] = 0.0;
         wv[i] = d.y[i] / d.Dg[i];
