@@ -1476,7 +1476,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
                 }
             }
             if (sc.solve_fault) {
-                // (a workgroup of the persistent factorisation waited ~0.1 s for another one and gave up — it cannot happen
+                // (a workgroup of the persistent factorisation waited ~2 s for another one and gave up — it cannot happen
                 //  while all of them are resident, which a launch of a dozen workgroups on an otherwise idle XCD is)
                 ptam_set_error("bundle adjustment: the persistent camera solve timed out (set PTAM_LDLT_NO_CHAIN=1 to use the launch-per-block form)");
                 return PTAM_E_HIP;
