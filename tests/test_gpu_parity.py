@@ -690,3 +690,45 @@ def test_bundle_points_without_measurements(hip, oracle, cams, pts, lo, hi):
     assert a["accepted"] > 0
     assert np.array_equal(a["points"][lo:hi], q["points"][lo:hi])          # untouched
     assert not np.array_equal(a["points"][hi:hi + 5], q["points"][hi:hi + 5])   # the others moved
+
+
+def test_persistent_solve_under_contention(hip):
+    """The persistent camera solve's workgroups wait for each other through flags (csrc/ldlt_chain.inc): with other queues
+    keeping the device busy every one of them must still be dispatched — a spin that gives up surfaces as PTAM_E_HIP — and
+    in deterministic mode the results must be bit-identical to the quiet runs (one chain: 50 dense cameras; two chains and a
+    middle part: 140 cameras, window 12).  tests/tools/stress_chain_contention.py is the long form."""
+    import threading
+    import time
+    probs = [synth.make_ba_problem(n_cams=50, n_pts=1500, seed=7), synth.make_ba_problem(n_cams=140, n_pts=2500, seed=8, window=12)]
+    quiet = [util.run_ba(hip, p, max_iterations=5, deterministic=1) for p in probs]
+    stop = []
+
+    def load():
+        ctx = host.Context(lib=hip)
+        a, b = synth.make_frame_pair()
+        kfa = host.KeyFrame(ctx).MakeKeyFrame_Lite(a)
+        case = synth.make_trackmap_case([kfa.level(l) for l in range(4)])
+        tr = host.Tracker(ctx, len(case["world"]))
+        tr.set_map(case["world"], case["pixel_right_w"], case["pixel_down_w"], kfa, case["src_level"], case["center"])
+        kfb, d_im, opts = host.KeyFrame(ctx), host.DevBuf(ctx, b), tr.opts()
+        while not stop:
+            tr.set_shuffle(case["shuffle_levels"], case["shuffle_fine"])
+            tr.TrackFrame(kfb, d_im, case["pose_in"], opts)
+
+    threads = [threading.Thread(target=load) for _ in range(4)]
+    for t in threads:
+        t.start()
+    try:
+        t0, runs = time.time(), 0
+        while time.time() - t0 < 3.0:
+            for p, q in zip(probs, quiet):
+                r = util.run_ba(hip, p, max_iterations=5, deterministic=1)
+                assert len(r["trials"]) == len(q["trials"])
+                assert np.array_equal(r["poses"], q["poses"]) and np.array_equal(r["points"], q["points"])
+                runs += 1
+        assert runs >= 4
+    finally:
+        stop.append(1)
+        for t in threads:
+            t.join()
+
