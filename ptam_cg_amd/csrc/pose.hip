@@ -706,6 +706,10 @@ __device__ __forceinline__ void pose_gn_small_body(const DevCam& cam, int n, con
     __shared__ Sh sh;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (size_guard == 1 && *n_dev > THREADS * MPT) return;   // (the general kernel, enqueued behind this one, takes the long list)
+    if (size_guard == 3 && *n_dev > THREADS * MPT) {         // (nobody is behind me: tell the host to send the general kernel)
+        if (threadIdx.x == 0 && io.result_seq) *(volatile unsigned long long*)io.result_seq = io.seq | POSE_CHAIN_LONG;
+        return;
+    }
     if (n_dev) n = min(n, max(*n_dev, 0));   // counted variant: the measurement list was compacted on the device
     if (tid < 12) sh.pose[tid] = pin.use ? pin.v[tid] : pose_io[tid];
     if (tid < 6) sh.mu[tid] = 0;
@@ -1263,8 +1267,13 @@ static int pose_gn_dev_impl(ptam_ctx* ctx, int n, const int32_t* d_n, const ptam
 
 // resident TrackMap chain: the list length sits in device memory and may exceed what the register-resident kernel holds,
 // so BOTH kernels are enqueued and the length picks the one that runs (the other leaves at once)
+// mode 0: the register-resident kernel and, when the list may exceed it, the general one behind it (the length picks one on the
+// device).  mode 1: the register-resident kernel only — on a longer list it publishes io.seq with POSE_CHAIN_LONG set instead
+// of a result, and the caller comes back with mode 2: the general kernel alone.  (A frame's list is longer than 1024 only in
+// maps that put more than a thousand points into one view; the general kernel launched behind every frame "just in case" and
+// returning at once cost the single-camera chain 4.3 us per frame.)
 int pose_launch_chain(ptam_ctx* ctx, int n_cap, const int* d_n, const ptam_pose_meas* d_meas, const ptam_projection* d_entry,
-                      double* d_pose_inout, const ptam_gn_opts* opts, int32_t* d_outlier_flags, const PoseChainIo& io) {
+                      double* d_pose_inout, const ptam_gn_opts* opts, int32_t* d_outlier_flags, const PoseChainIo& io, int mode) {
     ARG_TRY(ctx && n_cap >= 1 && d_n && d_meas && d_pose_inout && opts);
     const bool may_be_long = n_cap > GS_LIMIT;
     const size_t bs = may_be_long ? (size_t)n_cap * sizeof(PoseState) : 0, bu = (size_t)6 * 32 * 8;
@@ -1276,12 +1285,13 @@ int pose_launch_chain(ptam_ctx* ctx, int n_cap, const int* d_n, const ptam_pose_
     //  straight-line work per iteration and a ranking select without a histogram)
     int thr;
     const pose_small_fn fn = pose_small_pick(std::min(n_cap, GS_LIMIT), &thr);
-    hipLaunchKernelGGL(fn, dim3(1), dim3(thr), 0, ctx->stream,
-                       ctx->cam, std::min(n_cap, GS_LIMIT), d_meas, d_entry, d_pose_inout, *opts, d_outlier_flags, d_u, (ulonglong2*)nullptr,
-                       0ull, d_n, PoseIn{}, io, may_be_long ? 1 : 0);
-    if (may_be_long)
+    if (mode != 2)
+        hipLaunchKernelGGL(fn, dim3(1), dim3(thr), 0, ctx->stream,
+                           ctx->cam, std::min(n_cap, GS_LIMIT), d_meas, d_entry, d_pose_inout, *opts, d_outlier_flags, d_u, (ulonglong2*)nullptr,
+                           0ull, d_n, PoseIn{}, io, may_be_long ? (mode == 1 ? 3 : 1) : 0);
+    if (may_be_long && mode != 1)
         hipLaunchKernelGGL(pose_gn_kernel, dim3(1), dim3(GN_THREADS), 0, ctx->stream, ctx->cam, n_cap, d_meas, d_entry, d_pose_inout, *opts,
-                           (PoseState*)s, d_outlier_flags, d_u, d_n, PoseIn{}, io, 2);
+                           (PoseState*)s, d_outlier_flags, d_u, d_n, PoseIn{}, io, mode == 2 ? 0 : 2);
     HIP_TRY(hipGetLastError());
     return PTAM_OK;
 }

@@ -71,5 +71,6 @@ struct PoseBatchItem {
 };
 int pose_launch_chain_batch(ptam_ctx* ctx, int nb, int n_cap_max, const PoseBatchItem* d_items, const ptam_gn_opts* opts);
 int pose_chain_scratch(ptam_ctx* ctx, int n_cap, void** st_out, double** updates_out);
+#define POSE_CHAIN_LONG (1ull << 63)   // in the published sequence word: "the list is longer than the register-resident kernel holds" (pose.hip)
 int pose_launch_chain(ptam_ctx* ctx, int n_cap, const int* d_n, const ptam_pose_meas* d_meas, const ptam_projection* d_entry,
-                      double* d_pose_inout, const ptam_gn_opts* opts, int32_t* d_outlier_flags, const PoseChainIo& io);
+                      double* d_pose_inout, const ptam_gn_opts* opts, int32_t* d_outlier_flags, const PoseChainIo& io, int mode = 0);

@@ -489,17 +489,28 @@ __device__ __forceinline__ void tm_gather_body(const TmDev& d, int stage, int co
     // found slots in front of my workgroup's first (workgroup 0: also the totals and the per-level counts of this stage)
     const int upto = bx == 0 ? g_end : s0;
     int before = 0, total = 0, lf[4] = {0, 0, 0, 0}, la[4] = {0, 0, 0, 0}, nk = 0;
-    for (int j = lane; j < upto; j += TM_GATHER_THREADS) {
-        const int w = d.slot_stat[j];
-        total += w & 1;
-        if (j < s0) before += w & 1;
-        if (bx == 0 && j >= st_first) {
-            const int l = (w >> 2) & 3;
-            nk += (w >> 4) & 1;
+    // (eight status words per lane and round, requested together: one word per round was a round trip per 64 slots — twenty
+    //  in a row for the last workgroup of a thousand-slot list)
+    for (int jb = 0; jb < upto; jb += 8 * TM_GATHER_THREADS) {
+        int wq[8];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                lf[q] += (l == q) & (w & 1);
-                la[q] += (l == q) & ((w >> 1) & 1);
+        for (int u = 0; u < 8; u++) {
+            const int j = jb + u * TM_GATHER_THREADS + lane;
+            wq[u] = j < upto ? d.slot_stat[j] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int j = jb + u * TM_GATHER_THREADS + lane, w = wq[u];
+            total += w & 1;
+            if (j < s0) before += w & 1;
+            if (bx == 0 && j >= st_first && j < upto) {
+                const int l = (w >> 2) & 3;
+                nk += (w >> 4) & 1;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    lf[q] += (l == q) & (w & 1);
+                    la[q] += (l == q) & ((w >> 1) & 1);
+                }
             }
         }
     }
@@ -1201,20 +1212,31 @@ static int track_map_impl(ptam_tracker* t, ptam_kf* cur, const uint8_t* d_new_fr
         io.result_depth = t->mbox_dev->depth3;
         io.result_seq = &t->mbox_dev->seq;
         io.seq = seq;
-        rc = pose_launch_chain(ctx, std::max(n, 1), &d.ctl->n_meas, d.meas, d.entry, d.pose, &g, d.outlier, io);
+        rc = pose_launch_chain(ctx, std::max(n, 1), &d.ctl->n_meas, d.meas, d.entry, d.pose, &g, d.outlier, io, 1);
         if (rc) return rc;
-    }
-    HIP_TRY(hipGetLastError());
-    unsigned spins = 0;
-    while (*(volatile unsigned long long*)&t->mbox->seq != seq) {
-        if (++spins == 100000) {
-            spins = 0;
-            const hipError_t q = hipStreamQuery(st);
-            if (q != hipSuccess && q != hipErrorNotReady) {
-                ptam_set_error("track_map: stream failed: %s", hipGetErrorString(q));
-                return PTAM_E_HIP;
+        HIP_TRY(hipGetLastError());
+        // the frame's last kernel publishes the sequence number — or, for a list of more than 1024 measurements, asks for the
+        // general kernel (pose.hip: pose_launch_chain), which then publishes it
+        for (int pass = 0; pass < 2; pass++) {
+            unsigned spins = 0;
+            unsigned long long v;
+            while (((v = *(volatile unsigned long long*)&t->mbox->seq) & ~POSE_CHAIN_LONG) != seq) {
+                if (++spins == 100000) {
+                    spins = 0;
+                    const hipError_t q = hipStreamQuery(st);
+                    if (q != hipSuccess && q != hipErrorNotReady) {
+                        ptam_set_error("track_map: stream failed: %s", hipGetErrorString(q));
+                        return PTAM_E_HIP;
+                    }
+                    if (q == hipSuccess && (*(volatile unsigned long long*)&t->mbox->seq & ~POSE_CHAIN_LONG) != seq) return PTAM_E_HIP;
+                }
             }
-            if (q == hipSuccess && *(volatile unsigned long long*)&t->mbox->seq != seq) return PTAM_E_HIP;
+            if (!(v & POSE_CHAIN_LONG)) break;
+            if (pass == 1) return PTAM_E_STATE;
+            t->mbox->seq = 0;   // (the stream is idle: nobody else writes the word until the general kernel does)
+            rc = pose_launch_chain(ctx, std::max(n, 1), &d.ctl->n_meas, d.meas, d.entry, d.pose, &g, d.outlier, io, 2);
+            if (rc) return rc;
+            HIP_TRY(hipGetLastError());
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
