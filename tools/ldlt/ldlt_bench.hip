@@ -178,8 +178,8 @@ int main(int argc, char** argv) {
         std::vector<long long> st(8 * 64);
         CK(hipMemcpy(st.data(), dbg + 1000, st.size() * 8, hipMemcpyDeviceToHost));
         printf("backward kernel, workgroup 0, per block (cycles): loads issued | barrier A | mat-vec, x written | barrier B | updates | (to next block)\n");
-        for (int k = nblk - 1; k >= 0 && k > nblk - 12; k--)
-            if (st[8 * k]) printf("  k %2d: %5lld %5lld %5lld %5lld (%lld)\n", k, st[8 * k + 1] - st[8 * k], st[8 * k + 2] - st[8 * k + 1], st[8 * k + 3] - st[8 * k + 2],
+        for (int k = nblk - 1, shown = 0; k >= 0 && shown < 12; k--)
+            if (st[8 * k] && ++shown) printf("  k %2d: %5lld %5lld %5lld %5lld (%lld)\n", k, st[8 * k + 1] - st[8 * k], st[8 * k + 2] - st[8 * k + 1], st[8 * k + 3] - st[8 * k + 2],
                    st[8 * k + 4] - st[8 * k + 3], k > 0 ? st[8 * (k - 1)] - st[8 * k + 4] : 0);
     }
 #endif
