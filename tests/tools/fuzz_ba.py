@@ -1,4 +1,6 @@
-"""Random bundle shapes, HIP vs oracle trial by trial.   usage: fuzz_ba.py [seed] [n] [--diag] [--deterministic]
+"""Random bundle shapes, HIP vs oracle trial by trial.   usage: fuzz_ba.py [seed] [n] [--diag] [--deterministic] [--big]
+--big draws up to 220 cameras with covisibility windows (camera systems of up to 42 block rows: one persistent chain, two
+chains + middle part, launch-per-block-column forms) and fewer points, so that the oracle's dense solve stays in seconds.
 --deterministic runs the HIP side with ptam_ba_opts.deterministic = 1 (camera sums in a fixed order).
 --diag prints, for every mismatching case, the per-trial differences (is the discrete trajectory — lambda, accepted,
 n_bad — the same and only the floating-point values drift, or does it fork?)."""
@@ -16,8 +18,9 @@ det = 1 if "--deterministic" in sys.argv else 0
 rng = np.random.default_rng(int(args[0]) if len(args) > 0 else 7)
 bad = 0
 for i in range(int(args[1]) if len(args) > 1 else 150):
-    n_cams = int(rng.integers(2, 90)); n_pts = int(rng.integers(3, 900))
-    window = None if rng.random() < 0.35 else int(rng.integers(2, max(3, n_cams)))
+    big = "--big" in sys.argv
+    n_cams = int(rng.integers(60, 220)) if big else int(rng.integers(2, 90)); n_pts = int(rng.integers(200, 700)) if big else int(rng.integers(3, 900))
+    window = (int(rng.integers(4, 60)) if big else (None if rng.random() < 0.35 else int(rng.integers(2, max(3, n_cams)))))
     case = dict(n_cams=n_cams, n_pts=n_pts, seed=5000 + i, window=window, n_fixed=int(rng.integers(1, min(4, n_cams))),
                 outlier_frac=float(rng.choice([0.0, 0.02, 0.15])), pt_noise=float(rng.choice([0.002, 0.01, 0.05])),
                 dup=int(rng.choice([1, 1, 1, 3])))
