@@ -55,7 +55,7 @@ def parse():
     return ap.parse_args()
 
 
-def tracking_bench(hip, host, synth, frames=250, replicas=True):
+def tracking_bench(hip, host, synth, seq, frames=250, replicas=True):
     """tracked frames/s: K1+K2 (keyframe) + K3 (1000 patches) + K4 (pose GN, 10 iterations)."""
     C = ctypes
     ctx = host.Context(lib=hip)
@@ -144,15 +144,72 @@ def tracking_bench(hip, host, synth, frames=250, replicas=True):
     # the headline tracking figure: one dependent chain per frame through the C ABI, driven by a native host thread
     # (ptam_bench_track_frames, one context); frame_chain["fps"] is the same loop driven from Python (ctypes + interpreter per call)
     native1 = chain["aggregate_fps_by_concurrent_contexts"]["1"]
-    return {"tracked_fps": native1, "frame_us": 1e6 / native1, "frame_chain": chain, "kernels": tracking_kernel_record(),
+    moving = tracking_moving_bench(hip, host, synth, ctx, seq)
+    return {"tracked_fps": moving["fps"], "frame_us": moving["frame_us"], "moving_camera": moving,
+            "tracked_fps_stationary": native1, "frame_us_stationary": 1e6 / native1,
+            "frame_chain": chain, "kernels": tracking_kernel_record(),
             "fine_stage_only_fps": 1.0 / stage["frame"], "fine_stage_only_frame_us": stage["frame"] * 1e6,
             "keyframe_us": stage["keyframe"] * 1e6, "keyframe_plus_patch_us": stage["patch"] * 1e6,
             "pose_gn_us": stage["pose_dev"] * 1e6, "pose_gn_host_buffers_us": stage["pose"] * 1e6,
             "frame_host_staged_pose_us": stage["frame_staged"] * 1e6,
             "gather_us": stage["gather"] * 1e6,
             "frame_us_min_max_of_5_blocks": [spread["frame"][0] * 1e6, spread["frame"][1] * 1e6], "patches_per_frame": int(len(q)), "pose_meas": int(n),
-            "note": "tracked_fps / frame_us = the resident TrackMap chain, one context, native host thread (frame_chain: the same driven from Python, and k contexts); fine_stage_only_* = round 1's frame: pyramid + FAST + "
+            "note": "tracked_fps / frame_us = the moving-camera sequence (moving_camera: closed loop with the motion model, templates re-warped as the warps move); "
+                    "*_stationary = one image tracked from one prediction over and over, every template kept (the figure of rounds 2-3); frame_chain: "
+                    "the stationary frame driven from Python, and k contexts; fine_stage_only_* = round 1's frame: pyramid + FAST + "
                     "1000-patch search + gather + one 10-iteration pose solve fed from a separate pose case"}
+
+
+SEQ_FRAMES = 64   # frames of the closed trajectory (synth.sequence_pose), visited round and round
+
+
+def moving_sequence(synth):
+    """the moving-camera workload of the tracked-frames half of the metric: 64 rendered 640x480 frames of a camera that
+    translates, rises, rolls and tilts over a textured plane, and the view the map is made of"""
+    frames, poses, kim, kpose = synth.make_tracking_frames(SEQ_FRAMES)
+    return {"frames": frames, "poses": poses, "kf_image": kim, "kf_pose": kpose}
+
+
+def tracking_moving_bench(hip, host, synth, ctx, seq, passes=16):
+    """Tracker::TrackFrame's tracking branch (src/Tracker.cc:94,134-137) frame after frame on the moving sequence, closed loop
+    from one native host thread (ptam_bench_track_sequence): keyframe of the new image, motion-model prediction, bTryCoarse from
+    the velocity, TrackMap, motion-model update.  The per-point PatchFinders re-warp their templates whenever the warp has moved
+    by more than 0.07 (src/PatchFinder.cc:103-111)."""
+    kf0 = host.KeyFrame(ctx).MakeKeyFrame_Lite(seq["kf_image"])
+    m = synth.make_sequence_map([kf0.level(l) for l in range(4)], seq["kf_pose"])
+    tr = host.Tracker(ctx, len(m["world"]))
+    tr.set_map(m["world"], m["pixel_right_w"], m["pixel_down_w"], kf0, m["src_level"], m["center"])
+    kf = host.KeyFrame(ctx)
+    d_frames = [host.DevBuf(ctx, f) for f in seq["frames"]]
+    opts = tr.opts()
+    mm = tr.motion_model(seq["poses"][0])
+    tr.track_sequence_native(kf, d_frames, mm, opts, m["shuffle_levels"], m["shuffle_fine"], passes=2)             # warm-up: two rounds
+    blocks, stats = [], None
+    for _ in range(5):
+        secs, st = tr.track_sequence_native(kf, d_frames, mm, opts, m["shuffle_levels"], m["shuffle_fine"], passes=max(1, passes // 5),
+                                            poses_true=seq["poses"])
+        blocks.append(secs / st["frames"])
+        stats = st if stats is None else {k: (max(stats[k], v) if k == "max_position_error_m" else stats[k] + v) for k, v in st.items()}
+    blocks.sort()
+    # per-stage breakdown measured in this run (HIP events after every launch of the frame; profiled frames are not the timed ones)
+    tr.set_profiling(True)
+    tr.track_sequence_native(kf, d_frames, mm, opts, m["shuffle_levels"], m["shuffle_fine"], passes=2)
+    stages = tr.stage_times()
+    tr.set_profiling(False)
+    out = {"fps": 1.0 / blocks[2], "frame_us": blocks[2] * 1e6, "frame_us_min_max_of_5_blocks": [blocks[0] * 1e6, blocks[-1] * 1e6],
+           "frames_timed": int(stats["frames"]), "sequence_frames": len(d_frames), "map_points": int(len(m["world"])),
+           "patches_searched_per_frame": stats["searched"] / stats["frames"], "patches_found_per_frame": stats["measurements"] / stats["frames"],
+           "templates_reused_frac": stats["templates_reused"] / max(1.0, stats["searched"]),
+           "templates_rewarped_per_frame": (stats["searched"] - stats["templates_reused"]) / stats["frames"],
+           "frames_with_coarse_stage_frac": stats["frames_did_coarse"] / stats["frames"],
+           "max_position_error_m": stats["max_position_error_m"], "frames_below_50_measurements": int(stats["frames_below_50_measurements"]),
+           "stage_us_profiled": stages, "stage_us_profiled_sum": sum(stages.values()),
+           "workload": "64 rendered frames of a camera translating (up to 5 px / frame), rising by 8 %, rolling +-0.25 rad and tilting over a "
+                       "textured plane; closed trajectory visited round and round; constant-velocity motion model; one context, native host thread"}
+    for d in d_frames:
+        d.free()
+    tr.close()
+    return out
 
 
 def tracking_kernel_record():
@@ -653,14 +710,16 @@ def main():
             except Exception as e:   # noqa: BLE001
                 out["local_ba_config4"] = {"error": repr(e)}
         # the legs below report beside the headline record; a failure in one of them must not cost the record itself
+        seq = None
         if not args.no_tracking:
             try:
-                out["tracking"] = tracking_bench(hip, host, synth, replicas=not args.no_replicas)
+                seq = moving_sequence(synth)
+                out["tracking"] = tracking_bench(hip, host, synth, seq, replicas=not args.no_replicas)
             except Exception as e:   # noqa: BLE001
                 out["tracking"] = {"error": repr(e)}
         if not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"], otr = cpu_baseline(args, host, synth, prob)
+                out["cpu_baseline"], otr = cpu_baseline(args, host, synth, prob, seq)
                 # parity of the timed workload itself (oracle as checker, cheap: it already ran)
                 rel = abs(otr["err_new"][-1] - trials["err_new"][-1]) / abs(otr["err_new"][-1])
                 out["parity_rel_err_final_trial"] = float(rel)
@@ -677,7 +736,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, host, synth, prob):
+def cpu_baseline(args, host, synth, prob, seq=None):
     """the oracle (kind "port") on the host cores: one thread on the timed problem (a bounded sample: at most 20 trials),
     a tracked-frame loop, and one independent replica per PHYSICAL core for the per-node figure"""
     from tests.oracle_lib import load_oracle
@@ -712,11 +771,40 @@ def cpu_baseline(args, host, synth, prob):
         for _ in range(nf):
             tr.set_shuffle(case["shuffle_levels"], case["shuffle_fine"])
             rr = tr.TrackFrame(kfc, b.ctypes.data, pose_in, oo)
-        cpu["tracked_fps"] = nf / (time.perf_counter() - t0)
-        cpu["tracked_sample"] = (f"{nf} frames of the chain tracking.tracked_fps runs: keyframe of the 640x480 frame + TrackMap over "
+        cpu["tracked_fps_stationary"] = nf / (time.perf_counter() - t0)
+        cpu["tracked_stationary_sample"] = (f"{nf} frames of the chain tracking.tracked_fps_stationary runs: keyframe of the 640x480 frame + TrackMap over "
                                  f"{len(case['world'])} map points, {int(sum(rr['attempted']))} patches searched, {int(rr['n_meas'])} found, "
                                  f"oracle/ptam_oracle.cc ptamo_track_map_frame, one thread")
         tr.close()
+        if seq is not None:
+            # the moving-camera sequence tracking.tracked_fps runs, closed loop through the oracle's twin of ptam_track_frame
+            kf0 = host.KeyFrame(octx).MakeKeyFrame_Lite(seq["kf_image"])
+            m = synth.make_sequence_map([kf0.level(l) for l in range(4)], seq["kf_pose"])
+            tr = host.Tracker(octx, len(m["world"]))
+            tr.set_map(m["world"], m["pixel_right_w"], m["pixel_down_w"], kf0, m["src_level"], m["center"])
+            mm = tr.motion_model(seq["poses"][0])
+            oo = tr.opts()
+            nseq = len(seq["frames"])
+            tot = {"n": 0, "searched": 0, "reused": 0, "found": 0, "err": 0.0}
+            t0 = None
+            for k in range(3 * nseq):
+                if k == nseq:                       # the first round warms the finders up, two rounds are timed
+                    t0 = time.perf_counter()
+                f = k % nseq
+                tr.set_shuffle(m["shuffle_levels"], m["shuffle_fine"])
+                rr = tr.TrackFrameMoving(kfc, seq["frames"][f].ctypes.data, mm, oo)
+                if k >= nseq:
+                    tot["n"] += 1
+                    tot["searched"] += int(rr["n_coarse"] + rr["n_top"] + rr["n_fine"])
+                    tot["reused"] += int(rr["templates_reused"])
+                    tot["found"] += int(rr["n_meas"])
+                    tot["err"] = max(tot["err"], float(np.abs(rr["pose"] - seq["poses"][f]).max()))
+            cpu["tracked_fps"] = tot["n"] / (time.perf_counter() - t0)
+            cpu["tracked_sample"] = (f"{tot['n']} frames of the moving-camera sequence tracking.tracked_fps runs (keyframe + motion model + TrackMap, "
+                                     f"{tot['searched'] / tot['n']:.0f} patches searched and {tot['found'] / tot['n']:.0f} found per frame, "
+                                     f"{100.0 * tot['reused'] / max(1, tot['searched']):.0f} % of the templates kept, max pose error {tot['err']:.1e}), "
+                                     f"oracle/ptam_oracle.cc ptamo_track_frame, one thread")
+            tr.close()
         # round 1-2's figure, comparable to tracking.fine_stage_only_fps: keyframe + 1000-patch search + ONE pose loop
         q, t = synth.make_patch_queries([kfa.level(l) for l in range(4)], n=1000)
         kfb = host.KeyFrame(octx)

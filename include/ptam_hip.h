@@ -417,6 +417,41 @@ int ptam_track_map(ptam_tracker* t, const ptam_kf* current, const double pose_in
  * d_frame (stride == width) into `current`, then TrackMap against it: one entry, one queue, one wait. */
 int ptam_track_map_frame(ptam_tracker* t, ptam_kf* current, const uint8_t* d_frame, const double pose_in[12],
                          const ptam_trackmap_opts* opts, ptam_trackmap_result* out);
+/* ---- the tracker's motion model and Tracker::TrackFrame's tracking branch (src/Tracker.cc:134-137) ----------------------
+ *      Host scalar code (no device work of its own): the decaying constant-velocity model of :1008-1056 and the bTryCoarse
+ *      heuristics of :505-516, kept in a plain struct the caller owns.  The SmallBlurryImage rotation estimator
+ *      (Tracker.UseRotationEstimator, :1017-1028) is outside this path (SmallBlurryImage is out of scope);
+ *      this is the model with it switched off — the velocity comes from the last two tracked poses alone. */
+typedef struct {
+    double pose[12];               /* mse3CamFromWorld */
+    double start_pose[12];         /* mse3StartPos: the pose before the prediction, :1015 */
+    double velocity[6];            /* mv6CameraVelocity (translation, rotation) */
+    double msd_scaled_velocity;    /* mdMSDScaledVelocityMagnitude, :1052-1055 */
+    double scene_depth_mean;       /* mCurrentKF.dSceneDepthMean (1.0 after a reset, :56), updated when more than 20 points were found, :692-696 */
+    double scene_depth_sigma;      /* mCurrentKF.dSceneDepthSigma */
+    double coarse_min_velocity;    /* Tracker.CoarseMinVelocity 0.006, :496 */
+    int32_t use_constant_velocity; /* Tracker.UseConstantVelocity 1, :1041 */
+    int32_t disable_coarse;        /* Tracker.DisableCoarse 0, :495 */
+    int32_t just_recovered;        /* mbJustRecoveredSoUseCoarse: the next frame tries the coarse stage with doubled CoarseMax / CoarseRange, :508-513 */
+    int32_t pad_;
+} ptam_motion_model;
+/* Tracker::Reset's part of the model (:52-56): pose = the given one, zero velocity, depth mean 1, default tunables */
+void ptam_motion_reset(ptam_motion_model* m, const double pose[12]);
+/* Tracker::PredictPoseWithMotionModel :1013-1030: start_pose = pose; pose = exp(velocity) * start_pose */
+void ptam_motion_predict(ptam_motion_model* m);
+/* the end of TrackMap (:692-696: scene depth from the frame's sums when depth_n > 20) + Tracker::UpdateMotionModel :1036-1056 with
+ * pose = r->pose: velocity = ln(pose * start_pose^-1) (or its decaying mix), msd_scaled_velocity = |(v_t / depth mean, v_w)| */
+void ptam_motion_update(ptam_motion_model* m, const ptam_trackmap_result* r);
+/* TooN SE3<>::exp / SE3<>::ln on (R row-major | t) poses; mu = (translation part, rotation vector) */
+void ptam_se3_exp(const double mu[6], double pose_out[12]);
+void ptam_se3_ln(const double pose[12], double mu_out[6]);
+/* One tracked frame of a camera that moves (src/Tracker.cc:134-137 with :94 before them): MakeKeyFrame_Lite of the
+ * device-resident frame into `current`, PredictPoseWithMotionModel, the bTryCoarse heuristics (*opts is the caller's tunables;
+ * its try_coarse is ignored and decided here, coarse_max / coarse_range doubled after a recovery), TrackMap from the predicted
+ * pose, UpdateMotionModel.  m->pose is the tracked pose afterwards. */
+int ptam_track_frame(ptam_tracker* t, ptam_kf* current, const uint8_t* d_frame, ptam_motion_model* m,
+                     const ptam_trackmap_opts* opts, ptam_trackmap_result* out);
+
 /* nb frames of nb independent trackers (own context, map, keyframe, prediction each) as ONE chain of launches on the first
  * tracker's queue: every kernel of the chain gets a second grid dimension, row i works on frame i.  Not part of the
  * reference's surface (it tracks one camera); it exists because a process gets four hardware queues and a tracked frame
@@ -427,19 +462,6 @@ int ptam_track_map_frame(ptam_tracker* t, ptam_kf* current, const uint8_t* d_fra
  * variant; set the frames' permutations beforehand (ptam_tracker_set_shuffle). */
 int ptam_track_map_frames_batch(int nb, ptam_tracker* const* trackers, ptam_kf* const* current, const uint8_t* const* d_frames,
                                 const double* poses_in, const ptam_trackmap_opts* opts, ptam_trackmap_result* out);
-/* Measurement helper, not part of the reference's surface: n independent trackers (each with its own context, map and
- * keyframes) driven by n host threads inside the library, frames_each frames per thread — per frame ptam_tracker_set_shuffle
- * then ptam_track_map_frame, as the tracker thread of src/Tracker.cc:442-696 would issue them.  *seconds_out = wall time
- * from the common start to the last return (bench.py: aggregate frames/s of replicas on one device). */
-int ptam_bench_track_frames(int n, ptam_tracker* const* trackers, ptam_kf* const* current, const uint8_t* const* d_frames,
-                            const double pose_in[12], const ptam_trackmap_opts* opts, const int32_t* shuffle_levels,
-                            const int32_t* shuffle_fine, int frames_each, double* seconds_out);
-/* Measurement helper: `rounds` rounds of ptam_tracker_set_shuffle (every tracker) + ptam_track_map_frames_batch.  groups == 1:
- * one host thread, one batch of nb per round; groups > 1: the trackers dealt into that many groups, each batched by its own
- * host thread on its own queue.  *seconds_out = wall time (bench.py: frames/s of nb cameras tracked as batches). */
-int ptam_bench_track_batch(int nb, ptam_tracker* const* trackers, ptam_kf* const* current, const uint8_t* const* d_frames,
-                           const double pose_in[12], const ptam_trackmap_opts* opts, const int32_t* shuffle_levels,
-                           const int32_t* shuffle_fine, int rounds, int groups, double* seconds_out);
 /* vIterationSet of the last frame (what :667-676 turns into mCurrentKF.mMeasurements): *n = its length; out (nullable)
  * receives up to cap entries. */
 int ptam_tracker_read_iteration_set(ptam_tracker* t, ptam_trackmap_meas* out, int cap, int* n);
@@ -531,13 +553,7 @@ int ptam_ba_set_profiling(ptam_ba* ba, int on);
 int ptam_ba_kernel_time(const ptam_ba* ba, int kernel, double* total_ms, int* launches);
 /* upload + build the device structures without running (Compute does this implicitly) */
 int ptam_ba_prepare(ptam_ba* ba);
-/* launch ONLY the K7 kernel `reps` times on the prepared problem (pass 1 + sigma must have run
- * once: done internally), HIP-event timed; returns average ms per launch and the algorithmic
- * byte count of one launch. */
-int ptam_ba_bench_jacobian(ptam_ba* ba, int reps, double* avg_ms, double* algorithmic_bytes);
-/* the same bracket over `n` bundles of one context (copies of one problem) launched round-robin: with
- * (n - 1) working sets larger than the 256 MB Infinity Cache every launch finds its data in HBM only. */
-int ptam_ba_bench_jacobian_rotating(ptam_ba** bas, int n, int reps, double* avg_ms);
+/* (measurement-only entry points — the K7 launch bracket, the native frame drivers — are declared in ptam_hip_bench.h) */
 
 /* ---- sharded global BA: measurements sharded by point across ranks ----------- */
 /* A collective hook: all-reduce (sum) `count` doubles in place at device pointer `dptr`,

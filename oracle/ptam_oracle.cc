@@ -128,6 +128,83 @@ SE3 se3_mul(const SE3& a, const SE3& b) {
     return o;
 }
 
+// TooN SO3<>::ln (TooN/so3.h): result = antisymmetric part / 2; cos_angle from the trace; three ranges of the angle
+void so3_ln(const double* m, double result[3]) {
+    const double cos_angle = (m[0] + m[4] + m[8] - 1.0) * 0.5;
+    result[0] = (m[2 * 3 + 1] - m[1 * 3 + 2]) / 2;
+    result[1] = (m[0 * 3 + 2] - m[2 * 3 + 0]) / 2;
+    result[2] = (m[1 * 3 + 0] - m[0 * 3 + 1]) / 2;
+    double sin_angle_abs = std::sqrt(result[0] * result[0] + result[1] * result[1] + result[2] * result[2]);
+    if (cos_angle > M_SQRT1_2) {   // [0 - Pi/4[ use asin
+        if (sin_angle_abs > 0) {
+            const double f = std::asin(sin_angle_abs) / sin_angle_abs;
+            for (int i = 0; i < 3; i++) result[i] *= f;
+        }
+    } else if (cos_angle > -M_SQRT1_2) {   // [Pi/4 - 3Pi/4[ use acos, but antisymmetric part
+        const double angle = std::acos(cos_angle);
+        const double f = angle / sin_angle_abs;
+        for (int i = 0; i < 3; i++) result[i] *= f;
+    } else {   // rest use symmetric part
+        const double angle = M_PI - std::asin(sin_angle_abs);
+        const double d0 = m[0] - cos_angle, d1 = m[4] - cos_angle, d2 = m[8] - cos_angle;
+        double r2[3];
+        if (d0 * d0 > d1 * d1 && d0 * d0 > d2 * d2) {   // first is largest, fill with first column
+            r2[0] = d0;
+            r2[1] = (m[1 * 3 + 0] + m[0 * 3 + 1]) / 2;
+            r2[2] = (m[0 * 3 + 2] + m[2 * 3 + 0]) / 2;
+        } else if (d1 * d1 > d2 * d2) {   // second is largest
+            r2[0] = (m[1 * 3 + 0] + m[0 * 3 + 1]) / 2;
+            r2[1] = d1;
+            r2[2] = (m[2 * 3 + 1] + m[1 * 3 + 2]) / 2;
+        } else {   // third is largest
+            r2[0] = (m[0 * 3 + 2] + m[2 * 3 + 0]) / 2;
+            r2[1] = (m[2 * 3 + 1] + m[1 * 3 + 2]) / 2;
+            r2[2] = d2;
+        }
+        if (r2[0] * result[0] + r2[1] * result[1] + r2[2] * result[2] < 0)   // flip, if we point in the wrong direction
+            for (int i = 0; i < 3; i++) r2[i] *= -1;
+        const double n = std::sqrt(r2[0] * r2[0] + r2[1] * r2[1] + r2[2] * r2[2]);
+        for (int i = 0; i < 3; i++) result[i] = angle * (r2[i] / n);
+    }
+}
+
+// TooN SE3<>::ln (TooN/se3.h)
+void se3_ln(const SE3& se3, double out[6]) {
+    double rot[3];
+    so3_ln(se3.R, rot);
+    const double rr = rot[0] * rot[0] + rot[1] * rot[1] + rot[2] * rot[2];
+    const double theta = std::sqrt(rr);
+    double shtot = 0.5;
+    if (theta > 0.00001) shtot = std::sin(theta / 2) / theta;
+    // now do the rotation: halfrotator = SO3::exp(rot * -0.5)  (SO3::exp = the rotation part of SE3::exp)
+    const double hmu[6] = {0, 0, 0, rot[0] * -0.5, rot[1] * -0.5, rot[2] * -0.5};
+    const SE3 half = se3_exp(hmu);
+    double rottrans[3];
+    for (int r = 0; r < 3; r++) rottrans[r] = half.R[r * 3 + 0] * se3.t[0] + half.R[r * 3 + 1] * se3.t[1] + half.R[r * 3 + 2] * se3.t[2];
+    const double tr = se3.t[0] * rot[0] + se3.t[1] * rot[1] + se3.t[2] * rot[2];
+    if (theta > 0.001) {
+        const double f = tr * (1 - 2 * shtot) / rr;
+        for (int i = 0; i < 3; i++) rottrans[i] -= rot[i] * f;
+    } else {
+        const double f = tr / 24;
+        for (int i = 0; i < 3; i++) rottrans[i] -= rot[i] * f;
+    }
+    for (int i = 0; i < 3; i++) {
+        out[i] = rottrans[i] / (2 * shtot);
+        out[3 + i] = rot[i];
+    }
+}
+
+// SE3<>::inverse(): (R^T, -(R^T t))
+SE3 se3_inverse(const SE3& s) {
+    SE3 o;
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) o.R[r * 3 + c] = s.R[c * 3 + r];
+        o.t[r] = -(s.R[0 * 3 + r] * s.t[0] + s.R[1 * 3 + r] * s.t[1] + s.R[2 * 3 + r] * s.t[2]);
+    }
+    return o;
+}
+
 void se3_apply(const SE3& s, const double x[3], double out[3]) {
     for (int r = 0; r < 3; r++)
         out[r] = s.t[r] + (s.R[r * 3 + 0] * x[0] + s.R[r * 3 + 1] * x[1] + s.R[r * 3 + 2] * x[2]);
@@ -2238,6 +2315,71 @@ int ptamo_track_map_frame(ptamo_tracker* t, ptamo_kf* cur, const uint8_t* frame,
     if (!t || !cur || !frame) return PTAM_E_ARG;
     const int rc = ptamo_make_keyframe_lite(t->ctx, cur, frame, cur->w);
     return rc ? rc : ptamo_track_map(t, cur, pose_in, opts, out);
+}
+// ---- the motion model and the tracking branch of Tracker::TrackFrame (src/Tracker.cc:134-137), rotation estimator off ----
+void ptamo_motion_reset(ptam_motion_model* m, const double pose[12]) {
+    std::memset(m, 0, sizeof *m);
+    std::memcpy(m->pose, pose, 96);                  // mse3CamFromWorld
+    std::memcpy(m->start_pose, pose, 96);
+    m->scene_depth_mean = 1.0;                       // :56
+    m->coarse_min_velocity = 0.006;                  // gvdCoarseMinVel :496
+    m->use_constant_velocity = 1;                    // gvnConstVel :1041
+}
+// Tracker::PredictPoseWithMotionModel :1013-1030
+void ptamo_motion_predict(ptam_motion_model* m) {
+    std::memcpy(m->start_pose, m->pose, 96);         // mse3StartPos = mse3CamFromWorld
+    double v6Velocity[6];
+    std::memcpy(v6Velocity, m->velocity, 48);
+    se3_to12(se3_mul(se3_exp(v6Velocity), se3_from12(m->start_pose)), m->pose);   // :1029
+}
+// the scene-depth update that closes TrackMap (:678-697), then Tracker::UpdateMotionModel :1036-1056
+void ptamo_motion_update(ptam_motion_model* m, const ptam_trackmap_result* r) {
+    std::memcpy(m->pose, r->pose, 96);
+    if (r->depth_n > 20) {
+        m->scene_depth_mean = r->depth_sum / r->depth_n;
+        m->scene_depth_sigma = std::sqrt((r->depth_sum_sq / r->depth_n) - (m->scene_depth_mean) * (m->scene_depth_mean));
+    }
+    const SE3 se3NewFromOld = se3_mul(se3_from12(m->pose), se3_inverse(se3_from12(m->start_pose)));
+    double v6Motion[6];
+    se3_ln(se3NewFromOld, v6Motion);
+    if (m->use_constant_velocity) {
+        std::memcpy(m->velocity, v6Motion, 48);
+    } else {
+        double v6OldVel[6];
+        std::memcpy(v6OldVel, m->velocity, 48);
+        for (int i = 0; i < 6; i++) m->velocity[i] = 0.9 * (0.5 * v6Motion[i] + 0.5 * v6OldVel[i]);
+    }
+    double v6[6];
+    std::memcpy(v6, m->velocity, 48);
+    for (int i = 0; i < 3; i++) v6[i] *= 1.0 / m->scene_depth_mean;
+    double ss = 0;
+    for (int i = 0; i < 6; i++) ss += v6[i] * v6[i];
+    m->msd_scaled_velocity = std::sqrt(ss);
+}
+void ptamo_se3_ln(const double pose[12], double out6[6]) { se3_ln(se3_from12(pose), out6); }
+int ptamo_track_frame(ptamo_tracker* t, ptamo_kf* cur, const uint8_t* frame, ptam_motion_model* m, const ptam_trackmap_opts* opts,
+                      ptam_trackmap_result* out) {
+    if (!t || !cur || !frame || !m || !out) return PTAM_E_ARG;
+    ptam_trackmap_opts o;
+    if (opts) o = *opts;
+    else ptamo_trackmap_opts_default(&o);
+    // :94 MakeKeyFrame_Lite, :136 PredictPoseWithMotionModel, :137 TrackMap with the heuristics of :503-514, :138 UpdateMotionModel
+    int rc = ptamo_make_keyframe_lite(t->ctx, cur, frame, cur->w);
+    if (rc) return rc;
+    ptamo_motion_predict(m);
+    bool bTryCoarse = true;
+    if (m->disable_coarse || m->msd_scaled_velocity < m->coarse_min_velocity || o.coarse_max == 0) bTryCoarse = false;
+    if (m->just_recovered) {
+        bTryCoarse = true;
+        o.coarse_max *= 2;
+        o.coarse_range *= 2;
+        m->just_recovered = 0;
+    }
+    o.try_coarse = bTryCoarse ? 1 : 0;
+    rc = ptamo_track_map(t, cur, m->pose, &o, out);
+    if (rc) return rc;
+    ptamo_motion_update(m, out);
+    return PTAM_OK;
 }
 int ptamo_tracker_read_iteration_set(ptamo_tracker* t, ptam_trackmap_meas* out, int cap, int* n) {
     if (!t || !n) return PTAM_E_ARG;

@@ -13,6 +13,8 @@ HALFSAMPLE_R, HALFSAMPLE_T = 0, 1
 EST_TUKEY, EST_CAUCHY, EST_HUBER = 0, 1, 2
 K_PROJECT, K_SELECT, K_JACOBIAN, K_VINV, K_SCHUR, K_SOLVE, K_UPDATE, K_EXCHANGE, K_COUNT = range(9)
 KERNEL_NAMES = ["project", "select", "jacobian", "vinv", "schur", "solve", "update", "exchange"]
+TRACK_STAGE_NAMES = ["pyramid_pvs", "fast_detect", "compact_select", "search_coarse", "gather_coarse", "pose_coarse",
+                     "search_fine", "gather_fine", "pose_fine"]
 
 
 class Int2(C.Structure):
@@ -88,6 +90,14 @@ class BaOpts(C.Structure):
     _fields_ = [("max_iterations", C.c_int32), ("update_sq_conv_limit", C.c_double),
                 ("min_sigma", C.c_double), ("estimator", C.c_int32), ("verbose", C.c_int32),
                 ("deterministic", C.c_int32), ("pad_", C.c_int32)]
+
+
+class MotionModel(C.Structure):
+    """ptam_motion_model (src/Tracker.cc:1008-1056)"""
+    _fields_ = [("pose", C.c_double * 12), ("start_pose", C.c_double * 12), ("velocity", C.c_double * 6),
+                ("msd_scaled_velocity", C.c_double), ("scene_depth_mean", C.c_double), ("scene_depth_sigma", C.c_double),
+                ("coarse_min_velocity", C.c_double), ("use_constant_velocity", C.c_int32), ("disable_coarse", C.c_int32),
+                ("just_recovered", C.c_int32), ("pad_", C.c_int32)]
 
 
 class BaTrial(C.Structure):
@@ -176,6 +186,15 @@ PROTOTYPES = {
     "tracker_set_shuffle": (_i, [_vp, _vp, _vp]),
     "track_map": (_i, [_vp, _vp, _pd, _vp, _vp]),
     "track_map_frame": (_i, [_vp, _vp, _vp, _pd, _vp, _vp]),
+    "motion_reset": (None, [C.POINTER(MotionModel), _pd]),
+    "motion_predict": (None, [C.POINTER(MotionModel)]),
+    "motion_update": (None, [C.POINTER(MotionModel), _vp]),
+    "se3_exp": (None, [_vp, _vp]),
+    "se3_ln": (None, [_vp, _vp]),
+    "track_frame": (_i, [_vp, _vp, _vp, C.POINTER(MotionModel), _vp, _vp]),
+    "bench_track_sequence": (_i, [_vp, _vp, _i, _vp, C.POINTER(MotionModel), _vp, _vp, _vp, _i, _vp, _pd, _pd]),
+    "tracker_set_profiling": (_i, [_vp, _i]),
+    "tracker_stage_time": (_i, [_vp, _i, _pd, C.POINTER(_i)]),
     "bench_track_frames": (_i, [_i, _vp, _vp, _vp, _pd, _vp, _vp, _vp, _i, _pd]),
     "track_map_frames_batch": (_i, [_i, _vp, _vp, _vp, _pd, _vp, _vp]),
     "bench_track_batch": (_i, [_i, _vp, _vp, _vp, _pd, _vp, _vp, _vp, _i, _i, _pd]),

@@ -27,6 +27,7 @@
 #include <utility>
 
 #include "bundle.h"
+#include "../../include/ptam_hip_bench.h"
 
 #include "ba_math.inc"
 #include "ba_pass1.inc"

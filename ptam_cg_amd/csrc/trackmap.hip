@@ -22,6 +22,7 @@
 #include <thread>
 
 #include "track_internal.h"
+#include "../../include/ptam_hip_bench.h"
 #include "patch_device.h"
 #include "keyframe_device.h"
 #include "pvs_device.h"
@@ -943,6 +944,11 @@ struct ptam_tracker {
     void* batch_dev;
     size_t batch_cap;
     hipStream_t last_stream;   // the queue that last ran this tracker (its own context's, or a batch's lead tracker's)
+    // stage timing of ptam_track_map_frame (ptam_tracker_set_profiling): an event after every launch of the frame
+    bool prof;
+    hipEvent_t ev[PTAM_TS_COUNT + 1];
+    double stage_ms[PTAM_TS_COUNT];
+    int stage_frames;
 };
 
 extern "C" {
@@ -1054,6 +1060,8 @@ int ptam_tracker_destroy(ptam_tracker* t) {
     if (t->mbox) hipHostFree(t->mbox);
     if (t->perm_host) hipHostFree(t->perm_host);
     if (t->batch_dev) hipFree(t->batch_dev);
+    if (t->ev[0])
+        for (int i = 0; i <= PTAM_TS_COUNT; i++) hipEventDestroy(t->ev[i]);
     delete t;
     return PTAM_OK;
 }
@@ -1156,6 +1164,8 @@ static int track_map_impl(ptam_tracker* t, ptam_kf* cur, const uint8_t* d_new_fr
     const int n = d.n;
     hipStream_t st = ctx->stream;
     int rc = PTAM_OK;
+    const bool prof = t->prof && d_new_frame;
+    if (prof) hipEventRecord(t->ev[PTAM_TS_PYR_PVS], st);
     if (d_new_frame) {
         // KeyFrame::MakeKeyFrame_Lite (src/KeyFrame.cc:18-54) of the new image, the PVS pass (:453-478, the pose rides in as an
         // argument) and the set choice (:480-611) in three launches
@@ -1172,7 +1182,9 @@ static int track_map_impl(ptam_tracker* t, ptam_kf* cur, const uint8_t* d_new_fr
         else
             hipLaunchKernelGGL(tm_pyr_pvs_kernel<PTAM_HALFSAMPLE_R>, dim3(n_pyr + n_pvs), dim3(256), 0, st, pa, gx, n_pyr, ctx->cam, std::max(n, 0),
                                (const ptam_pvs_point*)d.pts, d.pvs, pv, d.pose, &d.finder->bad);
+        if (prof) hipEventRecord(t->ev[PTAM_TS_DETECT], st);
         kf_launch_detect(cur, st);
+        if (prof) hipEventRecord(t->ev[PTAM_TS_COMPACT_SELECT], st);
         hipLaunchKernelGGL(tm_compact_select_kernel, dim3(1 + fast_compact_blocks(cur->L)), dim3(1024), 0, st, cur->L, d, o);
     } else {
         rc = pvs_launch_dev(ctx, n, d.pts, d.pose, pose_in, d.pvs, &d.finder->bad, (int)sizeof(TmFinder));                         // :453-478 (the pose rides in as an argument)
@@ -1181,8 +1193,11 @@ static int track_map_impl(ptam_tracker* t, ptam_kf* cur, const uint8_t* d_new_fr
     }
     // ---- coarse stage :519-569 ----
     const int ncc = std::max(1, std::min(n, (int)o.coarse_max));
+    if (prof) hipEventRecord(t->ev[PTAM_TS_SEARCH_COARSE], st);
     hipLaunchKernelGGL(tm_search_kernel, dim3((ncc + 3) / 4), dim3(256), 0, st, ctx->cam, cur->L, d, 0, o.coarse_range, o.coarse_subpix_its);
+    if (prof) hipEventRecord(t->ev[PTAM_TS_GATHER_COARSE], st);
     hipLaunchKernelGGL(tm_gather_kernel, dim3(std::max(1, (ncc + TM_GATHER_THREADS - 1) / TM_GATHER_THREADS)), dim3(TM_GATHER_THREADS), 0, st, d, 0, o.coarse_subpix_its, o.coarse_min, t->mbox_dev);
+    if (prof) hipEventRecord(t->ev[PTAM_TS_POSE_COARSE], st);
     {
         ptam_gn_opts g;
         ptam_gn_opts_default(&g);
@@ -1198,8 +1213,11 @@ static int track_map_impl(ptam_tracker* t, ptam_kf* cur, const uint8_t* d_new_fr
         if (rc) return rc;
     }
     // ---- fine stage :571-643 ----
+    if (prof) hipEventRecord(t->ev[PTAM_TS_SEARCH_FINE], st);
     hipLaunchKernelGGL(tm_search_kernel, dim3(std::max(1, (n + 3) / 4)), dim3(256), 0, st, ctx->cam, cur->L, d, 1, 0u, 0);
+    if (prof) hipEventRecord(t->ev[PTAM_TS_GATHER_FINE], st);
     hipLaunchKernelGGL(tm_gather_kernel, dim3(std::max(1, (n + TM_GATHER_THREADS - 1) / TM_GATHER_THREADS)), dim3(TM_GATHER_THREADS), 0, st, d, 1, o.coarse_subpix_its, o.coarse_min, t->mbox_dev);
+    if (prof) hipEventRecord(t->ev[PTAM_TS_POSE_FINE], st);
     const unsigned long long seq = ++t->seq;
     t->last_stream = st;
     {
@@ -1214,6 +1232,7 @@ static int track_map_impl(ptam_tracker* t, ptam_kf* cur, const uint8_t* d_new_fr
         io.seq = seq;
         rc = pose_launch_chain(ctx, std::max(n, 1), &d.ctl->n_meas, d.meas, d.entry, d.pose, &g, d.outlier, io, 1);
         if (rc) return rc;
+        if (prof) hipEventRecord(t->ev[PTAM_TS_COUNT], st);
         HIP_TRY(hipGetLastError());
         // the frame's last kernel publishes the sequence number — or, for a list of more than 1024 measurements, asks for the
         // general kernel (pose.hip: pose_launch_chain), which then publishes it
@@ -1244,6 +1263,35 @@ static int track_map_impl(ptam_tracker* t, ptam_kf* cur, const uint8_t* d_new_fr
     out->depth_sum = t->mbox->depth3[0];
     out->depth_sum_sq = t->mbox->depth3[1];
     out->depth_n = (int)t->mbox->depth3[2];
+    if (prof) {
+        HIP_TRY(hipEventSynchronize(t->ev[PTAM_TS_COUNT]));
+        for (int i = 0; i < PTAM_TS_COUNT; i++) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, t->ev[i], t->ev[i + 1]));
+            t->stage_ms[i] += ms;
+        }
+        t->stage_frames++;
+    }
+    return PTAM_OK;
+}
+
+// Stage timing of ptam_track_map_frame (ptam_hip_bench.h): with profiling on, an event is recorded after every launch of the
+// frame; the nine differences are added up per stage.  The events lengthen the frame (about 1 us per record): profiled frames
+// are for the breakdown, not for the frame rate.
+int ptam_tracker_set_profiling(ptam_tracker* t, int on) {
+    ARG_TRY(t);
+    HIP_TRY(hipSetDevice(t->ctx->device));
+    if (on && !t->ev[0])
+        for (int i = 0; i <= PTAM_TS_COUNT; i++) HIP_TRY(hipEventCreate(&t->ev[i]));
+    t->prof = on != 0;
+    for (int i = 0; i < PTAM_TS_COUNT; i++) t->stage_ms[i] = 0;
+    t->stage_frames = 0;
+    return PTAM_OK;
+}
+int ptam_tracker_stage_time(const ptam_tracker* t, int stage, double* total_ms, int* frames) {
+    ARG_TRY(t && stage >= 0 && stage < PTAM_TS_COUNT && total_ms && frames);
+    *total_ms = t->stage_ms[stage];
+    *frames = t->stage_frames;
     return PTAM_OK;
 }
 

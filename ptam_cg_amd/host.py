@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _abi
-from ._abi import (BaOpts, BaTrial, CamParams, GnOpts, Int2, PatchQuery, PatchResult, PoseMeas,
+from ._abi import (BaOpts, BaTrial, CamParams, GnOpts, Int2, MotionModel, PatchQuery, PatchResult, PoseMeas,
                    PoseUpdateMeas, Projection)
 
 # config/camera.cfg:7
@@ -452,6 +452,51 @@ class Tracker:
         self.ctx._check(self.lib.track_map_frame(self.h, kf.h, dp, _pd(pose), _ptr(opts) if opts is not None else None, _ptr(res)),
                         "track_map_frame")
         return res[0]
+
+    def motion_model(self, pose):
+        """a ptam_motion_model at `pose` with zero velocity (Tracker::Reset, src/Tracker.cc:52-56)"""
+        m = MotionModel()
+        pose = np.ascontiguousarray(pose, dtype=np.float64).reshape(12)
+        self.lib.motion_reset(C.byref(m), _pd(pose))
+        return m
+
+    def TrackFrameMoving(self, kf, d_frame, motion, opts=None):
+        """the tracking branch of Tracker::TrackFrame (src/Tracker.cc:94,134-137): keyframe of the frame, motion-model
+        prediction, bTryCoarse heuristics, TrackMap, motion-model update — ptam_track_frame.  `motion` is updated in place."""
+        res = np.zeros(1, dtype=TRACKMAP_RESULT_DT)
+        dp = d_frame.p if isinstance(d_frame, DevBuf) else d_frame
+        self.ctx._check(self.lib.track_frame(self.h, kf.h, dp, C.byref(motion), _ptr(opts) if opts is not None else None, _ptr(res)),
+                        "track_frame")
+        return res[0]
+
+    def set_profiling(self, on=True):
+        self.ctx._check(self.lib.tracker_set_profiling(self.h, 1 if on else 0), "tracker_set_profiling")
+
+    def stage_times(self):
+        """-> {stage: us per profiled frame} (ptam_tracker_stage_time)"""
+        out = {}
+        for i, name in enumerate(_abi.TRACK_STAGE_NAMES):
+            ms, n = C.c_double(), C.c_int()
+            self.ctx._check(self.lib.tracker_stage_time(self.h, i, C.byref(ms), C.byref(n)), "tracker_stage_time")
+            out[name] = 1e3 * ms.value / max(1, n.value)
+        return out
+
+    def track_sequence_native(self, kf, d_frames, motion, opts, shuffle_levels, shuffle_fine, passes=1, poses_true=None):
+        """ptam_bench_track_sequence (ptam_hip_bench.h): the frames tracked in order, closed loop, from one native host thread
+        -> (seconds, stats dict)"""
+        n = len(d_frames)
+        raw = lambda d: d.p.value if isinstance(d, DevBuf) else int(d)
+        dis = (C.c_void_p * n)(*[raw(d) for d in d_frames])
+        sl = np.ascontiguousarray(shuffle_levels, dtype=np.int32)
+        sf = np.ascontiguousarray(shuffle_fine, dtype=np.int32)
+        pt = None if poses_true is None else np.ascontiguousarray(poses_true, dtype=np.float64).reshape(n, 12)
+        secs = C.c_double()
+        st = np.zeros(8)
+        self.ctx._check(self.lib.bench_track_sequence(self.h, kf.h, n, dis, C.byref(motion), _ptr(opts) if opts is not None else None,
+                                                      _ptr(sl), _ptr(sf), int(passes), _ptr(pt), C.byref(secs), _pd(st)), "bench_track_sequence")
+        keys = ("frames", "searched", "templates_reused", "measurements", "frames_did_coarse", "frames_tried_coarse",
+                "max_position_error_m", "frames_below_50_measurements")
+        return secs.value, dict(zip(keys, (float(x) for x in st)))
 
     @staticmethod
     def TrackFramesBatch(trackers, kfs, d_frames, poses, opts=None):

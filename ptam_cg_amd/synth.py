@@ -263,6 +263,131 @@ def make_trackmap_case(levels_a, counts=(800, 300, 80, 40), seed=0x5EED000A, cam
             "shuffle_levels": rng.permutation(n).astype(np.int32), "shuffle_fine": rng.permutation(n).astype(np.int32)}
 
 
+# ---------------------------------------------------------------------------------------------
+# a tracked SEQUENCE: a camera that moves over a textured plane (Tracker::TrackFrame, src/Tracker.cc:86-200)
+# ---------------------------------------------------------------------------------------------
+SEED_SEQUENCE = 0x5EED000B
+_TEXEL = 0.00125          # metres per texel of the plane's texture
+_TEX_HALF = 2.0           # the texture covers [-2, 2]^2 m of the plane z = 0
+
+
+def make_plane_texture(seed=SEED_SEQUENCE):
+    """rectangles + integer noise like make_frame, on a 3200 x 3200 texel plane (same rectangle density per pixel seen from
+    1.5 m as the 640 x 480 frames)"""
+    n = int(round(2 * _TEX_HALF / _TEXEL))
+    return make_frame(seed, w=n, h=n, n_rect=int(400 * n * n / (640 * 480)))
+
+
+def sequence_pose(k, n, height=1.5):
+    """camera-from-world pose (12,) of frame k of a closed n-frame trajectory: the camera looks down at the plane from about
+    `height`, swings sideways and fore-and-aft, rises and sinks by 8 %, rolls about its optical axis by +-0.25 rad and tilts
+    by a few degrees — per frame (n = 64) up to ~5 px of image motion and ~1.4 degrees of roll, so that a share of the warps
+    crosses MakeTemplateCoarseCont's 0.07 refresh limit (src/PatchFinder.cc:103-111) every frame."""
+    ph = 2.0 * np.pi * k / n
+    pos = np.array([0.12 * np.sin(ph), 0.08 * np.sin(2 * ph), height * (1.0 + 0.08 * np.sin(ph + 0.7))])
+    base = np.diag([1.0, -1.0, -1.0])                                    # looking straight down, image y = -world y
+    w = np.array([0.05 * np.sin(2 * ph + 1.0), 0.04 * (np.cos(ph) - 1.0), 0.25 * np.sin(ph)])
+    R = so3_exp(w) @ base
+    return np.concatenate([R.reshape(9), -R @ pos])
+
+
+def render_plane_view(cam, pose, texture, noise_rng=None):
+    """the image the ATAN camera at `pose` sees of the textured plane z = 0: every pixel's ray (ATANCamera::UnProject) is
+    intersected with the plane and the texture sampled bilinearly; +-2 grey levels of sensor noise"""
+    w, h = cam.size
+    u, v = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    xy = cam.unproject(np.stack([u, v], axis=-1))
+    R, t = pose[:9].reshape(3, 3), pose[9:]
+    ray = np.concatenate([xy, np.ones(xy.shape[:2] + (1,))], axis=-1) @ R      # R^T d  (world direction), row vectors
+    org = -R.T @ t                                                              # camera centre in the world
+    with np.errstate(divide="ignore", invalid="ignore"):
+        s = -org[2] / ray[..., 2]
+    X = org[0] + s * ray[..., 0]
+    Y = org[1] + s * ray[..., 1]
+    tx = (X + _TEX_HALF) / _TEXEL - 0.5
+    ty = (Y + _TEX_HALF) / _TEXEL - 0.5
+    n = texture.shape[0]
+    ok = (s > 0) & (tx >= 0) & (ty >= 0) & (tx < n - 1) & (ty < n - 1)
+    tx, ty = np.where(ok, tx, 0.0), np.where(ok, ty, 0.0)
+    x0, y0 = tx.astype(np.int64), ty.astype(np.int64)
+    fx, fy = tx - x0, ty - y0
+    tex = texture.astype(np.float64)
+    val = ((1 - fy) * ((1 - fx) * tex[y0, x0] + fx * tex[y0, x0 + 1]) + fy * ((1 - fx) * tex[y0 + 1, x0] + fx * tex[y0 + 1, x0 + 1]))
+    val = np.where(ok, val, 128.0)
+    if noise_rng is not None:
+        val = val + noise_rng.integers(-2, 3, val.shape)
+    return np.clip(np.floor(val + 0.5), 0, 255).astype(np.uint8)
+
+
+def sequence_keyframe_pose(height=1.5):
+    """the pose of the map's source keyframe: near the trajectory's start but on none of its frames (a tracked frame that IS
+    the patch source matches to the last bit — half of the reprojection errors are then exactly zero and Tukey's sigma with
+    them, include/Tools.h:156-165)"""
+    pos = np.array([0.017, -0.023, 0.97 * height])
+    R = so3_exp(np.array([0.012, -0.02, 0.03])) @ np.diag([1.0, -1.0, -1.0])
+    return np.concatenate([R.reshape(9), -R @ pos])
+
+
+def make_tracking_frames(n_frames=64, period=64, seed=SEED_SEQUENCE, camera=DEFAULT_CAMERA, size=(640, 480)):
+    """-> (frames (n, h, w) u8, true poses (n, 12), keyframe image, keyframe pose): the first n_frames of the closed trajectory
+    `sequence_pose` of `period` frames (n_frames == period: frame 0 follows the last one) and the view from
+    `sequence_keyframe_pose` the map is made of"""
+    cam = AtanCam(camera, size)
+    tex = make_plane_texture(seed)
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    poses = np.stack([sequence_pose(k, period) for k in range(n_frames)])
+    frames = np.stack([render_plane_view(cam, poses[k], tex, rng) for k in range(n_frames)])
+    kf_pose = sequence_keyframe_pose()
+    return frames, poses, render_plane_view(cam, kf_pose, tex, rng), kf_pose
+
+
+def make_sequence_map(levels_0, pose_0, counts=(800, 300, 80, 40), seed=SEED_SEQUENCE + 2, camera=DEFAULT_CAMERA, size=(640, 480),
+                      n_junk=24):
+    """The map of the sequence: every point is the back-projection of a FAST corner of the source keyframe (levels_0 =
+    KeyFrame.level(l) of its image, `counts` corners per level) onto the plane z = 0 through the camera at pose_0, with the
+    one-pixel-right / -down world vectors of its level (MapPoint::RefreshPixelVectors, src/Map.cc:40-65); junk points as in
+    make_trackmap_case.  That keyframe is every point's patch source."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    cam = AtanCam(camera, size)
+    R, t = pose_0[:9].reshape(3, 3), pose_0[9:]
+    org = -R.T @ t
+
+    def back_project(px0):
+        xy = cam.unproject(px0)
+        ray = np.column_stack([xy, np.ones(len(xy))]) @ R
+        s = -org[2] / ray[:, 2]
+        return org + s[:, None] * ray
+
+    world, right, down, lev, cen = [], [], [], [], []
+    for l, n_l in enumerate(counts):
+        c = levels_0[l]["corners"]
+        hh, ww = levels_0[l]["im"].shape
+        m = 14
+        c = c[(c[:, 0] >= m) & (c[:, 1] >= m) & (c[:, 0] < ww - m) & (c[:, 1] < hh - m)]
+        c = c[rng.permutation(len(c))[:n_l]]
+        s_ = float(1 << l)
+        p0 = (c + 0.5) * s_ - 0.5
+        w0 = back_project(p0)
+        world.append(w0)
+        right.append(back_project(p0 + [s_, 0.0]) - w0)
+        down.append(back_project(p0 + [0.0, s_]) - w0)
+        lev.append(np.full(len(c), l, np.int32))
+        cen.append(c.astype(np.int32))
+    world, right, down = np.vstack(world), np.vstack(right), np.vstack(down)
+    lev, cen = np.concatenate(lev), np.vstack(cen)
+    j = n_junk
+    jw = np.column_stack([rng.uniform(-6, 6, j), rng.uniform(-6, 6, j), rng.uniform(-1, 4, j)])
+    jr = rng.normal(0, 1, (j, 3)) * rng.choice([1e-6, 1e-3, 1.0], j)[:, None]
+    jd = rng.normal(0, 1, (j, 3)) * rng.choice([1e-6, 1e-3, 1.0], j)[:, None]
+    world, right, down = np.vstack([world, jw]), np.vstack([right, jr]), np.vstack([down, jd])
+    lev = np.concatenate([lev, rng.integers(0, 4, j).astype(np.int32)])
+    cen = np.vstack([cen, np.column_stack([rng.integers(14, 60, j), rng.integers(14, 40, j)]).astype(np.int32)])
+    perm = rng.permutation(len(world))
+    n = len(world)
+    return {"world": world[perm], "pixel_right_w": right[perm], "pixel_down_w": down[perm], "src_level": lev[perm], "center": cen[perm],
+            "shuffle_levels": rng.permutation(n).astype(np.int32), "shuffle_fine": rng.permutation(n).astype(np.int32)}
+
+
 def make_template_cases(size, n=600, seed=0x5EED0008):
     """Inputs of PatchFinder::MakeTemplateCoarseCont against a keyframe of level-0 size `size` (w, h): source level
     (50/25/15/10 mix), patch centre at that level (mostly interior, some hugging the border so that the walk

@@ -12,7 +12,7 @@ from ptam_cg_amd.sharding import shard_problem
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "ptam_cg_amd", "csrc", "libptam_hip.so")
-HEADER = os.path.join(ROOT, "include", "ptam_hip.h")
+HEADERS = [os.path.join(ROOT, "include", "ptam_hip.h"), os.path.join(ROOT, "include", "ptam_hip_bench.h")]
 
 
 @pytest.fixture(scope="module")
@@ -24,7 +24,7 @@ def built():
 
 
 def header_functions():
-    src = open(HEADER).read()
+    src = "\n".join(open(h).read() for h in HEADERS)
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(ptam_[a-z0-9_]+)\s*\(", src)) - {"ptam_allreduce_f64_fn"})
 
@@ -58,6 +58,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_abi.Projection) == 80 and ctypes.sizeof(_abi.PoseMeas) == 48
     assert ctypes.sizeof(_abi.PoseUpdateMeas) == 136 and ctypes.sizeof(_abi.BaTrial) == 48
     assert ctypes.sizeof(_abi.CamParams) == 48 and ctypes.sizeof(_abi.GnOpts) == 40 and ctypes.sizeof(_abi.BaOpts) == 40
+    assert ctypes.sizeof(_abi.MotionModel) == 12 * 8 * 2 + 6 * 8 + 4 * 8 + 16
 
 
 def test_product_never_touches_the_oracle():

@@ -492,3 +492,86 @@ def test_track_map_chain_against_oracle_twin_over_frames(hip, oracle):
         _check(rh, ih, ref, strict=False)
         assert rh["templates_reused"] == ro["templates_reused"], k
     assert runs["oracle"][1][0]["templates_reused"] > 0 and runs["oracle"][0][0]["n_meas"] > 300
+
+
+def _copy_model(m):
+    from ptam_cg_amd import _abi
+    import ctypes as C
+    c = _abi.MotionModel()
+    C.memmove(C.byref(c), C.byref(m), C.sizeof(m))
+    return c
+
+
+def test_moving_camera_sequence_against_oracle_twin(hip, oracle):
+    """a camera that MOVES (synth.make_tracking_frames: 48 distinct rendered frames of a trajectory that
+    translates, rises, rolls and tilts) tracked as Tracker::TrackFrame does it — keyframe of the new image, motion-model
+    prediction, bTryCoarse from the velocity, TrackMap, motion-model update (src/Tracker.cc:94,134-137,1013-1056).
+    (i) frame by frame, product and oracle twin start from the SAME model state (the oracle's closed-loop one) and must agree
+    like every other chain test: discrete outcome exactly, poses / sub-pixel positions within the documented allowance, the
+    number of kept templates exactly; (ii) the product's own closed loop stays on the true trajectory and beside the oracle's;
+    (iii) the native driver (ptam_bench_track_sequence) reproduces the closed loop bit for bit."""
+    frames, poses, kim, kpose = synth.make_tracking_frames(48)
+    sides = {}
+    for name, lib in (("hip", hip), ("oracle", oracle)):
+        ctx = host.Context(lib=lib)
+        kf0 = host.KeyFrame(ctx).MakeKeyFrame_Lite(kim)
+        m = synth.make_sequence_map([kf0.level(l) for l in range(4)], kpose)
+        tr = host.Tracker(ctx, len(m["world"]))
+        tr.set_map(m["world"], m["pixel_right_w"], m["pixel_down_w"], kf0, m["src_level"], m["center"])
+        sides[name] = (ctx, kf0, m, tr, host.KeyFrame(ctx))
+    ctx_h, _, m, tr_h, kf_h = sides["hip"]
+    _, _, mo, tr_o, kf_o = sides["oracle"]
+    for k in ("world", "src_level", "center"):
+        assert np.array_equal(m[k], mo[k])                       # bit-exact keyframes -> the same map on both sides
+    d_frames = [host.DevBuf(ctx_h, f) for f in frames]
+    opts = tr_h.opts()
+    mm_o = tr_o.motion_model(poses[0])
+    reused = searched = coarse = 0
+    closed_o = []
+    for k in range(len(frames)):
+        mm_h = _copy_model(mm_o)                                  # the same prediction and heuristics on both sides
+        tr_o.set_shuffle(np.roll(m["shuffle_levels"], 5 * k), np.roll(m["shuffle_fine"], 11 * k))
+        tr_h.set_shuffle(np.roll(m["shuffle_levels"], 5 * k), np.roll(m["shuffle_fine"], 11 * k))
+        ro = tr_o.TrackFrameMoving(kf_o, frames[k].ctypes.data, mm_o, tr_o.opts())
+        io = tr_o.iteration_set()
+        rh = tr_h.TrackFrameMoving(kf_h, d_frames[k], mm_h, opts)
+        ih = tr_h.iteration_set()
+        ref = {"pose": ro["pose"], "did_coarse": bool(ro["did_coarse"]), "n_pvs": list(ro["n_pvs"]), "attempted": list(ro["attempted"]),
+               "found": list(ro["found"]), "n_coarse": ro["n_coarse"], "n_top": ro["n_top"], "n_fine": ro["n_fine"], "n_meas": ro["n_meas"],
+               "depth": (ro["depth_sum"], ro["depth_sum_sq"], ro["depth_n"]), "iteration_set": io}
+        _check(rh, ih, ref, strict=False)
+        assert rh["templates_reused"] == ro["templates_reused"], k
+        # the models after the frame: same start pose, velocity = ln of poses that agree to 2e-5
+        assert np.array_equal(np.array(mm_h.start_pose), np.array(mm_o.start_pose))
+        assert np.allclose(np.array(mm_h.velocity), np.array(mm_o.velocity), rtol=0, atol=5e-5)
+        assert np.isclose(mm_h.scene_depth_mean, mm_o.scene_depth_mean, rtol=1e-5)
+        assert np.abs(ro["pose"] - poses[k]).max() < 3e-3, k
+        n = int(ro["n_coarse"] + ro["n_top"] + ro["n_fine"])
+        if k:
+            reused, searched, coarse = reused + int(ro["templates_reused"]), searched + n, coarse + int(ro["did_coarse"])
+        closed_o.append(ro["pose"].copy())
+    print("moving camera: %d of %d searched templates kept (%.0f %%), coarse stage on %d of %d frames"
+          % (reused, searched, 100.0 * reused / searched, coarse, len(frames) - 1))
+    assert 0.3 * searched < reused < 0.95 * searched and coarse >= len(frames) - 3
+    # (ii) the product's own closed loop
+    tr_h.set_map(m["world"], m["pixel_right_w"], m["pixel_down_w"], sides["hip"][1], m["src_level"], m["center"])
+    mm = tr_h.motion_model(poses[0])
+    closed_h = []
+    for k in range(len(frames)):
+        tr_h.set_shuffle(m["shuffle_levels"], m["shuffle_fine"])
+        r = tr_h.TrackFrameMoving(kf_h, d_frames[k], mm, opts)
+        assert np.abs(r["pose"] - poses[k]).max() < 3e-3 and r["n_meas"] > 600, k
+        closed_h.append(r["pose"].copy())
+    # (the two loops use different shuffles and round differently: they meet within the tracking noise, not to the bit)
+    assert np.abs(np.array(closed_h) - np.array(closed_o)).max() < 2e-3
+    # (iii) the native driver: the same closed loop from one C++ host thread
+    tr_h.set_map(m["world"], m["pixel_right_w"], m["pixel_down_w"], sides["hip"][1], m["src_level"], m["center"])
+    mm2 = tr_h.motion_model(poses[0])
+    secs, st = tr_h.track_sequence_native(kf_h, d_frames, mm2, opts, m["shuffle_levels"], m["shuffle_fine"], passes=1, poses_true=poses)
+    assert secs > 0 and st["frames"] == len(frames) and st["frames_below_50_measurements"] == 0
+    assert np.array_equal(np.array(mm2.pose), closed_h[-1]) and np.array_equal(np.array(mm2.velocity), np.array(mm.velocity))
+    assert 0 < st["templates_reused"] < st["searched"] and st["max_position_error_m"] < 5e-3
+    for d in d_frames:
+        d.free()
+    tr_h.close()
+    tr_o.close()
