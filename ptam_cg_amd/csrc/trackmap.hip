@@ -26,6 +26,7 @@
 #include "patch_device.h"
 #include "keyframe_device.h"
 #include "pvs_device.h"
+#include "pose_device.h"
 
 struct TmSrc {   // MapPoint::pPatchSourceKF / nSourceLevel / irCenter, resolved to the level image
     const uint8_t* im;
@@ -45,7 +46,7 @@ struct TmCtl {
     int attempted[4], found[4];   // manMeasAttempted / manMeasFound
     int range_all[2], range_c[2], range_hf[2], range_h[2];   // slot ranges {first, end} of the stages
     int n_reused;           // searched patches whose PatchFinder kept its template (src/PatchFinder.cc:103-111)
-    int pad_[1];
+    int outlier_by_slot;    // d.outlier is indexed by search slot (fused pose kernels) instead of by compacted measurement
     double depth[3];        // sum z, sum z^2, count over the found points (:680-690)
 };
 
@@ -425,7 +426,8 @@ __device__ __forceinline__ void tm_gather_finish(const TmDev& d, TmCtl& c, int s
         const int n_reused = c.n_reused + n_kept;   // searched patches of the stages so far whose finder kept its template
         c.n_reused = n_reused;
         int f4[4], a4[4];
-        for (int l = 0; l < 4; l++) {
+#pragma unroll
+        for (int l = 0; l < 4; l++) {   // (unrolled: dynamically indexed local arrays are scratch memory)
             int tf = 0, ta = 0;
             for (int w = 0; w < 16; w++) {
                 tf += lsum[l][w];
@@ -443,12 +445,14 @@ __device__ __forceinline__ void tm_gather_finish(const TmDev& d, TmCtl& c, int s
             c.fine_range = c.did_coarse ? 5 : 10;                           // :572
         } else {
             c.n_meas = tot[0];
+            c.outlier_by_slot = 0;
             // everything of the frame's result but the pose and the depth sums (the fine pose loop publishes those, then
             // the sequence word)
             ptam_trackmap_result& r = mbox->res;
             r.templates_reused = n_reused;
             r.pad_ = 0;
             r.did_coarse = c.did_coarse;
+#pragma unroll
             for (int l = 0; l < 4; l++) {
                 r.n_pvs[l] = c.n_lvl[l];
                 r.attempted[l] = a4[l];
@@ -547,6 +551,179 @@ __device__ __forceinline__ void tm_gather_body(const TmDev& d, int stage, int co
 }
 __global__ void __launch_bounds__(TM_GATHER_THREADS) tm_gather_kernel(TmDev d, int stage, int coarse_its, unsigned coarse_min, TmMailbox* mbox) {
     tm_gather_body(d, stage, coarse_its, coarse_min, mbox, blockIdx.x);
+}
+
+// ---- SearchForPoints' bookkeeping + the pose loop in ONE launch (round 4) -----------------------------------------------
+// The gather pass above exists to hand the pose kernel a compacted measurement list.  The register-resident pose loop does not
+// need one: a slot without a measurement is a lane with weight zero.  So the loop's prologue takes its measurements straight
+// from the search stage's slots — thread (q, tid) owns slot tid + q * THREADS — and books the stage's outcome itself: one
+// launch (and its boundary) less per stage, 2 x (5.6 us kernel + 2.3 us boundary) per frame.  Lists of more slots than the
+// kernel holds (a top-level set that outgrows MaxPatchesPerFrame) are told to the host, which sends the gather pass and the
+// general pose kernel instead.
+template <int MPT, int THREADS>
+struct TmSlotLoader {
+    const TmDev& d;
+    int stage;
+    unsigned coarse_min;
+    TmMailbox* mbox;
+    unsigned long long long_seq;   // what to publish when the list is too long (0: the host knows the capacity suffices)
+    int id[MPT];
+    int n_found;
+
+    template <class SH>
+    __device__ __forceinline__ bool begin(SH& sh, int& n, int cap, SmallMeas (&t)[MPT]) {
+        const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+        // (A) every load that hangs on no other: the control block (uniform), and my slots' status word, point id and found
+        //     position — fetched for the capacity, masked by the list's length afterwards: a load behind `slot < length` would
+        //     wait for the control block first, and every dependent round trip of this single-workgroup kernel is ~1 us of frame
+        const TmCtl c0 = *d.ctl;
+        int st[MPT];
+        double2 v2[MPT];
+#pragma unroll
+        for (int q = 0; q < MPT; q++) {
+            const int sc = min(tid + q * THREADS, d.cap - 1);
+            st[q] = d.slot_stat[sc];
+            id[q] = d.list[sc];
+            v2[q] = d.slot_v2[sc];
+        }
+        const int g_end = stage == 0 ? c0.nC : c0.n_slots;
+        const int st_first = stage == 0 ? 0 : c0.nC;
+        if (g_end > cap) {
+            if (tid == 0 && long_seq) *(volatile unsigned long long*)&mbox->seq = long_seq | POSE_CHAIN_LONG;
+            return false;
+        }
+        n = g_end;
+        // (B) the loads that hang on the point id: world position and TrackerData state (v3Cam, v2Image, m2CamDerivs)
+        int p_tot = 0, p_f01 = 0, p_f23 = 0, p_a01 = 0, p_a23 = 0;
+#pragma unroll
+        for (int q = 0; q < MPT; q++) {
+            const int s = tid + q * THREADS;
+            const bool valid = s < g_end;
+            st[q] = valid ? st[q] : 0;
+            id[q] = valid ? id[q] : 0;
+            const ptam_pvs_point* pp = &d.pts[id[q]];
+            const ptam_projection* pj = &d.pvs[id[q]].proj;
+            t[q].world[0] = pp->world[0], t[q].world[1] = pp->world[1], t[q].world[2] = pp->world[2];
+#pragma unroll
+            for (int k = 0; k < 3; k++) t[q].cam3[k] = pj->cam[k];
+            t[q].img[0] = pj->image[0];
+            t[q].img[1] = pj->image[1];
+#pragma unroll
+            for (int k = 0; k < 4; k++) t[q].D[k] = pj->derivs[k];
+            t[q].fnd[0] = v2[q].x;
+            t[q].fnd[1] = v2[q].y;
+            // per-level counts of the slots this stage decided (found | attempted << 1 | level << 2 | kept << 4), two 16-bit
+            // fields to a word: a list holds at most 1024 slots
+            const int w = st[q], l = (w >> 2) & 3, mine = valid && s >= st_first;
+            t[q].sn = 1.0 / (double)(1 << l);   // :889
+            t[q].listed = w & 1;
+            p_tot += (w & 1) | ((mine ? (w >> 4) & 1 : 0) << 16);
+            const int f = mine ? (w & 1) : 0, a = mine ? (w >> 1) & 1 : 0;
+            p_f01 += (l == 0 ? f : 0) | ((l == 1 ? f : 0) << 16);
+            p_f23 += (l == 2 ? f : 0) | ((l == 3 ? f : 0) << 16);
+            p_a01 += (l == 0 ? a : 0) | ((l == 1 ? a : 0) << 16);
+            p_a23 += (l == 2 ? a : 0) | ((l == 3 ? a : 0) << 16);
+        }
+        p_tot = wave_sum_i32(p_tot);
+        p_f01 = wave_sum_i32(p_f01);
+        p_f23 = wave_sum_i32(p_f23);
+        p_a01 = wave_sum_i32(p_a01);
+        p_a23 = wave_sum_i32(p_a23);
+        // (the pose loop's histogram is not in use yet: five words per wave meet there)
+        if (lane == 63) {
+            sh.hist[wid * 8 + 0] = (unsigned)p_tot;
+            sh.hist[wid * 8 + 1] = (unsigned)p_f01;
+            sh.hist[wid * 8 + 2] = (unsigned)p_f23;
+            sh.hist[wid * 8 + 3] = (unsigned)p_a01;
+            sh.hist[wid * 8 + 4] = (unsigned)p_a23;
+        }
+        __syncthreads();
+        unsigned tt = 0, f01 = 0, f23 = 0, a01 = 0, a23 = 0;
+#pragma unroll
+        for (int w = 0; w < THREADS / 64; w++) {
+            tt += sh.hist[w * 8 + 0];
+            f01 += sh.hist[w * 8 + 1];
+            f23 += sh.hist[w * 8 + 2];
+            a01 += sh.hist[w * 8 + 3];
+            a23 += sh.hist[w * 8 + 4];
+        }
+        __syncthreads();   // (the words are read; the loop's own zeroing pass of the histogram follows)
+        const int total = (int)(tt & 0xffffu), n_kept = (int)(tt >> 16);
+        const int did = stage == 0 ? (c0.do_coarse && (unsigned)total >= coarse_min) : 1;
+        if (tid == 0) {
+            TmCtl& c = *d.ctl;
+            const int lf[4] = {(int)(f01 & 0xffffu), (int)(f01 >> 16), (int)(f23 & 0xffffu), (int)(f23 >> 16)};
+            const int la[4] = {(int)(a01 & 0xffffu), (int)(a01 >> 16), (int)(a23 & 0xffffu), (int)(a23 >> 16)};
+            const int n_reused = c0.n_reused + n_kept;
+            c.n_reused = n_reused;
+            int f4[4], a4[4];
+#pragma unroll
+            for (int l = 0; l < 4; l++) {   // (unrolled: a dynamically indexed local array is scratch memory, and a kernel that
+                                            //  needs scratch is dispatched later)
+                f4[l] = c0.found[l] + lf[l];
+                a4[l] = c0.attempted[l] + la[l];
+                c.found[l] = f4[l];
+                c.attempted[l] = a4[l];
+            }
+            if (stage == 0) {
+                c.n_found_coarse = total;
+                c.did_coarse = did;                                   // :550-551
+                c.n_meas_coarse = did ? total : 0;
+                c.fine_range = did ? 5 : 10;                          // :572
+            } else {
+                c.n_meas = total;
+                c.outlier_by_slot = 1;
+                ptam_trackmap_result& r = mbox->res;
+                r.templates_reused = n_reused;
+                r.pad_ = 0;
+                r.did_coarse = c0.did_coarse;
+#pragma unroll
+                for (int l = 0; l < 4; l++) {
+                    r.n_pvs[l] = c0.n_lvl[l];
+                    r.attempted[l] = a4[l];
+                    r.found[l] = f4[l];
+                }
+                r.n_coarse = c0.nC;
+                r.n_top = c0.nH;
+                r.n_fine = c0.nF;
+                r.n_meas = total;
+            }
+        }
+        n_found = did ? total : 0;
+        if (!did) {   // the coarse stage found too little: no pose update (:550), nobody is listed
+#pragma unroll
+            for (int q = 0; q < MPT; q++) t[q].listed = 0;
+        }
+        return true;
+    }
+    __device__ __forceinline__ void load(int, int, int, SmallMeas&) const {}   // (begin has filled the slots)
+    __device__ __forceinline__ bool has_entry() const { return true; }
+    __device__ __forceinline__ ptam_projection* td_target(int q, int, const PoseChainIo&) const { return &d.pvs[id[q]].proj; }
+    __device__ __forceinline__ int listed_total(int) const { return n_found; }
+};
+
+template <int MPT, int THREADS>
+__device__ __forceinline__ void tm_pose_body(const DevCam& cam, const TmDev& d, int stage, unsigned coarse_min, TmMailbox* mbox,
+                                             const ptam_gn_opts& opts, const PoseChainIo& io, double* updates, unsigned long long long_seq) {
+    TmSlotLoader<MPT, THREADS> ld{d, stage, coarse_min, mbox, long_seq};
+    pose_gn_small_body<MPT, THREADS>(cam, THREADS * MPT, ld, d.pose, opts, stage == 1 ? d.outlier : nullptr, updates, nullptr, 0ull, nullptr, nullptr,
+                                     io, 0);
+}
+template <int MPT, int THREADS>
+__global__ void __launch_bounds__(THREADS) tm_pose_kernel(DevCam cam, TmDev d, int stage, unsigned coarse_min, TmMailbox* mbox, ptam_gn_opts opts,
+                                                          PoseChainIo io, double* updates, unsigned long long long_seq) {
+    tm_pose_body<MPT, THREADS>(cam, d, stage, coarse_min, mbox, opts, io, updates, long_seq);
+}
+typedef void (*tm_pose_fn)(DevCam, TmDev, int, unsigned, TmMailbox*, ptam_gn_opts, PoseChainIo, double*, unsigned long long);
+struct TmBatchItem;
+// instantiation for a list of at most cap slots (<= GS_LIMIT): one wave up to 64, one slot per thread up to 256, four up to 1024
+static tm_pose_fn tm_pose_pick(int cap, int* threads) {
+    if (cap <= GS_WAVE_LIMIT) {
+        *threads = GS_WAVE_LIMIT;
+        return tm_pose_kernel<1, GS_WAVE_LIMIT>;
+    }
+    *threads = GS_THREADS;
+    return cap <= GS_THREADS ? tm_pose_kernel<1, GS_THREADS> : tm_pose_kernel<GS_MPT, GS_THREADS>;
 }
 
 // ---- MapMaker::ReFind_Common (src/MapMaker.cc:943-1020), batched over the map points of one keyframe ----
@@ -926,6 +1103,24 @@ __global__ void __launch_bounds__(TM_GATHER_THREADS) tm_gather_batch_kernel(cons
     const TmBatchItem& it = items[blockIdx.y];
     tm_gather_body(it.d, stage, coarse_its, coarse_min, it.mbox, blockIdx.x);
 }
+// the fused bookkeeping + pose loop (tm_pose_body) for the frames of a batch: one workgroup per frame; io and scratch of the frame's
+// stage come from the pose items the unfused path uses
+template <int MPT, int THREADS>
+__global__ void __launch_bounds__(THREADS) tm_pose_batch_kernel(DevCam cam, const TmBatchItem* __restrict__ items, const PoseBatchItem* __restrict__ pitems,
+                                                                int stage, unsigned coarse_min, ptam_gn_opts opts) {
+    const TmBatchItem& it = items[blockIdx.x];
+    const PoseBatchItem& pi = pitems[blockIdx.x];
+    tm_pose_body<MPT, THREADS>(cam, it.d, stage, coarse_min, it.mbox, opts, pi.io, pi.updates, 0ull);
+}
+static void tm_pose_launch_batch(ptam_ctx* ctx, int nb, int cap, const TmBatchItem* d_it, const PoseBatchItem* d_p, int stage, unsigned coarse_min,
+                                 const ptam_gn_opts& g) {
+    if (cap <= GS_WAVE_LIMIT)
+        hipLaunchKernelGGL((tm_pose_batch_kernel<1, GS_WAVE_LIMIT>), dim3(nb), dim3(GS_WAVE_LIMIT), 0, ctx->stream, ctx->cam, d_it, d_p, stage, coarse_min, g);
+    else if (cap <= GS_THREADS)
+        hipLaunchKernelGGL((tm_pose_batch_kernel<1, GS_THREADS>), dim3(nb), dim3(GS_THREADS), 0, ctx->stream, ctx->cam, d_it, d_p, stage, coarse_min, g);
+    else
+        hipLaunchKernelGGL((tm_pose_batch_kernel<GS_MPT, GS_THREADS>), dim3(nb), dim3(GS_THREADS), 0, ctx->stream, ctx->cam, d_it, d_p, stage, coarse_min, g);
+}
 
 struct ptam_tracker {
     ptam_ctx* ctx;
@@ -1196,8 +1391,13 @@ static int track_map_impl(ptam_tracker* t, ptam_kf* cur, const uint8_t* d_new_fr
     if (prof) hipEventRecord(t->ev[PTAM_TS_SEARCH_COARSE], st);
     hipLaunchKernelGGL(tm_search_kernel, dim3((ncc + 3) / 4), dim3(256), 0, st, ctx->cam, cur->L, d, 0, o.coarse_range, o.coarse_subpix_its);
     if (prof) hipEventRecord(t->ev[PTAM_TS_GATHER_COARSE], st);
-    hipLaunchKernelGGL(tm_gather_kernel, dim3(std::max(1, (ncc + TM_GATHER_THREADS - 1) / TM_GATHER_THREADS)), dim3(TM_GATHER_THREADS), 0, st, d, 0, o.coarse_subpix_its, o.coarse_min, t->mbox_dev);
-    if (prof) hipEventRecord(t->ev[PTAM_TS_POSE_COARSE], st);
+    static const bool no_fuse = getenv("PTAM_TM_NO_FUSE") != nullptr;   // (A/B runs: the gather pass + pose kernel of rounds 2-3)
+    double* d_upd;
+    {
+        void* s_;
+        rc = pose_chain_scratch(ctx, std::max(n, 1), &s_, &d_upd);
+        if (rc) return rc;
+    }
     {
         ptam_gn_opts g;
         ptam_gn_opts_default(&g);
@@ -1209,15 +1409,23 @@ static int track_map_impl(ptam_tracker* t, ptam_kf* cur, const uint8_t* d_new_fr
         io.td_base = &d.pvs[0].proj;
         io.td_index = d.midx;
         io.td_stride = (int)sizeof(ptam_pvs_result);
-        rc = pose_launch_chain(ctx, ncc, &d.ctl->n_meas_coarse, d.meas, d.entry, d.pose, &g, nullptr, io);
-        if (rc) return rc;
+        if (ncc <= GS_LIMIT && !no_fuse) {
+            // SearchForPoints' bookkeeping and the ten coarse iterations in one launch (the coarse set holds at most CoarseMax slots)
+            if (prof) hipEventRecord(t->ev[PTAM_TS_POSE_COARSE], st);
+            int thr;
+            const tm_pose_fn fn = tm_pose_pick(ncc, &thr);
+            hipLaunchKernelGGL(fn, dim3(1), dim3(thr), 0, st, ctx->cam, d, 0, o.coarse_min, t->mbox_dev, g, io, d_upd, 0ull);
+        } else {
+            hipLaunchKernelGGL(tm_gather_kernel, dim3(std::max(1, (ncc + TM_GATHER_THREADS - 1) / TM_GATHER_THREADS)), dim3(TM_GATHER_THREADS), 0, st, d, 0, o.coarse_subpix_its, o.coarse_min, t->mbox_dev);
+            if (prof) hipEventRecord(t->ev[PTAM_TS_POSE_COARSE], st);
+            rc = pose_launch_chain(ctx, ncc, &d.ctl->n_meas_coarse, d.meas, d.entry, d.pose, &g, nullptr, io);
+            if (rc) return rc;
+        }
     }
     // ---- fine stage :571-643 ----
     if (prof) hipEventRecord(t->ev[PTAM_TS_SEARCH_FINE], st);
     hipLaunchKernelGGL(tm_search_kernel, dim3(std::max(1, (n + 3) / 4)), dim3(256), 0, st, ctx->cam, cur->L, d, 1, 0u, 0);
     if (prof) hipEventRecord(t->ev[PTAM_TS_GATHER_FINE], st);
-    hipLaunchKernelGGL(tm_gather_kernel, dim3(std::max(1, (n + TM_GATHER_THREADS - 1) / TM_GATHER_THREADS)), dim3(TM_GATHER_THREADS), 0, st, d, 1, o.coarse_subpix_its, o.coarse_min, t->mbox_dev);
-    if (prof) hipEventRecord(t->ev[PTAM_TS_POSE_FINE], st);
     const unsigned long long seq = ++t->seq;
     t->last_stream = st;
     {
@@ -1230,13 +1438,26 @@ static int track_map_impl(ptam_tracker* t, ptam_kf* cur, const uint8_t* d_new_fr
         io.result_depth = t->mbox_dev->depth3;
         io.result_seq = &t->mbox_dev->seq;
         io.seq = seq;
-        rc = pose_launch_chain(ctx, std::max(n, 1), &d.ctl->n_meas, d.meas, d.entry, d.pose, &g, d.outlier, io, 1);
-        if (rc) return rc;
+        bool fused = !no_fuse;
+        if (fused) {
+            // bookkeeping + the ten fine iterations in one launch.  The iteration set holds at most max(MaxPatchesPerFrame, coarse
+            // + top-level set) slots: with more than the kernel's 1024 it says so instead (POSE_CHAIN_LONG) and the gather pass
+            // and the general kernel follow
+            if (prof) hipEventRecord(t->ev[PTAM_TS_POSE_FINE], st);
+            int thr;
+            const tm_pose_fn fn = tm_pose_pick(std::min(std::max(n, 1), GS_LIMIT), &thr);
+            hipLaunchKernelGGL(fn, dim3(1), dim3(thr), 0, st, ctx->cam, d, 1, o.coarse_min, t->mbox_dev, g, io, d_upd, n > GS_LIMIT ? seq : 0ull);
+        } else {
+            hipLaunchKernelGGL(tm_gather_kernel, dim3(std::max(1, (n + TM_GATHER_THREADS - 1) / TM_GATHER_THREADS)), dim3(TM_GATHER_THREADS), 0, st, d, 1, o.coarse_subpix_its, o.coarse_min, t->mbox_dev);
+            if (prof) hipEventRecord(t->ev[PTAM_TS_POSE_FINE], st);
+            rc = pose_launch_chain(ctx, std::max(n, 1), &d.ctl->n_meas, d.meas, d.entry, d.pose, &g, d.outlier, io, 1);
+            if (rc) return rc;
+        }
         if (prof) hipEventRecord(t->ev[PTAM_TS_COUNT], st);
         HIP_TRY(hipGetLastError());
-        // the frame's last kernel publishes the sequence number — or, for a list of more than 1024 measurements, asks for the
-        // general kernel (pose.hip: pose_launch_chain), which then publishes it
-        for (int pass = 0; pass < 2; pass++) {
+        // the frame's last kernel publishes the sequence number — or, for a list of more than 1024 entries, asks for the
+        // general path, which then publishes it
+        for (int pass = 0; pass < 3; pass++) {
             unsigned spins = 0;
             unsigned long long v;
             while (((v = *(volatile unsigned long long*)&t->mbox->seq) & ~POSE_CHAIN_LONG) != seq) {
@@ -1251,9 +1472,17 @@ static int track_map_impl(ptam_tracker* t, ptam_kf* cur, const uint8_t* d_new_fr
                 }
             }
             if (!(v & POSE_CHAIN_LONG)) break;
-            if (pass == 1) return PTAM_E_STATE;
-            t->mbox->seq = 0;   // (the stream is idle: nobody else writes the word until the general kernel does)
-            rc = pose_launch_chain(ctx, std::max(n, 1), &d.ctl->n_meas, d.meas, d.entry, d.pose, &g, d.outlier, io, 2);
+            if (pass == 2) return PTAM_E_STATE;
+            t->mbox->seq = 0;   // (the stream is idle: nobody else writes the word until the next kernel does)
+            if (fused) {
+                // more slots than the fused kernel holds: compact them, then the register-resident kernel if the FOUND ones fit
+                // (it says so otherwise: next pass)
+                fused = false;
+                hipLaunchKernelGGL(tm_gather_kernel, dim3(std::max(1, (n + TM_GATHER_THREADS - 1) / TM_GATHER_THREADS)), dim3(TM_GATHER_THREADS), 0, st, d, 1, o.coarse_subpix_its, o.coarse_min, t->mbox_dev);
+                rc = pose_launch_chain(ctx, std::max(n, 1), &d.ctl->n_meas, d.meas, d.entry, d.pose, &g, d.outlier, io, 1);
+            } else {
+                rc = pose_launch_chain(ctx, std::max(n, 1), &d.ctl->n_meas, d.meas, d.entry, d.pose, &g, d.outlier, io, 2);
+            }
             if (rc) return rc;
             HIP_TRY(hipGetLastError());
         }
@@ -1420,8 +1649,10 @@ int ptam_track_map_frames_batch(int nb, ptam_tracker* const* ts, ptam_kf* const*
     hipLaunchKernelGGL(tm_compact_select_batch_kernel, dim3(1 + fast_compact_blocks(L0), nb), dim3(1024), 0, st, d_it, o);
     // ---- coarse stage :519-569 ----
     hipLaunchKernelGGL(tm_search_batch_kernel, dim3((ncc_max + 3) / 4, nb), dim3(256), 0, st, ctx->cam, d_it, 0, o.coarse_range, o.coarse_subpix_its);
-    hipLaunchKernelGGL(tm_gather_batch_kernel, dim3(std::max(1, (ncc_max + TM_GATHER_THREADS - 1) / TM_GATHER_THREADS), nb), dim3(TM_GATHER_THREADS), 0, st,
-                       d_it, 0, (int)o.coarse_subpix_its, o.coarse_min);
+    // (fused bookkeeping + pose loop per stage when no frame's list can outgrow the register-resident kernel: maps of at most
+    //  1024 points; larger maps keep the gather pass and the small / general kernel pair)
+    static const bool no_fuse = getenv("PTAM_TM_NO_FUSE") != nullptr;
+    const bool fuse = !no_fuse && n_max <= GS_LIMIT && ncc_max <= GS_LIMIT;
     {
         ptam_gn_opts g;
         ptam_gn_opts_default(&g);
@@ -1429,19 +1660,29 @@ int ptam_track_map_frames_batch(int nb, ptam_tracker* const* ts, ptam_kf* const*
         g.override_sigma_sq = 1.0;      // :565
         g.mark_outliers_iter = -1;
         g.estimator = o.estimator;
-        rc = pose_launch_chain_batch(ctx, nb, ncc_max, d_pc, &g);
-        if (rc) return rc;
+        if (fuse)
+            tm_pose_launch_batch(ctx, nb, ncc_max, d_it, d_pc, 0, o.coarse_min, g);
+        else {
+            hipLaunchKernelGGL(tm_gather_batch_kernel, dim3(std::max(1, (ncc_max + TM_GATHER_THREADS - 1) / TM_GATHER_THREADS), nb), dim3(TM_GATHER_THREADS), 0, st,
+                               d_it, 0, (int)o.coarse_subpix_its, o.coarse_min);
+            rc = pose_launch_chain_batch(ctx, nb, ncc_max, d_pc, &g);
+            if (rc) return rc;
+        }
     }
     // ---- fine stage :571-643 ----
     hipLaunchKernelGGL(tm_search_batch_kernel, dim3(std::max(1, (n_max + 3) / 4), nb), dim3(256), 0, st, ctx->cam, d_it, 1, 0u, 0);
-    hipLaunchKernelGGL(tm_gather_batch_kernel, dim3(std::max(1, (n_max + TM_GATHER_THREADS - 1) / TM_GATHER_THREADS), nb), dim3(TM_GATHER_THREADS), 0, st,
-                       d_it, 1, (int)o.coarse_subpix_its, o.coarse_min);
     {
         ptam_gn_opts g;
         ptam_gn_opts_default(&g);       // fine schedule :613-643
         g.estimator = o.estimator;
-        rc = pose_launch_chain_batch(ctx, nb, std::max(n_max, 1), d_pf, &g);
-        if (rc) return rc;
+        if (fuse)
+            tm_pose_launch_batch(ctx, nb, std::max(n_max, 1), d_it, d_pf, 1, o.coarse_min, g);
+        else {
+            hipLaunchKernelGGL(tm_gather_batch_kernel, dim3(std::max(1, (n_max + TM_GATHER_THREADS - 1) / TM_GATHER_THREADS), nb), dim3(TM_GATHER_THREADS), 0, st,
+                               d_it, 1, (int)o.coarse_subpix_its, o.coarse_min);
+            rc = pose_launch_chain_batch(ctx, nb, std::max(n_max, 1), d_pf, &g);
+            if (rc) return rc;
+        }
     }
     HIP_TRY(hipGetLastError());
     for (int i = 0; i < nb; i++) {
@@ -1503,6 +1744,12 @@ int ptam_tracker_read_iteration_set(ptam_tracker* t, ptam_trackmap_meas* out, in
         m.pad_ = 0;
         m.v2_found[0] = v2[(size_t)s].x;
         m.v2_found[1] = v2[(size_t)s].y;
+    }
+    if (c.outlier_by_slot) {   // (fused pose kernel: the flags sit at the slots)
+        std::vector<int> os((size_t)ns);
+        HIP_TRY(hipMemcpy(os.data(), t->d.outlier, (size_t)ns * 4, hipMemcpyDeviceToHost));
+        for (int s = 0; s < ns && s < cap; s++) out[s].outlier = sf[(size_t)s] ? os[(size_t)s] : 0;
+        return PTAM_OK;
     }
     for (int k = 0; k < c.n_meas; k++)
         if (ms[(size_t)k] < cap) out[ms[(size_t)k]].outlier = ou[(size_t)k];
@@ -1800,6 +2047,12 @@ void trackmap_preload_kernels() {
     ptam_preload((const void*)tm_compact_select_kernel);
     ptam_preload((const void*)tm_search_kernel);
     ptam_preload((const void*)tm_gather_kernel);
+    ptam_preload((const void*)tm_pose_kernel<1, GS_WAVE_LIMIT>);
+    ptam_preload((const void*)tm_pose_kernel<1, GS_THREADS>);
+    ptam_preload((const void*)tm_pose_kernel<GS_MPT, GS_THREADS>);
+    ptam_preload((const void*)tm_pose_batch_kernel<1, GS_WAVE_LIMIT>);
+    ptam_preload((const void*)tm_pose_batch_kernel<1, GS_THREADS>);
+    ptam_preload((const void*)tm_pose_batch_kernel<GS_MPT, GS_THREADS>);
     ptam_preload((const void*)tm_pyr_pvs_batch_kernel<PTAM_HALFSAMPLE_R>);
     ptam_preload((const void*)tm_pyr_pvs_batch_kernel<PTAM_HALFSAMPLE_T>);
     ptam_preload((const void*)tm_compact_select_batch_kernel);
