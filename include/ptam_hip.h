@@ -536,6 +536,11 @@ int ptam_ba_get_all(const ptam_ba* ba, double* poses12, double* points3);
 int ptam_ba_get_outliers(const ptam_ba* ba, int32_t* point_cam_pairs, int cap);
 int ptam_ba_get_trials(const ptam_ba* ba, ptam_ba_trial* out, int cap);   /* returns count */
 int ptam_ba_counts(const ptam_ba* ba, int* n_cams, int* n_free_cams, int* n_points, int* n_meas);
+/* Trials of this bundle that were run again with the launch-per-block-column form of the camera solve because the persistent
+ * form (one launch whose workgroups hand tiles to each other through flags) gave up a wait — it needs all of its workgroups
+ * resident, which a device shared with another process' solve may not grant.  The repeated trial's result is what the reference
+ * computes; the rest of the adjustment keeps the slower form.  0 in normal operation (returned as the function's value). */
+int ptam_ba_solve_fallbacks(const ptam_ba* ba);
 
 /* profiling hooks used by bench.py: HIP-event timing of individual kernels on the ctx stream. */
 enum {

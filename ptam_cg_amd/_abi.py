@@ -169,6 +169,7 @@ PROTOTYPES = {
     "ba_get_outliers": (_i, [_vp, _vp, _i]),
     "ba_get_trials": (_i, [_vp, _vp, _i]),
     "ba_counts": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "ba_solve_fallbacks": (_i, [_vp]),
     "ba_set_profiling": (_i, [_vp, _i]),
     "ba_kernel_time": (_i, [_vp, _i, _pd, C.POINTER(_i)]),
     "ba_prepare": (_i, [_vp]),

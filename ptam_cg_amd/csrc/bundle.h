@@ -138,6 +138,10 @@ struct BaDev {
     unsigned* sflags2;      //   and its flag words
     unsigned* sflags;       // flag words of the persistent factorisation (ldlt_chain.inc); [0]: a spin gave up
     unsigned solve_seq;     // its sequence number: a flag is up when it holds the current solve's number (the host increments it)
+    int chain_off;          // host: use the launch-per-block-column forms only (a persistent solve of this bundle timed out, or another
+                            // bundle of this process is adjusting on the same device: the persistent form needs its workgroups co-resident)
+    int chain_xcd;          // the XCD (blockIdx % 8) the persistent solve's working blocks sit on; a second chain takes the next one
+    int spin_limit;         // looks a waiting workgroup of the persistent solve takes before it gives up (ldlt_chain.inc)
     double* bw_scratch;     // [2][6 npad] the backward substitution's vectors when they do not fit LDS (solve.hip)
     double* sumsq2;         // [2] |da|^2 in two parts (the two workgroups of the backward substitution; consumers add them)
     // outliers
@@ -168,6 +172,7 @@ __host__ __device__ __forceinline__ double* se_E(const BaDev& d) { return d.SE +
 
 // solve.hip
 int ba_solve(ptam_ctx* ctx, BaDev& d, int cur);   // also writes the trial poses pose[cur^1] and |da|^2
+#define CH_SPIN_DEFAULT (1 << 18)   // BaDev::spin_limit unless PTAM_CH_SPIN_LIMIT says otherwise (ldlt_chain.inc)
 size_t ba_solve_flag_bytes(int nblk);   // bytes of BaDev::sflags for a system of nblk blocks
 int ba_solve_init();   // raises the dynamic-LDS limits of the solve kernels (once per process/device)
 

@@ -52,6 +52,7 @@ struct ptam_ba {
     // results
     bool converged = false;
     int accepted = 0;
+    int solve_fallbacks = 0;   // trials repeated with the launch-per-block-column solve after the persistent one timed out
     std::vector<ptam_ba_trial> trials;
     std::vector<std::pair<int, int>> outliers;   // (point, camera)
     std::vector<int> raw_out, raw_out_ends;      // measurement indices as purged + segment ends (per LM step), not yet digested
@@ -512,7 +513,12 @@ static int ba_prepare_impl(ptam_ba* ba) {
                 ba->k7_threads = 256;
             }
         }
-        if (ba->det && !ba->k7_big && ba->k7_threads == 512) ba->k7_threads = ba->k7_loop ? 256 : 1024;   // (the deterministic instantiations)
+        // (the deterministic instantiations are the one-chunk-per-wave form at 1024 threads and the looping form at 256; where the
+        //  former does not fit the CU's LDS — the reason a narrower workgroup was picked above — the looping form runs)
+        if (ba->det && !ba->k7_big && ba->k7_threads != (ba->k7_loop ? 256 : 1024)) {
+            ba->k7_loop = true;
+            ba->k7_threads = 256;
+        }
     }
     if (int rc = k7_occupancy(ba->k7_threads, &per_cu)) {
         ptam_set_error("the accumulation kernel cannot be launched with %zu bytes of LDS (%d free cameras)", k7_smem(ba->k7_threads), F);
@@ -535,7 +541,8 @@ static int ba_prepare_impl(ptam_ba* ba) {
     if (ba->use_wave && ba->k7_loop && !ba->k7_big) {
         if (const char* e = getenv("PTAM_K7_THREADS")) {
             const int t = atoi(e);
-            if (t == 256 || t == 512 || t == 1024) {
+            // (A/B override; never 512 in deterministic mode, which has no such instantiation, and never a width whose LDS does not fit)
+            if ((t == 256 || t == 512 || t == 1024) && !(ba->det && t != 256) && k7_smem(t) <= 160 * 1024) {
                 ba->k7_threads = t;
                 if (int rc = k7_occupancy(t, &per_cu)) return rc;
                 per_cu = std::max(1, std::min(per_cu, 8));
@@ -546,7 +553,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     if (ba->use_wave && !ba->k7_loop) {
         if (const char* e = getenv("PTAM_K7_THREADS1")) {   // (A/B of the one-chunk-per-wave shape: 512 / 1024-thread workgroups)
             const int t = atoi(e);
-            if (t == 512 || t == 1024) {
+            if ((t == 512 || t == 1024) && !(ba->det && t != 1024) && k7_smem(t) <= 160 * 1024) {
                 ba->k7_threads = t;
                 if (int rc = k7_occupancy(t, &per_cu)) return rc;
             }
@@ -669,6 +676,18 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.Dg2 = (double*)(base + o_Dg2);
     d.y2 = (double*)(base + o_y2);
     d.solve_seq = 0;
+    d.chain_off = 0;
+    {
+        // every bundle of the process takes the next XCD for its persistent solves: two bundles adjusting side by side (two
+        // contexts / threads) do not compete for the same 32 CUs
+        static std::atomic<unsigned> next_xcd{0};
+        d.chain_xcd = (int)(next_xcd.fetch_add(1) & 7u);
+        static const int lim = [] {
+            const char* e = getenv("PTAM_CH_SPIN_LIMIT");
+            return e ? std::max(1, atoi(e)) : CH_SPIN_DEFAULT;
+        }();
+        d.spin_limit = lim;
+    }
     d.outliers = (int*)(base + o_out);
     d.sc = (BaScalars*)(base + o_sc);
     d.dbg = (long long*)(base + o_dbg);
@@ -1033,7 +1052,7 @@ static int ba_trial(ptam_ba* ba, double lambda, bool skip_vinv, int last_allowed
     HIP_TRY(hipGetLastError());
     if (ba->comm && ba->world > 1) {
         hipLaunchKernelGGL(pack2_kernel, dim3(1), dim3(1), 0, ctx->stream, (const BaScalars*)d.sc, ba->d_xchg, 1, abort_local);
-        int rc = ba_allreduce(ba, ba->d_xchg, 3);
+        int rc = ba_allreduce(ba, ba->d_xchg, 4);
         if (rc) return rc;
         hipLaunchKernelGGL(unpack2_kernel, dim3(1), dim3(1), 0, ctx->stream, d.sc, (const double*)ba->d_xchg, 1);
     }
@@ -1324,6 +1343,28 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     BA_DBG("compute: prepared M=%d P=%d F=%d chunks=%d wchunks=%d grid_acc=%d schur_wg=%d", ba->d.M, ba->d.P, ba->d.F, ba->d.n_chunks,
            ba->d.n_wchunks, ba->d.grid_acc, ba->d.n_schur_wg);
     BaDev& d = ba->d;
+    // The persistent camera solve spins on flags between workgroups that must all be resident.  One bundle's launch is a dozen
+    // workgroups on an idle XCD; two bundles of this process adjusting on one device at the same moment could each be granted
+    // part of theirs.  So only the first one in uses that form; a second one takes the launch-per-block-column form for this call.
+    struct ChainTurn {
+        static std::atomic<int>& busy(int dev) {
+            static std::atomic<int> b[64];
+            return b[dev & 63];
+        }
+        BaDev& d;
+        int dev, was;
+        bool forced;
+        ChainTurn(BaDev& d_, int dev_) : d(d_), dev(dev_), was(d_.chain_off), forced(false) {
+            if (busy(dev).fetch_add(1) > 0 && !d.chain_off) {
+                d.chain_off = 1;
+                forced = true;
+            }
+        }
+        ~ChainTurn() {
+            busy(dev).fetch_sub(1);
+            if (forced && d.chain_off == 1) d.chain_off = was;   // (a fault during the call sets 2: that one stays)
+        }
+    } chain_turn(d, ctx->device);
     double lambda = 0.0001, lambda_factor = 2.0;   // :125-126
     ba->converged = false;
     ba->published_by_finalize = false;
@@ -1477,10 +1518,21 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
                 }
             }
             if (sc.solve_fault) {
-                // (a workgroup of the persistent factorisation waited ~2 s for another one and gave up — it cannot happen
-                //  while all of them are resident, which a launch of a dozen workgroups on an otherwise idle XCD is)
-                ptam_set_error("bundle adjustment: the persistent camera solve timed out (set PTAM_LDLT_NO_CHAIN=1 to use the launch-per-block form)");
-                return PTAM_E_HIP;
+                // A workgroup of the persistent factorisation gave up waiting for another one (ldlt_chain.inc): it cannot happen
+                // while all of them are resident — a launch of a dozen workgroups on an otherwise idle XCD — but a device shared
+                // with another process' persistent solve can leave each with half of its workgroups.  Nothing was committed (the
+                // trial's finalize kernel saw the fault and armed none of the guarded kernels; a sharded bundle has summed the
+                // fault over the ranks, so every rank is here): the rest of this adjustment uses the launch-per-block-column form,
+                // which waits for nobody, and the trial is run again.
+                if (d.chain_off) {   // (that form raises no fault: something else is wrong)
+                    ptam_set_error("bundle adjustment: the camera solve reports a fault in its launch-per-block form");
+                    return PTAM_E_HIP;
+                }
+                d.chain_off = 2;
+                ba->solve_fallbacks++;
+                HIP_TRY(hipMemsetAsync(&d.sc->solve_fault, 0, sizeof(int), ctx->stream));
+                if (getenv("PTAM_DEBUG_SOLVE")) std::fprintf(stderr, "[ptam] rank %d: persistent camera solve timed out at trial %d; repeating it with the launch-per-column form\n", ba->rank, counter);
+                continue;
             }
             ran_any = true;
             if (sharded) abort_all = abort_all || sc.abort_any != 0;
@@ -1657,6 +1709,10 @@ int ptam_ba_get_trials(const ptam_ba* ba, ptam_ba_trial* out, int cap) {
     const int n = (int)ba->trials.size();
     for (int i = 0; i < n && i < cap && out; i++) out[i] = ba->trials[i];
     return n;
+}
+int ptam_ba_solve_fallbacks(const ptam_ba* ba) {
+    ARG_TRY(ba);
+    return ba->solve_fallbacks;
 }
 int ptam_ba_counts(const ptam_ba* ba, int* n_cams, int* n_free, int* n_points, int* n_meas) {
     ARG_TRY(ba);

@@ -166,7 +166,12 @@ __global__ void __launch_bounds__(1024) ldlt_backward_kernel(BaDev d, int cur, i
     const int tid = threadIdx.x;
     const int c = tid % NB, rr = tid / NB;
     // (the persistent factorisation's error word: a spin gave up during THIS solve — the host stops the adjustment)
-    if (tid == 0 && chain == 0 && d.sflags && d.sflags[0] != 0) d.sc->solve_fault = 1;   // (sticky: any launch of any solve of this bundle; a solve may be three launches with three sequence numbers)
+    // (the persistent factorisation's error word: a wait gave up during one of THIS solve's launches — up to three, with three
+    //  sequence numbers.  The word is taken down again: the host repeats the trial with the launch-per-block-column form)
+    if (tid == 0 && chain == 0 && d.sflags && d.sflags[0] != 0) {
+        d.sc->solve_fault = 1;
+        d.sflags[0] = 0;
+    }
     for (int i = tid; i < npad; i += 1024) {
         pend[i] = pend[npad + i] = pend[2 * npad + i] = pend[3 * npad + i] = 0.0;
         wv[i] = d.y[i] / d.Dg[i];
@@ -341,7 +346,7 @@ int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
         // 202 / 287 at 28 of band 9.  (Where two chains apply they win: 137 against 152 at 23 rows of band 2.)
         static const bool no_chain = getenv("PTAM_LDLT_NO_CHAIN") != nullptr;   // (A/B runs)
         const size_t lds = ch_lds_bytes(band);
-        if (t_end == 0 && !no_chain && d.sflags && nblk <= CH_MAX_NB && lds <= CH_LDS_MAX) {
+        if (t_end == 0 && !no_chain && !d.chain_off && d.sflags && nblk <= CH_MAX_NB && lds <= CH_LDS_MAX) {
             d.solve_seq++;
             if (d.solve_seq >= (1u << 27)) d.solve_seq = 1;   // (flags carry it shifted by up to 4 bits; flags of 2^27 solves ago are no concern)
             {
@@ -359,7 +364,7 @@ int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
     // end") — where each chain's block rows fit one XCD; as one launch per step of both chains otherwise.
     static const bool no_chain2 = getenv("PTAM_LDLT_NO_CHAIN") != nullptr || getenv("PTAM_LDLT_TWIN_LAUNCHES") != nullptr;   // (A/B runs)
     const int kr2 = std::min(b_start, t_end + band);   // (each chain's rows: its columns and the `band` block rows they reach)
-    const bool two_persistent = t_end >= 2 && !no_chain2 && d.sflags && d.SE2 && kr2 <= CH_MAX_NB && ch_lds_bytes(band) <= CH_LDS_MAX;
+    const bool two_persistent = t_end >= 2 && !no_chain2 && !d.chain_off && d.sflags && d.SE2 && kr2 <= CH_MAX_NB && ch_lds_bytes(band) <= CH_LDS_MAX;
     if (two_persistent) {
         d.solve_seq++;
         if (d.solve_seq >= (1u << 27)) d.solve_seq = 1;
@@ -380,7 +385,7 @@ int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
         static const bool no_chain = getenv("PTAM_LDLT_NO_CHAIN") != nullptr;
         const int n_mid = b_start - t_end;
         const size_t lds = ch_lds_bytes(band);
-        if (t_end > 0 && !no_chain && d.sflags && n_mid >= 3 && n_mid <= CH_MAX_NB && lds <= CH_LDS_MAX) {
+        if (t_end > 0 && !no_chain && !d.chain_off && d.sflags && n_mid >= 3 && n_mid <= CH_MAX_NB && lds <= CH_LDS_MAX) {
             d.solve_seq++;
             if (d.solve_seq >= (1u << 27)) d.solve_seq = 1;
             {

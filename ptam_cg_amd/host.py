@@ -672,6 +672,10 @@ class Bundle:
             out[name] = (ms.value, n.value)
         return out
 
+    def solve_fallbacks(self):
+        """trials repeated with the launch-per-column camera solve after the persistent one gave up a wait (0 normally)"""
+        return int(self.lib.ba_solve_fallbacks(self.h)) if self.lib.has("ba_solve_fallbacks") else 0
+
     def prepare(self):
         self.ctx._check(self.lib.ba_prepare(self.h), "ba_prepare")
 

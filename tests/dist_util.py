@@ -21,7 +21,7 @@ def free_port():
     return p
 
 
-def run_sharded(which, world, case, timeout=300, extra_env=None, opts=None, drop=None, abort=None, dup=None):
+def run_sharded(which, world, case, timeout=300, extra_env=None, opts=None, drop=None, abort=None, dup=None, rank_env=None):
     """launch `world` worker processes (gloo on 127.0.0.1); returns rank 0's result dict"""
     out = tempfile.mktemp(suffix=".pkl")
     port = str(free_port())
@@ -38,6 +38,7 @@ def run_sharded(which, world, case, timeout=300, extra_env=None, opts=None, drop
         if dup is not None:
             env["PTAM_DIST_DUP"] = repr(dup)
         env.update(extra_env or {})
+        env.update((rank_env or {}).get(r, {}))   # (environment of ONE rank: a fault injected there only)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), which, out],
                                       env=env, cwd=ROOT))
     try:

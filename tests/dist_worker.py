@@ -73,6 +73,8 @@ def main():
     poses, pts = ba.get_all()
     n_trials_all = [None] * world
     dist.all_gather_object(n_trials_all, (len(ba.trials()), acc))
+    fallbacks_all = [None] * world
+    dist.all_gather_object(fallbacks_all, ba.solve_fallbacks())
 
     def all_gather(obj):
         out = [None] * world
@@ -85,7 +87,7 @@ def main():
     if rank == 0:
         with open(out_path, "wb") as f:
             pickle.dump(dict(accepted=acc, converged=ba.Converged(), trials=ba.trials(), poses=poses, points=full_pts,
-                             outliers=outl, poses_all=all_poses, trials_accepted_all=n_trials_all), f)
+                             outliers=outl, poses_all=all_poses, trials_accepted_all=n_trials_all, solve_fallbacks_all=fallbacks_all), f)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -120,3 +120,13 @@ def test_bench_n2_path_prints_one_json_line():
     assert one["workload"] == "bundle_24kf_x_900pts_window8" and one["value"] > 0
     assert abs(rec["speedup_vs_single_gpu"] - rec["value"] / one["value"]) < 1e-12
     assert set(rec["kernel_ms_per_trial"]) >= {"jacobian", "schur", "solve"}
+
+
+def test_solve_fault_on_one_rank_is_repeated_by_every_rank(oracle):
+    """a rank whose persistent camera solve gives up a wait (spin limit of one look on rank 1 only) must not
+    leave the others in the next all-reduce.  The fault rides in the trial's scalar exchange; every rank repeats the trial with
+    the launch-per-block-column form and the adjustment ends as the single-process oracle's does."""
+    case = dict(n_cams=64, n_pts=900, seed=43)
+    res = dist_util.run_sharded("hip", 3, case, opts=dict(max_iterations=6), rank_env={1: {"PTAM_CH_SPIN_LIMIT": "1"}})
+    dist_util.check_sharded_equals_single(res, oracle, case, rel=1e-6, max_iterations=6)
+    assert res["solve_fallbacks_all"] == [1, 1, 1]

@@ -27,7 +27,7 @@ def run_ba(lib, prob, **opts):
     acc = ba.Compute()
     poses, pts = ba.get_all()
     res = {"accepted": acc, "converged": ba.Converged(), "trials": ba.trials(), "poses": poses,
-           "points": pts, "outliers": ba.GetOutlierMeasurements()}
+           "points": pts, "outliers": ba.GetOutlierMeasurements(), "solve_fallbacks": ba.solve_fallbacks()}
     ba.close()
     ctx.close()
     return res
@@ -50,3 +50,26 @@ def assert_ba_equal(a, b, rel=1e-6, abs_state=1e-7):
     assert np.array_equal(a["outliers"], b["outliers"])
     assert np.allclose(a["poses"], b["poses"], rtol=0, atol=abs_state, equal_nan=True)
     assert np.allclose(a["points"], b["points"], rtol=0, atol=abs_state, equal_nan=True)
+
+
+def run_ba_subprocess(case, env=None, opts=None, timeout=600):
+    """the product library on synth.make_ba_problem(**case) in a process of its own (environment switches of the library are read
+    once per process) -> the result dict of run_ba"""
+    import os
+    import pickle
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tempfile.mktemp(suffix=".pkl")
+    code = ("import sys, pickle; sys.path.insert(0, %r)\n"
+            "from ptam_cg_amd import synth\nfrom ptam_cg_amd._lib import load\nfrom tests import util\n"
+            "res = util.run_ba(load(), synth.make_ba_problem(**%r), **%r)\n"
+            "pickle.dump(res, open(%r, 'wb'))\n") % (root, case, opts or {}, out)
+    e = dict(os.environ)
+    e.update(env or {})
+    subprocess.run([sys.executable, "-c", code], env=e, cwd=root, check=True, timeout=timeout)
+    with open(out, "rb") as f:
+        res = pickle.load(f)
+    os.unlink(out)
+    return res

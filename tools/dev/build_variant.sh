@@ -11,7 +11,7 @@ O=$R/tools/_exp/$NAME
 mkdir -p $O
 make -s -C $C -j8
 OBJS=""
-for f in ctx keyframe patch pose pvs trackmap bundle solve comm; do
+for f in ctx keyframe patch pose pvs trackmap motion bundle solve comm; do
   if echo " $FILES " | grep -q " $f.hip "; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wno-unused-function -Wno-unused-value -Wno-unused-result $FLAGS -c $C/$f.hip -o $O/$f.o
     OBJS="$OBJS $O/$f.o"
