@@ -407,6 +407,13 @@ int ptam_tracker_destroy(ptam_tracker* t);
 /* the map: world position + pixel vectors per point, and its patch source (src_kf, src_level, center_x / center_y of
  * ptam_template_query; the other fields are ignored).  The source keyframes must stay alive while the tracker uses them. */
 int ptam_tracker_set_map(ptam_tracker* t, int n, const ptam_pvs_point* points, const ptam_template_query* sources);
+/* The map after the mapmaker changed it (points added at a new keyframe, bad points removed, positions refined by a bundle
+ * adjustment): like ptam_tracker_set_map, but a point that was in the previous map keeps its TrackerData — prev_index[i] is the
+ * index new point i had in the map of the last set_map / update_map call, -1 for a new point.  Its PatchFinder's template, warp
+ * matrix and mbTemplateBad carry over as they do in the reference, where TrackerData lives as long as its MapPoint
+ * (include/Tracker.h:42-67, src/Tracker.cc:453-464); new points start with a fresh finder.  No old index may appear twice. */
+int ptam_tracker_update_map(ptam_tracker* t, int n, const ptam_pvs_point* points, const ptam_template_query* sources,
+                            const int32_t* prev_index);
 /* The frame's random orders, each a permutation of 0..n-1 (asynchronous upload): level l's PVS list is taken in the order
  * its members appear in shuffle_levels (replaces std::random_shuffle of avPVS[l], :483-484), the chop of the fine set to
  * MaxPatchesPerFrame in the order of shuffle_fine (:597-600).  Identity until set. */

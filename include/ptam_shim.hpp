@@ -372,6 +372,13 @@ public:
     void SetMap(const std::vector<ptam_pvs_point>& vMapPoints, const std::vector<ptam_template_query>& vSources) {
         check(ptam_tracker_set_map(h_, (int)vMapPoints.size(), vMapPoints.data(), vSources.data()), "ptam_tracker_set_map");
     }
+    // The map after the mapmaker changed it: vPrevIndex[i] = index of point i in the map handed over last time, -1 for a new
+    // point.  Persisting points keep their TrackerData (PatchFinder template, warp, mbTemplateBad) as in the reference.
+    void UpdateMap(const std::vector<ptam_pvs_point>& vMapPoints, const std::vector<ptam_template_query>& vSources,
+                   const std::vector<int32_t>& vPrevIndex) {
+        if (vSources.size() != vMapPoints.size() || vPrevIndex.size() != vMapPoints.size()) throw std::runtime_error("UpdateMap: sizes differ");
+        check(ptam_tracker_update_map(h_, (int)vMapPoints.size(), vMapPoints.data(), vSources.data(), vPrevIndex.data()), "ptam_tracker_update_map");
+    }
     void SetShuffle(const std::vector<int32_t>& vLevels, const std::vector<int32_t>& vFine) {
         check(ptam_tracker_set_shuffle(h_, vLevels.data(), vFine.data()), "ptam_tracker_set_shuffle");
     }

@@ -2044,6 +2044,26 @@ int ptamo_tracker_set_map(ptamo_tracker* t, int n, const ptam_pvs_point* pts, co
     t->n = n;
     return PTAM_OK;
 }
+// the same with the TrackerData of the points that persist (include/Tracker.h:42-67: TrackerData — and its PatchFinder — is a
+// member of the MapPoint's tracking data and lives as long as the point; the map's vector changing around it does not touch it)
+int ptamo_tracker_update_map(ptamo_tracker* t, int n, const ptam_pvs_point* pts, const ptam_template_query* src, const int32_t* prev) {
+    if (!t || n < 0 || n > t->cap || (n > 0 && (!pts || !src || !prev))) return PTAM_E_ARG;
+    std::vector<ptamo_tracker::Finder> old = t->finder;
+    const int n_old = t->n;
+    std::vector<char> seen((size_t)std::max(n_old, 1), 0);
+    for (int i = 0; i < n; i++) {   // (an old point is one new point at most)
+        if (prev[i] < -1 || prev[i] >= n_old) return PTAM_E_ARG;
+        if (prev[i] >= 0) {
+            if (seen[(size_t)prev[i]]) return PTAM_E_ARG;
+            seen[(size_t)prev[i]] = 1;
+        }
+    }
+    const int rc = ptamo_tracker_set_map(t, n, pts, src);
+    if (rc) return rc;
+    for (int i = 0; i < n; i++)
+        if (prev[i] >= 0) t->finder[(size_t)i] = old[(size_t)prev[i]];
+    return PTAM_OK;
+}
 int ptamo_tracker_set_shuffle(ptamo_tracker* t, const int32_t* a, const int32_t* b) {
     if (!t || !a || !b) return PTAM_E_ARG;
     t->sh_levels.assign(a, a + t->n);

@@ -184,6 +184,7 @@ PROTOTYPES = {
     "tracker_create": (_i, [_vp, _i, _ppv]),
     "tracker_destroy": (_i, [_vp]),
     "tracker_set_map": (_i, [_vp, _i, _vp, _vp]),
+    "tracker_update_map": (_i, [_vp, _i, _vp, _vp, _vp]),
     "tracker_set_shuffle": (_i, [_vp, _vp, _vp]),
     "track_map": (_i, [_vp, _vp, _pd, _vp, _vp]),
     "track_map_frame": (_i, [_vp, _vp, _vp, _pd, _vp, _vp]),

@@ -1261,10 +1261,33 @@ int ptam_tracker_destroy(ptam_tracker* t) {
     return PTAM_OK;
 }
 
-int ptam_tracker_set_map(ptam_tracker* t, int n, const ptam_pvs_point* pts, const ptam_template_query* src) {
+// new[i] = the finder of the point that was at prev[i] in the old map (a fresh one for prev[i] < 0 and past the new map's end)
+__global__ void __launch_bounds__(256) tm_finder_carry_kernel(TmFinder* __restrict__ fresh, const TmFinder* __restrict__ old, const int* __restrict__ prev,
+                                                              int n, int cap) {
+    // (a finder is 112 bytes = 28 words: thread = (point, word))
+    constexpr int W = (int)(sizeof(TmFinder) / 4);
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= (long long)cap * W) return;
+    const int i = (int)(g / W), w = (int)(g % W);
+    const int src = i < n ? prev[i] : -1;
+    ((unsigned*)fresh)[g] = src >= 0 ? ((const unsigned*)old)[(long long)src * W + w] : 0u;
+}
+static_assert(sizeof(TmFinder) % 4 == 0, "TmFinder is copied word by word");
+
+static int tracker_set_map_impl(ptam_tracker* t, int n, const ptam_pvs_point* pts, const ptam_template_query* src, const int32_t* prev_index) {
     ARG_TRY(t && n >= 0 && n <= t->d.cap && (n == 0 || (pts && src)));
     ptam_ctx* ctx = t->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
+    if (prev_index) {   // every old point carries its finder to at most one new point
+        std::vector<uint8_t> seen((size_t)std::max(t->d.n, 1), 0);
+        for (int i = 0; i < n; i++) {
+            ARG_TRY(prev_index[i] >= -1 && prev_index[i] < t->d.n);
+            if (prev_index[i] >= 0) {
+                ARG_TRY(!seen[(size_t)prev_index[i]]);
+                seen[(size_t)prev_index[i]] = 1;
+            }
+        }
+    }
     std::vector<TmSrc> s((size_t)n);
     for (int i = 0; i < n; i++) {
         const ptam_template_query& q = src[i];
@@ -1280,8 +1303,26 @@ int ptam_tracker_set_map(ptam_tracker* t, int n, const ptam_pvs_point* pts, cons
         HIP_TRY(hipMemcpy(t->d.pts, pts, (size_t)n * sizeof(ptam_pvs_point), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(t->d.src, s.data(), (size_t)n * sizeof(TmSrc), hipMemcpyHostToDevice));
     }
-    // a new map: new TrackerData, new PatchFinders (include/Tracker.h:42-67) — no template has been made, none is bad
-    HIP_TRY(hipMemset(t->d.finder, 0, (size_t)t->d.cap * sizeof(TmFinder)));
+    if (prev_index && n > 0) {
+        // the map changed, its points did not: a point that was in the old map keeps its TrackerData — the PatchFinder with its
+        // template, warp matrix and mbTemplateBad (include/Tracker.h:42-67 lives as long as the MapPoint)
+        const size_t bf = (size_t)t->d.cap * sizeof(TmFinder);
+        const size_t bfa = (bf + 255) & ~(size_t)255;
+        void* s_;
+        const int rc = ctx_scratch(ctx, bfa + (size_t)n * 4 + 256, &s_);   // (the queue is idle: the scratch is nobody's)
+        if (rc) return rc;
+        int* d_prev = (int*)((char*)s_ + bfa);
+        HIP_TRY(hipMemcpy(s_, t->d.finder, bf, hipMemcpyDeviceToDevice));
+        HIP_TRY(hipMemcpy(d_prev, prev_index, (size_t)n * 4, hipMemcpyHostToDevice));
+        const long long words = (long long)t->d.cap * (long long)(sizeof(TmFinder) / 4);
+        hipLaunchKernelGGL(tm_finder_carry_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, t->d.finder, (const TmFinder*)s_,
+                           (const int*)d_prev, n, t->d.cap);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(ptam_stream_wait(ctx->stream));
+    } else {
+        // a new map: new TrackerData, new PatchFinders (include/Tracker.h:42-67) — no template has been made, none is bad
+        HIP_TRY(hipMemset(t->d.finder, 0, (size_t)t->d.cap * sizeof(TmFinder)));
+    }
     if (n != t->d.n) {   // the shuffles are permutations of 0..n-1: back to the identity until the caller sets them again
         std::vector<int> idp((size_t)std::max(n, 1));
         for (int i = 0; i < n; i++) idp[(size_t)i] = i;
@@ -1294,6 +1335,14 @@ int ptam_tracker_set_map(ptam_tracker* t, int n, const ptam_pvs_point* pts, cons
     }
     t->d.n = n;
     return PTAM_OK;
+}
+
+int ptam_tracker_set_map(ptam_tracker* t, int n, const ptam_pvs_point* pts, const ptam_template_query* src) {
+    return tracker_set_map_impl(t, n, pts, src, nullptr);
+}
+int ptam_tracker_update_map(ptam_tracker* t, int n, const ptam_pvs_point* pts, const ptam_template_query* src, const int32_t* prev_index) {
+    ARG_TRY(prev_index || n == 0);
+    return tracker_set_map_impl(t, n, pts, src, prev_index);
 }
 
 int ptam_tracker_set_shuffle(ptam_tracker* t, const int32_t* shuffle_levels, const int32_t* shuffle_fine) {
@@ -2047,6 +2096,7 @@ void trackmap_preload_kernels() {
     ptam_preload((const void*)tm_compact_select_kernel);
     ptam_preload((const void*)tm_search_kernel);
     ptam_preload((const void*)tm_gather_kernel);
+    ptam_preload((const void*)tm_finder_carry_kernel);
     ptam_preload((const void*)tm_pose_kernel<1, GS_WAVE_LIMIT>);
     ptam_preload((const void*)tm_pose_kernel<1, GS_THREADS>);
     ptam_preload((const void*)tm_pose_kernel<GS_MPT, GS_THREADS>);

@@ -411,7 +411,9 @@ class Tracker:
         ctx._check(self.lib.tracker_create(ctx.h, int(max_points), C.byref(self.h)), "tracker_create")
         self._keep = []
 
-    def set_map(self, world, pixel_right_w, pixel_down_w, src_kfs, src_levels, centers):
+    def set_map(self, world, pixel_right_w, pixel_down_w, src_kfs, src_levels, centers, prev_index=None):
+        """prev_index (update_map): for every point its index in the previous map, -1 for a new one — those points keep their
+        PatchFinder state (ptam_tracker_update_map)"""
         n = len(world)
         pts = np.zeros(n, dtype=PVS_POINT_DT)
         pts["world"], pts["pixel_right_w"], pts["pixel_down_w"] = world, pixel_right_w, pixel_down_w
@@ -422,8 +424,16 @@ class Tracker:
         q["src_level"] = src_levels
         c = np.asarray(centers, dtype=np.int32).reshape(n, 2)
         q["center_x"], q["center_y"] = c[:, 0], c[:, 1]
-        self.ctx._check(self.lib.tracker_set_map(self.h, n, _ptr(pts), _ptr(q)), "tracker_set_map")
+        if prev_index is None:
+            self.ctx._check(self.lib.tracker_set_map(self.h, n, _ptr(pts), _ptr(q)), "tracker_set_map")
+        else:
+            pi = np.ascontiguousarray(prev_index, dtype=np.int32)
+            assert len(pi) == n
+            self.ctx._check(self.lib.tracker_update_map(self.h, n, _ptr(pts), _ptr(q), _ptr(pi)), "tracker_update_map")
         self.n = n
+
+    def update_map(self, world, pixel_right_w, pixel_down_w, src_kfs, src_levels, centers, prev_index):
+        self.set_map(world, pixel_right_w, pixel_down_w, src_kfs, src_levels, centers, prev_index=prev_index)
 
     def set_shuffle(self, shuffle_levels, shuffle_fine):
         a = np.ascontiguousarray(shuffle_levels, dtype=np.int32)

@@ -575,3 +575,46 @@ def test_moving_camera_sequence_against_oracle_twin(hip, oracle):
         d.free()
     tr_h.close()
     tr_o.close()
+
+
+def test_update_map_keeps_the_finders_of_persisting_points(hip, oracle):
+    """ptam_tracker_set_map starts every PatchFinder afresh, but the reference's TrackerData lives as long as its
+    MapPoint while the mapmaker adds and removes other points.  ptam_tracker_update_map carries the finders of the points that
+    persist (re-ordered) and gives new points fresh ones: product against the oracle's twin, two frames before and one after
+    the change; and set_map on the same tracker still resets them all."""
+    runs = {}
+    for name, lib in (("hip", hip), ("oracle", oracle)):
+        ctx, kfa, kfb, case = _setup(lib, (300, 150, 60, 30))
+        n = len(case["world"])
+        tr = host.Tracker(ctx, n + 5)
+        tr.set_map(case["world"], case["pixel_right_w"], case["pixel_down_w"], kfa, case["src_level"], case["center"])
+        out = []
+        tr.set_shuffle(case["shuffle_levels"], case["shuffle_fine"])
+        out.append((tr.TrackMap(kfb, case["pose_in"], tr.opts()).copy(), tr.iteration_set()))
+        rng = np.random.default_rng(3)
+        perm = rng.permutation(n)
+        keep, fresh = perm[: 2 * n // 3], perm[2 * n // 3:]
+        order = np.concatenate([keep, fresh])
+        prev = np.concatenate([keep, np.full(len(fresh), -1)]).astype(np.int32)
+        c2 = {k: case[k][order] for k in ("world", "pixel_right_w", "pixel_down_w", "src_level", "center")}
+        sl, sf = rng.permutation(n).astype(np.int32), rng.permutation(n).astype(np.int32)
+        tr.update_map(c2["world"], c2["pixel_right_w"], c2["pixel_down_w"], kfa, c2["src_level"], c2["center"], prev)
+        p1 = _moved(case["pose_in"], rot_z=2e-4, dx=1e-4)
+        tr.set_shuffle(sl, sf)
+        out.append((tr.TrackMap(kfb, p1, tr.opts()).copy(), tr.iteration_set()))
+        with pytest.raises(RuntimeError):        # an old index used twice is refused, the tracker keeps its map
+            tr.update_map(c2["world"], c2["pixel_right_w"], c2["pixel_down_w"], kfa, c2["src_level"], c2["center"], np.zeros(n, np.int32))
+        tr.set_map(c2["world"], c2["pixel_right_w"], c2["pixel_down_w"], kfa, c2["src_level"], c2["center"])
+        tr.set_shuffle(sl, sf)
+        out.append((tr.TrackMap(kfb, p1, tr.opts()).copy(), tr.iteration_set()))
+        runs[name] = out
+        tr.close()
+    for k, ((rh, ih), (ro, io)) in enumerate(zip(runs["hip"], runs["oracle"])):
+        ref = {"pose": ro["pose"], "did_coarse": bool(ro["did_coarse"]), "n_pvs": list(ro["n_pvs"]), "attempted": list(ro["attempted"]),
+               "found": list(ro["found"]), "n_coarse": ro["n_coarse"], "n_top": ro["n_top"], "n_fine": ro["n_fine"], "n_meas": ro["n_meas"],
+               "depth": (ro["depth_sum"], ro["depth_sum_sq"], ro["depth_n"]), "iteration_set": io}
+        _check(rh, ih, ref, strict=False)
+        assert rh["templates_reused"] == ro["templates_reused"], k
+    searched = len(runs["hip"][1][1])
+    assert runs["hip"][0][0]["templates_reused"] == 0 and runs["hip"][2][0]["templates_reused"] == 0
+    assert 0.3 * searched < runs["hip"][1][0]["templates_reused"] < 0.9 * searched

@@ -52,3 +52,47 @@ def test_oracle_track_map_equals_composed_stages(oracle, name):
         if k == 1:
             assert r["templates_reused"] > 0
     tr.close()
+
+
+def test_oracle_update_map_keeps_the_finders_of_persisting_points(oracle):
+    """ptam(o)_tracker_update_map: the mapmaker changed the map — points dropped, points added, the rest re-ordered — and the
+    persisting points keep their TrackerData (PatchFinder template, warp, mbTemplateBad: include/Tracker.h:42-67), the new ones
+    start afresh.  The oracle's tracker against the composed reference whose finder dictionary is re-keyed the same way."""
+    ctx = host.Context(lib=oracle)
+    a, b = synth.make_frame_pair()
+    kfa = host.KeyFrame(ctx).MakeKeyFrame_Lite(a)
+    kfb = host.KeyFrame(ctx).MakeKeyFrame_Lite(b)
+    case = synth.make_trackmap_case([kfa.level(l) for l in range(4)], counts=(300, 150, 60, 30))
+    n = len(case["world"])
+    tr = host.Tracker(ctx, n)
+    tr.set_map(case["world"], case["pixel_right_w"], case["pixel_down_w"], kfa, case["src_level"], case["center"])
+    finders = {}
+    tr.set_shuffle(case["shuffle_levels"], case["shuffle_fine"])
+    r0 = tr.TrackMap(kfb, case["pose_in"], tr.opts())
+    trackmap_ref.track_map(ctx, kfb, kfa, case, case["pose_in"], case["shuffle_levels"], case["shuffle_fine"], finders=finders)
+    assert r0["templates_reused"] == 0
+    # the new map: two thirds of the old points in another order, then the dropped third again as NEW points
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(n)
+    keep, fresh = perm[: 2 * n // 3], perm[2 * n // 3:]
+    order = np.concatenate([keep, fresh])
+    prev = np.concatenate([keep, np.full(len(fresh), -1)]).astype(np.int32)
+    case2 = dict(case)
+    for k in ("world", "pixel_right_w", "pixel_down_w", "src_level", "center"):
+        case2[k] = case[k][order]
+    case2["shuffle_levels"] = rng.permutation(n).astype(np.int32)
+    case2["shuffle_fine"] = rng.permutation(n).astype(np.int32)
+    tr.update_map(case2["world"], case2["pixel_right_w"], case2["pixel_down_w"], kfa, case2["src_level"], case2["center"], prev)
+    finders2 = {i: finders[int(p)] for i, p in enumerate(prev) if p >= 0 and int(p) in finders}
+    p1 = np.array(case["pose_in"], dtype=np.float64)
+    p1[9] += 1e-4
+    tr.set_shuffle(case2["shuffle_levels"], case2["shuffle_fine"])
+    r = tr.TrackMap(kfb, p1, tr.opts())
+    it = tr.iteration_set()
+    ref = trackmap_ref.track_map(ctx, kfb, kfa, case2, p1, case2["shuffle_levels"], case2["shuffle_fine"], finders=finders2)
+    assert np.array_equal(r["pose"], ref["pose"]) and r["templates_reused"] == ref["templates_reused"]
+    for f in ("point", "level", "found", "did_subpix", "outlier", "v2_found"):
+        assert np.array_equal(it[f], ref["iteration_set"][f]), f
+    searched = int(r["n_coarse"] + r["n_top"] + r["n_fine"])
+    assert 0.3 * searched < r["templates_reused"] < 0.9 * searched        # the persisting points keep theirs, the new ones warp
+    tr.close()
