@@ -219,8 +219,12 @@ def tracking_kernel_record():
     frame is their sum plus one host round trip."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "tracking_kernels.json")
     try:
+        from ptam_cg_amd._srchash import source_sha16
         with open(path) as f:
             rec = json.load(f)
+        if rec.get("source_sha16") != source_sha16():
+            return {"file": "profiles/tracking_kernels.json", "stale": True,
+                    "note": "taken from another build of the library (source_sha16 differs): not quoted; moving_camera.stage_us_profiled is measured in this run"}
     except (OSError, ValueError):
         return None
     px = 640 * 480
@@ -388,8 +392,11 @@ def pmc_traffic(workload):
     number is only reported for the workload it was measured on; anything else gets null."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "k7_pmc_traffic.json")
     try:
+        from ptam_cg_amd._srchash import source_sha16
         with open(path) as f:
             rec = json.load(f)
+        if rec.get("source_sha16") != source_sha16():   # (counters of another build of the library: not this run's)
+            return None
         return float(rec[workload]["traffic_bytes_per_launch"]) if workload in rec else None
     except (OSError, ValueError, KeyError):
         return None
@@ -427,6 +434,7 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     from ptam_cg_amd import _abi, host, synth
+    from ptam_cg_amd._srchash import source_sha16
     from ptam_cg_amd.sharding import shard_problem
     from ptam_cg_amd._lib import load
     hip = load()
@@ -589,6 +597,7 @@ def main():
             "spinup_k7_us_first_last_blocks": [spin[0] * 1e3, spin[-1] * 1e3, len(spin)],
             "err_first_last": [float(trials["err_old"][0]), float(trials["err_new"][-1])],
             "deterministic": bool(args.deterministic),
+            "source_sha16": source_sha16(),   # fingerprint of the library sources this run was built from (profiles/ are keyed by it)
             "prepare_ms": prepare_headline_ms,   # sort + work lists + upload of one Bundle of this workload: outside the timed region
         }
     if world > 1:
@@ -662,6 +671,29 @@ def main():
                                              f"on the same copy (Infinity Cache 256 MB + L2 32 MB)"})
         out["kernel_ms_per_trial"] = kernel_breakdown(prob, args.steps)
         out["schur_roofline"] = schur_roofline(prob, out["kernel_ms_per_trial"])
+        # ---- a cold call: the mapmaker thread calls Compute() from idle — no spin-up, no warm-up trials, 50 ms of nothing queued
+        cb = new_bundle(args.steps)
+        ctx.sync()
+        time.sleep(0.05)
+        t0 = time.perf_counter()
+        cb.Compute()
+        ctx.sync()
+        dtc = time.perf_counter() - t0
+        out["cold_call"] = {"value": args.steps / dtc, "unit": "LM iterations/s", "ms_per_step": 1e3 * dtc / args.steps, "idle_ms_before": 50,
+                            "trial_mix": trial_mix(cb.trials()),
+                            "note": "one Compute() of the same workload entered 50 ms after the device went idle, without the K7 spin-up and "
+                                    "the warm-up trials that precede `value`"}
+        cb.close()
+        # ---- the deterministic mode's figure beside the default one (fixed-order camera sums: bit-identical runs, one trajectory)
+        if not args.deterministic:
+            args.deterministic = True
+            try:
+                dtd, trd, _, _ = timed_compute(prob, args.steps, args.warmup)
+                out["deterministic_mode"] = {"value": args.steps / dtd, "unit": "LM iterations/s", "ms_per_step": 1e3 * dtd / args.steps,
+                                             "trial_mix": trial_mix(trd),
+                                             "note": "ptam_ba_opts.deterministic = 1: the accept / reject / stay mix of this problem is the same in every run"}
+            finally:
+                args.deterministic = False
         # ---- BASELINE configs[4] on ONE device: the N = 1 point of the strong-scaling curve that `--gpus N` measures ----
         if not is_global and not args.no_global:
             big = synth.make_ba_problem(GLOBAL_BA["cams"], GLOBAL_BA["points"], synth.SEED_BA_GLOBAL, window=GLOBAL_BA["window"])

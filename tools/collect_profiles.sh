@@ -41,18 +41,28 @@ for key, dd in (("bundle_50kf_x_5000pts_dense", "$R/gpurun_out/pmc_${TAG}_headli
         rec[key] = json.load(open(dd + "/traffic.json"))
     except OSError:
         pass
+import sys
+sys.path.insert(0, "$R")
+from ptam_cg_amd._srchash import source_sha16
+rec["source_sha16"] = source_sha16()
 json.dump(rec, open("$OUT/k7_pmc_traffic.json", "w"), indent=1)
 PY
-# the tracked frame, kernel by kernel: rocprofv3 stats of tools/dev/trackmap_only.py (one ptam_track_map_frame per frame),
-# per-frame launch counts and average durations -> tracking_kernels.json (bench.py embeds the committed copy in `tracking`)
+# the tracked frame, kernel by kernel: rocprofv3 stats of tools/dev/track_seq.py (the moving-camera sequence bench.py tracks: one
+# ptam_track_frame per frame), per-frame launch counts and average durations -> tracking_kernels.json (bench.py embeds the committed
+# copy in `tracking` when its source fingerprint is the running library's)
 cd /tmp
-FR=300
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ttrace -o tm -- python $R/tools/dev/trackmap_only.py $FR frame > $OUT/tracking_trace.log 2>&1
+PASSES=4
+FR=$((64 * (2 + 3 * PASSES) / 2))
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ttrace -o tm -- python $R/tools/dev/track_seq.py $PASSES > $OUT/tracking_trace.log 2>&1
 cp $OUT/ttrace/tm_kernel_stats.csv $OUT/tracking_kernel_stats.csv 2>/dev/null
 python3 - <<PY
 import csv, json
 frames = 2 * $FR   # (trackmap_only.py runs the loop twice)
-rec = {"source": "rocprofv3 --kernel-trace --stats -- python tools/dev/trackmap_only.py $FR frame", "frames": frames, "kernels": {}}
+import sys
+sys.path.insert(0, "$R")
+from ptam_cg_amd._srchash import source_sha16
+rec = {"source": "rocprofv3 --kernel-trace --stats -- python tools/dev/track_seq.py $PASSES (the moving-camera sequence)", "frames": frames,
+       "source_sha16": source_sha16(), "kernels": {}}
 tot = 0.0
 try:
     for r in csv.DictReader(open("$OUT/tracking_kernel_stats.csv")):
