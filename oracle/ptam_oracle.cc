@@ -1557,6 +1557,7 @@ int ptamo_epipolar_search_batch(ptamo_ctx* c, const ptamo_kf* src, ptamo_kf* tgt
     for (int i = 0; i < n; i++) epipolar_search(src->kf.lev[level], tgt->kf.lev[level], ip, q[i], res[i]);
     return PTAM_OK;
 }
+#ifndef PTAMO_REFEREE   // (takes ABI arrays of doubles: not part of the extended-precision build, oracle/referee.cc)
 int ptamo_make_templates_batch(ptamo_ctx*, int n, const ptam_template_query* q, uint8_t* tmpl, ptam_template_result* res) {
     for (int i = 0; i < n; i++) {
         ptam_template_result& r = res[i];
@@ -1573,6 +1574,7 @@ int ptamo_make_templates_batch(ptamo_ctx*, int n, const ptam_template_query* q, 
     }
     return PTAM_OK;
 }
+#endif
 int ptamo_zmssd_at_points(ptamo_ctx*, const ptamo_kf* k, int level, int n, const ptam_int2* pts,
                           const uint8_t* tmpl, int32_t* out) {
     int s, ss;
@@ -1581,6 +1583,7 @@ int ptamo_zmssd_at_points(ptamo_ctx*, const ptamo_kf* k, int level, int n, const
     return PTAM_OK;
 }
 
+#ifndef PTAMO_REFEREE   // (takes ABI arrays of doubles: not part of the extended-precision build, oracle/referee.cc)
 int ptamo_project_points(ptamo_ctx* c, int n, const double* world, const double pose[12], ptam_projection* out) {
     ATANCamera cam(c->c.cam);
     const SE3 T = se3_from12(pose);
@@ -1599,6 +1602,7 @@ int ptamo_project_points(ptamo_ctx* c, int n, const double* world, const double 
     }
     return PTAM_OK;
 }
+#endif
 
 int ptamo_subpix_batch(ptamo_ctx*, const ptamo_kf* k, int n, const ptam_subpix_query* q, const uint8_t* tmpl,
                        ptam_subpix_result* res) {
@@ -1608,6 +1612,7 @@ int ptamo_subpix_batch(ptamo_ctx*, const ptamo_kf* k, int n, const ptam_subpix_q
 
 // Tracker::TrackMap PVS loop src/Tracker.cc:453-478 + PatchFinder::CalcSearchLevelAndWarpMatrix
 // src/PatchFinder.cc:52-84
+#ifndef PTAMO_REFEREE   // (takes ABI arrays of doubles: not part of the extended-precision build, oracle/referee.cc)
 int ptamo_track_pvs(ptamo_ctx* c, int n, const ptam_pvs_point* pts, const double pose[12], ptam_pvs_result* out,
                     int32_t counts[4]) {
     ATANCamera cam(c->c.cam);
@@ -1663,11 +1668,13 @@ int ptamo_track_pvs(ptamo_ctx* c, int n, const ptam_pvs_point* pts, const double
     }
     return PTAM_OK;
 }
+#endif
 
 // MapMaker::ReFind_Common src/MapMaker.cc:943-1020 for a batch of map points against ONE keyframe (what
 // ReFindInSingleKeyFrame :1027-1042 loops over).  Per point, statement by statement; the set bookkeeping (sMeasurementKFs,
 // sNeverRetryKFs) is the caller's: `never_retry` says the point went into sNeverRetryKFs.  The static PatchFinder of the
 // reference keeps its last template between calls (:100-111); a batch never repeats a point, so every template is made anew.
+#ifndef PTAMO_REFEREE   // (takes ABI arrays of doubles: not part of the extended-precision build, oracle/referee.cc)
 int ptamo_refind_batch(ptamo_ctx* c, const ptamo_kf* k, const double kf_pose[12], int n, const ptam_pvs_point* pts,
                        const ptam_template_query* src, ptam_refind_result* out) {
     ATANCamera cam(c->c.cam);
@@ -1751,6 +1758,7 @@ int ptamo_refind_batch(ptamo_ctx* c, const ptamo_kf* k, const double kf_pose[12]
     }
     return PTAM_OK;
 }
+#endif
 
 // The same through the reference's ONE finder (`static PatchFinder Finder`, src/MapMaker.cc:977), pair after pair in the
 // caller's order — ReFindNewlyMade :1046-1066, ReFindFromFailureQueue :1070-1082: the finder's state that outlives a call.
@@ -1770,6 +1778,7 @@ int ptamo_refinder_destroy(ptamo_refinder* f) {
     delete f;
     return PTAM_OK;
 }
+#ifndef PTAMO_REFEREE   // (takes ABI arrays of doubles: not part of the extended-precision build, oracle/referee.cc)
 int ptamo_refind_pairs(ptamo_ctx* c, ptamo_refinder* F, int n, const ptam_refind_pair* pairs, ptam_refind_result* out, int32_t* kept) {
     if (!c || !F || n < 0 || (n > 0 && (!pairs || !out))) return PTAM_E_ARG;
     ATANCamera cam(c->c.cam);
@@ -1874,6 +1883,7 @@ int ptamo_refind_pairs(ptamo_ctx* c, ptamo_refinder* F, int n, const ptam_refind
     }
     return PTAM_OK;
 }
+#endif
 
 void ptamo_gn_opts_default(ptam_gn_opts* o) {
     o->iterations = 10;
@@ -2146,6 +2156,7 @@ static int tm_search_for_points(ptamo_tracker* t, const ptamo_kf* kf, std::vecto
     }
     return n_found;
 }
+#ifndef PTAMO_REFEREE   // (takes ABI arrays of doubles: not part of the extended-precision build, oracle/referee.cc)
 int ptamo_track_map(ptamo_tracker* t, const ptamo_kf* kf, const double pose_in[12], const ptam_trackmap_opts* opts, ptam_trackmap_result* out) {
     if (!t || !kf || !pose_in || !out) return PTAM_E_ARG;
     ptam_trackmap_opts o;
@@ -2329,13 +2340,16 @@ int ptamo_track_map(ptamo_tracker* t, const ptamo_kf* kf, const double pose_in[1
     out->depth_sum_sq = dsq;
     return PTAM_OK;
 }
+#endif
 // (the product's frame pointer is a device address; here it is the host image, stride == width)
+#ifndef PTAMO_REFEREE   // (takes ABI arrays of doubles: not part of the extended-precision build, oracle/referee.cc)
 int ptamo_track_map_frame(ptamo_tracker* t, ptamo_kf* cur, const uint8_t* frame, const double pose_in[12], const ptam_trackmap_opts* opts,
                           ptam_trackmap_result* out) {
     if (!t || !cur || !frame) return PTAM_E_ARG;
     const int rc = ptamo_make_keyframe_lite(t->ctx, cur, frame, cur->w);
     return rc ? rc : ptamo_track_map(t, cur, pose_in, opts, out);
 }
+#endif
 // ---- the motion model and the tracking branch of Tracker::TrackFrame (src/Tracker.cc:134-137), rotation estimator off ----
 void ptamo_motion_reset(ptam_motion_model* m, const double pose[12]) {
     std::memset(m, 0, sizeof *m);
@@ -2346,13 +2360,16 @@ void ptamo_motion_reset(ptam_motion_model* m, const double pose[12]) {
     m->use_constant_velocity = 1;                    // gvnConstVel :1041
 }
 // Tracker::PredictPoseWithMotionModel :1013-1030
+#ifndef PTAMO_REFEREE   // (takes ABI arrays of doubles: not part of the extended-precision build, oracle/referee.cc)
 void ptamo_motion_predict(ptam_motion_model* m) {
     std::memcpy(m->start_pose, m->pose, 96);         // mse3StartPos = mse3CamFromWorld
     double v6Velocity[6];
     std::memcpy(v6Velocity, m->velocity, 48);
     se3_to12(se3_mul(se3_exp(v6Velocity), se3_from12(m->start_pose)), m->pose);   // :1029
 }
+#endif
 // the scene-depth update that closes TrackMap (:678-697), then Tracker::UpdateMotionModel :1036-1056
+#ifndef PTAMO_REFEREE   // (takes ABI arrays of doubles: not part of the extended-precision build, oracle/referee.cc)
 void ptamo_motion_update(ptam_motion_model* m, const ptam_trackmap_result* r) {
     std::memcpy(m->pose, r->pose, 96);
     if (r->depth_n > 20) {
@@ -2376,7 +2393,9 @@ void ptamo_motion_update(ptam_motion_model* m, const ptam_trackmap_result* r) {
     for (int i = 0; i < 6; i++) ss += v6[i] * v6[i];
     m->msd_scaled_velocity = std::sqrt(ss);
 }
+#endif
 void ptamo_se3_ln(const double pose[12], double out6[6]) { se3_ln(se3_from12(pose), out6); }
+#ifndef PTAMO_REFEREE   // (takes ABI arrays of doubles: not part of the extended-precision build, oracle/referee.cc)
 int ptamo_track_frame(ptamo_tracker* t, ptamo_kf* cur, const uint8_t* frame, ptam_motion_model* m, const ptam_trackmap_opts* opts,
                       ptam_trackmap_result* out) {
     if (!t || !cur || !frame || !m || !out) return PTAM_E_ARG;
@@ -2401,6 +2420,7 @@ int ptamo_track_frame(ptamo_tracker* t, ptamo_kf* cur, const uint8_t* frame, pta
     ptamo_motion_update(m, out);
     return PTAM_OK;
 }
+#endif
 int ptamo_tracker_read_iteration_set(ptamo_tracker* t, ptam_trackmap_meas* out, int cap, int* n) {
     if (!t || !n) return PTAM_E_ARG;
     *n = (int)t->iteration_set.size();
@@ -2505,7 +2525,7 @@ int ptamo_ba_counts(const ptamo_ba* b, int* nc, int* nf, int* np, int* nm) {
 }
 int ptamo_ba_get_point(const ptamo_ba* b, int n, double pos[3]) {
     if (n < 0 || n >= (int)b->b.mvPoints.size()) return PTAM_E_ARG;
-    std::memcpy(pos, b->b.mvPoints[n].v3Pos, 24);
+    std::memcpy(pos, b->b.mvPoints[n].v3Pos, 3 * sizeof(double));
     return PTAM_OK;
 }
 int ptamo_ba_get_camera(const ptamo_ba* b, int n, double pose[12]) {
@@ -2515,7 +2535,7 @@ int ptamo_ba_get_camera(const ptamo_ba* b, int n, double pose[12]) {
 }
 int ptamo_ba_get_all(const ptamo_ba* b, double* poses, double* points) {
     for (size_t i = 0; i < b->b.mvCameras.size(); i++) se3_to12(b->b.mvCameras[i].se3CfW, poses + 12 * i);
-    for (size_t i = 0; i < b->b.mvPoints.size(); i++) std::memcpy(points + 3 * i, b->b.mvPoints[i].v3Pos, 24);
+    for (size_t i = 0; i < b->b.mvPoints.size(); i++) std::memcpy(points + 3 * i, b->b.mvPoints[i].v3Pos, 3 * sizeof(double));
     return PTAM_OK;
 }
 int ptamo_ba_get_outliers(const ptamo_ba* b, int32_t* pairs, int cap) {
@@ -2531,6 +2551,7 @@ int ptamo_ba_get_trials(const ptamo_ba* b, ptam_ba_trial* out, int cap) {
     for (int i = 0; i < n && i < cap; i++) out[i] = b->b.trials[i];
     return n;
 }
+#ifndef PTAMO_REFEREE   // (takes ABI arrays of doubles: not part of the extended-precision build, oracle/referee.cc)
 int ptamo_ba_set_comm(ptamo_ba* b, int rank, int world, ptam_allreduce_f64_fn fn, void* user) {
     b->b.rank = rank;
     b->b.world = world;
@@ -2538,5 +2559,6 @@ int ptamo_ba_set_comm(ptamo_ba* b, int rank, int world, ptam_allreduce_f64_fn fn
     b->b.comm_user = user;
     return PTAM_OK;
 }
+#endif
 
 }   // extern "C"

@@ -350,3 +350,16 @@ def test_atan_reduction_constants():
     got = hi - (t * (s1 + s2) - t)
     ref = np.arctan(x)
     assert np.max(np.abs(got - ref) / ref) < 4 * 2.0 ** -52
+
+
+def test_extended_precision_referee_agrees_with_the_oracle_on_a_well_posed_bundle(oracle):
+    """oracle/referee.cc — the oracle's Bundle with every double an x87 long double — is the same algorithm: on a well-conditioned
+    problem the two take the same trajectory and differ by rounding only (and they DO differ: the referee is not the double code)"""
+    from tests import referee_lib, util
+    prob = synth.make_ba_problem(12, 200, 5)
+    r, o = referee_lib.run_ba(prob), util.run_ba(oracle, prob)
+    assert len(r["trials"]) == len(o["trials"]) and r["accepted"] == o["accepted"] and r["converged"] == o["converged"]
+    assert np.array_equal(r["trials"]["accepted"], o["trials"]["accepted"]) and np.array_equal(r["trials"]["n_bad"], o["trials"]["n_bad"])
+    rel = np.abs(r["trials"]["err_new"] / o["trials"]["err_new"] - 1).max()
+    assert 0 < rel < 1e-9
+    assert np.abs(r["poses"] - o["poses"]).max() < 1e-10 and np.array_equal(np.asarray(r["outliers"]).ravel(), np.asarray(o["outliers"]).ravel())
