@@ -85,6 +85,11 @@ struct GnSmallShared {
     int scan[WAVES];
     unsigned long long cand[64];
     int n_cand;
+    // round 4, the two-barrier select (small_select_fast): a histogram pair used alternately — lane L's 32 bins at word j * 64 + L —
+    // and a candidate list pair
+    unsigned hist2[2][GS_BINS];
+    unsigned long long cand2[2][64];
+    int n_cand2[2];
     double tr[27][TR_PITCH];   // transposed per-thread partials of the 27 sums (row = sum, column = thread)
 };
 
@@ -99,14 +104,6 @@ __device__ __forceinline__ double wave_sum_f64_dpp(double v) {
     return v;
 }
 
-#ifdef K7_TIMING
-static __device__ long long g_sel_ph[4];   // select sub-phases (timing build): histogram | scan | candidates + rank | -
-#define SEL_PH(i) { if (threadIdx.x == 0) { const long long n_ = (long long)__builtin_readcyclecounter(); g_sel_ph[i] += n_ - spt_; spt_ = n_; } }
-#define SEL_PH0 long long spt_ = (long long)__builtin_readcyclecounter();
-#else
-#define SEL_PH(i)
-#define SEL_PH0
-#endif
 // exact k-th smallest of sh.keys[0..n) (non-found entries hold +inf), bit patterns compared as unsigned
 // 64-bit integers.
 //  - fast path: ONE histogram over the leading bits (sign, exponent, GS_KEY_MBITS mantissa bits) relative to the window's
@@ -185,9 +182,134 @@ __device__ void small_select_scan(GnSmallShared<THREADS, MPT>& sh, int k, bool c
     }
     __syncthreads();
 }
-// MPT == 1 and n <= 128 (the coarse set): no histogram — every key is ranked against the others by broadcast reads
+
+#ifdef K7_TIMING
+static __device__ long long g_sel_ph[4];   // select sub-phases (timing build): histogram | scan | candidates + rank | -
+#define SEL_PH(i) { if (threadIdx.x == 0) { const long long n_ = (long long)__builtin_readcyclecounter(); g_sel_ph[i] += n_ - spt_; spt_ = n_; } }
+#define SEL_PH0 long long spt_ = (long long)__builtin_readcyclecounter();
+#else
+#define SEL_PH(i)
+#define SEL_PH0
+#endif
+// ---- round 4: the order statistic on the pose loops' critical path (it was a quarter of both loops) ------------------------
+// wave maximum of a non-negative int, in every lane
+__device__ __forceinline__ int wave_max_nonneg_i32(int v) {
+    v = max(v, dpp_row_shr0_i32<1>(v));
+    v = max(v, dpp_row_shr0_i32<2>(v));
+    v = max(v, dpp_row_shr0_i32<4>(v));
+    v = max(v, dpp_row_shr0_i32<8>(v));
+    v = max(v, dpp_bcast_i32<0x142, 0xA>(0, v));
+    v = max(v, dpp_bcast_i32<0x143, 0xC>(0, v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// The k-th smallest of the keys the first `cnt` lanes of a wave hold (one each, cnt <= 64, k < number of finite keys), by
+// ranking in registers: every lane counts the keys below its own — key j travels through two v_readlane, no LDS, no barrier —
+// and the answer is the key of greatest rank <= k (equal keys share a rank: exactly the value sorted[k] has).
+template <int CNT_MAX>
+__device__ __forceinline__ unsigned long long wave_rank_select(unsigned long long me, int cnt, int k) {
+    const unsigned lo = (unsigned)me, hi = (unsigned)(me >> 32);
+    int rank = 0;
+    if (CNT_MAX == 64) {
+#pragma unroll
+        for (int j = 0; j < 64; j++) {
+            const unsigned long long o = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, j) << 32) | (unsigned)__builtin_amdgcn_readlane((int)lo, j);
+            rank += o < me ? 1 : 0;
+        }
+    } else {
+        for (int j = 0; j < cnt; j++) {   // (cnt is wave-uniform)
+            const unsigned long long o = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, j) << 32) | (unsigned)__builtin_amdgcn_readlane((int)lo, j);
+            rank += o < me ? 1 : 0;
+        }
+    }
+    const bool in = (int)(threadIdx.x & 63) < cnt && rank <= k;
+    const int m = wave_max_nonneg_i32(in ? rank + 1 : 0) - 1;
+    const unsigned long long pick = __builtin_amdgcn_ballot_w64(in && rank == m);
+    const int src = __builtin_ctzll(pick);
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, src) << 32) | (unsigned)__builtin_amdgcn_readlane((int)lo, src);
+}
+// bin b of the transposed histogram: lane L = b / 32 owns bins 32 L .. 32 L + 31, its j-th at word j * 64 + L (conflict-free for
+// the lane-parallel scan below)
+__device__ __forceinline__ int hist2_word(int b) { return (b & 31) * 64 + (b >> 5); }
+// Two-barrier exact select for the 256-thread loops (THREADS * MPT keys in registers): LDS-atomic histogram | barrier | EVERY wave
+// scans the histogram for itself (lane = 32 bins; the crossing lane's bins by a second 32-lane scan) — no meeting, no second
+// barrier for the scan | the few keys of the selected bin are appended to a list | barrier | every wave ranks them in registers.
+// `par` alternates between calls: a call clears the buffer of the call before.  Returns false (nothing consumed but the buffers,
+// which it leaves clean) when the selected bin is a clamped end bin or holds more than 64 keys: the caller takes the general path.
+// the histogram half of small_select_fast, for a caller that has a barrier of its own coming (the pose loop's error phase)
 template <int MPT, int THREADS>
-__device__ double small_select_kth(GnSmallShared<THREADS, MPT>& sh, int n, int k) {
+__device__ __forceinline__ void small_select_fast_hist(GnSmallShared<THREADS, MPT>& sh, const unsigned long long key[MPT], int n, int par) {
+    const int tid = threadIdx.x;
+    unsigned* h = sh.hist2[par];
+#pragma unroll
+    for (int q = 0; q < MPT; q++)
+        if (tid + q * THREADS < n) atomicAdd(&h[hist2_word(small_key_bin(key[q]))], 1u);
+    // (the other buffer: dirty from the call before, whose readers are long past their last barrier)
+    for (int b = tid; b < GS_BINS; b += THREADS) sh.hist2[par ^ 1][b] = 0;
+    if (tid == 0) sh.n_cand2[par] = 0;
+}
+template <int MPT, int THREADS, bool HIST_DONE = false>
+__device__ __forceinline__ bool small_select_fast(GnSmallShared<THREADS, MPT>& sh, const unsigned long long key[MPT], int n, int k, int par, double* out) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    unsigned* h = sh.hist2[par];
+    SEL_PH0
+    int bin[MPT];
+#pragma unroll
+    for (int q = 0; q < MPT; q++) bin[q] = small_key_bin(key[q]);
+    if (!HIST_DONE) {
+        small_select_fast_hist<MPT, THREADS>(sh, key, n, par);
+        __syncthreads();
+    }
+    SEL_PH(0)
+    unsigned c[32];
+    int ssum = 0;
+    {   // (four partial sums: a chain of 32 dependent adds is 300 cycles of a phase every wave waits for)
+        int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+        for (int j = 0; j < 32; j += 4) {
+            c[j] = h[j * 64 + lane];
+            c[j + 1] = h[(j + 1) * 64 + lane];
+            c[j + 2] = h[(j + 2) * 64 + lane];
+            c[j + 3] = h[(j + 3) * 64 + lane];
+            s0 += (int)c[j];
+            s1 += (int)c[j + 1];
+            s2 += (int)c[j + 2];
+            s3 += (int)c[j + 3];
+        }
+        ssum = (s0 + s1) + (s2 + s3);
+    }
+    const int incl = wave_incl_scan_i32(ssum), excl = incl - ssum;
+    const unsigned long long own = __builtin_amdgcn_ballot_w64(excl <= k && k < incl);   // exactly one lane (k < total)
+    const int L = __builtin_ctzll(own);
+    const int k1 = k - __builtin_amdgcn_readlane(excl, L);
+    // the crossing lane's 32 bins, one per lane of the lower half
+    const int cj = lane < 32 ? (int)h[lane * 64 + L] : 0;
+    const int incl2 = wave_incl_scan_i32(cj), excl2 = incl2 - cj;
+    const unsigned long long own2 = __builtin_amdgcn_ballot_w64(lane < 32 && excl2 <= k1 && k1 < incl2);
+    const int J = __builtin_ctzll(own2);
+    const int sel = 32 * L + J, k2 = k1 - __builtin_amdgcn_readlane(excl2, J), cnt = __builtin_amdgcn_readlane(cj, J);
+    const bool ok = sel != 0 && sel != GS_BINS - 1 && cnt <= 64;
+    SEL_PH(1)
+    if (ok) {
+#pragma unroll
+        for (int q = 0; q < MPT; q++)
+            if (tid + q * THREADS < n && bin[q] == sel) sh.cand2[par][atomicAdd(&sh.n_cand2[par], 1)] = key[q];
+    }
+    __syncthreads();
+    SEL_PH(2)
+    if (!ok) return false;
+    const unsigned long long me = lane < cnt ? sh.cand2[par][lane] : ~0ull;
+    *out = __longlong_as_double((long long)wave_rank_select<0>(me, cnt, k2));
+    SEL_PH(3)
+    return true;
+}
+// MPT == 1 and n <= 128 (the coarse set): no histogram — every key is ranked against the others by broadcast reads
+template <int MPT, int THREADS, bool HIST_DONE = false>
+__device__ double small_select_kth(GnSmallShared<THREADS, MPT>& sh, int n, int k, int par) {
+    if (MPT == 1 && THREADS == 64) {
+        // one wave (the coarse set): every lane's key stays in its register (the slot in LDS is read back once)
+        const unsigned long long me = (unsigned long long)__double_as_longlong(sh.keys[threadIdx.x]);
+        return __longlong_as_double((long long)wave_rank_select<64>(me, 64, k));
+    }
     if (MPT == 1 && n <= 128) {
         // One key per thread slot (slots past n hold +inf).  With n <= 64 (<= 128) only the first wave (two) holds
         // keys, so the list is cut in four (two) parts and thread (part, i) ranks key i against its part; the partial
@@ -236,8 +358,14 @@ __device__ double small_select_kth(GnSmallShared<THREADS, MPT>& sh, int n, int k
     for (int q = 0; q < MPT; q++) {
         const int i = tid + q * THREADS;
         key[q] = i < n ? (unsigned long long)__double_as_longlong(sh.keys[i]) : ~0ull;
-        if (i < n) atomicAdd(&sh.hist[small_key_bin(key[q])], 1u);
     }
+    {
+        double r_;
+        if (small_select_fast<MPT, THREADS, HIST_DONE>(sh, key, n, k, par, &r_)) return r_;
+    }
+#pragma unroll
+    for (int q = 0; q < MPT; q++)
+        if (tid + q * THREADS < n) atomicAdd(&sh.hist[small_key_bin(key[q])], 1u);
     __syncthreads();
     SEL_PH(0)
     small_select_scan<MPT, THREADS>(sh, k, true);
@@ -343,6 +471,7 @@ struct PoseArrayLoader {
         (void)q;
         return (ptam_projection*)((char*)io.td_base + (size_t)(io.td_index ? io.td_index[i] : i) * io.td_stride);
     }
+    __device__ __forceinline__ void td_also(int, int, const SmallMeas&) const {}
     __device__ __forceinline__ int listed_total(int n) const { return n; }
 };
 
@@ -382,6 +511,9 @@ __device__ __forceinline__ void pose_gn_small_body(const DevCam& cam, int n, LOA
         if (threadIdx.x == 0 && io.result_seq) *(volatile unsigned long long*)io.result_seq = io.seq | POSE_CHAIN_LONG;
         return;
     }
+#ifdef K7_TIMING
+    const long long tk0_ = (long long)__builtin_readcyclecounter();
+#endif
     SmallMeas t[MPT];
 #pragma unroll
     for (int q = 0; q < MPT; q++) {
@@ -399,10 +531,17 @@ __device__ __forceinline__ void pose_gn_small_body(const DevCam& cam, int n, LOA
     if (tid < 12) sh.pose[tid] = (pin && pin->use) ? pin->v[tid] : pose_io[tid];   // (pin: a kernel argument — a local copy indexed by tid would live in scratch memory)
     if (tid < 6) sh.mu[tid] = 0;
     if (!ld.begin(sh, n, THREADS * MPT, t)) return;
-    for (int b = tid; b < GS_BINS; b += THREADS) sh.hist[b] = 0;   // small_select_kth keeps it zero between calls
+#ifdef K7_TIMING
+    const long long tkA_ = (long long)__builtin_readcyclecounter();
+#endif
+    if (THREADS > 64)   // (the one-wave kernel ranks in registers: no histogram.  Its zeroing loop was 2.4 k cycles of the coarse stage)
+        for (int b = tid; b < GS_BINS; b += THREADS) sh.hist[b] = sh.hist2[0][b] = sh.hist2[1][b] = 0;   // the selects keep them zero between calls
 #pragma unroll
     for (int q = 0; q < MPT; q++) ld.load(q, tid + q * THREADS, n, t[q]);
     __syncthreads();
+#ifdef K7_TIMING
+    const long long tkB_ = (long long)__builtin_readcyclecounter();
+#endif
 #pragma unroll
     for (int q = 0; q < MPT; q++) {
         const int i = tid + q * THREADS;
@@ -420,11 +559,13 @@ __device__ __forceinline__ void pose_gn_small_body(const DevCam& cam, int n, LOA
         }
     }
 #ifdef K7_TIMING
+    const long long tk1_ = (long long)__builtin_readcyclecounter();
     long long ph[6] = {0, 0, 0, 0, 0, 0};
 #define PH(i) { const long long n_ = (long long)__builtin_readcyclecounter(); ph[i] += n_ - pt_; pt_ = n_; }
 #else
 #define PH(i)
 #endif
+    int sel_par = 0;
     for (int iter = 0; iter < opts.iterations; iter++) {
 #ifdef K7_TIMING
         long long pt_ = (long long)__builtin_readcyclecounter();
@@ -470,6 +611,13 @@ __device__ __forceinline__ void pose_gn_small_body(const DevCam& cam, int n, LOA
             cnt += t[q].found;
             if (!(ov > 0)) sh.keys[tid + q * THREADS] = t[q].found ? e2[q] : __longlong_as_double(0x7ff0000000000000ll);
         }
+        if (MPT > 1 && !(ov > 0)) {
+            // the select's histogram rides on this phase's barrier (one barrier and an LDS round trip of the keys less per call)
+            unsigned long long kk[MPT];
+#pragma unroll
+            for (int q = 0; q < MPT; q++) kk[q] = t[q].found ? (unsigned long long)__double_as_longlong(e2[q]) : 0x7ff0000000000000ull;
+            small_select_fast_hist<MPT, THREADS>(sh, kk, n, sel_par);
+        }
         cnt = wave_sum_i32(cnt);
         if (lane == 0) sh.wcount[wid] = cnt;
         __syncthreads();   // also: every thread is done reading sh.mu (linear update) and sh.pose
@@ -482,7 +630,8 @@ __device__ __forceinline__ void pose_gn_small_body(const DevCam& cam, int n, LOA
             if (ov > 0)
                 sigma_sq = ov;
             else {
-                const double med = small_select_kth<MPT, THREADS>(sh, n, nf / 2);
+                const double med = small_select_kth<MPT, THREADS, (MPT > 1)>(sh, n, nf / 2, sel_par);
+                sel_par ^= 1;
                 sigma_sq = est_sigma_sq_from_median(opts.estimator, med, (unsigned long long)nf);
             }
             PH(1)
@@ -582,6 +731,16 @@ __device__ __forceinline__ void pose_gn_small_body(const DevCam& cam, int n, LOA
         PH(5)
     }
 #ifdef K7_TIMING
+    if (tid == 0 && io.result_seq == nullptr && io.td_base && (clock64() & 0xf000) == 0)
+        printf("coarse pose kernel (%d threads): begin %lld | zero + barrier %lld | jacobian %lld | loop %lld (phases %lld %lld %lld %lld %lld %lld)\n", THREADS,
+               tkA_ - tk0_, tkB_ - tkA_, tk1_ - tkB_, (long long)__builtin_readcyclecounter() - tk1_, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
+    if (tid == 0 && io.result_seq && (io.seq & 127) == 0)
+        printf("fine pose kernel (%d threads x %d): begin %lld | zero + barrier %lld | jacobian %lld | loop %lld (phases %lld %lld %lld %lld %lld %lld)\n", THREADS, MPT,
+               tkA_ - tk0_, tkB_ - tkA_, tk1_ - tkB_, (long long)__builtin_readcyclecounter() - tk1_, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
+    if (tid == 0 && io.result_seq && (io.seq & 127) == 0) {
+        printf("   fine select sub-phases: histogram + barrier %lld | scans %lld | append + barrier %lld | rank %lld\n", g_sel_ph[0], g_sel_ph[1], g_sel_ph[2], g_sel_ph[3]);
+    }
+    if (tid == 0 && io.result_seq) g_sel_ph[0] = g_sel_ph[1] = g_sel_ph[2] = g_sel_ph[3] = 0;
     if (tid == 0 && updates)
         for (int i = 0; i < 6; i++) updates[6 * 20 + i] = (double)ph[i];
     if (tid == 0 && updates)
@@ -604,6 +763,7 @@ __device__ __forceinline__ void pose_gn_small_body(const DevCam& cam, int n, LOA
                 o->image[1] = t[q].img[1];
 #pragma unroll
                 for (int k = 0; k < 4; k++) o->derivs[k] = t[q].D[k];
+                ld.td_also(q, i, t[q]);
             }
         }
     }

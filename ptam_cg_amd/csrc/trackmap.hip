@@ -62,6 +62,12 @@ struct TmFinder {
     uint8_t tpl[64];        // mimTemplate
 };
 
+// What a search slot hands to the pose loop, written by the search wave when it is done with the slot, FIELD-MAJOR (plane f holds
+// field f of every slot): the pose kernel's prologue needs a single round trip — status, point id, position and TrackerData state
+// used to be four arrays, two of them behind the point id — and its loads are coalesced (slot-major 120-byte records cost a wave 60
+// load instructions of 64 cache lines each: 8.7 k cycles of the fine loop's prologue).
+//   planes 0-2 v3WorldPos | 3-4 v2Found | 5-7 v3Cam | 8-9 v2Image | 10-13 m2CamDerivs  (doubles);  tag: {status word, map point}
+#define TM_REC_F 14
 struct TmDev {
     int n, cap;
     ptam_pvs_point* pts;
@@ -80,6 +86,8 @@ struct TmDev {
     int* slot_stat;           // per slot: found | attempted << 1 | level << 2, written by the search kernel
     int* slot_subpix;
     double2* slot_v2;
+    double* recf;             // [TM_REC_F][cap] per slot: everything the pose loop wants of it (written by the search wave, state refreshed by the coarse pose loop)
+    int2* rect;               // [cap] {slot_stat, map point}
     ptam_pose_meas* meas;
     ptam_projection* entry;
     int* midx;                // measurement -> map point
@@ -287,21 +295,26 @@ __global__ void __launch_bounds__(1024) tm_compact_select_kernel(KfLevels L, TmD
 // control flow); lane 0 stores.  stage 0: the coarse set; stage 1: top-level and fine sets.
 __device__ __forceinline__ void tm_search_body(const DevCam& cam, const KfLevels& L, const TmDev& d, int stage, unsigned coarse_range,
                                                int coarse_its, int bx) {   // a 256-thread workgroup: four slots
+    // (the slot is the workgroup's own — the launch covers the slots from 0 — so that the point id is requested together with
+    //  the control block, not behind it: one dependent round trip less at the head of every search wave)
+    const int s = bx * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int id = d.list[min(s, d.cap - 1)];
     const TmCtl& c = *d.ctl;
     const int first = stage == 0 ? c.range_c[0] : c.range_hf[0], end = stage == 0 ? c.range_c[1] : c.range_hf[1];
-    const int s = first + bx * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (s >= end) return;
-    const int id = d.list[s];
+    if (s < first || s >= end) return;
     ptam_pvs_result& pv = d.pvs[id];
     // the point's PatchFinder state, requested with the point's TrackerData (one round trip, not one more behind the decision)
     TmFinder& fs = d.finder[id];
     const double fm0 = fs.m2[0], fm1 = fs.m2[1], fm2 = fs.m2[2], fm3 = fs.m2[3];
     const int f_valid = fs.valid, f_bad = fs.bad, f_sum = fs.sum, f_sum_sq = fs.sum_sq, f_tpl = fs.tpl[lane];
     double u = pv.proj.image[0], v = pv.proj.image[1];
+    const ptam_pvs_point& p = d.pts[id];
+    const double pw0 = p.world[0], pw1 = p.world[1], pw2 = p.world[2];
+    double pcam0 = pv.proj.cam[0], pcam1 = pv.proj.cam[1], pcam2 = pv.proj.cam[2];
+    const double pd0 = pv.proj.derivs[0], pd1 = pv.proj.derivs[1], pd2 = pv.proj.derivs[2], pd3 = pv.proj.derivs[3];
     if (stage == 1 && (s < c.range_h[1] || c.did_coarse)) {
-        const ptam_pvs_point& p = d.pts[id];
         double X, Y, Z;
-        se3_apply(d.pose, p.world[0], p.world[1], p.world[2], X, Y, Z);
+        se3_apply(d.pose, pw0, pw1, pw2, X, Y, Z);
         int in_image = 0;
         bool reached = false;
         if (!(Z < 0.001)) {
@@ -318,6 +331,7 @@ __device__ __forceinline__ void tm_search_body(const DevCam& cam, const KfLevels
             if (reached) pv.proj.image[0] = u, pv.proj.image[1] = v;
             pv.proj.in_image = in_image;
         }
+        pcam0 = X, pcam1 = Y, pcam2 = Z;   // (u, v: the new position if the projection got that far, the old one otherwise)
     }
     ptam_patch_query q;
     q.x = (int)u;   // ir(): truncation
@@ -386,6 +400,7 @@ __device__ __forceinline__ void tm_search_body(const DevCam& cam, const KfLevels
         if (lane == 0) d.sr[s] = sres;
     }
     // the slot's outcome (the tail of SearchForPoints, :880-906), for the gather pass: one packed word + the position
+    double2 v2pub = make_double2(0, 0);
     if (lane == 0) {
         const bool att = q.level >= 0 && !tr.bad;   // manMeasAttempted (:880)
         int found = att && res.found, sub = 0;
@@ -401,7 +416,19 @@ __device__ __forceinline__ void tm_search_body(const DevCam& cam, const KfLevels
         d.slot_found[s] = found;
         d.slot_subpix[s] = sub;
         d.slot_v2[s] = v2;
-        d.slot_stat[s] = found | ((int)att << 1) | ((q.level & 3) << 2) | (kept << 4);
+        v2pub = v2;
+        const int stat = found | ((int)att << 1) | ((q.level & 3) << 2) | (kept << 4);
+        d.slot_stat[s] = stat;
+        d.rect[s] = make_int2(stat, id);
+    }
+    {
+        // the slot's record: lane f stores field f (one store instruction for the fourteen planes)
+        const double2 v2r = make_double2(__shfl(v2pub.x, 0, 64), __shfl(v2pub.y, 0, 64));
+        const double fld[TM_REC_F] = {pw0, pw1, pw2, v2r.x, v2r.y, pcam0, pcam1, pcam2, u, v, pd0, pd1, pd2, pd3};
+        double mine = 0;
+#pragma unroll
+        for (int f = 0; f < TM_REC_F; f++) mine = lane == f ? fld[f] : mine;
+        if (lane < TM_REC_F) d.recf[(size_t)lane * d.cap + s] = mine;
     }
 }
 __global__ void __launch_bounds__(256) tm_search_kernel(DevCam cam, KfLevels L, TmDev d, int stage, unsigned coarse_range, int coarse_its) {
@@ -578,13 +605,22 @@ struct TmSlotLoader {
         //     wait for the control block first, and every dependent round trip of this single-workgroup kernel is ~1 us of frame
         const TmCtl c0 = *d.ctl;
         int st[MPT];
-        double2 v2[MPT];
 #pragma unroll
         for (int q = 0; q < MPT; q++) {
+            // the slot's record: ONE round trip, nothing behind the point id, every load coalesced (field-major planes)
             const int sc = min(tid + q * THREADS, d.cap - 1);
-            st[q] = d.slot_stat[sc];
-            id[q] = d.list[sc];
-            v2[q] = d.slot_v2[sc];
+            const int2 tg = d.rect[sc];
+            st[q] = tg.x;
+            id[q] = tg.y;
+            const double* rf = d.recf + sc;
+            const size_t pl = (size_t)d.cap;
+            t[q].world[0] = rf[0], t[q].world[1] = rf[pl], t[q].world[2] = rf[2 * pl];
+            t[q].fnd[0] = rf[3 * pl], t[q].fnd[1] = rf[4 * pl];
+#pragma unroll
+            for (int k = 0; k < 3; k++) t[q].cam3[k] = rf[(5 + k) * pl];
+            t[q].img[0] = rf[8 * pl], t[q].img[1] = rf[9 * pl];
+#pragma unroll
+            for (int k = 0; k < 4; k++) t[q].D[k] = rf[(10 + k) * pl];
         }
         const int g_end = stage == 0 ? c0.nC : c0.n_slots;
         const int st_first = stage == 0 ? 0 : c0.nC;
@@ -593,7 +629,6 @@ struct TmSlotLoader {
             return false;
         }
         n = g_end;
-        // (B) the loads that hang on the point id: world position and TrackerData state (v3Cam, v2Image, m2CamDerivs)
         int p_tot = 0, p_f01 = 0, p_f23 = 0, p_a01 = 0, p_a23 = 0;
 #pragma unroll
         for (int q = 0; q < MPT; q++) {
@@ -601,22 +636,18 @@ struct TmSlotLoader {
             const bool valid = s < g_end;
             st[q] = valid ? st[q] : 0;
             id[q] = valid ? id[q] : 0;
-            const ptam_pvs_point* pp = &d.pts[id[q]];
-            const ptam_projection* pj = &d.pvs[id[q]].proj;
-            t[q].world[0] = pp->world[0], t[q].world[1] = pp->world[1], t[q].world[2] = pp->world[2];
-#pragma unroll
-            for (int k = 0; k < 3; k++) t[q].cam3[k] = pj->cam[k];
-            t[q].img[0] = pj->image[0];
-            t[q].img[1] = pj->image[1];
-#pragma unroll
-            for (int k = 0; k < 4; k++) t[q].D[k] = pj->derivs[k];
-            t[q].fnd[0] = v2[q].x;
-            t[q].fnd[1] = v2[q].y;
             // per-level counts of the slots this stage decided (found | attempted << 1 | level << 2 | kept << 4), two 16-bit
             // fields to a word: a list holds at most 1024 slots
             const int w = st[q], l = (w >> 2) & 3, mine = valid && s >= st_first;
             t[q].sn = 1.0 / (double)(1 << l);   // :889
             t[q].listed = w & 1;
+            if (!(w & 1)) {   // (no measurement in this slot: benign values)
+                t[q].world[0] = t[q].world[1] = t[q].world[2] = t[q].fnd[0] = t[q].fnd[1] = t[q].sn = 0;
+                t[q].cam3[0] = t[q].cam3[1] = 0;
+                t[q].cam3[2] = 1;
+                t[q].img[0] = t[q].img[1] = 0;
+                t[q].D[0] = t[q].D[1] = t[q].D[2] = t[q].D[3] = 0;
+            }
             p_tot += (w & 1) | ((mine ? (w >> 4) & 1 : 0) << 16);
             const int f = mine ? (w & 1) : 0, a = mine ? (w >> 1) & 1 : 0;
             p_f01 += (l == 0 ? f : 0) | ((l == 1 ? f : 0) << 16);
@@ -699,6 +730,16 @@ struct TmSlotLoader {
     __device__ __forceinline__ void load(int, int, int, SmallMeas&) const {}   // (begin has filled the slots)
     __device__ __forceinline__ bool has_entry() const { return true; }
     __device__ __forceinline__ ptam_projection* td_target(int q, int, const PoseChainIo&) const { return &d.pvs[id[q]].proj; }
+    // the slot's record follows the TrackerData the coarse loop leaves (the fine loop starts from it)
+    __device__ __forceinline__ void td_also(int, int i, const SmallMeas& m) const {
+        double* rf = d.recf + i;
+        const size_t pl = (size_t)d.cap;
+#pragma unroll
+        for (int k = 0; k < 3; k++) rf[(5 + k) * pl] = m.cam3[k];
+        rf[8 * pl] = m.img[0], rf[9 * pl] = m.img[1];
+#pragma unroll
+        for (int k = 0; k < 4; k++) rf[(10 + k) * pl] = m.D[k];
+    }
     __device__ __forceinline__ int listed_total(int) const { return n_found; }
 };
 
@@ -1177,7 +1218,7 @@ int ptam_tracker_create(ptam_ctx* ctx, int max_points, ptam_tracker** out) {
                  o_pvs = take(cap * sizeof(ptam_pvs_result)), o_ll = take(cap * 16), o_fc = take(cap), o_list = take(cap * 4),
                  o_tr = take(cap * sizeof(ptam_template_result)),
                  o_q = take(cap * sizeof(ptam_patch_query)), o_r = take(cap * sizeof(ptam_patch_result)),
-                 o_sr = take(cap * sizeof(ptam_subpix_result)), o_sf = take(cap * 4), o_st = take(cap * 4), o_ss = take(cap * 4), o_sv = take(cap * 16),
+                 o_sr = take(cap * sizeof(ptam_subpix_result)), o_sf = take(cap * 4), o_st = take(cap * 4), o_ss = take(cap * 4), o_sv = take(cap * 16), o_rec = take(cap * TM_REC_F * 8), o_rect = take(cap * 8),
                  o_me = take(cap * sizeof(ptam_pose_meas)), o_en = take(cap * sizeof(ptam_projection)), o_mi = take(cap * 4),
                  o_ms = take(cap * 4), o_ou = take(cap * 4), o_ctl = take(sizeof(TmCtl)), o_pose = take(96),
                  o_fs = take(cap * sizeof(TmFinder));
@@ -1212,6 +1253,8 @@ int ptam_tracker_create(ptam_ctx* ctx, int max_points, ptam_tracker** out) {
     d.slot_stat = (int*)(b + o_st);
     d.slot_subpix = (int*)(b + o_ss);
     d.slot_v2 = (double2*)(b + o_sv);
+    d.recf = (double*)(b + o_rec);
+    d.rect = (int2*)(b + o_rect);
     d.meas = (ptam_pose_meas*)(b + o_me);
     d.entry = (ptam_projection*)(b + o_en);
     d.midx = (int*)(b + o_mi);
