@@ -303,23 +303,23 @@ static int ba_prepare_impl(ptam_ba* ba) {
     std::vector<int> pair_wg_begin(n_pairs + 1, 0);
     {
         int NX = 8;   // point ranges (1 or 8)
-        if (const char* e = getenv("PTAM_SCHUR_NX")) NX = atoi(e) == 8 ? 8 : 1;   // A/B runs (tools/dev/schur_ab.sh)
+        if (const char* e = ptam_ab_env("PTAM_SCHUR_NX")) NX = atoi(e) == 8 ? 8 : 1;   // A/B runs (tools/dev/schur_ab.sh)
         bool sort_pattern = true;
-        if (const char* e = getenv("PTAM_SCHUR_SORT")) sort_pattern = atoi(e) != 0;   // A/B runs
+        if (const char* e = ptam_ab_env("PTAM_SCHUR_SORT")) sort_pattern = atoi(e) != 0;   // A/B runs
         auto set01 = [](const unsigned o[2]) { return (o[0] != 0xffffffffu) || ((o[1] & 0xffffu) != 0xffffu); };   // slots 0..5
         auto set2 = [](const unsigned o[2]) { return (o[1] >> 8) != 0xffffffu; };                                    // slots 5..7
         auto pattern_of = [&](const SchurEntry& e) {
             return (int)set01(e.offa) | ((int)set2(e.offa) << 1) | ((int)set01(e.offb) << 2) | ((int)set2(e.offb) << 3);
         };
         bool span = true;   // a workgroup may end one pair and begin the next
-        if (const char* e = getenv("PTAM_SCHUR_SPAN")) span = atoi(e) != 0;
+        if (const char* e = ptam_ab_env("PTAM_SCHUR_SPAN")) span = atoi(e) != 0;
         const int SLOTS = 256 * SCHUR_WG_PER_CU / NX, MIN_SEG = 16;
         // 16x16 fragments per tile (row mappings of ba_schur.inc: 1-2 cameras in a tile = 1 fragment, 3-5 = 2, 6-8 = 3)
         auto frags = [&](int t) { const int n = std::min(SCHUR_TC, F - t * SCHUR_TC); return n <= 2 ? 1 : (n <= 5 ? 2 : 3); };
         // cost of an entry = fragments multiplied + 8: the loads of an iteration (the same for every entry) weigh about as much
         // as eight fragments' MFMAs (A/B of 0 = entries only / fragments + 3 / + 8 / max(5, fragments): 75 / 72 / 69 / 75 us at 50 x 5000)
         int cost_model = 8;
-        if (const char* e = getenv("PTAM_SCHUR_COST")) cost_model = atoi(e);   // A/B runs
+        if (const char* e = ptam_ab_env("PTAM_SCHUR_COST")) cost_model = atoi(e);   // A/B runs
         // cost of one entry: the 16x16 fragments its pattern multiplies (+ cost_model for its loads)
         std::vector<int> pair_a(n_pairs), pair_b(n_pairs);
         for (int a = 0, pr = 0; a < n_tiles; a++)
@@ -476,7 +476,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     //    which amortises the LDS prologue and the camera-partial flush.
     const int n64_all = (M + 63) / 64;
     ba->k7_loop = ba->use_wave && n64_all > 256 * 24;
-    if (const char* e = getenv("PTAM_K7_LOOP")) ba->k7_loop = ba->use_wave && atoi(e) != 0;   // shape sweeps (tools/k7_only.py)
+    if (const char* e = ptam_ab_env("PTAM_K7_LOOP")) ba->k7_loop = ba->use_wave && atoi(e) != 0;   // shape sweeps (tools/k7_only.py)
     ba->k7_threads = ba->k7_loop ? 256 : 1024;   // (one chunk per wave: 1024-thread workgroups halve the
                                                                                  //  camera-partial flush — 12.0 vs 12.3 us at 50 x 5000)
     int n_cu = 256;
@@ -539,7 +539,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     }
     per_cu = std::max(1, std::min(per_cu, 8));
     if (ba->use_wave && ba->k7_loop && !ba->k7_big) {
-        if (const char* e = getenv("PTAM_K7_THREADS")) {
+        if (const char* e = ptam_ab_env("PTAM_K7_THREADS")) {
             const int t = atoi(e);
             // (A/B override; never 512 in deterministic mode, which has no such instantiation, and never a width whose LDS does not fit)
             if ((t == 256 || t == 512 || t == 1024) && !(ba->det && t != 256) && k7_smem(t) <= 160 * 1024) {
@@ -548,10 +548,10 @@ static int ba_prepare_impl(ptam_ba* ba) {
                 per_cu = std::max(1, std::min(per_cu, 8));
             }
         }
-        if (const char* e = getenv("PTAM_K7_WG_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));
+        if (const char* e = ptam_ab_env("PTAM_K7_WG_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));
     }
     if (ba->use_wave && !ba->k7_loop) {
-        if (const char* e = getenv("PTAM_K7_THREADS1")) {   // (A/B of the one-chunk-per-wave shape: 512 / 1024-thread workgroups)
+        if (const char* e = ptam_ab_env("PTAM_K7_THREADS1")) {   // (A/B of the one-chunk-per-wave shape: 512 / 1024-thread workgroups)
             const int t = atoi(e);
             if ((t == 512 || t == 1024) && !(ba->det && t != 1024) && k7_smem(t) <= 160 * 1024) {
                 ba->k7_threads = t;
@@ -831,7 +831,7 @@ static int ba_allreduce(ptam_ba* ba, double* dptr, size_t count) {
 // pass 1 + sigma^2
 static int ba_sel_blocks() {   // workgroup cap of select_compact_kernel (each scans the first-level histogram for itself)
     static const int n = [] {
-        const char* e = getenv("PTAM_SEL_BLOCKS");
+        const char* e = ptam_ab_env("PTAM_SEL_BLOCKS");
         return e ? std::max(1, atoi(e)) : 256;
     }();
     return n;
@@ -859,7 +859,7 @@ static int ba_pass1_sigma(ptam_ba* ba) {
                            ctx->stream, d, (const double*)d.m_e2, (long long)d.M, (const uint8_t*)d.m_state);
     } else if (!ba->slow_select) {
         if (!ba->d_sel) {   // sized by the world the communicator was set for (ptam_ba_set_comm drops it on a change)
-            if (const char* e = getenv("PTAM_XCAND_CAP")) ba->xcand_cap = std::max(1, std::min(atoi(e), 1 << 20));
+            if (const char* e = ptam_ab_env("PTAM_XCAND_CAP")) ba->xcand_cap = std::max(1, std::min(atoi(e), 1 << 20));
             HIP_TRY(hipMalloc((void**)&ba->d_sel, (HIST_BINS + (size_t)ba->world * (1 + 2 * (size_t)ba->xcand_cap)) * sizeof(double)));
         }
         double* hx = ba->d_sel;                  // histogram exchange
@@ -1065,7 +1065,7 @@ static int ba_trial(ptam_ba* ba, double lambda, bool skip_vinv, int last_allowed
 // is still waiting for them.
 static int ba_p1_blocks() {   // workgroup cap of the pass-1 kernels (each flushes its LDS histogram with global atomics)
     static const int n = [] {
-        const char* e = getenv("PTAM_P1_BLOCKS");
+        const char* e = ptam_ab_env("PTAM_P1_BLOCKS");
         return e ? std::max(1, atoi(e)) : 512;
     }();
     return n;
@@ -1441,7 +1441,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     }
     const bool empty = d.M == 0;
     // speculative step prologue (ba_enqueue_speculative): single device, not while per-kernel events are being taken
-    const bool spec = !sharded && !ba->prof && d.n_chunks > 0 && !getenv("PTAM_NO_SPECULATION");
+    const bool spec = !sharded && !ba->prof && d.n_chunks > 0 && !ptam_ab_env("PTAM_NO_SPECULATION");
     bool spec_ready = false;   // pass 1 .. V*^-1 of the coming step are already running behind the device-side flag
     while (!empty && !ba->converged && !hit_max && !aborted()) {
         // ---- Do_LM_Step :209-551 ----

@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(THREADS) pose_gn_small_batch_kernel(DevCam cam
 typedef void (*pose_small_fn)(DevCam, int, const ptam_pose_meas*, const ptam_projection*, double*, ptam_gn_opts, int*, double*, ulonglong2*,
                               unsigned long long, const int*, PoseIn, PoseChainIo, int);
 static pose_small_fn pose_small_pick(int n_cap, int* threads) {
-    static const bool no_wave = getenv("PTAM_POSE_NO_WAVE") != nullptr;   // (A/B runs)
+    static const bool no_wave = ptam_ab_env("PTAM_POSE_NO_WAVE") != nullptr;   // (A/B runs)
     if (n_cap <= GS_WAVE_LIMIT && !no_wave) {
         *threads = GS_WAVE_LIMIT;
         return pose_gn_small_kernel<1, GS_WAVE_LIMIT>;

@@ -313,7 +313,7 @@ int ba_solve_init() {
 // blocks the downward chain eliminates before the middle part of a two-ended elimination (0: plain top-down elimination).
 // The two chains must never update the same tile: the middle keeps at least 2 * band blocks.
 static int ldlt_twist_len(int nblk, int band) {
-    static const bool off = getenv("PTAM_LDLT_ONE_ENDED") != nullptr;   // (A/B runs)
+    static const bool off = ptam_ab_env("PTAM_LDLT_ONE_ENDED") != nullptr;   // (A/B runs)
     if (off || band < 1 || nblk < 2 * band + 8) return 0;   // (at least four block columns per chain: below that the mirrored copy and the third launch cost what the shorter chain saves)
     return (nblk - 2 * band) / 2;
 }
@@ -326,7 +326,7 @@ static ChainArgs chain_args_natural(const BaDev& d, int k0, int k1, int kr) {
 
 int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
     const int nblk = d.npad / NB, band = se_band(d);
-    static const bool no_small = getenv("PTAM_LDLT_NO_SMALL") != nullptr;   // (A/B runs: launch-per-block-column form only)
+    static const bool no_small = ptam_ab_env("PTAM_LDLT_NO_SMALL") != nullptr;   // (A/B runs: launch-per-block-column form only)
     // one or two block rows in one workgroup and one launch: ldlt_small.inc.  (It holds up to SM_NB = 5 block rows and was the
     // form of every system up to that size until the persistent launch's row workers learnt to keep up with the chain; now,
     // us per solve, small / persistent: 10.3 / 10.7 at 1 block row, 16.8 / 16.5 at 2, 25.7 / 23.8 at 3, 36.1 / 30.6 at 4,
@@ -362,7 +362,7 @@ int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
     // Two chains: as TWO persistent chains of one launch — the downward one on S itself (blocks 0, 8, 16 ... of the launch: XCD
     // 0), the upward one on a mirrored copy of the system's bottom end (blocks 1, 9, 17 ...: XCD 1; ldlt_chain.inc, "the bottom
     // end") — where each chain's block rows fit one XCD; as one launch per step of both chains otherwise.
-    static const bool no_chain2 = getenv("PTAM_LDLT_NO_CHAIN") != nullptr || getenv("PTAM_LDLT_TWIN_LAUNCHES") != nullptr;   // (A/B runs)
+    static const bool no_chain2 = getenv("PTAM_LDLT_NO_CHAIN") != nullptr || ptam_ab_env("PTAM_LDLT_TWIN_LAUNCHES") != nullptr;   // (A/B runs)
     const int kr2 = std::min(b_start, t_end + band);   // (each chain's rows: its columns and the `band` block rows they reach)
     const bool two_persistent = t_end >= 2 && !no_chain2 && !d.chain_off && d.sflags && d.SE2 && kr2 <= CH_MAX_NB && ch_lds_bytes(band) <= CH_LDS_MAX;
     if (two_persistent) {

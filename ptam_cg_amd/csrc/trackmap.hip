@@ -1483,7 +1483,7 @@ static int track_map_impl(ptam_tracker* t, ptam_kf* cur, const uint8_t* d_new_fr
     if (prof) hipEventRecord(t->ev[PTAM_TS_SEARCH_COARSE], st);
     hipLaunchKernelGGL(tm_search_kernel, dim3((ncc + 3) / 4), dim3(256), 0, st, ctx->cam, cur->L, d, 0, o.coarse_range, o.coarse_subpix_its);
     if (prof) hipEventRecord(t->ev[PTAM_TS_GATHER_COARSE], st);
-    static const bool no_fuse = getenv("PTAM_TM_NO_FUSE") != nullptr;   // (A/B runs: the gather pass + pose kernel of rounds 2-3)
+    static const bool no_fuse = ptam_ab_env("PTAM_TM_NO_FUSE") != nullptr;   // (A/B runs: the gather pass + pose kernel of rounds 2-3)
     double* d_upd;
     {
         void* s_;
@@ -1743,7 +1743,7 @@ int ptam_track_map_frames_batch(int nb, ptam_tracker* const* ts, ptam_kf* const*
     hipLaunchKernelGGL(tm_search_batch_kernel, dim3((ncc_max + 3) / 4, nb), dim3(256), 0, st, ctx->cam, d_it, 0, o.coarse_range, o.coarse_subpix_its);
     // (fused bookkeeping + pose loop per stage when no frame's list can outgrow the register-resident kernel: maps of at most
     //  1024 points; larger maps keep the gather pass and the small / general kernel pair)
-    static const bool no_fuse = getenv("PTAM_TM_NO_FUSE") != nullptr;
+    static const bool no_fuse = ptam_ab_env("PTAM_TM_NO_FUSE") != nullptr;
     const bool fuse = !no_fuse && n_max <= GS_LIMIT && ncc_max <= GS_LIMIT;
     {
         ptam_gn_opts g;

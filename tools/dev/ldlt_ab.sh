@@ -1,4 +1,6 @@
 python -m pytest tests/test_gpu_parity.py -x -q -k "bundle" 2>&1 | tail -2
+# (the switches below exist in the measurement build only: make -C ptam_cg_amd/csrc ab)
+export PTAM_HIP_LIB=${PTAM_HIP_LIB:-${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}/tools/_ab/libptam_hip.so}
 python -m pytest tests/test_gpu_dist.py -x -q -k "config5" 2>&1 | tail -1
 for m in 1 0; do
   if [ $m = 1 ]; then export PTAM_LDLT_ONE_ENDED=1; else unset PTAM_LDLT_ONE_ENDED; fi
