@@ -548,6 +548,9 @@ int ptam_ba_counts(const ptam_ba* ba, int* n_cams, int* n_free_cams, int* n_poin
  * resident, which a device shared with another process' solve may not grant.  The repeated trial's result is what the reference
  * computes; the rest of the adjustment keeps the slower form.  0 in normal operation (returned as the function's value). */
 int ptam_ba_solve_fallbacks(const ptam_ba* ba);
+/* Operating switches of the camera solve, read from the environment once per process: PTAM_LDLT_NO_CHAIN=1 uses the
+ * launch-per-block-column form everywhere (a device shared between processes that all adjust bundles); PTAM_CH_SPIN_LIMIT=<n> is
+ * the number of looks (~1 us each, default 2^18) a workgroup of the persistent form takes before it gives up a wait. */
 
 /* profiling hooks used by bench.py: HIP-event timing of individual kernels on the ctx stream. */
 enum {
