@@ -54,15 +54,30 @@ __device__ __forceinline__ unsigned wave_pack_template4(int T, int lane) {
     return (unsigned)__shfl(T, tb, 64) | ((unsigned)__shfl(T, tb + 1, 64) << 8) | ((unsigned)__shfl(T, tb + 2, 64) << 16) |
            ((unsigned)__shfl(T, tb + 3, 64) << 24);
 }
+// The search region of a FindPatchCoarse call staged in LDS by its wave (SW_SIDE x SW_SIDE bytes, origin (x0, y0) inside the
+// image): every candidate window then comes out of LDS instead of costing a dependent global round trip per four candidates.
+#define SW_SIDE 32
+#define SW_LIST 128                                 // candidate list of the lane-per-candidate path (int2 each)
+#define SW_BYTES (SW_SIDE * SW_SIDE + 16 + SW_LIST * 8)
+struct SearchWin {
+    const unsigned* lds;   // nullptr: score from global memory
+    int x0, y0;
+};
 __device__ __forceinline__ int wave_zmssd4(const uint8_t* __restrict__ im, int w, int h, const int cx[4], const int cy[4], int n,
-                                           unsigned T4, int tsum, int tsumsq, int lane) {
+                                           unsigned T4, int tsum, int tsumsq, int lane, const SearchWin sw = SearchWin{nullptr, 0, 0}) {
     typedef unsigned u32_unaligned __attribute__((aligned(1)));
     const int sub = lane & 15, grp = lane >> 4;
     const int mx = grp == 0 ? cx[0] : grp == 1 ? cx[1] : grp == 2 ? cx[2] : cx[3];
     const int my = grp == 0 ? cy[0] : grp == 1 ? cy[1] : grp == 2 ? cy[2] : cy[3];
     const bool inb = grp < n && mx >= 4 && my >= 4 && mx < w - 4 && my < h - 4;
     unsigned I4 = 0;
-    if (inb) I4 = *(const u32_unaligned*)(im + (size_t)(my - 4 + (sub >> 1)) * w + (mx - 4 + 4 * (sub & 1)));
+    if (sw.lds) {
+        // four bytes at an arbitrary byte offset of the window: two aligned words and a byte shift
+        const int off = inb ? (my - 4 + (sub >> 1) - sw.y0) * SW_SIDE + (mx - 4 + 4 * (sub & 1) - sw.x0) : 0;
+        const unsigned lo = sw.lds[off >> 2], hi = sw.lds[(off >> 2) + 1];
+        I4 = inb ? __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(off & 3)) : 0u;
+    } else if (inb)
+        I4 = *(const u32_unaligned*)(im + (size_t)(my - 4 + (sub >> 1)) * w + (mx - 4 + 4 * (sub & 1)));
     int s1 = (int)__builtin_amdgcn_udot4(I4, 0x01010101u, 0u, false);
     int s2 = (int)__builtin_amdgcn_udot4(I4, I4, 0u, false);
     int s3 = (int)__builtin_amdgcn_udot4(I4, T4, 0u, false);
@@ -75,8 +90,47 @@ __device__ __forceinline__ int wave_zmssd4(const uint8_t* __restrict__ im, int w
 
 // PatchFinder::FindPatchCoarse (src/PatchFinder.cc:160-211) by one wave: lane = pixel of the 8x8 window, T = this lane's
 // template pixel.  enabled = false: the query is not searched (bad template).
+// wave minimum of an unsigned key, in every lane (row shifts keep a lane's own value where there is no source)
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    v = min(v, (unsigned)dpp_row_shr_i32<1>((int)v, (int)v));
+    v = min(v, (unsigned)dpp_row_shr_i32<2>((int)v, (int)v));
+    v = min(v, (unsigned)dpp_row_shr_i32<4>((int)v, (int)v));
+    v = min(v, (unsigned)dpp_row_shr_i32<8>((int)v, (int)v));
+    v = min(v, (unsigned)dpp_bcast_i32<0x142, 0xA>((int)v, (int)v));
+    v = min(v, (unsigned)dpp_bcast_i32<0x143, 0xC>((int)v, (int)v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// ONE candidate per lane, its whole 8 x 8 window out of the staged region: per row three aligned words, two byte shifts, six
+// v_dot4 against the row's template words (Tw[16]: wave-uniform, row r = words 2 r, 2 r + 1) — ~110 instructions for up to 64
+// candidates, against ~80 per FOUR candidates in the 16-lanes-per-candidate form, whose passes were a serial chain of scalar
+// hand-overs (2 000 cycles per pass: the coarse stage's range-30 search spent 15-20 k cycles on ~25 candidates).  Integer
+// arithmetic: the same numbers.
+__device__ __forceinline__ int lane_zmssd_lds(const SearchWin& sw, int w, int h, int mx, int my, bool have, const unsigned Tw[16], int tsum, int tsumsq) {
+    const bool inb = have && mx >= 4 && my >= 4 && mx < w - 4 && my < h - 4;
+    const int off0 = inb ? (my - 4 - sw.y0) * SW_SIDE + (mx - 4 - sw.x0) : 0;
+    const unsigned sh = (unsigned)(off0 & 3);
+    const unsigned* p = sw.lds + (off0 >> 2);
+    unsigned s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const unsigned a = p[r * (SW_SIDE / 4)], b = p[r * (SW_SIDE / 4) + 1], c = p[r * (SW_SIDE / 4) + 2];
+        const unsigned lo = __builtin_amdgcn_alignbyte(b, a, sh), hi = __builtin_amdgcn_alignbyte(c, b, sh);
+        s1 = __builtin_amdgcn_udot4(lo, 0x01010101u, s1, false);
+        s1 = __builtin_amdgcn_udot4(hi, 0x01010101u, s1, false);
+        s2 = __builtin_amdgcn_udot4(lo, lo, s2, false);
+        s2 = __builtin_amdgcn_udot4(hi, hi, s2, false);
+        s3 = __builtin_amdgcn_udot4(lo, Tw[2 * r], s3, false);
+        s3 = __builtin_amdgcn_udot4(hi, Tw[2 * r + 1], s3, false);
+    }
+    return inb ? zmssd_finish(tsum, (int)s1, (int)s2, tsumsq, (int)s3) : PTAM_MAX_SSD + 1;
+}
+// win (nullable): SW_BYTES of LDS of the wave's own.  When the search region — the candidates' 8 x 8 windows around the circle of
+// radius nRange — fits SW_SIDE x SW_SIDE, it is fetched once (16 bytes per lane, together with the row LUT) and the corner list
+// of the row range is requested SCH chunks at a time: two or three dependent round trips per call instead of one per 64 corners
+// and one per four candidates (the coarse stage's range-30 search scored ~25 candidates behind ~14 round trips: 18 k cycles).
+#define SCH 6
 __device__ __forceinline__ void wave_find_patch_coarse(const KfLevels& L, const ptam_patch_query& q, bool enabled, int T, int lane,
-                                                       ptam_patch_result& res) {
+                                                       ptam_patch_result& res, unsigned* win = nullptr) {
     res.found = 0;
     res.best_ssd = PTAM_MAX_SSD + 1;
     res.best_x = res.best_y = -1;
@@ -111,16 +165,101 @@ __device__ __forceinline__ void wave_find_patch_coarse(const KfLevels& L, const 
             i1 = nBottomPlusOne >= h ? L.ncorners[lev] : L.rowlut[lev][nBottomPlusOne];
         }
     }
-    if (search) {
+    SearchWin sw{nullptr, 0, 0};
+    if (search && win && 2 * (int)nRange + 8 <= SW_SIDE && w >= SW_SIDE && h >= SW_SIDE) {
+        // origin: the region's corner, moved inside the image (the in-image part of the region stays covered: side <= SW_SIDE)
+        sw.x0 = min(max(px - (int)nRange - 4, 0), w - SW_SIDE);
+        sw.y0 = min(max(py - (int)nRange - 4, 0), h - SW_SIDE);
+        typedef unsigned u32_unaligned __attribute__((aligned(1)));
+        const uint8_t* src = im + (size_t)(sw.y0 + (lane >> 1)) * w + sw.x0 + 16 * (lane & 1);
+        const unsigned a0 = *(const u32_unaligned*)src, a1 = *(const u32_unaligned*)(src + 4), a2 = *(const u32_unaligned*)(src + 8),
+                       a3 = *(const u32_unaligned*)(src + 12);
+        ((uint4*)win)[lane] = make_uint4(a0, a1, a2, a3);   // row lane / 2, bytes 16 (lane % 2) .. + 15
+        if (lane < 4) win[SW_SIDE * SW_SIDE / 4 + lane] = 0;   // (the word past the last one, read by the byte shift)
+        sw.lds = win;
+    }
+    if (search && sw.lds) {
+        // ---- lane-per-candidate path: the passing corners of the row range are compacted, in corner order, into a list in
+        // LDS; every 64 of them (and the rest at the end) are scored at once, and the first strict minimum in corner order is the
+        // minimum of (score << 7 | position in the batch), earlier batches winning ties ----
+        const int tsum = wave_sum_i32(T), tsumsq = wave_sum_i32(T * T);
+        unsigned Tw[16];   // the template as 16 words (row r: columns 0-3, 4-7), wave-uniform
+        {
+            const unsigned t0 = (unsigned)__shfl(T, (lane * 4) & 63, 64), t1 = (unsigned)__shfl(T, (lane * 4 + 1) & 63, 64),
+                           t2 = (unsigned)__shfl(T, (lane * 4 + 2) & 63, 64), t3 = (unsigned)__shfl(T, (lane * 4 + 3) & 63, 64);
+            const unsigned packed = t0 | (t1 << 8) | (t2 << 16) | (t3 << 24);   // (lanes 0 .. 15 hold the 16 words)
+#pragma unroll
+            for (int k = 0; k < 16; k++) Tw[k] = (unsigned)__builtin_amdgcn_readlane((int)packed, k);
+        }
+        int2* list = (int2*)(win + (SW_SIDE * SW_SIDE + 16) / 4);
+        int best = PTAM_MAX_SSD + 1, bx = -1, by = -1, nsc = 0, head = 0, tail = 0;   // list entries [head, tail), positions mod SW_LIST
+        auto score_batch = [&](int nb) {
+            const int2 e = list[(head + min(lane, nb - 1)) & (SW_LIST - 1)];
+            const int ssd = lane_zmssd_lds(sw, w, h, e.x, e.y, lane < nb, Tw, tsum, tsumsq);
+            const unsigned key = lane < nb ? (((unsigned)ssd << 7) | (unsigned)lane) : 0xffffffffu;
+            const unsigned mk = wave_min_u32(key);
+            const int mssd = (int)(mk >> 7), ml = (int)(mk & 127u);
+            if (mssd < best) {
+                best = mssd;
+                bx = __builtin_amdgcn_readlane(e.x, ml);
+                by = __builtin_amdgcn_readlane(e.y, ml);
+            }
+            nsc += nb;
+            head += nb;
+        };
+        for (int base0 = i0; base0 < i1; base0 += 64 * SCH) {
+            ptam_int2 cc[SCH];
+#pragma unroll
+            for (int u = 0; u < SCH; u++) cc[u] = corners[min(base0 + 64 * u + lane, max(i1 - 1, 0))];
+#pragma unroll
+            for (int u = 0; u < SCH; u++) {
+                const int idx = base0 + 64 * u + lane;
+                bool pass = false;
+                if (idx < i1) {
+                    const int dx = px - cc[u].x, dy = py - cc[u].y;
+                    pass = !(cc[u].x < nLeft || cc[u].x > nRight) && !((unsigned)(dx * dx + dy * dy) > nRange * nRange);
+                }
+                const unsigned long long m = __ballot(pass);
+                if (m) {
+                    const int pos = tail + __popcll(m & ((1ull << lane) - 1ull));
+                    if (pass) list[pos & (SW_LIST - 1)] = make_int2(cc[u].x, cc[u].y);
+                    tail += __popcll(m);
+                    if (tail - head >= 64) score_batch(64);
+                }
+            }
+        }
+        if (tail > head) score_batch(tail - head);
+        res.best_ssd = best;
+        res.best_x = bx;
+        res.best_y = by;
+        res.n_scored = nsc;
+        if (best < PTAM_MAX_SSD) {
+            const int scale = 1 << q.level;
+            res.found = 1;
+            res.pos[0] = (bx + 0.5) * scale - 0.5;   // Level::LevelZeroPos include/KeyFrame.h:91-94
+            res.pos[1] = (by + 0.5) * scale - 0.5;
+        }
+    } else if (search) {
         const int tsum = wave_sum_i32(T), tsumsq = wave_sum_i32(T * T);
         const unsigned T4 = wave_pack_template4(T, lane);   // candidates are scored four at a time (wave_zmssd4)
         int best = PTAM_MAX_SSD + 1, bx = -1, by = -1, nsc = 0;
-        for (int base = i0; base < i1; base += 64) {
+        for (int base0 = i0; base0 < i1; base0 += 64 * SCH) {
+          // (SCH chunks of the corner list requested together)
+          ptam_int2 cc[SCH];
+#pragma unroll
+          for (int u = 0; u < SCH; u++) {
+              const int idx = base0 + 64 * u + lane;
+              cc[u] = corners[min(idx, max(i1 - 1, 0))];
+          }
+#pragma unroll
+          for (int u = 0; u < SCH; u++) {
+            const int base = base0 + 64 * u;
+            if (base >= i1) break;
             const int idx = base + lane;
             ptam_int2 c = {0, 0};
             bool pass = false;
             if (idx < i1) {
-                c = corners[idx];
+                c = cc[u];
                 const int dx = px - c.x, dy = py - c.y;
                 pass = !(c.x < nLeft || c.x > nRight) && !((unsigned)(dx * dx + dy * dy) > nRange * nRange);
             }
@@ -136,7 +275,7 @@ __device__ __forceinline__ void wave_find_patch_coarse(const KfLevels& L, const 
                         cy[k] = __builtin_amdgcn_readlane(c.y, b);
                         n = k + 1;
                     }
-                const int ssd_l = wave_zmssd4(im, w, h, cx, cy, n, T4, tsum, tsumsq, lane);
+                const int ssd_l = wave_zmssd4(im, w, h, cx, cy, n, T4, tsum, tsumsq, lane, sw);
 #pragma unroll
                 for (int k = 0; k < 4; k++)
                     if (k < n) {   // in corner order: the first strict minimum wins
@@ -149,6 +288,7 @@ __device__ __forceinline__ void wave_find_patch_coarse(const KfLevels& L, const 
                         }
                     }
             }
+          }
         }
         res.best_ssd = best;
         res.best_x = bx;
@@ -197,7 +337,12 @@ __device__ __forceinline__ void ldlt3_inverse(double A[9], double out[9]) {   //
 
 // PatchFinder::MakeSubPixTemplate + IterateSubPixToConvergence (src/PatchFinder.cc:219-318) by one wave, T = this lane's
 // template pixel
-__device__ __forceinline__ void wave_subpix(const KfLevels& L, const ptam_subpix_query& q, int T, int lane, ptam_subpix_result& res) {
+// win (nullable): 256 bytes of LDS of the wave's own — a 16 x 16 window of the level around the coarse position is fetched ONCE
+// and the iterations interpolate out of it (the fit moves by fractions of a pixel per iteration: it leaves a window that
+// reaches 4 pixels past the patch on every side only in pathological cases, which take the global loads as before).  Every
+// iteration used to wait for a dependent global round trip — eight of them in a row on the coarse stage's critical path.
+__device__ __forceinline__ void wave_subpix(const KfLevels& L, const ptam_subpix_query& q, int T, int lane, ptam_subpix_result& res,
+                                            uint8_t* win = nullptr) {
     res.converged = 0;
     res.iterations = 0;
     res.pos[0] = q.coarse_pos[0];
@@ -225,6 +370,20 @@ __device__ __forceinline__ void wave_subpix(const KfLevels& L, const ptam_subpix
         const double jx = (double)(float)gx, jy = (double)(float)gy;   // mimJacs holds floats
         double pos0 = q.coarse_pos[0], pos1 = q.coarse_pos[1], mean_diff = 0.0;
         const int scale = 1 << q.level;
+        // the window: rows wy0 .. wy0 + 15, columns wx0 .. wx0 + 15 (lane = 4 consecutive bytes of a row), if it lies in the image
+        int wx0 = 0, wy0 = 0;
+        bool have_win = false;
+        if (win) {
+            const double c0x = (pos0 + 0.5) / scale - 0.5, c0y = (pos1 + 0.5) / scale - 0.5;
+            wx0 = (int)floor(c0x) - 8;
+            wy0 = (int)floor(c0y) - 8;
+            have_win = wx0 >= 0 && wy0 >= 0 && wx0 + 16 <= w && wy0 + 16 <= h;
+            if (have_win) {
+                const uint8_t* src = im + (size_t)(wy0 + (lane >> 2)) * w + wx0 + 4 * (lane & 3);
+                const unsigned b0 = src[0], b1 = src[1], b2 = src[2], b3 = src[3];
+                ((unsigned*)win)[lane] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+            }
+        }
         for (int it = 0; it < q.max_its; it++) {
             res.iterations = it + 1;
             // IterateSubPix :271-318
@@ -238,10 +397,16 @@ __device__ __forceinline__ void wave_subpix(const KfLevels& L, const ptam_subpix
             const int ibx = (int)bx, iby = (int)by;   // ::ir() truncation
             double d0 = 0, d1 = 0, d2 = 0;
             if (inner) {
-                const uint8_t* p = im + (size_t)(iby + py) * w + ibx + px;
-                const float fPixel = nc_addf(nc_addf(nc_addf(nc_mulf(fTL, (float)p[0]), nc_mulf(fTR, (float)p[1])),
-                                                     nc_mulf(fBL, (float)p[w])),
-                                             nc_mulf(fBR, (float)p[w + 1]));
+                float p00, p01, p10, p11;
+                const int ox = ibx - wx0, oy = iby - wy0;
+                if (have_win && ox >= 0 && oy >= 0 && ox + 8 <= 15 && oy + 8 <= 15) {   // (wave-uniform: rows oy + py + 1, columns ox + px + 1 stay inside)
+                    const uint8_t* p = win + (oy + py) * 16 + ox + px;
+                    p00 = (float)p[0], p01 = (float)p[1], p10 = (float)p[16], p11 = (float)p[17];
+                } else {
+                    const uint8_t* p = im + (size_t)(iby + py) * w + ibx + px;
+                    p00 = (float)p[0], p01 = (float)p[1], p10 = (float)p[w], p11 = (float)p[w + 1];
+                }
+                const float fPixel = nc_addf(nc_addf(nc_addf(nc_mulf(fTL, p00), nc_mulf(fTR, p01)), nc_mulf(fBL, p10)), nc_mulf(fBR, p11));
                 const double dDiff = (double)fPixel - (double)T + mean_diff;
                 d0 = dDiff * jx;
                 d1 = dDiff * jy;

@@ -298,6 +298,9 @@ __device__ __forceinline__ void tm_search_body(const DevCam& cam, const KfLevels
     // (the slot is the workgroup's own — the launch covers the slots from 0 — so that the point id is requested together with
     //  the control block, not behind it: one dependent round trip less at the head of every search wave)
     const int s = bx * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+#ifdef K7_TIMING
+    const long long ts0_ = (long long)__builtin_readcyclecounter();
+#endif
     const int id = d.list[min(s, d.cap - 1)];
     const TmCtl& c = *d.ctl;
     const int first = stage == 0 ? c.range_c[0] : c.range_hf[0], end = stage == 0 ? c.range_c[1] : c.range_hf[1];
@@ -352,6 +355,9 @@ __device__ __forceinline__ void tm_search_body(const DevCam& cam, const KfLevels
     // (nearly) this warp — then the template, its sums and mbTemplateBad stay as they are
     ptam_template_result tr;
     int T, kept = 0;
+#ifdef K7_TIMING
+    const long long ts1_ = (long long)__builtin_readcyclecounter();
+#endif
     {
         double m2[4];
         template_m2(jb, m2);
@@ -379,7 +385,14 @@ __device__ __forceinline__ void tm_search_body(const DevCam& cam, const KfLevels
         }
     }
     ptam_patch_result res;
-    wave_find_patch_coarse(L, q, !tr.bad, T, lane, res);
+#ifdef K7_TIMING
+    const long long ts2_ = (long long)__builtin_readcyclecounter();
+#endif
+    __shared__ __attribute__((aligned(16))) unsigned sw_win[4][SW_BYTES / 4];   // (a wave's own search region: no barrier)
+    wave_find_patch_coarse(L, q, !tr.bad, T, lane, res, sw_win[threadIdx.x >> 6]);
+#ifdef K7_TIMING
+    const long long ts3_ = (long long)__builtin_readcyclecounter();
+#endif
     if (lane == 0) {
         d.tres[s] = tr;
         d.q[s] = q;
@@ -389,6 +402,7 @@ __device__ __forceinline__ void tm_search_body(const DevCam& cam, const KfLevels
     const int its = stage == 0 ? coarse_its : (s < c.range_h[1] ? 8 : 0);
     ptam_subpix_result sres;
     sres.converged = 0;
+    sres.iterations = 0;
     sres.pos[0] = sres.pos[1] = 0;
     if (its > 0) {
         ptam_subpix_query sq;
@@ -396,9 +410,15 @@ __device__ __forceinline__ void tm_search_body(const DevCam& cam, const KfLevels
         sq.max_its = its;
         sq.coarse_pos[0] = res.pos[0];
         sq.coarse_pos[1] = res.pos[1];
-        wave_subpix(L, sq, T, lane, sres);
+        __shared__ uint8_t sp_win[4][256];   // (a wave's own 16 x 16 window: no barrier)
+        wave_subpix(L, sq, T, lane, sres, sp_win[threadIdx.x >> 6]);
         if (lane == 0) d.sr[s] = sres;
     }
+#ifdef K7_TIMING
+    if (lane == 0 && (s == 3 || s == 40 || s == 500) && (clock64() & 0x3f000) == 0)
+        printf("search wave stage %d slot %d level %d kept %d its %d(%d): loads %lld | template %lld | search %lld (scored %d) | sub-pixel %lld\n", stage, s, q.level,
+               kept, its, sres.iterations, ts1_ - ts0_, ts2_ - ts1_, ts3_ - ts2_, res.n_scored, (long long)__builtin_readcyclecounter() - ts3_);
+#endif
     // the slot's outcome (the tail of SearchForPoints, :880-906), for the gather pass: one packed word + the position
     double2 v2pub = make_double2(0, 0);
     if (lane == 0) {
