@@ -30,7 +30,8 @@ __global__ void __launch_bounds__(256) zmssd_search_kernel(KfLevels L, int n, co
     const ptam_patch_query q = queries[qi];
     const int T = templates[(size_t)qi * 64 + lane];
     ptam_patch_result res;
-    wave_find_patch_coarse(L, q, !(tres && tres[qi].bad), T, lane, res);
+    __shared__ __attribute__((aligned(16))) unsigned sw_win[4][SW_BYTES / 4];   // (a wave's own search region: no barrier)
+    wave_find_patch_coarse(L, q, !(tres && tres[qi].bad), T, lane, res, sw_win[threadIdx.x >> 6]);
     if (lane == 0) results[qi] = res;
 }
 

@@ -303,34 +303,48 @@ __device__ __forceinline__ void wave_find_patch_coarse(const KfLevels& L, const 
     }
 }
 
+// (reciprocals by v_rcp_f64 + two Newton steps, <= 1 ulp, as in the pose and bundle kernels: twelve IEEE divisions — a dependent
+//  chain of ~12 instructions each — were most of this routine, which sits at the head of every sub-pixel refinement)
 __device__ __forceinline__ void ldlt3_inverse(double A[9], double out[9]) {   // TooN Cholesky<3>::get_inverse
+    double inv_d[3];
+#pragma unroll
     for (int col = 0; col < 3; col++) {
         double inv_diag = 1;
+#pragma unroll
         for (int row = col; row < 3; row++) {
             double val = A[row * 3 + col];
+#pragma unroll
             for (int c2 = 0; c2 < col; c2++) val -= A[c2 * 3 + col] * A[row * 3 + c2];
             if (row == col) {
                 A[row * 3 + col] = val;
-                inv_diag = 1 / val;
+                inv_diag = rcp_nr(val);
+                inv_d[col] = inv_diag;
             } else {
                 A[col * 3 + row] = val;
                 A[row * 3 + col] = val * inv_diag;
             }
         }
     }
+#pragma unroll
     for (int c = 0; c < 3; c++) {
         double y[3], x[3];
+#pragma unroll
         for (int i = 0; i < 3; i++) {
             double val = (i == c) ? 1.0 : 0.0;
+#pragma unroll
             for (int j = 0; j < i; j++) val -= A[i * 3 + j] * y[j];
             y[i] = val;
         }
-        for (int i = 0; i < 3; i++) y[i] /= A[i * 3 + i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) y[i] *= inv_d[i];
+#pragma unroll
         for (int i = 2; i >= 0; i--) {
             double val = y[i];
+#pragma unroll
             for (int j = i + 1; j < 3; j++) val -= A[j * 3 + i] * x[j];
             x[i] = val;
         }
+#pragma unroll
         for (int r = 0; r < 3; r++) out[r * 3 + c] = x[r];
     }
 }
@@ -370,11 +384,12 @@ __device__ __forceinline__ void wave_subpix(const KfLevels& L, const ptam_subpix
         const double jx = (double)(float)gx, jy = (double)(float)gy;   // mimJacs holds floats
         double pos0 = q.coarse_pos[0], pos1 = q.coarse_pos[1], mean_diff = 0.0;
         const int scale = 1 << q.level;
+        const double inv_scale = 1.0 / scale;   // (a power of two: x * inv_scale IS x / scale, without the division's twelve instructions)
         // the window: rows wy0 .. wy0 + 15, columns wx0 .. wx0 + 15 (lane = 4 consecutive bytes of a row), if it lies in the image
         int wx0 = 0, wy0 = 0;
         bool have_win = false;
         if (win) {
-            const double c0x = (pos0 + 0.5) / scale - 0.5, c0y = (pos1 + 0.5) / scale - 0.5;
+            const double c0x = (pos0 + 0.5) * inv_scale - 0.5, c0y = (pos1 + 0.5) * inv_scale - 0.5;
             wx0 = (int)floor(c0x) - 8;
             wy0 = (int)floor(c0y) - 8;
             have_win = wx0 >= 0 && wy0 >= 0 && wx0 + 16 <= w && wy0 + 16 <= h;
@@ -387,7 +402,7 @@ __device__ __forceinline__ void wave_subpix(const KfLevels& L, const ptam_subpix
         for (int it = 0; it < q.max_its; it++) {
             res.iterations = it + 1;
             // IterateSubPix :271-318
-            const double cx = (pos0 + 0.5) / scale - 0.5, cy = (pos1 + 0.5) / scale - 0.5;   // LevelNPos
+            const double cx = (pos0 + 0.5) * inv_scale - 0.5, cy = (pos1 + 0.5) * inv_scale - 0.5;   // LevelNPos
             const int rx = (int)(cx > 0.0 ? cx + 0.5 : cx - 0.5), ry = (int)(cy > 0.0 ? cy + 0.5 : cy - 0.5);   // ir_rounded
             if (!(rx >= 5 && ry >= 5 && rx < w - 5 && ry < h - 5)) break;
             const double bx = cx - 4, by = cy - 4;

@@ -313,6 +313,11 @@ __device__ __forceinline__ void tm_search_body(const DevCam& cam, const KfLevels
     double u = pv.proj.image[0], v = pv.proj.image[1];
     const ptam_pvs_point& p = d.pts[id];
     const double pw0 = p.world[0], pw1 = p.world[1], pw2 = p.world[2];
+    const TmSrc sr = d.src[id];   // (with the point's other records: behind the re-projection it was a round trip of its own)
+    const int pv_level = pv.level;
+    double pwi[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) pwi[k] = pv.warp_inverse[k];
     double pcam0 = pv.proj.cam[0], pcam1 = pv.proj.cam[1], pcam2 = pv.proj.cam[2];
     const double pd0 = pv.proj.derivs[0], pd1 = pv.proj.derivs[1], pd2 = pv.proj.derivs[2], pd3 = pv.proj.derivs[3];
     if (stage == 1 && (s < c.range_h[1] || c.did_coarse)) {
@@ -339,18 +344,17 @@ __device__ __forceinline__ void tm_search_body(const DevCam& cam, const KfLevels
     ptam_patch_query q;
     q.x = (int)u;   // ir(): truncation
     q.y = (int)v;
-    q.level = pv.level;
+    q.level = pv_level;
     q.range = stage == 0 ? coarse_range : (unsigned)c.fine_range;
-    const TmSrc sr = d.src[id];
     TemplateJob jb;
     jb.im = sr.im;
     jb.w = sr.w;
     jb.h = sr.h;
-    jb.search_level = pv.level;
+    jb.search_level = pv_level;
     jb.cx = sr.cx;
     jb.cy = sr.cy;
 #pragma unroll
-    for (int k = 0; k < 4; k++) jb.wi[k] = pv.warp_inverse[k];
+    for (int k = 0; k < 4; k++) jb.wi[k] = pwi[k];
     // MakeTemplateCoarseCont (src/PatchFinder.cc:98-127): re-make the template unless this finder's last one was made with
     // (nearly) this warp — then the template, its sums and mbTemplateBad stay as they are
     ptam_template_result tr;
@@ -363,11 +367,11 @@ __device__ __forceinline__ void tm_search_body(const DevCam& cam, const KfLevels
         template_m2(jb, m2);
         const double c0x = m2[0] - fm0, c0y = m2[2] - fm2, c1x = m2[1] - fm1, c1y = m2[3] - fm3;   // columns m2.T()[0], m2.T()[1]
         const double lim = 0.07 * 0.07;
-        const bool refresh = !f_valid || pv.level < 0 || c0x * c0x + c0y * c0y > lim || c1x * c1x + c1y * c1y > lim;
+        const bool refresh = !f_valid || pv_level < 0 || c0x * c0x + c0y * c0y > lim || c1x * c1x + c1y * c1y > lim;
         if (refresh) {
             T = wave_make_template(jb, lane, tr);
             fs.tpl[lane] = (uint8_t)T;
-            if (lane == 0 && pv.level >= 0) {
+            if (lane == 0 && pv_level >= 0) {
                 fs.m2[0] = tr.m2[0], fs.m2[1] = tr.m2[1], fs.m2[2] = tr.m2[2], fs.m2[3] = tr.m2[3];
                 fs.valid = 1;
                 fs.bad = tr.bad;
@@ -1082,7 +1086,8 @@ __global__ void __launch_bounds__(256) rp_search_kernel(RpDev d) {
         if (lane == 0) d.bad[i] = bad;
         const KfLevels& L = d.Ls[d.pairs[i].kf];
         ptam_patch_result res;
-        wave_find_patch_coarse(L, q, !bad, T, lane, res);                              // :982-988 (range 4)
+        __shared__ __attribute__((aligned(16))) unsigned rp_win[4][SW_BYTES / 4];
+        wave_find_patch_coarse(L, q, !bad, T, lane, res, rp_win[threadIdx.x >> 6]);   // :982-988 (range 4)
         if (!bad && res.found) {
             o.found = 1;
             o.never_retry = 0;
@@ -1093,7 +1098,7 @@ __global__ void __launch_bounds__(256) rp_search_kernel(RpDev d) {
                 sq.coarse_pos[0] = res.pos[0];
                 sq.coarse_pos[1] = res.pos[1];
                 ptam_subpix_result sres;
-                wave_subpix(L, sq, T, lane, sres);
+                wave_subpix(L, sq, T, lane, sres, (uint8_t*)rp_win[threadIdx.x >> 6]);   // (the search is done with the buffer)
                 o.sub_pix = 1;
                 o.root_pos[0] = sres.pos[0];
                 o.root_pos[1] = sres.pos[1];
