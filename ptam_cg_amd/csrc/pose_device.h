@@ -475,19 +475,74 @@ struct PoseArrayLoader {
     __device__ __forceinline__ int listed_total(int n) const { return n; }
 };
 
-// TrackerData::Project with the pose in LDS; updates the cached state exactly like td_project
+// atan for x >= 0 by argument reduction (c in {0, 1/2, 1, 3/2}; x >= 39/16: pi/2 - atan(1/x)) and the 11-term odd minimax
+// polynomial of fdlibm on |t| < 7/16, <= 2 ulp against libm (the bundle kernels' form, ba_math.inc): ~45 VALU instructions
+// where the library call is ~80 — on the one-wave coarse loop every instruction of the re-projection is on the frame's critical path
+static __constant__ double POSE_ATAN_K[20] = {
+    3.33333333333329318027e-01,  -1.99999999998764832476e-01, 1.42857142725034663711e-01,  -1.11111104054623557880e-01,
+    9.09088713343650656196e-02,  -7.69187620504482999495e-02, 6.66107313738753120669e-02,  -5.83357013379057348645e-02,
+    4.97687799461593236017e-02,  -3.65315727442169155270e-02, 1.62858201153657823623e-02,
+    4.63647609000806093515e-01,  7.85398163397448278999e-01,  9.82793723247329054082e-01,  1.57079632679489655800e+00,
+    0.4375, 0.6875, 1.1875, 2.4375, 1.5};
+__device__ __forceinline__ double pose_atan_pos(double x) {
+    const double* __restrict__ K = POSE_ATAN_K;
+    double c = 0.0, hi = 0.0;
+    if (x >= K[15]) c = 0.5, hi = K[11];
+    if (x >= K[16]) c = 1.0, hi = K[12];
+    if (x >= K[17]) c = K[19], hi = K[13];
+    double num = x - c, den = fma(c, x, 1.0);
+    if (x >= K[18]) {
+        num = -1.0;
+        den = x;
+        hi = K[14];
+    }
+    const double t = num * rcp_nr(den);
+    const double z = t * t, w = z * z;
+    double p1 = fma(w, K[10], K[8]);
+    p1 = fma(w, p1, K[6]);
+    p1 = fma(w, p1, K[4]);
+    p1 = fma(w, p1, K[2]);
+    p1 = fma(w, p1, K[0]);
+    double p2 = fma(w, K[9], K[7]);
+    p2 = fma(w, p2, K[5]);
+    p2 = fma(w, p2, K[3]);
+    p2 = fma(w, p2, K[1]);
+    return hi - (t * (z * p1 + w * p2) - t);
+}
+
+// TrackerData::Project with the pose in LDS; updates the cached state exactly like td_project.  Same formulas as cam_project /
+// cam_derivs (common.h) with the seven IEEE divisions of a projection — a dependent chain of a dozen instructions each — as
+// Newton-refined reciprocals (1 / Z, 1 / r, 1 / (r^2 (1 + k^2 r^2)): <= 1 ulp each) and the atan above.
 __device__ __forceinline__ void small_project(const DevCam& cam, const double* pose, SmallMeas& t, bool& in_image) {
     in_image = false;
     se3_apply(pose, t.world[0], t.world[1], t.world[2], t.cam3[0], t.cam3[1], t.cam3[2]);
-    t.iz = 1.0 / t.cam3[2];
+    t.iz = rcp_nr(t.cam3[2]);
     if (t.cam3[2] < 0.001) return;
-    const double x = t.cam3[0] / t.cam3[2], y = t.cam3[1] / t.cam3[2];
-    if (x * x + y * y > cam.largest_radius * cam.largest_radius) return;
-    double u, v, r, f;
-    cam_project(cam, x, y, u, v, r, f);
+    const double x = t.cam3[0] * t.iz, y = t.cam3[1] * t.iz;
+    const double r2 = x * x + y * y;
+    if (r2 > cam.largest_radius * cam.largest_radius) return;
+    const double r = sqrt(r2);
+    const bool small_r = r < 0.001 || cam.w == 0.0;
+    const double ir = rcp_nr(small_r ? 1.0 : r);
+    const double f = small_r ? 1.0 : cam.w_inv * pose_atan_pos(r * cam.two_tan) * ir;
+    const double u = cam.cx + cam.fx * (f * x), v = cam.cy + cam.fy * (f * y);
     t.img[0] = u;
     t.img[1] = v;
-    cam_derivs(cam, x, y, r, f, t.D);
+    {
+        // GetProjectionDerivs src/ATANCamera.cc:179-209
+        const double k = cam.two_tan, rd = r * cam.dist_enabled;
+        double dx = 0.0, dy = 0.0;
+        if (!(rd < 0.01)) {
+            const double rr = rd * rd;
+            const double inv_den = rcp_nr(rr * (1 + k * k * rr)), irr = rcp_nr(rr);
+            dx = cam.w_inv * (k * x) * inv_den - x * f * irr;
+            dy = cam.w_inv * (k * y) * inv_den - y * f * irr;
+        }
+        t.D[0] = cam.fx * (dx * x + f);
+        t.D[2] = cam.fy * (dx * y);
+        t.D[1] = cam.fx * (dy * x);
+        t.D[3] = cam.fy * (dy * y + f);
+    }
     if (r > cam.max_r) return;
     if (u < 0 || v < 0 || u > cam.width || v > cam.height) return;
     in_image = true;
@@ -549,7 +604,7 @@ __device__ __forceinline__ void pose_gn_small_body(const DevCam& cam, int n, LOA
         if (t[q].listed) {
             t[q].found = 1;
             if (ld.has_entry()) {
-                t[q].iz = 1.0 / t[q].cam3[2];
+                t[q].iz = rcp_nr(t[q].cam3[2]);
             } else {
                 bool in_image;
                 small_project(cam, sh.pose, t[q], in_image);
