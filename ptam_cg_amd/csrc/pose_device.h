@@ -90,6 +90,7 @@ struct GnSmallShared {
     unsigned hist2[2][GS_BINS];
     unsigned long long cand2[2][64];
     int n_cand2[2];
+    int book[20];   // the frame's integer results, parked until the result block is written (loader's begin -> publish)
     double tr[27][TR_PITCH];   // transposed per-thread partials of the 27 sums (row = sum, column = thread)
 };
 
@@ -472,6 +473,8 @@ struct PoseArrayLoader {
         return (ptam_projection*)((char*)io.td_base + (size_t)(io.td_index ? io.td_index[i] : i) * io.td_stride);
     }
     __device__ __forceinline__ void td_also(int, int, const SmallMeas&) const {}
+    template <class SH>
+    __device__ __forceinline__ void publish(SH&) const {}
     __device__ __forceinline__ int listed_total(int n) const { return n; }
 };
 
@@ -856,6 +859,7 @@ __device__ __forceinline__ void pose_gn_small_body(const DevCam& cam, int n, LOA
     }
     if (io.result_seq) {   // the frame's last kernel: pose, then the sequence word the host spins on (host-mapped memory)
         __syncthreads();
+        ld.publish(sh);   // (what the loader booked at the kernel's start: every store to host memory happens here, once)
         if (threadIdx.x < 12) io.result_pose[threadIdx.x] = sh.pose[threadIdx.x];
         __threadfence_system();
         __syncthreads();

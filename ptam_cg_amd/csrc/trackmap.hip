@@ -728,20 +728,23 @@ struct TmSlotLoader {
             } else {
                 c.n_meas = total;
                 c.outlier_by_slot = 1;
-                ptam_trackmap_result& r = mbox->res;
-                r.templates_reused = n_reused;
-                r.pad_ = 0;
-                r.did_coarse = c0.did_coarse;
+                // the frame's integer results: parked in LDS and written to the (host-mapped) result block at the kernel's end —
+                // a store over PCIe issued here is waited for by this wave's next barrier (its release fence), i.e. by everybody
+                int* bk = sh.book;   // ptam_trackmap_result from did_coarse on: did_coarse | n_pvs[4] | attempted[4] | found[4] | n_coarse n_top n_fine n_meas | depth_n | templates_reused | pad_
+                bk[0] = c0.did_coarse;
 #pragma unroll
                 for (int l = 0; l < 4; l++) {
-                    r.n_pvs[l] = c0.n_lvl[l];
-                    r.attempted[l] = a4[l];
-                    r.found[l] = f4[l];
+                    bk[1 + l] = c0.n_lvl[l];
+                    bk[5 + l] = a4[l];
+                    bk[9 + l] = f4[l];
                 }
-                r.n_coarse = c0.nC;
-                r.n_top = c0.nH;
-                r.n_fine = c0.nF;
-                r.n_meas = total;
+                bk[13] = c0.nC;
+                bk[14] = c0.nH;
+                bk[15] = c0.nF;
+                bk[16] = total;
+                bk[17] = 0;
+                bk[18] = n_reused;
+                bk[19] = 0;
             }
         }
         n_found = did ? total : 0;
@@ -752,6 +755,11 @@ struct TmSlotLoader {
         return true;
     }
     __device__ __forceinline__ void load(int, int, int, SmallMeas&) const {}   // (begin has filled the slots)
+    template <class SH>
+    __device__ __forceinline__ void publish(SH& sh) const {
+        static_assert(offsetof(ptam_trackmap_result, pad_) == offsetof(ptam_trackmap_result, did_coarse) + 19 * 4, "ptam_trackmap_result layout");
+        if (stage == 1 && threadIdx.x < 20 && threadIdx.x != 17) (&mbox->res.did_coarse)[threadIdx.x] = sh.book[threadIdx.x];
+    }
     __device__ __forceinline__ bool has_entry() const { return true; }
     __device__ __forceinline__ ptam_projection* td_target(int q, int, const PoseChainIo&) const { return &d.pvs[id[q]].proj; }
     // the slot's record follows the TrackerData the coarse loop leaves (the fine loop starts from it)
@@ -771,6 +779,11 @@ template <int MPT, int THREADS>
 __device__ __forceinline__ void tm_pose_body(const DevCam& cam, const TmDev& d, int stage, unsigned coarse_min, TmMailbox* mbox,
                                              const ptam_gn_opts& opts, const PoseChainIo& io, double* updates, unsigned long long long_seq) {
     TmSlotLoader<MPT, THREADS> ld{d, stage, coarse_min, mbox, long_seq};
+    // (no per-iteration record of the updates: nobody reads it in the chain, and a global store in front of a barrier is waited
+    //  for by the barrier's release fence — ten times per loop, on the frame's critical path)
+#if !defined(K7_TIMING) && !defined(TM_KEEP_UPDATES)   // (TM_KEEP_UPDATES: A/B builds)
+    updates = nullptr;
+#endif
     pose_gn_small_body<MPT, THREADS>(cam, THREADS * MPT, ld, d.pose, opts, stage == 1 ? d.outlier : nullptr, updates, nullptr, 0ull, nullptr, nullptr,
                                      io, 0);
 }
