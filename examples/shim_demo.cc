@@ -170,6 +170,24 @@ int main() {
         for (int i = 0; i < 2; i++)
             same &= both[i].n_meas == one.n_meas && std::memcmp(both[i].pose, one.pose, sizeof one.pose) == 0;
         std::printf("BATCH %d %d %d %d\n", one.n_meas, both[0].n_meas, both[1].n_meas, same);
+        // Tracker::TrackFrame's tracking branch with the motion model (three frames of the same image: the camera stands still,
+        // the velocity stays ~0, the coarse stage off), then the map handed over again in reverse order with every point
+        // persisting: UpdateMap keeps the finders (every template kept), SetMap would start them afresh
+        ptam_motion_model mm;
+        const double id12[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+        ptam_motion_reset(&mm, id12);
+        ptam_trackmap_result tf{};
+        for (int f = 0; f < 3; f++) tf = mt.TrackFrame(curA, (const uint8_t*)dA, mm);
+        std::vector<ptam_pvs_point> ptsR(pts.rbegin(), pts.rend());
+        std::vector<ptam_template_query> srcR(src.rbegin(), src.rend());
+        std::vector<int32_t> prev(pts.size());
+        for (size_t i = 0; i < pts.size(); i++) prev[i] = (int32_t)(pts.size() - 1 - i);
+        mt.UpdateMap(ptsR, srcR, prev);
+        const ptam_trackmap_result tu = mt.TrackFrame(curA, (const uint8_t*)dA, mm);
+        mt.SetMap(ptsR, srcR);
+        const ptam_trackmap_result ts = mt.TrackFrame(curA, (const uint8_t*)dA, mm);
+        std::printf("MOTION %d %d %d %d %d %.3e %.3e\n", tf.n_meas, tf.templates_reused, tu.templates_reused, ts.templates_reused, tf.did_coarse,
+                    mm.msd_scaled_velocity, std::fabs(mm.pose[9]) + std::fabs(mm.pose[10]) + std::fabs(mm.pose[11]));
         ptam_dev_free(ctx.handle(), dA);
         ptam_dev_free(ctxB.handle(), dB);
     }

@@ -397,6 +397,15 @@ public:
         check(ptam_track_map_frame(h_, kfCurrent.handle(), dFrame, in, pOpts, &r), "ptam_track_map_frame");
         return r;
     }
+    // The tracking branch of Tracker::TrackFrame (src/Tracker.cc:94, :134-137) for a camera that moves: MakeKeyFrame_Lite of the
+    // device-resident frame, PredictPoseWithMotionModel, the bTryCoarse heuristics, TrackMap, UpdateMotionModel.  `motion` is the
+    // tracker's model (ptam_motion_reset at Tracker::Reset; motion.just_recovered = 1 after a recovery); motion.pose is
+    // mse3CamFromWorld afterwards.
+    ptam_trackmap_result TrackFrame(KeyFrame& kfCurrent, const uint8_t* dFrame, ptam_motion_model& motion, const ptam_trackmap_opts* pOpts = nullptr) {
+        ptam_trackmap_result r;
+        check(ptam_track_frame(h_, kfCurrent.handle(), dFrame, &motion, pOpts, &r), "ptam_track_frame");
+        return r;
+    }
     // Several cameras (or agents) on one device: ONE chain of launches for all their frames, results as the single calls give
     // them (ptam_track_map_frames_batch).  The trackers live in different Contexts with the same camera model and image size;
     // SetShuffle each of them first.

@@ -69,6 +69,12 @@ def test_shim_demo_matches_oracle(oracle, tmp_path):
     # two trackers in two contexts, one chain of launches: both frames come back exactly as the single call's
     bt = [int(v) for v in next(x for x in lines if x[0] == "BATCH")[1:]]
     assert bt[0] >= 0.8 * t[0] and bt[1] == bt[0] and bt[2] == bt[0] and bt[3] == 1
+    # the motion-model frame call and the map update: a camera that stands still keeps (nearly) zero velocity and every template;
+    # UpdateMap with all points persisting keeps every finder, SetMap starts them afresh
+    mo = next(x for x in lines if x[0] == "MOTION")
+    n_meas, reused_f, reused_u, reused_s, did_coarse = [int(v) for v in mo[1:6]]
+    assert n_meas >= 0.8 * t[0] and reused_f == reused_u and reused_f >= t[0] - 1 and reused_s == 0 and did_coarse == 0
+    assert float(mo[6]) < 1e-3 and float(mo[7]) < 1e-2
     # bundle: replicate the toy problem through the oracle
     ctx = host.Context(lib=oracle)
     ba = host.Bundle(ctx)
