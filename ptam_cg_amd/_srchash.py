@@ -12,7 +12,7 @@ def source_sha16():
     csrc = os.path.join(_HERE, "csrc")
     inc = os.path.join(os.path.dirname(_HERE), "include")
     files = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".inc", ".h")) or f == "Makefile"]
-    files += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith((".h", ".hpp"))]
+    files += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]   # (what the .so is built from: not the header-only C++ shim)
     for p in sorted(files):
         h.update(os.path.basename(p).encode())
         with open(p, "rb") as f:
