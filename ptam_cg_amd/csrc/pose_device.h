@@ -61,9 +61,14 @@ struct PoseIn {
 // keys of the order statistic in LDS, wave sums by DPP (no LDS round trips), same arithmetic and
 // the same fixed reduction order as the general kernel above.
 // ------------------------------------------------------------------------------------------------
+// The workgroup of the large instantiations and the measurements per thread of the largest one (n <= 1024).  Round 4: 512 x 2 —
+// two waves per SIMD.  Rounds 2-3 ran 256 x 4 (one wave per SIMD, the four measurements of a thread interleaved as the only
+// latency hiding) and had measured 512 x 2 as no faster; with the five-barrier order statistic and the wave-0-only finisher gone
+// it is: every phase of an iteration is a chain of dependent instructions at ~6-8 cycles each, and a second wave per SIMD
+// fills the gaps (frame 134.8 -> 129.2 us, A/B on one box: tools/dev/frame_ab.sh).
 #ifndef GS_THREADS
-#define GS_THREADS 256   // the workgroup of the 1024- and 256-measurement instantiations
-#define GS_MPT 4         // measurements per thread of the largest one: n <= 1024
+#define GS_THREADS 512
+#define GS_MPT 2
 #endif
 static_assert(GS_THREADS * GS_MPT == GS_LIMIT, "GS_LIMIT");
 #define GS_WAVE_LIMIT 64 // lists of at most 64 measurements (the coarse set: Tracker.CoarseMax = 60) run as ONE wave — see pose_gn_small_kernel
