@@ -278,6 +278,19 @@ __global__ void __launch_bounds__(256) tm_pyr_pvs_kernel(PyrArgs a, int gx, int 
     else
         track_pvs_body(cam, n, pts, pose_out, out, nullptr, pv, pose_out, b - n_pyr, finder_bad, (int)sizeof(TmFinder));
 }
+// (round 4) launch 1 of a tracked frame: the keyframe's tiles — pyramid pixels + FAST test per tile (keyframe_device.h:
+// kf_fused_tile_body) — beside the PVS pass; launch 2: set choice | corner compaction.  One launch and the pyramid kernel less.
+template <int VARIANT>
+__global__ void __launch_bounds__(256) tm_kf_pvs_kernel(PyrArgs a, KfLevels L, int n_tiles, DevCam cam, int n, const ptam_pvs_point* __restrict__ pts,
+                                                        ptam_pvs_result* __restrict__ out, PoseArg pv, double* __restrict__ pose_out,
+                                                        int* __restrict__ finder_bad) {
+    // workgroup order = start order: the PVS blocks first, then the tiles from the coarsest level (the longest cascade) down
+    const int n_pvs = (int)gridDim.x - n_tiles, b = blockIdx.x;
+    if (b < n_pvs)
+        track_pvs_body(cam, n, pts, pose_out, out, nullptr, pv, pose_out, b, finder_bad, (int)sizeof(TmFinder));
+    else
+        kf_fused_tile_body<VARIANT>(a, L, n_tiles - 1 - (b - n_pvs));
+}
 __global__ void __launch_bounds__(1024) tm_compact_select_kernel(KfLevels L, TmDev d, ptam_trackmap_opts o) {
     if (blockIdx.x == 0)
         tm_select_body(d, o);
@@ -1501,14 +1514,26 @@ static int track_map_impl(ptam_tracker* t, ptam_kf* cur, const uint8_t* d_new_fr
         std::memcpy(pv.v, pose_in, 96);
         pv.use = 1;
         const int n_pyr = gx * gy, n_pvs = std::max(1, (n + 255) / 256);
-        if (ctx->halfsample == PTAM_HALFSAMPLE_T)
-            hipLaunchKernelGGL(tm_pyr_pvs_kernel<PTAM_HALFSAMPLE_T>, dim3(n_pyr + n_pvs), dim3(256), 0, st, pa, gx, n_pyr, ctx->cam, std::max(n, 0),
-                               (const ptam_pvs_point*)d.pts, d.pvs, pv, d.pose, &d.finder->bad);
-        else
-            hipLaunchKernelGGL(tm_pyr_pvs_kernel<PTAM_HALFSAMPLE_R>, dim3(n_pyr + n_pvs), dim3(256), 0, st, pa, gx, n_pyr, ctx->cam, std::max(n, 0),
-                               (const ptam_pvs_point*)d.pts, d.pvs, pv, d.pose, &d.finder->bad);
-        if (prof) hipEventRecord(t->ev[PTAM_TS_DETECT], st);
-        kf_launch_detect(cur, st);
+        static const bool kf_two = ptam_ab_env("PTAM_TM_KF_TWO_LAUNCHES") != nullptr;   // (A/B builds: pyramid | FAST as two launches)
+        if (!kf_two) {
+            const int n_tiles = cur->n_blocks;
+            if (ctx->halfsample == PTAM_HALFSAMPLE_T)
+                hipLaunchKernelGGL(tm_kf_pvs_kernel<PTAM_HALFSAMPLE_T>, dim3(n_tiles + n_pvs), dim3(256), 0, st, pa, cur->L, n_tiles, ctx->cam, std::max(n, 0),
+                                   (const ptam_pvs_point*)d.pts, d.pvs, pv, d.pose, &d.finder->bad);
+            else
+                hipLaunchKernelGGL(tm_kf_pvs_kernel<PTAM_HALFSAMPLE_R>, dim3(n_tiles + n_pvs), dim3(256), 0, st, pa, cur->L, n_tiles, ctx->cam, std::max(n, 0),
+                                   (const ptam_pvs_point*)d.pts, d.pvs, pv, d.pose, &d.finder->bad);
+            if (prof) hipEventRecord(t->ev[PTAM_TS_DETECT], st);
+        } else {
+            if (ctx->halfsample == PTAM_HALFSAMPLE_T)
+                hipLaunchKernelGGL(tm_pyr_pvs_kernel<PTAM_HALFSAMPLE_T>, dim3(n_pyr + n_pvs), dim3(256), 0, st, pa, gx, n_pyr, ctx->cam, std::max(n, 0),
+                                   (const ptam_pvs_point*)d.pts, d.pvs, pv, d.pose, &d.finder->bad);
+            else
+                hipLaunchKernelGGL(tm_pyr_pvs_kernel<PTAM_HALFSAMPLE_R>, dim3(n_pyr + n_pvs), dim3(256), 0, st, pa, gx, n_pyr, ctx->cam, std::max(n, 0),
+                                   (const ptam_pvs_point*)d.pts, d.pvs, pv, d.pose, &d.finder->bad);
+            if (prof) hipEventRecord(t->ev[PTAM_TS_DETECT], st);
+            kf_launch_detect(cur, st);
+        }
         if (prof) hipEventRecord(t->ev[PTAM_TS_COMPACT_SELECT], st);
         hipLaunchKernelGGL(tm_compact_select_kernel, dim3(1 + fast_compact_blocks(cur->L)), dim3(1024), 0, st, cur->L, d, o);
     } else {
@@ -2175,6 +2200,8 @@ void trackmap_preload_kernels() {
     ptam_preload((const void*)tm_pyr_pvs_kernel<PTAM_HALFSAMPLE_R>);
     ptam_preload((const void*)tm_pyr_pvs_kernel<PTAM_HALFSAMPLE_T>);
     ptam_preload((const void*)tm_compact_select_kernel);
+    ptam_preload((const void*)tm_kf_pvs_kernel<PTAM_HALFSAMPLE_R>);
+    ptam_preload((const void*)tm_kf_pvs_kernel<PTAM_HALFSAMPLE_T>);
     ptam_preload((const void*)tm_search_kernel);
     ptam_preload((const void*)tm_gather_kernel);
     ptam_preload((const void*)tm_finder_carry_kernel);

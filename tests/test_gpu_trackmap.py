@@ -290,6 +290,34 @@ def test_batch_keyframes_and_degenerate_maps(hip, size):
         tr.close()
 
 
+@pytest.mark.parametrize("variant", ["R", "T"])
+@pytest.mark.parametrize("size", [(640, 480), (608, 407), (322, 243), (163, 121), (96, 64)], ids=lambda s: f"{s[0]}x{s[1]}")
+def test_track_frame_keyframe_is_make_keyframe_lite(hip, size, variant):
+    """the tracked frame's own keyframe launch (pyramid pixels computed inside the FAST tiles: one word per thread at widths that
+    are multiples of 32, pixel by pixel otherwise) leaves the keyframe exactly as MakeKeyFrame_Lite does — images, corners, row
+    LUTs of all four levels, in both halfSample roundings"""
+    from ptam_cg_amd import _abi
+    w, h = size
+    a, b = synth.make_frame_pair()
+    rng = np.random.default_rng(11)
+    ims = [np.ascontiguousarray(b[:h, :w]), rng.integers(0, 256, (h, w)).astype(np.uint8), np.ascontiguousarray(a[h // 7:h // 7 + h, 5:5 + w]) if h * 8 // 7 <= a.shape[0] and w + 5 <= a.shape[1] else np.ascontiguousarray(a[:h, :w])]
+    cx = host.Context(lib=hip, size=size, halfsample=_abi.HALFSAMPLE_R if variant == "R" else _abi.HALFSAMPLE_T)
+    tr = host.Tracker(cx, 32)
+    ka = host.KeyFrame(cx).MakeKeyFrame_Lite(ims[0])
+    tr.set_map(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3)), ka, np.zeros(0, np.int32), np.zeros((0, 2), np.int32))
+    pose = np.concatenate([np.eye(3).reshape(9), [0.0, 0.0, 1.5]])
+    kb = host.KeyFrame(cx)
+    for im in ims:
+        r = tr.TrackFrame(kb, host.DevBuf(cx, im), pose)
+        assert np.array_equal(r["pose"], pose) and r["n_meas"] == 0
+        want = host.KeyFrame(cx).MakeKeyFrame_Lite(im)
+        for l in range(4):
+            g, q = kb.level(l), want.level(l)
+            assert np.array_equal(g["im"], q["im"]) and np.array_equal(g["corners"], q["corners"]) and np.array_equal(g["rowlut"], q["rowlut"]), (size, l)
+    assert len(kb.level(0)["corners"]) > 0
+    tr.close()
+
+
 def test_batch_with_maps_of_different_sizes(hip):
     """a batch whose maps differ in size: grids are sized for the largest, every frame works on its own counts; the pose
     kernels run in the instantiation the LARGEST list capacity selects, so a small map's sums are taken in another order
