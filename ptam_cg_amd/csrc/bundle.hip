@@ -479,6 +479,10 @@ static int ba_prepare_impl(ptam_ba* ba) {
     if (const char* e = ptam_ab_env("PTAM_K7_LOOP")) ba->k7_loop = ba->use_wave && atoi(e) != 0;   // shape sweeps (tools/k7_only.py)
     ba->k7_threads = ba->k7_loop ? 256 : 1024;   // (one chunk per wave: 1024-thread workgroups halve the
                                                                                  //  camera-partial flush — 12.0 vs 12.3 us at 50 x 5000)
+    // (a small bundle in 1024-thread workgroups leaves most CUs idle — 20 x 3 000: 58 workgroups, four waves per SIMD on 58 CUs —
+    //  and its waves share a SIMD for nothing: 512 threads, 13.5 instead of 14.6 us per launch there; not in deterministic mode,
+    //  which has no such instantiation)
+    if (!ba->k7_loop && ba->opts.deterministic == 0 && n64_all < 16 * 128) ba->k7_threads = 512;
     int n_cu = 256;
     {
         hipDeviceProp_t prop;
