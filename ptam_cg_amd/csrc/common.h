@@ -130,14 +130,14 @@ PTAM_HD void se3_apply(const double* T, double x, double y, double z, double& ox
     oz = T[11] + (T[6] * x + T[7] * y + T[8] * z);
 }
 
-// TooN SE3<>::exp followed by left-multiplication: out = exp(mu) * T
+// TooN SE3<>::exp: the rotation R (row-major) and the translation et of exp(mu)
 template <bool SERIES = false>
-PTAM_HD void se3_exp_mul(const double* mu, const double* T, double* out) {
+PTAM_HD void se3_exp_parts(const double* mu, double* R, double* et) {
     const double one_6th = 1.0 / 6.0, one_20th = 1.0 / 20.0;
     const double tx = mu[0], ty = mu[1], tz = mu[2], wx = mu[3], wy = mu[4], wz = mu[5];
     const double theta_sq = wx * wx + wy * wy + wz * wz;
     const double cx = wy * tz - wz * ty, cy = wz * tx - wx * tz, cz = wx * ty - wy * tx;
-    double A, B, et[3];
+    double A, B;
     if (theta_sq < 1e-8) {
         A = 1.0 - one_6th * theta_sq;
         B = 0.5;
@@ -173,7 +173,6 @@ PTAM_HD void se3_exp_mul(const double* mu, const double* T, double* out) {
         et[1] = ty + B * cy + Cc * dy;
         et[2] = tz + B * cz + Cc * dz;
     }
-    double R[9];
     {
         const double wx2 = wx * wx, wy2 = wy * wy, wz2 = wz * wz;
         R[0] = 1.0 - B * (wy2 + wz2);
@@ -191,6 +190,12 @@ PTAM_HD void se3_exp_mul(const double* mu, const double* T, double* out) {
         R[5] = b - a;
         R[7] = b + a;
     }
+}
+// ... followed by left-multiplication: out = exp(mu) * T
+template <bool SERIES = false>
+PTAM_HD void se3_exp_mul(const double* mu, const double* T, double* out) {
+    double R[9], et[3];
+    se3_exp_parts<SERIES>(mu, R, et);
     double o[12];
     for (int r = 0; r < 3; r++) {
         for (int c = 0; c < 3; c++)

@@ -767,7 +767,11 @@ __device__ __forceinline__ void pose_gn_small_body(const DevCam& cam, int n, LOA
         }
         __syncthreads();
         PH(4)
-        if (tid == 0) {
+        if (wid == 0) {
+            // The 6 x 6 solve and exp() on EVERY lane of wave 0 (an instruction costs the wave the same whether one lane or all
+            // of them are enabled), so that the last step — exp(x) * pose, 36 products, twelve LDS reads and twelve writes on
+            // one thread — is three products, three reads and one write on lanes 0..11: lane 3 r + c forms R'[r][c], lane
+            // 9 + r the translation's row r (the same sums in the same order as se3_exp_mul).
             double x[6] = {0, 0, 0, 0, 0, 0};
             if (nf > 0) {
                 double C[36], b[6];
@@ -783,12 +787,23 @@ __device__ __forceinline__ void pose_gn_small_body(const DevCam& cam, int n, LOA
                 }
                 ldlt6_solve(C, b, x);
             }
-            double np[12];
-            se3_exp_mul<true>(x, sh.pose, np);   // mse3CamFromWorld = SE3<>::exp(v6Update) * mse3CamFromWorld
-            for (int k = 0; k < 12; k++) sh.pose[k] = np[k];
-            for (int k = 0; k < 6; k++) sh.mu[k] = x[k];
-            if (updates)
-                for (int k = 0; k < 6; k++) updates[6 * iter + k] = x[k];
+            double R[9], et[3];
+            se3_exp_parts<true>(x, R, et);   // mse3CamFromWorld = SE3<>::exp(v6Update) * mse3CamFromWorld
+            const int orow = lane < 9 ? lane / 3 : min(lane - 9, 2), ocol = lane < 9 ? lane - 3 * (lane / 3) : 0;
+            const double r0 = orow == 0 ? R[0] : (orow == 1 ? R[3] : R[6]), r1 = orow == 0 ? R[1] : (orow == 1 ? R[4] : R[7]),
+                         r2 = orow == 0 ? R[2] : (orow == 1 ? R[5] : R[8]);
+            const double* Tc = lane < 9 ? sh.pose + ocol : sh.pose + 9;   // column ocol of the rotation (rows 3 apart), or the translation (rows 1 apart)
+            const int ts = lane < 9 ? 3 : 1;
+            const double t0 = Tc[0], t1 = Tc[ts], t2 = Tc[2 * ts];
+            double o = r0 * t0 + r1 * t1 + r2 * t2;
+            if (lane >= 9) o = (orow == 0 ? et[0] : (orow == 1 ? et[1] : et[2])) + o;
+            __builtin_amdgcn_wave_barrier();   // (every lane has read the old pose)
+            if (lane < 12) sh.pose[lane] = o;
+            if (lane == 0) {
+                for (int k = 0; k < 6; k++) sh.mu[k] = x[k];
+                if (updates)
+                    for (int k = 0; k < 6; k++) updates[6 * iter + k] = x[k];
+            }
         }
         __syncthreads();
         PH(5)
