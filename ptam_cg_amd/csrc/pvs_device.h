@@ -10,6 +10,11 @@ __device__ __forceinline__ void track_pvs_body(const DevCam& cam, int n, const p
                                                const double* __restrict__ pose, ptam_pvs_result* __restrict__ out,
                                                int* __restrict__ counts, const PoseArg& pv, double* __restrict__ pose_out, int block,
                                                int* __restrict__ finder_bad = nullptr, int finder_stride = 0) {
+    // No contraction of a * b + c * d in this function: which product the compiler fuses depends on the kernel the body is inlined
+    // into, and the LAST BIT of the warp matrix decides grey levels of the warped template (CVD::transform truncates to a byte,
+    // src/PatchFinder.cc:116) — the batch's PVS kernel and the single frame's gave 3-6 of ~1 000 templates one grey level apart
+    // on maps of 2 000 points (tests/tools/batch_long_lists.py).  Plain products and sums are also what the reference's compiler emits.
+#pragma clang fp contract(off)
     const int i = block * 256 + threadIdx.x;   // (a 256-thread workgroup)
     const int lane = threadIdx.x & 63;
     int level = -1;

@@ -359,6 +359,43 @@ def test_batch_with_maps_of_different_sizes(hip):
         tr.close()
 
 
+@pytest.mark.parametrize("counts", [(900, 500, 300, 200), (1000, 900, 700, 500)], ids=lambda c: f"{sum(c)}pts")
+def test_batch_equals_single_call_on_maps_of_two_thousand_points(hip, counts):
+    """maps beyond the fused pose kernels' 1 024 slots take the gather pass and the small / general pose kernel pair in a batch:
+    the searches must give the single call's positions to the bit, the pose its pose to rounding.  (The PVS body inlined into
+    the batch's kernel and into the single frame's had fused different products of the warp matrix: last-bit differences, one
+    grey level in 3-6 of ~1 000 warped templates, sub-pixel fits 0.01 px and one corner apart — pvs_device.h now computes
+    uncontracted.)  Also with a patch budget above the kernels' limit (the general pose kernel on both sides)."""
+    a, b = synth.make_frame_pair()
+    ctx = host.Context(lib=hip)
+    ka = host.KeyFrame(ctx).MakeKeyFrame_Lite(a)
+    case = synth.make_trackmap_case([ka.level(l) for l in range(4)], counts=counts, seed=300)
+    tr = host.Tracker(ctx, len(case["world"]))
+    kb, di = host.KeyFrame(ctx), host.DevBuf(ctx, b)
+
+    def fresh():   # (the same history on both sides: set_map starts every point's PatchFinder afresh)
+        tr.set_map(case["world"], case["pixel_right_w"], case["pixel_down_w"], ka, case["src_level"], case["center"])
+        tr.set_shuffle(case["shuffle_levels"], case["shuffle_fine"])
+
+    for budget in (1000, 2000):
+        opts = tr.opts(max_patches=budget)
+        fresh()
+        single = tr.TrackFrame(kb, di, case["pose_in"], opts).copy()
+        its = tr.iteration_set().copy()
+        fresh()
+        res = host.Tracker.TrackFramesBatch([tr], [kb], [di], [case["pose_in"]], opts)[0]
+        itb = tr.iteration_set()
+        for f in its.dtype.names:
+            assert np.array_equal(its[f], itb[f]), (budget, f)
+        for f in res.dtype.names:
+            if f in ("pose", "depth_sum", "depth_sum_sq"):
+                assert np.allclose(res[f], single[f], rtol=1e-12, atol=1e-12), (budget, f)
+            else:
+                assert np.array_equal(res[f], single[f]), (budget, f)
+        assert single["n_meas"] > (900 if budget == 1000 else 1024)
+    tr.close()
+
+
 @pytest.mark.parametrize("tile", [1, 4], ids=["2561pts_lds_lists", "10244pts_global_lists"])
 def test_track_map_large_maps(hip, tile):
     """maps beyond the one- and two-entries-per-thread runs of the set choice: 2 561 points (LDS level lists, three entries per
