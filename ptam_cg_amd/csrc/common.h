@@ -98,7 +98,11 @@ int ctx_pinned(ptam_ctx* ctx, size_t bytes, void** out);      // pinned host sta
 #define PTAM_HD __host__ __device__ __forceinline__
 
 // rtrans_factor include/ATANCamera.h:143-149 + Project src/ATANCamera.cc:109-121
+// (cam_project, cam_derivs, se3_apply: no FMA contraction — which product of a * b + c * d gets fused depends on the kernel a copy is
+//  inlined into, and these feed truncations: ir() of the image position, the grey levels of a warped template through the warp
+//  matrix.  Plain products and sums are what the reference's compiler emits: pvs_device.h)
 PTAM_HD void cam_project(const DevCam& c, double x, double y, double& u, double& v, double& r, double& f) {
+#pragma clang fp contract(off)
     r = sqrt(x * x + y * y);
     f = (r < 0.001 || c.w == 0.0) ? 1.0 : (c.w_inv * atan(r * c.two_tan) / r);
     u = c.cx + c.fx * (f * x);
@@ -106,6 +110,7 @@ PTAM_HD void cam_project(const DevCam& c, double x, double y, double& u, double&
 }
 // GetProjectionDerivs src/ATANCamera.cc:179-209 for the projection (x, y, r, f)
 PTAM_HD void cam_derivs(const DevCam& c, double x, double y, double r_in, double f, double D[4]) {
+#pragma clang fp contract(off)
     const double k = c.two_tan;
     const double r = r_in * c.dist_enabled;
     double dx, dy;
@@ -125,6 +130,7 @@ PTAM_HD void cam_derivs(const DevCam& c, double x, double y, double r_in, double
 
 // pose = R row-major (9) + t (3)
 PTAM_HD void se3_apply(const double* T, double x, double y, double z, double& ox, double& oy, double& oz) {
+#pragma clang fp contract(off)
     ox = T[9] + (T[0] * x + T[1] * y + T[2] * z);
     oy = T[10] + (T[3] * x + T[4] * y + T[5] * z);
     oz = T[11] + (T[6] * x + T[7] * y + T[8] * z);

@@ -82,11 +82,14 @@ def _check(res, it, ref, strict):
             print("chain vs oracle stages on the device's warp matrices: max |dv| %.2e px over %d found patches, max |dpose| %.2e"
                   % (dv.max() if dv.size else 0.0, dv.size, np.abs(res["pose"] - ref["pose"]).max()))
     else:
-        # CVD::transform truncates the interpolated value to a byte (src/PatchFinder.cc:116): last-bit differences of the PVS
-        # warp matrix (device atan / FMA vs glibc) flip one grey level in about 1 % of the warped templates, which moves
-        # the sub-pixel fit of those patches by up to ~0.1 px (found / not found, levels, outlier flags are unaffected)
-        assert (dv <= 0.3).all() and (dv.size == 0 or (dv > 1e-6).mean() <= 0.05)
-        assert np.allclose(res["pose"], ref["pose"], rtol=0, atol=2e-5)
+        # CVD::transform truncates the interpolated value to a byte (src/PatchFinder.cc:116): a last-bit difference of the PVS warp
+        # matrix can flip one grey level of a warped template, which moves that patch's sub-pixel fit by up to ~0.1 px (found /
+        # not found, levels, outlier flags are unaffected).  Rounds 2-3: ~1 % of the templates (the device's PVS had its a * b +
+        # c * d fused into FMAs, the oracle's compiler emits none), 5 % of the positions allowed here and 2e-5 on the pose.  Round
+        # 4: pvs_device.h computes uncontracted — what is left is the device's atan against glibc's: ONE template in the
+        # eight scenarios (0.026 px, pose 2.6e-6), every other position within 3e-7 px
+        assert (dv <= 0.3).all() and (dv > 1e-6).sum() <= max(2, int(0.005 * dv.size))
+        assert np.allclose(res["pose"], ref["pose"], rtol=0, atol=5e-6)
     assert res["depth_n"] == ref["depth"][2]
     tol = 1e-12 if strict is True else (1e-9 if strict else 1e-5)
     assert np.isclose(res["depth_sum"], ref["depth"][0], rtol=tol) and np.isclose(res["depth_sum_sq"], ref["depth"][1], rtol=tol)
