@@ -6,6 +6,26 @@
 
 // pv.use: the pose travels as a kernel argument (the resident TrackMap chain: the motion model's prediction needs no copy of
 // its own) and block 0 also leaves it in pose_out for the kernels that follow
+// mm2WarpInverse of CalcSearchLevelAndWarpMatrix (src/PatchFinder.cc:52-69) and its determinant: ONE copy for the PVS pass and the
+// two ReFind kernels, uncontracted (see track_pvs_body)
+__device__ __forceinline__ double pvs_warp_matrix(const double* T, double X, double Y, double Z, const double* D, const ptam_pvs_point& p, double* W) {
+#pragma clang fp contract(off)
+    const double iz = 1.0 / Z;
+    double mr[3], md[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        mr[a] = T[a * 3] * p.pixel_right_w[0] + T[a * 3 + 1] * p.pixel_right_w[1] + T[a * 3 + 2] * p.pixel_right_w[2];
+        md[a] = T[a * 3] * p.pixel_down_w[0] + T[a * 3 + 1] * p.pixel_down_w[1] + T[a * 3 + 2] * p.pixel_down_w[2];
+    }
+    const double ax = (mr[0] - X * mr[2] * iz) * iz, ay = (mr[1] - Y * mr[2] * iz) * iz;
+    const double bx = (md[0] - X * md[2] * iz) * iz, by = (md[1] - Y * md[2] * iz) * iz;
+    W[0] = D[0] * ax + D[1] * ay;
+    W[2] = D[2] * ax + D[3] * ay;
+    W[1] = D[0] * bx + D[1] * by;
+    W[3] = D[2] * bx + D[3] * by;
+    return W[0] * W[3] - W[1] * W[2];
+}
+
 __device__ __forceinline__ void track_pvs_body(const DevCam& cam, int n, const ptam_pvs_point* __restrict__ pts,
                                                const double* __restrict__ pose, ptam_pvs_result* __restrict__ out,
                                                int* __restrict__ counts, const PoseArg& pv, double* __restrict__ pose_out, int block,
@@ -47,22 +67,8 @@ __device__ __forceinline__ void track_pvs_body(const DevCam& cam, int n, const p
         }
         if (r.proj.in_image) {
             // CalcSearchLevelAndWarpMatrix src/PatchFinder.cc:52-84
-            const double* D = r.proj.derivs;
-            const double iz = 1.0 / Z;
-            double mr[3], md[3];
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                mr[a] = T[a * 3] * p.pixel_right_w[0] + T[a * 3 + 1] * p.pixel_right_w[1] + T[a * 3 + 2] * p.pixel_right_w[2];
-                md[a] = T[a * 3] * p.pixel_down_w[0] + T[a * 3 + 1] * p.pixel_down_w[1] + T[a * 3 + 2] * p.pixel_down_w[2];
-            }
-            const double ax = (mr[0] - X * mr[2] * iz) * iz, ay = (mr[1] - Y * mr[2] * iz) * iz;
-            const double bx = (md[0] - X * md[2] * iz) * iz, by = (md[1] - Y * md[2] * iz) * iz;
             double* W = r.warp_inverse;   // mm2WarpInverse; .T()[0] / .T()[1] are its columns
-            W[0] = D[0] * ax + D[1] * ay;
-            W[2] = D[2] * ax + D[3] * ay;
-            W[1] = D[0] * bx + D[1] * by;
-            W[3] = D[2] * bx + D[3] * by;
-            double det = W[0] * W[3] - W[1] * W[2];
+            double det = pvs_warp_matrix(T, X, Y, Z, r.proj.derivs, p, W);
             int l = 0;
             while (det > 3 && l < PTAM_LEVELS - 1) {
                 l++;

@@ -849,20 +849,7 @@ __global__ void __launch_bounds__(256) refind_prep_kernel(DevCam cam, int n, con
             if (!(rr > cam.max_r) && !(u < 0 || v < 0 || u > cam.width || v > cam.height)) {
                 double D[4];
                 cam_derivs(cam, x, y, rr, f, D);
-                const double iz = 1.0 / Z;
-                double mr[3], md[3];
-#pragma unroll
-                for (int a = 0; a < 3; a++) {
-                    mr[a] = T[a * 3] * p.pixel_right_w[0] + T[a * 3 + 1] * p.pixel_right_w[1] + T[a * 3 + 2] * p.pixel_right_w[2];
-                    md[a] = T[a * 3] * p.pixel_down_w[0] + T[a * 3 + 1] * p.pixel_down_w[1] + T[a * 3 + 2] * p.pixel_down_w[2];
-                }
-                const double ax = (mr[0] - X * mr[2] * iz) * iz, ay = (mr[1] - Y * mr[2] * iz) * iz;
-                const double bx = (md[0] - X * md[2] * iz) * iz, by = (md[1] - Y * md[2] * iz) * iz;
-                j.wi[0] = D[0] * ax + D[1] * ay;
-                j.wi[2] = D[2] * ax + D[3] * ay;
-                j.wi[1] = D[0] * bx + D[1] * by;
-                j.wi[3] = D[2] * bx + D[3] * by;
-                double det = j.wi[0] * j.wi[3] - j.wi[1] * j.wi[2];
+                double det = pvs_warp_matrix(T, X, Y, Z, D, p, j.wi);
                 int l = 0;
                 while (det > 3 && l < PTAM_LEVELS - 1) {
                     l++;
@@ -987,20 +974,7 @@ __global__ void __launch_bounds__(256) rp_prep_kernel(DevCam cam, RpDev d) {
             if (!(rr > cam.max_r) && !(u < 0 || v < 0 || u > cam.width || v > cam.height)) {   // :963-975
                 double D[4];
                 cam_derivs(cam, x, y, rr, f, D);
-                const double iz = 1.0 / Z;
-                double mr[3], md[3];
-#pragma unroll
-                for (int a = 0; a < 3; a++) {
-                    mr[a] = T[a * 3] * p.pixel_right_w[0] + T[a * 3 + 1] * p.pixel_right_w[1] + T[a * 3 + 2] * p.pixel_right_w[2];
-                    md[a] = T[a * 3] * p.pixel_down_w[0] + T[a * 3 + 1] * p.pixel_down_w[1] + T[a * 3 + 2] * p.pixel_down_w[2];
-                }
-                const double ax = (mr[0] - X * mr[2] * iz) * iz, ay = (mr[1] - Y * mr[2] * iz) * iz;
-                const double bx = (md[0] - X * md[2] * iz) * iz, by = (md[1] - Y * md[2] * iz) * iz;
-                j.wi[0] = D[0] * ax + D[1] * ay;
-                j.wi[2] = D[2] * ax + D[3] * ay;
-                j.wi[1] = D[0] * bx + D[1] * by;
-                j.wi[3] = D[2] * bx + D[3] * by;
-                double det = j.wi[0] * j.wi[3] - j.wi[1] * j.wi[2];
+                double det = pvs_warp_matrix(T, X, Y, Z, D, p, j.wi);
                 int l = 0;
                 while (det > 3 && l < PTAM_LEVELS - 1) {
                     l++;
