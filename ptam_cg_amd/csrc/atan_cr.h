@@ -51,6 +51,7 @@ __device__ __forceinline__ double atan_cr(double x_in) {
     const double PI2_HI = 0x1.921fb54442d18p+0, PI2_LO = 0x1.1a62633145c07p-54;
     const double ax = x_in < 0 ? -x_in : x_in;
     if (!(ax == ax)) return x_in;
+    if (ax > 0x1p1000) return x_in < 0 ? -PI2_HI : PI2_HI;   // (1 / x underflows its correction term; the result is pi/2 rounded from 2^54 on anyway)
     const bool recip = ax > 2.0;
     // t = ax, or 1 / ax in double-double
     double th = ax, tl = 0.0;

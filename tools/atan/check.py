@@ -3,7 +3,7 @@ import numpy as np, mpmath as mp, subprocess, os, sys
 here = os.path.dirname(os.path.abspath(__file__))
 rng = np.random.default_rng(3)
 x = np.concatenate([rng.uniform(0, 2.0, 200000), rng.uniform(2.0, 50.0, 20000), -rng.uniform(0, 3.0, 20000), 10.0 ** rng.uniform(-12, 4, 20000),
-                    np.arange(0, 65) / 32.0, [0.0, 1e-300, 1e300, 2.0, 2.0000000000000004, 0.015625, 0.984375]])
+                    np.arange(0, 65) / 32.0, [0.0, 1e-300, 1e300, 1e305, np.inf, -np.inf, 2.0, 2.0000000000000004, 0.015625, 0.984375]])
 x.tofile("/tmp/atan_in.bin")
 subprocess.check_call([os.path.join(here, "atan_cr_check"), "/tmp/atan_in.bin", "/tmp/atan_out.bin"])
 o = np.fromfile("/tmp/atan_out.bin")
