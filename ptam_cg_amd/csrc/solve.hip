@@ -345,16 +345,24 @@ int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
         // 96 / 133 at 13 (dense: from 14 block rows on a worker's tiles no longer fit), 105 / 149 at 15 rows of band 5,
         // 202 / 287 at 28 of band 9.  (Where two chains apply they win: 137 against 152 at 23 rows of band 2.)
         static const bool no_chain = getenv("PTAM_LDLT_NO_CHAIN") != nullptr;   // (A/B runs)
-        const size_t lds = ch_lds_bytes(band);
+        // (the right-hand-side workgroup of that launch also substitutes backwards — ldlt_chain.inc, "and backwards" — when
+        //  its vectors fit beside a row worker's tiles; PTAM_LDLT_SEPARATE_BACKWARD=1: ldlt_backward_kernel behind it, A/B runs)
+        static const bool sep_bw = getenv("PTAM_LDLT_SEPARATE_BACKWARD") != nullptr;
+        // (measured, tools/ldlt, us per solve inside / behind the launch: 28.8 / 29.7 at 4 block rows, 47.4 / 47.9 at 7, 69.0 / 68.4 at 10 — one
+        //  compute unit fetches a tile from the L2 in ~200 cycles, 34 B per cycle, whoever asks; so only where the rows are short)
+        const bool bw_in = !sep_bw && nblk <= CH_BW_NBLK && band <= CH_BW_MAXT && ch_lds_bytes_bw(band, nblk) <= CH_LDS_MAX;
+        const size_t lds = bw_in ? ch_lds_bytes_bw(band, nblk) : ch_lds_bytes(band);
         if (t_end == 0 && !no_chain && !d.chain_off && d.sflags && nblk <= CH_MAX_NB && lds <= CH_LDS_MAX) {
             d.solve_seq++;
             if (d.solve_seq >= (1u << 27)) d.solve_seq = 1;   // (flags carry it shifted by up to 4 bits; flags of 2^27 solves ago are no concern)
             {
                 const ChainArgs a = chain_args_natural(d, 0, nblk, nblk);
-                hipLaunchKernelGGL(ldlt_chain_kernel, dim3(8 * ch_roles(nblk)), dim3(TPB), lds, ctx->stream, d, a, a, 1);
+                hipLaunchKernelGGL(ldlt_chain_kernel, dim3(8 * ch_roles(nblk)), dim3(TPB), lds, ctx->stream, d, a, a, 1, cur, bw_in ? 1 : 0);
             }
-            const size_t bw = (size_t)6 * d.npad * sizeof(double);
-            hipLaunchKernelGGL(ldlt_backward_kernel<false>, dim3(1), dim3(1024), bw, ctx->stream, d, cur, nblk);
+            if (!bw_in) {
+                const size_t bw = (size_t)6 * d.npad * sizeof(double);
+                hipLaunchKernelGGL(ldlt_backward_kernel<false>, dim3(1), dim3(1024), bw, ctx->stream, d, cur, nblk);
+            }
             HIP_TRY(hipGetLastError());
             return PTAM_OK;
         }
@@ -371,7 +379,7 @@ int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
         hipLaunchKernelGGL(ldlt_mirror_in_kernel, dim3(kr2 * (band + 1)), dim3(TPB), 0, ctx->stream, d, kr2);
         const ChainArgs a0 = chain_args_natural(d, 0, t_end, kr2);
         const ChainArgs a1{d.SE2, d.SE2 + se_size(nblk, band), d.L2, d.Dg2, d.y2, d.sflags2, 0, t_end, kr2, d.npad};   // (mirrored: the padding comes first, nothing to skip)
-        hipLaunchKernelGGL(ldlt_chain_kernel, dim3(8 * ch_roles(kr2)), dim3(TPB), ch_lds_bytes(band), ctx->stream, d, a0, a1, 2);
+        hipLaunchKernelGGL(ldlt_chain_kernel, dim3(8 * ch_roles(kr2)), dim3(TPB), ch_lds_bytes(band), ctx->stream, d, a0, a1, 2, cur, 0);
         hipLaunchKernelGGL(ldlt_mirror_out_kernel, dim3(kr2 * (band + 1)), dim3(TPB), 0, ctx->stream, d, t_end, kr2);
     }
     for (int st = 0; st < (two_persistent ? 0 : t_end); st++) {   // one step of each chain per launch
@@ -390,7 +398,7 @@ int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
             if (d.solve_seq >= (1u << 27)) d.solve_seq = 1;
             {
                 const ChainArgs a = chain_args_natural(d, t_end, b_start, b_start);
-                hipLaunchKernelGGL(ldlt_chain_kernel, dim3(8 * ch_roles(n_mid)), dim3(TPB), lds, ctx->stream, d, a, a, 1);
+                hipLaunchKernelGGL(ldlt_chain_kernel, dim3(8 * ch_roles(n_mid)), dim3(TPB), lds, ctx->stream, d, a, a, 1, cur, 0);
             }
         } else {
             for (int k = t_end; k < b_start; k++) {

@@ -94,6 +94,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d.Dg2, npad * 8));
     CK(hipMalloc(&d.y2, npad * 8));
     CK(hipMemset(d.sflags, 0, ba_solve_flag_bytes(nblk)));
+    d.spin_limit = CH_SPIN_DEFAULT;   // (a zero limit makes every wait of the persistent form give up at once)
+    CK(hipMalloc(&d.sc, sizeof(BaScalars)));
+    CK(hipMemset(d.sc, 0, sizeof(BaScalars)));
     CK(hipMalloc(&dbg, 65536 * 8));
     CK(hipMemset(dbg, 0, 65536 * 8));
     d.dbg = (long long*)dbg;
@@ -121,6 +124,11 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(da.data(), d.da, npad * 8, hipMemcpyDeviceToHost));
     double err = 0, nrm = 0;
     for (int i = 0; i < n; i++) err = std::max(err, fabs(da[i] - x[i])), nrm = std::max(nrm, fabs(x[i]));
+    {
+        BaScalars sc;
+        CK(hipMemcpy(&sc, d.sc, sizeof sc, hipMemcpyDeviceToHost));
+        if (sc.solve_fault) printf("SOLVE FAULT: a wait of the persistent form gave up\n");
+    }
     printf("F %d n %d nblk %d band %d: %.2f us per solve (copy included), max |da - ref| = %.3e (|ref| max %.3e) %s\n", F, n, nblk, band,
            1e3 * best / reps, err, nrm, err <= 1e-11 * nrm + 1e-300 ? "OK" : "MISMATCH");
 #ifdef K7_TIMING
@@ -171,6 +179,36 @@ int main(int argc, char** argv) {
         printf("stamps (cycles between consecutive ones):");
         for (int i = 1; i < 400 && st[32 + i]; i++) printf(" %lld", st[32 + i] - st[31 + i]);
         printf("\n");
+    }
+#endif
+#ifdef K7_TIMING
+    {
+        std::vector<long long> st(8 * 64 + 8);
+        CK(hipMemcpy(st.data(), dbg + 1392, st.size() * 8, hipMemcpyDeviceToHost));
+        const long long* q0 = &st[8];
+        if (st[7]) {
+            printf("backward inside the launch, per block (cycles): next row requested | barrier A, v, barrier | mat-vec | barrier C | products | (to next block's top)\n");
+            for (int k = nblk - 1; k >= 0; k--) {
+                const long long* q = q0 + 8 * k;
+                printf("  k %2d: %5lld %5lld %5lld %5lld %5lld (%lld)   top at %lld\n", k, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4],
+                       k > 0 ? q0[8 * (k - 1)] - q[5] : 0, q[0] - st[7]);
+            }
+            printf("  epilogue starts at %lld (cycles after the forward pass ended)\n", st[6] - st[7]);
+        }
+    }
+#endif
+#ifdef FL_STAMPS
+    {
+        std::vector<long long> st(4 * 32);
+        CK(hipMemcpy(st.data(), dbg + 1200, st.size() * 8, hipMemcpyDeviceToHost));
+        printf("factor loop of step 2, per wave and iteration (cycles): top -> before MFMA | MFMA issued -> before publish | publish -> before barrier | barrier -> next top\n");
+        for (int w = 0; w < 4; w++)
+            for (int t = 0; t < 8; t++) {
+                const long long* q = &st[32 * w + 4 * t];
+                if (!q[0]) continue;
+                printf("  wave %d t %d: %5lld %5lld %5lld %5lld   (top at %lld)\n", w, t, q[1] ? q[1] - q[0] : 0, q[2] ? q[2] - q[1] : 0, q[3] - (q[2] ? q[2] : q[0]),
+                       t < 7 && q[4] ? q[4] - q[3] : 0, q[0] - st[0]);
+            }
     }
 #endif
 #ifdef K7_TIMING
