@@ -201,13 +201,12 @@ int main(int argc, char** argv) {
     {
         std::vector<long long> st(4 * 32);
         CK(hipMemcpy(st.data(), dbg + 1200, st.size() * 8, hipMemcpyDeviceToHost));
-        printf("factor loop of step 2, per wave and iteration (cycles): top -> before MFMA | MFMA issued -> before publish | publish -> before barrier | barrier -> next top\n");
+        printf("factor loop of step 2, per wave and iteration (cycles): top -> MFMAs issued | -> at the barrier | barrier -> next top   (top, relative to wave 0's first)\n");
         for (int w = 0; w < 4; w++)
             for (int t = 0; t < 8; t++) {
                 const long long* q = &st[32 * w + 4 * t];
                 if (!q[0]) continue;
-                printf("  wave %d t %d: %5lld %5lld %5lld %5lld   (top at %lld)\n", w, t, q[1] ? q[1] - q[0] : 0, q[2] ? q[2] - q[1] : 0, q[3] - (q[2] ? q[2] : q[0]),
-                       t < 7 && q[4] ? q[4] - q[3] : 0, q[0] - st[0]);
+                printf("  wave %d t %d: %5lld %5lld %5lld   (top at %lld)\n", w, t, q[1] - q[0], q[2] - q[1], t < 7 && q[4] ? q[4] - q[2] : 0, q[0] - st[0]);
             }
     }
 #endif
