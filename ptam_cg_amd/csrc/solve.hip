@@ -350,7 +350,7 @@ int ba_solve(ptam_ctx* ctx, BaDev& d, int cur) {
         static const bool sep_bw = getenv("PTAM_LDLT_SEPARATE_BACKWARD") != nullptr;
         // (measured, tools/ldlt, us per solve inside / behind the launch: 28.8 / 29.7 at 4 block rows, 47.4 / 47.9 at 7, 69.0 / 68.4 at 10 — one
         //  compute unit fetches a tile from the L2 in ~200 cycles, 34 B per cycle, whoever asks; so only where the rows are short)
-        const bool bw_in = !sep_bw && nblk <= CH_BW_NBLK && band <= CH_BW_MAXT && ch_lds_bytes_bw(band, nblk) <= CH_LDS_MAX;
+        const bool bw_in = !sep_bw && band <= CH_BW_MAXT && ch_lds_bytes_bw(band, nblk) <= CH_LDS_MAX;
         const size_t lds = bw_in ? ch_lds_bytes_bw(band, nblk) : ch_lds_bytes(band);
         if (t_end == 0 && !no_chain && !d.chain_off && d.sflags && nblk <= CH_MAX_NB && lds <= CH_LDS_MAX) {
             d.solve_seq++;

@@ -187,11 +187,10 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(st.data(), dbg + 1392, st.size() * 8, hipMemcpyDeviceToHost));
         const long long* q0 = &st[8];
         if (st[7]) {
-            printf("backward inside the launch, per block (cycles): next row requested | barrier A, v, barrier | mat-vec | barrier C | products | (to next block's top)\n");
+            printf("backward inside the launch, per block (cycles): wave 0: chain | diag request | at barrier B -> released | (wave 1: top -> barrier B released)   top at\n");
             for (int k = nblk - 1; k >= 0; k--) {
                 const long long* q = q0 + 8 * k;
-                printf("  k %2d: %5lld %5lld %5lld %5lld %5lld (%lld)   top at %lld\n", k, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4],
-                       k > 0 ? q0[8 * (k - 1)] - q[5] : 0, q[0] - st[7]);
+                printf("  k %2d: %5lld %5lld %5lld   (%lld)   top at %lld\n", k, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[7] - q[4], q[0] - st[7]);
             }
             printf("  epilogue starts at %lld (cycles after the forward pass ended)\n", st[6] - st[7]);
         }
