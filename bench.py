@@ -474,7 +474,7 @@ def main():
         ctx._check(hip.rccl_create(ctx.h, ident, rank, world, ctypes.byref(comm)), "rccl_create")
         hook = ctypes.cast(hip.lib.ptam_rccl_allreduce_f64, _abi.ALLREDUCE_FN)
 
-    prepare_ms = []   # host + upload time of every ptam_ba_prepare of this run (never part of `value`)
+    prepare_ms = []   # host + upload time of every ptam_ba_prepare of this run (never part of `value`; docs/LOG_r01_r04.md section 5)
 
     def new_bundle(max_it, problem=None, sharded=True):
         ba = synth.load_into(host.Bundle(ctx, max_iterations=max_it, update_sq_conv_limit=0.0, deterministic=1 if args.deterministic else 0),

@@ -1132,7 +1132,7 @@ __global__ void __launch_bounds__(64) rp_state_kernel(RpDev d) {
 // ---- a batch of frames in ONE chain of launches (ptam_track_map_frames_batch) ----
 // A process gets four hardware queues, and a tracked frame occupies its queue for the whole dependent chain (two
 // single-workgroup pose loops are 94 of its ~157 us): whatever the chip has idle, at most four frames of independent
-// trackers are in flight (20 k frames/s).  A batch runs the SAME chain once for nb trackers: every
+// trackers are in flight (20 k frames/s, docs/LOG_r01_r04.md section 5).  A batch runs the SAME chain once for nb trackers: every
 // launch gets a second grid dimension, workgroup row y works on frame y with that frame's arguments taken from a device
 // array — the kernels' bodies are the single-frame ones.
 struct TmBatchItem {
