@@ -10,41 +10,42 @@
 // TooN Cholesky<6> (unpivoted LDL^T, lower triangle) + backsub, run by one thread
 // (reciprocals by v_rcp_f64 + two Newton steps, as everywhere in the bundle kernels: one thread runs this on the critical
 //  path of every iteration, and an IEEE division is a dependent chain of ~12 instructions — twelve of them were half of it)
+// RIGHT-LOOKING (round 5): after pivot k every element of the trailing triangle takes its update at once — the same
+// subtractions in the same order per element as TooN's left-looking loops (pivots ascending, one FMA each: the same bits),
+// but fifteen independent FMAs per pivot instead of chains of them: one lane's dependent fp64 instructions cost ~8 cycles
+// each, independent ones 4.  The forward substitution is column-oriented for the same reason (same order: columns
+// ascending); the backward one keeps TooN's row-wise order (columns ascending inside a row), which is its dependent form.
 static __device__ void ldlt6_solve(double A[36], const double b[6], double x[6]) {
-    double inv_d[6];
+    double inv_d[6], l[6][6];   // l[i][k]: multipliers (i > k)
 #pragma unroll
-    for (int col = 0; col < 6; col++) {
-        double inv_diag = 1;
+    for (int k = 0; k < 6; k++) {
+        const double inv = rcp_nr(A[k * 6 + k]);
+        inv_d[k] = inv;
+        double u[6];
 #pragma unroll
-        for (int row = col; row < 6; row++) {
-            double val = A[row * 6 + col];
-#pragma unroll
-            for (int c2 = 0; c2 < col; c2++) val -= A[c2 * 6 + col] * A[row * 6 + c2];
-            if (row == col) {
-                A[row * 6 + col] = val;
-                inv_diag = rcp_nr(val);
-                inv_d[col] = inv_diag;
-            } else {
-                A[col * 6 + row] = val;
-                A[row * 6 + col] = val * inv_diag;
-            }
+        for (int i = k + 1; i < 6; i++) {
+            u[i] = A[i * 6 + k];        // the undivided column
+            l[i][k] = u[i] * inv;
         }
+#pragma unroll
+        for (int j = k + 1; j < 6; j++)
+#pragma unroll
+            for (int i = j; i < 6; i++) A[i * 6 + j] = fma(-u[j], l[i][k], A[i * 6 + j]);
     }
     double y[6];
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        double val = b[i];
+    for (int i = 0; i < 6; i++) y[i] = b[i];
 #pragma unroll
-        for (int j = 0; j < i; j++) val -= A[i * 6 + j] * y[j];
-        y[i] = val;
-    }
+    for (int j = 0; j < 5; j++)
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) y[i] = fma(-l[i][j], y[j], y[i]);
 #pragma unroll
     for (int i = 0; i < 6; i++) y[i] *= inv_d[i];
 #pragma unroll
     for (int i = 5; i >= 0; i--) {
         double val = y[i];
 #pragma unroll
-        for (int j = i + 1; j < 6; j++) val -= A[j * 6 + i] * x[j];
+        for (int j = i + 1; j < 6; j++) val = fma(-l[j][i], x[j], val);
         x[i] = val;
     }
 }

@@ -382,6 +382,31 @@ def test_bundle_deterministic_mode_headline_size(hip):
     assert np.allclose(a["trials"]["err_new"], c["trials"]["err_new"], rtol=1e-9)
 
 
+def test_bundle_headline_full_length_deterministic_against_oracle(hip, oracle):
+    """the headline problem at its FULL length — Bundle.MaxIterations = 20 trials — in deterministic
+    mode against the oracle, trial by trial (lambda, accept / reject, bad counts, sigma^2, errors, outliers, poses, points).
+    (a) as PTAM runs it (convergence test on): the whole trajectory; (b) as bench.py runs it (convergence limit 0: exactly 20
+    trials, the second half at the noise floor, where a trial comes back with new == current error to the last bit or 4e-12
+    better): the whole trajectory up to the first trial whose improvement is below 1e-9 of the error — from there on the
+    discrete outcome is decided by the last bits of two different summation orders — and every error to 1e-6 throughout."""
+    prob = synth.make_ba_problem(**BA_BIG_CASES["headline_50x5000"])
+    rh = util.run_ba(hip, prob, max_iterations=20, deterministic=1)
+    ro = util.run_ba(oracle, prob, max_iterations=20)
+    util.assert_ba_equal(rh, ro, rel=1e-6)
+    assert rh["accepted"] >= 5
+    rh0 = util.run_ba(hip, prob, max_iterations=20, update_sq_conv_limit=0.0, deterministic=1)
+    ro0 = util.run_ba(oracle, prob, max_iterations=20, update_sq_conv_limit=0.0)
+    th, to = rh0["trials"], ro0["trials"]
+    assert len(th) == len(to) == 20
+    floor = next((i for i, x in enumerate(to) if abs(x["err_new"] - x["err_old"]) <= 1e-9 * abs(x["err_old"])), 20)
+    assert floor >= 5, floor
+    for i in range(floor):
+        assert th[i]["lambda"] == to[i]["lambda"] and th[i]["accepted"] == to[i]["accepted"] and th[i]["n_bad"] == to[i]["n_bad"], i
+    for i in range(20):
+        for k in ("err_old", "err_new"):
+            assert abs(th[i][k] - to[i][k]) <= 1e-6 * abs(to[i][k]), (i, k, th[i][k], to[i][k])
+
+
 def _fuzz_cases(n=18, seed=2024):
     rng = np.random.default_rng(seed)
     out = []
