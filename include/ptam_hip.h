@@ -455,7 +455,8 @@ void ptam_se3_ln(const double pose[12], double mu_out[6]);
 /* One tracked frame of a camera that moves (src/Tracker.cc:134-137 with :94 before them): MakeKeyFrame_Lite of the
  * device-resident frame into `current`, PredictPoseWithMotionModel, the bTryCoarse heuristics (*opts is the caller's tunables;
  * its try_coarse is ignored and decided here, coarse_max / coarse_range doubled after a recovery), TrackMap from the predicted
- * pose, UpdateMotionModel.  m->pose is the tracked pose afterwards. */
+ * pose, UpdateMotionModel.  m->pose is the tracked pose afterwards.  A call that returns an error leaves *m untouched (the
+ * model is advanced on a copy and committed on success): the frame can be retried. */
 int ptam_track_frame(ptam_tracker* t, ptam_kf* current, const uint8_t* d_frame, ptam_motion_model* m,
                      const ptam_trackmap_opts* opts, ptam_trackmap_result* out);
 

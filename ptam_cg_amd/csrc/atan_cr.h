@@ -7,6 +7,8 @@
 // z = (x - c) / (1 + x c) in double-double (|z| <= 2^-6), atan(z) = z + z^3 P(z^2) with P to z^13 in plain fp64 (its error is
 // below 2^-66 of the result); x > 2 through pi/2 - atan(1/x).  No contraction: the error-free transformations need exactly
 // the products and sums written.
+// Used by cam_project (PVS pass, search stage: bit-class results).  NOT by the pose loops' re-projection (pose_device.h:
+// small_project — reciprocals and a 2-ulp atan, tolerance-class; INTEGRATION.md says which is which).
 #pragma once
 __device__ __forceinline__ double atan_cr(double x_in) {
 #pragma clang fp contract(off)
@@ -84,5 +86,5 @@ __device__ __forceinline__ double atan_cr(double x_in) {
         res = qh + ql;
     } else
         res = sh + sl;
-    return x_in < 0 ? -res : res;
+    return __builtin_copysign(res, x_in);   // (the sign of the argument, of a zero too: atan(-0.0) = -0.0 as IEEE and libm have it)
 }

@@ -1353,7 +1353,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     struct ChainTurn {
         static std::atomic<int>& busy(int dev) {
             static std::atomic<int> b[64];
-            return b[dev & 63];
+            return b[dev & 63];   // (device ids 64 apart would share a counter: one node has at most 8)
         }
         BaDev& d;
         int dev, was;
@@ -1410,13 +1410,19 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
         int n_free = 0;
         for (uint8_t x : ba->cam_fixed) n_free += x ? 0 : 1;
         const int nblk_x = (6 * n_free + SOLVE_NB - 1) / SOLVE_NB;
-        const bool band_fits = nblk_x + 4 <= 512;   // d_xchg holds 512 doubles
-        std::vector<double> mine(band_fits ? 4 + nblk_x : 4, 0.0), all(mine.size(), 0.0);
+        // ... and the FORM of the replicated camera solve: a rank that may not use the persistent launch for this call (another
+        // bundle of its process is adjusting on the same device — ranks that are threads of one process sharing a GPU —, or an
+        // earlier solve of it timed out) says so, and then NO rank uses it: every rank solves with the same code, the pose copies
+        // stay bit-identical (the two forms agree to 1e-6 only)
+        constexpr int XF = 5;   // fixed slots in front of the bandwidth marks
+        const bool band_fits = nblk_x + XF <= 512;   // d_xchg holds 512 doubles
+        std::vector<double> mine(band_fits ? XF + nblk_x : XF, 0.0), all(mine.size(), 0.0);
         mine[0] = (!rc_prepare && d.M == 0) ? 1.0 : 0.0;
         mine[1] = (double)d.M;
         mine[2] = rc_prepare ? 1.0 : 0.0;
         mine[3] = abort_local() ? 1.0 : 0.0;
-        if (!rc_prepare && band_fits && nblk_x > 0) mine[4 + std::min(ba->band_local, nblk_x - 1)] = 1.0;
+        mine[4] = d.chain_off ? 1.0 : 0.0;
+        if (!rc_prepare && band_fits && nblk_x > 0) mine[XF + std::min(ba->band_local, nblk_x - 1)] = 1.0;
         if (!ba->d_xchg) HIP_TRY(hipMalloc((void**)&ba->d_xchg, 4096));   // (a failed prepare has not allocated it)
         HIP_TRY(hipMemcpyAsync(ba->d_xchg, mine.data(), mine.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         rc = ba_allreduce(ba, ba->d_xchg, mine.size());
@@ -1430,10 +1436,14 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
             return PTAM_E_STATE;
         }
         abort_all = all[3] > 0.5;
+        if (all[4] > 0.5 && !d.chain_off) {   // (for this call only: chain_turn puts a forced value back)
+            d.chain_off = 1;
+            chain_turn.forced = true;
+        }
         ba->d.band = std::max(0, nblk_x - 1);
         if (band_fits)
             for (int b = nblk_x - 1; b >= 0; b--)
-                if (all[4 + b] > 0.5) {
+                if (all[XF + b] > 0.5) {
                     ba->d.band = b;
                     break;
                 }

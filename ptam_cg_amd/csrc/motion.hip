@@ -153,16 +153,21 @@ int ptam_track_frame(ptam_tracker* t, ptam_kf* current, const uint8_t* d_frame, 
     // src/Tracker.cc:503-514
     o.try_coarse = 1;
     if (m->disable_coarse || m->msd_scaled_velocity < m->coarse_min_velocity || o.coarse_max == 0) o.try_coarse = 0;
-    if (m->just_recovered) {
+    // (the model is advanced on a COPY and committed only when the frame was tracked: a call that fails — time-out, HIP error,
+    //  PTAM_E_STATE — leaves the caller's model as it was, so that a retry neither predicts twice nor has lost the doubled
+    //  coarse range of a recovery; the reference has no such partial state)
+    ptam_motion_model tmp = *m;
+    if (tmp.just_recovered) {
         o.try_coarse = 1;
         o.coarse_max *= 2;
         o.coarse_range *= 2;
-        m->just_recovered = 0;
+        tmp.just_recovered = 0;
     }
-    ptam_motion_predict(m);
-    const int rc = ptam_track_map_frame(t, current, d_frame, m->pose, &o, out);
+    ptam_motion_predict(&tmp);
+    const int rc = ptam_track_map_frame(t, current, d_frame, tmp.pose, &o, out);
     if (rc) return rc;
-    ptam_motion_update(m, out);
+    ptam_motion_update(&tmp, out);
+    *m = tmp;
     return PTAM_OK;
 }
 

@@ -177,6 +177,10 @@ __device__ __forceinline__ void wave_find_patch_coarse(const KfLevels& L, const 
         ((uint4*)win)[lane] = make_uint4(a0, a1, a2, a3);   // row lane / 2, bytes 16 (lane % 2) .. + 15
         if (lane < 4) win[SW_SIDE * SW_SIDE / 4 + lane] = 0;   // (the word past the last one, read by the byte shift)
         sw.lds = win;
+        // (lanes read what OTHER lanes of the wave stored: in-order LDS and the compiler's ignorance of aliasing made it work;
+        //  the memory model wants a fence and a wave barrier — which cost nothing at run time)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     if (search && sw.lds) {
         // ---- lane-per-candidate path: the passing corners of the row range are compacted, in corner order, into a list in
@@ -224,6 +228,8 @@ __device__ __forceinline__ void wave_find_patch_coarse(const KfLevels& L, const 
                     const int pos = tail + __popcll(m & ((1ull << lane) - 1ull));
                     if (pass) list[pos & (SW_LIST - 1)] = make_int2(cc[u].x, cc[u].y);
                     tail += __popcll(m);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the list is read back by other lanes of the wave)
+                    __builtin_amdgcn_wave_barrier();
                     if (tail - head >= 64) score_batch(64);
                 }
             }
@@ -398,6 +404,8 @@ __device__ __forceinline__ void wave_subpix(const KfLevels& L, const ptam_subpix
                 const unsigned b0 = src[0], b1 = src[1], b2 = src[2], b3 = src[3];
                 ((unsigned*)win)[lane] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the window is read by other lanes of the wave: see wave_find_patch_coarse)
+            __builtin_amdgcn_wave_barrier();
         }
         for (int it = 0; it < q.max_its; it++) {
             res.iterations = it + 1;

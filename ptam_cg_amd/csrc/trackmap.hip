@@ -807,7 +807,7 @@ __global__ void __launch_bounds__(THREADS) tm_pose_kernel(DevCam cam, TmDev d, i
 }
 typedef void (*tm_pose_fn)(DevCam, TmDev, int, unsigned, TmMailbox*, ptam_gn_opts, PoseChainIo, double*, unsigned long long);
 struct TmBatchItem;
-// instantiation for a list of at most cap slots (<= GS_LIMIT): one wave up to 64, one slot per thread up to 256, four up to 1024
+// instantiation for a list of at most cap slots (<= GS_LIMIT): one wave up to 64, one slot per thread up to GS_THREADS (512), GS_MPT (two) up to GS_LIMIT (1024)
 static tm_pose_fn tm_pose_pick(int cap, int* threads) {
     if (cap <= GS_WAVE_LIMIT) {
         *threads = GS_WAVE_LIMIT;
