@@ -696,10 +696,15 @@ __device__ __forceinline__ void pose_gn_small_body(const DevCam& cam, int n, LOA
             else {
                 const double med = small_select_kth<MPT, THREADS, (MPT > 1)>(sh, n, nf / 2, sel_par);
                 sel_par ^= 1;
-                sigma_sq = est_sigma_sq_from_median(opts.estimator, med, (unsigned long long)nf);
+                // FindSigmaSquared (include/Tools.h:128-162) with its division as a Newton-refined reciprocal: the formula sits on the
+                // iteration's critical path in every thread, and an IEEE fp64 division is a dependent chain of a dozen instructions
+                const unsigned long long den = (unsigned long long)nf * 2ull - 6ull;   // wraps for n < 3 like the reference
+                double sigma = 1.4826 * (1 + 5.0 * rcp_nr((double)den)) * sqrt(med);
+                sigma = (opts.estimator == PTAM_EST_HUBER ? 1.345 : 4.6851) * sigma;
+                sigma_sq = sigma * sigma;
             }
             PH(1)
-            const double inv_sigma_sq = 1.0 / sigma_sq;   // (one division for the workgroup's weights instead of one per measurement)
+            const double inv_sigma_sq = rcp_nr(sigma_sq);   // (one reciprocal for the workgroup's weights instead of a division per measurement)
             // WLS<6> :973-1002: C += (w J_r)(J_r)^T, b += e_r (w J_r), J_r scaled by dSqrtInvNoise
             double acc[27];
 #pragma unroll

@@ -407,6 +407,25 @@ def test_bundle_headline_full_length_deterministic_against_oracle(hip, oracle):
             assert abs(th[i][k] - to[i][k]) <= 1e-6 * abs(to[i][k]), (i, k, th[i][k], to[i][k])
 
 
+@pytest.mark.parametrize("case", ["config4_20x3000", "chain_33x500", "chain_58x700_w20", "headline_50x5000"])
+def test_backward_substitution_inside_the_launch_equals_the_separate_kernel(hip, case):
+    """round 5: for camera systems whose band is at most 9 blocks the persistent solve's right-hand-side workgroup substitutes
+    backwards itself (ldlt_chain.inc, wave roles); PTAM_LDLT_SEPARATE_BACKWARD=1 puts ldlt_backward_kernel behind the launch
+    as before.  The two sum in different (both fixed) orders: the same discrete trajectory, every trial's numbers to 1e-9, the
+    state to 1e-9 — and, deterministic mode, the in-launch form to the last bit against itself."""
+    big = case in BA_BIG_CASES
+    kw = dict(max_iterations=6) if big else {}
+    c = BA_BIG_CASES[case] if big else BA_CASES[case]
+    a = util.run_ba_subprocess(c, opts=dict(deterministic=1, **kw))
+    b = util.run_ba_subprocess(c, env={"PTAM_LDLT_SEPARATE_BACKWARD": "1"}, opts=dict(deterministic=1, **kw))
+    a2 = util.run_ba_subprocess(c, opts=dict(deterministic=1, **kw))
+    assert a["solve_fallbacks"] == 0 and b["solve_fallbacks"] == 0
+    util.assert_ba_equal(a, b, rel=1e-9, abs_state=1e-9)
+    for k in a["trials"].dtype.names:
+        assert np.array_equal(a["trials"][k], a2["trials"][k], equal_nan=True), k
+    assert np.array_equal(a["poses"], a2["poses"]) and np.array_equal(a["points"], a2["points"])
+
+
 def _fuzz_cases(n=18, seed=2024):
     rng = np.random.default_rng(seed)
     out = []
