@@ -1545,6 +1545,10 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
                 d.chain_off = 2;
                 ba->solve_fallbacks++;
                 HIP_TRY(hipMemsetAsync(&d.sc->solve_fault, 0, sizeof(int), ctx->stream));
+                // (the launch's error word too: where the right-hand-side workgroup substitutes backwards inside the launch it takes
+                //  the word down itself, and a workgroup that gives up AFTER that would leave it up for the per-column form's
+                //  backward kernel to find; behind the launch, in stream order, nobody is left to raise it)
+                if (d.sflags) HIP_TRY(hipMemsetAsync(d.sflags, 0, sizeof(unsigned), ctx->stream));
                 if (getenv("PTAM_DEBUG_SOLVE")) std::fprintf(stderr, "[ptam] rank %d: persistent camera solve timed out at trial %d; repeating it with the launch-per-column form\n", ba->rank, counter);
                 continue;
             }
