@@ -672,6 +672,12 @@ def main():
                                              f"on the same copy (Infinity Cache 256 MB + L2 32 MB)"})
         out["kernel_ms_per_trial"] = kernel_breakdown(prob, args.steps)
         out["schur_roofline"] = schur_roofline(prob, out["kernel_ms_per_trial"])
+        # the same kernel as it runs INSIDE Compute() (between the select and the Schur complement, its inputs and W in whatever cache
+        # state the trial leaves them): HIP events around the launch of a profiled Compute(), event overhead included
+        jac_ms = out["kernel_ms_per_trial"].get("jacobian")
+        if jac_ms:
+            out["roofline"]["avg_launch_us_in_compute"] = 1e3 * jac_ms
+            out["roofline"]["frac_in_compute"] = alg_bytes / (jac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         # ---- a cold call: the mapmaker thread calls Compute() from idle — no spin-up, no warm-up trials, 50 ms of nothing queued
         cb = new_bundle(args.steps)
         ctx.sync()
