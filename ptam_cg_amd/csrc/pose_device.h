@@ -192,6 +192,9 @@ __device__ void small_select_scan(GnSmallShared<THREADS, MPT>& sh, int k, bool c
 
 #ifdef K7_TIMING
 static __device__ long long g_sel_ph[4];   // select sub-phases (timing build): histogram | scan | candidates + rank | -
+#endif
+#if defined(K7_TIMING) && defined(SEL_TIMING)   // (their stamps are read-modify-writes of global memory by thread 0: ~2 k cycles per
+                                                //  select call of their own — only with -DSEL_TIMING, or the `select` phase is mostly them)
 #define SEL_PH(i) { if (threadIdx.x == 0) { const long long n_ = (long long)__builtin_readcyclecounter(); g_sel_ph[i] += n_ - spt_; spt_ = n_; } }
 #define SEL_PH0 long long spt_ = (long long)__builtin_readcyclecounter();
 #else
