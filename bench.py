@@ -722,9 +722,17 @@ def main():
             try:
                 loc = synth.make_ba_problem(LOCAL_BA["cams"], LOCAL_BA["points"], synth.SEED_BA_LOCAL)
                 lsteps = 10   # (configs[3] is quoted at 10 LM iterations)
-                dtl, trl, cl, _ = timed_compute(loc, lsteps, args.warmup)
+                # FIVE timed Compute() calls of the same problem, the median reported: a call is ten trials = 1 ms, and one host
+                # hiccup of 80 - 100 us in it (the mailbox spin pre-empted once) was the "bimodal" 100 / 113 - 122 us of round 4 —
+                # the per-kernel times and the trial mix of slow and fast runs are identical (tools/dev/r05_local_spread.sh)
+                reps_l = []
+                for _ in range(5):
+                    dtl, trl, cl, _ = timed_compute(loc, lsteps, args.warmup)
+                    reps_l.append(dtl)
+                dtl = sorted(reps_l)[len(reps_l) // 2]
                 lb = {"workload": workload_name(LOCAL_BA["cams"], LOCAL_BA["points"], 0), "value": lsteps / dtl, "unit": "LM iterations/s",
                       "ms_per_step": 1e3 * dtl / lsteps, "steps": lsteps, "keyframes_free": int(cl[1]), "measurements": int(cl[3]),
+                      "ms_per_step_of_5_calls": [round(1e3 * x / lsteps, 4) for x in reps_l],
                       "trial_mix": trial_mix(trl), "kernel_ms_per_trial": kernel_breakdown(loc, lsteps)}
                 n_lead_l = 0
                 for a in trl["accepted"]:
