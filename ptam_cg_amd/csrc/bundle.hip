@@ -320,6 +320,10 @@ static int ba_prepare_impl(ptam_ba* ba) {
         // as eight fragments' MFMAs (A/B of 0 = entries only / fragments + 3 / + 8 / max(5, fragments): 75 / 72 / 69 / 75 us at 50 x 5000)
         int cost_model = 8;
         if (const char* e = ptam_ab_env("PTAM_SCHUR_COST")) cost_model = atoi(e);   // A/B runs
+        // fixed cost of a SEGMENT in the same units (pipeline fill, cross-wave reduction, partial tile out): a workgroup that ends
+        // one pair and begins the next pays it twice
+        int seg_cost = 0;
+        if (const char* e = ptam_ab_env("PTAM_SCHUR_SEGCOST")) seg_cost = atoi(e);   // A/B runs
         // cost of one entry: the 16x16 fragments its pattern multiplies (+ cost_model for its loads)
         std::vector<int> pair_a(n_pairs), pair_b(n_pairs);
         for (int a = 0, pr = 0; a < n_tiles; a++)
@@ -369,7 +373,9 @@ static int ba_prepare_impl(ptam_ba* ba) {
             }
             if (ent_x == 0) continue;
             const int n_wg = (int)std::max<size_t>(1, std::min<size_t>(SLOTS, ent_x / (4 * MIN_SEG)));
-            const double target = cost_x / n_wg * 1.005;
+            int chunks_x = 0;
+            for (int pr = 0; pr < n_pairs; pr++) chunks_x += hi[pr] > lo[pr];
+            const double target = (cost_x + (double)seg_cost * (n_wg + chunks_x - 1)) / n_wg * 1.005;
             std::vector<int> cur;
             double cur_cost = 0;
             auto close = [&]() {
@@ -402,7 +408,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
                 while (pos < hi[pr]) {
                     const int left = hi[pr] - pos;
                     // as many whole 4-entry groups as the workgroup's remaining budget pays for
-                    const double room = target - cur_cost, p0 = pre[(size_t)(pos - lo[pr])];
+                    const double room = target - cur_cost - seg_cost, p0 = pre[(size_t)(pos - lo[pr])];
                     int take = (int)(std::upper_bound(pre.begin() + (pos - lo[pr]), pre.end(), p0 + room) - (pre.begin() + (pos - lo[pr]))) - 1;
                     take = std::max(0, take) / 4 * 4;
                     if (take < MIN_SEG && !cur.empty() && left > take) {   // a sliver at the end of a full workgroup: start the next one
@@ -415,7 +421,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
                     segs_of_pair[pr].push_back((int)s_segs.size());
                     cur.push_back((int)s_segs.size());
                     s_segs.push_back(SchurWG{pr, base + pos, base + pos + take, -1});
-                    cur_cost += pre[(size_t)(pos - lo[pr] + take)] - p0;
+                    cur_cost += pre[(size_t)(pos - lo[pr] + take)] - p0 + seg_cost;
                     pos += take;
                     if (cur_cost >= target * 0.98) close();
                 }
@@ -1685,6 +1691,37 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
         for (long long i = 0; i < n_tl; i++)
             std::printf("TL %4lld %-16s start %9.2f us  (+%.2f)\n", i, nm[tl[2 + 2 * i] < 18 ? tl[2 + 2 * i] : 0], (tl[3 + 2 * i] - tl[3]) * 0.01,
                         i ? (tl[3 + 2 * i] - tl[1 + 2 * i]) * 0.01 : 0.0);
+    }
+#endif
+#ifdef SCHUR_STAMPS
+    {
+        std::vector<long long> wt(1024);
+        HIP_TRY(hipMemcpy(wt.data(), d.dbg + 3072, wt.size() * 8, hipMemcpyDeviceToHost));
+        const int nw = std::min(512, d.n_schur_wg);
+        long long e0 = wt[0], x1 = 0;
+        for (int i = 0; i < nw; i++) e0 = std::min(e0, wt[2 * i]), x1 = std::max(x1, wt[2 * i + 1] & ((1ll << 56) - 1));
+        std::printf("SCHUR workgroups %d: makespan %.2f us; per workgroup (entry, exit in us from the first entry, segments):\n", nw, (x1 - e0) * 0.01);
+        for (int i = 0; i < nw; i++)
+            std::printf("%s[%d %.1f %.1f %d]", i % 8 ? " " : "\n  ", i, (wt[2 * i] - e0) * 0.01, ((wt[2 * i + 1] & ((1ll << 56) - 1)) - e0) * 0.01, (int)(wt[2 * i + 1] >> 56));
+        std::printf("\n");
+    }
+    {
+        std::vector<long long> st(1024);
+        HIP_TRY(hipMemcpy(st.data(), d.dbg + 2048, st.size() * 8, hipMemcpyDeviceToHost));
+        for (int sel = 0; sel < 2; sel++) {
+            const long long* b = st.data() + sel * 512;
+            long long t0 = b[0];
+            for (int w = 0; w < 4; w++) if (b[w * 64] && b[w * 64] < t0) t0 = b[w * 64];
+            std::printf("SCHUR stamps wg %d (groups %lld): per wave, per group: top, loads issued, data there, MFMAs issued (cycles from the first top)\n", sel ? 300 : 0, b[260]);
+            for (int w = 0; w < 4; w++) {
+                std::printf("  w%d:", w);
+                for (int i = 0; i < 16 && b[(w * 16 + i) * 4]; i++)
+                    std::printf(" [%lld %lld %lld %lld]", b[(w * 16 + i) * 4] - t0, b[(w * 16 + i) * 4 + 1] - t0, b[(w * 16 + i) * 4 + 2] - t0, b[(w * 16 + i) * 4 + 3] - t0);
+                std::printf(" end %lld\n", b[256 + w] - t0);
+            }
+            std::printf("  kernel entry %lld, exit %lld, segments %lld; last segment's epilogue (wave 0): loop end %lld, barrier 1 %lld, 2 %lld, 3 %lld, laid out %lld, stores issued %lld\n",
+                        b[264] - t0, b[265] - t0, b[266], b[268] - t0, b[269] - t0, b[270] - t0, b[271] - t0, b[272] - t0, b[273] - t0);
+        }
     }
 #endif
     if (getenv("PTAM_DEBUG_STALL"))

@@ -16,7 +16,7 @@ PY
 }
 run product $R/ptam_cg_amd/csrc/libptam_hip.so
 for v in $(ls $R/tools/_exp 2>/dev/null); do [ -f $R/tools/_exp/$v/libptam_hip.so ] && run $v $R/tools/_exp/$v/libptam_hip.so; done
-for grp in ; do
+for grp in ${SCHUR_PMC-"SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS" "TA_BUSY_avr TA_TA_BUSY_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCP_PENDING_STALL_CYCLES_sum"}; do
   rm -rf /tmp/pmc; mkdir -p /tmp/pmc
   timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmc -o p -- python $R/bench.py --no-cpu-baseline --no-tracking --no-global --no-local > /tmp/pmc/log.txt 2>&1
   python3 - <<PY
