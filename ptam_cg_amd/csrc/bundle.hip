@@ -596,6 +596,11 @@ static int ba_prepare_impl(ptam_ba* ba) {
         HIP_TRY(det_attr);
     }
     d.u_rows = ba->det ? n_dtiles : (ba->k7_big || !ba->use_wave) ? 1 : d.grid_acc;
+    {
+        static const hipError_t schur_attr =
+            hipFuncSetAttribute((const void*)schur_tile_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SCHUR_RED_BYTES);
+        HIP_TRY(schur_attr);
+    }
 
     lap("launch shape");
     // ---- carve one device allocation ------------------------------------------------------------
@@ -617,7 +622,8 @@ static int ba_prepare_impl(ptam_ba* ba) {
     const size_t o_sent = cv.take(std::max<size_t>(1, s_entries.size()) * sizeof(SchurEntry)),
                  o_swg = cv.take(std::max<size_t>(1, s_segs.size()) * sizeof(SchurWG)), o_swgseg = cv.take(s_wg_seg.size() * 4),
                  o_spw = cv.take((size_t)(n_pairs + 1) * 4),
-                 o_spart = cv.take(std::max<size_t>(1, s_segs.size()) * SCHUR_TILE_ELEMS * 8);
+                 o_spart = cv.take(std::max<size_t>(1, s_segs.size()) * SCHUR_TILE_ELEMS * 8),
+                 o_smap = cv.take((size_t)SCHUR_N_VARIANTS * SCHUR_TILE_ELEMS * 2);
     const size_t npad = std::max(d.npad, SOLVE_NB);
     // S and L block-banded (bundle.h: se_blk); sized for the full lower triangle, because a sharded bundle only learns the
     // bandwidth in force (the widest over all ranks) in Compute()'s first exchange
@@ -672,6 +678,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.s_wg_seg = (int*)(base + o_swgseg);
     d.s_pair_wg_begin = (int*)(base + o_spw);
     d.s_part = (double*)(base + o_spart);
+    d.s_map = (unsigned short*)(base + o_smap);
     d.SE = (double*)(base + o_SE);
     d.L = (double*)(base + o_L);
     d.Dg = (double*)(base + o_Dg);
@@ -789,6 +796,8 @@ static int ba_prepare_impl(ptam_ba* ba) {
     UP(d.s_segs, s_segs.data(), s_segs.size() * sizeof(SchurWG));
     UP(d.s_wg_seg, s_wg_seg.data(), s_wg_seg.size() * 4);
     UP(d.s_pair_wg_begin, pair_wg_begin.data(), pair_wg_begin.size() * 4);
+    const std::vector<unsigned short> s_map = schur_index_map();
+    UP(d.s_map, s_map.data(), s_map.size() * 2);
 #undef UP
     lap("stage + enqueue");
     HIP_TRY(ptam_stream_wait(ctx->stream));   // host staging vectors die here
@@ -1016,7 +1025,7 @@ static int ba_trial(ptam_ba* ba, double lambda, bool skip_vinv, int last_allowed
     if (d.F > 0) {
         prof_begin(ba, PTAM_K_SCHUR);
         if (d.n_schur_wg > 0)
-            hipLaunchKernelGGL(schur_tile_mfma_kernel, dim3(d.n_schur_wg), dim3(256), 0, ctx->stream, d);
+            hipLaunchKernelGGL(schur_tile_mfma_kernel, dim3(d.n_schur_wg), dim3(64 * SCHUR_NW), SCHUR_RED_BYTES, ctx->stream, d);
         hipLaunchKernelGGL(schur_reduce_kernel, dim3(d.n_pairs, SRED_SLICES), dim3(256), 0, ctx->stream, d, lambda,
                            (ba->world > 1 && ba->rank != 0) ? 0 : 1);
         prof_end(ba, PTAM_K_SCHUR);
@@ -1698,11 +1707,13 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
         std::vector<long long> wt(1024);
         HIP_TRY(hipMemcpy(wt.data(), d.dbg + 3072, wt.size() * 8, hipMemcpyDeviceToHost));
         const int nw = std::min(512, d.n_schur_wg);
-        long long e0 = wt[0], x1 = 0;
-        for (int i = 0; i < nw; i++) e0 = std::min(e0, wt[2 * i]), x1 = std::max(x1, wt[2 * i + 1] & ((1ll << 56) - 1));
-        std::printf("SCHUR workgroups %d: makespan %.2f us; per workgroup (entry, exit in us from the first entry, segments):\n", nw, (x1 - e0) * 0.01);
+        const long long M40 = (1ll << 40) - 1, M56 = (1ll << 56) - 1;
+        long long e0 = wt[0] & M40, x1 = 0;
+        for (int i = 0; i < nw; i++) e0 = std::min(e0, wt[2 * i] & M40), x1 = std::max(x1, wt[2 * i + 1] & M56 & M40);
+        std::printf("SCHUR workgroups %d: makespan %.2f us; per workgroup (entry, exit in us from the first entry, segments, hw id):\n", nw, (x1 - e0) * 0.01);
         for (int i = 0; i < nw; i++)
-            std::printf("%s[%d %.1f %.1f %d]", i % 8 ? " " : "\n  ", i, (wt[2 * i] - e0) * 0.01, ((wt[2 * i + 1] & ((1ll << 56) - 1)) - e0) * 0.01, (int)(wt[2 * i + 1] >> 56));
+            std::printf("%s[%d %.1f %.1f %d %llx]", i % 8 ? " " : "\n  ", i, ((wt[2 * i] & M40) - e0) * 0.01, ((wt[2 * i + 1] & M40) - e0) * 0.01, (int)(wt[2 * i + 1] >> 56),
+                        (unsigned long long)(wt[2 * i] >> 40));
         std::printf("\n");
     }
     {
@@ -1712,7 +1723,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
             const long long* b = st.data() + sel * 512;
             long long t0 = b[0];
             for (int w = 0; w < 4; w++) if (b[w * 64] && b[w * 64] < t0) t0 = b[w * 64];
-            std::printf("SCHUR stamps wg %d (groups %lld): per wave, per group: top, loads issued, data there, MFMAs issued (cycles from the first top)\n", sel ? 300 : 0, b[260]);
+            std::printf("SCHUR stamps wg %d (groups %lld): per wave, per group: top, loads issued, data there, MFMAs issued (cycles from the first top)\n", sel ? 150 : 0, b[260]);
             for (int w = 0; w < 4; w++) {
                 std::printf("  w%d:", w);
                 for (int i = 0; i < 16 && b[(w * 16 + i) * 4]; i++)
