@@ -13,7 +13,7 @@ import json, sys
 b = json.loads([l for l in open("$O/log.txt") if l.startswith("{")][-1])
 g = b.get("global_ba_single_gpu", {}); l = b.get("local_ba_config4", {})
 s = lambda d: 1e3 * d.get("kernel_ms_per_trial", {}).get("schur", 0)
-print("%-40s schur us: headline %.1f  config5 %.1f  config4 %.1f | it/s %.0f %.0f %.0f" % (sys.argv[1], s(b), s(g), s(l), b["value"], g.get("value", 0), l.get("value", 0)))
+print("%-40s schur us: headline %.1f  config5 %.1f  config4 %.1f | it/s %.0f %.0f %.0f | accepted trial %.1f us, mix %s" % (sys.argv[1], s(b), s(g), s(l), b["value"], g.get("value", 0), l.get("value", 0), b.get("accepted_trial_us", 0), list(b.get("trial_mix", {}).values())))
 PY
 done
 done
