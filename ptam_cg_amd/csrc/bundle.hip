@@ -133,6 +133,11 @@ struct Carver {
 };
 
 static void ba_finish_outliers(ptam_ba* ba);
+static int pair_a_of(int pair) {   // tile row a of pair index a (a + 1) / 2 + b, b <= a
+    int a = 0;
+    while ((a + 1) * (a + 2) / 2 <= pair) a++;
+    return a;
+}
 static int ba_prepare_impl(ptam_ba* ba) {
     ptam_ctx* ctx = ba->ctx;
     // PTAM_DEBUG_PREPARE=1: host time of the phases of this function (sort | lists | Schur work lists | launch shape | alloc + clear | upload)
@@ -451,6 +456,30 @@ static int ba_prepare_impl(ptam_ba* ba) {
         s_segs.swap(ordered);
     }
 
+    if (getenv("PTAM_DEBUG_SCHUR")) {   // groups by fragment pattern: what the tile kernel multiplies and loads
+        std::vector<long long> grp(16 * 3, 0);
+        long long mf = 0, ld = 0, ld_need = 0;
+        for (const SchurWG& sg : s_segs) {
+            const int a = pair_a_of(sg.pair), b = sg.pair - a * (a + 1) / 2;
+            auto fr = [&](int t) { const int n = std::min(SCHUR_TC, F - t * SCHUR_TC); return n <= 2 ? 1 : (n <= 5 ? 2 : 3); };
+            const int ma = fr(a), mb = fr(b);
+            for (int e = sg.e_begin; e < sg.e_end; e += 4) {
+                int pm = 0;
+                for (int q = e; q < std::min(e + 4, sg.e_end); q++) pm |= (s_entries[(size_t)q].pad >> 16) & 15;
+                grp[(size_t)pm * 3 + (a == b ? 0 : 1)]++;
+                const int a01 = (pm & 1) ? std::min(ma, 2) : 0, a2 = (ma == 3 && (pm & 2)) ? 1 : 0;
+                const int b01 = (pm & 4) ? std::min(mb, 2) : 0, b2 = (mb == 3 && (pm & 8)) ? 1 : 0;
+                mf += 3 * (a == b ? a01 * a01 + a2 * a01 + a2 : (a01 + a2) * (b01 + b2));
+                ld += 2 + 5 + (ma == 3 ? 6 : 3) + (a == b ? 3 : (mb == 3 ? 6 : 3));
+                ld_need += 2 + 5 + (a01 ? 3 : 0) + (a2 ? 3 : 0) + (a == b ? 3 : (b01 ? 3 : 0) + (b2 ? 3 : 0));
+            }
+        }
+        std::fprintf(stderr, "[ptam] schur: %zu segments, %d workgroups; MFMAs %lld, loads issued %lld (needed by the patterns %lld); groups by pattern (diag / off):",
+                     s_segs.size(), (int)s_wg_seg.size() - 1, mf, ld, ld_need);
+        for (int pm = 0; pm < 16; pm++)
+            if (grp[(size_t)pm * 3] + grp[(size_t)pm * 3 + 1]) std::fprintf(stderr, " %d:%lld/%lld", pm, grp[(size_t)pm * 3], grp[(size_t)pm * 3 + 1]);
+        std::fprintf(stderr, "\n");
+    }
     lap("schur split");
     d.C = C;
     d.F = F;
@@ -1714,6 +1743,18 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
         for (int i = 0; i < nw; i++)
             std::printf("%s[%d %.1f %.1f %d %llx]", i % 8 ? " " : "\n  ", i, ((wt[2 * i] & M40) - e0) * 0.01, ((wt[2 * i + 1] & M40) - e0) * 0.01, (int)(wt[2 * i + 1] >> 56),
                         (unsigned long long)(wt[2 * i] >> 40));
+        std::printf("\n");
+        // the schedule: per workgroup its segments as pair:groups
+        std::vector<int> wseg((size_t)d.n_schur_wg + 1);
+        HIP_TRY(hipMemcpy(wseg.data(), d.s_wg_seg, wseg.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<SchurWG> segs((size_t)wseg.back());
+        HIP_TRY(hipMemcpy(segs.data(), d.s_segs, segs.size() * sizeof(SchurWG), hipMemcpyDeviceToHost));
+        std::printf("SCHUR schedule:");
+        for (int i = 0; i < nw; i++) {
+            std::printf("%s{%d", i % 8 ? " " : "\n  ", i);
+            for (int sg = wseg[i]; sg < wseg[i + 1]; sg++) std::printf(" %d:%d", segs[sg].pair, (segs[sg].e_end - segs[sg].e_begin + 3) / 4);
+            std::printf("}");
+        }
         std::printf("\n");
     }
     {
