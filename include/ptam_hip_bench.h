@@ -60,6 +60,12 @@ int ptam_ba_bench_jacobian(ptam_ba* ba, int reps, double* avg_ms, double* algori
 /* the same bracket over `n` bundles of one context (copies of one problem) launched round-robin: with
  * (n - 1) working sets larger than the 256 MB Infinity Cache every launch finds its data in HBM only. */
 int ptam_ba_bench_jacobian_rotating(ptam_ba** bas, int n, int reps, double* avg_ms);
+/* Test hook (host only, no device needed): the index map the Schur tile kernel's epilogue gathers a partial tile through
+ * (csrc/ba_schur.inc: schur_index_map) — for variant 0..5 = {diagonal pair with 3 / 2 / 1 row fragments, off-diagonal pair with
+ * 3 / 2 / 1 row fragments against 3}, out[e] = value index * 64 + lane of element e of the tile's [8][8][6][6] + E[48] layout in
+ * the accumulator layout of the cross-wave reduction, 0xffff for an element nothing is multiplied into.  Returns the number of
+ * elements (2352) or a negative error. */
+int ptam_ba_schur_index_map(int variant, uint16_t* out, int cap);
 
 #ifdef __cplusplus
 }

@@ -202,6 +202,7 @@ PROTOTYPES = {
     "bench_track_batch": (_i, [_i, _vp, _vp, _vp, _pd, _vp, _vp, _vp, _i, _i, _pd]),
     "tracker_read_iteration_set": (_i, [_vp, _vp, _i, C.POINTER(_i)]),
     "ba_bench_jacobian_rotating": (_i, [_vp, _i, _i, _pd]),
+    "ba_schur_index_map": (_i, [_i, _vp, _i]),
     "ba_set_comm": (_i, [_vp, _i, _i, ALLREDUCE_FN, _vp]),
     "rccl_unique_id": (_i, [_vp]),
     "rccl_create": (_i, [_vp, _vp, _i, _i, _ppv]),

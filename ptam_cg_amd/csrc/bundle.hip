@@ -1901,6 +1901,13 @@ int ptam_ba_bench_jacobian(ptam_ba* ba, int reps, double* avg_ms, double* algori
 // problem) are launched round-robin, back to back, inside ONE event bracket — the method of ptam_ba_bench_jacobian, but
 // between two launches on the same bundle lie the n - 1 other working sets.  The caller picks n so that
 // (n - 1) x (bytes one launch touches) exceeds the cache by a wide margin; then every launch streams from / to HBM.
+int ptam_ba_schur_index_map(int variant, uint16_t* out, int cap) {   // (test hook: host only)
+    ARG_TRY(out && variant >= 0 && variant < SCHUR_N_VARIANTS && cap >= SCHUR_TILE_ELEMS);
+    const std::vector<unsigned short> m = schur_index_map();
+    std::memcpy(out, m.data() + (size_t)variant * SCHUR_TILE_ELEMS, (size_t)SCHUR_TILE_ELEMS * 2);
+    return SCHUR_TILE_ELEMS;
+}
+
 int ptam_ba_bench_jacobian_rotating(ptam_ba** bas, int n, int reps, double* avg_ms) {
     ARG_TRY(bas && n > 0 && reps > 0 && avg_ms);
     ptam_ctx* ctx = bas[0]->ctx;

@@ -100,3 +100,47 @@ def test_shard_problem_is_a_partition():
         assert np.array_equal(s["points"], prob["points"][s["global_point_ids"]])
         assert np.array_equal(s["global_point_ids"][s["pt_idx"]], prob["pt_idx"][s["global_meas_ids"]])
         assert s["pt_idx"].max() < len(s["points"]) and len(s["poses"]) == 6
+
+
+def _schur_row(mode, t, rid):
+    """csrc/ba_schur.inc: which row (6 * camera slot + parameter) of a 48-row camera tile MFMA row `rid` of fragment t stands for"""
+    if mode == 1:
+        return rid
+    if t < 2:
+        return 6 * (rid // 3) + 2 * (rid % 3) + t
+    q = 16 + (rid >> 1)
+    return 6 * (q // 3) + 2 * (q % 3) + (rid & 1)
+
+
+@pytest.mark.parametrize("variant", range(6))
+def test_schur_index_map_is_the_inverse_of_the_row_mapping(built, variant):
+    """round 5: the Schur tile kernel's epilogue gathers a partial tile through a host-built index map.  Re-derived here from the
+    row mapping and the D layout of v_mfma_f64_16x16x4_f64 (column = lane & 15, row = (lane >> 4) + 4 v): every element of the
+    [8][8][6][6] + E[48] layout that a fragment covers points at exactly one accumulator slot, no slot is used twice, and the
+    elements no fragment covers are marked as zeros."""
+    out = (ctypes.c_uint16 * 2352)()
+    assert built.ptam_ba_schur_index_map(variant, out, 2352) == 2352
+    got = np.frombuffer(out, dtype=np.uint16).copy()
+    diag = variant < 3
+    ma = 3 - variant if diag else 6 - variant
+    mb = ma if diag else 3
+    want = np.full(2352, 0xFFFF, dtype=np.uint16)
+    for ti in range(ma):
+        for tj in range(mb):
+            for lane in range(64):
+                for v in range(4):
+                    row, col = _schur_row(ma, ti, (lane >> 4) + 4 * v), _schur_row(mb, tj, lane & 15)
+                    if row < 48 and col < 48:
+                        e = ((row // 6) * 8 + col // 6) * 36 + (row % 6) * 6 + col % 6
+                        assert want[e] == 0xFFFF
+                        want[e] = ((ti * 3 + tj) * 4 + v) * 64 + lane
+    if diag:
+        for t in range(ma):
+            for rid in range(16):
+                row = _schur_row(ma, t, rid)
+                if row < 48:
+                    want[2304 + row] = (36 + t) * 64 + rid
+    assert np.array_equal(got, want)
+    used = got[got != 0xFFFF]
+    assert len(set(used.tolist())) == len(used) and used.max() < 39 * 64
+    assert built.ptam_ba_schur_index_map(6, out, 2352) < 0 and built.ptam_ba_schur_index_map(0, out, 100) < 0
