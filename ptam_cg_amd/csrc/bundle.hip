@@ -904,7 +904,7 @@ static int ba_pass1_sigma(ptam_ba* ba) {
     prof_begin(ba, PTAM_K_SELECT);
     if (!sharded) {
         hipLaunchKernelGGL(select_compact_kernel, dim3(std::max(1, std::min((d.M + 1023) / 1024, ba_sel_blocks()))), dim3(256), 0,
-                           ctx->stream, d, (const double*)d.m_e2, (long long)d.M, (const uint8_t*)d.m_state);
+                           ctx->stream, d, (const double*)d.m_e2, (long long)d.M, (const uint8_t*)d.m_state, 0);
     } else if (!ba->slow_select) {
         if (!ba->d_sel) {   // sized by the world the communicator was set for (ptam_ba_set_comm drops it on a change)
             if (const char* e = ptam_ab_env("PTAM_XCAND_CAP")) ba->xcand_cap = std::max(1, std::min(atoi(e), 1 << 20));
@@ -925,7 +925,7 @@ static int ba_pass1_sigma(ptam_ba* ba) {
         int rc = reduce_hist(d.hist);
         if (rc) return rc;
         hipLaunchKernelGGL(select_compact_kernel, dim3(std::max(1, std::min((d.M + 1023) / 1024, ba_sel_blocks()))), dim3(256), 0,
-                           ctx->stream, d, (const double*)d.m_e2, (long long)d.M, (const uint8_t*)d.m_state);
+                           ctx->stream, d, (const double*)d.m_e2, (long long)d.M, (const uint8_t*)d.m_state, 1);
         rc = reduce_hist(d.hist + HIST_BINS);
         if (rc) return rc;
         HIP_TRY(hipMemsetAsync(xc, 0, n_xc * sizeof(double), ctx->stream));
@@ -975,7 +975,7 @@ static int ba_pass1_sigma(ptam_ba* ba) {
             hipLaunchKernelGGL(hist_keys_kernel, dim3((int)std::max<long long>(1, std::min<long long>((total + 255) / 256, 1024))),
                                dim3(256), 0, ctx->stream, (const double*)ba->d_gather, total, d.hist);
         hipLaunchKernelGGL(select_compact_kernel, dim3((int)std::max<long long>(1, std::min<long long>((total + 1023) / 1024, 256))),
-                           dim3(256), 0, ctx->stream, dg, (const double*)ba->d_gather, total, (const uint8_t*)nullptr);
+                           dim3(256), 0, ctx->stream, dg, (const double*)ba->d_gather, total, (const uint8_t*)nullptr, 0);
         hipLaunchKernelGGL(select_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, dg, ba->opts.estimator, min_s2);
         prof_end(ba, PTAM_K_SELECT);
         HIP_TRY(hipGetLastError());
@@ -1125,7 +1125,7 @@ static int ba_enqueue_speculative(ptam_ba* ba, double lambda_next, double lambda
     d.guard = 1;
     hipLaunchKernelGGL(purge_pass1_kernel, dim3(std::max(1, std::min((d.M + 256 * P1_U - 1) / (256 * P1_U), ba_p1_blocks()))), dim3(256), 0, ctx->stream, d);
     hipLaunchKernelGGL(select_compact_kernel, dim3(std::max(1, std::min((d.M + 1023) / 1024, ba_sel_blocks()))), dim3(256), 0, ctx->stream, d,
-                       (const double*)d.m_e2, (long long)d.M, (const uint8_t*)d.m_state);
+                       (const double*)d.m_e2, (long long)d.M, (const uint8_t*)d.m_state, 0);
     hipLaunchKernelGGL(select_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, d, ba->opts.estimator, min_s2);
     launch_k7(ba, 1);
     {
