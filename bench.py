@@ -552,7 +552,11 @@ def main():
         t = kms.get("schur", 0.0) * 1e-3
         return {"kernel": "schur_tile_mfma_kernel + schur_reduce_kernel", "bound": "mfma (fp64)", "useful_flop_per_trial": flops,
                 "us_per_trial": t * 1e6, "achieved": flops / t / 1e12 if t > 0 else None, "peak": 78.6, "unit": "TFLOP/s",
-                "frac": flops / t / 78.6e12 if t > 0 else None}
+                "frac": flops / t / 78.6e12 if t > 0 else None,
+                # what the matrix pipe sustains under THIS kernel's load: the shader clock reads 2.1 GHz inside the tile kernel
+                # (s_memtime against the 100 MHz clock, docs/LOG_r05.md), and a v_mfma_f64_16x16x4 holds the pipe 64 cycles
+                "sustained_peak": 78.6 * 2.1 / 2.4,
+                "frac_of_sustained": flops / t / (78.6e12 * 2.1 / 2.4) if t > 0 else None}
 
     def kernel_breakdown(problem, steps, sharded=True):
         # two profiled runs, per kernel the smaller average: now and then one event bracket of a run catches a stall of
