@@ -321,14 +321,24 @@ static int ba_prepare_impl(ptam_ba* ba) {
         const int SLOTS = 256 * SCHUR_WG_PER_CU / NX, MIN_SEG = 16;
         // 16x16 fragments per tile (row mappings of ba_schur.inc: 1-2 cameras in a tile = 1 fragment, 3-5 = 2, 6-8 = 3)
         auto frags = [&](int t) { const int n = std::min(SCHUR_TC, F - t * SCHUR_TC); return n <= 2 ? 1 : (n <= 5 ? 2 : 3); };
-        // cost of an entry = fragments multiplied + 8: the loads of an iteration (the same for every entry) weigh about as much
-        // as eight fragments' MFMAs (A/B of 0 = entries only / fragments + 3 / + 8 / max(5, fragments): 75 / 72 / 69 / 75 us at 50 x 5000)
-        int cost_model = 8;
+        // Cost model of the split, fitted to the tile kernel's per-workgroup entry / exit stamps at 50 x 5000 (tools/dev/schur_fit.py,
+        // docs/LOG_r05.md): a group of four entries takes  10 f + 36  units (f: the 16x16 fragment products of its pattern; the 36
+        // are its loads), a SEGMENT costs as much as ~10 full groups (pipeline fill: three dependent round trips; cross-wave
+        // reduction; partial tile out), and the SECOND workgroup of a CU — its waves are the younger ones, the issue arbiter
+        // prefers the older — ends 4.5 - 9 us behind the first for the same work (fits before / after the re-balancing), so it gets 7 us less.
+        // (Rounds 2-5 had f + 8 and no segment term: workgroups of load-bound pairs — a last tile of one camera — were taken for
+        //  lighter than they are, ran alone on their CU for 12-17 us after the partner had left, and set the launch's end.)
+        int cost_model = 36;
         if (const char* e = ptam_ab_env("PTAM_SCHUR_COST")) cost_model = atoi(e);   // A/B runs
-        // fixed cost of a SEGMENT in the same units (pipeline fill, cross-wave reduction, partial tile out): a workgroup that ends
-        // one pair and begins the next pays it twice
-        int seg_cost = 0;
+        // fixed cost of a SEGMENT in the same units: a workgroup that ends one pair and begins the next pays it twice
+        int seg_cost = 4900;
         if (const char* e = ptam_ab_env("PTAM_SCHUR_SEGCOST")) seg_cost = atoi(e);   // A/B runs
+        int second_lag = 7000;   // what a CU's second workgroup is given less than its first (A/B: 4500 / 7000 / 9000 / 12000 -> 47.9 / 46.7 / 46.8 / 48.7 us)
+        double min_room = seg_cost;   // a workgroup begins another segment only for at least this much work
+        if (const char* e = ptam_ab_env("PTAM_SCHUR_MINROOM")) min_room = atof(e);   // A/B runs
+        double fixed_target = -1;   // >= 0: no bisection, the budget is this multiple of the mean cost (A/B runs: 1.005 = rounds 2-5)
+        if (const char* e = ptam_ab_env("PTAM_SCHUR_FIXED_TARGET")) fixed_target = atof(e);
+        if (const char* e = ptam_ab_env("PTAM_SCHUR_LAG")) second_lag = atoi(e);   // A/B runs
         // cost of one entry: the 16x16 fragments its pattern multiplies (+ cost_model for its loads)
         std::vector<int> pair_a(n_pairs), pair_b(n_pairs);
         for (int a = 0, pr = 0; a < n_tiles; a++)
@@ -344,8 +354,24 @@ static int ba_prepare_impl(ptam_ba* ba) {
                 const int b01 = set01(e.offb) ? std::min(mb, 2) : 0, b2 = (mb == 3 && set2(e.offb)) ? 1 : 0;
                 f = (a01 + a2) * (b01 + b2);
             }
-            return cost_model == 1 ? std::max(5, f) : f + cost_model;
+            return 10 * f + cost_model;
         };
+        // Order of the pairs in an XCD's list: the fewest fragment products first.  The list's first half becomes the FIRST
+        // workgroup of each CU, whose (older) waves the issue arbiter prefers: a load-bound pair there — a last tile of one or two
+        // cameras: 3 products a step against 21 loads — leaves the matrix pipe to the younger product-bound partner, while
+        // in the second slot it starved behind the partner's products and then ran on alone for 12 us (stamps: docs/LOG_r05.md).
+        std::vector<int> pair_order(n_pairs);
+        for (int pr = 0; pr < n_pairs; pr++) pair_order[pr] = pr;
+        {
+            bool by_products = true;
+            if (const char* e = ptam_ab_env("PTAM_SCHUR_ORDER")) by_products = atoi(e) != 0;   // A/B runs
+            auto full_f = [&](int pr) {
+                const int ma = frags(pair_a[pr]), mb = frags(pair_b[pr]);
+                return pair_a[pr] == pair_b[pr] ? (ma == 3 ? 7 : (ma == 2 ? 4 : 1)) : ma * mb;
+            };
+            if (by_products)
+                std::stable_sort(pair_order.begin(), pair_order.end(), [&](int p, int q) { return full_f(p) < full_f(q); });
+        }
         // point ranges of equal cost
         // (an entry's cost is worked out once and kept in its padding word, which the device does not read)
         std::vector<double> pt_cost(P + 1, 0.0);
@@ -377,19 +403,12 @@ static int ba_prepare_impl(ptam_ba* ba) {
                 ent_x += (size_t)(hi[pr] - lo[pr]);
             }
             if (ent_x == 0) continue;
-            const int n_wg = (int)std::max<size_t>(1, std::min<size_t>(SLOTS, ent_x / (4 * MIN_SEG)));
-            int chunks_x = 0;
-            for (int pr = 0; pr < n_pairs; pr++) chunks_x += hi[pr] > lo[pr];
-            const double target = (cost_x + (double)seg_cost * (n_wg + chunks_x - 1)) / n_wg * 1.005;
-            std::vector<int> cur;
-            double cur_cost = 0;
-            auto close = [&]() {
-                if (!cur.empty()) wgs_x[x].push_back(cur);
-                cur.clear();
-                cur_cost = 0;
-            };
-            for (int pr = 0; pr < n_pairs; pr++) {
-                const int base = (int)s_entries.size() - lo[pr];   // position of the pair's entry i in s_entries: base + i
+            const int n_wg_max = (int)std::max<size_t>(1, std::min<size_t>(SLOTS, ent_x / (4 * MIN_SEG)));
+            // the XCD's entries: pair after pair, a pair's entries sorted by fragment pattern, with their prefix costs
+            std::vector<int> base(n_pairs);                  // position of pair pr's entry i in s_entries: base[pr] + i
+            std::vector<std::vector<double>> pre(n_pairs);   // prefix costs of the pair's (sorted) entries lo..hi
+            for (int pr : pair_order) {
+                base[pr] = (int)s_entries.size() - lo[pr];
                 s_entries.insert(s_entries.end(), per_pair[pr].begin() + lo[pr], per_pair[pr].begin() + hi[pr]);
                 if (sort_pattern && hi[pr] > lo[pr]) {   // entries of one fragment pattern next to each other: the kernel skips a
                                                           // fragment set only when none of the FOUR points of a group has a camera in it
@@ -407,32 +426,85 @@ static int ba_prepare_impl(ptam_ba* ba) {
                         for (int i = 0; i < nn; i++) e0[cnt16[(sort_tmp[(size_t)i].pad >> 16) & 15]++] = sort_tmp[(size_t)i];
                     }
                 }
-                std::vector<double> pre((size_t)(hi[pr] - lo[pr]) + 1, 0.0);   // prefix costs of the chunk's (sorted) entries
-                for (int i = lo[pr]; i < hi[pr]; i++) pre[(size_t)(i - lo[pr]) + 1] = pre[(size_t)(i - lo[pr])] + (s_entries[(size_t)(base + i)].pad & 0xffff);
-                int pos = lo[pr];
-                while (pos < hi[pr]) {
-                    const int left = hi[pr] - pos;
-                    // as many whole 4-entry groups as the workgroup's remaining budget pays for
-                    const double room = target - cur_cost - seg_cost, p0 = pre[(size_t)(pos - lo[pr])];
-                    int take = (int)(std::upper_bound(pre.begin() + (pos - lo[pr]), pre.end(), p0 + room) - (pre.begin() + (pos - lo[pr]))) - 1;
-                    take = std::max(0, take) / 4 * 4;
-                    if (take < MIN_SEG && !cur.empty() && left > take) {   // a sliver at the end of a full workgroup: start the next one
-                        close();
-                        continue;
-                    }
-                    take = std::max(take, MIN_SEG);
-                    if (left - take < MIN_SEG) take = left;                // ... or at the end of the pair's chunk: take it along
-                    take = std::min(take, left);
-                    segs_of_pair[pr].push_back((int)s_segs.size());
-                    cur.push_back((int)s_segs.size());
-                    s_segs.push_back(SchurWG{pr, base + pos, base + pos + take, -1});
-                    cur_cost += pre[(size_t)(pos - lo[pr] + take)] - p0 + seg_cost;
-                    pos += take;
-                    if (cur_cost >= target * 0.98) close();
-                }
-                if (!span) close();
+                pre[pr].assign((size_t)(hi[pr] - lo[pr]) + 1, 0.0);
+                for (int i = lo[pr]; i < hi[pr]; i++)
+                    pre[pr][(size_t)(i - lo[pr]) + 1] = pre[pr][(size_t)(i - lo[pr])] + (s_entries[(size_t)(base[pr] + i)].pad & 0xffff);
             }
-            close();
+            // The cut: the pairs' entries, one pair after another, into at most n_wg workgroups of whole 4-entry groups such that
+            // no workgroup's cost — entries + seg_cost per segment (+ second_lag for list positions >= SLOTS / 2: block 8 i + x >= 256,
+            // the second workgroup of its CU) — exceeds a budget T; T is the smallest for which the greedy fill needs no more than
+            // n_wg workgroups (bisection: the fill is exact about the segments a cut makes, which an a-priori budget — rounds 2-5:
+            // the mean cost — can only guess).
+            struct Cut { int pr, begin, end; };   // entries [begin, end) of pair pr, relative to lo[pr]
+            const int n_first = SCHUR_WG_PER_CU == 2 ? SLOTS / 2 : SLOTS;
+            auto fill = [&](double T, std::vector<std::vector<Cut>>* out) {
+                int n_out = 0;
+                std::vector<Cut> cur;
+                double cur_cost = 0;
+                auto close = [&]() {
+                    if (!cur.empty()) {
+                        if (out) out->push_back(cur);
+                        n_out++;
+                    }
+                    cur.clear();
+                    cur_cost = 0;
+                };
+                for (int pr : pair_order) {
+                    const std::vector<double>& pp = pre[pr];
+                    const int n = hi[pr] - lo[pr];
+                    int pos = 0;
+                    while (pos < n) {
+                        const int left = n - pos;
+                        // as many whole 4-entry groups as the workgroup's remaining budget pays for
+                        const double room = T - (n_out >= n_first ? second_lag : 0) - cur_cost - seg_cost, p0 = pp[(size_t)pos];
+                        int take = (int)(std::upper_bound(pp.begin() + pos, pp.end(), p0 + room) - (pp.begin() + pos)) - 1;
+                        take = take >= left ? left : std::max(0, take) / 4 * 4;
+                        // a sliver at the end of a full workgroup — less work than the segment itself would cost: start the next one
+                        if (!cur.empty() && left > take && (take < MIN_SEG || room < min_room)) {
+                            close();
+                            continue;
+                        }
+                        take = std::max(take, MIN_SEG);
+                        if (left - take < MIN_SEG) take = left;                // ... or at the end of the pair's chunk: take it along
+                        take = std::min(take, left);
+                        cur.push_back(Cut{pr, pos, pos + take});
+                        cur_cost += pp[(size_t)(pos + take)] - p0 + seg_cost;
+                        pos += take;
+                    }
+                    if (!span) close();
+                }
+                close();
+                return n_out;
+            };
+            int chunks_x = 0;
+            for (int pr = 0; pr < n_pairs; pr++) chunks_x += hi[pr] > lo[pr];
+            // ... for two workgroup counts when the XCD's work does not fill both slots of its CUs: one workgroup per CU, or as many as
+            // the entries allow (a few CUs with two workgroups and the rest with one take as long as two everywhere); T says which
+            auto smallest_budget = [&](int n_wg) {
+                double t_lo = cost_x / n_wg, t_hi = cost_x + (double)seg_cost * (chunks_x + n_wg) + second_lag + 1;
+                if (fixed_target >= 0) return (cost_x + (double)seg_cost * (n_wg + chunks_x - 1)) / n_wg * fixed_target;   // (rounds 2-5; A/B runs)
+                for (int it = 0; it < 40 && t_hi - t_lo > 1.0; it++) {
+                    const double mid = 0.5 * (t_lo + t_hi);
+                    if (fill(mid, nullptr) <= n_wg)
+                        t_hi = mid;
+                    else
+                        t_lo = mid;
+                }
+                return t_hi;
+            };
+            double t_cut = smallest_budget(n_wg_max);
+            if (n_wg_max > n_first && fixed_target < 0 && !ptam_ab_env("PTAM_SCHUR_NO_HALF")) t_cut = std::min(t_cut, smallest_budget(n_first));
+            std::vector<std::vector<Cut>> cuts;
+            fill(t_cut, &cuts);
+            for (const std::vector<Cut>& wg : cuts) {
+                std::vector<int> ids;
+                for (const Cut& c : wg) {
+                    segs_of_pair[c.pr].push_back((int)s_segs.size());
+                    ids.push_back((int)s_segs.size());
+                    s_segs.push_back(SchurWG{c.pr, base[c.pr] + lo[c.pr] + c.begin, base[c.pr] + lo[c.pr] + c.end, -1});
+                }
+                wgs_x[x].push_back(ids);
+            }
         }
         // partial-tile slots: contiguous per pair
         int slot = 0;
