@@ -318,7 +318,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
         };
         bool span = true;   // a workgroup may end one pair and begin the next
         if (const char* e = ptam_ab_env("PTAM_SCHUR_SPAN")) span = atoi(e) != 0;
-        const int SLOTS = 256 * SCHUR_WG_PER_CU / NX, MIN_SEG = 16;
+        const int MIN_SEG = 16;
         // 16x16 fragments per tile (row mappings of ba_schur.inc: 1-2 cameras in a tile = 1 fragment, 3-5 = 2, 6-8 = 3)
         auto frags = [&](int t) { const int n = std::min(SCHUR_TC, F - t * SCHUR_TC); return n <= 2 ? 1 : (n <= 5 ? 2 : 3); };
         // Cost model of the split, fitted to the tile kernel's per-workgroup entry / exit stamps at 50 x 5000 (tools/dev/schur_fit.py,
@@ -363,7 +363,11 @@ static int ba_prepare_impl(ptam_ba* ba) {
         std::vector<int> pair_order(n_pairs);
         for (int pr = 0; pr < n_pairs; pr++) pair_order[pr] = pr;
         {
-            bool by_products = true;
+            // (only where both slots of the CUs are in use: a small bundle — 20 x 3 000: 35 workgroups per XCD, 8 of its kernel's 12 us
+            //  fixed cost — ran 1.6 us longer in this order than in the natural one)
+            size_t ent_all = 0;
+            for (int pr = 0; pr < n_pairs; pr++) ent_all += per_pair[pr].size();
+            bool by_products = ent_all / (size_t)NX / (4 * MIN_SEG) >= (size_t)(256 * SCHUR_WG_PER_CU / NX);
             if (const char* e = ptam_ab_env("PTAM_SCHUR_ORDER")) by_products = atoi(e) != 0;   // A/B runs
             auto full_f = [&](int pr) {
                 const int ma = frags(pair_a[pr]), mb = frags(pair_b[pr]);
@@ -372,160 +376,193 @@ static int ba_prepare_impl(ptam_ba* ba) {
             if (by_products)
                 std::stable_sort(pair_order.begin(), pair_order.end(), [&](int p, int q) { return full_f(p) < full_f(q); });
         }
-        // point ranges of equal cost
         // (an entry's cost is worked out once and kept in its padding word, which the device does not read)
-        std::vector<double> pt_cost(P + 1, 0.0);
         for (int pr = 0; pr < n_pairs; pr++)
-            for (SchurEntry& e : per_pair[pr]) {
-                const int c_ = entry_cost(pr, e);
-                e.pad = c_ | (pattern_of(e) << 16);   // (cost: low half, fragment pattern: high half)
-                pt_cost[e.pt + 1] += c_;
-            }
-        for (int p = 0; p < P; p++) pt_cost[p + 1] += pt_cost[p];
-        int bound[9];
-        bound[0] = 0;
-        for (int x = 1; x < NX; x++)
-            bound[x] = (int)(std::lower_bound(pt_cost.begin(), pt_cost.end(), pt_cost[P] * x / NX) - pt_cost.begin());
-        bound[NX] = P;
+            for (SchurEntry& e : per_pair[pr]) e.pad = entry_cost(pr, e) | (pattern_of(e) << 16);   // (cost: low half, fragment pattern: high half)
         std::vector<SchurEntry> sort_tmp;
-        std::vector<std::vector<std::vector<int>>> wgs_x(NX);    // per XCD: workgroups = lists of segment indices
-        std::vector<std::vector<int>> segs_of_pair(n_pairs);
-        for (int x = 0; x < NX; x++) {
-            std::vector<int> lo(n_pairs), hi(n_pairs);
-            double cost_x = 0;
-            size_t ent_x = 0;
-            for (int pr = 0; pr < n_pairs; pr++) {
-                auto& v = per_pair[pr];
-                auto cmp = [](const SchurEntry& e, int p) { return e.pt < p; };
-                lo[pr] = (int)(std::lower_bound(v.begin(), v.end(), bound[x], cmp) - v.begin());
-                hi[pr] = (int)(std::lower_bound(v.begin(), v.end(), bound[x + 1], cmp) - v.begin());
-                for (int i = lo[pr]; i < hi[pr]; i++) cost_x += v[i].pad & 0xffff;
-                ent_x += (size_t)(hi[pr] - lo[pr]);
-            }
-            if (ent_x == 0) continue;
-            const int n_wg_max = (int)std::max<size_t>(1, std::min<size_t>(SLOTS, ent_x / (4 * MIN_SEG)));
-            // the XCD's entries: pair after pair, a pair's entries sorted by fragment pattern, with their prefix costs
-            std::vector<int> base(n_pairs);                  // position of pair pr's entry i in s_entries: base[pr] + i
-            std::vector<std::vector<double>> pre(n_pairs);   // prefix costs of the pair's (sorted) entries lo..hi
-            for (int pr : pair_order) {
-                base[pr] = (int)s_entries.size() - lo[pr];
-                s_entries.insert(s_entries.end(), per_pair[pr].begin() + lo[pr], per_pair[pr].begin() + hi[pr]);
-                if (sort_pattern && hi[pr] > lo[pr]) {   // entries of one fragment pattern next to each other: the kernel skips a
-                                                          // fragment set only when none of the FOUR points of a group has a camera in it
-                    // stable counting sort over the 16 patterns (kept in the entries' padding word); a chunk whose entries share
-                    // one pattern — every chunk of a dense problem — stays as it is
-                    SchurEntry* e0 = s_entries.data() + (s_entries.size() - (size_t)(hi[pr] - lo[pr]));
-                    const int nn = hi[pr] - lo[pr];
-                    int cnt16[17] = {0};
-                    for (int i = 0; i < nn; i++) cnt16[((e0[i].pad >> 16) & 15) + 1]++;
-                    bool uniform = false;
-                    for (int q = 1; q <= 16; q++) uniform = uniform || cnt16[q] == nn;
-                    if (!uniform) {
-                        for (int q = 0; q < 16; q++) cnt16[q + 1] += cnt16[q];
-                        sort_tmp.assign(e0, e0 + nn);
-                        for (int i = 0; i < nn; i++) e0[cnt16[(sort_tmp[(size_t)i].pad >> 16) & 15]++] = sort_tmp[(size_t)i];
-                    }
+        // One work list: the pairs [pr_lo, pr_hi) over the XCDs `xcds` (the points cut into as many ranges of equal cost; block
+        // stride * i + xcds[k] = the i-th workgroup of XCD xcds[k]).  Its entries are appended to s_entries, its segments come back
+        // in creation order (no slots yet), with the budget the cut ended on.
+        struct SchurList {
+            std::vector<SchurWG> segs;
+            std::vector<std::vector<std::vector<int>>> wgs_x;   // per XCD of the list: workgroups = lists of segment indices
+            std::vector<int> xcds;
+            int stride = 8;
+            double t_cut = 0;
+        };
+        auto build_list = [&](int pr_lo, int pr_hi, const std::vector<int>& xcds, int stride, int wg_per_cu) {
+            SchurList out;
+            out.xcds = xcds;
+            out.stride = stride;
+            const int NXL = (int)xcds.size();
+            const int SLOTS = 256 * wg_per_cu / 8 * (stride == 8 ? 1 : 8);   // workgroups of one XCD's list: its CUs' resident slots
+            out.wgs_x.resize(NXL);
+            // point ranges of equal cost
+            std::vector<double> pt_cost(P + 1, 0.0);
+            for (int pr = pr_lo; pr < pr_hi; pr++)
+                for (const SchurEntry& e : per_pair[pr]) pt_cost[e.pt + 1] += e.pad & 0xffff;
+            for (int p = 0; p < P; p++) pt_cost[p + 1] += pt_cost[p];
+            std::vector<int> bound(NXL + 1, 0);
+            for (int x = 1; x < NXL; x++)
+                bound[x] = (int)(std::lower_bound(pt_cost.begin(), pt_cost.end(), pt_cost[P] * x / NXL) - pt_cost.begin());
+            bound[NXL] = P;
+            for (int x = 0; x < NXL; x++) {
+                std::vector<int> lo(n_pairs, 0), hi(n_pairs, 0);
+                double cost_x = 0;
+                size_t ent_x = 0;
+                for (int pr = pr_lo; pr < pr_hi; pr++) {
+                    auto& v = per_pair[pr];
+                    auto cmp = [](const SchurEntry& e, int p) { return e.pt < p; };
+                    lo[pr] = (int)(std::lower_bound(v.begin(), v.end(), bound[x], cmp) - v.begin());
+                    hi[pr] = (int)(std::lower_bound(v.begin(), v.end(), bound[x + 1], cmp) - v.begin());
+                    for (int i = lo[pr]; i < hi[pr]; i++) cost_x += v[i].pad & 0xffff;
+                    ent_x += (size_t)(hi[pr] - lo[pr]);
                 }
-                pre[pr].assign((size_t)(hi[pr] - lo[pr]) + 1, 0.0);
-                for (int i = lo[pr]; i < hi[pr]; i++)
-                    pre[pr][(size_t)(i - lo[pr]) + 1] = pre[pr][(size_t)(i - lo[pr])] + (s_entries[(size_t)(base[pr] + i)].pad & 0xffff);
-            }
-            // The cut: the pairs' entries, one pair after another, into at most n_wg workgroups of whole 4-entry groups such that
-            // no workgroup's cost — entries + seg_cost per segment (+ second_lag for list positions >= SLOTS / 2: block 8 i + x >= 256,
-            // the second workgroup of its CU) — exceeds a budget T; T is the smallest for which the greedy fill needs no more than
-            // n_wg workgroups (bisection: the fill is exact about the segments a cut makes, which an a-priori budget — rounds 2-5:
-            // the mean cost — can only guess).
-            struct Cut { int pr, begin, end; };   // entries [begin, end) of pair pr, relative to lo[pr]
-            const int n_first = SCHUR_WG_PER_CU == 2 ? SLOTS / 2 : SLOTS;
-            auto fill = [&](double T, std::vector<std::vector<Cut>>* out) {
-                int n_out = 0;
-                std::vector<Cut> cur;
-                double cur_cost = 0;
-                auto close = [&]() {
-                    if (!cur.empty()) {
-                        if (out) out->push_back(cur);
-                        n_out++;
-                    }
-                    cur.clear();
-                    cur_cost = 0;
-                };
+                if (ent_x == 0) continue;
+                const int n_wg_max = (int)std::max<size_t>(1, std::min<size_t>(SLOTS, ent_x / (4 * MIN_SEG)));
+                // the XCD's entries: pair after pair, a pair's entries sorted by fragment pattern, with their prefix costs
+                std::vector<int> base(n_pairs, 0);               // position of pair pr's entry i in s_entries: base[pr] + i
+                std::vector<std::vector<double>> pre(n_pairs);   // prefix costs of the pair's (sorted) entries lo..hi
                 for (int pr : pair_order) {
-                    const std::vector<double>& pp = pre[pr];
-                    const int n = hi[pr] - lo[pr];
-                    int pos = 0;
-                    while (pos < n) {
-                        const int left = n - pos;
-                        // as many whole 4-entry groups as the workgroup's remaining budget pays for
-                        const double room = T - (n_out >= n_first ? second_lag : 0) - cur_cost - seg_cost, p0 = pp[(size_t)pos];
-                        int take = (int)(std::upper_bound(pp.begin() + pos, pp.end(), p0 + room) - (pp.begin() + pos)) - 1;
-                        take = take >= left ? left : std::max(0, take) / 4 * 4;
-                        // a sliver at the end of a full workgroup — less work than the segment itself would cost: start the next one
-                        if (!cur.empty() && left > take && (take < MIN_SEG || room < min_room)) {
-                            close();
-                            continue;
+                    if (pr < pr_lo || pr >= pr_hi) continue;
+                    base[pr] = (int)s_entries.size() - lo[pr];
+                    s_entries.insert(s_entries.end(), per_pair[pr].begin() + lo[pr], per_pair[pr].begin() + hi[pr]);
+                    if (sort_pattern && hi[pr] > lo[pr]) {   // entries of one fragment pattern next to each other: the kernel skips a
+                                                              // fragment set only when none of the FOUR points of a group has a camera in it
+                        // stable counting sort over the 16 patterns (kept in the entries' padding word); a chunk whose entries share
+                        // one pattern — every chunk of a dense problem — stays as it is
+                        SchurEntry* e0 = s_entries.data() + (s_entries.size() - (size_t)(hi[pr] - lo[pr]));
+                        const int nn = hi[pr] - lo[pr];
+                        int cnt16[17] = {0};
+                        for (int i = 0; i < nn; i++) cnt16[((e0[i].pad >> 16) & 15) + 1]++;
+                        bool uniform = false;
+                        for (int q = 1; q <= 16; q++) uniform = uniform || cnt16[q] == nn;
+                        if (!uniform) {
+                            for (int q = 0; q < 16; q++) cnt16[q + 1] += cnt16[q];
+                            sort_tmp.assign(e0, e0 + nn);
+                            for (int i = 0; i < nn; i++) e0[cnt16[(sort_tmp[(size_t)i].pad >> 16) & 15]++] = sort_tmp[(size_t)i];
                         }
-                        take = std::max(take, MIN_SEG);
-                        if (left - take < MIN_SEG) take = left;                // ... or at the end of the pair's chunk: take it along
-                        take = std::min(take, left);
-                        cur.push_back(Cut{pr, pos, pos + take});
-                        cur_cost += pp[(size_t)(pos + take)] - p0 + seg_cost;
-                        pos += take;
                     }
-                    if (!span) close();
+                    pre[pr].assign((size_t)(hi[pr] - lo[pr]) + 1, 0.0);
+                    for (int i = lo[pr]; i < hi[pr]; i++)
+                        pre[pr][(size_t)(i - lo[pr]) + 1] = pre[pr][(size_t)(i - lo[pr])] + (s_entries[(size_t)(base[pr] + i)].pad & 0xffff);
                 }
-                close();
-                return n_out;
-            };
-            int chunks_x = 0;
-            for (int pr = 0; pr < n_pairs; pr++) chunks_x += hi[pr] > lo[pr];
-            // ... for two workgroup counts when the XCD's work does not fill both slots of its CUs: one workgroup per CU, or as many as
-            // the entries allow (a few CUs with two workgroups and the rest with one take as long as two everywhere); T says which
-            auto smallest_budget = [&](int n_wg) {
-                double t_lo = cost_x / n_wg, t_hi = cost_x + (double)seg_cost * (chunks_x + n_wg) + second_lag + 1;
-                if (fixed_target >= 0) return (cost_x + (double)seg_cost * (n_wg + chunks_x - 1)) / n_wg * fixed_target;   // (rounds 2-5; A/B runs)
-                for (int it = 0; it < 40 && t_hi - t_lo > 1.0; it++) {
-                    const double mid = 0.5 * (t_lo + t_hi);
-                    if (fill(mid, nullptr) <= n_wg)
-                        t_hi = mid;
-                    else
-                        t_lo = mid;
+                // The cut: the pairs' entries, one pair after another, into at most n_wg workgroups of whole 4-entry groups such that
+                // no workgroup's cost — entries + seg_cost per segment (+ second_lag for list positions >= SLOTS / 2: block 8 i + x >= 256,
+                // the second workgroup of its CU) — exceeds a budget T; T is the smallest for which the greedy fill needs no more than
+                // n_wg workgroups (bisection: the fill is exact about the segments a cut makes, which an a-priori budget — rounds 2-5:
+                // the mean cost — can only guess).
+                struct Cut { int pr, begin, end; };   // entries [begin, end) of pair pr, relative to lo[pr]
+                const int n_first = wg_per_cu == 2 ? SLOTS / 2 : SLOTS;
+                auto fill = [&](double T, std::vector<std::vector<Cut>>* outc) {
+                    int n_out = 0;
+                    std::vector<Cut> cur;
+                    double cur_cost = 0;
+                    auto close = [&]() {
+                        if (!cur.empty()) {
+                            if (outc) outc->push_back(cur);
+                            n_out++;
+                        }
+                        cur.clear();
+                        cur_cost = 0;
+                    };
+                    for (int pr : pair_order) {
+                        if (pr < pr_lo || pr >= pr_hi) continue;
+                        const std::vector<double>& pp = pre[pr];
+                        const int n = hi[pr] - lo[pr];
+                        int pos = 0;
+                        while (pos < n) {
+                            const int left = n - pos;
+                            // as many whole 4-entry groups as the workgroup's remaining budget pays for
+                            const double room = T - (n_out >= n_first ? second_lag : 0) - cur_cost - seg_cost, p0 = pp[(size_t)pos];
+                            int take = (int)(std::upper_bound(pp.begin() + pos, pp.end(), p0 + room) - (pp.begin() + pos)) - 1;
+                            take = take >= left ? left : std::max(0, take) / 4 * 4;
+                            // a sliver at the end of a full workgroup — less work than the segment itself would cost: start the next one
+                            if (!cur.empty() && left > take && (take < MIN_SEG || room < min_room)) {
+                                close();
+                                continue;
+                            }
+                            take = std::max(take, MIN_SEG);
+                            if (left - take < MIN_SEG) take = left;                // ... or at the end of the pair's chunk: take it along
+                            take = std::min(take, left);
+                            cur.push_back(Cut{pr, pos, pos + take});
+                            cur_cost += pp[(size_t)(pos + take)] - p0 + seg_cost;
+                            pos += take;
+                        }
+                        if (!span) close();
+                    }
+                    close();
+                    return n_out;
+                };
+                int chunks_x = 0;
+                for (int pr = pr_lo; pr < pr_hi; pr++) chunks_x += hi[pr] > lo[pr];
+                // ... for two workgroup counts when the XCD's work does not fill both slots of its CUs: one workgroup per CU, or as many as
+                // the entries allow (a few CUs with two workgroups and the rest with one take as long as two everywhere); T says which
+                auto smallest_budget = [&](int n_wg) {
+                    double t_lo = cost_x / n_wg, t_hi = cost_x + (double)seg_cost * (chunks_x + n_wg) + second_lag + 1;
+                    if (fixed_target >= 0) return (cost_x + (double)seg_cost * (n_wg + chunks_x - 1)) / n_wg * fixed_target;   // (rounds 2-5; A/B runs)
+                    for (int it = 0; it < 40 && t_hi - t_lo > 1.0; it++) {
+                        const double mid = 0.5 * (t_lo + t_hi);
+                        if (fill(mid, nullptr) <= n_wg)
+                            t_hi = mid;
+                        else
+                            t_lo = mid;
+                    }
+                    return t_hi;
+                };
+                double t_cut = smallest_budget(n_wg_max);
+                if (n_wg_max > n_first && fixed_target < 0 && !ptam_ab_env("PTAM_SCHUR_NO_HALF")) t_cut = std::min(t_cut, smallest_budget(n_first));
+                out.t_cut = std::max(out.t_cut, t_cut);
+                std::vector<std::vector<Cut>> cuts;
+                fill(t_cut, &cuts);
+                for (const std::vector<Cut>& wg : cuts) {
+                    std::vector<int> ids;
+                    for (const Cut& c : wg) {
+                        ids.push_back((int)out.segs.size());
+                        out.segs.push_back(SchurWG{c.pr, base[c.pr] + lo[c.pr] + c.begin, base[c.pr] + lo[c.pr] + c.end, -1});
+                    }
+                    out.wgs_x[x].push_back(ids);
                 }
-                return t_hi;
-            };
-            double t_cut = smallest_budget(n_wg_max);
-            if (n_wg_max > n_first && fixed_target < 0 && !ptam_ab_env("PTAM_SCHUR_NO_HALF")) t_cut = std::min(t_cut, smallest_budget(n_first));
-            std::vector<std::vector<Cut>> cuts;
-            fill(t_cut, &cuts);
-            for (const std::vector<Cut>& wg : cuts) {
-                std::vector<int> ids;
-                for (const Cut& c : wg) {
-                    segs_of_pair[c.pr].push_back((int)s_segs.size());
-                    ids.push_back((int)s_segs.size());
-                    s_segs.push_back(SchurWG{c.pr, base[c.pr] + lo[c.pr] + c.begin, base[c.pr] + lo[c.pr] + c.end, -1});
-                }
-                wgs_x[x].push_back(ids);
             }
-        }
-        // partial-tile slots: contiguous per pair
-        int slot = 0;
-        for (int pr = 0; pr < n_pairs; pr++) {
-            pair_wg_begin[pr] = slot;
-            for (int sg : segs_of_pair[pr]) s_segs[sg].slot = slot++;
-        }
-        pair_wg_begin[n_pairs] = slot;
-        // blocks: 8 i + x = the i-th workgroup of XCD x (short lists are padded with empty workgroups); a workgroup's segments
-        // are consecutive in s_segs by construction
-        size_t longest = 0;
-        for (auto& v : wgs_x) longest = std::max(longest, v.size());
-        std::vector<SchurWG> ordered;
-        for (size_t i = 0; i < longest; i++)
-            for (int x = 0; x < NX; x++) {
-                s_wg_seg.push_back((int)ordered.size());
-                if (i < wgs_x[x].size())
-                    for (int sg : wgs_x[x][i]) ordered.push_back(s_segs[sg]);
+            return out;
+        };
+        // partial-tile slots, contiguous per pair in creation order (XCD range, then position), over the lists of one set; then the
+        // lists' segments in block order: a workgroup's segments consecutive (short lists are padded with empty workgroups)
+        auto finish_set = [&](std::vector<SchurList*> lists, std::vector<int>& pwb, std::vector<std::vector<SchurWG>*> segs_out,
+                              std::vector<std::vector<int>*> wg_seg_out) {
+            std::vector<std::vector<std::pair<int, int>>> of_pair(n_pairs);
+            for (size_t l = 0; l < lists.size(); l++)
+                for (size_t sg = 0; sg < lists[l]->segs.size(); sg++) of_pair[lists[l]->segs[sg].pair].push_back({(int)l, (int)sg});
+            int slot = 0;
+            pwb.assign(n_pairs + 1, 0);
+            for (int pr = 0; pr < n_pairs; pr++) {
+                pwb[pr] = slot;
+                for (auto& q : of_pair[pr]) lists[q.first]->segs[q.second].slot = slot++;
             }
-        s_wg_seg.push_back((int)ordered.size());
-        s_segs.swap(ordered);
+            pwb[n_pairs] = slot;
+            for (size_t l = 0; l < lists.size(); l++) {
+                const SchurList& L = *lists[l];
+                size_t longest = 0;
+                for (auto& v : L.wgs_x) longest = std::max(longest, v.size());
+                std::vector<SchurWG>& ordered = *segs_out[l];
+                std::vector<int>& wseg = *wg_seg_out[l];
+                ordered.clear();
+                wseg.clear();
+                for (size_t i = 0; i < longest; i++)
+                    for (int xb = 0; xb < L.stride; xb++) {   // block L.stride * i + xb
+                        wseg.push_back((int)ordered.size());
+                        for (size_t k = 0; k < L.xcds.size(); k++)
+                            if (L.xcds[k] == xb && i < L.wgs_x[k].size())
+                                for (int sg : L.wgs_x[k][i]) ordered.push_back(L.segs[sg]);
+                    }
+                wseg.push_back((int)ordered.size());
+            }
+            return slot;
+        };
+        std::vector<int> all_x;
+        for (int x = 0; x < NX; x++) all_x.push_back(x);
+        SchurList full = build_list(0, n_pairs, all_x, NX, SCHUR_WG_PER_CU);
+        finish_set({&full}, pair_wg_begin, {&s_segs}, {&s_wg_seg});
     }
 
     if (getenv("PTAM_DEBUG_SCHUR")) {   // groups by fragment pattern: what the tile kernel multiplies and loads
