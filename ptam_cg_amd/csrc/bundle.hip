@@ -1858,10 +1858,16 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
         HIP_TRY(hipMemcpy(wseg.data(), d.s_wg_seg, wseg.size() * 4, hipMemcpyDeviceToHost));
         std::vector<SchurWG> segs((size_t)wseg.back());
         HIP_TRY(hipMemcpy(segs.data(), d.s_segs, segs.size() * sizeof(SchurWG), hipMemcpyDeviceToHost));
-        std::printf("SCHUR schedule:");
+        std::vector<SchurEntry> ents((size_t)std::max(1, d.n_schur_entries));
+        HIP_TRY(hipMemcpy(ents.data(), d.s_entries, (size_t)d.n_schur_entries * sizeof(SchurEntry), hipMemcpyDeviceToHost));
+        std::printf("SCHUR schedule:");   // per segment  pair : groups : model cost of its entries (the split's units)
         for (int i = 0; i < nw; i++) {
             std::printf("%s{%d", i % 8 ? " " : "\n  ", i);
-            for (int sg = wseg[i]; sg < wseg[i + 1]; sg++) std::printf(" %d:%d", segs[sg].pair, (segs[sg].e_end - segs[sg].e_begin + 3) / 4);
+            for (int sg = wseg[i]; sg < wseg[i + 1]; sg++) {
+                long long cost = 0;
+                for (int e = segs[sg].e_begin; e < segs[sg].e_end; e++) cost += ents[(size_t)e].pad & 0xffff;
+                std::printf(" %d:%d:%lld", segs[sg].pair, (segs[sg].e_end - segs[sg].e_begin + 3) / 4, cost);
+            }
             std::printf("}");
         }
         std::printf("\n");
