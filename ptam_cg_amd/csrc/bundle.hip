@@ -24,6 +24,7 @@
 #include <climits>
 #include <atomic>
 #include <numeric>
+#include <thread>
 #include <utility>
 
 #include "bundle.h"
@@ -138,6 +139,23 @@ static int pair_a_of(int pair) {   // tile row a of pair index a (a + 1) / 2 + b
     while ((a + 1) * (a + 2) / 2 <= pair) a++;
     return a;
 }
+// The host loops of prepare that walk every measurement through an index (random reads of the insertion-order arrays: latency, not
+// arithmetic — 2.8 + 1.8 ms of an 8.6 ms prepare at 250 000 measurements on one core) are cut into ranges for a few threads;
+// fn(begin, end) must only write its own range's outputs.  Small bundles stay on the calling thread.
+template <class Fn>
+static void ba_par_ranges(int n, Fn fn) {
+    static const int hw = (int)std::thread::hardware_concurrency();
+    const int nt = std::min(std::min(8, std::max(1, hw / 2)), n / 65536);   // (a thread costs ~0.1 ms to start: 60 000 measurements on three threads took longer than on one)
+    if (nt <= 1) {
+        fn(0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back([=] { fn((int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt)); });
+    fn(0, (int)((long long)n / nt));
+    for (std::thread& t : th) t.join();
+}
+
 static int ba_prepare_impl(ptam_ba* ba) {
     ptam_ctx* ctx = ba->ctx;
     // PTAM_DEBUG_PREPARE=1: host time of the phases of this function (sort | lists | Schur work lists | launch shape | alloc + clear | upload)
@@ -185,17 +203,22 @@ static int ba_prepare_impl(ptam_ba* ba) {
         // the way an offset is at most 7 — in camera-id order, 255 or more fixed keyframes between two free ones of a
         // tile overflowed the 8-bit offsets, and a local adjustment has many fixed keyframes.)
         auto key = [&](int i) { const int c = ba->m_cam[i], f = cam_free[c]; return f >= 0 ? f : F + c; };
-        for (int p = 0; p < P_all; p++) {
-            int* b0 = order.data() + start[p];
-            int* b1 = order.data() + start[p + 1];
-            bool sorted = true;
-            for (int* q = b0; q + 1 < b1; q++)
-                if (key(q[0]) > key(q[1])) {
-                    sorted = false;
-                    break;
-                }
-            if (!sorted) std::stable_sort(b0, b1, [&](int x, int y) { return key(x) < key(y); });
-        }
+        // (ranges of points of about equal measurement counts: start[] is their prefix sum)
+        ba_par_ranges(live, [&](int m_lo, int m_hi) {
+            const int p_lo = (int)(std::lower_bound(start.begin(), start.end() - 1, m_lo) - start.begin());
+            const int p_hi = m_hi >= live ? P_all : (int)(std::lower_bound(start.begin(), start.end() - 1, m_hi) - start.begin());
+            for (int p = p_lo; p < p_hi; p++) {
+                int* b0 = order.data() + start[p];
+                int* b1 = order.data() + start[p + 1];
+                bool sorted = true;
+                for (int* q = b0; q + 1 < b1; q++)
+                    if (key(q[0]) > key(q[1])) {
+                        sorted = false;
+                        break;
+                    }
+                if (!sorted) std::stable_sort(b0, b1, [&](int x, int y) { return key(x) < key(y); });
+            }
+        });
         // The device sees only the points that HAVE a live measurement, numbered densely in their original order: the kernels
         // walk the point-major list 64 measurements at a time and fetch "the chunk's points" as one run of consecutive ids,
         // which a stretch of unobserved points (never measured, or every measurement purged earlier) would break.  An
@@ -217,6 +240,10 @@ static int ba_prepare_impl(ptam_ba* ba) {
             return PTAM_E_ARG;
         }
     ba->sorted_orig = order;
+    std::vector<int> f_sorted((size_t)M);   // free-camera index of the sorted list's measurements (read by three loops below)
+    ba_par_ranges(M, [&](int i_lo, int i_hi) {
+        for (int i = i_lo; i < i_hi; i++) f_sorted[(size_t)i] = cam_free[ba->m_cam[order[i]]];
+    });
     std::vector<int> rowptr(P + 1, 0);
     for (int i = 0; i < M; i++) rowptr[dense_of[(size_t)ba->m_pt[order[i]]] + 1]++;
     for (int p = 0; p < P; p++) rowptr[p + 1] += rowptr[p];
@@ -266,7 +293,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
             // in between and have no slot)
             int last_tile = -1;
             for (int i = rowptr[p]; i < rowptr[p + 1]; i++) {
-                const int f = cam_free[ba->m_cam[order[i]]];
+                const int f = f_sorted[(size_t)i];
                 if (f < 0) continue;
                 const int t = f / SCHUR_TC;
                 if (t != last_tile) {
@@ -499,9 +526,14 @@ static int ba_prepare_impl(ptam_ba* ba) {
                 // ... for two workgroup counts when the XCD's work does not fill both slots of its CUs: one workgroup per CU, or as many as
                 // the entries allow (a few CUs with two workgroups and the rest with one take as long as two everywhere); T says which
                 auto smallest_budget = [&](int n_wg) {
-                    double t_lo = cost_x / n_wg, t_hi = cost_x + (double)seg_cost * (chunks_x + n_wg) + second_lag + 1;
                     if (fixed_target >= 0) return (cost_x + (double)seg_cost * (n_wg + chunks_x - 1)) / n_wg * fixed_target;   // (rounds 2-5; A/B runs)
-                    for (int it = 0; it < 40 && t_hi - t_lo > 1.0; it++) {
+                    // (the mean cost is a lower bound; the upper one by steps of a quarter — the answer is 1.2 - 1.5 times the mean —,
+                    //  then bisection to 0.2 %: ~10 fills instead of the ~22 of a bisection from "everything in one workgroup")
+                    double t_lo = cost_x / n_wg, t_hi = 1.25 * t_lo + seg_cost + second_lag;
+                    const double t_all = cost_x + (double)seg_cost * (chunks_x + n_wg) + second_lag + 1;   // (one workgroup takes it all)
+                    while (t_hi < t_all && fill(t_hi, nullptr) > n_wg) t_lo = t_hi, t_hi *= 1.25;
+                    t_hi = std::min(t_hi, t_all);
+                    for (int it = 0; it < 40 && t_hi - t_lo > 0.002 * t_hi; it++) {
                         const double mid = 0.5 * (t_lo + t_hi);
                         if (fill(mid, nullptr) <= n_wg)
                             t_hi = mid;
@@ -511,7 +543,9 @@ static int ba_prepare_impl(ptam_ba* ba) {
                     return t_hi;
                 };
                 double t_cut = smallest_budget(n_wg_max);
-                if (n_wg_max > n_first && fixed_target < 0 && !ptam_ab_env("PTAM_SCHUR_NO_HALF")) t_cut = std::min(t_cut, smallest_budget(n_first));
+                // (one workgroup per CU cannot end before the mean of ITS cut: only tried where that is below the budget found)
+                if (n_wg_max > n_first && fixed_target < 0 && cost_x / n_first + seg_cost < t_cut && !ptam_ab_env("PTAM_SCHUR_NO_HALF"))
+                    t_cut = std::min(t_cut, smallest_budget(n_first));
                 out.t_cut = std::max(out.t_cut, t_cut);
                 std::vector<std::vector<Cut>> cuts;
                 fill(t_cut, &cuts);
@@ -862,16 +896,18 @@ static int ba_prepare_impl(ptam_ba* ba) {
     int* h_fidx = h_orig + Mz;
     double* h_found = (double*)(h_fidx + Mz);   // (16 Mz bytes in: 8-byte aligned)
     double* h_s = h_found + 2 * Mz;
-    for (int i = 0; i < M; i++) {
-        const int o = order[i];
-        h_cam[i] = ba->m_cam[o];
-        h_pt[i] = dense_of[(size_t)ba->m_pt[o]];
-        h_orig[i] = o;
-        h_fidx[i] = cam_free[ba->m_cam[o]];
-        h_found[2 * i] = ba->m_found[2 * o];
-        h_found[2 * i + 1] = ba->m_found[2 * o + 1];
-        h_s[i] = ba->m_s[o];
-    }
+    ba_par_ranges(M, [&](int i_lo, int i_hi) {
+        for (int i = i_lo; i < i_hi; i++) {
+            const int o = order[i];
+            h_cam[i] = ba->m_cam[o];
+            h_pt[i] = dense_of[(size_t)ba->m_pt[o]];
+            h_orig[i] = o;
+            h_fidx[i] = f_sorted[(size_t)i];
+            h_found[2 * i] = ba->m_found[2 * o];
+            h_found[2 * i + 1] = ba->m_found[2 * o + 1];
+            h_s[i] = ba->m_s[o];
+        }
+    });
     // block bandwidth of the camera system: S_jk != 0 only if cameras j, k share a point.  Keyframes that see the same
     // points are neighbours in time (src/MapMaker.cc adds them in order), so for a long trajectory S is banded and the
     // blocked LDL^T never leaves the band (no pivoting -> no fill outside it).  A sharded bundle only knows its own
