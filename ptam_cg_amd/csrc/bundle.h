@@ -128,8 +128,9 @@ struct BaDev {
     int* s_wg_seg;          // [n_schur_wg + 1] first segment of each workgroup (block 8 i + x = i-th workgroup of XCD x)
     int* s_pair_wg_begin;   // [n_pairs+1] first WG of each pair
     double* s_part;         // [partial-tile slots][48*48 + 48]
-    unsigned short* s_map;  // [6 variants of the tile body][48*48 + 48] where an element of the partial tile sits in the accumulator
-                            // layout of the cross-wave reduction (value index * 64 + lane; 0xffff: a zero) — schur_index_map()
+    unsigned* s_map;        // [6 variants of the tile body][256 threads][SCHUR_MAP_WPT] where the elements of the partial tile a thread
+                            // stores sit in the accumulator layout of the cross-wave reduction (two 16-bit indices per word: value
+                            // index * 64 + lane; 0xffff: a zero; 0xffffffff: no element) — schur_index_map_device()
     // camera system
     double* SE;             // S then E
     double* L;

@@ -795,7 +795,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
                  o_swg = cv.take(std::max<size_t>(1, s_segs.size()) * sizeof(SchurWG)), o_swgseg = cv.take(s_wg_seg.size() * 4),
                  o_spw = cv.take((size_t)(n_pairs + 1) * 4),
                  o_spart = cv.take(std::max<size_t>(1, s_segs.size()) * SCHUR_TILE_ELEMS * 8),
-                 o_smap = cv.take((size_t)SCHUR_N_VARIANTS * SCHUR_TILE_ELEMS * 2);
+                 o_smap = cv.take((size_t)SCHUR_N_VARIANTS * 64 * SCHUR_NW * SCHUR_MAP_WPT * 4);
     const size_t npad = std::max(d.npad, SOLVE_NB);
     // S and L block-banded (bundle.h: se_blk); sized for the full lower triangle, because a sharded bundle only learns the
     // bandwidth in force (the widest over all ranks) in Compute()'s first exchange
@@ -850,7 +850,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.s_wg_seg = (int*)(base + o_swgseg);
     d.s_pair_wg_begin = (int*)(base + o_spw);
     d.s_part = (double*)(base + o_spart);
-    d.s_map = (unsigned short*)(base + o_smap);
+    d.s_map = (unsigned*)(base + o_smap);
     d.SE = (double*)(base + o_SE);
     d.L = (double*)(base + o_L);
     d.Dg = (double*)(base + o_Dg);
@@ -970,8 +970,8 @@ static int ba_prepare_impl(ptam_ba* ba) {
     UP(d.s_segs, s_segs.data(), s_segs.size() * sizeof(SchurWG));
     UP(d.s_wg_seg, s_wg_seg.data(), s_wg_seg.size() * 4);
     UP(d.s_pair_wg_begin, pair_wg_begin.data(), pair_wg_begin.size() * 4);
-    const std::vector<unsigned short> s_map = schur_index_map();
-    UP(d.s_map, s_map.data(), s_map.size() * 2);
+    const std::vector<unsigned> s_map = schur_index_map_device();
+    UP(d.s_map, s_map.data(), s_map.size() * 4);
 #undef UP
     lap("stage + enqueue");
     HIP_TRY(ptam_stream_wait(ctx->stream));   // host staging vectors die here
