@@ -127,6 +127,7 @@ struct BaDev {
     SchurWG* s_segs;        // segments, a workgroup's one after another
     int* s_wg_seg;          // [n_schur_wg + 1] first segment of each workgroup (block 8 i + x = i-th workgroup of XCD x)
     int* s_pair_wg_begin;   // [n_pairs+1] first WG of each pair
+    int* s_wg_head;         // [n_schur_wg][8] {first segment, end, then the first segment itself: pair, e_begin, e_end, slot, 0, 0}
     double* s_part;         // [partial-tile slots][48*48 + 48]
     unsigned* s_map;        // [6 variants of the tile body][256 threads][SCHUR_MAP_WPT] where the elements of the partial tile a thread
                             // stores sit in the accumulator layout of the cross-wave reduction (two 16-bit indices per word: value

@@ -793,7 +793,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     const size_t o_hist = cv.take(2 * HIST_BINS * 4), o_cand = cv.take(Mz * 8);
     const size_t o_sent = cv.take(std::max<size_t>(1, s_entries.size()) * sizeof(SchurEntry)),
                  o_swg = cv.take(std::max<size_t>(1, s_segs.size()) * sizeof(SchurWG)), o_swgseg = cv.take(s_wg_seg.size() * 4),
-                 o_spw = cv.take((size_t)(n_pairs + 1) * 4),
+                 o_spw = cv.take((size_t)(n_pairs + 1) * 4), o_swghead = cv.take(std::max<size_t>(1, s_wg_seg.size()) * 32),
                  o_spart = cv.take(std::max<size_t>(1, s_segs.size()) * SCHUR_TILE_ELEMS * 8),
                  o_smap = cv.take((size_t)SCHUR_N_VARIANTS * 64 * SCHUR_NW * SCHUR_MAP_WPT * 4);
     const size_t npad = std::max(d.npad, SOLVE_NB);
@@ -849,6 +849,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.s_segs = (SchurWG*)(base + o_swg);
     d.s_wg_seg = (int*)(base + o_swgseg);
     d.s_pair_wg_begin = (int*)(base + o_spw);
+    d.s_wg_head = (int*)(base + o_swghead);
     d.s_part = (double*)(base + o_spart);
     d.s_map = (unsigned*)(base + o_smap);
     d.SE = (double*)(base + o_SE);
@@ -970,6 +971,16 @@ static int ba_prepare_impl(ptam_ba* ba) {
     UP(d.s_segs, s_segs.data(), s_segs.size() * sizeof(SchurWG));
     UP(d.s_wg_seg, s_wg_seg.data(), s_wg_seg.size() * 4);
     UP(d.s_pair_wg_begin, pair_wg_begin.data(), pair_wg_begin.size() * 4);
+    std::vector<int> s_wg_head((size_t)std::max(1, d.n_schur_wg) * 8, 0);   // (outlives the asynchronous upload: the function waits for the queue at its end)
+    for (int b = 0; b < d.n_schur_wg; b++) {
+        int* h = s_wg_head.data() + (size_t)8 * b;
+        h[0] = s_wg_seg[(size_t)b], h[1] = s_wg_seg[(size_t)b + 1];
+        if (h[1] > h[0]) {
+            const SchurWG& sg = s_segs[(size_t)h[0]];
+            h[2] = sg.pair, h[3] = sg.e_begin, h[4] = sg.e_end, h[5] = sg.slot;
+        }
+    }
+    UP(d.s_wg_head, s_wg_head.data(), s_wg_head.size() * 4);
     const std::vector<unsigned> s_map = schur_index_map_device();
     UP(d.s_map, s_map.data(), s_map.size() * 4);
 #undef UP
