@@ -150,9 +150,19 @@ static void ba_par_ranges(int n, Fn fn) {
         fn(0, n);
         return;
     }
+    // (a thread that cannot be started — resource limits of the host process — must not take the caller down through a C ABI:
+    //  the ranges that got no thread run here)
     std::vector<std::thread> th;
-    for (int t = 1; t < nt; t++) th.emplace_back([=] { fn((int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt)); });
+    int started = 1;
+    try {
+        for (; started < nt; started++) {
+            const int t = started;
+            th.emplace_back([=] { fn((int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt)); });
+        }
+    } catch (...) {
+    }
     fn(0, (int)((long long)n / nt));
+    for (int t = started; t < nt; t++) fn((int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt));
     for (std::thread& t : th) t.join();
 }
 
