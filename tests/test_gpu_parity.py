@@ -882,3 +882,29 @@ def test_ill_conditioned_bundles_before_the_extended_precision_referee(hip, orac
         # both are off by the same order; the product is not the outlier of the three
         assert d_got <= 10 * max(d_orc, 1e-9)
         assert np.array_equal(got["outliers"], ref["outliers"])
+
+
+@pytest.mark.parametrize("shape", [(50, 5000, None), (20, 3000, None), (200, 26000, 16), (9, 400, None)])
+def test_schur_work_lists_fit_the_resident_slots(shape):
+    """The Schur tile kernel's work split (ba_prepare_impl: cost model fitted to stamps, budget by bisection) must never make
+    more workgroups than the chip holds at once — 2 per CU, 512 — or a second round of them doubles the launch; and a
+    workgroup should stay at a few segments (each costs ~5 us of pipeline fill and partial-tile traffic).  Read from the
+    library's own PTAM_DEBUG_SCHUR report, in a process of its own (the variable is looked at once)."""
+    import os
+    import re
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import torch\n"
+            "from ptam_cg_amd import host, synth\n"
+            "from ptam_cg_amd._lib import load\n"
+            "ctx = host.Context(lib=load())\n"
+            "ba = synth.load_into(host.Bundle(ctx), synth.make_ba_problem(%d, %d, 11, window=%r))\n"
+            "ba.prepare(); ctx.sync(); ba.close()\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), shape[0], shape[1], shape[2])
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PTAM_DEBUG_SCHUR="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m = re.search(r"schur: (\d+) segments, (\d+) workgroups", r.stderr)
+    assert m, r.stderr[-2000:]
+    segs, wgs = int(m.group(1)), int(m.group(2))
+    assert 0 < wgs <= 512
+    assert segs <= 2.5 * wgs
