@@ -363,3 +363,69 @@ def test_extended_precision_referee_agrees_with_the_oracle_on_a_well_posed_bundl
     rel = np.abs(r["trials"]["err_new"] / o["trials"]["err_new"] - 1).max()
     assert 0 < rel < 1e-9
     assert np.abs(r["poses"] - o["poses"]).max() < 1e-10 and np.array_equal(np.asarray(r["outliers"]).ravel(), np.asarray(o["outliers"]).ravel())
+
+
+def test_bundle_lm_trial_against_finite_difference_normal_equations(oracle):
+    """An anchor for Do_LM_Step (src/Bundle.cc:209-551) that reads none of its derivative formulas: the oracle's FIRST lambda
+    trial on a toy problem against the damped Gauss-Newton step of the mathematical definition — residuals
+    sqrt(weight) * sqrtInvNoise * (found - Project(exp(da) * T * (X + db))), their Jacobian by central finite differences of the
+    oracle's own projection (pinned above against the pinhole limit and its own finite differences), the FULL normal equations
+    with (1 + lambda) on the diagonals of the camera and point blocks (:341-359, :383-390) solved densely by numpy, the update
+    applied as exp(da) * T / X + db (:496-504), the new error as the sum of Tukey objective scores.  What it pins: the camera
+    and point Jacobians (:291-313), the block elimination being equivalent to the full system (:374-458), the damping, the update
+    and the scores — by numbers, not by a second reading of the same source."""
+    prob = synth.make_ba_problem(3, 14, 5, outlier_frac=0.0, pt_noise=0.004, pose_noise=0.002)
+    r = util.run_ba(oracle, prob, max_iterations=1)
+    t = r["trials"][0]
+    lam, s2 = float(t["lambda"]), float(t["sigma_sq"])
+    ctx = host.Context(lib=oracle)
+    free = np.flatnonzero(prob["fixed"] == 0)
+    col_c = {int(c): 6 * i for i, c in enumerate(free)}
+    n_c, n_p = 6 * len(free), 3 * len(prob["points"])
+    cam_idx, pt_idx = prob["cam_idx"], prob["pt_idx"]
+    sn = np.sqrt(1.0 / prob["sigma_sq"])
+
+    def project(pose, X):
+        return ctx.project_points(np.asarray(X, float).reshape(1, 3), pose)["image"][0]
+
+    def moved(pose, mu):
+        return synth.se3_mul(se3_exp(oracle, mu), pose)
+
+    # residuals at the start state; the step's Tukey weights from them and the trial's sigma^2 (include/Tools.h:193-228)
+    e0 = np.array([sn[i] * (prob["found"][i] - project(prob["poses"][cam_idx[i]], prob["points"][pt_idx[i]])) for i in range(len(cam_idx))])
+    e2 = (e0 ** 2).sum(1)
+    assert (e2 < s2).all() and float(t["n_bad"]) == 0   # (a toy without outliers: every measurement takes part)
+    wsq = 1.0 - e2 / s2                                   # SquareRootWeight
+    cur = np.sum(1.0 - (1.0 - e2 / s2) ** 3)              # ObjectiveScore
+    assert cur == pytest.approx(float(t["err_old"]), rel=1e-9)
+    J = np.zeros((2 * len(cam_idx), n_c + n_p))
+    h = 1e-6
+    for i, (c, p) in enumerate(zip(cam_idx, pt_idx)):
+        T, X = prob["poses"][c], prob["points"][p]
+        if int(c) in col_c:
+            for k in range(6):
+                d = np.zeros(6)
+                d[k] = h
+                J[2 * i:2 * i + 2, col_c[int(c)] + k] = (project(moved(T, d), X) - project(moved(T, -d), X)) / (2 * h)
+        for k in range(3):
+            d = np.zeros(3)
+            d[k] = h
+            J[2 * i:2 * i + 2, n_c + 3 * p + k] = (project(T, X + d) - project(T, X - d)) / (2 * h)
+    sc = np.repeat(wsq * sn, 2)
+    Jw, ew = J * sc[:, None], (np.repeat(wsq, 2) * e0.ravel())
+    H, g = Jw.T @ Jw, Jw.T @ ew
+    H[np.diag_indices_from(H)] *= (1.0 + lam)             # every diagonal element belongs to a camera's or a point's own block
+    used = np.flatnonzero(np.diag(H) > 0)                 # (a point no camera of the toy sees takes no part)
+    delta = np.zeros(n_c + n_p)
+    delta[used] = np.linalg.solve(H[np.ix_(used, used)], g[used])
+    poses_new = prob["poses"].copy()
+    for c, o in col_c.items():
+        poses_new[c] = moved(prob["poses"][c], delta[o:o + 6])
+    pts_new = prob["points"] + delta[n_c:].reshape(-1, 3)
+    e2n = np.array([((sn[i] * (prob["found"][i] - project(poses_new[cam_idx[i]], pts_new[pt_idx[i]]))) ** 2).sum() for i in range(len(cam_idx))])
+    new = np.sum(np.where(e2n > s2, 1.0, 1.0 - (1.0 - e2n / s2) ** 3))
+    assert new == pytest.approx(float(t["err_new"]), rel=1e-6)
+    assert int(t["accepted"]) == 1
+    assert np.allclose(r["poses"], poses_new, rtol=0, atol=1e-7)
+    assert np.allclose(r["points"], pts_new, rtol=0, atol=1e-7)
+    ctx.close()
