@@ -429,3 +429,41 @@ def test_bundle_lm_trial_against_finite_difference_normal_equations(oracle):
     assert np.allclose(r["poses"], poses_new, rtol=0, atol=1e-7)
     assert np.allclose(r["points"], pts_new, rtol=0, atol=1e-7)
     ctx.close()
+
+
+def test_pose_gn_first_update_against_finite_difference_jacobians(oracle):
+    """The same kind of anchor for the tracker's pose step (TrackerData::CalcJacobian include/Tracker.h:84-94, CalcPoseUpdate
+    src/Tracker.cc:928-1005): the FIRST Gauss-Newton update of the oracle's pose loop against
+    (prior I + sum w s^2 J^T J)^-1 sum w s^2 J^T (found - image)  with J by central finite differences of
+    Project(exp(mu) * T * X) and w the Tukey weight for the sigma^2 of the errors' median (pinned above on a fixed vector)."""
+    rng = np.random.default_rng(12)
+    ctx = host.Context(lib=oracle)
+    pose_true = synth.look_at([0.3, -2.0, 1.0], [0, 0, 0])
+    world = np.column_stack([rng.uniform(-0.5, 0.5, 40), rng.uniform(-0.5, 0.5, 40), rng.uniform(-0.1, 0.1, 40)])
+    lv = rng.integers(0, 4, 40)
+    s = 1.0 / 2.0 ** lv
+    found = ctx.project_points(world, pose_true)["image"] + rng.normal(0, 0.4, (40, 2)) * (2.0 ** lv)[:, None]
+    pose0 = synth.se3_mul(se3_exp(oracle, rng.normal(0, 0.01, 6)), pose_true)
+    opts = ctx.gn_opts(iterations=1, mark_outliers_iter=-1)
+    _, _, updates = ctx.pose_gn(world, found, s, pose0, opts)
+    image = ctx.project_points(world, pose0)["image"]
+    e = s[:, None] * (found - image)
+    e2 = np.ascontiguousarray((e ** 2).sum(1))
+    s2 = oracle.lib.ptamo_tukey_sigma_sq(e2.ctypes.data, len(e2))
+    w = np.where(e2 > s2, 0.0, (1.0 - e2 / s2) ** 2)   # Tukey::Weight = SquareRootWeight^2 (include/Tools.h:193-207)
+    h = 1e-6
+    H, g = opts.prior * np.eye(6), np.zeros(6)
+    for i in range(40):
+        J = np.zeros((2, 6))
+        for k in range(6):
+            d = np.zeros(6)
+            d[k] = h
+            J[:, k] = (ctx.project_points(world[i:i + 1], synth.se3_mul(se3_exp(oracle, d), pose0))["image"][0] -
+                       ctx.project_points(world[i:i + 1], synth.se3_mul(se3_exp(oracle, -d), pose0))["image"][0]) / (2 * h)
+        Js = s[i] * J
+        H += w[i] * Js.T @ Js
+        g += w[i] * Js.T @ e[i]
+    mu = np.linalg.solve(H, g)
+    assert np.abs(mu).max() > 1e-4                       # (the start pose is off: a real step)
+    assert np.allclose(updates[0], mu, rtol=1e-6, atol=1e-9)
+    ctx.close()
