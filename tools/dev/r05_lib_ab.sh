@@ -12,7 +12,7 @@ b = json.loads([l for l in open("/tmp/ab_log.txt") if l.startswith("{")][-1])
 g = b.get("global_ba_single_gpu", {}); l = b.get("local_ba_config4", {})
 k = {a: round(1e3 * v, 1) for a, v in b.get("kernel_ms_per_trial", {}).items()}
 kl = {a: round(1e3 * v, 1) for a, v in l.get("kernel_ms_per_trial", {}).items()}
-print("%-8s accepted trial %.1f us mix %s | %s | local %.1f us sel %.1f prj %.1f | config5 %.0f it/s" % (sys.argv[1].split("/")[-2], b.get("accepted_trial_us", 0), list(b.get("trial_mix", {}).values()), k, 1e3 * l.get("ms_per_step", 0), kl.get("select", 0), kl.get("project", 0), g.get("value", 0)))
+print("%-8s accepted trial %.1f us mix %s | %s | local %.1f us sel %.1f prj %.1f | config5 %.0f it/s solve %.1f" % (sys.argv[1].split("/")[-2], b.get("accepted_trial_us", 0), list(b.get("trial_mix", {}).values()), k, 1e3 * l.get("ms_per_step", 0), kl.get("select", 0), kl.get("project", 0), g.get("value", 0), 1e3 * g.get("kernel_ms_per_trial", {}).get("solve", 0)))
 PY
 done
 done
