@@ -1,0 +1,154 @@
+// ba_split.h — the work split of the Schur tile kernel (ba_schur.inc) as integer arithmetic on RUN LISTS, shared by the device
+// kernels that build the lists (ba_prepare.inc) and by the host-side checker of the instrumented build (bundle.hip, PTAM_AB_SWITCHES).
+//
+// One XCD's work list is the tile pairs' entries one pair after another; inside a pair the entries are sorted by fragment pattern,
+// and an entry's model cost depends on (pair, pattern) only — so a pair's list is at most 16 RUNS of equal-cost entries, and
+// everything the split needs ("how many whole entries fit this budget", "what do entries [pos, pos + take) cost") is a walk over
+// one to three runs instead of a binary search over per-entry prefix sums.  The split then needs the (XCD, pair, pattern) counts
+// only — not the entries — and runs before they are placed.  Budgets and costs are integers (the cost model's units are ~ns):
+// host and device take the same decisions bit for bit.
+#pragma once
+
+struct SplitCfg {
+    int seg_cost;     // fixed cost of a segment (pipeline fill, cross-wave reduction, partial tile out)
+    int second_lag;   // what a CU's second workgroup is given less than its first
+    int min_room;     // a workgroup begins another segment only for at least this much work
+    int min_seg;      // entries of the shortest segment
+    int n_first;      // list positions >= n_first are second workgroups of their CUs
+    int cost_model;   // load term of an entry's cost (0: every entry costs 1)
+    int slots;        // workgroups one XCD holds at once
+};
+
+// one XCD's list: pairs k = 0..np-1 (the non-empty ones, in list order), pair k's runs are [pl_run0[k], pl_run0[k + 1])
+struct SplitRuns {
+    const int* run_cnt;
+    const int* run_cost;
+    const int* pl_run0;   // [np + 1]
+    const int* pl_n;      // entries of the pair
+    int np;
+};
+
+// 16x16 fragments per tile (row mappings of ba_schur.inc: 1-2 cameras in a tile = 1 fragment, 3-5 = 2, 6-8 = 3)
+__host__ __device__ inline int split_frags(int F, int t) {
+    int n = F - t * 8;
+    if (n > 8) n = 8;
+    return n <= 2 ? 1 : (n <= 5 ? 2 : 3);
+}
+// Model cost of one entry of tile pair (a, b), a >= b, with fragment pattern `pat` (bit 0: a camera of the point in slots 0..5 of
+// tile a, bit 1: in slots 5..7, bits 2, 3: the same for tile b): 10 units per 16x16 fragment product + cost_model for its loads
+// (fitted to per-workgroup stamps of the tile kernel, tools/dev/schur_fit.py, docs/LOG_r05.md).
+__host__ __device__ inline int split_entry_cost(int F, int a, int b, int pat, int cost_model) {
+    if (!cost_model) return 1;
+    const int ma = split_frags(F, a), mb = split_frags(F, b);
+    const int a01 = (pat & 1) ? (ma < 2 ? ma : 2) : 0, a2 = (ma == 3 && (pat & 2)) ? 1 : 0;
+    int f;
+    if (a == b)
+        f = a01 * a01 + a2 * a01 + a2;
+    else {
+        const int b01 = (pat & 4) ? (mb < 2 ? mb : 2) : 0, b2 = (mb == 3 && (pat & 8)) ? 1 : 0;
+        f = (a01 + a2) * (b01 + b2);
+    }
+    return 10 * f + cost_model;
+}
+// fragment products of a pair whose points have cameras everywhere (the order of the pairs in a list: fewest first)
+__host__ __device__ inline int split_full_products(int F, int a, int b) {
+    const int ma = split_frags(F, a), mb = split_frags(F, b);
+    return a == b ? (ma == 3 ? 7 : (ma == 2 ? 4 : 1)) : ma * mb;
+}
+
+// The greedy fill: the pairs' entries, one pair after another, into workgroups of whole 4-entry groups such that no workgroup's
+// cost — entries + seg_cost per segment (+ second_lag for list positions >= n_first) — exceeds T.  Returns the workgroups made;
+// emit(k, begin, end, wg) is called for every segment (entries [begin, end) of pair k, relative to the pair's first entry in
+// this list, in workgroup wg).
+template <class Emit>
+__host__ __device__ inline int split_fill(long long T, const SplitRuns& R, const SplitCfg& c, Emit&& emit) {
+    int n_out = 0, cur_n = 0;
+    long long cur_cost = 0;
+    for (int k = 0; k < R.np; k++) {
+        const int n = R.pl_n[k], run1 = R.pl_run0[k + 1];
+        int pos = 0, ri = R.pl_run0[k], ro = 0;
+        while (pos < n) {
+            const int left = n - pos;
+            const long long room = T - (n_out >= c.n_first ? c.second_lag : 0) - cur_cost - c.seg_cost;
+            // as many whole entries as the workgroup's remaining budget pays for
+            int take = 0;
+            if (room >= 0) {
+                long long rem = room;
+                int i = ri, o = ro;
+                while (i < run1) {
+                    const int avail = R.run_cnt[i] - o, cst = R.run_cost[i];
+                    if ((long long)avail * cst <= rem) {
+                        take += avail;
+                        rem -= (long long)avail * cst;
+                        i++;
+                        o = 0;
+                    } else {
+                        take += (int)(rem / cst);
+                        break;
+                    }
+                }
+            }
+            take = take >= left ? left : take / 4 * 4;
+            // a sliver at the end of a full workgroup — less work than the segment itself would cost: start the next one
+            if (cur_n > 0 && left > take && (take < c.min_seg || room < c.min_room)) {
+                n_out++;
+                cur_n = 0;
+                cur_cost = 0;
+                continue;
+            }
+            if (take < c.min_seg) take = c.min_seg;
+            if (left - take < c.min_seg) take = left;   // ... or at the end of the pair's chunk: take it along
+            if (take > left) take = left;
+            long long cst = 0;
+            for (int t = take; t > 0;) {
+                const int avail = R.run_cnt[ri] - ro, s = avail < t ? avail : t;
+                cst += (long long)s * R.run_cost[ri];
+                t -= s;
+                ro += s;
+                if (ro == R.run_cnt[ri]) ri++, ro = 0;
+            }
+            emit(k, pos, pos + take, n_out);
+            cur_n++;
+            cur_cost += cst + c.seg_cost;
+            pos += take;
+        }
+    }
+    if (cur_n > 0) n_out++;
+    return n_out;
+}
+
+// The budget search looks at SPLIT_NC budgets per round, evenly spaced in (lo, hi], and keeps the bracket around the smallest
+// one whose fill needs no more than n_wg workgroups (the device: one lane per budget; the host checker: one after another).
+#define SPLIT_NC 256
+struct SplitBracket {
+    long long lo, hi, t_all;
+    int done;
+};
+__host__ __device__ inline SplitBracket split_bracket_begin(long long cost_x, int n_wg, int chunks_x, const SplitCfg& c) {
+    SplitBracket b;
+    b.lo = cost_x / n_wg;                                   // the mean cost is a lower bound
+    b.hi = b.lo + b.lo / 4 + c.seg_cost + c.second_lag;     // the answer is 1.2 - 1.5 times the mean
+    b.t_all = cost_x + (long long)c.seg_cost * (chunks_x + n_wg) + c.second_lag + 1;   // one workgroup takes it all
+    if (b.hi > b.t_all) b.hi = b.t_all;
+    if (b.lo >= b.hi) b.lo = b.hi - 1;
+    b.done = 0;
+    return b;
+}
+__host__ __device__ inline long long split_candidate(const SplitBracket& b, int j) { return b.lo + (b.hi - b.lo) * (j + 1) / SPLIT_NC; }
+// jmin: the smallest j whose candidate was feasible (SPLIT_NC: none)
+__host__ __device__ inline void split_bracket_step(SplitBracket& b, int jmin) {
+    if (jmin >= SPLIT_NC) {
+        if (b.hi >= b.t_all) {   // (cannot happen: one workgroup always takes it all)
+            b.done = 1;
+            return;
+        }
+        b.lo = b.hi;
+        b.hi = b.hi + b.hi / 4 + 1;
+        if (b.hi > b.t_all) b.hi = b.t_all;
+        return;
+    }
+    const long long nhi = split_candidate(b, jmin), nlo = jmin > 0 ? split_candidate(b, jmin - 1) : b.lo;
+    b.lo = nlo;
+    b.hi = nhi;
+    if (b.hi - b.lo <= b.hi / 400 + 1) b.done = 1;   // 0.25 %
+}

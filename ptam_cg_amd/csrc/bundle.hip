@@ -23,8 +23,9 @@
 #include <chrono>
 #include <climits>
 #include <atomic>
+#include <map>
+#include <mutex>
 #include <numeric>
-#include <thread>
 #include <utility>
 
 #include "bundle.h"
@@ -36,20 +37,79 @@
 #include "ba_jacobian.inc"
 #include "ba_schur.inc"
 #include "ba_update.inc"
+#include "ba_prepare.inc"
 
 // =================================================================================================
 // host
 // =================================================================================================
+// A growing array in PINNED host memory: the measurements are uploaded as they were added (the index structures are built on the
+// device, ba_prepare.inc), and a copy out of pageable memory is staged by the runtime piece by piece (2.5 ms for the 8 MB of
+// 250 000 measurements against 0.3 ms).  Released arrays go to the context's cache: MapMaker builds a new Bundle for every
+// adjustment (src/MapMaker.cc:838-845), and pinning pages costs far more than using them.
+template <class T>
+struct PinVec {
+    ptam_ctx* ctx = nullptr;
+    T* p = nullptr;
+    size_t n = 0, cap = 0, cap_bytes = 0;
+    size_t size() const { return n; }
+    T* data() { return p; }
+    const T* data() const { return p; }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+    int reserve(size_t want) {
+        if (want <= cap) return PTAM_OK;
+        const size_t bytes = std::max<size_t>(want * sizeof(T), 4096);
+        void* np = nullptr;
+        size_t nbytes = 0;
+        if (!ctx_cache_take(ctx->pin_cache, CTX_NCACHE(ctx->pin_cache), bytes, &np, &nbytes)) {
+            HIP_TRY(hipSetDevice(ctx->device));
+            HIP_TRY(hipHostMalloc(&np, bytes, hipHostMallocDefault));
+            nbytes = bytes;
+        }
+        if (n) std::memcpy(np, p, n * sizeof(T));
+        release();
+        p = (T*)np;
+        cap_bytes = nbytes;
+        cap = nbytes / sizeof(T);
+        return PTAM_OK;
+    }
+    int grow(size_t more) { return n + more <= cap ? PTAM_OK : reserve(std::max(n + more, 2 * cap)); }
+    int push_back(const T& v) {
+        if (n == cap) {
+            const int rc = grow(1);
+            if (rc) return rc;
+        }
+        p[n++] = v;
+        return PTAM_OK;
+    }
+    int append(const T* src, size_t k) {
+        const int rc = grow(k);
+        if (rc) return rc;
+        std::memcpy(p + n, src, k * sizeof(T));
+        n += k;
+        return PTAM_OK;
+    }
+    void release() {   // (keeps n: reserve() re-points the array)
+        if (p) {
+            void* drop = ctx_cache_give(ctx->pin_cache, CTX_NCACHE(ctx->pin_cache), p, cap_bytes);
+            if (drop) hipHostFree(drop);
+        }
+        p = nullptr;
+        cap = cap_bytes = 0;
+    }
+};
+
 struct ptam_ba {
     ptam_ctx* ctx;
     ptam_ba_opts opts;
-    // inputs (insertion order), copied at add_* time like the reference
+    // inputs (insertion order), copied at add_* time like the reference; the per-measurement and per-point arrays in pinned memory
     std::vector<double> cam_pose;
     std::vector<uint8_t> cam_fixed;
-    std::vector<double> pts;
-    std::vector<int> m_cam, m_pt;
-    std::vector<double> m_found, m_s;
-    std::vector<uint8_t> m_dead;
+    PinVec<double> pts;
+    PinVec<int> m_cam, m_pt;
+    PinVec<double> m_found, m_sig;   // m_sig: sigma^2 as given (dSqrtInvNoise is formed on the device)
+    PinVec<uint8_t> m_dead;
+    int n_dead = 0;
     // results
     bool converged = false;
     int accepted = 0;
@@ -63,6 +123,10 @@ struct ptam_ba {
     BaDev d;
     void* block = nullptr;
     size_t block_bytes = 0, block_cap = 0;
+    void* sblock = nullptr;   // the Schur work lists (sized after the device has counted their entries)
+    size_t sblock_bytes = 0, sblock_cap = 0;
+    int n_schur_segs = 0;
+    bool xchg_owned = false;   // d_xchg is an allocation of its own (a sharded bundle whose prepare failed)
     bool e2_is_current = false;   // m_e2 / m_state hold pass 1 of the CURRENT poses and points (the last step accepted nothing)
     int band_local = 0;     // block bandwidth of S needed by THIS process' points (ba->d.band: the one in force)
     int cur = 0;
@@ -84,7 +148,6 @@ struct ptam_ba {
     bool trial_is_current = false;   // the last trial was accepted: its new-error pass == pass 1 of the next step
     int k7_threads = BA_CHUNK;
     bool k7_loop = false;
-    std::vector<int> sorted_orig;   // sorted position -> insertion index
     std::vector<int> pt_orig;       // device point id -> original point id (the points with a live measurement, ascending)
     // gather buffers (sharded mode)
     double* d_gather = nullptr;
@@ -108,16 +171,21 @@ struct ptam_ba {
 };
 
 static void ba_free_device(ptam_ba* ba) {
-    if (ba->block) {
-        // the block's kernels may still be queued: the next owner only touches it through the same stream
-        void* drop = ctx_cache_give(ba->ctx->dev_cache, ba->block, ba->block_cap);
-        if (drop) hipFree(drop);
+    for (int k = 0; k < 2; k++) {
+        void* blk = k ? ba->sblock : ba->block;
+        if (blk) {
+            // the block's kernels may still be queued: the next owner only touches it through the same stream
+            void* drop = ctx_cache_give(ba->ctx->dev_cache, CTX_NCACHE(ba->ctx->dev_cache), blk, k ? ba->sblock_cap : ba->block_cap);
+            if (drop) hipFree(drop);
+        }
     }
     if (ba->d_gather) hipFree(ba->d_gather);
-    if (ba->d_xchg) hipFree(ba->d_xchg);
+    if (ba->d_xchg && ba->xchg_owned) hipFree(ba->d_xchg);   // (otherwise a piece of the block)
+    ba->xchg_owned = false;
     if (ba->d_sel) hipFree(ba->d_sel);
     ba->d_sel = nullptr;
     ba->block = nullptr;
+    ba->sblock = nullptr;
     ba->d_gather = nullptr;
     ba->d_xchg = nullptr;
     ba->gather_cap = 0;
@@ -134,41 +202,56 @@ struct Carver {
 };
 
 static void ba_finish_outliers(ptam_ba* ba);
-static int pair_a_of(int pair) {   // tile row a of pair index a (a + 1) / 2 + b, b <= a
-    int a = 0;
-    while ((a + 1) * (a + 2) / 2 <= pair) a++;
-    return a;
-}
-// The host loops of prepare that walk every measurement through an index (random reads of the insertion-order arrays: latency, not
-// arithmetic — 2.8 + 1.8 ms of an 8.6 ms prepare at 250 000 measurements on one core) are cut into ranges for a few threads;
-// fn(begin, end) must only write its own range's outputs.  Small bundles stay on the calling thread.
-template <class Fn>
-static void ba_par_ranges(int n, Fn fn) {
-    static const int hw = (int)std::thread::hardware_concurrency();
-    const int nt = std::min(std::min(8, std::max(1, hw / 2)), n / 65536);   // (a thread costs ~0.1 ms to start: 60 000 measurements on three threads took longer than on one)
-    if (nt <= 1) {
-        fn(0, n);
-        return;
-    }
-    // (a thread that cannot be started — resource limits of the host process — must not take the caller down through a C ABI:
-    //  the ranges that got no thread run here)
-    std::vector<std::thread> th;
-    int started = 1;
-    try {
-        for (; started < nt; started++) {
-            const int t = started;
-            th.emplace_back([=] { fn((int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt)); });
+// Wait for a stamp a kernel writes into host-mapped memory behind its results (ptam_stream_wait sleeps on an interrupt: up to
+// milliseconds to wake up); every now and then ask the runtime whether the stream died instead.
+static int ba_wait_stamp(ptam_ctx* ctx, volatile unsigned long long* slot, unsigned long long seq) {
+    unsigned spins = 0;
+    while (*slot != seq) {
+        if (++spins == 100000) {
+            spins = 0;
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q != hipSuccess && q != hipErrorNotReady) {
+                ptam_set_error("the device queue failed while the bundle was being prepared: %s", hipGetErrorString(q));
+                return PTAM_E_HIP;
+            }
+            if (q == hipSuccess && *slot != seq) {
+                ptam_set_error("bundle prepare: the queue drained without its stamp");
+                return PTAM_E_HIP;
+            }
         }
-    } catch (...) {
     }
-    fn(0, (int)((long long)n / nt));
-    for (int t = started; t < nt; t++) fn((int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt));
-    for (std::thread& t : th) t.join();
+    (void)hipGetLastError();   // (hipErrorNotReady is sticky in the last-error slot)
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return PTAM_OK;
+}
+
+// launch shape of K7 for (threads, LDS bytes): asked of the runtime once per process and shape (each query is 10 - 40 us)
+static int ba_k7_occupancy(const void* k7, int threads, size_t smem, int* per_cu) {
+    struct Key {
+        const void* f;
+        int t;
+        size_t s;
+        bool operator<(const Key& o) const { return f != o.f ? f < o.f : (t != o.t ? t < o.t : s < o.s); }
+    };
+    static std::mutex mu;
+    static std::map<Key, std::pair<int, int>> known;
+    std::lock_guard<std::mutex> lock(mu);
+    const Key key{k7, threads, smem};
+    auto it = known.find(key);
+    if (it == known.end()) {
+        int rc = PTAM_OK, n = 0;
+        if (smem > 64 * 1024 && hipFuncSetAttribute(k7, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) rc = PTAM_E_HIP;
+        if (!rc && hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k7, threads, smem) != hipSuccess) rc = PTAM_E_HIP;
+        if (rc) (void)hipGetLastError();
+        it = known.emplace(key, std::make_pair(rc, n)).first;
+    }
+    *per_cu = it->second.second;
+    return it->second.first;
 }
 
 static int ba_prepare_impl(ptam_ba* ba) {
     ptam_ctx* ctx = ba->ctx;
-    // PTAM_DEBUG_PREPARE=1: host time of the phases of this function (sort | lists | Schur work lists | launch shape | alloc + clear | upload)
+    // PTAM_DEBUG_PREPARE=1: host time of the phases of this function
     static const bool dbg_prep = getenv("PTAM_DEBUG_PREPARE") != nullptr;
     auto pt0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
@@ -185,468 +268,55 @@ static int ba_prepare_impl(ptam_ba* ba) {
     std::memset(&d, 0, sizeof d);
     const int C = (int)ba->cam_fixed.size(), P_all = (int)(ba->pts.size() / 3);
     const int Mall = (int)ba->m_cam.size();
+    const int M = Mall - ba->n_dead;
     // free-camera indices in insertion order  (nStartRow, src/Bundle.cc:52-57)
     std::vector<int> cam_free(C, -1);
     int F = 0;
     for (int c = 0; c < C; c++)
         if (!ba->cam_fixed[c]) cam_free[c] = F++;
-    // live measurements sorted point-major (point, then free cameras by free index, then fixed cameras); ties keep insertion order
-    std::vector<int> dense_of;   // original point id -> device point id (-1: no live measurement)
-    // (a counting sort over the points, then each point's short run by camera: a comparison sort of the whole list was 1.8 ms
-    //  of a 10 ms prepare at 250 000 measurements)
-    std::vector<int> order;
-    {
-        std::vector<int> start(P_all + 1, 0);
-        int live = 0;
-        for (int i = 0; i < Mall; i++)
-            if (!ba->m_dead[i]) {
-                start[ba->m_pt[i] + 1]++;
-                live++;
-            }
-        for (int p = 0; p < P_all; p++) start[p + 1] += start[p];
-        order.resize((size_t)live);
-        std::vector<int> fill(start.begin(), start.end() - 1);
-        for (int i = 0; i < Mall; i++)
-            if (!ba->m_dead[i]) order[(size_t)fill[ba->m_pt[i]]++] = i;   // insertion order inside a point: stable
-        // inside a point: the free cameras first, by free index, then the fixed ones.  (The Schur work lists address a
-        // tile's cameras by their offset from the tile's first measurement of the point: with the fixed cameras out of
-        // the way an offset is at most 7 — in camera-id order, 255 or more fixed keyframes between two free ones of a
-        // tile overflowed the 8-bit offsets, and a local adjustment has many fixed keyframes.)
-        auto key = [&](int i) { const int c = ba->m_cam[i], f = cam_free[c]; return f >= 0 ? f : F + c; };
-        // (ranges of points of about equal measurement counts: start[] is their prefix sum)
-        ba_par_ranges(live, [&](int m_lo, int m_hi) {
-            const int p_lo = (int)(std::lower_bound(start.begin(), start.end() - 1, m_lo) - start.begin());
-            const int p_hi = m_hi >= live ? P_all : (int)(std::lower_bound(start.begin(), start.end() - 1, m_hi) - start.begin());
-            for (int p = p_lo; p < p_hi; p++) {
-                int* b0 = order.data() + start[p];
-                int* b1 = order.data() + start[p + 1];
-                bool sorted = true;
-                for (int* q = b0; q + 1 < b1; q++)
-                    if (key(q[0]) > key(q[1])) {
-                        sorted = false;
-                        break;
-                    }
-                if (!sorted) std::stable_sort(b0, b1, [&](int x, int y) { return key(x) < key(y); });
-            }
-        });
-        // The device sees only the points that HAVE a live measurement, numbered densely in their original order: the kernels
-        // walk the point-major list 64 measurements at a time and fetch "the chunk's points" as one run of consecutive ids,
-        // which a stretch of unobserved points (never measured, or every measurement purged earlier) would break.  An
-        // unobserved point takes no part in an adjustment and keeps its position (its V* is zero, src/Bundle.cc:341-359).
-        dense_of.assign((size_t)P_all, -1);
-        ba->pt_orig.clear();
-        for (int p = 0; p < P_all; p++)
-            if (start[p + 1] > start[p]) {
-                dense_of[(size_t)p] = (int)ba->pt_orig.size();
-                ba->pt_orig.push_back(p);
-            }
-    }
-    lap("sort");
-    const int P = (int)ba->pt_orig.size();
-    const int M = (int)order.size();
-    for (int i = 1; i < M; i++)
-        if (ba->m_pt[order[i]] == ba->m_pt[order[i - 1]] && ba->m_cam[order[i]] == ba->m_cam[order[i - 1]]) {
-            ptam_set_error("duplicate measurement of point %d by camera %d", ba->m_pt[order[i]], ba->m_cam[order[i]]);
-            return PTAM_E_ARG;
-        }
-    ba->sorted_orig = order;
-    std::vector<int> f_sorted((size_t)M);   // free-camera index of the sorted list's measurements (read by three loops below)
-    ba_par_ranges(M, [&](int i_lo, int i_hi) {
-        for (int i = i_lo; i < i_hi; i++) f_sorted[(size_t)i] = cam_free[ba->m_cam[order[i]]];
-    });
-    std::vector<int> rowptr(P + 1, 0);
-    for (int i = 0; i < M; i++) rowptr[dense_of[(size_t)ba->m_pt[order[i]]] + 1]++;
-    for (int p = 0; p < P; p++) rowptr[p + 1] += rowptr[p];
-    // chunks: consecutive whole points, at most BA_CHUNK measurements — or ONE point with more than that (a point seen by
-    // more than 256 keyframes: the kernels that own whole points walk such a chunk BA_CHUNK measurements at a time;
-    // src/Bundle.cc:75-93 puts no bound on the measurements of a point)
-    std::vector<BaChunk> chunks;
-    {
-        int p = 0;
-        while (p < P) {
-            BaChunk ch;
-            ch.pt_begin = p;
-            ch.m_begin = rowptr[p];
-            int cnt = 0, np = 0;
-            while (p < P && cnt + (rowptr[p + 1] - rowptr[p]) <= BA_CHUNK && np < BA_CHUNK) {
-                cnt += rowptr[p + 1] - rowptr[p];
-                p++;
-                np++;
-            }
-            if (np == 0) p++;   // a long point, alone in its chunk
-            ch.pt_end = p;
-            ch.m_end = rowptr[p];
-            chunks.push_back(ch);
-        }
-    }
-    // K7's wave variant walks the point-major list 64 measurements at a time whatever the points' lengths: a point cut by a
-    // chunk edge — or covering whole chunks, when more than 64 cameras measure it — leaves one piece per chunk, which K8a adds in
-    // chunk order.  (Rounds 1-2 also had a block variant whose workgroups owned whole points: 38.8 instead of ~10 us per launch
-    // at 100 dense cameras, removed in round 3.)
-    std::vector<BaChunk> wchunks;   // (one dummy entry; the kernel does not read it)
-    if (M > 0) wchunks.push_back(BaChunk{0, P, 0, M});
-    lap("rowptr + chunks");
-    // Schur work lists
     const int n_tiles = (F + SCHUR_TC - 1) / SCHUR_TC;
     const int n_pairs = n_tiles * (n_tiles + 1) / 2;
-    std::vector<std::vector<SchurEntry>> per_pair(n_pairs);
-    {
-        // (a point contributes at most one entry to a pair)
-        const size_t guess = n_pairs > 0 ? std::min<size_t>((size_t)P, 2 * (size_t)M / (size_t)n_pairs + 16) : 0;
-        for (auto& v : per_pair) v.reserve(guess);
-        std::vector<int> t_first(n_tiles), touched;
-        std::vector<std::array<unsigned, 2>> t_off(n_tiles);
-        for (int p = 0; p < P; p++) {
-            touched.clear();
-            // per tile the point touches: its first measurement by a camera of the tile and, per camera slot, the offset
-            // of that camera's measurement from it (camera ids ascending -> free indices ascending; fixed cameras may sit
-            // in between and have no slot)
-            int last_tile = -1;
-            for (int i = rowptr[p]; i < rowptr[p + 1]; i++) {
-                const int f = f_sorted[(size_t)i];
-                if (f < 0) continue;
-                const int t = f / SCHUR_TC;
-                if (t != last_tile) {
-                    touched.push_back(t);
-                    t_first[t] = i;
-                    t_off[t] = {0xffffffffu, 0xffffffffu};
-                    last_tile = t;
-                }
-                const int off = i - t_first[t], slot = f - t * SCHUR_TC;   // (off <= 7: the point's free cameras are consecutive)
-                t_off[t][slot >> 2] &= ~(0xffu << (8 * (slot & 3)));
-                t_off[t][slot >> 2] |= (unsigned)off << (8 * (slot & 3));
-            }
-            for (size_t ia = 0; ia < touched.size(); ia++)
-                for (size_t ib = 0; ib <= ia; ib++) {
-                    const int a = touched[ia], b = touched[ib];
-                    SchurEntry e;
-                    e.pt = p;
-                    e.ma = t_first[a];
-                    e.mb = t_first[b];
-                    e.pad = 0;
-                    e.offa[0] = t_off[a][0], e.offa[1] = t_off[a][1];
-                    e.offb[0] = t_off[b][0], e.offb[1] = t_off[b][1];
-                    per_pair[a * (a + 1) / 2 + b].push_back(e);
-                }
-        }
-    }
-    lap("schur entries");
-    // Workgroups of the tile kernel: XCD-aware, cost-balanced, a workgroup = a few SEGMENTS (pair, entry range).
-    // Block b runs on XCD b % 8 (observed placement, MI355X_MICROARCH.md), each XCD has its own 4 MB L2, and every W block
-    // is read once per tile pair its tile takes part in.  The points are cut into 8 ranges of equal cost; XCD x multiplies
-    // ALL tile pairs over range x, so that its L2 holds one eighth of W (4.5 MB at 50 x 5000) and the pairs sharing a tile
-    // find its lines there (round-robin slices of the pairs: 41 % L2 hits; this: 83 %).  Inside an XCD the work — the
-    // chunks of all pairs, one after another — is cut into 64 pieces of equal cost (2 resident workgroups per CU), so a
-    // piece may end one pair and begin the next: the workgroup then leaves one partial tile per segment.
-    // Partial tiles keep one slot per segment, contiguous per pair (fixed-order sum in schur_reduce_kernel).
-    std::vector<SchurEntry> s_entries;
-    std::vector<SchurWG> s_segs;
-    std::vector<int> s_wg_seg;
-    std::vector<int> pair_wg_begin(n_pairs + 1, 0);
-    {
-        int NX = 8;   // point ranges (1 or 8)
-        if (const char* e = ptam_ab_env("PTAM_SCHUR_NX")) NX = atoi(e) == 8 ? 8 : 1;   // A/B runs (tools/dev/schur_ab.sh)
-        bool sort_pattern = true;
-        if (const char* e = ptam_ab_env("PTAM_SCHUR_SORT")) sort_pattern = atoi(e) != 0;   // A/B runs
-        auto set01 = [](const unsigned o[2]) { return (o[0] != 0xffffffffu) || ((o[1] & 0xffffu) != 0xffffu); };   // slots 0..5
-        auto set2 = [](const unsigned o[2]) { return (o[1] >> 8) != 0xffffffu; };                                    // slots 5..7
-        auto pattern_of = [&](const SchurEntry& e) {
-            return (int)set01(e.offa) | ((int)set2(e.offa) << 1) | ((int)set01(e.offb) << 2) | ((int)set2(e.offb) << 3);
-        };
-        bool span = true;   // a workgroup may end one pair and begin the next
-        if (const char* e = ptam_ab_env("PTAM_SCHUR_SPAN")) span = atoi(e) != 0;
-        const int MIN_SEG = 16;
-        // 16x16 fragments per tile (row mappings of ba_schur.inc: 1-2 cameras in a tile = 1 fragment, 3-5 = 2, 6-8 = 3)
-        auto frags = [&](int t) { const int n = std::min(SCHUR_TC, F - t * SCHUR_TC); return n <= 2 ? 1 : (n <= 5 ? 2 : 3); };
-        // Cost model of the split, fitted to the tile kernel's per-workgroup entry / exit stamps at 50 x 5000 (tools/dev/schur_fit.py,
-        // docs/LOG_r05.md): a group of four entries takes  10 f + 36  units (f: the 16x16 fragment products of its pattern; the 36
-        // are its loads), a SEGMENT costs as much as ~10 full groups (pipeline fill: three dependent round trips; cross-wave
-        // reduction; partial tile out), and the SECOND workgroup of a CU — its waves are the younger ones, the issue arbiter
-        // prefers the older — ends 4.5 - 9 us behind the first for the same work (fits before / after the re-balancing), so it gets 7 us less.
-        // (Rounds 2-5 had f + 8 and no segment term: workgroups of load-bound pairs — a last tile of one camera — were taken for
-        //  lighter than they are, ran alone on their CU for 12-17 us after the partner had left, and set the launch's end.)
-        int cost_model = 36;
-        if (const char* e = ptam_ab_env("PTAM_SCHUR_COST")) cost_model = atoi(e);   // A/B runs
-        // fixed cost of a SEGMENT in the same units: a workgroup that ends one pair and begins the next pays it twice
-        int seg_cost = 4900;
-        if (const char* e = ptam_ab_env("PTAM_SCHUR_SEGCOST")) seg_cost = atoi(e);   // A/B runs
-        int second_lag = 7000;   // what a CU's second workgroup is given less than its first (A/B: 4500 / 7000 / 9000 / 12000 -> 47.9 / 46.7 / 46.8 / 48.7 us)
-        double min_room = seg_cost;   // a workgroup begins another segment only for at least this much work
-        if (const char* e = ptam_ab_env("PTAM_SCHUR_MINROOM")) min_room = atof(e);   // A/B runs
-        double fixed_target = -1;   // >= 0: no bisection, the budget is this multiple of the mean cost (A/B runs: 1.005 = rounds 2-5)
-        if (const char* e = ptam_ab_env("PTAM_SCHUR_FIXED_TARGET")) fixed_target = atof(e);
-        if (const char* e = ptam_ab_env("PTAM_SCHUR_LAG")) second_lag = atoi(e);   // A/B runs
-        // cost of one entry: the 16x16 fragments its pattern multiplies (+ cost_model for its loads)
-        std::vector<int> pair_a(n_pairs), pair_b(n_pairs);
-        for (int a = 0, pr = 0; a < n_tiles; a++)
-            for (int b = 0; b <= a; b++, pr++) pair_a[pr] = a, pair_b[pr] = b;
-        auto entry_cost = [&](int pr, const SchurEntry& e) {
-            if (!cost_model) return 1;
-            const int ma = frags(pair_a[pr]), mb = frags(pair_b[pr]);
-            const int a01 = set01(e.offa) ? std::min(ma, 2) : 0, a2 = (ma == 3 && set2(e.offa)) ? 1 : 0;
-            int f;
-            if (pair_a[pr] == pair_b[pr])
-                f = a01 * a01 + a2 * a01 + a2;
-            else {
-                const int b01 = set01(e.offb) ? std::min(mb, 2) : 0, b2 = (mb == 3 && set2(e.offb)) ? 1 : 0;
-                f = (a01 + a2) * (b01 + b2);
-            }
-            return 10 * f + cost_model;
-        };
-        // Order of the pairs in an XCD's list: the fewest fragment products first.  The list's first half becomes the FIRST
-        // workgroup of each CU, whose (older) waves the issue arbiter prefers: a load-bound pair there — a last tile of one or two
-        // cameras: 3 products a step against 21 loads — leaves the matrix pipe to the younger product-bound partner, while
-        // in the second slot it starved behind the partner's products and then ran on alone for 12 us (stamps: docs/LOG_r05.md).
-        std::vector<int> pair_order(n_pairs);
-        for (int pr = 0; pr < n_pairs; pr++) pair_order[pr] = pr;
-        {
-            // (only where both slots of the CUs are in use: a small bundle — 20 x 3 000: 35 workgroups per XCD, 8 of its kernel's 12 us
-            //  fixed cost — ran 1.6 us longer in this order than in the natural one)
-            size_t ent_all = 0;
-            for (int pr = 0; pr < n_pairs; pr++) ent_all += per_pair[pr].size();
-            bool by_products = ent_all / (size_t)NX / (4 * MIN_SEG) >= (size_t)(256 * SCHUR_WG_PER_CU / NX);
-            if (const char* e = ptam_ab_env("PTAM_SCHUR_ORDER")) by_products = atoi(e) != 0;   // A/B runs
-            auto full_f = [&](int pr) {
-                const int ma = frags(pair_a[pr]), mb = frags(pair_b[pr]);
-                return pair_a[pr] == pair_b[pr] ? (ma == 3 ? 7 : (ma == 2 ? 4 : 1)) : ma * mb;
-            };
-            if (by_products)
-                std::stable_sort(pair_order.begin(), pair_order.end(), [&](int p, int q) { return full_f(p) < full_f(q); });
-        }
-        // (an entry's cost is worked out once and kept in its padding word, which the device does not read)
-        for (int pr = 0; pr < n_pairs; pr++)
-            for (SchurEntry& e : per_pair[pr]) e.pad = entry_cost(pr, e) | (pattern_of(e) << 16);   // (cost: low half, fragment pattern: high half)
-        std::vector<SchurEntry> sort_tmp;
-        // One work list: the pairs [pr_lo, pr_hi) over the XCDs `xcds` (the points cut into as many ranges of equal cost; block
-        // stride * i + xcds[k] = the i-th workgroup of XCD xcds[k]).  Its entries are appended to s_entries, its segments come back
-        // in creation order (no slots yet), with the budget the cut ended on.
-        struct SchurList {
-            std::vector<SchurWG> segs;
-            std::vector<std::vector<std::vector<int>>> wgs_x;   // per XCD of the list: workgroups = lists of segment indices
-            std::vector<int> xcds;
-            int stride = 8;
-            double t_cut = 0;
-        };
-        auto build_list = [&](int pr_lo, int pr_hi, const std::vector<int>& xcds, int stride, int wg_per_cu) {
-            SchurList out;
-            out.xcds = xcds;
-            out.stride = stride;
-            const int NXL = (int)xcds.size();
-            const int SLOTS = 256 * wg_per_cu / 8 * (stride == 8 ? 1 : 8);   // workgroups of one XCD's list: its CUs' resident slots
-            out.wgs_x.resize(NXL);
-            // point ranges of equal cost
-            std::vector<double> pt_cost(P + 1, 0.0);
-            for (int pr = pr_lo; pr < pr_hi; pr++)
-                for (const SchurEntry& e : per_pair[pr]) pt_cost[e.pt + 1] += e.pad & 0xffff;
-            for (int p = 0; p < P; p++) pt_cost[p + 1] += pt_cost[p];
-            std::vector<int> bound(NXL + 1, 0);
-            for (int x = 1; x < NXL; x++)
-                bound[x] = (int)(std::lower_bound(pt_cost.begin(), pt_cost.end(), pt_cost[P] * x / NXL) - pt_cost.begin());
-            bound[NXL] = P;
-            for (int x = 0; x < NXL; x++) {
-                std::vector<int> lo(n_pairs, 0), hi(n_pairs, 0);
-                double cost_x = 0;
-                size_t ent_x = 0;
-                for (int pr = pr_lo; pr < pr_hi; pr++) {
-                    auto& v = per_pair[pr];
-                    auto cmp = [](const SchurEntry& e, int p) { return e.pt < p; };
-                    lo[pr] = (int)(std::lower_bound(v.begin(), v.end(), bound[x], cmp) - v.begin());
-                    hi[pr] = (int)(std::lower_bound(v.begin(), v.end(), bound[x + 1], cmp) - v.begin());
-                    for (int i = lo[pr]; i < hi[pr]; i++) cost_x += v[i].pad & 0xffff;
-                    ent_x += (size_t)(hi[pr] - lo[pr]);
-                }
-                if (ent_x == 0) continue;
-                const int n_wg_max = (int)std::max<size_t>(1, std::min<size_t>(SLOTS, ent_x / (4 * MIN_SEG)));
-                // the XCD's entries: pair after pair, a pair's entries sorted by fragment pattern, with their prefix costs
-                std::vector<int> base(n_pairs, 0);               // position of pair pr's entry i in s_entries: base[pr] + i
-                std::vector<std::vector<double>> pre(n_pairs);   // prefix costs of the pair's (sorted) entries lo..hi
-                for (int pr : pair_order) {
-                    if (pr < pr_lo || pr >= pr_hi) continue;
-                    base[pr] = (int)s_entries.size() - lo[pr];
-                    s_entries.insert(s_entries.end(), per_pair[pr].begin() + lo[pr], per_pair[pr].begin() + hi[pr]);
-                    if (sort_pattern && hi[pr] > lo[pr]) {   // entries of one fragment pattern next to each other: the kernel skips a
-                                                              // fragment set only when none of the FOUR points of a group has a camera in it
-                        // stable counting sort over the 16 patterns (kept in the entries' padding word); a chunk whose entries share
-                        // one pattern — every chunk of a dense problem — stays as it is
-                        SchurEntry* e0 = s_entries.data() + (s_entries.size() - (size_t)(hi[pr] - lo[pr]));
-                        const int nn = hi[pr] - lo[pr];
-                        int cnt16[17] = {0};
-                        for (int i = 0; i < nn; i++) cnt16[((e0[i].pad >> 16) & 15) + 1]++;
-                        bool uniform = false;
-                        for (int q = 1; q <= 16; q++) uniform = uniform || cnt16[q] == nn;
-                        if (!uniform) {
-                            for (int q = 0; q < 16; q++) cnt16[q + 1] += cnt16[q];
-                            sort_tmp.assign(e0, e0 + nn);
-                            for (int i = 0; i < nn; i++) e0[cnt16[(sort_tmp[(size_t)i].pad >> 16) & 15]++] = sort_tmp[(size_t)i];
-                        }
-                    }
-                    pre[pr].assign((size_t)(hi[pr] - lo[pr]) + 1, 0.0);
-                    for (int i = lo[pr]; i < hi[pr]; i++)
-                        pre[pr][(size_t)(i - lo[pr]) + 1] = pre[pr][(size_t)(i - lo[pr])] + (s_entries[(size_t)(base[pr] + i)].pad & 0xffff);
-                }
-                // The cut: the pairs' entries, one pair after another, into at most n_wg workgroups of whole 4-entry groups such that
-                // no workgroup's cost — entries + seg_cost per segment (+ second_lag for list positions >= SLOTS / 2: block 8 i + x >= 256,
-                // the second workgroup of its CU) — exceeds a budget T; T is the smallest for which the greedy fill needs no more than
-                // n_wg workgroups (bisection: the fill is exact about the segments a cut makes, which an a-priori budget — rounds 2-5:
-                // the mean cost — can only guess).
-                struct Cut { int pr, begin, end; };   // entries [begin, end) of pair pr, relative to lo[pr]
-                const int n_first = wg_per_cu == 2 ? SLOTS / 2 : SLOTS;
-                auto fill = [&](double T, std::vector<std::vector<Cut>>* outc) {
-                    int n_out = 0;
-                    std::vector<Cut> cur;
-                    double cur_cost = 0;
-                    auto close = [&]() {
-                        if (!cur.empty()) {
-                            if (outc) outc->push_back(cur);
-                            n_out++;
-                        }
-                        cur.clear();
-                        cur_cost = 0;
-                    };
-                    for (int pr : pair_order) {
-                        if (pr < pr_lo || pr >= pr_hi) continue;
-                        const std::vector<double>& pp = pre[pr];
-                        const int n = hi[pr] - lo[pr];
-                        int pos = 0;
-                        while (pos < n) {
-                            const int left = n - pos;
-                            // as many whole 4-entry groups as the workgroup's remaining budget pays for
-                            const double room = T - (n_out >= n_first ? second_lag : 0) - cur_cost - seg_cost, p0 = pp[(size_t)pos];
-                            int take = (int)(std::upper_bound(pp.begin() + pos, pp.end(), p0 + room) - (pp.begin() + pos)) - 1;
-                            take = take >= left ? left : std::max(0, take) / 4 * 4;
-                            // a sliver at the end of a full workgroup — less work than the segment itself would cost: start the next one
-                            if (!cur.empty() && left > take && (take < MIN_SEG || room < min_room)) {
-                                close();
-                                continue;
-                            }
-                            take = std::max(take, MIN_SEG);
-                            if (left - take < MIN_SEG) take = left;                // ... or at the end of the pair's chunk: take it along
-                            take = std::min(take, left);
-                            cur.push_back(Cut{pr, pos, pos + take});
-                            cur_cost += pp[(size_t)(pos + take)] - p0 + seg_cost;
-                            pos += take;
-                        }
-                        if (!span) close();
-                    }
-                    close();
-                    return n_out;
-                };
-                int chunks_x = 0;
-                for (int pr = pr_lo; pr < pr_hi; pr++) chunks_x += hi[pr] > lo[pr];
-                // ... for two workgroup counts when the XCD's work does not fill both slots of its CUs: one workgroup per CU, or as many as
-                // the entries allow (a few CUs with two workgroups and the rest with one take as long as two everywhere); T says which
-                auto smallest_budget = [&](int n_wg) {
-                    if (fixed_target >= 0) return (cost_x + (double)seg_cost * (n_wg + chunks_x - 1)) / n_wg * fixed_target;   // (rounds 2-5; A/B runs)
-                    // (the mean cost is a lower bound; the upper one by steps of a quarter — the answer is 1.2 - 1.5 times the mean —,
-                    //  then bisection to 0.2 %: ~10 fills instead of the ~22 of a bisection from "everything in one workgroup")
-                    double t_lo = cost_x / n_wg, t_hi = 1.25 * t_lo + seg_cost + second_lag;
-                    const double t_all = cost_x + (double)seg_cost * (chunks_x + n_wg) + second_lag + 1;   // (one workgroup takes it all)
-                    while (t_hi < t_all && fill(t_hi, nullptr) > n_wg) t_lo = t_hi, t_hi *= 1.25;
-                    t_hi = std::min(t_hi, t_all);
-                    for (int it = 0; it < 40 && t_hi - t_lo > 0.002 * t_hi; it++) {
-                        const double mid = 0.5 * (t_lo + t_hi);
-                        if (fill(mid, nullptr) <= n_wg)
-                            t_hi = mid;
-                        else
-                            t_lo = mid;
-                    }
-                    return t_hi;
-                };
-                double t_cut = smallest_budget(n_wg_max);
-                // (one workgroup per CU cannot end before the mean of ITS cut: only tried where that is below the budget found)
-                if (n_wg_max > n_first && fixed_target < 0 && cost_x / n_first + seg_cost < t_cut && !ptam_ab_env("PTAM_SCHUR_NO_HALF"))
-                    t_cut = std::min(t_cut, smallest_budget(n_first));
-                out.t_cut = std::max(out.t_cut, t_cut);
-                std::vector<std::vector<Cut>> cuts;
-                fill(t_cut, &cuts);
-                for (const std::vector<Cut>& wg : cuts) {
-                    std::vector<int> ids;
-                    for (const Cut& c : wg) {
-                        ids.push_back((int)out.segs.size());
-                        out.segs.push_back(SchurWG{c.pr, base[c.pr] + lo[c.pr] + c.begin, base[c.pr] + lo[c.pr] + c.end, -1});
-                    }
-                    out.wgs_x[x].push_back(ids);
-                }
-            }
-            return out;
-        };
-        // partial-tile slots, contiguous per pair in creation order (XCD range, then position), over the lists of one set; then the
-        // lists' segments in block order: a workgroup's segments consecutive (short lists are padded with empty workgroups)
-        auto finish_set = [&](std::vector<SchurList*> lists, std::vector<int>& pwb, std::vector<std::vector<SchurWG>*> segs_out,
-                              std::vector<std::vector<int>*> wg_seg_out) {
-            std::vector<std::vector<std::pair<int, int>>> of_pair(n_pairs);
-            for (size_t l = 0; l < lists.size(); l++)
-                for (size_t sg = 0; sg < lists[l]->segs.size(); sg++) of_pair[lists[l]->segs[sg].pair].push_back({(int)l, (int)sg});
-            int slot = 0;
-            pwb.assign(n_pairs + 1, 0);
-            for (int pr = 0; pr < n_pairs; pr++) {
-                pwb[pr] = slot;
-                for (auto& q : of_pair[pr]) lists[q.first]->segs[q.second].slot = slot++;
-            }
-            pwb[n_pairs] = slot;
-            for (size_t l = 0; l < lists.size(); l++) {
-                const SchurList& L = *lists[l];
-                size_t longest = 0;
-                for (auto& v : L.wgs_x) longest = std::max(longest, v.size());
-                std::vector<SchurWG>& ordered = *segs_out[l];
-                std::vector<int>& wseg = *wg_seg_out[l];
-                ordered.clear();
-                wseg.clear();
-                for (size_t i = 0; i < longest; i++)
-                    for (int xb = 0; xb < L.stride; xb++) {   // block L.stride * i + xb
-                        wseg.push_back((int)ordered.size());
-                        for (size_t k = 0; k < L.xcds.size(); k++)
-                            if (L.xcds[k] == xb && i < L.wgs_x[k].size())
-                                for (int sg : L.wgs_x[k][i]) ordered.push_back(L.segs[sg]);
-                    }
-                wseg.push_back((int)ordered.size());
-            }
-            return slot;
-        };
-        std::vector<int> all_x;
-        for (int x = 0; x < NX; x++) all_x.push_back(x);
-        SchurList full = build_list(0, n_pairs, all_x, NX, SCHUR_WG_PER_CU);
-        finish_set({&full}, pair_wg_begin, {&s_segs}, {&s_wg_seg});
-    }
-
-    if (getenv("PTAM_DEBUG_SCHUR")) {   // groups by fragment pattern: what the tile kernel multiplies and loads
-        std::vector<long long> grp(16 * 3, 0);
-        long long mf = 0, ld = 0, ld_need = 0;
-        for (const SchurWG& sg : s_segs) {
-            const int a = pair_a_of(sg.pair), b = sg.pair - a * (a + 1) / 2;
-            auto fr = [&](int t) { const int n = std::min(SCHUR_TC, F - t * SCHUR_TC); return n <= 2 ? 1 : (n <= 5 ? 2 : 3); };
-            const int ma = fr(a), mb = fr(b);
-            for (int e = sg.e_begin; e < sg.e_end; e += 4) {
-                int pm = 0;
-                for (int q = e; q < std::min(e + 4, sg.e_end); q++) pm |= (s_entries[(size_t)q].pad >> 16) & 15;
-                grp[(size_t)pm * 3 + (a == b ? 0 : 1)]++;
-                const int a01 = (pm & 1) ? std::min(ma, 2) : 0, a2 = (ma == 3 && (pm & 2)) ? 1 : 0;
-                const int b01 = (pm & 4) ? std::min(mb, 2) : 0, b2 = (mb == 3 && (pm & 8)) ? 1 : 0;
-                mf += 3 * (a == b ? a01 * a01 + a2 * a01 + a2 : (a01 + a2) * (b01 + b2));
-                ld += 2 + 5 + (ma == 3 ? 6 : 3) + (a == b ? 3 : (mb == 3 ? 6 : 3));
-                ld_need += 2 + 5 + (a01 ? 3 : 0) + (a2 ? 3 : 0) + (a == b ? 3 : (b01 ? 3 : 0) + (b2 ? 3 : 0));
-            }
-        }
-        std::fprintf(stderr, "[ptam] schur: %zu segments, %d workgroups; MFMAs %lld, loads issued %lld (needed by the patterns %lld); groups by pattern (diag / off):",
-                     s_segs.size(), (int)s_wg_seg.size() - 1, mf, ld, ld_need);
-        for (int pm = 0; pm < 16; pm++)
-            if (grp[(size_t)pm * 3] + grp[(size_t)pm * 3 + 1]) std::fprintf(stderr, " %d:%lld/%lld", pm, grp[(size_t)pm * 3], grp[(size_t)pm * 3 + 1]);
-        std::fprintf(stderr, "\n");
-    }
-    lap("schur split");
+    const bool lists = F > 0 && M > 0;   // Schur work lists exist
     d.C = C;
     d.F = F;
-    d.P = P;
     d.M = M;
     d.n = 6 * F;
     d.npad = ((d.n + SOLVE_NB - 1) / SOLVE_NB) * SOLVE_NB;
-    d.n_chunks = (int)chunks.size();
-    d.n_wchunks = (int)wchunks.size();
-    ba->use_wave = !wchunks.empty();   // (false: no live measurement at all — K7 is then a memset of its outputs)
+    d.n_wchunks = M > 0 ? 1 : 0;
+    ba->use_wave = M > 0;   // (false: no live measurement at all — K7 is then a memset of its outputs)
     d.n_tiles = n_tiles;
     d.n_pairs = n_pairs;
-    d.n_schur_wg = (int)s_wg_seg.size() - 1;
-    d.n_schur_entries = (int)s_entries.size();
+    // The tile kernel's work split (ba_split.h): cost model fitted to the kernel's per-workgroup stamps at 50 x 5000
+    // (tools/dev/schur_fit.py, docs/LOG_r05.md) — a group of four entries takes 10 f + 36 units (f: the 16x16 fragment products of
+    // its pattern; the 36 are its loads), a SEGMENT costs as much as ~10 full groups (pipeline fill: three dependent round trips;
+    // cross-wave reduction; partial tile out), and the SECOND workgroup of a CU — its waves are the younger ones, the issue arbiter
+    // prefers the older — ends 4.5 - 9 us behind the first for the same work, so it gets 7 us less.
+    SplitCfg cfg;
+    cfg.cost_model = 36;
+    cfg.seg_cost = 4900;
+    cfg.second_lag = 7000;
+    cfg.min_seg = 16;
+    cfg.slots = 256 * SCHUR_WG_PER_CU / 8;   // workgroups one XCD holds at once (block b runs on XCD b % 8)
+    cfg.n_first = SCHUR_WG_PER_CU == 2 ? cfg.slots / 2 : cfg.slots;
+    if (const char* e = ptam_ab_env("PTAM_SCHUR_COST")) cfg.cost_model = atoi(e);   // A/B runs
+    if (const char* e = ptam_ab_env("PTAM_SCHUR_SEGCOST")) cfg.seg_cost = atoi(e);
+    if (const char* e = ptam_ab_env("PTAM_SCHUR_LAG")) cfg.second_lag = atoi(e);
+    cfg.min_room = cfg.seg_cost;   // a workgroup begins another segment only for at least this much work
+    if (const char* e = ptam_ab_env("PTAM_SCHUR_MINROOM")) cfg.min_room = atoi(e);
+    // Order of the pairs in an XCD's list, both candidates (the device picks: by products only where both slots of the CUs are
+    // in use).  By products = the fewest fragment products first: the list's first half becomes the FIRST workgroup of each CU,
+    // whose (older) waves the issue arbiter prefers — a load-bound pair there (a last tile of one or two cameras: 3 products a step
+    // against 21 loads) leaves the matrix pipe to the younger product-bound partner, while in the second slot it starved behind the
+    // partner's products and then ran on alone for 12 us (stamps: docs/LOG_r05.md).
+    std::vector<int> pair_order((size_t)2 * std::max(n_pairs, 1), 0);
+    {
+        std::vector<int> pa(n_pairs), pb(n_pairs);
+        for (int a = 0, pr = 0; a < n_tiles; a++)
+            for (int b = 0; b <= a; b++, pr++) pa[pr] = a, pb[pr] = b;
+        for (int pr = 0; pr < n_pairs; pr++) pair_order[pr] = pair_order[(size_t)n_pairs + pr] = pr;
+        std::stable_sort(pair_order.begin() + n_pairs, pair_order.begin() + 2 * (size_t)n_pairs,
+                         [&](int p, int q) { return split_full_products(F, pa[p], pb[p]) < split_full_products(F, pa[q], pb[q]); });
+    }
     // persistent grid of the accumulate kernel: bounded by LDS residency, 2 x 256 CUs by default
     // (wave variant: + one 3 KB W transposition buffer per wave, K7_WT_DOUBLES)
     ba->k7_big = false;
@@ -671,22 +341,9 @@ static int ba_prepare_impl(ptam_ba* ba) {
     //  and its waves share a SIMD for nothing: 512 threads, 13.5 instead of 14.6 us per launch there; not in deterministic mode,
     //  which has no such instantiation)
     if (!ba->k7_loop && ba->opts.deterministic == 0 && n64_all < 16 * 128) ba->k7_threads = 512;
-    int n_cu = 256;
-    {
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
-        n_cu = prop.multiProcessorCount;
-    }
+    const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
     auto k7_fn = [&](int threads) -> const void* { return k7_wave_fn(threads, ba->k7_loop, ba->opts.estimator, ba->k7_big, ba->det); };
-
-    auto k7_occupancy = [&](int threads, int* per_cu) -> int {
-        const void* k7 = k7_fn(threads);
-        if (k7_smem(threads) > 64 * 1024) {
-            const hipError_t e = hipFuncSetAttribute(k7, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k7_smem(threads));
-            if (e != hipSuccess) return PTAM_E_HIP;
-        }
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k7, threads, k7_smem(threads)) == hipSuccess ? PTAM_OK : PTAM_E_HIP;
-    };
+    auto k7_occupancy = [&](int threads, int* per_cu) -> int { return ba_k7_occupancy(k7_fn(threads), threads, k7_smem(threads), per_cu); };
     int per_cu = 0;
     {
         // the workgroup's LDS — camera partials F * 216 B + poses C * 96 B + 3 KB per wave — must fit the CU's 160 KB: many
@@ -783,29 +440,28 @@ static int ba_prepare_impl(ptam_ba* ba) {
             hipFuncSetAttribute((const void*)schur_tile_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SCHUR_RED_BYTES);
         HIP_TRY(schur_attr);
     }
-
     lap("launch shape");
-    // ---- carve one device allocation ------------------------------------------------------------
+
+    // ---- carve the main device allocation (sizes the host knows: M exactly, the points by their upper bound) --------------------
     Carver cv;
-    const size_t Mz = std::max(M, 1), Pz = std::max(P, 1), Cz = std::max(C, 1), Fz = std::max(F, 1);
-    const size_t o_pose0 = cv.take(Cz * 96), o_pose1 = cv.take(Cz * 96), o_camfree = cv.take(Cz * 4);
+    const size_t Mz = std::max(M, 1), Pz = std::max(P_all, 1), Cz = std::max(C, 1), Fz = std::max(F, 1), Maz = std::max(Mall, 1);
+    // chunks: consecutive whole points, at most BA_CHUNK measurements — two neighbours together exceed BA_CHUNK measurements or
+    // BA_CHUNK points, or one of them is a long point
+    const size_t chunks_cap = std::min<size_t>(Pz, (size_t)M / 64 + (size_t)P_all / 128 + 8);
+    const size_t o_pose0 = cv.take(Cz * 96), o_pose1 = cv.take(Cz * 96);
     const size_t o_pt0 = cv.take(Pz * 24), o_pt1 = cv.take(Pz * 24), o_V = cv.take(Pz * 48), o_epsB = cv.take(Pz * 24),
                  o_Vinv = cv.take(Pz * 72), o_rowptr = cv.take((Pz + 1) * 4),
                  o_cut = cv.take(ba->use_wave ? (size_t)((M + 63) / 64) * 2 * 72 : 8);
     const size_t o_mcam = cv.take(Mz * 4), o_mpt = cv.take(Mz * 4), o_mfound = cv.take(Mz * 16), o_ms = cv.take(Mz * 8),
                  o_morig = cv.take(Mz * 4), o_mfidx = cv.take(Mz * 4), o_mstate = cv.take(Mz), o_me2 = cv.take(Mz * 8), o_me2t = cv.take(Mz * 8), o_zbad = cv.take(Mz), o_W = cv.take((Mz + 1) * 144);
     const size_t o_U = cv.take(Fz * 27 * 8 * 16), o_Upart = cv.take((size_t)std::max(d.grid_acc, ba->det ? n_dtiles : 1) * Fz * 27 * 8);
-    const size_t o_adet = cv.take(ba->det ? Mz * 14 * 8 : 8), o_camptr = cv.take(ba->det ? (size_t)n_dtiles * (Fz + 1) * 4 : 8), o_cammeas = cv.take(ba->det ? Mz * 4 : 8);
-    const size_t n_part = std::max(d.n_chunks, d.grid_acc);
+    const size_t o_adet = cv.take(ba->det ? Mz * 14 * 8 : 8), o_camptr = cv.take(ba->det ? (size_t)n_dtiles * (Fz + 1) * 4 : 8), o_cammeas = cv.take(ba->det ? Mz * 4 : 8),
+                 o_tilefree = cv.take(ba->det ? ((size_t)n_dtiles + 1) * 4 : 8);
+    const size_t n_part = std::max<size_t>(chunks_cap, (size_t)d.grid_acc);
     const size_t o_errp = cv.take(n_part * 16 + 16), o_badp = cv.take((size_t)d.grid_acc * 4 + 16);
-    const size_t o_chunks = cv.take(std::max<size_t>(1, chunks.size()) * sizeof(BaChunk));
-    const size_t o_wchunks = cv.take(std::max<size_t>(1, wchunks.size()) * sizeof(BaChunk));
+    const size_t o_chunks = cv.take(chunks_cap * sizeof(BaChunk));
+    const size_t o_wchunks = cv.take(sizeof(BaChunk));
     const size_t o_hist = cv.take(2 * HIST_BINS * 4), o_cand = cv.take(Mz * 8);
-    const size_t o_sent = cv.take(std::max<size_t>(1, s_entries.size()) * sizeof(SchurEntry)),
-                 o_swg = cv.take(std::max<size_t>(1, s_segs.size()) * sizeof(SchurWG)), o_swgseg = cv.take(s_wg_seg.size() * 4),
-                 o_spw = cv.take((size_t)(n_pairs + 1) * 4), o_swghead = cv.take(std::max<size_t>(1, s_wg_seg.size()) * 32),
-                 o_spart = cv.take(std::max<size_t>(1, s_segs.size()) * SCHUR_TILE_ELEMS * 8),
-                 o_smap = cv.take((size_t)SCHUR_N_VARIANTS * 64 * SCHUR_NW * SCHUR_MAP_WPT * 4);
     const size_t npad = std::max(d.npad, SOLVE_NB);
     // S and L block-banded (bundle.h: se_blk); sized for the full lower triangle, because a sharded bundle only learns the
     // bandwidth in force (the widest over all ranks) in Compute()'s first exchange
@@ -815,17 +471,34 @@ static int ba_prepare_impl(ptam_ba* ba) {
                  o_bws = cv.take(npad * 8 * 12), o_sflags = cv.take(ba_solve_flag_bytes((int)(npad / SOLVE_NB))),
                  o_sflags2 = cv.take(ba_solve_flag_bytes((int)(npad / SOLVE_NB))), o_SE2 = cv.take((se_full + npad + 8) * 8),
                  o_L2 = cv.take(se_full * 8), o_Dg2 = cv.take(npad * 8), o_y2 = cv.take(npad * 8);
-    const size_t o_out = cv.take(Mz * 4), o_sc = cv.take(sizeof(BaScalars)), o_dbg = cv.take(65536);
+    const size_t o_out = cv.take(Mz * 4), o_sc = cv.take(sizeof(BaScalars)), o_dbg = cv.take(65536), o_xchg = cv.take(4096);
+    // the builder's cleared tables: live measurements per point, tile codes, (XCD, pair, pattern) counts
+    const int nw = std::max(1, (n_tiles + 31) / 32);
+    const size_t hist_n = (size_t)8 * std::max(n_pairs, 1) * 16;
+    const size_t o_cnt = cv.take(Pz * 4), o_tcode = cv.take(Pz * (size_t)nw * 8), o_phist = cv.take(hist_n * 4);
+    const size_t clear_bytes = cv.off;   // ---- everything up to here is cleared; what follows is written before it is read ----
+    // small tables the host fills, one upload: [initial PrepScalars | poses | free-camera indices | both pair orders]
+    Carver sm;
+    const size_t s_ps = sm.take(sizeof(PrepScalars)), s_pose = sm.take(Cz * 96), s_camfree = sm.take(Cz * 4),
+                 s_porder = sm.take(pair_order.size() * 4);
+    const size_t o_small = cv.take(sm.off);
+    // raw input (insertion order) and the builder's temporaries
+    const size_t o_rcam = cv.take(Maz * 4), o_rpt = cv.take(Maz * 4), o_rfound = cv.take(Maz * 16), o_rsig = cv.take(Maz * 8),
+                 o_rdead = cv.take(Maz), o_ptsraw = cv.take(Pz * 24);
+    const size_t o_start = cv.take((Pz + 1) * 4), o_denseof = cv.take(Pz * 4), o_ptorig = cv.take(Pz * 4), o_arr = cv.take(Maz * 4),
+                 o_tmpi = cv.take(Mz * 4), o_tmpkey = cv.take(Mz * 4), o_ptile = cv.take(Mz * 16), o_kp = cv.take(Pz * 4),
+                 o_costp = cv.take(Pz * 4), o_entpre = cv.take((Pz + 1) * 8), o_costpre = cv.take((Pz + 1) * 8), o_ebase = cv.take(hist_n * 4);
     ba->block_bytes = cv.off;
-    if (!ctx_cache_take(ctx->dev_cache, ba->block_bytes, &ba->block, &ba->block_cap)) {   // (a released bundle's block, if it fits)
+    if (!ctx_cache_take(ctx->dev_cache, CTX_NCACHE(ctx->dev_cache), ba->block_bytes, &ba->block, &ba->block_cap)) {   // (a released bundle's block, if it fits)
         HIP_TRY(hipMalloc(&ba->block, ba->block_bytes));
         ba->block_cap = ba->block_bytes;
     }
-    HIP_TRY(hipMemsetAsync(ba->block, 0, ba->block_bytes, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ba->block, 0, clear_bytes, ctx->stream));
     char* base = (char*)ba->block;
-    d.pose[0] = (double*)(base + o_pose0);
+    d.pose[0] = (double*)(base + o_small + s_pose);   // (uploaded with the small tables)
     d.pose[1] = (double*)(base + o_pose1);
-    d.cam_free = (int*)(base + o_camfree);
+    (void)o_pose0;
+    d.cam_free = (int*)(base + o_small + s_camfree);
     d.pt[0] = (double*)(base + o_pt0);
     d.pt[1] = (double*)(base + o_pt1);
     d.V = (double*)(base + o_V);
@@ -843,7 +516,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.m_e2 = (double*)(base + o_me2);
     d.m_e2t = (double*)(base + o_me2t);
     d.m_zbad_t = (uint8_t*)(base + o_zbad);
-    d.W = (double*)(base + o_W);   // (slot M of every plane stays zero: the block is cleared below and nobody writes it)
+    d.W = (double*)(base + o_W);   // (slot M of every plane stays zero: the block is cleared and nobody writes it)
     d.Usplit = (double*)(base + o_U);
     d.Upart = (double*)(base + o_Upart);
     d.Adet = ba->det ? (double*)(base + o_adet) : nullptr;
@@ -855,13 +528,6 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.wchunks = (BaChunk*)(base + o_wchunks);
     d.hist = (unsigned*)(base + o_hist);
     d.cand = (double*)(base + o_cand);
-    d.s_entries = (SchurEntry*)(base + o_sent);
-    d.s_segs = (SchurWG*)(base + o_swg);
-    d.s_wg_seg = (int*)(base + o_swgseg);
-    d.s_pair_wg_begin = (int*)(base + o_spw);
-    d.s_wg_head = (int*)(base + o_swghead);
-    d.s_part = (double*)(base + o_spart);
-    d.s_map = (unsigned*)(base + o_smap);
     d.SE = (double*)(base + o_SE);
     d.L = (double*)(base + o_L);
     d.Dg = (double*)(base + o_Dg);
@@ -891,119 +557,250 @@ static int ba_prepare_impl(ptam_ba* ba) {
     d.outliers = (int*)(base + o_out);
     d.sc = (BaScalars*)(base + o_sc);
     d.dbg = (long long*)(base + o_dbg);
-
+    ba->d_xchg = (double*)(base + o_xchg);
+    if (!ctx->d_smap) {   // the tile kernel's index maps: a constant of the build, one device copy per context
+        static const std::vector<unsigned> s_map = schur_index_map_device();
+        HIP_TRY(hipMalloc((void**)&ctx->d_smap, s_map.size() * 4));
+        HIP_TRY(hipMemcpy(ctx->d_smap, s_map.data(), s_map.size() * 4, hipMemcpyHostToDevice));
+    }
+    d.s_map = ctx->d_smap;
     lap("alloc + clear");
-    // ---- upload -------------------------------------------------------------------------------------
-    // the per-measurement arrays are put together in the context's PINNED staging buffer: a copy out of pageable vectors is
-    // staged by the runtime piece by piece (2.5 ms of a 10 ms prepare at 250 000 measurements)
-    void* pin_m = nullptr;
+
+    // ---- pinned staging: [stamp | scalars read back | rowptr | dense point ids | small tables | chunks] -------------------------
+    Carver hs;
+    const size_t h_stamp = hs.take(64), h_psrb = hs.take(sizeof(PrepScalars)), h_rowptr = hs.take((Pz + 1) * 4), h_ptorig = hs.take(Pz * 4),
+                 h_small = hs.take(sm.off), h_chunks = hs.take(chunks_cap * sizeof(BaChunk));
+    (void)h_stamp;
+    void* pin = nullptr;
     {
-        const int rc_p = ctx_pinned(ctx, Mz * 40 + 256, &pin_m);
+        // (also what Compute()'s read-back will need: growing the staging later would re-map host memory under queued kernels)
+        const size_t later = 64 + (size_t)C * 96 + (size_t)P_all * 24 + (size_t)M * 4 + 64;
+        const int rc_p = ctx_pinned(ctx, std::max(hs.off, later), &pin);
         if (rc_p) return rc_p;
     }
-    int* h_cam = (int*)pin_m;
-    int* h_pt = h_cam + Mz;
-    int* h_orig = h_pt + Mz;
-    int* h_fidx = h_orig + Mz;
-    double* h_found = (double*)(h_fidx + Mz);   // (16 Mz bytes in: 8-byte aligned)
-    double* h_s = h_found + 2 * Mz;
-    ba_par_ranges(M, [&](int i_lo, int i_hi) {
-        for (int i = i_lo; i < i_hi; i++) {
-            const int o = order[i];
-            h_cam[i] = ba->m_cam[o];
-            h_pt[i] = dense_of[(size_t)ba->m_pt[o]];
-            h_orig[i] = o;
-            h_fidx[i] = f_sorted[(size_t)i];
-            h_found[2 * i] = ba->m_found[2 * o];
-            h_found[2 * i + 1] = ba->m_found[2 * o + 1];
-            h_s[i] = ba->m_s[o];
-        }
-    });
-    // block bandwidth of the camera system: S_jk != 0 only if cameras j, k share a point.  Keyframes that see the same
-    // points are neighbours in time (src/MapMaker.cc adds them in order), so for a long trajectory S is banded and the
-    // blocked LDL^T never leaves the band (no pivoting -> no fill outside it).  A sharded bundle only knows its own
-    // points: it keeps the full width (the other ranks' points may couple other cameras).
+    char* hp = (char*)pin;
+    char* dp = (char*)ctx->d_pinned;
+    volatile unsigned long long* stamp = (volatile unsigned long long*)hp;
+    PrepScalars* ps_host = (PrepScalars*)(hp + h_psrb);
     {
-        int band = 0;
-        for (int p = 0; p < P; p++) {
-            int lo = INT_MAX, hi = -1;
-            for (int i = rowptr[p]; i < rowptr[p + 1]; i++)
-                if (h_fidx[i] >= 0) {
-                    lo = std::min(lo, h_fidx[i]);
-                    hi = std::max(hi, h_fidx[i]);
-                }
-            if (hi >= 0) band = std::max(band, (6 * hi + 5) / SOLVE_NB - (6 * lo) / SOLVE_NB);
-        }
-        d.band = ba->band_local = band;
+        PrepScalars init;
+        std::memset(&init, 0, sizeof init);
+        init.dup_key = ~0ull;
+        std::memcpy(hp + h_small + s_ps, &init, sizeof init);
+        std::memcpy(hp + h_small + s_pose, ba->cam_pose.data(), (size_t)C * 96);
+        std::memcpy(hp + h_small + s_camfree, cam_free.data(), (size_t)C * 4);
+        std::memcpy(hp + h_small + s_porder, pair_order.data(), pair_order.size() * 4);
     }
 #define UP(dst, src, bytes)                                                                        \
     if ((bytes) > 0) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream))
-    std::vector<int> cam_ptr, cam_meas;   // (outlive the asynchronous uploads below: the function waits for the queue at its end)
+    UP(base + o_small, hp + h_small, sm.off);
+    UP(base + o_rpt, ba->m_pt.data(), (size_t)Mall * 4);   // (the count kernel's input first)
+    UP(base + o_rcam, ba->m_cam.data(), (size_t)Mall * 4);
+    UP(base + o_rfound, ba->m_found.data(), (size_t)Mall * 16);
+    UP(base + o_rsig, ba->m_sig.data(), (size_t)Mall * 8);
+    if (ba->n_dead > 0) UP(base + o_rdead, ba->m_dead.data(), (size_t)Mall);
+    UP(base + o_ptsraw, ba->pts.data(), (size_t)P_all * 24);
+    PrepDev q;
+    std::memset(&q, 0, sizeof q);
+    q.C = C, q.F = F, q.P_all = P_all, q.Mall = Mall, q.M = M;
+    q.n_tiles = n_tiles, q.n_pairs = n_pairs, q.nw = nw;
+    q.r_cam = (const int*)(base + o_rcam);
+    q.r_pt = (const int*)(base + o_rpt);
+    q.r_found = (const double2*)(base + o_rfound);
+    q.r_sig = (const double*)(base + o_rsig);
+    q.r_dead = ba->n_dead > 0 ? (const uint8_t*)(base + o_rdead) : nullptr;
+    q.pts_raw = (const double*)(base + o_ptsraw);
+    q.cnt = (int*)(base + o_cnt);
+    q.start = (int*)(base + o_start);
+    q.dense_of = (int*)(base + o_denseof);
+    q.pt_orig = (int*)(base + o_ptorig);
+    q.arr = (int*)(base + o_arr);
+    q.tmp_i = (int*)(base + o_tmpi);
+    q.tmp_key = (int*)(base + o_tmpkey);
+    q.ptile = (int4*)(base + o_ptile);
+    q.tcode = (unsigned long long*)(base + o_tcode);
+    q.kp = (int*)(base + o_kp);
+    q.costp = (int*)(base + o_costp);
+    q.ent_pre = (long long*)(base + o_entpre);
+    q.cost_pre = (long long*)(base + o_costpre);
+    q.hist = (int*)(base + o_phist);
+    q.ebase = (int*)(base + o_ebase);
+    q.pair_order = (const int*)(base + o_small + s_porder);
+    q.ps = (PrepScalars*)(base + o_small + s_ps);
+    q.h_ps = (PrepScalars*)(dp + h_psrb);
+    q.h_rowptr = (int*)(dp + h_rowptr);
+    q.h_pt_orig = (int*)(dp + h_ptorig);
+    // ---- phase 1: point-major sort, rowptr, per-point tiles, XCD ranges, pattern counts ------------------------------------------
+    if (Mall > 0) hipLaunchKernelGGL(prep_count_kernel, dim3((Mall + 255) / 256), dim3(256), 0, ctx->stream, q);
+    hipLaunchKernelGGL(prep_scan_points_kernel, dim3(1), dim3(1024), 0, ctx->stream, q, d);
+    if (M > 0) {
+        hipLaunchKernelGGL(prep_scatter_kernel, dim3((Mall + 255) / 256), dim3(256), 0, ctx->stream, q, (const int*)d.cam_free);
+        hipLaunchKernelGGL(prep_rank_kernel, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, q, d);
+    }
+    if (lists) {
+        hipLaunchKernelGGL(prep_tiles_kernel, dim3((P_all + 63) / 64), dim3(64), 0, ctx->stream, q, d, cfg.cost_model);
+        hipLaunchKernelGGL(prep_scan_cost_kernel, dim3(1), dim3(1024), 0, ctx->stream, q, cfg.min_seg, cfg.slots);
+        hipLaunchKernelGGL(prep_hist_kernel, dim3(n_pairs, 8), dim3(256), 0, ctx->stream, q);
+    }
+    unsigned long long seq = ++ctx->pose_seq;
+    *stamp = 0;
+    hipLaunchKernelGGL(prep_publish_kernel, dim3(1), dim3(64), 0, ctx->stream, q, (volatile unsigned long long*)dp, seq);
+    HIP_TRY(hipGetLastError());
+    lap("phase 1 enqueued");
+    if (int rc = ba_wait_stamp(ctx, stamp, seq)) return rc;
+    lap("phase 1 wait");
+    PrepScalars ps = *ps_host;
+    if (ps.dup > 0) {
+        ptam_set_error("duplicate measurement of point %d by camera %d", (int)(ps.dup_key >> 32), (int)(ps.dup_key & 0xffffffffu));
+        return PTAM_E_ARG;
+    }
+    if (ps.M != M || ps.P > P_all || ps.n_entries >= (1ll << 31)) {
+        ptam_set_error("bundle prepare: inconsistent counts (live measurements %d / %d, points %d / %d, Schur entries %lld)", ps.M, M, ps.P,
+                       P_all, ps.n_entries);
+        return PTAM_E_STATE;
+    }
+    const int P = ps.P;
+    d.P = P;
+    d.band = ba->band_local = ps.band;
+    const int* rowptr = (const int*)(hp + h_rowptr);
+    ba->pt_orig.assign((const int*)(hp + h_ptorig), (const int*)(hp + h_ptorig) + P);
+    // chunks: consecutive whole points, at most BA_CHUNK measurements — or ONE point with more than that (a point seen by
+    // more than 256 keyframes: the kernels that own whole points walk such a chunk BA_CHUNK measurements at a time;
+    // src/Bundle.cc:75-93 puts no bound on the measurements of a point).  (The one walk over the points the host keeps: a chunk
+    // begins where the previous one ends.)
+    BaChunk* chunks = (BaChunk*)(hp + h_chunks);
+    size_t n_chunks = 0;
+    {
+        int p = 0;
+        while (p < P) {
+            BaChunk ch;
+            ch.pt_begin = p;
+            ch.m_begin = rowptr[p];
+            int cnt = 0, np = 0;
+            while (p < P && cnt + (rowptr[p + 1] - rowptr[p]) <= BA_CHUNK && np < BA_CHUNK) {
+                cnt += rowptr[p + 1] - rowptr[p];
+                p++;
+                np++;
+            }
+            if (np == 0) p++;   // a long point, alone in its chunk
+            ch.pt_end = p;
+            ch.m_end = rowptr[p];
+            if (n_chunks >= chunks_cap) {
+                ptam_set_error("bundle prepare: more chunks than their bound (%zu)", chunks_cap);
+                return PTAM_E_STATE;
+            }
+            chunks[n_chunks++] = ch;
+        }
+    }
+    d.n_chunks = (int)n_chunks;
+    // K7's wave variant walks the point-major list 64 measurements at a time whatever the points' lengths: a point cut by a
+    // chunk edge — or covering whole chunks, when more than 64 cameras measure it — leaves one piece per chunk, which K8a adds in
+    // chunk order.  (Rounds 1-2 also had a block variant whose workgroups owned whole points: removed in round 3.)
+    UP(d.chunks, chunks, n_chunks * sizeof(BaChunk));
+    lap("chunks");
+    // ---- phase 2: the Schur work lists ----------------------------------------------------------------------------------------
+    d.n_schur_entries = (int)ps.n_entries;
+    d.n_schur_wg = 0;
+    if (lists && ps.n_entries > 0) {
+        const int cap_pl = std::max(1, std::min(n_pairs, ps.n_xp));
+        const int cap_cut = cfg.slots + cap_pl;
+        const size_t cap_segs = (size_t)8 * cfg.slots + (size_t)ps.n_xp;
+        const int nb_max = 8 * cfg.slots;
+        Carver sv;
+        const size_t o_sent = sv.take((size_t)ps.n_entries * sizeof(SchurEntry)), o_swg = sv.take(cap_segs * sizeof(SchurWG)),
+                     o_swgseg = sv.take(((size_t)nb_max + 1) * 4), o_spw = sv.take((size_t)(n_pairs + 1) * 4),
+                     o_swghead = sv.take((size_t)nb_max * 32), o_spart = sv.take(cap_segs * SCHUR_TILE_ELEMS * 8),
+                     o_cpx = sv.take(((size_t)n_pairs * 8 + 1) * 4);
+        const size_t sclear = sv.off;
+        const size_t o_runcnt = sv.take((size_t)8 * 16 * cap_pl * 4), o_runcost = sv.take((size_t)8 * 16 * cap_pl * 4),
+                     o_plpair = sv.take((size_t)8 * cap_pl * 4), o_pln = sv.take((size_t)8 * cap_pl * 4),
+                     o_plrun0 = sv.take((size_t)8 * (cap_pl + 1) * 4), o_ple0 = sv.take((size_t)8 * cap_pl * 4),
+                     o_cutpair = sv.take((size_t)8 * cap_cut * 4), o_cute0 = sv.take((size_t)8 * cap_cut * 4),
+                     o_cute1 = sv.take((size_t)8 * cap_cut * 4), o_cutwg = sv.take((size_t)8 * cap_cut * 4),
+                     o_wgfirst = sv.take((size_t)8 * (cfg.slots + 1) * 4), o_pairfirst = sv.take((size_t)n_pairs * 8 * 4),
+                     o_wsegtmp = sv.take(((size_t)nb_max + 1) * 4);
+        ba->sblock_bytes = sv.off;
+        if (!ctx_cache_take(ctx->dev_cache, CTX_NCACHE(ctx->dev_cache), ba->sblock_bytes, &ba->sblock, &ba->sblock_cap)) {
+            HIP_TRY(hipMalloc(&ba->sblock, ba->sblock_bytes));
+            ba->sblock_cap = ba->sblock_bytes;
+        }
+        HIP_TRY(hipMemsetAsync(ba->sblock, 0, sclear, ctx->stream));
+        char* sb = (char*)ba->sblock;
+        d.s_entries = (SchurEntry*)(sb + o_sent);
+        d.s_segs = (SchurWG*)(sb + o_swg);
+        d.s_wg_seg = (int*)(sb + o_swgseg);
+        d.s_pair_wg_begin = (int*)(sb + o_spw);
+        d.s_wg_head = (int*)(sb + o_swghead);
+        d.s_part = (double*)(sb + o_spart);
+        q.cap_pl = cap_pl, q.cap_cut = cap_cut;
+        q.cpx = (int*)(sb + o_cpx);
+        q.run_cnt = (int*)(sb + o_runcnt);
+        q.run_cost = (int*)(sb + o_runcost);
+        q.pl_pair = (int*)(sb + o_plpair);
+        q.pl_n = (int*)(sb + o_pln);
+        q.pl_run0 = (int*)(sb + o_plrun0);
+        q.pl_e0 = (int*)(sb + o_ple0);
+        q.cut_pair = (int*)(sb + o_cutpair);
+        q.cut_e0 = (int*)(sb + o_cute0);
+        q.cut_e1 = (int*)(sb + o_cute1);
+        q.cut_wg = (int*)(sb + o_cutwg);
+        q.wg_first = (int*)(sb + o_wgfirst);
+        q.pair_first = (int*)(sb + o_pairfirst);
+        q.wseg_tmp = (int*)(sb + o_wsegtmp);
+        hipLaunchKernelGGL(prep_split_kernel, dim3(8), dim3(512), 0, ctx->stream, q, cfg);
+        hipLaunchKernelGGL(prep_entries_kernel, dim3(n_pairs, 8), dim3(256), 0, ctx->stream, q, d, cfg.cost_model);
+        hipLaunchKernelGGL(prep_finish_kernel, dim3(1), dim3(1024), 0, ctx->stream, q, d, cfg.slots);
+    } else if (F > 0) {
+        // free cameras but no entry: the reduction still reads the pairs' (empty) slot ranges
+        Carver sv;
+        const size_t o_spw = sv.take((size_t)(n_pairs + 1) * 4), o_spart = sv.take(SCHUR_TILE_ELEMS * 8), o_one = sv.take(256);
+        ba->sblock_bytes = sv.off;
+        if (!ctx_cache_take(ctx->dev_cache, CTX_NCACHE(ctx->dev_cache), ba->sblock_bytes, &ba->sblock, &ba->sblock_cap)) {
+            HIP_TRY(hipMalloc(&ba->sblock, ba->sblock_bytes));
+            ba->sblock_cap = ba->sblock_bytes;
+        }
+        HIP_TRY(hipMemsetAsync(ba->sblock, 0, ba->sblock_bytes, ctx->stream));
+        char* sb = (char*)ba->sblock;
+        d.s_pair_wg_begin = (int*)(sb + o_spw);
+        d.s_part = (double*)(sb + o_spart);
+        d.s_entries = (SchurEntry*)(sb + o_one);
+        d.s_segs = (SchurWG*)(sb + o_one);
+        d.s_wg_seg = (int*)(sb + o_one);
+        d.s_wg_head = (int*)(sb + o_one);
+    }
     if (ba->det) {
-        // per tile of DET_TILE consecutive measurements: the measurements by free cameras, camera-major (counting sort:
-        // ascending measurement id inside a camera); cam_ptr rows index cam_meas globally
-        cam_ptr.assign((size_t)n_dtiles * (F + 1), 0);
-        cam_meas.reserve((size_t)M);
-        std::vector<int> cnt((size_t)F + 1);
-        for (int t = 0; t < n_dtiles; t++) {
-            const int m0 = t * DET_TILE, m1 = std::min(M, m0 + DET_TILE);
-            std::fill(cnt.begin(), cnt.end(), 0);
-            for (int i = m0; i < m1; i++)
-                if (h_fidx[i] >= 0) cnt[(size_t)h_fidx[i] + 1]++;
-            int* row = cam_ptr.data() + (size_t)t * (F + 1);
-            row[0] = (int)cam_meas.size();
-            for (int f = 0; f < F; f++) row[f + 1] = row[f] + cnt[(size_t)f + 1];
-            cam_meas.resize((size_t)row[F]);
-            std::vector<int> fill(row, row + F);
-            for (int i = m0; i < m1; i++)
-                if (h_fidx[i] >= 0) cam_meas[(size_t)fill[(size_t)h_fidx[i]]++] = i;
-        }
-        if (cam_meas.empty()) cam_meas.push_back(0);
-        UP(d.cam_ptr, cam_ptr.data(), cam_ptr.size() * 4);
-        UP(d.cam_meas, cam_meas.data(), cam_meas.size() * 4);
+        int* tile_free = (int*)(base + o_tilefree);
+        hipLaunchKernelGGL(prep_det_count_kernel, dim3(n_dtiles), dim3(256), 0, ctx->stream, d, tile_free);
+        hipLaunchKernelGGL(prep_det_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, tile_free, n_dtiles);
+        hipLaunchKernelGGL(prep_det_lists_kernel, dim3(n_dtiles), dim3(256), 0, ctx->stream, d, (const int*)tile_free);
     }
-    UP(d.pose[0], ba->cam_pose.data(), (size_t)C * 96);
-    UP(d.cam_free, cam_free.data(), (size_t)C * 4);
-    std::vector<double> h_pts((size_t)std::max(P, 1) * 3);
-    for (int q = 0; q < P; q++)
-        for (int k = 0; k < 3; k++) h_pts[(size_t)3 * q + k] = ba->pts[(size_t)3 * ba->pt_orig[(size_t)q] + k];
-    UP(d.pt[0], h_pts.data(), (size_t)P * 24);
-    UP(d.rowptr, rowptr.data(), (size_t)(P + 1) * 4);
-    UP(d.m_cam, h_cam, (size_t)M * 4);
-    UP(d.m_pt, h_pt, (size_t)M * 4);
-    UP(d.m_found, h_found, (size_t)M * 16);
-    UP(d.m_s, h_s, (size_t)M * 8);
-    UP(d.m_orig, h_orig, (size_t)M * 4);
-    UP(d.m_fidx, h_fidx, (size_t)M * 4);
-    UP(d.chunks, chunks.data(), chunks.size() * sizeof(BaChunk));
-    UP(d.wchunks, wchunks.data(), wchunks.size() * sizeof(BaChunk));
-    UP(d.s_entries, s_entries.data(), s_entries.size() * sizeof(SchurEntry));
-    UP(d.s_segs, s_segs.data(), s_segs.size() * sizeof(SchurWG));
-    UP(d.s_wg_seg, s_wg_seg.data(), s_wg_seg.size() * 4);
-    UP(d.s_pair_wg_begin, pair_wg_begin.data(), pair_wg_begin.size() * 4);
-    std::vector<int> s_wg_head((size_t)std::max(1, d.n_schur_wg) * 8, 0);   // (outlives the asynchronous upload: the function waits for the queue at its end)
-    for (int b = 0; b < d.n_schur_wg; b++) {
-        int* h = s_wg_head.data() + (size_t)8 * b;
-        h[0] = s_wg_seg[(size_t)b], h[1] = s_wg_seg[(size_t)b + 1];
-        if (h[1] > h[0]) {
-            const SchurWG& sg = s_segs[(size_t)h[0]];
-            h[2] = sg.pair, h[3] = sg.e_begin, h[4] = sg.e_end, h[5] = sg.slot;
-        }
-    }
-    UP(d.s_wg_head, s_wg_head.data(), s_wg_head.size() * 4);
-    const std::vector<unsigned> s_map = schur_index_map_device();
-    UP(d.s_map, s_map.data(), s_map.size() * 4);
 #undef UP
-    lap("stage + enqueue");
-    HIP_TRY(ptam_stream_wait(ctx->stream));   // host staging vectors die here
-    lap("upload wait");
+    seq = ++ctx->pose_seq;
+    *stamp = 0;
+    hipLaunchKernelGGL(prep_publish_kernel, dim3(1), dim3(64), 0, ctx->stream, q, (volatile unsigned long long*)dp, seq);
+    HIP_TRY(hipGetLastError());
+    lap("phase 2 enqueued");
+    if (int rc = ba_wait_stamp(ctx, stamp, seq)) return rc;
+    lap("phase 2 wait");
+    ps = *ps_host;
+    if (ps.bad) {
+        ptam_set_error("bundle prepare: a Schur work list outgrew its bound (%d)", ps.bad);
+        return PTAM_E_STATE;
+    }
+    d.n_schur_wg = ps.n_schur_wg;
+    ba->n_schur_segs = ps.n_segs;
+    if (getenv("PTAM_DEBUG_SCHUR")) {
+        std::fprintf(stderr, "[ptam] schur: %d segments, %d workgroups; %lld entries in %d (XCD, pair) lists, budgets", ps.n_segs, ps.n_schur_wg,
+                     ps.n_entries, ps.n_xp);
+        for (int x = 0; x < 8; x++) std::fprintf(stderr, " %lld", ps.t_cut[x]);
+        std::fprintf(stderr, "; workgroups per XCD");
+        for (int x = 0; x < 8; x++) std::fprintf(stderr, " %d", ps.n_wgs[x]);
+        std::fprintf(stderr, "\n");
+    }
     {
         const int rc_s = ba_solve_init();
         if (rc_s) return rc_s;
     }
-    HIP_TRY(hipMalloc((void**)&ba->d_xchg, 4096));
-    lap("solve init + xchg");
-
     ba->cur = 0;
     ba->prepared = true;
     return PTAM_OK;
@@ -1201,7 +998,7 @@ static int ba_ensure_mailbox(ptam_ba* ba) {
     if (ba->mbox) return PTAM_OK;
     void* h = nullptr;
     size_t cap = 0;
-    if (!ctx_cache_take(ba->ctx->host_cache, sizeof(ptam_ba::Mailbox), &h, &cap))
+    if (!ctx_cache_take(ba->ctx->host_cache, CTX_NCACHE(ba->ctx->host_cache), sizeof(ptam_ba::Mailbox), &h, &cap))
         HIP_TRY(hipHostMalloc(&h, sizeof(ptam_ba::Mailbox), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(h, 0, sizeof(ptam_ba::Mailbox));
     void* dv = nullptr;
@@ -1381,6 +1178,7 @@ static void ba_finish_outliers(ptam_ba* ba) {
         for (int i = begin; i < end; i++) {
             const int o = ba->raw_out[i];
             ba->outliers.push_back(std::make_pair(ba->m_pt[o], ba->m_cam[o]));
+            if (!ba->m_dead[o]) ba->n_dead++;
             ba->m_dead[o] = 1;
         }
         begin = end;
@@ -1406,6 +1204,7 @@ int ptam_ba_create(ptam_ctx* ctx, const ptam_ba_opts* opts, ptam_ba** out) {
     ARG_TRY(ctx && out);
     ptam_ba* ba = new ptam_ba();
     ba->ctx = ctx;
+    ba->pts.ctx = ba->m_cam.ctx = ba->m_pt.ctx = ba->m_found.ctx = ba->m_sig.ctx = ba->m_dead.ctx = ctx;
     if (opts)
         ba->opts = *opts;
     else
@@ -1424,7 +1223,7 @@ int ptam_ba_destroy(ptam_ba* ba) {
     ptam_stream_wait(ba->ctx->stream);
     ba_free_device(ba);
     if (ba->mbox) {
-        void* drop = ctx_cache_give(ba->ctx->host_cache, ba->mbox, sizeof(ptam_ba::Mailbox));
+        void* drop = ctx_cache_give(ba->ctx->host_cache, CTX_NCACHE(ba->ctx->host_cache), ba->mbox, sizeof(ptam_ba::Mailbox));
         if (drop) hipHostFree(drop);
     }
     if (ba->ev_ok)
@@ -1432,6 +1231,12 @@ int ptam_ba_destroy(ptam_ba* ba) {
             hipEventDestroy(ba->ev[k][0]);
             hipEventDestroy(ba->ev[k][1]);
         }
+    ba->pts.release();
+    ba->m_cam.release();
+    ba->m_pt.release();
+    ba->m_found.release();
+    ba->m_sig.release();
+    ba->m_dead.release();
     delete ba;
     return PTAM_OK;
 }
@@ -1450,7 +1255,7 @@ int ptam_ba_add_point(ptam_ba* ba, const double pos[3]) {
     const int n = (int)(ba->pts.size() / 3);
     double v[3] = {pos[0], pos[1], pos[2]};
     if (std::isnan(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])) v[0] = v[1] = v[2] = 0;   // src/Bundle.cc:70-74
-    ba->pts.insert(ba->pts.end(), v, v + 3);
+    if (int rc = ba->pts.append(v, 3)) return rc;
     ba->prepared = false;
     return n;
 }
@@ -1459,11 +1264,17 @@ int ptam_ba_add_meas(ptam_ba* ba, int cam, int point, const double found[2], dou
     ARG_TRY(ba && found);
     ARG_TRY(cam >= 0 && cam < (int)ba->cam_fixed.size());
     ARG_TRY(point >= 0 && point < (int)(ba->pts.size() / 3));
+    // (room for all five first: a failed allocation must not leave the arrays at different lengths)
+    if (int rc = ba->m_cam.grow(1)) return rc;
+    if (int rc = ba->m_pt.grow(1)) return rc;
+    if (int rc = ba->m_found.grow(2)) return rc;
+    if (int rc = ba->m_sig.grow(1)) return rc;
+    if (int rc = ba->m_dead.grow(1)) return rc;
     ba->m_cam.push_back(cam);
     ba->m_pt.push_back(point);
     ba->m_found.push_back(found[0]);
     ba->m_found.push_back(found[1]);
-    ba->m_s.push_back(std::sqrt(1.0 / sigma_sq));   // dSqrtInvNoise src/Bundle.cc:91
+    ba->m_sig.push_back(sigma_sq);   // (dSqrtInvNoise = sqrt(1 / sigma^2), src/Bundle.cc:91, is formed when the measurements are sorted: prep_rank_kernel)
     ba->m_dead.push_back(0);
     ba->prepared = false;
     return PTAM_OK;
@@ -1482,10 +1293,24 @@ int ptam_ba_add_points(ptam_ba* ba, int n, const double* pos3) {
 int ptam_ba_add_measurements(ptam_ba* ba, int n, const int32_t* cam, const int32_t* point, const double* found2,
                              const double* sigma_sq) {
     ARG_TRY(ba && n >= 0 && (n == 0 || (cam && point && found2 && sigma_sq)));
+    const int n_cams = (int)ba->cam_fixed.size(), n_pts = (int)(ba->pts.size() / 3);
     for (int i = 0; i < n; i++) {
-        const int rc = ptam_ba_add_meas(ba, cam[i], point[i], found2 + 2 * i, sigma_sq[i]);
-        if (rc < 0) return rc;
+        ARG_TRY(cam[i] >= 0 && cam[i] < n_cams);
+        ARG_TRY(point[i] >= 0 && point[i] < n_pts);
     }
+    if (n == 0) return PTAM_OK;
+    if (int rc = ba->m_cam.grow((size_t)n)) return rc;
+    if (int rc = ba->m_pt.grow((size_t)n)) return rc;
+    if (int rc = ba->m_found.grow((size_t)2 * n)) return rc;
+    if (int rc = ba->m_sig.grow((size_t)n)) return rc;
+    if (int rc = ba->m_dead.grow((size_t)n)) return rc;
+    ba->m_cam.append(cam, (size_t)n);
+    ba->m_pt.append(point, (size_t)n);
+    ba->m_found.append(found2, (size_t)2 * n);
+    ba->m_sig.append(sigma_sq, (size_t)n);
+    std::memset(ba->m_dead.data() + ba->m_dead.size(), 0, (size_t)n);
+    ba->m_dead.n += (size_t)n;
+    ba->prepared = false;
     return PTAM_OK;
 }
 
@@ -1633,7 +1458,10 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
         mine[3] = abort_local() ? 1.0 : 0.0;
         mine[4] = d.chain_off ? 1.0 : 0.0;
         if (!rc_prepare && band_fits && nblk_x > 0) mine[XF + std::min(ba->band_local, nblk_x - 1)] = 1.0;
-        if (!ba->d_xchg) HIP_TRY(hipMalloc((void**)&ba->d_xchg, 4096));   // (a failed prepare has not allocated it)
+        if (!ba->d_xchg) {   // (a failed prepare has not carved it)
+            HIP_TRY(hipMalloc((void**)&ba->d_xchg, 4096));
+            ba->xchg_owned = true;
+        }
         HIP_TRY(hipMemcpyAsync(ba->d_xchg, mine.data(), mine.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         rc = ba_allreduce(ba, ba->d_xchg, mine.size());
         if (rc) return rc_prepare ? rc_prepare : rc;
@@ -1998,8 +1826,7 @@ int ptam_ba_counts(const ptam_ba* ba, int* n_cams, int* n_free, int* n_points, i
     int f = 0;
     for (uint8_t x : ba->cam_fixed) f += x ? 0 : 1;
     ba_finish_outliers(const_cast<ptam_ba*>(ba));
-    int live = 0;
-    for (uint8_t x : ba->m_dead) live += x ? 0 : 1;
+    const int live = (int)ba->m_dead.size() - ba->n_dead;
     if (n_cams) *n_cams = (int)ba->cam_fixed.size();
     if (n_free) *n_free = f;
     if (n_points) *n_points = (int)(ba->pts.size() / 3);

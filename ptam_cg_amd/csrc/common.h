@@ -63,11 +63,15 @@ struct ptam_ctx {
         void* p;
         size_t bytes;
     };
-    Cached dev_cache[2];    // device blocks
+    Cached dev_cache[4];    // device blocks (a bundle holds two: its main block and its Schur work lists)
     Cached host_cache[2];   // host-mapped mailboxes
+    Cached pin_cache[12];   // pinned host arrays of released bundles (the measurements as they are added: PinVec, bundle.hip)
+    unsigned* d_smap;       // the Schur tile kernel's index maps (schur_index_map_device: a compile-time constant, uploaded once)
+    int n_cu;               // compute units of the device
 };
-int ctx_cache_take(ptam_ctx::Cached* c, size_t bytes, void** out, size_t* cap);   // smallest cached block >= bytes, or null
-void* ctx_cache_give(ptam_ctx::Cached* c, void* p, size_t bytes);                 // returns the pointer the caller must free (or null)
+#define CTX_NCACHE(a) ((int)(sizeof(a) / sizeof((a)[0])))
+int ctx_cache_take(ptam_ctx::Cached* c, int slots, size_t bytes, void** out, size_t* cap);   // smallest cached block >= bytes, or null
+void* ctx_cache_give(ptam_ctx::Cached* c, int slots, void* p, size_t bytes);                 // returns the pointer the caller must free (or null)
 
 // hipStreamSynchronize sleeps on an interrupt, and waking from it was measured at up to 7 ms on this platform; the waits
 // of this library end within microseconds to a few milliseconds, so every one of them polls first (2 ms) and only then sleeps.

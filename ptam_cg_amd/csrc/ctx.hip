@@ -43,9 +43,9 @@ hipError_t ptam_stream_wait(hipStream_t stream) {
     return hipStreamSynchronize(stream);
 }
 
-int ctx_cache_take(ptam_ctx::Cached* c, size_t bytes, void** out, size_t* cap) {
+int ctx_cache_take(ptam_ctx::Cached* c, int slots, size_t bytes, void** out, size_t* cap) {
     int best = -1;
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < slots; i++)
         if (c[i].p && c[i].bytes >= bytes && (best < 0 || c[i].bytes < c[best].bytes)) best = i;
     *out = nullptr;
     *cap = 0;
@@ -57,15 +57,17 @@ int ctx_cache_take(ptam_ctx::Cached* c, size_t bytes, void** out, size_t* cap) {
     }
     return best >= 0;
 }
-void* ctx_cache_give(ptam_ctx::Cached* c, void* p, size_t bytes) {
+void* ctx_cache_give(ptam_ctx::Cached* c, int slots, void* p, size_t bytes) {
     if (!p) return nullptr;
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < slots; i++)
         if (!c[i].p) {
             c[i].p = p;
             c[i].bytes = bytes;
             return nullptr;
         }
-    const int small = c[0].bytes <= c[1].bytes ? 0 : 1;   // both slots taken: keep the two largest
+    int small = 0;   // every slot taken: keep the largest
+    for (int i = 1; i < slots; i++)
+        if (c[i].bytes < c[small].bytes) small = i;
     if (bytes <= c[small].bytes) return p;
     void* drop = c[small].p;
     c[small].p = p;
@@ -216,6 +218,10 @@ int ptam_ctx_create(const ptam_cam_params* cam, int device, ptam_ctx** out) {
     c->params = *cam;
     c->cam = make_devcam(*cam);
     c->halfsample = PTAM_HALFSAMPLE_R;
+    {
+        hipDeviceProp_t prop;
+        c->n_cu = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         ptam_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -241,10 +247,13 @@ int ptam_ctx_destroy(ptam_ctx* ctx) {
     ptam_stream_wait(ctx->stream);
     if (ctx->d_scratch) hipFree(ctx->d_scratch);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < CTX_NCACHE(ctx->dev_cache); i++)
         if (ctx->dev_cache[i].p) hipFree(ctx->dev_cache[i].p);
+    for (int i = 0; i < CTX_NCACHE(ctx->host_cache); i++)
         if (ctx->host_cache[i].p) hipHostFree(ctx->host_cache[i].p);
-    }
+    for (int i = 0; i < CTX_NCACHE(ctx->pin_cache); i++)
+        if (ctx->pin_cache[i].p) hipHostFree(ctx->pin_cache[i].p);
+    if (ctx->d_smap) hipFree(ctx->d_smap);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return PTAM_OK;
