@@ -66,6 +66,31 @@ int ptam_ba_bench_jacobian_rotating(ptam_ba** bas, int n, int reps, double* avg_
  * the accumulator layout of the cross-wave reduction, 0xffff for an element nothing is multiplied into.  Returns the number of
  * elements (2352) or a negative error. */
 int ptam_ba_schur_index_map(int variant, uint16_t* out, int cap);
+/* Test hook: one of the index structures ptam_ba_prepare built on the device (csrc/ba_prepare.inc), copied to `out` (at most
+ * cap_bytes).  Returns the structure's size in bytes (also with out == NULL: a size query) or a negative error; the bundle must be
+ * prepared.  tests/test_gpu_prepare.py rebuilds every one of them with numpy (and the work split with csrc/ba_split.h compiled
+ * for the host) and compares. */
+enum {
+    PTAM_BL_COUNTS = 0,      /* int32[16]: C, F, P, M, band, n_chunks, n_tiles, n_pairs, n_schur_wg, n_schur_entries, n_segments, grid_acc */
+    PTAM_BL_ROWPTR = 1,      /* int32[P + 1] */
+    PTAM_BL_M_CAM = 2,       /* int32[M] camera of the sorted measurements */
+    PTAM_BL_M_PT = 3,        /* int32[M] dense point id */
+    PTAM_BL_M_ORIG = 4,      /* int32[M] insertion index */
+    PTAM_BL_M_FIDX = 5,      /* int32[M] free-camera index or -1 */
+    PTAM_BL_M_FOUND = 6,     /* double[M][2] */
+    PTAM_BL_M_S = 7,         /* double[M] dSqrtInvNoise */
+    PTAM_BL_PT_ORIG = 8,     /* int32[P] dense point id -> original id */
+    PTAM_BL_POINTS = 9,      /* double[P][3] current positions of the dense points */
+    PTAM_BL_CHUNKS = 10,     /* int32[n_chunks][4] pt_begin, pt_end, m_begin, m_end */
+    PTAM_BL_S_ENTRIES = 11,  /* int32[n_schur_entries][8] pt, ma, mb, cost | pattern << 16, offa[2], offb[2] */
+    PTAM_BL_S_SEGS = 12,     /* int32[n_segments][4] pair, e_begin, e_end, slot */
+    PTAM_BL_S_WG_SEG = 13,   /* int32[n_schur_wg + 1] */
+    PTAM_BL_S_PAIR_BEGIN = 14, /* int32[n_pairs + 1] */
+    PTAM_BL_S_WG_HEAD = 15,  /* int32[n_schur_wg][8] */
+    PTAM_BL_CAM_PTR = 16,    /* deterministic mode: int32[tiles of 1024 measurements][F + 1] */
+    PTAM_BL_CAM_MEAS = 17    /* deterministic mode: int32[measurements by free cameras] */
+};
+int ptam_ba_debug_lists(ptam_ba* ba, int which, void* out, size_t cap_bytes);
 
 #ifdef __cplusplus
 }

@@ -203,6 +203,7 @@ PROTOTYPES = {
     "tracker_read_iteration_set": (_i, [_vp, _vp, _i, C.POINTER(_i)]),
     "ba_bench_jacobian_rotating": (_i, [_vp, _i, _i, _pd]),
     "ba_schur_index_map": (_i, [_i, _vp, _i]),
+    "ba_debug_lists": (_i, [_vp, _i, _vp, C.c_size_t]),
     "ba_set_comm": (_i, [_vp, _i, _i, ALLREDUCE_FN, _vp]),
     "rccl_unique_id": (_i, [_vp]),
     "rccl_create": (_i, [_vp, _vp, _i, _i, _ppv]),

@@ -1907,6 +1907,61 @@ int ptam_ba_schur_index_map(int variant, uint16_t* out, int cap) {   // (test ho
     return SCHUR_TILE_ELEMS;
 }
 
+int ptam_ba_debug_lists(ptam_ba* ba, int which, void* out, size_t cap_bytes) {   // (test hook: include/ptam_hip_bench.h)
+    ARG_TRY(ba);
+    if (!ba->prepared) {
+        ptam_set_error("ptam_ba_debug_lists: the bundle is not prepared");
+        return PTAM_E_STATE;
+    }
+    ptam_ctx* ctx = ba->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const BaDev& d = ba->d;
+    int counts[16] = {d.C, d.F, d.P, d.M, d.band, d.n_chunks, d.n_tiles, d.n_pairs, d.n_schur_wg, d.n_schur_entries, ba->n_schur_segs, d.grid_acc, 0, 0, 0, 0};
+    const void* src = nullptr;
+    size_t bytes = 0;
+    bool host_src = false;
+    int n_free_meas = 0;
+    switch (which) {
+        case PTAM_BL_COUNTS: src = counts, bytes = sizeof counts, host_src = true; break;
+        case PTAM_BL_ROWPTR: src = d.rowptr, bytes = ((size_t)d.P + 1) * 4; break;
+        case PTAM_BL_M_CAM: src = d.m_cam, bytes = (size_t)d.M * 4; break;
+        case PTAM_BL_M_PT: src = d.m_pt, bytes = (size_t)d.M * 4; break;
+        case PTAM_BL_M_ORIG: src = d.m_orig, bytes = (size_t)d.M * 4; break;
+        case PTAM_BL_M_FIDX: src = d.m_fidx, bytes = (size_t)d.M * 4; break;
+        case PTAM_BL_M_FOUND: src = d.m_found, bytes = (size_t)d.M * 16; break;
+        case PTAM_BL_M_S: src = d.m_s, bytes = (size_t)d.M * 8; break;
+        case PTAM_BL_PT_ORIG: src = ba->pt_orig.data(), bytes = (size_t)d.P * 4, host_src = true; break;
+        case PTAM_BL_POINTS: src = d.pt[ba->cur], bytes = (size_t)d.P * 24; break;
+        case PTAM_BL_CHUNKS: src = d.chunks, bytes = (size_t)d.n_chunks * sizeof(BaChunk); break;
+        case PTAM_BL_S_ENTRIES: src = d.s_entries, bytes = (size_t)d.n_schur_entries * sizeof(SchurEntry); break;
+        case PTAM_BL_S_SEGS: src = d.s_segs, bytes = (size_t)ba->n_schur_segs * sizeof(SchurWG); break;
+        case PTAM_BL_S_WG_SEG: src = d.s_wg_seg, bytes = d.n_schur_wg > 0 ? ((size_t)d.n_schur_wg + 1) * 4 : 0; break;
+        case PTAM_BL_S_PAIR_BEGIN: src = d.s_pair_wg_begin, bytes = d.F > 0 ? ((size_t)d.n_pairs + 1) * 4 : 0; break;
+        case PTAM_BL_S_WG_HEAD: src = d.s_wg_head, bytes = (size_t)d.n_schur_wg * 32; break;
+        case PTAM_BL_CAM_PTR: src = d.cam_ptr, bytes = ba->det ? (size_t)((d.M + DET_TILE - 1) / DET_TILE) * ((size_t)d.F + 1) * 4 : 0; break;
+        case PTAM_BL_CAM_MEAS:
+            if (ba->det && d.M > 0) {   // its length is the last tile's last row end
+                const size_t last = (size_t)((d.M + DET_TILE - 1) / DET_TILE) * ((size_t)d.F + 1) - 1;
+                HIP_TRY(hipMemcpyAsync(&n_free_meas, d.cam_ptr + last, 4, hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(ptam_stream_wait(ctx->stream));
+            }
+            src = d.cam_meas, bytes = (size_t)n_free_meas * 4;
+            break;
+        default: ARG_TRY(!"which"); 
+    }
+    if (out && bytes > 0) {
+        ARG_TRY(cap_bytes >= bytes);
+        if (host_src)
+            std::memcpy(out, src, bytes);
+        else {
+            HIP_TRY(hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ptam_stream_wait(ctx->stream));
+        }
+    }
+    if (bytes > (size_t)INT_MAX) return PTAM_E_LIMIT;
+    return (int)bytes;
+}
+
 int ptam_ba_bench_jacobian_rotating(ptam_ba** bas, int n, int reps, double* avg_ms) {
     ARG_TRY(bas && n > 0 && reps > 0 && avg_ms);
     ptam_ctx* ctx = bas[0]->ctx;

@@ -689,6 +689,13 @@ class Bundle:
     def prepare(self):
         self.ctx._check(self.lib.ba_prepare(self.h), "ba_prepare")
 
+    def debug_lists(self, which, dtype):
+        """one of the index structures ptam_ba_prepare built on the device (include/ptam_hip_bench.h: PTAM_BL_*), flat"""
+        n = self.ctx._check(self.lib.ba_debug_lists(self.h, which, None, 0), "ba_debug_lists")
+        out = np.zeros(max(n, 1), dtype=np.uint8)
+        self.ctx._check(self.lib.ba_debug_lists(self.h, which, _ptr(out), n), "ba_debug_lists")
+        return out[:n].view(dtype)
+
     def bench_jacobian(self, reps):
         ms, by = C.c_double(), C.c_double()
         self.ctx._check(self.lib.ba_bench_jacobian(self.h, reps, C.byref(ms), C.byref(by)), "ba_bench_jacobian")
