@@ -603,7 +603,7 @@ def main():
             "err_first_last": [float(trials["err_old"][0]), float(trials["err_new"][-1])],
             "deterministic": bool(args.deterministic),
             "source_sha16": source_sha16(),   # fingerprint of the library sources this run was built from (profiles/ are keyed by it)
-            "prepare_ms": prepare_headline_ms,   # sort + work lists + upload of one Bundle of this workload: outside the timed region
+            "prepare_ms": prepare_headline_ms,   # upload + device-built index structures of one Bundle of this workload: outside the timed region
         }
     if world > 1:
         # per-kernel breakdown of the sharded run (HIP events, separate Compute; every rank takes part in its collectives)
@@ -695,6 +695,32 @@ def main():
                             "note": "one Compute() of the same workload entered 50 ms after the device went idle, without the K7 spin-up and "
                                     "the warm-up trials that precede `value`"}
         cb.close()
+        # ---- one adjustment as the mapmaker thread runs it (src/MapMaker.cc:838-900): a NEW Bundle, Add*, Compute(), Get*, destroyed.
+        # The reference's Compute() builds its index structures inside itself (src/Bundle.cc:116-123, :558-599); here that is
+        # ptam_ba_prepare (device-built lists, csrc/ba_prepare.inc), timed as its own phase.  Host buffers -> PCIe upload included.
+        e2e = []
+        for _ in range(7):
+            t0 = time.perf_counter()
+            eb = synth.load_into(host.Bundle(ctx, max_iterations=args.steps, update_sq_conv_limit=0.0), prob)
+            t1 = time.perf_counter()
+            eb.prepare()
+            t2 = time.perf_counter()
+            eb.Compute()
+            t3 = time.perf_counter()
+            eb.get_all()
+            eb.GetOutlierMeasurements()
+            t4 = time.perf_counter()
+            n_tr = len(eb.trials())
+            eb.close()
+            t5 = time.perf_counter()
+            e2e.append((t5 - t0, t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, n_tr))
+        e2e = sorted(e2e[1:])   # (the first call finds the context's caches empty)
+        med = e2e[len(e2e) // 2]
+        out["compute_call_end_to_end"] = {
+            "ms": 1e3 * med[0], "add_ms": 1e3 * med[1], "prepare_ms": 1e3 * med[2], "compute_ms": 1e3 * med[3], "get_ms": 1e3 * med[4],
+            "destroy_ms": 1e3 * med[5], "trials": med[6], "calls_ms": [round(1e3 * e[0], 3) for e in e2e],
+            "note": "median of 6 calls: new Bundle + Add* (bulk marshalling) + ptam_ba_prepare + Compute() + Get* + destroy, host buffers in, "
+                    "host buffers out — one MapMaker::BundleAdjust (src/MapMaker.cc:838-900)"}
         # ---- the deterministic mode's figure beside the default one (fixed-order camera sums: bit-identical runs, one trajectory)
         if not args.deterministic:
             args.deterministic = True
@@ -782,14 +808,16 @@ def main():
             for k_ in ks:
                 d_ = d_.get(k_) if isinstance(d_, dict) else None
             return round(scale * d_, nd) if isinstance(d_, (int, float)) else None
-        out["record_version"] = 5   # 4: tracking.tracked_fps became the moving-camera sequence (stationary: tracked_fps_stationary); 5: + summary, tracked_fps_moving
+        out["record_version"] = 6   # 4: tracking.tracked_fps became the moving-camera sequence (stationary: tracked_fps_stationary); 5: + summary, tracked_fps_moving; 6: + compute_call_end_to_end, summary.prepare_ms / trial_mix
         out["value_note"] = ("`value` is the WARM figure (bundles built, K7 spun up until its launch time settles, warm-up trials, then K timed "
                              "trials); `cold_call` is one Compute() 50 ms after the device went idle — what PTAM's mapmaker thread sees")
         out["summary"] = {"ba_it_s": round(out["value"], 1), "cold_call_it_s": _g(out, "cold_call", "value"),
                           "accepted_trial_us": _g(out, "accepted_trial_us"), "k7_roofline_frac": _g(out, "roofline", "frac", nd=3),
                           "solve_us": _g(out, "kernel_ms_per_trial", "solve", scale=1e3), "schur_us": _g(out, "kernel_ms_per_trial", "schur", scale=1e3),
                           "local_ba_it_s": _g(out, "local_ba_config4", "value"), "global_ba_it_s": _g(out, "global_ba_single_gpu", "value"),
-                          "tracked_fps": _g(out, "tracking", "tracked_fps"), "frame_us": _g(out, "tracking", "frame_us")}
+                          "tracked_fps": _g(out, "tracking", "tracked_fps"), "frame_us": _g(out, "tracking", "frame_us"),
+                          "prepare_ms": _g(out, "prepare_ms", nd=3), "compute_call_ms": _g(out, "compute_call_end_to_end", "ms", nd=3),
+                          "k7_frac_in_compute": _g(out, "roofline", "frac_in_compute", nd=3), "trial_mix": out.get("trial_mix")}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)

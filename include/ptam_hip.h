@@ -211,6 +211,13 @@ int ptam_epipolar_search_batch(ptam_ctx* ctx, const ptam_kf* src, ptam_kf* targe
                                const ptam_epipolar_query* queries, ptam_epipolar_result* results);
 /* ATANCamera::OnePixelDist() (src/ATANCamera.cc:69-75) for max_dist_sq */
 int ptam_ctx_one_pixel_dist(ptam_ctx* ctx, double* out);
+/* A deliberate deviation made observable.  TrackerData::ProjectAndDerivs (include/Tracker.h:89-94) calls GetProjectionDerivs()
+ * after Project() even when Project() bailed out before the camera model (:73-80: a point behind the camera or outside the model's
+ * radius) — the derivatives it then reads are the camera's cache of whichever point was projected last.  Here such a point keeps
+ * its own derivatives of the previous iteration.  *out = how often that happened in the pose loops
+ * (ptam_pose_gn*, ptam_track_map*, ptam_track_frame) on this context's device since the library was loaded: 0 means every
+ * tracked frame so far was also bit-for-bit what the reference's data flow gives. */
+int ptam_ctx_cache_hazards(ptam_ctx* ctx, long long* out);
 
 /* ---- TrackerData::Project / ProjectAndDerivs + ATANCamera (include/Tracker.h:70-94,
  *      src/ATANCamera.cc:109-121, 179-209) ------------------------------------------------------- */
@@ -549,6 +556,11 @@ int ptam_ba_counts(const ptam_ba* ba, int* n_cams, int* n_free_cams, int* n_poin
  * resident, which a device shared with another process' solve may not grant.  The repeated trial's result is what the reference
  * computes; the rest of the adjustment keeps the slower form.  0 in normal operation (returned as the function's value). */
 int ptam_ba_solve_fallbacks(const ptam_ba* ba);
+/* The other deliberate deviation made observable.  The reference accepts a second measurement of a point by the same camera
+ * (both stay in mMeasList, src/Bundle.cc:76-93, while the look-up table of :558-567 keeps the last one: the two are summed into
+ * U, V and the gradients but only one reaches the Schur complement); here ptam_ba_prepare / ptam_ba_compute refuse such a bundle
+ * with PTAM_E_ARG.  Returns how many measurements of the last prepare had a twin (0 for a bundle that was accepted). */
+int ptam_ba_duplicates_refused(const ptam_ba* ba);
 /* Operating switches of the camera solve, read from the environment once per process: PTAM_LDLT_NO_CHAIN=1 uses the
  * launch-per-block-column form everywhere (a device shared between processes that all adjust bundles); PTAM_CH_SPIN_LIMIT=<n> is
  * the number of looks (~1 us each, default 2^18) a workgroup of the persistent form takes before it gives up a wait. */

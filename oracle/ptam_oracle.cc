@@ -19,8 +19,9 @@
 //   libCVD fast_corner_detect_10: pixel p is a corner iff >= 10 contiguous pixels of the 16-pixel
 //     radius-3 ring are all > p+b or all < p-b (strict); y in [3,h-3), x in [3,w-3); raster order.
 //   TooN SE3::exp, SE3*SE3, generator_field, Cholesky (unpivoted LDL^T, lower triangle), WLS
-//     (normal equations; TooN's default decomposition for WLS is an SVD back-substitution, which for
-//     the SPD, prior-regularised 6x6 systems here equals the LDL^T solve used below to rounding).
+//     (normal equations; in TooN 2.x WLS<Size, Precision, Decomposition = Cholesky> solves them with
+//     that same Cholesky class — an LDL^T, the solve used below; SQSVD is the optional alternative,
+//     which src/Tracker.cc does not ask for).
 //
 // Each function cites the reference file:line it follows.  Loop and data-structure order mirror the
 // reference (std::list of measurements, dense camera x point LUT, off-diagonal scripts, std::sort
@@ -1455,7 +1456,11 @@ int ptamo_ctx_set_halfsample(ptamo_ctx* c, int v) {
     c->c.variant = v;
     return PTAM_OK;
 }
-long ptamo_ctx_cache_hazards(ptamo_ctx* c) { return c->c.cache_hazards; }
+// same signature as the product's ptam_ctx_cache_hazards (include/ptam_hip.h)
+int ptamo_ctx_cache_hazards(ptamo_ctx* c, long long* out) {
+    *out = c->c.cache_hazards;
+    return PTAM_OK;
+}
 int ptamo_ctx_camera_constants(ptamo_ctx* c, double out[8]) {
     ATANCamera cam(c->c.cam);
     out[0] = cam.focal[0];

@@ -145,6 +145,7 @@ PROTOTYPES = {
     "kf_implane_corners": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     "epipolar_search_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "ctx_one_pixel_dist": (_i, [_vp, _pd]),
+    "ctx_cache_hazards": (_i, [_vp, C.POINTER(C.c_longlong)]),
     "track_pvs": (_i, [_vp, _i, _vp, _pd, _vp, _vp]),
     "gn_opts_default": (None, [C.POINTER(GnOpts)]),
     "pose_gn": (_i, [_vp, _i, _vp, _vp, _pd, C.POINTER(GnOpts), _vp, _vp]),
@@ -170,6 +171,7 @@ PROTOTYPES = {
     "ba_get_trials": (_i, [_vp, _vp, _i]),
     "ba_counts": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "ba_solve_fallbacks": (_i, [_vp]),
+    "ba_duplicates_refused": (_i, [_vp]),
     "ba_set_profiling": (_i, [_vp, _i]),
     "ba_kernel_time": (_i, [_vp, _i, _pd, C.POINTER(_i)]),
     "ba_prepare": (_i, [_vp]),

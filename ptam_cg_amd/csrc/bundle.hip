@@ -126,6 +126,7 @@ struct ptam_ba {
     void* sblock = nullptr;   // the Schur work lists (sized after the device has counted their entries)
     size_t sblock_bytes = 0, sblock_cap = 0;
     int n_schur_segs = 0;
+    int dups_refused = 0;     // measurements of the last prepare that had a twin (same point, same camera)
     bool xchg_owned = false;   // d_xchg is an allocation of its own (a sharded bundle whose prepare failed)
     bool e2_is_current = false;   // m_e2 / m_state hold pass 1 of the CURRENT poses and points (the last step accepted nothing)
     int band_local = 0;     // block bandwidth of S needed by THIS process' points (ba->d.band: the one in force)
@@ -650,6 +651,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     if (int rc = ba_wait_stamp(ctx, stamp, seq)) return rc;
     lap("phase 1 wait");
     PrepScalars ps = *ps_host;
+    ba->dups_refused = ps.dup;
     if (ps.dup > 0) {
         ptam_set_error("duplicate measurement of point %d by camera %d", (int)(ps.dup_key >> 32), (int)(ps.dup_key & 0xffffffffu));
         return PTAM_E_ARG;
@@ -1820,6 +1822,10 @@ int ptam_ba_get_trials(const ptam_ba* ba, ptam_ba_trial* out, int cap) {
 int ptam_ba_solve_fallbacks(const ptam_ba* ba) {
     ARG_TRY(ba);
     return ba->solve_fallbacks;
+}
+int ptam_ba_duplicates_refused(const ptam_ba* ba) {
+    ARG_TRY(ba);
+    return ba->dups_refused;
 }
 int ptam_ba_counts(const ptam_ba* ba, int* n_cams, int* n_free, int* n_points, int* n_meas) {
     ARG_TRY(ba);

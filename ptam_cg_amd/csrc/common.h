@@ -84,6 +84,8 @@ void patch_preload_kernels();
 void kf_preload_kernels();
 void pvs_preload_kernels();
 void trackmap_preload_kernels();
+int pose_hazards_read_pose(hipStream_t st, unsigned long long* out);
+int pose_hazards_read_trackmap(hipStream_t st, unsigned long long* out);
 int ctx_scratch(ptam_ctx* ctx, size_t bytes, void** out);     // device scratch >= bytes
 int ctx_pinned(ptam_ctx* ctx, size_t bytes, void** out);      // pinned host staging >= bytes
 

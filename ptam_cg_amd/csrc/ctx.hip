@@ -287,6 +287,18 @@ int ptam_ctx_camera_constants(ptam_ctx* ctx, double out[8]) {
     return PTAM_OK;
 }
 
+int ptam_ctx_cache_hazards(ptam_ctx* ctx, long long* out) {
+    ARG_TRY(ctx && out);
+    HIP_TRY(hipSetDevice(ctx->device));
+    unsigned long long a = 0, b = 0;
+    int rc = pose_hazards_read_pose(ctx->stream, &a);
+    if (!rc) rc = pose_hazards_read_trackmap(ctx->stream, &b);
+    if (rc) return rc;
+    HIP_TRY(ptam_stream_wait(ctx->stream));
+    *out = (long long)(a + b);
+    return PTAM_OK;
+}
+
 int ptam_ctx_one_pixel_dist(ptam_ctx* ctx, double* out) {
     ARG_TRY(ctx && out);
     *out = ctx->cam.one_pixel_dist;

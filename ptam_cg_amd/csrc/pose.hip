@@ -270,7 +270,8 @@ __device__ __forceinline__ void pose_gn_body(const DevCam& cam, int n, const pta
                     if (st[i].found) {
                         PoseState s = st[i];
                         bool in_image;
-                        td_project(cam, sh.pose, meas[i].world, s, in_image);   // keeps img/D when not reached
+                        if (!td_project(cam, sh.pose, meas[i].world, s, in_image))   // keeps img/D when not reached
+                            atomicAdd(&g_pose_hazards, 1ull);                          // (counted: ptam_ctx_cache_hazards)
                         st[i] = s;
                     }
             } else {
@@ -832,6 +833,10 @@ int pose_chain_scratch(ptam_ctx* ctx, int n_cap, void** st_out, double** updates
     return PTAM_OK;
 }
 
+int pose_hazards_read_pose(hipStream_t st, unsigned long long* out) {   // (this translation unit's copy of the counter)
+    HIP_TRY(hipMemcpyFromSymbolAsync(out, HIP_SYMBOL(g_pose_hazards), 8, 0, hipMemcpyDeviceToHost, st));
+    return PTAM_OK;
+}
 void pose_preload_kernels() {
     ptam_preload((const void*)pose_gn_kernel);
     ptam_preload((const void*)pose_gn_small_kernel<1, GS_THREADS>);

@@ -525,14 +525,18 @@ __device__ __forceinline__ double pose_atan_pos(double x) {
 // TrackerData::Project with the pose in LDS; updates the cached state exactly like td_project.  Same formulas as cam_project /
 // cam_derivs (common.h) with the seven IEEE divisions of a projection — a dependent chain of a dozen instructions each — as
 // Newton-refined reciprocals (1 / Z, 1 / r, 1 / (r^2 (1 + k^2 r^2)): <= 1 ulp each) and the atan above.
-__device__ __forceinline__ void small_project(const DevCam& cam, const double* pose, SmallMeas& t, bool& in_image) {
+// Returns "camera model reached" (include/Tracker.h:70-85 bails out before it for a point behind the camera or outside the model's
+// radius; ProjectAndDerivs :89-94 then reads the camera's cache of ANOTHER point's projection — here the point keeps its own
+// derivatives, and the event is counted: g_pose_hazards, ptam_ctx_cache_hazards).
+static __device__ unsigned long long g_pose_hazards;
+__device__ __forceinline__ bool small_project(const DevCam& cam, const double* pose, SmallMeas& t, bool& in_image) {
     in_image = false;
     se3_apply(pose, t.world[0], t.world[1], t.world[2], t.cam3[0], t.cam3[1], t.cam3[2]);
     t.iz = rcp_nr(t.cam3[2]);
-    if (t.cam3[2] < 0.001) return;
+    if (t.cam3[2] < 0.001) return false;
     const double x = t.cam3[0] * t.iz, y = t.cam3[1] * t.iz;
     const double r2 = x * x + y * y;
-    if (r2 > cam.largest_radius * cam.largest_radius) return;
+    if (r2 > cam.largest_radius * cam.largest_radius) return false;
     const double r = sqrt(r2);
     const bool small_r = r < 0.001 || cam.w == 0.0;
     const double ir = rcp_nr(small_r ? 1.0 : r);
@@ -555,9 +559,10 @@ __device__ __forceinline__ void small_project(const DevCam& cam, const double* p
         t.D[1] = cam.fx * (dy * x);
         t.D[3] = cam.fy * (dy * y + f);
     }
-    if (r > cam.max_r) return;
-    if (u < 0 || v < 0 || u > cam.width || v > cam.height) return;
+    if (r > cam.max_r) return true;
+    if (u < 0 || v < 0 || u > cam.width || v > cam.height) return true;
     in_image = true;
+    return true;
 }
 
 // Fast path, n <= 1024: 256 threads x 4 measurements held in registers (one wave per SIMD, the four
@@ -633,6 +638,7 @@ __device__ __forceinline__ void pose_gn_small_body(const DevCam& cam, int n, LOA
 #define PH(i)
 #endif
     int sel_par = 0;
+    int hazards = 0;   // re-projections of found measurements that bailed out before the camera model (see small_project)
     for (int iter = 0; iter < opts.iterations; iter++) {
 #ifdef K7_TIMING
         long long pt_ = (long long)__builtin_readcyclecounter();
@@ -650,7 +656,7 @@ __device__ __forceinline__ void pose_gn_small_body(const DevCam& cam, int n, LOA
             for (int q = 0; q < MPT; q++)
                 if (t[q].found) {
                     bool in_image;
-                    small_project(cam, sh.pose, t[q], in_image);
+                    if (!small_project(cam, sh.pose, t[q], in_image)) hazards++;
                     small_jacobian(t[q].cam3, t[q].iz, t[q].D, t[q].J);
                 }
         } else if (iter != 0) {   // LinearUpdate include/Tracker.h:139-142
@@ -837,6 +843,7 @@ __device__ __forceinline__ void pose_gn_small_body(const DevCam& cam, int n, LOA
         }
 #endif
     if (tid < 12) pose_io[tid] = sh.pose[tid];
+    if (hazards) atomicAdd(&g_pose_hazards, (unsigned long long)hazards);   // (rare: a tracked point that left the camera model)
     // resident chain: the measurements' TrackerData state goes back to the per-point table, scene depth sums
     if (io.td_base) {
 #pragma unroll

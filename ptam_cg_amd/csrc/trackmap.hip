@@ -2161,6 +2161,10 @@ int ptam_bench_track_batch(int nb, ptam_tracker* const* trackers, ptam_kf* const
 
 }   // extern "C"
 
+int pose_hazards_read_trackmap(hipStream_t st, unsigned long long* out) {   // (this translation unit's copy of the counter)
+    HIP_TRY(hipMemcpyFromSymbolAsync(out, HIP_SYMBOL(g_pose_hazards), 8, 0, hipMemcpyDeviceToHost, st));
+    return PTAM_OK;
+}
 void trackmap_preload_kernels() {
     ptam_preload((const void*)refind_prep_kernel);
     ptam_preload((const void*)refind_mask_kernel);

@@ -93,6 +93,13 @@ class Context:
     def sync(self):
         self._check(self.lib.ctx_sync(self.h), "ctx_sync")
 
+    def cache_hazards(self):
+        """pose-loop re-projections that bailed out before the camera model (ptam_ctx_cache_hazards: where the reference's
+        ProjectAndDerivs would read another point's cached derivatives)"""
+        v = C.c_longlong()
+        self._check(self.lib.ctx_cache_hazards(self.h, C.byref(v)), "ctx_cache_hazards")
+        return v.value
+
     def camera_constants(self):
         out = np.zeros(8)
         self._check(self.lib.ctx_camera_constants(self.h, _pd(out)), "camera_constants")
@@ -688,6 +695,10 @@ class Bundle:
 
     def prepare(self):
         self.ctx._check(self.lib.ba_prepare(self.h), "ba_prepare")
+
+    def duplicates_refused(self):
+        """measurements of the last prepare that had a twin (same point, same camera): such a bundle is refused"""
+        return int(self.lib.ba_duplicates_refused(self.h))
 
     def debug_lists(self, which, dtype):
         """one of the index structures ptam_ba_prepare built on the device (include/ptam_hip_bench.h: PTAM_BL_*), flat"""

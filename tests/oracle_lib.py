@@ -28,6 +28,4 @@ def load_oracle(build=True):
         lib.ptamo_tukey_sigma_sq.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.ptamo_tukey_sigma_sq.restype = ctypes.c_double
         lib.ptamo_ldlt_solve.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-        lib.ptamo_ctx_cache_hazards.argtypes = [ctypes.c_void_p]
-        lib.ptamo_ctx_cache_hazards.restype = ctypes.c_long
     return _bound

@@ -119,6 +119,46 @@ def test_pose_gn(hip, oracle, stage):
     assert np.abs(ph - pc["true_pose"]).max() < 5e-3
 
 
+def _pose_case_with_points_leaving_the_camera_model(n, seed):
+    """make_pose_case + 16 map points that project half a pixel inside the image corner farthest from the principal point — where
+    the camera model's radius ends (src/ATANCamera.cc:56-63): a pose update of a pixel in the wrong direction takes them outside,
+    TrackerData::Project bails out before the model (include/Tracker.h:73-80) and ProjectAndDerivs (:89-94) would read stale derivatives"""
+    pc = synth.make_pose_case(n=n, seed=seed)
+    cam = synth.AtanCam()
+    rng = np.random.default_rng(seed)
+    px = rng.uniform(0.05, 0.45, (16, 2))                      # pixel (0, 0) is the far corner of the default camera (cx, cy > 0.5)
+    d = np.column_stack([cam.unproject(px), np.ones(16)])      # rays in the camera frame of the INITIAL pose
+    R, t = pc["init_pose"][:9].reshape(3, 3), pc["init_pose"][9:]
+    o, dw = -R.T @ t, d @ R                                    # camera centre and ray directions in the world
+    lam = -o[2] / dw[:, 2]                                     # onto the plane z = 0
+    extra = o + lam[:, None] * dw
+    ok0, _ = cam.visible(pc["init_pose"], extra)
+    assert ok0.all()
+    _, im_true = cam.visible(pc["true_pose"], extra)
+    return {"world": np.vstack([pc["world"], extra]), "found": np.vstack([pc["found"], im_true]),
+            "sqrt_inv_noise": np.concatenate([pc["sqrt_inv_noise"], np.ones(16)]), "init_pose": pc["init_pose"]}
+
+
+@pytest.mark.parametrize("n", [40, 600, 1500])   # one wave | 512 x 2 in registers | the general kernel
+def test_pose_gn_counts_the_projections_that_leave_the_camera_model(hip, oracle, n):
+    """The deviation of DESIGN section 2 is observable: ptam_ctx_cache_hazards counts the re-projections of found measurements that bail
+    out before the camera model — the same events the checker counts — and the pose loop's result is the checker's."""
+    ch, co = host.Context(lib=hip), host.Context(lib=oracle)
+    seen = 0
+    for seed in range(40, 60):
+        pc = _pose_case_with_points_leaving_the_camera_model(n, seed)
+        h0, o0 = ch.cache_hazards(), co.cache_hazards()
+        ph, fh, uh = ch.pose_gn(pc["world"], pc["found"], pc["sqrt_inv_noise"], pc["init_pose"])
+        po, fo, uo = co.pose_gn(pc["world"], pc["found"], pc["sqrt_inv_noise"], pc["init_pose"])
+        dh, do = ch.cache_hazards() - h0, co.cache_hazards() - o0
+        assert dh == do, (seed, dh, do)
+        assert np.allclose(ph, po, rtol=0, atol=1e-10) and np.array_equal(fh, fo)
+        seen += do
+        if seen >= 3:
+            break
+    assert seen >= 3   # (the construction does produce the event)
+
+
 def test_pose_gn_with_massive_ties(hip, oracle):
     """12 distinct measurements, each repeated 80 times: the squared errors tie in runs of 80, so the order-statistic
     select cannot finish from one histogram bin and has to take its general radix path"""
@@ -882,6 +922,61 @@ def test_ill_conditioned_bundles_before_the_extended_precision_referee(hip, orac
         # both are off by the same order; the product is not the outlier of the three
         assert d_got <= 10 * max(d_orc, 1e-9)
         assert np.array_equal(got["outliers"], ref["outliers"])
+
+
+# a seeded slice of the fuzzers (tests/tools/fuzz_ba.py, referee_fuzz.py: the same generator) inside the gated
+# suite.  The rule, per case: the product is within the 1e-6 the path promises of the checker, trial by trial — or, where the two
+# differ by more (2 % of random shapes: thin, ill-conditioned chains on which last-bit differences of an early trial are amplified),
+# the x87 extended-precision referee arbitrates: over the trials all three walk together the product must be no farther from the
+# referee than the checker is (factor 10 as in the named cases above), and it must follow the referee's discrete trajectory at
+# least as long as the checker does.
+def _fuzz_cases(big, seed, n):
+    rng = np.random.default_rng(seed)
+    for i in range(n):
+        n_cams = int(rng.integers(60, 220)) if big else int(rng.integers(2, 90))
+        n_pts = int(rng.integers(200, 700)) if big else int(rng.integers(3, 900))
+        window = (int(rng.integers(4, 60)) if big else (None if rng.random() < 0.35 else int(rng.integers(2, max(3, n_cams)))))
+        case = dict(n_cams=n_cams, n_pts=n_pts, seed=5000 + i, window=window, n_fixed=int(rng.integers(1, min(4, n_cams))),
+                    outlier_frac=float(rng.choice([0.0, 0.02, 0.15])), pt_noise=float(rng.choice([0.002, 0.01, 0.05])),
+                    dup=int(rng.choice([1, 1, 1, 3])))
+        est = [_abi.EST_TUKEY, _abi.EST_CAUCHY, _abi.EST_HUBER][i % 3]
+        mi = int(rng.choice([20, 20, 3, 7]))
+        yield i, case, est, mi
+
+
+def _common_prefix(a, b):
+    n = 0
+    for x, y in zip(a, b):
+        if not (abs(x["lambda"] - y["lambda"]) <= 1e-12 * abs(y["lambda"]) and x["accepted"] == y["accepted"] and x["n_bad"] == y["n_bad"]):
+            break
+        n += 1
+    return n
+
+
+@pytest.mark.parametrize("kind,seed,n", [("small", 101, 60), ("big", 11, 20)])
+def test_fuzz_slice_within_tolerance_or_as_close_to_the_referee_as_the_checker(hip, oracle, kind, seed, n):
+    from tests import referee_lib
+    refereed = []
+    for i, case, est, mi in _fuzz_cases(kind == "big", seed, n):
+        prob = synth.make_ba_problem(**case)
+        if len(prob["cam_idx"]) == 0:
+            continue
+        a = util.run_ba(hip, prob, estimator=est, max_iterations=mi)
+        b = util.run_ba(oracle, prob, estimator=est, max_iterations=mi)
+        try:
+            util.assert_ba_equal(a, b, rel=1e-6)
+            continue
+        except AssertionError:
+            pass
+        r = referee_lib.run_ba(prob, estimator=est, max_iterations=mi)
+        pa, pb = _common_prefix(a["trials"], r["trials"]), _common_prefix(b["trials"], r["trials"])
+        n3 = min(pa, pb)
+        dp, do = _trial_distance(a["trials"], r["trials"], n3), _trial_distance(b["trials"], r["trials"], n3)
+        refereed.append((i, n3, dp, do))
+        assert pa >= pb, (i, case, pa, pb)                      # leaves the referee's trajectory no earlier than the checker
+        assert dp <= 10 * max(do, 1e-9), (i, case, dp, do)      # and is no farther from it
+    print(f"{kind}: {len(refereed)} of {n} cases before the referee: {refereed}")
+    assert len(refereed) <= max(3, n // 8)                      # (2 % expected: more would be a regression of the path, not of its conditioning)
 
 
 @pytest.mark.parametrize("shape", [(50, 5000, None), (20, 3000, None), (200, 26000, 16), (9, 400, None)])
