@@ -280,6 +280,7 @@ def test_device_built_lists_equal_the_numpy_restatement(hip, split_ref, case):
     ba = synth.load_into(host.Bundle(ctx), prob)
     ba.prepare()
     check_lists(ba, prob, np.zeros(len(prob["cam_idx"]), bool), split_ref)
+    assert ba.duplicates_refused() == 0
     ba.close()
     ctx.close()
 
@@ -333,5 +334,6 @@ def test_duplicate_measurement_is_refused_with_its_point_and_camera(hip):
     with pytest.raises(host.PtamError) as ei:
         ba.prepare()
     assert f"duplicate measurement of point {prob['pt_idx'][1234]} by camera {prob['cam_idx'][1234]}" in str(ei.value)
+    assert ba.duplicates_refused() == 2   # (both twins count; 0 for an accepted bundle)
     ba.close()
     ctx.close()
