@@ -19,14 +19,18 @@ struct SplitCfg {
     int slots;        // workgroups one XCD holds at once
 };
 
-// one XCD's list: pairs k = 0..np-1 (the non-empty ones, in list order), pair k's runs are [pl_run0[k], pl_run0[k + 1])
-struct SplitRuns {
-    const int* run_cnt;
-    const int* run_cost;
-    const int* pl_run0;   // [np + 1]
-    const int* pl_n;      // entries of the pair
+// one XCD's list: pairs k = 0..np-1 (the non-empty ones, in list order), pair k's runs are [pl_run0[k], pl_run0[k + 1]).
+// P: the pointer type of the arrays (the device kernel keeps them in LDS and says so in the type: a fill is a serial chain of
+// dependent reads, and through generic pointers each was a FLAT load of several hundred cycles).
+template <class P>
+struct SplitRunsT {
+    P run_cnt;
+    P run_cost;
+    P pl_run0;   // [np + 1]
+    P pl_n;      // entries of the pair
     int np;
 };
+typedef SplitRunsT<const int*> SplitRuns;
 
 // 16x16 fragments per tile (row mappings of ba_schur.inc: 1-2 cameras in a tile = 1 fragment, 3-5 = 2, 6-8 = 3)
 __host__ __device__ inline int split_frags(int F, int t) {
@@ -59,39 +63,46 @@ __host__ __device__ inline int split_full_products(int F, int a, int b) {
 // The greedy fill: the pairs' entries, one pair after another, into workgroups of whole 4-entry groups such that no workgroup's
 // cost — entries + seg_cost per segment (+ second_lag for list positions >= n_first) — exceeds T.  Returns the workgroups made;
 // emit(k, begin, end, wg) is called for every segment (entries [begin, end) of pair k, relative to the pair's first entry in
-// this list, in workgroup wg).
-template <class Emit>
-__host__ __device__ inline int split_fill(long long T, const SplitRuns& R, const SplitCfg& c, Emit&& emit) {
+// this list, in workgroup wg).  I: the integer type budgets and costs are held in (int where the list's total cost fits 31 bits:
+// the device's 64-bit divisions are software; the decisions are the same).  The fill gives up — returns a count > limit — as
+// soon as it has made more than `limit` workgroups: a budget near the mean cost makes hundreds of them (every one the
+// minimum segment), and the budget search's wave runs as long as its slowest lane.
+template <class I, class RUNS, class Emit>
+__host__ __device__ inline int split_fill(I T, const RUNS& R, const SplitCfg& c, Emit&& emit, int limit = 0x7fffffff) {
     int n_out = 0, cur_n = 0;
-    long long cur_cost = 0;
+    I cur_cost = 0;
     for (int k = 0; k < R.np; k++) {
         const int n = R.pl_n[k], run1 = R.pl_run0[k + 1];
         int pos = 0, ri = R.pl_run0[k], ro = 0;
+        int rc = R.run_cnt[ri], rs = R.run_cost[ri];   // the run `pos` is in
         while (pos < n) {
             const int left = n - pos;
-            const long long room = T - (n_out >= c.n_first ? c.second_lag : 0) - cur_cost - c.seg_cost;
+            const I room = T - (I)(n_out >= c.n_first ? c.second_lag : 0) - cur_cost - (I)c.seg_cost;
             // as many whole entries as the workgroup's remaining budget pays for
             int take = 0;
             if (room >= 0) {
-                long long rem = room;
-                int i = ri, o = ro;
-                while (i < run1) {
-                    const int avail = R.run_cnt[i] - o, cst = R.run_cost[i];
-                    if ((long long)avail * cst <= rem) {
-                        take += avail;
-                        rem -= (long long)avail * cst;
-                        i++;
-                        o = 0;
-                    } else {
-                        take += (int)(rem / cst);
-                        break;
+                const int avail0 = rc - ro;
+                if ((I)avail0 * rs <= room) {
+                    take = avail0;
+                    I rem = room - (I)avail0 * rs;
+                    for (int i = ri + 1; i < run1; i++) {
+                        const int avail = R.run_cnt[i], cst = R.run_cost[i];
+                        if ((I)avail * cst <= rem) {
+                            take += avail;
+                            rem -= (I)avail * cst;
+                        } else {
+                            take += (int)(rem / cst);
+                            break;
+                        }
                     }
-                }
+                } else
+                    take = (int)(room / rs);
             }
             take = take >= left ? left : take / 4 * 4;
             // a sliver at the end of a full workgroup — less work than the segment itself would cost: start the next one
-            if (cur_n > 0 && left > take && (take < c.min_seg || room < c.min_room)) {
+            if (cur_n > 0 && left > take && (take < c.min_seg || room < (I)c.min_room)) {
                 n_out++;
+                if (n_out > limit) return n_out;
                 cur_n = 0;
                 cur_cost = 0;
                 continue;
@@ -99,17 +110,21 @@ __host__ __device__ inline int split_fill(long long T, const SplitRuns& R, const
             if (take < c.min_seg) take = c.min_seg;
             if (left - take < c.min_seg) take = left;   // ... or at the end of the pair's chunk: take it along
             if (take > left) take = left;
-            long long cst = 0;
+            I cst = 0;
             for (int t = take; t > 0;) {
-                const int avail = R.run_cnt[ri] - ro, s = avail < t ? avail : t;
-                cst += (long long)s * R.run_cost[ri];
+                const int avail = rc - ro, s = avail < t ? avail : t;
+                cst += (I)s * rs;
                 t -= s;
                 ro += s;
-                if (ro == R.run_cnt[ri]) ri++, ro = 0;
+                if (ro == rc) {
+                    ri++;
+                    ro = 0;
+                    if (ri < run1) rc = R.run_cnt[ri], rs = R.run_cost[ri];
+                }
             }
             emit(k, pos, pos + take, n_out);
             cur_n++;
-            cur_cost += cst + c.seg_cost;
+            cur_cost += cst + (I)c.seg_cost;
             pos += take;
         }
     }
@@ -126,8 +141,8 @@ struct SplitBracket {
 };
 __host__ __device__ inline SplitBracket split_bracket_begin(long long cost_x, int n_wg, int chunks_x, const SplitCfg& c) {
     SplitBracket b;
-    b.lo = cost_x / n_wg;                                   // the mean cost is a lower bound
-    b.hi = b.lo + b.lo / 4 + c.seg_cost + c.second_lag;     // the answer is 1.2 - 1.5 times the mean
+    b.lo = cost_x / n_wg + c.seg_cost;                      // a lower bound: the mean cost + the one segment every workgroup has
+    b.hi = b.lo + b.lo / 4 + c.second_lag;                  // the answer is 1.1 - 1.4 times that
     b.t_all = cost_x + (long long)c.seg_cost * (chunks_x + n_wg) + c.second_lag + 1;   // one workgroup takes it all
     if (b.hi > b.t_all) b.hi = b.t_all;
     if (b.lo >= b.hi) b.lo = b.hi - 1;
@@ -150,5 +165,5 @@ __host__ __device__ inline void split_bracket_step(SplitBracket& b, int jmin) {
     const long long nhi = split_candidate(b, jmin), nlo = jmin > 0 ? split_candidate(b, jmin - 1) : b.lo;
     b.lo = nlo;
     b.hi = nhi;
-    if (b.hi - b.lo <= b.hi / 400 + 1) b.done = 1;   // 0.25 %
+    if (b.hi - b.lo <= b.hi / 200 + 1) b.done = 1;   // 0.5 %: one round of 256 budgets over a bracket of 0.7 means
 }

@@ -721,6 +721,9 @@ static int ba_prepare_impl(ptam_ba* ba) {
                      o_cute1 = sv.take((size_t)8 * cap_cut * 4), o_cutwg = sv.take((size_t)8 * cap_cut * 4),
                      o_wgfirst = sv.take((size_t)8 * (cfg.slots + 1) * 4), o_pairfirst = sv.take((size_t)n_pairs * 8 * 4),
                      o_wsegtmp = sv.take(((size_t)nb_max + 1) * 4);
+        // every lane of the budget search keeps the cut its budget makes, unless that would be more than 64 MB
+        const size_t rec_bytes = (size_t)8 * 512 * cap_cut * sizeof(int4);
+        const size_t o_rec = rec_bytes <= ((size_t)64 << 20) ? sv.take(rec_bytes) : 0;
         ba->sblock_bytes = sv.off;
         if (!ctx_cache_take(ctx->dev_cache, CTX_NCACHE(ctx->dev_cache), ba->sblock_bytes, &ba->sblock, &ba->sblock_cap)) {
             HIP_TRY(hipMalloc(&ba->sblock, ba->sblock_bytes));
@@ -749,6 +752,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
         q.wg_first = (int*)(sb + o_wgfirst);
         q.pair_first = (int*)(sb + o_pairfirst);
         q.wseg_tmp = (int*)(sb + o_wsegtmp);
+        q.rec = rec_bytes <= ((size_t)64 << 20) ? (int4*)(sb + o_rec) : nullptr;
         hipLaunchKernelGGL(prep_split_kernel, dim3(8), dim3(512), 0, ctx->stream, q, cfg);
         hipLaunchKernelGGL(prep_entries_kernel, dim3(n_pairs, 8), dim3(256), 0, ctx->stream, q, d, cfg.cost_model);
         hipLaunchKernelGGL(prep_finish_kernel, dim3(1), dim3(1024), 0, ctx->stream, q, d, cfg.slots);
@@ -786,11 +790,20 @@ static int ba_prepare_impl(ptam_ba* ba) {
     lap("phase 2 wait");
     ps = *ps_host;
     if (ps.bad) {
-        ptam_set_error("bundle prepare: a Schur work list outgrew its bound (%d)", ps.bad);
+        ptam_set_error("bundle prepare: a Schur work list outgrew its bound (%d; workgroups per list %d %d %d %d %d %d %d %d, budgets %lld %lld, segments %d %d)", ps.bad,
+                       ps.n_wgs[0], ps.n_wgs[1], ps.n_wgs[2], ps.n_wgs[3], ps.n_wgs[4], ps.n_wgs[5], ps.n_wgs[6], ps.n_wgs[7], ps.t_cut[0], ps.t_cut[1],
+                       ps.n_cuts[0], ps.n_cuts[1]);
         return PTAM_E_STATE;
     }
     d.n_schur_wg = ps.n_schur_wg;
     ba->n_schur_segs = ps.n_segs;
+#ifdef PREP_STAMPS
+    for (int x = 0; x < 8; x++) {
+        std::fprintf(stderr, "[ptam] split kernel, list %d (us from its start): lists built %.1f | in LDS %.1f | round 1 done %.1f | search done %.1f | cut written %.1f\n", x,
+                     (ps.stamp[x][1] - ps.stamp[x][0]) * 0.01, (ps.stamp[x][2] - ps.stamp[x][0]) * 0.01, (ps.stamp[x][3] - ps.stamp[x][0]) * 0.01,
+                     (ps.stamp[x][4] - ps.stamp[x][0]) * 0.01, (ps.stamp[x][5] - ps.stamp[x][0]) * 0.01);
+    }
+#endif
     if (getenv("PTAM_DEBUG_SCHUR")) {
         std::fprintf(stderr, "[ptam] schur: %d segments, %d workgroups; %lld entries in %d (XCD, pair) lists, budgets", ps.n_segs, ps.n_schur_wg,
                      ps.n_entries, ps.n_xp);

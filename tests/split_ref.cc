@@ -11,7 +11,7 @@ static long long smallest_budget(const SplitRuns& R, const SplitCfg& c, long lon
     for (int round = 0; round < 64 && !br.done; round++) {
         int jmin = SPLIT_NC;
         for (int j = 0; j < SPLIT_NC; j++)
-            if (split_fill(split_candidate(br, j), R, c, none) <= n_wg) {
+            if (split_fill(split_candidate(br, j), R, c, none, n_wg) <= n_wg) {
                 jmin = j;
                 break;
             }
