@@ -72,11 +72,14 @@ struct BaScalars {
                             //                next one starts from the unchanged state with the unchanged lambda
     int abort_any;          // sharded: some rank's abort flag was up when this trial was enqueued (summed with the trial's scalars)
     int solve_fault;        // the persistent factorisation gave up waiting for one of its workgroups (ldlt_chain.inc): the solve is void
+    int spec_seq;           // which trial's decision end_step / spec_go / spec_stay are (its mailbox sequence number): a guarded kernel enqueued
+                            // behind another trial — a leftover on the queue a rejected trial's continuation has left — does nothing
 };
 
 struct BaDev {
     int C, F, P, M;
     int guard;              // 0: run; 1: run only if sc->spec_go or sc->spec_stay; 2: only if sc->end_step (speculatively enqueued kernels)
+    int guard_seq;          //    ... and only if sc->spec_seq is this (the trial the kernel was enqueued behind)
     int n, npad;            // camera system order 6F and its padding to SOLVE_NB
     int band;               // block bandwidth of S (in SOLVE_NB blocks): |block(row) - block(col)| <= band wherever two cameras share a point
     int n_chunks, grid_acc; // measurement chunks; persistent grid of the accumulate kernel

@@ -99,16 +99,103 @@ struct PinVec {
     }
 };
 
+// The measurements as they are added (ba_prepare.inc: MS_CH, ms_cam ...): 1 MB chunks of [cam | point | found | sigma^2] in pinned
+// host memory and, in the same layout, on the device — a chunk is uploaded as ONE copy the moment it is full, so the PCIe transfer
+// (0.3 ms of a 0.5 ms prepare at 250 000 measurements) runs while the host is still adding; prepare sends the last, partial chunk.
+struct MeasStore {
+    ptam_ctx* ctx = nullptr;
+    char* h = nullptr;   // pinned host chunks
+    size_t h_chunks = 0, h_bytes = 0;
+    size_t n = 0;        // measurements
+    char* d = nullptr;   // device chunks
+    size_t d_chunks = 0, d_bytes = 0;
+    size_t up_chunks = 0;     // complete chunks already on their way to the device
+    bool in_flight = false;   // a copy out of h may still be queued
+    size_t size() const { return n; }
+    int& cam(size_t i) { return const_cast<int&>(ms_cam(h, i)); }
+    int& pt(size_t i) { return const_cast<int&>(ms_pt(h, i)); }
+    double2& found(size_t i) { return const_cast<double2&>(ms_found(h, i)); }
+    double& sig(size_t i) { return const_cast<double&>(ms_sig(h, i)); }
+    int reserve_host(size_t chunks) {
+        if (chunks <= h_chunks) return PTAM_OK;
+        chunks = std::max(chunks, 2 * h_chunks);
+        void* np = nullptr;
+        size_t nbytes = 0;
+        if (!ctx_cache_take(ctx->pin_cache, CTX_NCACHE(ctx->pin_cache), chunks * MS_CH_BYTES, &np, &nbytes)) {
+            HIP_TRY(hipSetDevice(ctx->device));
+            HIP_TRY(hipHostMalloc(&np, chunks * MS_CH_BYTES, hipHostMallocDefault));
+            nbytes = chunks * MS_CH_BYTES;
+        }
+        if (n) std::memcpy(np, h, ((n + MS_CH - 1) >> MS_LOG) * MS_CH_BYTES);
+        if (in_flight) HIP_TRY(ptam_stream_wait(ctx->stream));   // (copies out of the old chunks)
+        in_flight = false;
+        release_host();
+        h = (char*)np;
+        h_bytes = nbytes;
+        h_chunks = nbytes / MS_CH_BYTES;
+        return PTAM_OK;
+    }
+    int reserve_dev(size_t chunks) {
+        if (chunks <= d_chunks) return PTAM_OK;
+        chunks = std::max(std::max(chunks, 2 * d_chunks), h_chunks);
+        void* np = nullptr;
+        size_t nbytes = 0;
+        HIP_TRY(hipSetDevice(ctx->device));
+        if (!ctx_cache_take(ctx->dev_cache, CTX_NCACHE(ctx->dev_cache), chunks * MS_CH_BYTES, &np, &nbytes)) {
+            HIP_TRY(hipMalloc(&np, chunks * MS_CH_BYTES));
+            nbytes = chunks * MS_CH_BYTES;
+        }
+        release_dev();   // (queued copies into the old block: its next owner only touches it through the same queue)
+        d = (char*)np;
+        d_bytes = nbytes;
+        d_chunks = nbytes / MS_CH_BYTES;
+        up_chunks = 0;   // everything goes up again
+        return PTAM_OK;
+    }
+    // enqueue the upload of the complete chunks that have not gone yet (and of the partial last one: prepare)
+    int flush(bool with_partial) {
+        const size_t full = n >> MS_LOG, want = with_partial ? (n + MS_CH - 1) >> MS_LOG : full;
+        if (want > d_chunks) {
+            const int rc = reserve_dev(want);
+            if (rc) return rc;
+        }
+        if (want > up_chunks) {
+            HIP_TRY(hipSetDevice(ctx->device));
+            HIP_TRY(hipMemcpyAsync(d + up_chunks * MS_CH_BYTES, h + up_chunks * MS_CH_BYTES, (want - up_chunks) * MS_CH_BYTES, hipMemcpyHostToDevice,
+                                   ctx->stream));
+            in_flight = true;
+        }
+        up_chunks = full;
+        return PTAM_OK;
+    }
+    void release_host() {
+        if (h) {
+            void* drop = ctx_cache_give(ctx->pin_cache, CTX_NCACHE(ctx->pin_cache), h, h_bytes);
+            if (drop) hipHostFree(drop);
+        }
+        h = nullptr;
+        h_chunks = h_bytes = 0;
+    }
+    void release_dev() {
+        if (d) {
+            void* drop = ctx_cache_give(ctx->dev_cache, CTX_NCACHE(ctx->dev_cache), d, d_bytes);
+            if (drop) hipFree(drop);
+        }
+        d = nullptr;
+        d_chunks = d_bytes = 0;
+        up_chunks = 0;
+    }
+};
+
 struct ptam_ba {
     ptam_ctx* ctx;
     ptam_ba_opts opts;
-    // inputs (insertion order), copied at add_* time like the reference; the per-measurement and per-point arrays in pinned memory
+    // inputs (insertion order), copied at add_* time like the reference; the measurements and the points in pinned memory
     std::vector<double> cam_pose;
     std::vector<uint8_t> cam_fixed;
     PinVec<double> pts;
-    PinVec<int> m_cam, m_pt;
-    PinVec<double> m_found, m_sig;   // m_sig: sigma^2 as given (dSqrtInvNoise is formed on the device)
-    PinVec<uint8_t> m_dead;
+    MeasStore ms;                  // camera, point, found position, sigma^2 per measurement (dSqrtInvNoise is formed on the device)
+    std::vector<uint8_t> m_dead;   // erased by an earlier Compute()
     int n_dead = 0;
     // results
     bool converged = false;
@@ -268,7 +355,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     BaDev& d = ba->d;
     std::memset(&d, 0, sizeof d);
     const int C = (int)ba->cam_fixed.size(), P_all = (int)(ba->pts.size() / 3);
-    const int Mall = (int)ba->m_cam.size();
+    const int Mall = (int)ba->ms.size();
     const int M = Mall - ba->n_dead;
     // free-camera indices in insertion order  (nStartRow, src/Bundle.cc:52-57)
     std::vector<int> cam_free(C, -1);
@@ -484,8 +571,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
                  s_porder = sm.take(pair_order.size() * 4);
     const size_t o_small = cv.take(sm.off);
     // raw input (insertion order) and the builder's temporaries
-    const size_t o_rcam = cv.take(Maz * 4), o_rpt = cv.take(Maz * 4), o_rfound = cv.take(Maz * 16), o_rsig = cv.take(Maz * 8),
-                 o_rdead = cv.take(Maz), o_ptsraw = cv.take(Pz * 24);
+    const size_t o_rdead = cv.take(Maz), o_ptsraw = cv.take(Pz * 24);
     const size_t o_start = cv.take((Pz + 1) * 4), o_denseof = cv.take(Pz * 4), o_ptorig = cv.take(Pz * 4), o_arr = cv.take(Maz * 4),
                  o_tmpi = cv.take(Mz * 4), o_tmpkey = cv.take(Mz * 4), o_ptile = cv.take(Mz * 16), o_kp = cv.take(Pz * 4),
                  o_costp = cv.take(Pz * 4), o_entpre = cv.take((Pz + 1) * 8), o_costpre = cv.take((Pz + 1) * 8), o_ebase = cv.take(hist_n * 4);
@@ -570,7 +656,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     // ---- pinned staging: [stamp | scalars read back | rowptr | dense point ids | small tables | chunks] -------------------------
     Carver hs;
     const size_t h_stamp = hs.take(64), h_psrb = hs.take(sizeof(PrepScalars)), h_rowptr = hs.take((Pz + 1) * 4), h_ptorig = hs.take(Pz * 4),
-                 h_small = hs.take(sm.off), h_chunks = hs.take(chunks_cap * sizeof(BaChunk));
+                 h_small = hs.take(sm.off), h_chunks = hs.take(chunks_cap * sizeof(BaChunk)), h_dead = hs.take(ba->n_dead > 0 ? Maz : 1);
     (void)h_stamp;
     void* pin = nullptr;
     {
@@ -595,20 +681,17 @@ static int ba_prepare_impl(ptam_ba* ba) {
 #define UP(dst, src, bytes)                                                                        \
     if ((bytes) > 0) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream))
     UP(base + o_small, hp + h_small, sm.off);
-    UP(base + o_rpt, ba->m_pt.data(), (size_t)Mall * 4);   // (the count kernel's input first)
-    UP(base + o_rcam, ba->m_cam.data(), (size_t)Mall * 4);
-    UP(base + o_rfound, ba->m_found.data(), (size_t)Mall * 16);
-    UP(base + o_rsig, ba->m_sig.data(), (size_t)Mall * 8);
-    if (ba->n_dead > 0) UP(base + o_rdead, ba->m_dead.data(), (size_t)Mall);
+    if (int rc_f = ba->ms.flush(true)) return rc_f;   // (the complete chunks went up while they were added: only the last one is left)
+    if (ba->n_dead > 0) {
+        std::memcpy(hp + h_dead, ba->m_dead.data(), (size_t)Mall);
+        UP(base + o_rdead, hp + h_dead, (size_t)Mall);
+    }
     UP(base + o_ptsraw, ba->pts.data(), (size_t)P_all * 24);
     PrepDev q;
     std::memset(&q, 0, sizeof q);
     q.C = C, q.F = F, q.P_all = P_all, q.Mall = Mall, q.M = M;
     q.n_tiles = n_tiles, q.n_pairs = n_pairs, q.nw = nw;
-    q.r_cam = (const int*)(base + o_rcam);
-    q.r_pt = (const int*)(base + o_rpt);
-    q.r_found = (const double2*)(base + o_rfound);
-    q.r_sig = (const double*)(base + o_rsig);
+    q.r_base = ba->ms.d;
     q.r_dead = ba->n_dead > 0 ? (const uint8_t*)(base + o_rdead) : nullptr;
     q.pts_raw = (const double*)(base + o_ptsraw);
     q.cnt = (int*)(base + o_cnt);
@@ -969,6 +1052,7 @@ static void launch_k7(ptam_ba* ba, int guard = 0) {
     ptam_ctx* ctx = ba->ctx;
     BaDev d = ba->d;
     d.guard = guard;
+    d.guard_seq = (int)ba->mbox_seq;   // (the trial just enqueued)
     int cur = guard ? (ba->cur ^ 1) : ba->cur;   // a guarded launch belongs to the next step: the trial state is current there
     if ((ba->k7_big && !ba->det) || !ba->use_wave)   // the one row of camera partials every wave adds to (or, without measurements, all there is)
         (void)hipMemsetAsync(d.Upart, 0, std::max<size_t>(1, (size_t)d.F * 27) * sizeof(double), ctx->stream);
@@ -1101,6 +1185,7 @@ static int ba_enqueue_speculative(ptam_ba* ba, double lambda_next, double lambda
     BaDev d = ba->d;
     const double min_s2 = ba->opts.min_sigma * ba->opts.min_sigma;
     d.guard = 1;
+    d.guard_seq = (int)ba->mbox_seq;   // (the trial just enqueued: its finalize kernel writes this number next to its decision)
     hipLaunchKernelGGL(purge_pass1_kernel, dim3(std::max(1, std::min((d.M + 256 * P1_U - 1) / (256 * P1_U), ba_p1_blocks()))), dim3(256), 0, ctx->stream, d);
     hipLaunchKernelGGL(select_compact_kernel, dim3(std::max(1, std::min((d.M + 1023) / 1024, ba_sel_blocks()))), dim3(256), 0, ctx->stream, d,
                        (const double*)d.m_e2, (long long)d.M, (const uint8_t*)d.m_state, 0);
@@ -1192,7 +1277,7 @@ static void ba_finish_outliers(ptam_ba* ba) {
         std::sort(ba->raw_out.begin() + begin, ba->raw_out.begin() + end);
         for (int i = begin; i < end; i++) {
             const int o = ba->raw_out[i];
-            ba->outliers.push_back(std::make_pair(ba->m_pt[o], ba->m_cam[o]));
+            ba->outliers.push_back(std::make_pair(ba->ms.pt((size_t)o), ba->ms.cam((size_t)o)));
             if (!ba->m_dead[o]) ba->n_dead++;
             ba->m_dead[o] = 1;
         }
@@ -1219,7 +1304,7 @@ int ptam_ba_create(ptam_ctx* ctx, const ptam_ba_opts* opts, ptam_ba** out) {
     ARG_TRY(ctx && out);
     ptam_ba* ba = new ptam_ba();
     ba->ctx = ctx;
-    ba->pts.ctx = ba->m_cam.ctx = ba->m_pt.ctx = ba->m_found.ctx = ba->m_sig.ctx = ba->m_dead.ctx = ctx;
+    ba->pts.ctx = ba->ms.ctx = ctx;
     if (opts)
         ba->opts = *opts;
     else
@@ -1247,11 +1332,8 @@ int ptam_ba_destroy(ptam_ba* ba) {
             hipEventDestroy(ba->ev[k][1]);
         }
     ba->pts.release();
-    ba->m_cam.release();
-    ba->m_pt.release();
-    ba->m_found.release();
-    ba->m_sig.release();
-    ba->m_dead.release();
+    ba->ms.release_host();
+    ba->ms.release_dev();
     delete ba;
     return PTAM_OK;
 }
@@ -1279,19 +1361,17 @@ int ptam_ba_add_meas(ptam_ba* ba, int cam, int point, const double found[2], dou
     ARG_TRY(ba && found);
     ARG_TRY(cam >= 0 && cam < (int)ba->cam_fixed.size());
     ARG_TRY(point >= 0 && point < (int)(ba->pts.size() / 3));
-    // (room for all five first: a failed allocation must not leave the arrays at different lengths)
-    if (int rc = ba->m_cam.grow(1)) return rc;
-    if (int rc = ba->m_pt.grow(1)) return rc;
-    if (int rc = ba->m_found.grow(2)) return rc;
-    if (int rc = ba->m_sig.grow(1)) return rc;
-    if (int rc = ba->m_dead.grow(1)) return rc;
-    ba->m_cam.push_back(cam);
-    ba->m_pt.push_back(point);
-    ba->m_found.push_back(found[0]);
-    ba->m_found.push_back(found[1]);
-    ba->m_sig.push_back(sigma_sq);   // (dSqrtInvNoise = sqrt(1 / sigma^2), src/Bundle.cc:91, is formed when the measurements are sorted: prep_rank_kernel)
+    MeasStore& ms = ba->ms;
+    if (int rc = ms.reserve_host((ms.n >> MS_LOG) + 1)) return rc;
+    const size_t i = ms.n;
+    ms.cam(i) = cam;
+    ms.pt(i) = point;
+    ms.found(i) = make_double2(found[0], found[1]);
+    ms.sig(i) = sigma_sq;   // (dSqrtInvNoise = sqrt(1 / sigma^2), src/Bundle.cc:91, is formed when the measurements are sorted: prep_rank_kernel)
+    ms.n++;
     ba->m_dead.push_back(0);
     ba->prepared = false;
+    if ((ms.n & (MS_CH - 1)) == 0) return ms.flush(false);   // a chunk is full: on its way while the caller adds the next
     return PTAM_OK;
 }
 
@@ -1314,18 +1394,22 @@ int ptam_ba_add_measurements(ptam_ba* ba, int n, const int32_t* cam, const int32
         ARG_TRY(point[i] >= 0 && point[i] < n_pts);
     }
     if (n == 0) return PTAM_OK;
-    if (int rc = ba->m_cam.grow((size_t)n)) return rc;
-    if (int rc = ba->m_pt.grow((size_t)n)) return rc;
-    if (int rc = ba->m_found.grow((size_t)2 * n)) return rc;
-    if (int rc = ba->m_sig.grow((size_t)n)) return rc;
-    if (int rc = ba->m_dead.grow((size_t)n)) return rc;
-    ba->m_cam.append(cam, (size_t)n);
-    ba->m_pt.append(point, (size_t)n);
-    ba->m_found.append(found2, (size_t)2 * n);
-    ba->m_sig.append(sigma_sq, (size_t)n);
-    std::memset(ba->m_dead.data() + ba->m_dead.size(), 0, (size_t)n);
-    ba->m_dead.n += (size_t)n;
+    MeasStore& ms = ba->ms;
+    if (int rc = ms.reserve_host(((ms.n + (size_t)n - 1) >> MS_LOG) + 1)) return rc;
+    ba->m_dead.resize(ba->m_dead.size() + (size_t)n, 0);
     ba->prepared = false;
+    // chunk by chunk: a full chunk's upload runs while the next one is being filled
+    for (size_t done = 0; done < (size_t)n;) {
+        const size_t i = ms.n, room = MS_CH - (i & (MS_CH - 1)), k = std::min(room, (size_t)n - done);
+        std::memcpy(&ms.cam(i), cam + done, k * 4);
+        std::memcpy(&ms.pt(i), point + done, k * 4);
+        std::memcpy(&ms.found(i), found2 + 2 * done, k * 16);
+        std::memcpy(&ms.sig(i), sigma_sq + done, k * 8);
+        ms.n += k;
+        done += k;
+        if ((ms.n & (MS_CH - 1)) == 0)
+            if (int rc = ms.flush(false)) return rc;
+    }
     return PTAM_OK;
 }
 
@@ -1419,6 +1503,27 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
             if (forced && d.chain_off == 1) d.chain_off = was;   // (a fault during the call sets 2: that one stays)
         }
     } chain_turn(d, ctx->device);
+    // A REJECTED trial's continuation — the same step again with a larger lambda — does not queue behind the five guarded kernels
+    // that were enqueued for the other outcome (each leaves at once, but a kernel that only reads its guard still costs its launch
+    // and its first memory access: ~4.4 us each, ~22 us of idle chip per rejected trial): it goes to the context's second queue,
+    // which is empty.  Nothing on the queue left behind writes (the guards' sequence word also stops a leftover that is late), the
+    // trial's own kernels were all complete when its finalize kernel published the verdict the host has just read.  The context's
+    // queues are swapped for the rest of this call and put back at its end.
+    struct QueueTurn {
+        ptam_ctx* c;
+        bool flipped = false, ever = false;
+        void flip() {
+            std::swap(c->stream, c->stream_alt);
+            flipped = !flipped;
+            ever = true;
+        }
+        ~QueueTurn() {
+            // (whatever is left on the queue that is not the current one are guarded kernels of trials long decided: wait them out —
+            //  a query in practice — so that none of them outlives the call and meets the block in another bundle's hands)
+            if (ever) (void)ptam_stream_wait(c->stream_alt);
+            if (flipped) std::swap(c->stream, c->stream_alt);
+        }
+    } queue_turn{ctx};
     double lambda = 0.0001, lambda_factor = 2.0;   // :125-126
     ba->converged = false;
     ba->published_by_finalize = false;
@@ -1442,6 +1547,8 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     BaScalars sc;
     std::memset(&sc, 0, sizeof sc);
     double dbg_enq_ms = 0, dbg_wait_ms = 0;   // host time spent enqueueing trials / waiting for their scalars (PTAM_DEBUG_STALL)
+    static const bool dbg_times = getenv("PTAM_DEBUG_TRIAL_TIMES") != nullptr;   // print when each trial's verdict reached the host
+    std::vector<double> trial_read_us;
     const auto dbg_t0 = std::chrono::steady_clock::now();
 #ifdef K7_TIMING
     auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1510,6 +1617,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     // speculative step prologue (ba_enqueue_speculative): single device, not while per-kernel events are being taken
     const bool spec = !sharded && !ba->prof && d.n_chunks > 0 && !ptam_ab_env("PTAM_NO_SPECULATION");
     bool spec_ready = false;   // pass 1 .. V*^-1 of the coming step are already running behind the device-side flag
+    static const bool two_queues = !getenv("PTAM_ONE_QUEUE");   // (operating switch: rejected continuations stay on the one queue)
     while (!empty && !ba->converged && !hit_max && !aborted()) {
         // ---- Do_LM_Step :209-551 ----
         bool skip_vinv = false;
@@ -1606,6 +1714,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
                 continue;
             }
             ran_any = true;
+            if (dbg_times) trial_read_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count());
             if (sharded) abort_all = abort_all || sc.abort_any != 0;
             new_err = sc.new_err;
             const double sumsq = sc.sumsq_cam + sc.sumsq_pt;
@@ -1623,6 +1732,8 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
             if (new_err > cur_err) {   // ModifyLambda_BadStep :607-611
                 lambda = lambda * lambda_factor;
                 lambda_factor = lambda_factor * 2;
+                if (spec && two_queues && ctx->stream_alt && !ba->converged && counter + 1 < ba->opts.max_iterations && !aborted())
+                    queue_turn.flip();   // (the retry starts on the empty queue)
             }
             counter++;
             if (counter >= ba->opts.max_iterations) hit_max = true;   // :518-520
@@ -1658,6 +1769,15 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
         n_steps++;
     }
     BA_DBG("loop done, steps %d", n_steps);
+    if (dbg_times && !trial_read_us.empty()) {
+        // per trial: a(ccepted) / r(ejected) / s(tay: new == old error) and the time since the previous verdict (the first: since the call began)
+        std::fprintf(stderr, "[ptam] trial times (us):");
+        for (size_t i = 0; i < trial_read_us.size() && i < ba->trials.size(); i++) {
+            const ptam_ba_trial& t = ba->trials[i];
+            std::fprintf(stderr, " %c%.1f", t.accepted ? 'a' : (t.err_new > t.err_old ? 'r' : 's'), trial_read_us[i] - (i ? trial_read_us[i - 1] : 0.0));
+        }
+        std::fprintf(stderr, "\n");
+    }
     if (getenv("PTAM_DEBUG_STALL"))
         std::fprintf(stderr, "[ptam] compute loop: %zu trials in %.3f ms; host enqueueing trials %.3f ms, waiting for scalars %.3f ms\n",
                      ba->trials.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0).count(),

@@ -46,6 +46,7 @@ struct DevCam {
 struct ptam_ctx {
     int device;
     hipStream_t stream;
+    hipStream_t stream_alt;   // second queue, created when a bundle's rejected trial first needs it (bundle.hip: QueueTurn)
     ptam_cam_params params;
     DevCam cam;
     int halfsample;
@@ -63,7 +64,7 @@ struct ptam_ctx {
         void* p;
         size_t bytes;
     };
-    Cached dev_cache[4];    // device blocks (a bundle holds two: its main block and its Schur work lists)
+    Cached dev_cache[8];    // device blocks (a bundle holds three: its main block, its Schur work lists, its measurements as they were added)
     Cached host_cache[2];   // host-mapped mailboxes
     Cached pin_cache[12];   // pinned host arrays of released bundles (the measurements as they are added: PinVec, bundle.hip)
     unsigned* d_smap;       // the Schur tile kernel's index maps (schur_index_map_device: a compile-time constant, uploaded once)

@@ -228,6 +228,12 @@ int ptam_ctx_create(const ptam_cam_params* cam, int device, ptam_ctx** out) {
         delete c;
         return PTAM_E_HIP;
     }
+    // (the second queue of a bundle's rejected trials, bundle.hip: created here — creating a queue while kernels are queued elsewhere
+    //  stalls them for milliseconds)
+    if (hipStreamCreateWithFlags(&c->stream_alt, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        c->stream_alt = nullptr;
+    }
     ptam_preload((const void*)project_points_kernel);
     ptam_preload((const void*)reproject_points_kernel);
     trackmap_preload_kernels();
@@ -254,6 +260,7 @@ int ptam_ctx_destroy(ptam_ctx* ctx) {
     for (int i = 0; i < CTX_NCACHE(ctx->pin_cache); i++)
         if (ctx->pin_cache[i].p) hipHostFree(ctx->pin_cache[i].p);
     if (ctx->d_smap) hipFree(ctx->d_smap);
+    if (ctx->stream_alt) hipStreamDestroy(ctx->stream_alt);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return PTAM_OK;
