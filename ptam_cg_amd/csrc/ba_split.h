@@ -60,6 +60,13 @@ __host__ __device__ inline int split_full_products(int F, int a, int b) {
     return a == b ? (ma == 3 ? 7 : (ma == 2 ? 4 : 1)) : ma * mb;
 }
 
+// n / (cost of run i), n >= 0: a list type may bring its own (the device's lists in LDS keep the runs' reciprocals: an integer division
+// is ~45 dependent instructions of the fill's serial chain)
+template <class RUNS, class I>
+__host__ __device__ inline I split_quot(const RUNS& R, int i, I n) {
+    return n / (I)R.run_cost[i];
+}
+
 // The greedy fill: the pairs' entries, one pair after another, into workgroups of whole 4-entry groups such that no workgroup's
 // cost — entries + seg_cost per segment (+ second_lag for list positions >= n_first) — exceeds T.  Returns the workgroups made;
 // emit(k, begin, end, wg) is called for every segment (entries [begin, end) of pair k, relative to the pair's first entry in
@@ -75,6 +82,32 @@ __host__ __device__ inline int split_fill(I T, const RUNS& R, const SplitCfg& c,
         const int n = R.pl_n[k], run1 = R.pl_run0[k + 1];
         int pos = 0, ri = R.pl_run0[k], ro = 0;
         int rc = R.run_cnt[ri], rs = R.run_cost[ri];   // the run `pos` is in
+        if (run1 - ri == 1) {
+            // ONE pattern in this pair's part of the list (every pair of a dense problem): the same decisions with the walks over
+            // the runs folded away — the loop below, executed by one lane per budget, is a serial chain, and its length is the kernel
+            while (pos < n) {
+                const int left = n - pos;
+                const I room = T - (I)(n_out >= c.n_first ? c.second_lag : 0) - cur_cost - (I)c.seg_cost;
+                int take = 0;
+                if (room >= 0) take = (I)left * rs <= room ? left : (int)split_quot(R, ri, room);
+                take = take >= left ? left : take / 4 * 4;
+                if (cur_n > 0 && left > take && (take < c.min_seg || room < (I)c.min_room)) {
+                    n_out++;
+                    if (n_out > limit) return n_out;
+                    cur_n = 0;
+                    cur_cost = 0;
+                    continue;
+                }
+                if (take < c.min_seg) take = c.min_seg;
+                if (left - take < c.min_seg) take = left;
+                if (take > left) take = left;
+                emit(k, pos, pos + take, n_out);
+                cur_n++;
+                cur_cost += (I)take * rs + (I)c.seg_cost;
+                pos += take;
+            }
+            continue;
+        }
         while (pos < n) {
             const int left = n - pos;
             const I room = T - (I)(n_out >= c.n_first ? c.second_lag : 0) - cur_cost - (I)c.seg_cost;
@@ -91,12 +124,12 @@ __host__ __device__ inline int split_fill(I T, const RUNS& R, const SplitCfg& c,
                             take += avail;
                             rem -= (I)avail * cst;
                         } else {
-                            take += (int)(rem / cst);
+                            take += (int)split_quot(R, i, rem);
                             break;
                         }
                     }
                 } else
-                    take = (int)(room / rs);
+                    take = (int)split_quot(R, ri, room);
             }
             take = take >= left ? left : take / 4 * 4;
             // a sliver at the end of a full workgroup — less work than the segment itself would cost: start the next one

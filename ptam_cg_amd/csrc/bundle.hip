@@ -885,6 +885,8 @@ static int ba_prepare_impl(ptam_ba* ba) {
         std::fprintf(stderr, "[ptam] split kernel, list %d (us from its start): lists built %.1f | in LDS %.1f | round 1 done %.1f | search done %.1f | cut written %.1f\n", x,
                      (ps.stamp[x][1] - ps.stamp[x][0]) * 0.01, (ps.stamp[x][2] - ps.stamp[x][0]) * 0.01, (ps.stamp[x][3] - ps.stamp[x][0]) * 0.01,
                      (ps.stamp[x][4] - ps.stamp[x][0]) * 0.01, (ps.stamp[x][5] - ps.stamp[x][0]) * 0.01);
+        std::fprintf(stderr, "[ptam]    the search: %lld shader cycles in %.1f us = %.2f GHz\n", ps.stamp[x][7] - ps.stamp[x][6], (ps.stamp[x][4] - ps.stamp[x][2]) * 0.01,
+                     (double)(ps.stamp[x][7] - ps.stamp[x][6]) / ((ps.stamp[x][4] - ps.stamp[x][2]) * 10.0));
     }
 #endif
     if (getenv("PTAM_DEBUG_SCHUR")) {
