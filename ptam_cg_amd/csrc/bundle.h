@@ -21,6 +21,8 @@
 //            (src/Bundle.cc:451-453 mirrors it) and outside the band S is zero, so neither is stored,
 //            factored or exchanged.  L (same layout) + Dg (npad) hold the LDL^T factor.
 #pragma once
+#include <cstddef>
+
 #include "common.h"
 
 enum { MS_ALIVE = 0, MS_BAD = 1, MS_DEAD = 2 };
@@ -66,15 +68,18 @@ struct BaScalars {
     int sel_bin2;           // sharded select: second-level bin (-1: clamped first-level bin, all candidates count)
     int sel_k2;             //                 residual rank inside it
     int select_overflow;    //                 a rank had more last-stage candidates than its exchange slot holds
+    int abort_any;          // sharded: some rank's abort flag was up when this trial was enqueued (summed with the trial's scalars)
+    int solve_fault;        // the persistent factorisation gave up waiting for one of its workgroups (ldlt_chain.inc): the solve is void
+    // the device-side decision the speculatively enqueued kernels wait for: FOUR words 16-byte aligned, read as one scalar load
+    // (ba_guard_blocks: a second dependent load in a kernel's guard is ~2 us, and five guarded kernels follow every trial)
     int end_step;           // after a trial: the LM step is over (accepted, converged or out of trials)
     int spec_go;            //                and the next step will run with the trial state as current
     int spec_stay;          //                or: the step is over WITHOUT an accepted trial (new == current error) and the
                             //                next one starts from the unchanged state with the unchanged lambda
-    int abort_any;          // sharded: some rank's abort flag was up when this trial was enqueued (summed with the trial's scalars)
-    int solve_fault;        // the persistent factorisation gave up waiting for one of its workgroups (ldlt_chain.inc): the solve is void
-    int spec_seq;           // which trial's decision end_step / spec_go / spec_stay are (its mailbox sequence number): a guarded kernel enqueued
-                            // behind another trial — a leftover on the queue a rejected trial's continuation has left — does nothing
+    int spec_seq;           // which trial's decision these are (its mailbox sequence number): a guarded kernel enqueued behind another
+                            // trial — a leftover on the queue a rejected trial's continuation has left — does nothing
 };
+static_assert(offsetof(BaScalars, end_step) % 16 == 0 && sizeof(BaScalars) % 8 == 0, "BaScalars: the decision words are read as one 16-byte load");
 
 struct BaDev {
     int C, F, P, M;
