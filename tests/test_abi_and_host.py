@@ -144,3 +144,28 @@ def test_schur_index_map_is_the_inverse_of_the_row_mapping(built, variant):
     used = got[got != 0xFFFF]
     assert len(set(used.tolist())) == len(used) and used.max() < 39 * 64
     assert built.ptam_ba_schur_index_map(6, out, 2352) < 0 and built.ptam_ba_schur_index_map(0, out, 100) < 0
+
+
+def test_persistent_solve_keeps_its_in_flight_registers_out_of_scratch():
+    """ldlt_chain.inc requests tiles with inline-asm loads whose destination registers the compiler believes valid at
+    once (ch_ld2_issue / ch_ld2_wait).  That holds as long as nothing moves those registers between request and wait — which a
+    spill would.  The persistent solve's kernels must therefore use no scratch at all: checked on the compiler's own summary."""
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this host")
+    src = os.path.join(ROOT, "ptam_cg_amd", "csrc", "solve.hip")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "solve.s")
+        subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-S", "--cuda-device-only", "-o", out, src],
+                              stderr=subprocess.DEVNULL)
+        txt = open(out).read()
+    seen = 0
+    for m in re.finditer(r"\.amdhsa_kernel (\S*ldlt_chain\S*)(.*?)\.end_amdhsa_kernel", txt, re.S):
+        seen += 1
+        body = m.group(2)
+        size = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body)
+        assert size and int(size.group(1)) == 0, (m.group(1), size and size.group(1))
+    assert seen >= 1
