@@ -563,7 +563,9 @@ int ptam_ba_solve_fallbacks(const ptam_ba* ba);
 int ptam_ba_duplicates_refused(const ptam_ba* ba);
 /* Operating switches of the camera solve, read from the environment once per process: PTAM_LDLT_NO_CHAIN=1 uses the
  * launch-per-block-column form everywhere (a device shared between processes that all adjust bundles); PTAM_CH_SPIN_LIMIT=<n> is
- * the number of looks (~1 us each, default 2^18) a workgroup of the persistent form takes before it gives up a wait. */
+ * the number of looks (~1 us each, default 2^18) a workgroup of the persistent form takes before it gives up a wait.
+ * PTAM_ONE_QUEUE=1 keeps a rejected trial's continuation on the context's one queue (by default it goes to the context's second
+ * queue, which is empty, instead of behind the kernels that were enqueued for the other outcome: ~6 us per rejected trial). */
 
 /* profiling hooks used by bench.py: HIP-event timing of individual kernels on the ctx stream. */
 enum {

@@ -337,3 +337,69 @@ def test_duplicate_measurement_is_refused_with_its_point_and_camera(hip):
     assert ba.duplicates_refused() == 2   # (both twins count; 0 for an accepted bundle)
     ba.close()
     ctx.close()
+
+
+def test_measurements_added_between_two_computes_and_exact_chunk_sizes(hip, oracle, split_ref):
+    """The measurements go to the device in chunks of 32 768 while they are added (MeasStore): a bundle of exactly one chunk, one
+    of a chunk + 1, and a bundle that is adjusted, given MORE measurements (the partial chunk goes up again) and adjusted again —
+    lists against the numpy restatement, results against the checker driven the same way."""
+    from tests import util
+    for n_meas in (32768, 32769):
+        prob = synth.make_ba_problem(n_cams=30, n_pts=1400, seed=21)
+        assert len(prob["cam_idx"]) > n_meas
+        for k in ("cam_idx", "pt_idx", "found", "sigma_sq"):
+            prob[k] = prob[k][:n_meas]
+        ctx = host.Context(lib=hip)
+        ba = synth.load_into(host.Bundle(ctx), prob)
+        ba.prepare()
+        check_lists(ba, prob, np.zeros(n_meas, bool), split_ref)
+        ba.close()
+        ctx.close()
+    prob = synth.make_ba_problem(n_cams=16, n_pts=900, seed=22)
+    half = len(prob["cam_idx"]) // 2
+    res = []
+    for lib in (hip, oracle):
+        ctx = host.Context(lib=lib)
+        ba = host.Bundle(ctx, max_iterations=4)
+        ba.add_problem(prob["poses"], prob["fixed"], prob["points"], prob["cam_idx"][:half], prob["pt_idx"][:half], prob["found"][:half],
+                       prob["sigma_sq"][:half])
+        ba.Compute()
+        first = ba.trials().copy()
+        c = ctx._check
+        n2 = len(prob["cam_idx"]) - half
+        c(lib.ba_add_measurements(ba.h, n2, host._ptr(np.ascontiguousarray(prob["cam_idx"][half:])), host._ptr(np.ascontiguousarray(prob["pt_idx"][half:])),
+                                  host._ptr(np.ascontiguousarray(prob["found"][half:])), host._ptr(np.ascontiguousarray(prob["sigma_sq"][half:]))), "add")
+        ba.Compute()
+        poses, pts = ba.get_all()
+        res.append({"accepted": 0, "converged": ba.Converged(), "trials": np.concatenate([first, ba.trials()]), "poses": poses, "points": pts,
+                    "outliers": ba.GetOutlierMeasurements()})
+        ba.close()
+        ctx.close()
+    util.assert_ba_equal(res[0], res[1], rel=1e-6)
+
+
+@pytest.mark.parametrize("what", ["no_measurements", "all_cameras_fixed", "one_measurement", "every_measurement_erased_point"])
+def test_degenerate_bundles_prepare_and_compute(hip, oracle, what):
+    from tests import util
+    prob = synth.make_ba_problem(n_cams=5, n_pts=40, seed=23)
+    if what == "no_measurements":
+        for k in ("cam_idx", "pt_idx", "found", "sigma_sq"):
+            prob[k] = prob[k][:0]
+    elif what == "all_cameras_fixed":
+        prob["fixed"] = np.ones(5, np.uint8)
+    elif what == "one_measurement":
+        for k in ("cam_idx", "pt_idx", "found", "sigma_sq"):
+            prob[k] = prob[k][7:8]
+    else:   # most points unobserved, the observed ones in the middle of the id range
+        keep = (prob["pt_idx"] >= 17) & (prob["pt_idx"] < 21)
+        for k in ("cam_idx", "pt_idx", "found", "sigma_sq"):
+            prob[k] = prob[k][keep]
+    rh = util.run_ba(hip, prob, max_iterations=5)
+    if what == "no_measurements":
+        # (the reference asserts in FindSigmaSquared on an empty error vector, include/MEstimator.h, and so does the checker: here the
+        #  call returns at once with nothing adjusted)
+        assert len(rh["trials"]) == 0 and rh["accepted"] == 0 and len(rh["outliers"]) == 0
+        assert np.array_equal(rh["poses"], np.asarray(prob["poses"]).reshape(-1, 12)) and np.array_equal(rh["points"], prob["points"])
+        return
+    ro = util.run_ba(oracle, prob, max_iterations=5)
+    util.assert_ba_equal(rh, ro, rel=1e-6)
