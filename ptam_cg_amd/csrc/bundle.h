@@ -68,8 +68,10 @@ struct BaScalars {
     int sel_bin2;           // sharded select: second-level bin (-1: clamped first-level bin, all candidates count)
     int sel_k2;             //                 residual rank inside it
     int select_overflow;    //                 a rank had more last-stage candidates than its exchange slot holds
-    int abort_any;          // sharded: some rank's abort flag was up when this trial was enqueued (summed with the trial's scalars)
-    int solve_fault;        // the persistent factorisation gave up waiting for one of its workgroups (ldlt_chain.inc): the solve is void
+    int n_outliers_pub;     // n_outliers as the last select found it — behind every purge, never while one is running: what the host reads
+                            // as "the outlier list's length when the previous step closed" from a trial whose decision and whose step-closing
+                            // purge are ONE launch (purge_pass1_decide_kernel)
+    int pad_;
     // the device-side decision the speculatively enqueued kernels wait for: FOUR words 16-byte aligned, read as one scalar load
     // (ba_guard_blocks: a second dependent load in a kernel's guard is ~2 us, and five guarded kernels follow every trial)
     int end_step;           // after a trial: the LM step is over (accepted, converged or out of trials)
@@ -78,6 +80,8 @@ struct BaScalars {
                             //                next one starts from the unchanged state with the unchanged lambda
     int spec_seq;           // which trial's decision these are (its mailbox sequence number): a guarded kernel enqueued behind another
                             // trial — a leftover on the queue a rejected trial's continuation has left — does nothing
+    int abort_any;          // sharded: some rank's abort flag was up when this trial was enqueued (summed with the trial's scalars)
+    int solve_fault;        // the persistent factorisation gave up waiting for one of its workgroups (ldlt_chain.inc): the solve is void
 };
 static_assert(offsetof(BaScalars, end_step) % 16 == 0 && sizeof(BaScalars) % 8 == 0, "BaScalars: the decision words are read as one 16-byte load");
 

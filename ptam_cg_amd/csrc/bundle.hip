@@ -233,6 +233,8 @@ struct ptam_ba {
     Mailbox* mbox_dev = nullptr;   // device address of the same memory
     unsigned long long mbox_seq = 0;
     bool published_by_finalize = false;
+    bool decide_pending = false;     // the trial's decision is left to the first launch of the speculative prologue (purge_pass1_decide_kernel)
+    int decide_last_allowed = 0;
     bool trial_is_current = false;   // the last trial was accepted: its new-error pass == pass 1 of the next step
     int k7_threads = BA_CHUNK;
     bool k7_loop = false;
@@ -1109,7 +1111,7 @@ static int ba_ensure_mailbox(ptam_ba* ba) {
     return PTAM_OK;
 }
 
-static int ba_trial(ptam_ba* ba, double lambda, bool skip_vinv, int last_allowed, int abort_local) {
+static int ba_trial(ptam_ba* ba, double lambda, bool skip_vinv, int last_allowed, int abort_local, bool decide_in_prologue = false) {
     ptam_ctx* ctx = ba->ctx;
     BaDev& d = ba->d;
     prof_begin(ba, PTAM_K_VINV);
@@ -1157,8 +1159,13 @@ static int ba_trial(ptam_ba* ba, double lambda, bool skip_vinv, int last_allowed
             seq = ++ba->mbox_seq;
             ba->published_by_finalize = true;
         }
-        hipLaunchKernelGGL(finalize_new_kernel, dim3(1), dim3(256), 0, ctx->stream, d, ba->opts.update_sq_conv_limit, last_allowed,
-                           slots, seq);
+        // (with the next step's prologue enqueued behind every trial, the decision is the first thing ITS first launch works out:
+        //  purge_pass1_decide_kernel, ba_enqueue_speculative — one dependent launch less per trial)
+        ba->decide_pending = decide_in_prologue;
+        ba->decide_last_allowed = last_allowed;
+        if (!decide_in_prologue)
+            hipLaunchKernelGGL(finalize_new_kernel, dim3(1), dim3(256), 0, ctx->stream, d, ba->opts.update_sq_conv_limit, last_allowed,
+                               slots, seq);
     }
     prof_end(ba, PTAM_K_UPDATE);
     HIP_TRY(hipGetLastError());
@@ -1187,8 +1194,14 @@ static int ba_enqueue_speculative(ptam_ba* ba, double lambda_next, double lambda
     BaDev d = ba->d;
     const double min_s2 = ba->opts.min_sigma * ba->opts.min_sigma;
     d.guard = 1;
-    d.guard_seq = (int)ba->mbox_seq;   // (the trial just enqueued: its finalize kernel writes this number next to its decision)
-    hipLaunchKernelGGL(purge_pass1_kernel, dim3(std::max(1, std::min((d.M + 256 * P1_U - 1) / (256 * P1_U), ba_p1_blocks()))), dim3(256), 0, ctx->stream, d);
+    d.guard_seq = (int)ba->mbox_seq;   // (the trial just enqueued: its decision carries this number)
+    const dim3 g_p1(std::max(1, std::min((d.M + 256 * P1_U - 1) / (256 * P1_U), ba_p1_blocks())));
+    if (ba->decide_pending) {
+        hipLaunchKernelGGL(purge_pass1_decide_kernel, g_p1, dim3(256), 0, ctx->stream, d, ba->opts.update_sq_conv_limit, ba->decide_last_allowed,
+                           (ulonglong2*)ba->mbox_dev, ba->mbox_seq);
+        ba->decide_pending = false;
+    } else
+        hipLaunchKernelGGL(purge_pass1_kernel, g_p1, dim3(256), 0, ctx->stream, d);
     hipLaunchKernelGGL(select_compact_kernel, dim3(std::max(1, std::min((d.M + 1023) / 1024, ba_sel_blocks()))), dim3(256), 0, ctx->stream, d,
                        (const double*)d.m_e2, (long long)d.M, (const uint8_t*)d.m_state, 0);
     hipLaunchKernelGGL(select_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, d, ba->opts.estimator, min_s2);
@@ -1620,6 +1633,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     const bool spec = !sharded && !ba->prof && d.n_chunks > 0 && !ptam_ab_env("PTAM_NO_SPECULATION");
     bool spec_ready = false;   // pass 1 .. V*^-1 of the coming step are already running behind the device-side flag
     static const bool two_queues = !getenv("PTAM_ONE_QUEUE");   // (operating switch: rejected continuations stay on the one queue)
+    const bool fused_decision = !ptam_ab_env("PTAM_SEPARATE_FINALIZE");   // (A/B: the decision as a launch of its own, rounds 2-5)
     while (!empty && !ba->converged && !hit_max && !aborted()) {
         // ---- Do_LM_Step :209-551 ----
         bool skip_vinv = false;
@@ -1641,7 +1655,7 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
             if (ba->converged || hit_max || aborted()) break;
             BA_DBG("trial %d lambda %g", counter, lambda);
             const auto q0 = std::chrono::steady_clock::now();
-            rc = ba_trial(ba, lambda, skip_vinv, counter + 1 >= ba->opts.max_iterations ? 1 : 0, abort_local() ? 1 : 0);
+            rc = ba_trial(ba, lambda, skip_vinv, counter + 1 >= ba->opts.max_iterations ? 1 : 0, abort_local() ? 1 : 0, spec && fused_decision);
             {
                 const double qms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - q0).count();
                 dbg_enq_ms += qms;
@@ -1674,7 +1688,9 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
             if (!have_cur) {
                 // (every step runs at least one trial: this first read of step s also carries the outlier-list
                 //  length left by the purge that closed step s-1 — no separate read-back for it)
-                if (prev_end_pending) step_outlier_end.push_back(sc.n_outliers);
+                // (n_outliers_pub: the list's length as the last select found it — with the decision inside the step-closing launch the
+                //  live counter may already hold part of THIS trial's purge)
+                if (prev_end_pending) step_outlier_end.push_back(spec && fused_decision ? sc.n_outliers_pub : sc.n_outliers);
                 prev_end_pending = false;
                 if (sc.select_overflow && !ba->slow_select) {
                     // sharded select: a rank's exchange slot overflowed (thousands of bit-identical errors), so this
@@ -2143,6 +2159,7 @@ void ba_preload_kernels() {
     ptam_preload((const void*)pass1_from_trial_kernel);
     ptam_preload((const void*)pass1_keep_kernel);
     ptam_preload((const void*)purge_pass1_kernel);
+    ptam_preload((const void*)purge_pass1_decide_kernel);
     ptam_preload((const void*)hist_keys_kernel);
     ptam_preload((const void*)select_compact_kernel);
     ptam_preload((const void*)select_final_kernel);
