@@ -17,18 +17,23 @@ struct SplitCfg {
     int n_first;      // list positions >= n_first are second workgroups of their CUs
     int cost_model;   // load term of an entry's cost (0: every entry costs 1)
     int slots;        // workgroups one XCD holds at once
+    int greedy;       // 1: the greedy fill + budget search of round 6's first form (measurement build only); 0: the even split
 };
 
 // one XCD's list: pairs k = 0..np-1 (the non-empty ones, in list order), pair k's runs are [pl_run0[k], pl_run0[k + 1]).
 // P: the pointer type of the arrays (the device kernel keeps them in LDS and says so in the type: a fill is a serial chain of
 // dependent reads, and through generic pointers each was a FLAT load of several hundred cycles).
-template <class P>
+template <class P, class P64 = const long long*>
 struct SplitRunsT {
     P run_cnt;
     P run_cost;
     P pl_run0;   // [np + 1]
     P pl_n;      // entries of the pair
     int np;
+    // the even split's prefixes over the pairs: entries before pair k (pl_e[np]: all of them), and H at the pair's start — the model
+    // cost of the pairs before it + one segment cost per pair start before it
+    P pl_e;      // [np + 1]
+    P64 pl_h;    // [np + 1]
 };
 typedef SplitRunsT<const int*> SplitRuns;
 
@@ -199,4 +204,123 @@ __host__ __device__ inline void split_bracket_step(SplitBracket& b, int jmin) {
     b.lo = nlo;
     b.hi = nhi;
     if (b.hi - b.lo <= b.hi / 200 + 1) b.done = 1;   // 0.5 %: one round of 256 budgets over a bracket of 0.7 means
+}
+
+
+// ---- the even split ---------------------------------------------------------------------------------------------------------------
+// No walk, no search: along the list, H(e) = model cost of the entries before e + one segment cost per pair start before e grows
+// monotonically; a workgroup that starts at e and ends at e' costs H(e') - H(e) + one more segment (its own first one — charged
+// twice where it starts exactly at a pair's start: such a workgroup is given a little less than it could take).  With n workgroups
+// of which those at list positions >= n_first are given second_lag less, the budget that makes the parts add up is
+//   T = ceil((H_total + n seg + lag (n - n_first)+) / n),
+// workgroup w starts where H reaches  w (T - seg) - lag (w - n_first)+ , rounded down to a whole 4-entry group of its pair and
+// snapped to the pair's start / the next pair's start where less than min_seg entries would be left on either side.  Every start is
+// a closed form of w: the device computes them one per lane, the host one after the other — the same integers.
+struct SplitEven {
+    long long T;
+    int n_wg;
+    int lag;   // second_lag, or 0 where the list is too light for it (a second workgroup's budget must stay positive)
+};
+__host__ __device__ inline SplitEven split_even_budget(long long h_total, long long ent_x, const SplitCfg& c) {
+    long long n_max = ent_x / (4 * c.min_seg);
+    if (n_max > c.slots) n_max = c.slots;
+    if (n_max < 1) n_max = 1;
+    SplitEven best;
+    best.T = -1;
+    best.n_wg = 0;
+    best.lag = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        const long long n = pass == 0 ? n_max : c.n_first;
+        if (pass == 1 && n_max <= c.n_first) break;   // (one workgroup per CU is a different cut only where both slots would be used)
+        const long long n2 = n > c.n_first ? n - c.n_first : 0;
+        long long lag = c.second_lag;
+        long long T = (h_total + (long long)c.seg_cost * n + lag * n2 + n - 1) / n;
+        if (T - c.seg_cost - lag < (long long)c.min_seg) {   // too light a list for the lag
+            lag = 0;
+            T = (h_total + (long long)c.seg_cost * n + n - 1) / n;
+        }
+        if (best.T < 0 || T < best.T) {
+            best.T = T;
+            best.n_wg = (int)n;
+            best.lag = (int)lag;
+        }
+    }
+    return best;
+}
+// where workgroup w starts: entry position in the list (0 .. all entries); *k_out / *o_out: its pair and the offset inside it
+template <class RUNS>
+__host__ __device__ inline int split_even_start(int w, const SplitEven& e, const RUNS& R, const SplitCfg& c, int* k_out, int* o_out) {
+    if (w == 0) {
+        *k_out = 0;
+        *o_out = 0;
+        return 0;
+    }
+    const long long cw = (long long)w * (e.T - c.seg_cost) - (long long)e.lag * (w > c.n_first ? w - c.n_first : 0);
+    int lo = 0, hi = R.np - 1;   // the last pair whose start H has reached
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (R.pl_h[mid] <= cw)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    int k = lo, o = 0;
+    long long r = cw - R.pl_h[k] - c.seg_cost;   // what is left for the pair's entries behind its own segment cost
+    if (r > 0)
+        for (int i = R.pl_run0[k]; i < R.pl_run0[k + 1]; i++) {
+            const int cnt = R.run_cnt[i], cst = R.run_cost[i];
+            if ((long long)cnt * cst <= r) {
+                o += cnt;
+                r -= (long long)cnt * cst;
+            } else {
+                o += (int)(r / cst);
+                break;
+            }
+        }
+    o = o / 4 * 4;
+    if (o < c.min_seg) o = 0;
+    if (R.pl_n[k] - o < c.min_seg) {
+        k++;
+        o = 0;
+    }
+    *k_out = k;
+    *o_out = o;
+    return R.pl_e[k] + o;   // (k == np: the list's end — an empty workgroup)
+}
+// The host's form of the cut (the device builds the same segments from ranks, ba_prepare.inc: prep_split_even): emit(k, begin, end,
+// wg) per segment in list order; returns the workgroups made.
+template <class RUNS, class Emit>
+inline int split_even_cut(const SplitEven& e, const RUNS& R, const SplitCfg& c, Emit&& emit) {
+    const int ent = R.pl_e[R.np];
+    int wg = -1, next_w = 0, n_wgs = 0;
+    int next_start = 0;   // where the next workgroup that starts something begins
+    auto advance = [&](int from_w) {   // the first w >= from_w whose start lies behind the current one
+        int w = from_w, k, o;
+        int cur = next_start;
+        for (; w < e.n_wg; w++) {
+            const int g = split_even_start(w, e, R, c, &k, &o);
+            if (w == 0 || g > cur) {
+                next_start = g;
+                return w;
+            }
+        }
+        next_start = ent;
+        return e.n_wg;
+    };
+    next_w = advance(0);
+    for (int k = 0; k < R.np; k++) {
+        int pos = R.pl_e[k];
+        const int end_k = R.pl_e[k + 1];
+        while (pos < end_k) {
+            if (next_w < e.n_wg && next_start == pos) {   // a workgroup starts here
+                wg++;
+                n_wgs++;
+                next_w = advance(next_w + 1);
+            }
+            const int stop = next_w < e.n_wg && next_start < end_k ? next_start : end_k;
+            emit(k, pos - R.pl_e[k], stop - R.pl_e[k], wg);
+            pos = stop;
+        }
+    }
+    return n_wgs;
 }

@@ -391,6 +391,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
     if (const char* e = ptam_ab_env("PTAM_SCHUR_COST")) cfg.cost_model = atoi(e);   // A/B runs
     if (const char* e = ptam_ab_env("PTAM_SCHUR_SEGCOST")) cfg.seg_cost = atoi(e);
     if (const char* e = ptam_ab_env("PTAM_SCHUR_LAG")) cfg.second_lag = atoi(e);
+    cfg.greedy = ptam_ab_env("PTAM_SPLIT_GREEDY") ? 1 : 0;   // (A/B: the greedy fill + budget search, this round's first form)
     cfg.min_room = cfg.seg_cost;   // a workgroup begins another segment only for at least this much work
     if (const char* e = ptam_ab_env("PTAM_SCHUR_MINROOM")) cfg.min_room = atoi(e);
     // Order of the pairs in an XCD's list, both candidates (the device picks: by products only where both slots of the CUs are
@@ -802,13 +803,15 @@ static int ba_prepare_impl(ptam_ba* ba) {
         const size_t o_runcnt = sv.take((size_t)8 * 16 * cap_pl * 4), o_runcost = sv.take((size_t)8 * 16 * cap_pl * 4),
                      o_plpair = sv.take((size_t)8 * cap_pl * 4), o_pln = sv.take((size_t)8 * cap_pl * 4),
                      o_plrun0 = sv.take((size_t)8 * (cap_pl + 1) * 4), o_ple0 = sv.take((size_t)8 * cap_pl * 4),
+                     o_ple = sv.take((size_t)8 * (cap_pl + 1) * 4), o_plh = sv.take((size_t)8 * (cap_pl + 1) * 8),
                      o_cutpair = sv.take((size_t)8 * cap_cut * 4), o_cute0 = sv.take((size_t)8 * cap_cut * 4),
                      o_cute1 = sv.take((size_t)8 * cap_cut * 4), o_cutwg = sv.take((size_t)8 * cap_cut * 4),
                      o_wgfirst = sv.take((size_t)8 * (cfg.slots + 1) * 4), o_pairfirst = sv.take((size_t)n_pairs * 8 * 4),
                      o_wsegtmp = sv.take(((size_t)nb_max + 1) * 4);
         // every lane of the budget search keeps the cut its budget makes, unless that would be more than 64 MB
         const size_t rec_bytes = (size_t)8 * 512 * cap_cut * sizeof(int4);
-        const size_t o_rec = rec_bytes <= ((size_t)64 << 20) ? sv.take(rec_bytes) : 0;
+        const bool with_rec = cfg.greedy && rec_bytes <= ((size_t)64 << 20);   // (the greedy form's lanes only)
+        const size_t o_rec = with_rec ? sv.take(rec_bytes) : 0;
         ba->sblock_bytes = sv.off;
         if (!ctx_cache_take(ctx->dev_cache, CTX_NCACHE(ctx->dev_cache), ba->sblock_bytes, &ba->sblock, &ba->sblock_cap)) {
             HIP_TRY(hipMalloc(&ba->sblock, ba->sblock_bytes));
@@ -830,6 +833,8 @@ static int ba_prepare_impl(ptam_ba* ba) {
         q.pl_n = (int*)(sb + o_pln);
         q.pl_run0 = (int*)(sb + o_plrun0);
         q.pl_e0 = (int*)(sb + o_ple0);
+        q.pl_e = (int*)(sb + o_ple);
+        q.pl_h = (long long*)(sb + o_plh);
         q.cut_pair = (int*)(sb + o_cutpair);
         q.cut_e0 = (int*)(sb + o_cute0);
         q.cut_e1 = (int*)(sb + o_cute1);
@@ -837,7 +842,7 @@ static int ba_prepare_impl(ptam_ba* ba) {
         q.wg_first = (int*)(sb + o_wgfirst);
         q.pair_first = (int*)(sb + o_pairfirst);
         q.wseg_tmp = (int*)(sb + o_wsegtmp);
-        q.rec = rec_bytes <= ((size_t)64 << 20) ? (int4*)(sb + o_rec) : nullptr;
+        q.rec = with_rec ? (int4*)(sb + o_rec) : nullptr;
         hipLaunchKernelGGL(prep_split_kernel, dim3(8), dim3(512), 0, ctx->stream, q, cfg);
         hipLaunchKernelGGL(prep_entries_kernel, dim3(n_pairs, 8), dim3(256), 0, ctx->stream, q, d, cfg.cost_model);
         hipLaunchKernelGGL(prep_finish_kernel, dim3(1), dim3(1024), 0, ctx->stream, q, d, cfg.slots);

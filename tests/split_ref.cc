@@ -21,14 +21,32 @@ static long long smallest_budget(const SplitRuns& R, const SplitCfg& c, long lon
 }
 
 extern "C" {
-// cfg7: seg_cost, second_lag, min_room, min_seg, n_first, cost_model, slots.  Returns the number of segments (cuts) written —
-// each (k, begin, end, wg) — or -1 if `cap` is too small; *n_wgs_out, *t_cut_out as the device publishes them.
+// cfg8: seg_cost, second_lag, min_room, min_seg, n_first, cost_model, slots, greedy.  pl_e / pl_h: the pairs' entry and H prefixes
+// (ba_split.h: the even split).  Returns the number of segments (cuts) written — each (k, begin, end, wg) — or -1 if `cap` is too
+// small; *n_wgs_out, *t_cut_out as the device publishes them.
 int split_ref_list(const int* run_cnt, const int* run_cost, const int* pl_run0, const int* pl_n, int np, long long cost_x,
-                   long long ent_x, const int* cfg7, int* cuts4, int cap, int* n_wgs_out, long long* t_cut_out) {
+                   long long ent_x, const int* cfg8, int* cuts4, int cap, int* n_wgs_out, long long* t_cut_out, const int* pl_e,
+                   const long long* pl_h) {
     SplitCfg c;
-    c.seg_cost = cfg7[0], c.second_lag = cfg7[1], c.min_room = cfg7[2], c.min_seg = cfg7[3], c.n_first = cfg7[4], c.cost_model = cfg7[5],
-    c.slots = cfg7[6];
-    SplitRuns R{run_cnt, run_cost, pl_run0, pl_n, np};
+    c.seg_cost = cfg8[0], c.second_lag = cfg8[1], c.min_room = cfg8[2], c.min_seg = cfg8[3], c.n_first = cfg8[4], c.cost_model = cfg8[5],
+    c.slots = cfg8[6], c.greedy = cfg8[7];
+    SplitRuns R{run_cnt, run_cost, pl_run0, pl_n, np, pl_e, pl_h};
+    if (!c.greedy) {
+        const SplitEven ev = split_even_budget(pl_h[np], ent_x, c);
+        int n = 0;
+        bool over = false;
+        const int n_wgs = split_even_cut(ev, R, c, [&](int k, int b, int e, int wg) {
+            if (n >= cap) {
+                over = true;
+                return;
+            }
+            cuts4[4 * n] = k, cuts4[4 * n + 1] = b, cuts4[4 * n + 2] = e, cuts4[4 * n + 3] = wg;
+            n++;
+        });
+        *n_wgs_out = n_wgs;
+        *t_cut_out = ev.T;
+        return over ? -1 : n;
+    }
     long long n_wg_max = ent_x / (4 * c.min_seg);
     if (n_wg_max > c.slots) n_wg_max = c.slots;
     if (n_wg_max < 1) n_wg_max = 1;

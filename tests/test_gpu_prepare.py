@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 (BL_COUNTS, BL_ROWPTR, BL_M_CAM, BL_M_PT, BL_M_ORIG, BL_M_FIDX, BL_M_FOUND, BL_M_S, BL_PT_ORIG, BL_POINTS, BL_CHUNKS, BL_S_ENTRIES,
  BL_S_SEGS, BL_S_WG_SEG, BL_S_PAIR_BEGIN, BL_S_WG_HEAD, BL_CAM_PTR, BL_CAM_MEAS) = range(18)
 SOLVE_NB, BA_CHUNK, TC, DET_TILE = 32, 256, 8, 1024
-CFG = dict(seg_cost=4900, second_lag=7000, min_room=4900, min_seg=16, n_first=32, cost_model=36, slots=64)
+CFG = dict(seg_cost=4900, second_lag=7000, min_room=4900, min_seg=16, n_first=32, cost_model=36, slots=64, greedy=0)
 
 
 @pytest.fixture(scope="module")
@@ -137,7 +137,7 @@ def expected_lists(prob, dead, split_ref):
     E["s_entries"] = np.column_stack([ent[:, 0], ent[:, 4], ent[:, 5], ent[:, 3] | (ent[:, 2] << 16), ent[:, 6], ent[:, 7], ent[:, 8],
                                       ent[:, 9]]).astype(np.uint32).view(np.int32)
     # the split, per XCD list
-    cfg7 = np.array([CFG[k] for k in ("seg_cost", "second_lag", "min_room", "min_seg", "n_first", "cost_model", "slots")], np.int32)
+    cfg8 = np.array([CFG[k] for k in ("seg_cost", "second_lag", "min_room", "min_seg", "n_first", "cost_model", "slots", "greedy")], np.int32)
     cuts_x, n_wgs_x = [], []
     for x in range(8):
         sel = np.flatnonzero(x_of == x)
@@ -166,11 +166,14 @@ def expected_lists(prob, dead, split_ref):
             i = j
         pl_run0.append(len(run_cnt))
         run_cnt, run_cost, pl_run0, pl_n = (np.array(v, np.int32) for v in (run_cnt, run_cost, pl_run0, pl_n))
+        pcost = np.array([int((run_cnt[pl_run0[k]:pl_run0[k + 1]].astype(np.int64) * run_cost[pl_run0[k]:pl_run0[k + 1]]).sum()) for k in range(len(pl_n))], np.int64)
+        pl_e = np.concatenate([[0], np.cumsum(pl_n)]).astype(np.int32)
+        pl_h = np.concatenate([[0], np.cumsum(pcost + CFG["seg_cost"])]).astype(np.int64)
         cap = 4 * (CFG["slots"] + len(pl_n) + 8)
         cuts = np.zeros(cap * 4, np.int32)
         n_wgs, t_cut = C.c_int(), C.c_longlong()
         n = split_ref.split_ref_list(_ip(run_cnt), _ip(run_cost), _ip(pl_run0), _ip(pl_n), len(pl_n), C.c_longlong(int(ex[:, 3].sum())),
-                                     C.c_longlong(len(ex)), _ip(cfg7), _ip(cuts), cap, C.byref(n_wgs), C.byref(t_cut))
+                                     C.c_longlong(len(ex)), _ip(cfg8), _ip(cuts), cap, C.byref(n_wgs), C.byref(t_cut), _ip(pl_e), _ip(pl_h))
         assert n >= 0
         cuts_x.append([(pl_pair[k], pl_e0[k] + b, pl_e0[k] + e, wg) for k, b, e, wg in cuts[:4 * n].reshape(-1, 4)])
         n_wgs_x.append(n_wgs.value)
