@@ -961,7 +961,10 @@ def test_fuzz_slice_within_tolerance_or_as_close_to_the_referee_as_the_checker(h
         prob = synth.make_ba_problem(**case)
         if len(prob["cam_idx"]) == 0:
             continue
-        a = util.run_ba(hip, prob, estimator=est, max_iterations=mi)
+        # (fixed-order camera sums: the product's trajectory on these ill-conditioned shapes is then the same in every run of the
+        #  suite — with the default LDS atomics a case at the noise floor may leave the referee's trajectory a trial earlier in one
+        #  run than in the next)
+        a = util.run_ba(hip, prob, estimator=est, max_iterations=mi, deterministic=1)
         b = util.run_ba(oracle, prob, estimator=est, max_iterations=mi)
         try:
             util.assert_ba_equal(a, b, rel=1e-6)
