@@ -1872,6 +1872,13 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
 #ifdef K7_TIMING
     std::printf("HOST Compute: first trial read at %.1f us, loop end %.1f us, total %.1f us (%zu trials)\n", ht_first - ht0, ht_loop - ht0,
                 now_us() - ht0, ba->trials.size());
+    {
+        long long c[4];
+        HIP_TRY(hipMemcpy(c, d.dbg + 5000, sizeof c, hipMemcpyDeviceToHost));
+        if (c[3] > c[1])
+            std::printf("K7 INSIDE Compute() (its last launch, block 100): %lld shader cycles in %.2f us = %.2f GHz\n", c[2] - c[0], (c[3] - c[1]) * 0.01,
+                        (double)(c[2] - c[0]) / ((c[3] - c[1]) * 10.0));
+    }
     if (getenv("PTAM_TIMELINE")) {
         std::vector<long long> tl(2 + 2 * TL_MAX);
         HIP_TRY(hipMemcpy(tl.data(), d.dbg + TL_BASE, tl.size() * 8, hipMemcpyDeviceToHost));
@@ -2032,6 +2039,13 @@ int ptam_ba_bench_jacobian(ptam_ba* ba, int reps, double* avg_ms, double* algori
     {
         long long h[16];
         HIP_TRY(hipMemcpy(h, d.dbg, sizeof h, hipMemcpyDeviceToHost));
+        {
+            long long c[4];
+            HIP_TRY(hipMemcpy(c, d.dbg + 5000, sizeof c, hipMemcpyDeviceToHost));
+            if (c[3] > c[1])
+                std::printf("K7 BACK TO BACK (last of %d launches, block 100): %lld shader cycles in %.2f us = %.2f GHz\n", reps, c[2] - c[0], (c[3] - c[1]) * 0.01,
+                            (double)(c[2] - c[0]) / ((c[3] - c[1]) * 10.0));
+        }
         std::printf("K7 stamps (10 ns ticks since kernel-body start):");
         for (int i = 1; i < 10; i++) std::printf(" [%d] %lld", i, h[i] - h[0]);
         std::printf("\n");
