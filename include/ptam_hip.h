@@ -564,8 +564,9 @@ int ptam_ba_duplicates_refused(const ptam_ba* ba);
 /* Operating switches of the camera solve, read from the environment once per process: PTAM_LDLT_NO_CHAIN=1 uses the
  * launch-per-block-column form everywhere (a device shared between processes that all adjust bundles); PTAM_CH_SPIN_LIMIT=<n> is
  * the number of looks (~1 us each, default 2^18) a workgroup of the persistent form takes before it gives up a wait.
- * PTAM_ONE_QUEUE=1 keeps a rejected trial's continuation on the context's one queue (by default it goes to the context's second
- * queue, which is empty, instead of behind the kernels that were enqueued for the other outcome: ~6 us per rejected trial). */
+ * PTAM_TWO_QUEUES=1 sends a rejected trial's continuation to the context's second queue, which is empty, instead of behind the
+ * kernels that were enqueued for the other outcome (~6 us per rejected trial); the trial's decision is then a launch of its own
+ * again (2.3 us per trial: the default folds it into the next step's first launch, which is only safe on one queue). */
 
 /* profiling hooks used by bench.py: HIP-event timing of individual kernels on the ctx stream. */
 enum {

@@ -1523,10 +1523,9 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
             if (forced && d.chain_off == 1) d.chain_off = was;   // (a fault during the call sets 2: that one stays)
         }
     } chain_turn(d, ctx->device);
-    // A REJECTED trial's continuation — the same step again with a larger lambda — does not queue behind the five guarded kernels
-    // that were enqueued for the other outcome (each leaves at once, but a kernel that only reads its guard still costs its launch
-    // and its first memory access: ~4.4 us each, ~22 us of idle chip per rejected trial): it goes to the context's second queue,
-    // which is empty.  Nothing on the queue left behind writes (the guards' sequence word also stops a leftover that is late), the
+    // (PTAM_TWO_QUEUES=1 only, see below.)  A REJECTED trial's continuation — the same step again with a larger lambda — does not
+    // queue behind the guarded kernels that were enqueued for the other outcome (each leaves at once, but a kernel that only reads
+    // its guard still costs its launch and its first memory access: ~4.4 us each): it goes to the context's second queue, which is empty.  Nothing on the queue left behind writes (the guards' sequence word also stops a leftover that is late), the
     // trial's own kernels were all complete when its finalize kernel published the verdict the host has just read.  The context's
     // queues are swapped for the rest of this call and put back at its end.
     struct QueueTurn {
@@ -1637,8 +1636,15 @@ int ptam_ba_compute(ptam_ba* ba, const volatile unsigned char* abort_flag, int* 
     // speculative step prologue (ba_enqueue_speculative): single device, not while per-kernel events are being taken
     const bool spec = !sharded && !ba->prof && d.n_chunks > 0 && !ptam_ab_env("PTAM_NO_SPECULATION");
     bool spec_ready = false;   // pass 1 .. V*^-1 of the coming step are already running behind the device-side flag
-    static const bool two_queues = !getenv("PTAM_ONE_QUEUE");   // (operating switch: rejected continuations stay on the one queue)
-    const bool fused_decision = !ptam_ab_env("PTAM_SEPARATE_FINALIZE");   // (A/B: the decision as a launch of its own, rounds 2-5)
+    // Two ways to shorten the chain behind a trial, and they exclude each other.  (1) The trial's decision inside the next step's first
+    // launch (default): one dependent launch less per trial, 2.3 us.  (2) PTAM_TWO_QUEUES=1: a rejected trial's continuation on the
+    // context's second queue, 6 us per REJECTED trial — safe only while the kernel that publishes the verdict is over when the host
+    // reads it (finalize_new_kernel: one workgroup, the mailbox is its last act).  purge_pass1_decide_kernel publishes from
+    // workgroup 0 while its other workgroups may still be summing: a continuation on another queue could overwrite those sums
+    // (the solve's |da|^2, the point update's per-chunk errors) under a workgroup that is late, which would then decide differently.
+    // On one queue everything is in order.
+    static const bool two_queues = getenv("PTAM_TWO_QUEUES") != nullptr;
+    const bool fused_decision = !two_queues && !ptam_ab_env("PTAM_SEPARATE_FINALIZE");   // (A/B: the decision as a launch of its own, rounds 2-5)
     while (!empty && !ba->converged && !hit_max && !aborted()) {
         // ---- Do_LM_Step :209-551 ----
         bool skip_vinv = false;

@@ -93,7 +93,7 @@ int ctx_pinned(ptam_ctx* ctx, size_t bytes, void** out);      // pinned host sta
 // Measurement switches (kernel shapes, work splits, forms of a stage side by side) are read from the environment only in the
 // instrumented builds of tools/ (-DPTAM_AB_SWITCHES: `make ab` -> tools/_ab/libptam_hip.so); the product library has none of them.
 // What the product does read: PTAM_LDLT_NO_CHAIN (launch-per-block-column camera solve only), PTAM_CH_SPIN_LIMIT (how long a
-// workgroup of the persistent solve waits for another one) and PTAM_ONE_QUEUE (no second queue for a rejected trial's continuation) — operating switches, documented in ptam_hip.h — and the PTAM_DEBUG_*
+// workgroup of the persistent solve waits for another one) and PTAM_TWO_QUEUES (a second queue for a rejected trial's continuation) — operating switches, documented in ptam_hip.h — and the PTAM_DEBUG_*
 // diagnostics, which only print.
 #ifdef PTAM_AB_SWITCHES
 #define ptam_ab_env(name) getenv(name)

@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 6: a rejected trial's continuation on the context's second queue (default) against PTAM_ONE_QUEUE=1, alternating runs of the
+# round 6: a rejected trial's continuation on the context's second queue (PTAM_TWO_QUEUES=1; the default when this was measured)
+# against the one queue, alternating runs of the
 # headline leg in one GPU call.   -> gpurun_out/r06_queue_ab.txt
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $R
@@ -7,7 +8,7 @@ OUT=$R/gpurun_out/r06_queue_ab.txt
 : > $OUT
 for rep in 1 2 3 4; do
 for one in 0 1; do
-  if [ $one = 1 ]; then export PTAM_ONE_QUEUE=1; else unset PTAM_ONE_QUEUE; fi
+  if [ $one = 1 ]; then unset PTAM_TWO_QUEUES; else export PTAM_TWO_QUEUES=1; fi
   timeout 300 python bench.py --no-cpu-baseline --no-tracking --no-global --no-local > /tmp/ab_log.txt 2>&1
   python3 - "$one" >> $OUT <<PY
 import json, sys

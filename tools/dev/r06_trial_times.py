@@ -1,5 +1,5 @@
 """per-trial wall times by outcome (accepted / rejected / stay) of the headline bundle: PTAM_DEBUG_TRIAL_TIMES=1 in the library,
-parsed here; `the trial after a rejected one` is what the second queue is about.   usage: r06_trial_times.py [reps]"""
+parsed here; `the trial after a rejected one` is what the second queue (PTAM_TWO_QUEUES=1: the first line) is about; the second line is the default.   usage: r06_trial_times.py [reps]"""
 import os, sys, re, subprocess
 R = os.environ.get("GRAFT_REPO_ROOT", ".")
 code = ("import sys; sys.path.insert(0, %r)\n"
@@ -14,9 +14,9 @@ code = ("import sys; sys.path.insert(0, %r)\n"
 for one in ("", "1"):
     env = dict(os.environ, PTAM_DEBUG_TRIAL_TIMES="1")
     if one:
-        env["PTAM_ONE_QUEUE"] = "1"
+        env.pop("PTAM_TWO_QUEUES", None)
     else:
-        env.pop("PTAM_ONE_QUEUE", None)
+        env["PTAM_TWO_QUEUES"] = "1"   # (a rejected trial's continuation on the second queue; the decision is then a launch of its own)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     acc, rej, stay, after_rej, after_other = [], [], [], [], []
     for line in r.stderr.splitlines()[2:]:   # (the first calls: cold)
