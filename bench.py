@@ -682,6 +682,11 @@ def main():
         if jac_ms:
             out["roofline"]["avg_launch_us_in_compute"] = 1e3 * jac_ms
             out["roofline"]["frac_in_compute"] = alg_bytes / (jac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["roofline"]["note"] = ("frac / achieved / avg_launch_us: back-to-back launches in one HIP-event bracket after the spin-up (the figure "
+                                       "the rocprofv3 kernel stats' average agrees with); *_in_compute: HIP events around the ONE launch inside a profiled "
+                                       "Compute(), ~2.7 us of event bracket included — the kernel trace has 14.1 us there = 0.40 "
+                                       "(profiles/r06_k7_in_situ.txt: 2.07 GHz and 15 % more cycles than spun up, docs/LOG_r06.md section 3); *_cold: working "
+                                       "set out of the Infinity Cache")
         # ---- a cold call: the mapmaker thread calls Compute() from idle — no spin-up, no warm-up trials, 50 ms of nothing queued
         cb = new_bundle(args.steps)
         ctx.sync()
